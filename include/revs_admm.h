@@ -1,0 +1,221 @@
+/*
+ * revs_admm.h -- C ABI of librevs_admm.so, the MI355X (gfx950) engine behind the
+ * distributed ("ADMM") path of REVS, rounak-meyur/revs-admm.
+ *
+ * Boundary: everything `lpsolver.solve_ADMM` (reference lpsolver.py:242-290) does
+ * per iteration -- the operator ("Utility") QP, the per-residence ("Home")
+ * problem for every home, the dual update and the `diff` residual -- on device
+ * buffers the caller owns.  Plain pointers and sizes only; `stream` is a
+ * hipStream_t passed as void* (NULL = the null stream).  All pointers are DEVICE
+ * pointers unless the name ends in `_host`.  Every entry point returns 0 on
+ * success and a negative REVS_E* code otherwise; revs_last_error() gives the text.
+ * Nothing here allocates, frees or synchronises (safe under hipGraph capture),
+ * except the revs_op_* setup/teardown pair, which says so.
+ *
+ * Layout in HBM: home-major, slot-contiguous.  A "profile" is float[n_homes][T].
+ */
+#ifndef REVS_ADMM_H
+#define REVS_ADMM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define REVS_OK          0
+#define REVS_EINVAL     -1   /* bad argument (null pointer, T out of range, ...) */
+#define REVS_ELAUNCH    -2   /* hip launch / runtime error */
+#define REVS_ENOTCONV   -3   /* operator solve hit max_iter before eps */
+
+/* Largest T the agent kernels are instantiated for. */
+#define REVS_MAX_T 192
+
+/* ---- per-residence data -------------------------------------------------
+ * One record per home; replaces homes[h]["EV"] of the reference
+ * (extract.py:122-131, consumed by Home.add_EV, lpsolver.py:68-110).
+ * nmin/nmax: number of full-rate slots the SOC rows allow, i.e. the integers n
+ * with initial + n*rating/capacity in [0.9, 1.0] (lpsolver.py:101-109).  The
+ * host computes them in double so that the device never rounds a borderline
+ * case differently from the model (revs_admm_amd/lpsolver.py: pack_homes).   */
+typedef struct {
+    int32_t ev;        /* 0: no EV (p = 0, s = 0: lpsolver.py:70-79) */
+    int32_t start;     /* first slot charging is allowed  (lpsolver.py:97) */
+    int32_t end;       /* one past the last allowed slot                  */
+    int32_t nmin;
+    int32_t nmax;
+    float   rating;    /* kW   */
+    float   capacity;  /* kWh  */
+    float   initial;   /* SOC at slot 0 */
+} revs_home_t;
+
+/* how the Home problem treats the charger */
+#define REVS_MODE_BINARY        0  /* p_t in {0, rating}: the reference MIQP, exact     */
+#define REVS_MODE_RELAXED_PDHG  1  /* 0 <= p_t <= rating, batched PDHG (north star)     */
+#define REVS_MODE_RELAXED_EXACT 2  /* same QP, closed-form multiplier search            */
+
+typedef struct {
+    int32_t max_iter;     /* PDHG iteration cap (multiple of check)           */
+    int32_t check;        /* convergence test every `check` iterations        */
+    float   tol;          /* stop when max(|dx|, |dy|/sigma) <= tol           */
+    float   tau_scale;    /* tau   = tau_scale   / ||K||                      */
+    float   sigma_scale;  /* sigma = sigma_scale / ||K||                      */
+} revs_pdhg_t;
+
+const char *revs_version(void);
+const char *revs_last_error(void);
+
+/* Defaults used when `pdhg` is NULL: 4000, 8, 1e-6, 0.25, 4.0 */
+void revs_pdhg_defaults(revs_pdhg_t *out_host);
+
+/* Number of float2 partial-residual slots revs_agent_step writes for n_homes
+ * (one per workgroup); size `partials` with it. */
+int64_t revs_agent_num_partials(int64_t n_homes, int32_t T);
+
+/* One ADMM iteration of the residence side for ALL homes:
+ *   Home(cost, homes[h], P_est[k][h], P_sch[k][h], G[k][h]).solve()  lpsolver.py:273-277
+ *   check = P_est[k+1][h] - P_sch[k+1][h]                            lpsolver.py:280-281
+ *   G[k+1][h] = G[k][h] + (kappa/2) check                            lpsolver.py:282-283
+ *   diff[k+1][h] = |check|_2 / T                                     lpsolver.py:284
+ * fused in one kernel.
+ *   cost        float[T]          tariff
+ *   load        float[n][T]       homes[h]["LOAD"]
+ *   p_est_old   float[n][T]       P_est[k]     (read)
+ *   p_est_new   float[n][T]       P_est[k+1]   (read; may alias p_est_old)
+ *   p_sch       float[n][T]       in: P_sch[k]   out: P_sch[k+1] = g_opt
+ *   gamma       float[n][T]       in: G[k]       out: G[k+1]
+ *   s_out       float[n][T]       p_opt  (reference's S)   or NULL to skip
+ *   c_out       float[n][T+1]     s_opt  (reference's C)   or NULL to skip
+ *   diff        float[n]          diff[k+1]
+ *   partials    float[2*np]       per-workgroup sums {|P_est-P_sch|^2, |P_sch[k+1]-P_sch[k]|^2}
+ *   status      int32[n]          0 ok, 1 infeasible ("No solution found", lpsolver.py:153-155),
+ *                                 for PDHG: iterations used in bits 8.. ; or NULL
+ */
+int revs_agent_step(int64_t n_homes, int32_t T,
+                    const float *cost, const revs_home_t *homes, const float *load,
+                    const float *p_est_old, const float *p_est_new,
+                    float *p_sch, float *gamma,
+                    float *s_out, float *c_out, float *diff,
+                    float *partials, int32_t *status,
+                    float kappa, int32_t mode, const revs_pdhg_t *pdhg_host,
+                    void *stream);
+
+/* Wavefront reduction of the per-workgroup partials to the global ADMM residuals
+ *   out[0] = |P_est - P_sch|_2      (primal)
+ *   out[1] = kappa * |P_sch[k+1] - P_sch[k]|_2   (dual)
+ *   out[2] = 1.0f if both <= eps * sqrt(n*T) else 0.0f   (convergence flag)
+ * out: float[4] on the device.  Deterministic (fixed summation order).          */
+int revs_residual_finalize(const float *partials, int64_t num_partials,
+                           int64_t n_homes, int32_t T, float kappa, float eps,
+                           float *out, void *stream);
+
+/* Individual mode, lpsolver.py:430-460 (solve_residence): min 0.01 tariff.g +
+ * 0.99 (1 - s_T), binary charger, SOC box, no s_T >= 0.9 row.
+ *   p_out float[n][T], soc_out float[n][T+1], g_out float[n][T]                 */
+int revs_residence_solve(int64_t n_homes, int32_t T,
+                         const float *tariff, const revs_home_t *homes, const float *load,
+                         float *p_out, float *soc_out, float *g_out, void *stream);
+
+/* ---- operator ("Utility") side -------------------------------------------
+ * lpsolver.py:163-238:  min (kappa/2)|g - g0|^2  s.t.  g >= 0,
+ *                        vlo <= R (A g) <= vhi   per slot,
+ * g0 = (P_est + P_sch)/2 - G/kappa, A = home->node aggregation, R the LinDistFlow
+ * sensitivity matrix of the constrained nodes (compute_Rmat, lpsolver.py:17-26).
+ * Solved by ADMM in OSQP form with the KKT matrix applied through the SVD
+ * R diag(sqrt(n_m)) = U S V^T, so rho can be re-tuned per slot without
+ * refactoring.  All operator arithmetic is double (the QP is ill conditioned:
+ * cond(R)^2 ~ 5e7 on the 121144 feeder); the three products with U/V per inner
+ * iteration run on v_mfma_f64_16x16x4_f64.
+ */
+
+/* C[m][n] (+)= At^T * B on the matrix cores.  At is stored k-major (double
+ * At[k][lda], element At[kk][i] = A[i][kk]); B is double[k][ldb]; C double[m][ldc].
+ * n is small (T, up to 192).  accumulate != 0 adds into C.  f64 uses
+ * v_mfma_f64_16x16x4_f64, f32 v_mfma_f32_16x16x4_f32 (exact f32 fma chain). */
+int revs_gemm_tn_f64(int32_t m, int32_t n, int32_t k, const double *At, int32_t lda,
+                     const double *B, int32_t ldb, double *C, int32_t ldc,
+                     int32_t accumulate, void *stream);
+int revs_gemm_tn_f32(int32_t m, int32_t n, int32_t k, const float *At, int32_t lda,
+                     const float *B, int32_t ldb, float *C, int32_t ldc,
+                     int32_t accumulate, void *stream);
+
+/* V = R P : the operator's LinDistFlow voltage-sensitivity check -- `R_res @ g[:,t]`
+ * of lpsolver.py:191-193 and `R@P` of drawing.py:75 -- for all slots at once.
+ * Rt = R transposed, float[m][m] row-major (R itself: it is symmetric);
+ * P float[m][T] node injections; V float[m][T]. */
+int revs_voltage_f32(int32_t m, int32_t T, const float *Rt, const float *P, float *V,
+                     void *stream);
+
+/* Segmented home->node aggregation: out[node][t] = scale[node] * sum over the
+ * homes of that node of in[home][t].  Homes are sorted by node; node_ptr is the
+ * CSR offset array int64[m+1].  scale may be NULL (=1).  Deterministic. */
+int revs_aggregate_f64(int32_t m, int32_t T, const int64_t *node_ptr,
+                       const double *in_home, const double *scale, double *out_node,
+                       void *stream);
+int revs_aggregate_f32(int32_t m, int32_t T, const int64_t *node_ptr,
+                       const float *in_home, float *out_node, void *stream);
+
+/* g0 = (P_est + P_sch)/2 - G/kappa : the unconstrained minimiser of the Utility
+ * objective (lpsolver.py:196-207).  float in, double out. */
+int revs_op_g0(int64_t n_homes, int32_t T, const float *p_est, const float *p_sch,
+               const float *gamma, float kappa, double *g0, void *stream);
+
+/* Cold start of the operator ADMM state: x = z_b = max(g0,0), y_b = 0;
+ * z_v = clip(cx, vlo, vhi), y_v = 0, w = rho_v z_v. */
+int revs_op_init_home(int64_t n_homes, int32_t T, const double *g0, double *x, double *zb,
+                      double *yb, void *stream);
+int revs_op_init_node(int32_t m, int32_t T, const double *cx, const double *rho_v,
+                      double vlo, double vhi, double *zv, double *yv, double *w, void *stream);
+
+/* Home pass of one inner iteration (all double[n][T]; rho_b double[T];
+ * c = kappa + sigma + rho_b[t]; node m owns homes node_ptr[m]..node_ptr[m+1]-1):
+ *   if xc != NULL (double[m][T], node correction from revs_op_node_update):
+ *       rhs = sigma x + kappa g0 + rho_b z_b - y_b
+ *       xt  = rhs / c + inv_sqrt_n[m] xc[m]
+ *       x   = alpha xt + (1-alpha) x ;  h = alpha xt + (1-alpha) z_b
+ *       z_b = max(h + y_b/rho_b, 0)  ;  y_b += rho_b (h - z_b)
+ *   rhat[m] = inv_sqrt_n[m] * sum_homes (sigma x + kappa g0 + rho_b z_b - y_b)
+ * With homes sharded over GPUs rhat is this rank's partial sum: all-reduce it. */
+int revs_op_home_pass(int32_t m, int32_t T, const int64_t *node_ptr,
+                      const double *inv_sqrt_n, double *x, double *zb, double *yb,
+                      const double *g0, const double *xc, const double *rho_b,
+                      double kappa, double sigma, double alpha, double *rhat, void *stream);
+
+/* Node passes (double[m][T]; s double[m] singular values; rho_v, rho_b double[T]):
+ *   revs_op_node_w:      w  = rho_v z_v - y_v
+ *   revs_op_node_scale:  a  = (ta + s tb) / (c + rho_v s^2),  sa = s a
+ *                        with ta = V^T rhat, tb = U^T w from revs_gemm_tn_f64
+ *   revs_op_node_update: xc = va - rhat/c            (va = V a)
+ *                        h  = alpha usa + (1-alpha) z_v   (usa = U sa = C_v xt)
+ *                        z_v = clip(h + y_v/rho_v, vlo, vhi); y_v += rho_v (h - z_v)
+ *                        cx = alpha usa + (1-alpha) cx ;  w = rho_v z_v - y_v        */
+int revs_op_node_w(int32_t m, int32_t T, const double *zv, const double *yv,
+                   const double *rho_v, double *w, void *stream);
+int revs_op_node_scale(int32_t m, int32_t T, const double *ta, const double *tb,
+                       const double *s, const double *rho_v, const double *rho_b,
+                       double kappa, double sigma, double *a, double *sa, void *stream);
+int revs_op_node_update(int32_t m, int32_t T, const double *va, const double *rhat,
+                        const double *usa, const double *rho_v, const double *rho_b,
+                        double kappa, double sigma, double alpha, double vlo, double vhi,
+                        double *xc, double *zv, double *yv, double *cx, double *w,
+                        void *stream);
+
+/* Per-slot residual maxima for the stopping test and the rho update.
+ * out double[8][T] must be ZERO on entry (maxima are merged with atomicMax):
+ *   0 max|cx - z_v|  1 max|x - z_b|  2 max|kappa (x-g0) + C^T y|  3 max|cx|
+ *   4 max|z_v|       5 max|x|        6 max|C^T y|                 7 max|kappa g0|
+ * cty_node double[m][T] = V S U^T y_v (two revs_gemm_tn_f64 calls by the driver). */
+int revs_op_residuals(int32_t m, int32_t T, const int64_t *node_ptr,
+                      const double *inv_sqrt_n, const double *x, const double *zb,
+                      const double *yb, const double *g0, const double *cty_node,
+                      const double *cx, const double *zv, double kappa, double *out,
+                      void *stream);
+
+/* z_b (double) -> P_est (float): the operator's answer handed to the homes
+ * (U_obj.g_opt, lpsolver.py:236-237, 259). */
+int revs_op_export(int64_t n_homes, int32_t T, const double *zb, float *p_est, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REVS_ADMM_H */

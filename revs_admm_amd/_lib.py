@@ -1,0 +1,97 @@
+"""ctypes binding of librevs_admm.so (include/revs_admm.h).
+
+Loading fails loudly when the library has not been built: nothing in this
+package computes on the CPU instead.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librevs_admm.so")
+
+# numpy mirror of revs_home_t (include/revs_admm.h)
+HOME_DTYPE = np.dtype([("ev", "<i4"), ("start", "<i4"), ("end", "<i4"), ("nmin", "<i4"),
+                       ("nmax", "<i4"), ("rating", "<f4"), ("capacity", "<f4"),
+                       ("initial", "<f4")])
+assert HOME_DTYPE.itemsize == 32
+
+MODE_BINARY, MODE_RELAXED_PDHG, MODE_RELAXED_EXACT = 0, 1, 2
+MODES = {"binary": MODE_BINARY, "relaxed": MODE_RELAXED_PDHG, "pdhg": MODE_RELAXED_PDHG,
+         "relaxed_exact": MODE_RELAXED_EXACT}
+
+
+class PDHG(C.Structure):
+    _fields_ = [("max_iter", C.c_int32), ("check", C.c_int32), ("tol", C.c_float),
+                ("tau_scale", C.c_float), ("sigma_scale", C.c_float)]
+
+
+class RevsError(RuntimeError):
+    pass
+
+
+_p = C.c_void_p
+_i32, _i64, _f32, _f64 = C.c_int32, C.c_int64, C.c_float, C.c_double
+
+# name -> (restype, argtypes); every symbol include/revs_admm.h declares
+SIGNATURES = {
+    "revs_version": (C.c_char_p, []),
+    "revs_last_error": (C.c_char_p, []),
+    "revs_pdhg_defaults": (None, [C.POINTER(PDHG)]),
+    "revs_agent_num_partials": (_i64, [_i64, _i32]),
+    "revs_agent_step": (C.c_int, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                  _f32, _i32, C.POINTER(PDHG), _p]),
+    "revs_residual_finalize": (C.c_int, [_p, _i64, _i64, _i32, _f32, _f32, _p, _p]),
+    "revs_residence_solve": (C.c_int, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p]),
+    "revs_gemm_tn_f64": (C.c_int, [_i32, _i32, _i32, _p, _i32, _p, _i32, _p, _i32, _i32, _p]),
+    "revs_gemm_tn_f32": (C.c_int, [_i32, _i32, _i32, _p, _i32, _p, _i32, _p, _i32, _i32, _p]),
+    "revs_voltage_f32": (C.c_int, [_i32, _i32, _p, _p, _p, _p]),
+    "revs_aggregate_f64": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p]),
+    "revs_aggregate_f32": (C.c_int, [_i32, _i32, _p, _p, _p, _p]),
+    "revs_op_g0": (C.c_int, [_i64, _i32, _p, _p, _p, _f32, _p, _p]),
+    "revs_op_init_home": (C.c_int, [_i64, _i32, _p, _p, _p, _p, _p]),
+    "revs_op_init_node": (C.c_int, [_i32, _i32, _p, _p, _f64, _f64, _p, _p, _p, _p]),
+    "revs_op_home_pass": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _f64, _f64,
+                                    _f64, _p, _p]),
+    "revs_op_node_w": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p]),
+    "revs_op_node_scale": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p, _f64, _f64, _p, _p, _p]),
+    "revs_op_node_update": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p, _f64, _f64, _f64, _f64,
+                                      _f64, _p, _p, _p, _p, _p, _p]),
+    "revs_op_residuals": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f64, _p,
+                                    _p]),
+    "revs_op_export": (C.c_int, [_i64, _i32, _p, _p, _p]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; raise (never fall back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RevsError(
+            f"{LIB_PATH} is missing: build it with `python -m revs_admm_amd.build` "
+            "(hipcc, gfx950).  revs_admm_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().revs_last_error().decode()
+        raise RevsError(f"{what or 'librevs_admm'} failed ({rc}): {msg}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,500 @@
+// Residence ("Home") side of one ADMM iteration, all homes at once -- gfx950.
+//
+// Replaces, per iteration k of lpsolver.solve_ADMM (reference lpsolver.py:262-284):
+//   H_obj = Home(cost, homes[h], P_est[k][h], P_sch[k][h], G[k][h]); H_obj.solve()
+//   check = P_est[k+1][h] - P_sch[k+1][h];  G[k+1][h] = G[k][h] + (kappa/2) check
+//   diff[k+1][h] = |check| / T
+// for every home h, in ONE kernel: the profiles of a home are read once, the
+// schedule is solved in registers, and P_sch, G, S, C, diff are written once.
+//
+// Mapping.  A home's T slots are spread over a group of LPA lanes, SPL
+// consecutive slots per lane (LPA*SPL >= T), so a 64-wide wavefront carries
+// 64/LPA homes: T=24 -> 8 lanes x 3 slots, 8 homes per wavefront, every lane
+// busy.  (One whole wavefront per home would idle 40 of 64 lanes at T=24.)
+// Rows are slot-contiguous in HBM, so the 64 lanes of a wavefront read one
+// contiguous 64/LPA * T * 4 byte span per profile (768 B at T=24): coalesced.
+// The SOC operator K (prefix sum over slots, lpsolver.py:105-108) and its
+// transpose (suffix sum) are an in-lane scan plus a log2(LPA)-step DPP scan
+// across the group -- no LDS, no T x T matrix is ever formed.
+//
+// Arithmetic: float (BASELINE north star); the residual partials are summed in
+// float per workgroup and in double by residual_finalize_kernel.
+#include "common.h"
+#include <math.h>
+
+namespace revs {
+
+struct AgentArgs {
+    int64_t n;
+    int32_t T;
+    const float *cost;
+    const revs_home_t *homes;
+    const float *load;
+    const float *pe_old;
+    const float *pe_new;
+    float *ps;
+    float *gam;
+    float *s_out;
+    float *c_out;
+    float *diff;
+    float *partials;
+    int32_t *status;
+    float kappa;
+    revs_pdhg_t pd;
+};
+
+constexpr int kBlock = 256;
+constexpr float kSocTarget = 0.9f;   // lpsolver.py:109
+constexpr float kSocMax = 1.0f;      // lpsolver.py:102-103
+
+// rank of each of this lane's SPL keys among the group's LPA*SPL keys, ties to
+// the earlier slot: rank_j = #{tau : key_tau < key_j or (key_tau == key_j and tau < t_j)}
+template <int LPA, int SPL>
+__device__ __forceinline__ void group_rank(const float (&key)[SPL], int t0, int (&rank)[SPL]) {
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) rank[j] = 0;
+#pragma unroll 1
+    for (int sl = 0; sl < LPA; ++sl) {
+#pragma unroll
+        for (int sj = 0; sj < SPL; ++sj) {
+            const float other = __shfl(key[sj], sl, LPA);
+            const int tau = sl * SPL + sj;
+#pragma unroll
+            for (int j = 0; j < SPL; ++j) {
+                const int t = t0 + j;
+                rank[j] += (other < key[j]) || (other == key[j] && tau < t);
+            }
+        }
+    }
+}
+
+template <int LPA, int SPL, int MODE>
+__global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
+    constexpr int kHomesPerBlock = kBlock / LPA;
+    const int tid = threadIdx.x;
+    const int lig = tid & (LPA - 1);
+    const int64_t agent = (int64_t)blockIdx.x * kHomesPerBlock + tid / LPA;
+    const bool live = agent < a.n;
+    const int T = a.T;
+    const int t0 = lig * SPL;
+    const float kappa = a.kappa;
+
+    revs_home_t h;
+    if (live) {
+        h = a.homes[agent];
+    } else {
+        h.ev = 0; h.start = 0; h.end = 0; h.nmin = 0; h.nmax = 0;
+        h.rating = 0.f; h.capacity = 1.f; h.initial = 0.f;
+    }
+    const bool ev = h.ev != 0;
+    const int64_t row = agent * (int64_t)T;
+
+    float L[SPL], pe[SPL], pso[SPL], gm[SPL], pen[SPL], q[SPL], p[SPL];
+    bool valid[SPL], win[SPL];
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+        const int t = t0 + j;
+        valid[j] = live && (t < T);
+        const int64_t o = row + t;
+        L[j]   = valid[j] ? a.load[o] : 0.f;
+        pe[j]  = valid[j] ? a.pe_old[o] : 0.f;
+        pen[j] = valid[j] ? a.pe_new[o] : 0.f;
+        pso[j] = valid[j] ? a.ps[o] : 0.f;
+        gm[j]  = valid[j] ? a.gam[o] : 0.f;
+        const float c = (t < T) ? a.cost[t] : 0.f;
+        // lpsolver.py:118-119  a_t = gamma_t + (kappa/2)(p_util_t + p_res_t)
+        const float at = gm[j] + 0.5f * kappa * (pe[j] + pso[j]);
+        // objective in p:  (kappa/2) p^2 + q p,  q = kappa*LOAD + c - a
+        q[j] = kappa * L[j] + c - at;
+        win[j] = ev && valid[j] && (t >= h.start) && (t < h.end);
+        p[j] = 0.f;
+    }
+
+    int status = 0;
+
+    if constexpr (MODE == REVS_MODE_BINARY) {
+        // p_t = e_t * rating, e_t binary (lpsolver.py:92-98).  Switching slot t on
+        // costs delta_t = rating ((kappa/2) rating + q_t); take the nmin cheapest,
+        // then more while delta < 0, up to nmax.
+        float key[SPL];
+        int rank[SPL];
+        int nwin = 0;
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+            key[j] = win[j] ? h.rating * (0.5f * kappa * h.rating + q[j]) : INFINITY;
+            nwin += win[j] ? 1 : 0;
+        }
+        nwin = (int)group_sum<LPA>((float)nwin);
+        group_rank<LPA, SPL>(key, t0, rank);
+        const bool infeasible = ev && (h.nmin > h.nmax || h.nmin > nwin);
+        status = infeasible ? 1 : 0;
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+            const bool take = win[j] && !infeasible &&
+                              (rank[j] < h.nmin || (rank[j] < h.nmax && key[j] < 0.f));
+            p[j] = take ? h.rating : 0.f;
+        }
+    } else if constexpr (MODE == REVS_MODE_RELAXED_PDHG) {
+        // PDHG on  min x^2/2 + b x,  0 <= x <= w,  lo <= K x <= hi,  x = p/rating,
+        // K = delta * inclusive prefix sum (rows j: s_{j+1} - initial).
+        const float rate = ev ? h.rating : 1.f;
+        const float delta = ev ? h.rating / h.capacity : 1.f;
+        const int ws = max(h.start, 0), we = min(h.end, T);
+        const float Tw = (float)max(we - ws, 1);
+        const float nK = delta * 0.63661977236758134f * (Tw + 1.0f);
+        const float tau = a.pd.tau_scale / nK;
+        const float sig = a.pd.sigma_scale / nK;
+        const float inv1pt = 1.0f / (1.0f + tau);
+        const float sd = sig * delta;
+        const float hi = kSocMax - h.initial;
+        const float lo_last = fmaxf(kSocTarget, h.initial) - h.initial;
+        float b[SPL], w[SPL], x[SPL], y[SPL], lo[SPL];
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+            b[j] = q[j] / (kappa * rate);
+            w[j] = win[j] ? 1.f : 0.f;
+            lo[j] = (t0 + j == T - 1) ? lo_last : 0.f;
+            x[j] = 0.f;
+            y[j] = 0.f;
+        }
+        bool done = !ev;
+        int iters = 0;
+        const int check = max(a.pd.check, 1);
+        for (int it = 0; it < a.pd.max_iter; it += check) {
+            if (__all(done)) break;          // wave-uniform exit every wave reaches
+            float res = 0.f;
+            for (int c = 0; c < check; ++c) {
+                // K^T y : inclusive suffix sum of y
+                float sfx[SPL], acc = 0.f;
+#pragma unroll
+                for (int j = SPL - 1; j >= 0; --j) { acc += y[j]; sfx[j] = acc; }
+                const float so = group_excl_suffix<LPA>(acc, lig);
+                float xn[SPL], xb[SPL];
+#pragma unroll
+                for (int j = 0; j < SPL; ++j) {
+                    const float kty = sd * (sfx[j] + so);
+                    xn[j] = fminf(fmaxf((x[j] - tau * (kty + b[j])) * inv1pt, 0.f), w[j]);
+                    xb[j] = xn[j] + (xn[j] - x[j]);
+                }
+                // K xbar : inclusive prefix sum
+                float pfx[SPL];
+                acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < SPL; ++j) { acc += xb[j]; pfx[j] = acc; }
+                const float po = group_excl_prefix<LPA>(acc, lig);
+                float dmax = 0.f;
+#pragma unroll
+                for (int j = 0; j < SPL; ++j) {
+                    const float v = y[j] + delta * (pfx[j] + po);
+                    float yn = v - fminf(fmaxf(v, lo[j]), hi);
+                    yn = valid[j] ? yn : 0.f;
+                    dmax = fmaxf(dmax, fmaxf(fabsf(xn[j] - x[j]), fabsf(yn - y[j])));
+                    if (!done) { x[j] = xn[j]; y[j] = yn; }
+                }
+                res = dmax;
+            }
+            iters += done ? 0 : check;
+            res = group_max<LPA>(res);
+            done = done || (res <= a.pd.tol);
+        }
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) p[j] = ev ? x[j] * h.rating : 0.f;
+        status = iters << 8;
+    } else {
+        // closed form: p_t = clip(u_t + nu, 0, ub_t), u = -q/kappa; nu is the
+        // multiplier of the terminal SOC rows (the only ones that can bind when
+        // p >= 0), found by bisection then solved exactly on the identified piece.
+        float u[SPL], ub[SPL];
+        float cap_sum = 0.f, umax = 0.f;
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+            u[j] = -q[j] / kappa;
+            ub[j] = win[j] ? h.rating : 0.f;
+            cap_sum += ub[j];
+            umax = fmaxf(umax, win[j] ? fabsf(u[j]) : 0.f);
+        }
+        cap_sum = group_sum<LPA>(cap_sum);
+        umax = group_max<LPA>(umax);
+        const float Elo = ev ? (fmaxf(kSocTarget, h.initial) - h.initial) * h.capacity : 0.f;
+        const float Ehi = ev ? (kSocMax - h.initial) * h.capacity : 0.f;
+        auto fsum = [&](float nu) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < SPL; ++j) s += fminf(fmaxf(u[j] + nu, 0.f), ub[j]);
+            return group_sum<LPA>(s);
+        };
+        const float s0 = fsum(0.f);
+        const bool infeasible = ev && (Elo > cap_sum * (1.f + 1e-6f));
+        status = infeasible ? 1 : 0;
+        float nu = 0.f;
+        const bool need_lo = s0 < Elo, need_hi = s0 > Ehi;
+        if (ev && !infeasible && (need_lo || need_hi)) {
+            const float tgt = need_lo ? Elo : Ehi;
+            float lo_ = -(umax + h.rating + 1.f), hi_ = -lo_;
+            for (int i = 0; i < 40; ++i) {
+                const float mid = 0.5f * (lo_ + hi_);
+                const bool below = fsum(mid) < tgt;
+                lo_ = below ? mid : lo_;
+                hi_ = below ? hi_ : mid;
+            }
+            nu = 0.5f * (lo_ + hi_);
+            float nfree = 0.f, fixed = 0.f;
+#pragma unroll
+            for (int j = 0; j < SPL; ++j) {
+                const float xv = u[j] + nu;
+                const bool fr = xv > 0.f && xv < ub[j];
+                nfree += fr ? 1.f : 0.f;
+                fixed += fr ? u[j] : ((xv >= ub[j]) ? ub[j] : 0.f);
+            }
+            nfree = group_sum<LPA>(nfree);
+            fixed = group_sum<LPA>(fixed);
+            if (nfree > 0.f) nu = (tgt - fixed) / nfree;
+        }
+#pragma unroll
+        for (int j = 0; j < SPL; ++j)
+            p[j] = (ev && !infeasible) ? fminf(fmaxf(u[j] + nu, 0.f), ub[j]) : 0.f;
+    }
+
+    // ---- epilogue: g, SOC, dual update, residuals (lpsolver.py:275-284) ----
+    float ss = 0.f, dd = 0.f, pacc = 0.f, pfx[SPL];
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) { pacc += p[j]; pfx[j] = pacc; }
+    const float poff = group_excl_prefix<LPA>(pacc, lig);
+    const float invcap = ev ? 1.0f / h.capacity : 0.f;
+    const int64_t crow = agent * (int64_t)(T + 1);
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+        const int t = t0 + j;
+        if (valid[j]) {
+            const int64_t o = row + t;
+            const float g = p[j] + L[j];                    // lpsolver.py:64-65
+            const float chk = pen[j] - g;                   // lpsolver.py:280
+            a.ps[o] = g;
+            a.gam[o] = gm[j] + 0.5f * kappa * chk;          // lpsolver.py:282
+            ss += chk * chk;
+            const float dg = g - pso[j];
+            dd += dg * dg;
+            if (a.s_out) a.s_out[o] = p[j];
+            if (a.c_out)
+                a.c_out[crow + t + 1] = ev ? h.initial + (pfx[j] + poff) * invcap : 0.f;
+        }
+    }
+    if (live && lig == 0 && a.c_out) a.c_out[crow] = ev ? h.initial : 0.f;
+    const float ssg = group_sum<LPA>(ss);
+    if (live && lig == 0) {
+        a.diff[agent] = sqrtf(ssg) / (float)T;              // lpsolver.py:284
+        if (a.status) a.status[agent] = status;
+    }
+    // per-workgroup partial residuals
+    float wss = group_sum<64>(ss), wdd = group_sum<64>(dd);
+    __shared__ float red[2][kBlock / 64];
+    const int wave = tid >> 6;
+    if ((tid & 63) == 0) { red[0][wave] = wss; red[1][wave] = wdd; }
+    __syncthreads();
+    if (tid == 0) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) { s0 += red[0][w]; s1 += red[1][w]; }
+        a.partials[2 * (int64_t)blockIdx.x + 0] = s0;
+        a.partials[2 * (int64_t)blockIdx.x + 1] = s1;
+    }
+}
+
+// One wavefront-strided pass over the per-workgroup partials, double accumulation,
+// fixed order -> bitwise reproducible residual norms and convergence flag.
+__global__ __launch_bounds__(256) void residual_finalize_kernel(
+        const float *partials, int64_t np, double count, float kappa, float eps, float *out) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int64_t i = threadIdx.x; i < np; i += 256) {
+        s0 += (double)partials[2 * i];
+        s1 += (double)partials[2 * i + 1];
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        s0 += __shfl_xor(s0, d, 64);
+        s1 += __shfl_xor(s1, d, 64);
+    }
+    __shared__ double red[2][4];
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s0 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        s1 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        const float rp = (float)sqrt(s0), rd = kappa * (float)sqrt(s1);
+        const float lim = eps * (float)sqrt(count);
+        out[0] = rp;
+        out[1] = rd;
+        out[2] = (rp <= lim && rd <= lim) ? 1.0f : 0.0f;
+        out[3] = lim;
+    }
+}
+
+// Individual mode (lpsolver.py:407-460): switching slot t on changes
+// 0.01 tariff.g + 0.99 (1 - s_T) by 0.01 c_t rating - 0.99 rating/capacity;
+// take the cheapest slots while that is negative, up to nmax.
+template <int LPA, int SPL>
+__global__ __launch_bounds__(kBlock) void residence_kernel(
+        int64_t n, int32_t T, const float *tariff, const revs_home_t *homes,
+        const float *load, float *p_out, float *soc_out, float *g_out) {
+    const int tid = threadIdx.x;
+    const int lig = tid & (LPA - 1);
+    const int64_t agent = (int64_t)blockIdx.x * (kBlock / LPA) + tid / LPA;
+    const bool live = agent < n;
+    const int t0 = lig * SPL;
+    revs_home_t h;
+    if (live) h = homes[agent];
+    else { h.ev = 0; h.start = 0; h.end = 0; h.nmin = 0; h.nmax = 0; h.rating = 0.f; h.capacity = 1.f; h.initial = 0.f; }
+    const bool ev = h.ev != 0;
+    float key[SPL], p[SPL], pfx[SPL];
+    int rank[SPL];
+    bool win[SPL];
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+        const int t = t0 + j;
+        win[j] = ev && live && t < T && t >= h.start && t < h.end;
+        const float c = (t < T) ? tariff[t] : 0.f;
+        key[j] = win[j] ? 0.01f * c * h.rating - 0.99f * (h.rating / h.capacity) : INFINITY;
+    }
+    group_rank<LPA, SPL>(key, t0, rank);
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+        p[j] = (win[j] && rank[j] < h.nmax && key[j] < 0.f) ? h.rating : 0.f;
+        acc += p[j];
+        pfx[j] = acc;
+    }
+    const float poff = group_excl_prefix<LPA>(acc, lig);
+    const float invcap = ev ? 1.f / h.capacity : 0.f;
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+        const int t = t0 + j;
+        if (live && t < T) {
+            const int64_t o = agent * (int64_t)T + t;
+            p_out[o] = p[j];
+            g_out[o] = p[j] + load[o];
+            soc_out[agent * (int64_t)(T + 1) + t + 1] = ev ? h.initial + (pfx[j] + poff) * invcap : 0.f;
+        }
+    }
+    if (live && lig == 0) soc_out[agent * (int64_t)(T + 1)] = ev ? h.initial : 0.f;
+}
+
+// ---- dispatch ---------------------------------------------------------------
+struct Shape { int lpa, spl; };
+static Shape pick_shape(int T) {
+    if (T <= 8) return {8, 1};
+    if (T <= 16) return {8, 2};
+    if (T <= 24) return {8, 3};
+    if (T <= 32) return {8, 4};
+    if (T <= 48) return {16, 3};
+    if (T <= 64) return {16, 4};
+    if (T <= 96) return {32, 3};
+    if (T <= 128) return {32, 4};
+    return {64, 3};
+}
+
+template <int LPA, int SPL>
+static void launch_agent(const AgentArgs &a, int mode, dim3 grid, hipStream_t s) {
+    switch (mode) {
+        case REVS_MODE_BINARY:
+            hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_BINARY>), grid, dim3(kBlock), 0, s, a);
+            break;
+        case REVS_MODE_RELAXED_PDHG:
+            hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_RELAXED_PDHG>), grid, dim3(kBlock), 0, s, a);
+            break;
+        default:
+            hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_RELAXED_EXACT>), grid, dim3(kBlock), 0, s, a);
+            break;
+    }
+}
+
+#define REVS_FOR_SHAPE(sh, CALL)                                   \
+    do {                                                           \
+        if (sh.lpa == 8 && sh.spl == 1) { CALL(8, 1); }            \
+        else if (sh.lpa == 8 && sh.spl == 2) { CALL(8, 2); }       \
+        else if (sh.lpa == 8 && sh.spl == 3) { CALL(8, 3); }       \
+        else if (sh.lpa == 8 && sh.spl == 4) { CALL(8, 4); }       \
+        else if (sh.lpa == 16 && sh.spl == 3) { CALL(16, 3); }     \
+        else if (sh.lpa == 16 && sh.spl == 4) { CALL(16, 4); }     \
+        else if (sh.lpa == 32 && sh.spl == 3) { CALL(32, 3); }     \
+        else if (sh.lpa == 32 && sh.spl == 4) { CALL(32, 4); }     \
+        else { CALL(64, 3); }                                      \
+    } while (0)
+
+}  // namespace revs
+
+using namespace revs;
+
+extern "C" void revs_pdhg_defaults(revs_pdhg_t *o) {
+    o->max_iter = 4000;
+    o->check = 8;
+    o->tol = 1e-6f;
+    o->tau_scale = 0.25f;
+    o->sigma_scale = 4.0f;
+}
+
+extern "C" int64_t revs_agent_num_partials(int64_t n_homes, int32_t T) {
+    if (n_homes <= 0 || T <= 0 || T > REVS_MAX_T) return 0;
+    const Shape sh = pick_shape(T);
+    const int64_t per = kBlock / sh.lpa;
+    return (n_homes + per - 1) / per;
+}
+
+extern "C" int revs_agent_step(int64_t n_homes, int32_t T, const float *cost,
+                               const revs_home_t *homes, const float *load,
+                               const float *p_est_old, const float *p_est_new, float *p_sch,
+                               float *gamma, float *s_out, float *c_out, float *diff,
+                               float *partials, int32_t *status, float kappa, int32_t mode,
+                               const revs_pdhg_t *pdhg_host, void *stream) {
+    REVS_REQUIRE(n_homes > 0, "revs_agent_step: n_homes=%lld", (long long)n_homes);
+    REVS_REQUIRE(T > 0 && T <= REVS_MAX_T, "revs_agent_step: T=%d outside 1..%d", T, REVS_MAX_T);
+    REVS_REQUIRE(cost && homes && load && p_est_old && p_est_new && p_sch && gamma && diff && partials,
+                 "revs_agent_step: null pointer argument");
+    REVS_REQUIRE(mode >= 0 && mode <= 2, "revs_agent_step: mode=%d", mode);
+    REVS_REQUIRE(kappa > 0.f, "revs_agent_step: kappa=%g must be positive", (double)kappa);
+    AgentArgs a;
+    a.n = n_homes; a.T = T; a.cost = cost; a.homes = homes; a.load = load;
+    a.pe_old = p_est_old; a.pe_new = p_est_new; a.ps = p_sch; a.gam = gamma;
+    a.s_out = s_out; a.c_out = c_out; a.diff = diff; a.partials = partials;
+    a.status = status; a.kappa = kappa;
+    if (pdhg_host) a.pd = *pdhg_host; else revs_pdhg_defaults(&a.pd);
+    REVS_REQUIRE(a.pd.max_iter > 0 && a.pd.check > 0 && a.pd.tau_scale > 0 && a.pd.sigma_scale > 0,
+                 "revs_agent_step: bad PDHG parameters");
+    const Shape sh = pick_shape(T);
+    const int64_t nblk = revs_agent_num_partials(n_homes, T);
+    REVS_REQUIRE(nblk < (1ll << 31), "revs_agent_step: too many homes for one launch");
+    const dim3 grid((unsigned)nblk);
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(LPA, SPL) launch_agent<LPA, SPL>(a, mode, grid, s)
+    REVS_FOR_SHAPE(sh, CALL);
+#undef CALL
+    REVS_CHECK_LAUNCH("revs_agent_step");
+    return REVS_OK;
+}
+
+extern "C" int revs_residual_finalize(const float *partials, int64_t num_partials,
+                                      int64_t n_homes, int32_t T, float kappa, float eps,
+                                      float *out, void *stream) {
+    REVS_REQUIRE(partials && out && num_partials > 0, "revs_residual_finalize: bad argument");
+    hipLaunchKernelGGL(residual_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
+                       partials, num_partials, (double)n_homes * (double)T, kappa, eps, out);
+    REVS_CHECK_LAUNCH("revs_residual_finalize");
+    return REVS_OK;
+}
+
+extern "C" int revs_residence_solve(int64_t n_homes, int32_t T, const float *tariff,
+                                    const revs_home_t *homes, const float *load, float *p_out,
+                                    float *soc_out, float *g_out, void *stream) {
+    REVS_REQUIRE(n_homes > 0 && T > 0 && T <= REVS_MAX_T, "revs_residence_solve: bad size");
+    REVS_REQUIRE(tariff && homes && load && p_out && soc_out && g_out,
+                 "revs_residence_solve: null pointer argument");
+    const Shape sh = pick_shape(T);
+    const int64_t per = kBlock / sh.lpa;
+    const dim3 grid((unsigned)((n_homes + per - 1) / per));
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(LPA, SPL)                                                                         \
+    hipLaunchKernelGGL((residence_kernel<LPA, SPL>), grid, dim3(kBlock), 0, s, n_homes, T,     \
+                       tariff, homes, load, p_out, soc_out, g_out)
+    REVS_FOR_SHAPE(sh, CALL);
+#undef CALL
+    REVS_CHECK_LAUNCH("revs_residence_solve");
+    return REVS_OK;
+}

@@ -1,0 +1,111 @@
+// Shared helpers for librevs_admm.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "revs_admm.h"
+
+namespace revs {
+
+void set_error(const char *fmt, ...);
+
+#define REVS_REQUIRE(cond, ...)                                  \
+    do {                                                         \
+        if (!(cond)) {                                           \
+            revs::set_error(__VA_ARGS__);                        \
+            return REVS_EINVAL;                                  \
+        }                                                        \
+    } while (0)
+
+#define REVS_CHECK_LAUNCH(what)                                                  \
+    do {                                                                         \
+        hipError_t e__ = hipGetLastError();                                      \
+        if (e__ != hipSuccess) {                                                 \
+            revs::set_error("%s: %s", what, hipGetErrorString(e__));             \
+            return REVS_ELAUNCH;                                                 \
+        }                                                                        \
+    } while (0)
+
+// ---- DPP cross-lane moves (64-wide wavefront, rows of 16 lanes) ----------
+// dpp_ctrl encodings: quad_perm 0x00-0xFF, row_shl:n 0x100+n, row_shr:n 0x110+n,
+// row_mirror 0x140, row_half_mirror 0x141.  bound_ctrl=1: lanes whose source is
+// outside the row read 0.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(
+        __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+
+// Sum / max over an aligned group of LPA lanes, result in every lane of the group.
+template <int LPA>
+__device__ __forceinline__ float group_sum(float v) {
+    if constexpr (LPA >= 2) v += dpp_f<0xB1>(v);            // quad_perm [1,0,3,2]
+    if constexpr (LPA >= 4) v += dpp_f<0x4E>(v);            // quad_perm [2,3,0,1]
+    if constexpr (LPA >= 8) v += dpp_f<0x141>(v);           // row_half_mirror
+    if constexpr (LPA >= 16) v += dpp_f<0x140>(v);          // row_mirror
+    if constexpr (LPA >= 32) v += __shfl_xor(v, 16, 64);
+    if constexpr (LPA >= 64) v += __shfl_xor(v, 32, 64);
+    return v;
+}
+template <int LPA>
+__device__ __forceinline__ float group_max(float v) {
+    if constexpr (LPA >= 2) v = fmaxf(v, dpp_f<0xB1>(v));
+    if constexpr (LPA >= 4) v = fmaxf(v, dpp_f<0x4E>(v));
+    if constexpr (LPA >= 8) v = fmaxf(v, dpp_f<0x141>(v));
+    if constexpr (LPA >= 16) v = fmaxf(v, dpp_f<0x140>(v));
+    if constexpr (LPA >= 32) v = fmaxf(v, __shfl_xor(v, 16, 64));
+    if constexpr (LPA >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+
+// Exclusive prefix sum over the lanes of a group: lane l gets sum of v over group
+// lanes < l.  lig = lane index inside the group.
+template <int LPA>
+__device__ __forceinline__ float group_excl_prefix(float v, int lig) {
+    float s, t;
+    if constexpr (LPA <= 16) {
+        s = dpp_f<0x111>(v);                                 // row_shr:1
+        s = (lig >= 1) ? s : 0.0f;
+        if constexpr (LPA >= 4) { t = dpp_f<0x111>(s); s += (lig >= 1) ? t : 0.0f; }
+        if constexpr (LPA >= 4) { t = dpp_f<0x112>(s); s += (lig >= 2) ? t : 0.0f; }
+        if constexpr (LPA >= 8) { t = dpp_f<0x114>(s); s += (lig >= 4) ? t : 0.0f; }
+        if constexpr (LPA >= 16) { t = dpp_f<0x118>(s); s += (lig >= 8) ? t : 0.0f; }
+    } else {
+        s = __shfl_up(v, 1, LPA);
+        s = (lig >= 1) ? s : 0.0f;
+#pragma unroll
+        for (int d = 1; d < LPA; d <<= 1) {
+            t = __shfl_up(s, d, LPA);
+            s += (lig >= d) ? t : 0.0f;
+        }
+    }
+    return s;
+}
+// Exclusive suffix sum: lane l gets sum of v over group lanes > l.
+template <int LPA>
+__device__ __forceinline__ float group_excl_suffix(float v, int lig) {
+    float s, t;
+    if constexpr (LPA <= 16) {
+        s = dpp_f<0x101>(v);                                 // row_shl:1
+        s = (lig + 1 < LPA) ? s : 0.0f;
+        if constexpr (LPA >= 4) { t = dpp_f<0x101>(s); s += (lig + 1 < LPA) ? t : 0.0f; }
+        if constexpr (LPA >= 4) { t = dpp_f<0x102>(s); s += (lig + 2 < LPA) ? t : 0.0f; }
+        if constexpr (LPA >= 8) { t = dpp_f<0x104>(s); s += (lig + 4 < LPA) ? t : 0.0f; }
+        if constexpr (LPA >= 16) { t = dpp_f<0x108>(s); s += (lig + 8 < LPA) ? t : 0.0f; }
+    } else {
+        s = __shfl_down(v, 1, LPA);
+        s = (lig + 1 < LPA) ? s : 0.0f;
+#pragma unroll
+        for (int d = 1; d < LPA; d <<= 1) {
+            t = __shfl_down(s, d, LPA);
+            s += (lig + d < LPA) ? t : 0.0f;
+        }
+    }
+    return s;
+}
+
+}  // namespace revs

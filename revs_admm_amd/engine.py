@@ -1,0 +1,370 @@
+"""Array-level ADMM engine: owns the device buffers and drives librevs_admm.so.
+
+One `AdmmEngine` holds one rank's shard of residences (all of them on a single
+GPU) plus a replica of the node-space operator state.  Mirrors the data flow of
+`lpsolver.solve_ADMM` (reference lpsolver.py:242-290); the dict-level call
+surface lives in `revs_admm_amd.lpsolver`.
+
+PyTorch is used for device memory, streams and (multi-GPU) the RCCL all-reduce of
+the node aggregate -- every number is computed by the HIP kernels behind the C
+ABI.  There is no CPU path: constructing an engine without a GPU or without the
+built library raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import HOME_DTYPE, MODES, PDHG, check, ptr
+
+SOC_TARGET, SOC_MAX, _SOC_TOL = 0.9, 1.0, 1e-9
+
+
+def pack_homes(ev, rating, capacity, initial, start, end) -> np.ndarray:
+    """Per-residence records (revs_home_t).  nmin/nmax -- the slot counts the SOC
+    rows of lpsolver.py:101-109 allow -- are computed here in double so that the
+    float kernels never decide a borderline case."""
+    ev = np.asarray(ev, bool)
+    n = len(ev)
+    rating = np.broadcast_to(np.asarray(rating, float), (n,))
+    capacity = np.broadcast_to(np.asarray(capacity, float), (n,))
+    initial = np.broadcast_to(np.asarray(initial, float), (n,))
+    rec = np.zeros(n, HOME_DTYPE)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        per = np.where(ev, rating / np.where(capacity != 0, capacity, 1.0), 1.0)
+        per = np.where(per > 0, per, 1.0)
+    nmin = np.ceil((np.maximum(SOC_TARGET, initial) - initial) / per - _SOC_TOL)
+    nmax = np.floor((SOC_MAX - initial) / per + _SOC_TOL)
+    rec["ev"] = ev
+    rec["start"] = np.broadcast_to(np.asarray(start), (n,))
+    rec["end"] = np.broadcast_to(np.asarray(end), (n,))
+    rec["nmin"] = np.where(ev, np.clip(nmin, 0, 2**30), 0)
+    rec["nmax"] = np.where(ev, np.clip(nmax, -1, 2**30), 0)
+    rec["rating"] = np.where(ev, rating, 0.0)
+    rec["capacity"] = np.where(ev, capacity, 1.0)
+    rec["initial"] = np.where(ev, initial, 0.0)
+    return rec
+
+
+def voltage_limits(vset, vlow, vhigh):
+    """lpsolver.py:185-186."""
+    return vlow * vlow - vset * vset, vhigh * vhigh - vset * vset
+
+
+@dataclass
+class OperatorOptions:
+    eps: float = 1e-8            # OSQP-style abs = rel tolerance on the scaled residuals
+    max_iter: int = 20000
+    check_every: int = 25
+    adapt_every: int = 100
+    alpha: float = 1.6
+    sigma: float = 1e-6
+    rho_b_scale: float = 1.0     # rho_b = scale * kappa
+    rho_v_scale: float = 25.0    # rho_v = scale * kappa / smax^2
+    warm_start: bool = True
+
+
+def _dev_check(device):
+    if not torch.cuda.is_available():
+        raise _lib.RevsError("revs_admm_amd needs a ROCm GPU (torch.cuda.is_available() is "
+                             "False); there is no CPU fallback")
+    return torch.device(device)
+
+
+class AdmmEngine:
+    """State of one ADMM run on one GPU.
+
+    Parameters
+    ----------
+    cost      (T,)   tariff
+    homes     (n,)   HOME_DTYPE records (pack_homes) -- this rank's residences
+    load      (n,T)  base load
+    node_of   (n,)   constraint-node index of each residence (0..M-1)
+    Rn        (M,M)  LinDistFlow matrix restricted to the constraint nodes
+    group            torch.distributed process group when residences are sharded
+    """
+
+    def __init__(self, cost, homes, load, node_of, Rn, kappa=5.0, vset=1.0, vlow=0.95,
+                 vhigh=1.05, mode="binary", device="cuda:0", pdhg=None,
+                 op: OperatorOptions | None = None, group=None, node_counts=None):
+        self.lib = _lib.load()
+        self.dev = _dev_check(device)
+        torch.cuda.set_device(self.dev)
+        self.group = group
+        self.kappa = float(kappa)
+        self.mode = MODES[mode] if isinstance(mode, str) else int(mode)
+        self.op = op or OperatorOptions()
+        self.vlo, self.vhi = voltage_limits(vset, vlow, vhigh)
+
+        load = np.ascontiguousarray(load, np.float32)
+        n, T = load.shape
+        self.n, self.T = n, T
+        node_of = np.asarray(node_of, np.int64)
+        Rn = np.asarray(Rn, np.float64)
+        M = Rn.shape[0]
+        self.M = M
+        assert homes.dtype == HOME_DTYPE and len(homes) == n and len(node_of) == n
+        assert node_of.min(initial=0) >= 0 and node_of.max(initial=0) < M
+
+        # residences sorted by node -> CSR; remember the permutation
+        self.perm = np.argsort(node_of, kind="stable")
+        self.inv_perm = np.empty_like(self.perm)
+        self.inv_perm[self.perm] = np.arange(n)
+        local_counts = np.bincount(node_of, minlength=M).astype(np.int64)
+        node_ptr = np.concatenate([[0], np.cumsum(local_counts)]).astype(np.int64)
+        counts = local_counts.copy()
+        if group is not None:
+            ct = torch.from_numpy(counts).to(self.dev)
+            torch.distributed.all_reduce(ct, group=group)
+            counts = ct.cpu().numpy()
+        if node_counts is not None:
+            counts = np.asarray(node_counts, np.int64)
+        self.node_counts = counts
+
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        f64 = dict(dtype=torch.float64, device=self.dev)
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+        self.cost = up(np.asarray(cost, np.float32))
+        self.homes = up(homes[self.perm].view(np.uint8).reshape(n, HOME_DTYPE.itemsize))
+        self.load = up(load[self.perm])
+        self.node_ptr = up(node_ptr)
+        self.P_est = torch.zeros(n, T, **f32)          # lpsolver.py:244
+        self.P_est_new = torch.zeros(n, T, **f32)
+        self.P_sch = torch.zeros(n, T, **f32)          # lpsolver.py:245
+        self.G = torch.zeros(n, T, **f32)              # lpsolver.py:246
+        self.S = torch.zeros(n, T, **f32)
+        self.Csoc = torch.zeros(n, T + 1, **f32)
+        self.diff = torch.zeros(n, **f32)
+        self.status = torch.zeros(n, dtype=torch.int32, device=self.dev)
+        self.n_part = int(self.lib.revs_agent_num_partials(n, T))
+        self.partials = torch.zeros(2 * self.n_part, **f32)
+        self.resid = torch.zeros(4, **f32)
+        self.pdhg = PDHG()
+        self.lib.revs_pdhg_defaults(C.byref(self.pdhg))
+        if pdhg:
+            for k, v in pdhg.items():
+                setattr(self.pdhg, k, v)
+
+        # ---- operator setup (host, double): R' = R diag(sqrt(n_m)) = U S V^T ----
+        sq = np.sqrt(counts.astype(np.float64))
+        U, s, Vt = np.linalg.svd(Rn * sq[None, :])
+        self.smax = float(s.max())
+        self.U, self.UT = up(U), up(U.T)
+        self.V, self.VT = up(Vt.T), up(Vt)
+        self.s = up(s)
+        self.inv_sqrt_n = up(np.where(counts > 0, 1.0 / np.maximum(sq, 1e-300), 0.0))
+        self.g0 = torch.zeros(n, T, **f64)
+        self.x = torch.zeros(n, T, **f64)
+        self.zb = torch.zeros(n, T, **f64)
+        self.yb = torch.zeros(n, T, **f64)
+        nz = lambda: torch.zeros(M, T, **f64)
+        (self.zv, self.yv, self.cx, self.w, self.rhat, self.xc, self.ta, self.tb, self.a,
+         self.sa, self.va, self.usa, self.cty) = (nz() for _ in range(13))
+        self.rho_v = torch.full((T,), self.op.rho_v_scale * self.kappa / self.smax ** 2, **f64)
+        self.rho_b = torch.full((T,), self.op.rho_b_scale * self.kappa, **f64)
+        self.res_out = torch.zeros(8, T, **f64)
+        self.op_cold = True
+        self.op_iters_hist: list[int] = []
+        self.iteration = 0
+        # R (float) for the voltage check
+        self.R32 = up(Rn.astype(np.float32))
+        self.node_load = torch.zeros(M, T, **f32)
+        self.volt = torch.zeros(M, T, **f32)
+
+    # ------------------------------------------------------------------ util
+    @property
+    def stream(self):
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def _gemm(self, At, B, Cout, accumulate=0):
+        k, m = At.shape
+        n = B.shape[1]
+        check(self.lib.revs_gemm_tn_f64(m, n, k, ptr(At), m, ptr(B), n, ptr(Cout), n,
+                                        accumulate, self.stream), "revs_gemm_tn_f64")
+
+    def _allreduce(self, t, op=None):
+        if self.group is not None:
+            torch.distributed.all_reduce(
+                t, op=op or torch.distributed.ReduceOp.SUM, group=self.group)
+
+    # -------------------------------------------------------------- operator
+    def _home_pass(self, with_update: bool):
+        o = self.op
+        check(self.lib.revs_op_home_pass(
+            self.M, self.T, ptr(self.node_ptr), ptr(self.inv_sqrt_n), ptr(self.x), ptr(self.zb),
+            ptr(self.yb), ptr(self.g0), ptr(self.xc) if with_update else None, ptr(self.rho_b),
+            self.kappa, o.sigma, o.alpha, ptr(self.rhat), self.stream), "revs_op_home_pass")
+        self._allreduce(self.rhat)
+
+    def _node_half(self):
+        """rhat -> xc, and the z_v / y_v update (GEMMs on the f64 matrix cores)."""
+        o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
+        self._gemm(self.V, self.rhat, self.ta)                      # V^T rhat
+        self._gemm(self.U, self.w, self.tb)                         # U^T w
+        check(lib.revs_op_node_scale(M, T, ptr(self.ta), ptr(self.tb), ptr(self.s),
+                                     ptr(self.rho_v), ptr(self.rho_b), self.kappa, o.sigma,
+                                     ptr(self.a), ptr(self.sa), st), "revs_op_node_scale")
+        self._gemm(self.VT, self.a, self.va)                        # V a
+        self._gemm(self.UT, self.sa, self.usa)                      # U (s a) = C_v xt
+        check(lib.revs_op_node_update(M, T, ptr(self.va), ptr(self.rhat), ptr(self.usa),
+                                      ptr(self.rho_v), ptr(self.rho_b), self.kappa, o.sigma,
+                                      o.alpha, self.vlo, self.vhi, ptr(self.xc), ptr(self.zv),
+                                      ptr(self.yv), ptr(self.cx), ptr(self.w), st),
+              "revs_op_node_update")
+
+    def _residuals(self):
+        lib, M, T, st = self.lib, self.M, self.T, self.stream
+        self._gemm(self.U, self.yv, self.tb)                        # U^T y_v
+        self.tb.mul_(self.s[:, None])
+        self._gemm(self.VT, self.tb, self.cty)                      # V S U^T y_v
+        self.res_out.zero_()
+        check(lib.revs_op_residuals(M, T, ptr(self.node_ptr), ptr(self.inv_sqrt_n), ptr(self.x),
+                                    ptr(self.zb), ptr(self.yb), ptr(self.g0), ptr(self.cty),
+                                    ptr(self.cx), ptr(self.zv), self.kappa, ptr(self.res_out),
+                                    st), "revs_op_residuals")
+        self._allreduce(self.res_out, torch.distributed.ReduceOp.MAX if self.group else None)
+        return self.res_out.cpu().numpy()
+
+    def operator_solve(self):
+        """Utility(graph, P_est[k], P_sch[k], G[k]).solve() -> P_est[k+1]
+        (lpsolver.py:256-259), written to self.P_est_new."""
+        o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
+        check(lib.revs_op_g0(self.n, T, ptr(self.P_est), ptr(self.P_sch), ptr(self.G),
+                             self.kappa, ptr(self.g0), st), "revs_op_g0")
+        if self.op_cold or not o.warm_start:
+            check(lib.revs_op_init_home(self.n, T, ptr(self.g0), ptr(self.x), ptr(self.zb),
+                                        ptr(self.yb), st), "revs_op_init_home")
+            check(lib.revs_aggregate_f64(M, T, ptr(self.node_ptr), ptr(self.x),
+                                         ptr(self.inv_sqrt_n), ptr(self.rhat), st),
+                  "revs_aggregate_f64")
+            self._allreduce(self.rhat)
+            self._gemm(self.V, self.rhat, self.ta)
+            self.ta.mul_(self.s[:, None])
+            self._gemm(self.UT, self.ta, self.cx)                   # cx = C_v x
+            self.rho_v.fill_(o.rho_v_scale * self.kappa / self.smax ** 2)
+            self.rho_b.fill_(o.rho_b_scale * self.kappa)
+            check(lib.revs_op_init_node(M, T, ptr(self.cx), ptr(self.rho_v), self.vlo, self.vhi,
+                                        ptr(self.zv), ptr(self.yv), ptr(self.w), st),
+                  "revs_op_init_node")
+            self.op_cold = False
+        self._home_pass(with_update=False)
+        it, converged = 0, False
+        vscale = max(abs(self.vlo), abs(self.vhi), 1e-300)
+        while it < o.max_iter:
+            for _ in range(o.check_every):
+                self._node_half()
+                self._home_pass(with_update=True)
+            it += o.check_every
+            r = self._residuals()
+            n_pv = np.maximum(np.maximum(r[3], r[4]), vscale)
+            n_pb = np.maximum(r[5], 1e-12)
+            n_d = np.maximum(np.maximum(self.kappa * r[5], r[6]), np.maximum(r[7], 1e-12))
+            rel_p = np.maximum(r[0] / n_pv, r[1] / n_pb)
+            rel_d = r[2] / n_d
+            if max(rel_p.max(), rel_d.max()) <= o.eps:
+                converged = True
+                break
+            if o.adapt_every and it % o.adapt_every == 0:
+                sc = np.sqrt(np.maximum(rel_p, 1e-14) / np.maximum(rel_d, 1e-14))
+                sc = np.clip(sc, 0.2, 5.0)
+                sc = np.where((sc > 2.0) | (sc < 0.5), sc, 1.0)
+                if (sc != 1.0).any():
+                    sct = torch.from_numpy(sc).to(self.dev)
+                    self.rho_v.mul_(sct)
+                    self.rho_b.mul_(sct)
+                    check(lib.revs_op_node_w(M, T, ptr(self.zv), ptr(self.yv), ptr(self.rho_v),
+                                             ptr(self.w), st), "revs_op_node_w")
+                    self._home_pass(with_update=False)
+        self.op_iters_hist.append(it)
+        self.op_converged = converged
+        check(lib.revs_op_export(self.n, T, ptr(self.zb), ptr(self.P_est_new), st),
+              "revs_op_export")
+        return converged
+
+    # ----------------------------------------------------------------- homes
+    def agent_step(self, write_sc=True):
+        """All Home(...).solve() of one iteration + dual update + diff
+        (lpsolver.py:269-284) in one kernel launch."""
+        check(self.lib.revs_agent_step(
+            self.n, self.T, ptr(self.cost), ptr(self.homes), ptr(self.load), ptr(self.P_est),
+            ptr(self.P_est_new), ptr(self.P_sch), ptr(self.G),
+            ptr(self.S) if write_sc else None, ptr(self.Csoc) if write_sc else None,
+            ptr(self.diff), ptr(self.partials), ptr(self.status), self.kappa, self.mode,
+            C.byref(self.pdhg), self.stream), "revs_agent_step")
+
+    def residuals(self, eps=1e-4):
+        """Global primal / dual residual norms of the iteration just finished,
+        reduced on the device; returns (r_primal, r_dual, converged)."""
+        check(self.lib.revs_residual_finalize(ptr(self.partials), self.n_part, self.n, self.T,
+                                              self.kappa, eps, ptr(self.resid), self.stream),
+              "revs_residual_finalize")
+        r = self.resid.cpu().numpy().astype(np.float64)
+        if self.group is not None:
+            t = torch.tensor([r[0] ** 2, r[1] ** 2], dtype=torch.float64, device=self.dev)
+            self._allreduce(t)
+            nt = torch.tensor([float(self.n)], dtype=torch.float64, device=self.dev)
+            self._allreduce(nt)
+            rp, rd = math.sqrt(t[0].item()), math.sqrt(t[1].item())
+            lim = eps * math.sqrt(nt.item() * self.T)
+            return rp, rd, bool(rp <= lim and rd <= lim)
+        return r[0], r[1], bool(r[2] > 0.5)
+
+    def step(self, write_sc=True):
+        """One iteration of the while-loop of lpsolver.py:254-287."""
+        self.operator_solve()
+        self.agent_step(write_sc)
+        self.P_est, self.P_est_new = self.P_est_new, self.P_est
+        self.iteration += 1
+
+    def run(self, iter_max=15):
+        """Full solve_ADMM loop; returns diff (iter_max, n) in the caller's home order."""
+        diffs = np.zeros((iter_max, self.n), np.float32)
+        for k in range(iter_max):
+            self.step(write_sc=(k == iter_max - 1))
+            if (self.status & 0xFF).any().item():
+                raise _lib.RevsError("No solution found (lpsolver.py:153-155): a residence's "
+                                     "charging window cannot reach 90% state of charge")
+            diffs[k] = self.diff.cpu().numpy()[self.inv_perm]
+        return diffs
+
+    # ----------------------------------------------------------- inspection
+    def _unsort(self, t):
+        return t.cpu().numpy()[self.inv_perm]
+
+    def result(self):
+        """(P_sch, S, C) of the last iteration in the caller's home order."""
+        return self._unsort(self.P_sch), self._unsort(self.S), self._unsort(self.Csoc)
+
+    def voltage(self, profile=None):
+        """R . (node aggregate of a home profile) on the f32 matrix cores: the
+        operator's voltage-sensitivity check (lpsolver.py:191-193, drawing.py:60-78)."""
+        prof = self.P_sch if profile is None else profile
+        check(self.lib.revs_aggregate_f32(self.M, self.T, ptr(self.node_ptr), ptr(prof),
+                                          ptr(self.node_load), self.stream), "revs_aggregate_f32")
+        self._allreduce(self.node_load)
+        check(self.lib.revs_voltage_f32(self.M, self.T, ptr(self.R32), ptr(self.node_load),
+                                        ptr(self.volt), self.stream), "revs_voltage_f32")
+        return self.volt
+
+
+def residence_solve(tariff, homes, load, device="cuda:0"):
+    """solve_residence for every home (lpsolver.py:430-460) -> p, soc, g arrays."""
+    lib = _lib.load()
+    dev = _dev_check(device)
+    load = np.ascontiguousarray(load, np.float32)
+    n, T = load.shape
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_t, d_l = up(np.asarray(tariff, np.float32)), up(load)
+    d_h = up(homes.view(np.uint8).reshape(n, HOME_DTYPE.itemsize))
+    p = torch.zeros(n, T, dtype=torch.float32, device=dev)
+    g = torch.zeros_like(p)
+    soc = torch.zeros(n, T + 1, dtype=torch.float32, device=dev)
+    check(lib.revs_residence_solve(n, T, ptr(d_t), ptr(d_h), ptr(d_l), ptr(p), ptr(soc), ptr(g),
+                                   torch.cuda.current_stream(dev).cuda_stream),
+          "revs_residence_solve")
+    return p.cpu().numpy(), soc.cpu().numpy(), g.cpu().numpy()

@@ -1,0 +1,182 @@
+"""Parity of the residence-side kernel (revs_agent_step) with the oracle, through
+the C ABI.  Reference: lpsolver.py:44-160 (Home) and 262-284 (loop body)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_agent(lib, w, pe_old, pe_new, ps, gm, mode, pdhg=None):
+    import torch
+    from revs_admm_amd import _lib
+    from revs_admm_amd._lib import HOME_DTYPE, PDHG, check, ptr
+    dev = torch.device("cuda:0")
+    n, T = w.load.shape
+    up = lambda a, dt=np.float32: torch.from_numpy(np.ascontiguousarray(a, dt)).to(dev)
+    d_cost, d_load = up(w.cost), up(w.load)
+    d_h = torch.from_numpy(w.homes.view(np.uint8).reshape(n, HOME_DTYPE.itemsize).copy()).to(dev)
+    d_peo, d_pen, d_ps, d_gm = up(pe_old), up(pe_new), up(ps), up(gm)
+    S = torch.zeros(n, T, dtype=torch.float32, device=dev)
+    Cs = torch.zeros(n, T + 1, dtype=torch.float32, device=dev)
+    diff = torch.zeros(n, dtype=torch.float32, device=dev)
+    status = torch.zeros(n, dtype=torch.int32, device=dev)
+    npart = lib.revs_agent_num_partials(n, T)
+    part = torch.zeros(2 * npart, dtype=torch.float32, device=dev)
+    pd = PDHG()
+    lib.revs_pdhg_defaults(C.byref(pd))
+    for k, v in (pdhg or {}).items():
+        setattr(pd, k, v)
+    check(lib.revs_agent_step(n, T, ptr(d_cost), ptr(d_h), ptr(d_load), ptr(d_peo), ptr(d_pen),
+                              ptr(d_ps), ptr(d_gm), ptr(S), ptr(Cs), ptr(diff), ptr(part),
+                              ptr(status), w.kappa, _lib.MODES[mode], C.byref(pd),
+                              torch.cuda.current_stream().cuda_stream), "agent_step")
+    out = torch.zeros(4, dtype=torch.float32, device=dev)
+    check(lib.revs_residual_finalize(ptr(part), npart, n, T, w.kappa, 1e-4, ptr(out),
+                                     torch.cuda.current_stream().cuda_stream), "finalize")
+    torch.cuda.synchronize()
+    g = lambda t: t.cpu().numpy().astype(np.float64)
+    return dict(P_sch=g(d_ps), G=g(d_gm), S=g(S), C=g(Cs), diff=g(diff),
+                status=status.cpu().numpy(), resid=g(out))
+
+
+def _state(w, seed, scale=1.0):
+    """A mid-ADMM looking state (float32-representable so both sides see one input)."""
+    from helpers import f32
+    rng = np.random.default_rng(seed)
+    n, T = w.load.shape
+    ps = f32(w.load + rng.uniform(0, 3, (n, T)) * scale)
+    pe_old = f32(ps * rng.uniform(0.7, 1.1, (n, T)))
+    pe_new = f32(ps * rng.uniform(0.7, 1.1, (n, T)))
+    gm = f32(rng.normal(0, 2.0, (n, T)) * scale)
+    return pe_old, pe_new, ps, gm
+
+
+def _prep(n, T, seed, **kw):
+    from helpers import f32, oracle_homes
+    from revs_admm_amd.synthetic import make_workload
+    w = make_workload(n, T, seed=seed, n_nodes=16, **kw)
+    w.load = f32(w.load)
+    w.cost = f32(w.cost)
+    return w, oracle_homes(w)
+
+
+@pytest.mark.parametrize("T", [24, 96, 7, 33, 130])
+@pytest.mark.parametrize("zero_state", [True, False])
+def test_binary_matches_oracle(gpu_lib, T, zero_state):
+    """Binary charger = the reference MIQP.  Bit-exact schedule wherever the oracle's
+    decision margin exceeds float rounding; objective equal everywhere."""
+    from oracle import revs_oracle as ro
+    n = 3001
+    w, oh = _prep(n, T, seed=T)
+    if zero_state:
+        pe_old = pe_new = ps = gm = np.zeros((n, T))          # lpsolver.py:244-246
+    else:
+        pe_old, pe_new, ps, gm = _state(w, T)
+    r = _run_agent(gpu_lib, w, pe_old, pe_new, ps, gm, "binary")
+    p, s, g, st = ro.home_solve_binary(w.cost, oh, pe_old, ps, gm, w.kappa)
+    assert (r["status"] == 0).all() and (st == 0).all()
+    # the schedule is a set of slots: compare objective (ties / near-ties may pick
+    # another slot of equal cost) and exact equality where the choice is unique
+    obj_gpu = ro.home_objective(w.cost, oh, r["S"], pe_old, ps, gm, w.kappa)
+    obj_ref = ro.home_objective(w.cost, oh, p, pe_old, ps, gm, w.kappa)
+    scale = np.maximum(1.0, np.abs(obj_ref))
+    assert np.max(np.abs(obj_gpu - obj_ref) / scale) < 2e-5
+    same = (np.abs(r["S"] - p).max(axis=1) == 0)
+    assert same.mean() > 0.995
+    # slot counts and window are exact
+    assert ((r["S"] > 0).sum(1) == (p > 0).sum(1)).all()
+    assert (r["S"][~oh.window()] == 0).all()
+    assert np.isin(r["S"], np.concatenate([[0.0], np.unique(w.homes["rating"]).astype(np.float64)])).all()
+    # epilogue on the homes with identical schedules: g, SOC, dual update, diff
+    chk = pe_new - g
+    G = gm + 0.5 * w.kappa * chk
+    np.testing.assert_allclose(r["P_sch"][same], g[same], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(r["C"][same], s[same], rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(r["G"][same], G[same], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(r["diff"][same], np.linalg.norm(chk, axis=1)[same] / T,
+                               rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("T", [24, 96, 50])
+@pytest.mark.parametrize("mode", ["relaxed_exact", "pdhg"])
+def test_relaxed_matches_oracle(gpu_lib, T, mode):
+    """Continuous box+SOC QP (north star).  float32 tolerance: 2e-4 kW absolute on
+    schedules of 3.6-7.2 kW chargers (PDHG stops at a 1e-6 relative step)."""
+    from oracle import revs_oracle as ro
+    n = 2003
+    w, oh = _prep(n, T, seed=100 + T, binary_feasible=False)
+    pe_old, pe_new, ps, gm = _state(w, T + 1)
+    r = _run_agent(gpu_lib, w, pe_old, pe_new, ps, gm, mode)
+    p, s, g, st = ro.home_solve_relaxed(w.cost, oh, pe_old, ps, gm, w.kappa)
+    tol = 2e-4 if mode == "pdhg" else 5e-5
+    assert np.abs(r["S"] - p).max() < tol * max(1.0, w.homes["rating"].max())
+    np.testing.assert_allclose(r["C"], s, atol=2e-4)
+    chk = pe_new - g
+    np.testing.assert_allclose(r["G"], gm + 0.5 * w.kappa * chk, atol=2e-3, rtol=1e-5)
+    np.testing.assert_allclose(r["diff"], np.linalg.norm(chk, axis=1) / T, atol=1e-4, rtol=1e-4)
+    # global residuals from the wavefront reduction
+    rp = np.sqrt((chk ** 2).sum())
+    rd = w.kappa * np.sqrt(((g - ps) ** 2).sum())
+    np.testing.assert_allclose(r["resid"][0], rp, rtol=1e-4)
+    np.testing.assert_allclose(r["resid"][1], rd, rtol=1e-4)
+
+
+def test_pdhg_follows_oracle_iteration(gpu_lib):
+    """Same PDHG, same step sizes, fixed 64 iterations: kernel vs float32 numpy."""
+    from oracle import revs_oracle as ro
+    n, T = 512, 24
+    w, oh = _prep(n, T, seed=7, binary_feasible=False)
+    pe_old, pe_new, ps, gm = _state(w, 3)
+    r = _run_agent(gpu_lib, w, pe_old, pe_new, ps, gm, "pdhg",
+                   dict(max_iter=64, check=64, tol=0.0))
+    p, *_ = ro.home_solve_relaxed_pdhg(w.cost, oh, pe_old, ps, gm, w.kappa, iters=64, tol=0.0,
+                                       check=64, dtype=np.float32)
+    assert np.abs(r["S"] - p).max() < 5e-4
+    assert ((r["status"] >> 8)[oh.ev] == 64).all()
+
+
+def test_no_ev_and_ragged(gpu_lib):
+    """Residences without EV keep p = 0, s = 0 (lpsolver.py:70-79); n not a multiple
+    of the homes-per-workgroup; a single home."""
+    from oracle import revs_oracle as ro
+    for n in (1, 5, 33):
+        w, oh = _prep(n, 24, seed=n, adoption=0.0)
+        z = np.zeros((n, 24))
+        r = _run_agent(gpu_lib, w, z, z, z, z, "binary")
+        assert (r["S"] == 0).all() and (r["C"] == 0).all()
+        np.testing.assert_allclose(r["P_sch"], w.load, rtol=0, atol=0)
+        np.testing.assert_allclose(r["G"], -0.5 * w.kappa * w.load, rtol=1e-6)
+
+
+def test_infeasible_flagged(gpu_lib):
+    """A window too short to reach 90% SOC: the reference prints 'No solution found'
+    and exits (lpsolver.py:153-155); the kernel flags status 1."""
+    w, oh = _prep(64, 24, seed=3)
+    w.homes["end"] = w.homes["start"] + 1
+    w.homes["nmin"] = np.maximum(w.homes["nmin"], 2)
+    w.homes["nmax"] = np.maximum(w.homes["nmax"], w.homes["nmin"])
+    z = np.zeros((64, 24))
+    r = _run_agent(gpu_lib, w, z, z, z, z, "binary")
+    ev = w.homes["ev"].astype(bool)
+    assert ((r["status"] & 0xFF)[ev] == 1).all() and ((r["status"] & 0xFF)[~ev] == 0).all()
+
+
+def test_golden_diff1(gpu_lib, golden):
+    """First ADMM iteration on the reference's own feeder data: diff[1] of all 267 EV
+    homes equals what the reference stored (out/121144-com2/distributed), to float32."""
+    from conftest import golden_homes
+    from helpers import f32
+    from revs_admm_amd.engine import pack_homes
+    from revs_admm_amd.synthetic import Workload
+    z, fd = golden
+    oh, evi = golden_homes(z, "dis_a90_r4800", 4.8)
+    homes = pack_homes(oh.ev, 4.8, 20.0, 0.2, 11, 23)
+    n, T = oh.LOAD.shape
+    w = Workload(f32(z["tariff_shift6"]), f32(oh.LOAD), homes, np.arange(n), np.eye(2), None, None,
+                 1.03, 0.95, 1.05, 5.0)
+    zero = np.zeros((n, T))
+    r = _run_agent(gpu_lib, w, zero, zero, zero, zero, "binary")
+    ref = z["dis_a90_r4800_diff"][:, 0]
+    np.testing.assert_allclose(r["diff"][evi], ref, rtol=2e-6)

@@ -1,0 +1,147 @@
+"""The oracle checked against itself (independent formulations) and against the
+reference's stored results.  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import revs_oracle as ro
+
+
+def _wl(n, T, seed, **kw):
+    from helpers import oracle_homes
+    from revs_admm_amd.synthetic import make_workload
+    w = make_workload(n, T, seed=seed, n_nodes=12, **kw)
+    return w, oracle_homes(w)
+
+
+def _state(w, seed):
+    rng = np.random.default_rng(seed)
+    n, T = w.load.shape
+    ps = w.load + rng.uniform(0, 3, (n, T))
+    return ps * rng.uniform(0.7, 1.1, (n, T)), ps, rng.normal(0, 2.0, (n, T))
+
+
+def test_R_dense_equals_tree(golden):
+    """compute_Rmat restated literally (lpsolver.py:17-26) == path-sum form."""
+    z, fd = golden
+    # a 300-node sub-tree keeps the dense inverse fast; the full feeder is checked too
+    R = ro.compute_Rmat(fd)
+    Rt = ro.compute_Rmat_tree(fd)
+    assert R.shape == (1691, 1691)
+    assert np.abs(R - Rt).max() < 1e-15
+    assert np.abs(R - R.T).max() < 1e-18 and R.min() >= 0
+
+
+@pytest.mark.parametrize("T", [6, 10, 12])
+def test_binary_selection_is_the_miqp_optimum(T):
+    """home_solve_binary (selection) vs literal enumeration of every on/off pattern."""
+    w, oh = _wl(60, T, seed=T)
+    # shrink the windows to the toy horizon
+    oh.start[:] = np.minimum(oh.start, T // 3)
+    oh.end[:] = T
+    nmin, nmax = ro.slot_count_bounds(oh)
+    pe, ps, gm = _state(w, T)
+    p, s, g, st = ro.home_solve_binary(w.cost, oh, pe, ps, gm, w.kappa)
+    best = ro.home_solve_binary_bruteforce(w.cost, oh, pe, ps, gm, w.kappa)
+    obj = ro.home_objective(w.cost, oh, p, pe, ps, gm, w.kappa)
+    feas = st == 0
+    assert feas.sum() > 20
+    np.testing.assert_allclose(obj[feas], best[feas], rtol=1e-12, atol=1e-12)
+    assert np.isinf(best[~feas]).all()
+    # SOC rows hold literally
+    assert (s[feas][:, -1][oh.ev[feas]] >= 0.9 - 1e-9).all() and (s <= 1 + 1e-9).all()
+
+
+@pytest.mark.parametrize("T", [24, 96])
+def test_relaxed_exact_vs_pdhg(T):
+    """Closed-form relaxed optimum == a long float64 PDHG run on the full SOC rows."""
+    w, oh = _wl(300, T, seed=T, binary_feasible=False)
+    pe, ps, gm = _state(w, T)
+    p, s, g, st = ro.home_solve_relaxed(w.cost, oh, pe, ps, gm, w.kappa)
+    p2, *_ , nit = ro.home_solve_relaxed_pdhg(w.cost, oh, pe, ps, gm, w.kappa, iters=20000,
+                                             tol=1e-12)
+    assert (st == 0).all()
+    assert np.abs(p - p2).max() < 1e-7
+    # KKT of the closed form: energy window respected, box respected
+    Elo, Ehi = ro.energy_bounds(oh)
+    e = p.sum(1)
+    assert (e >= Elo - 1e-9).all() and (e <= Ehi + 1e-9).all()
+    assert (p >= 0).all() and (p <= oh.rating[:, None] + 1e-12).all() and (p[~oh.window()] == 0).all()
+
+
+def test_utility_solver_kkt():
+    """Operator QP: ADMM answer satisfies the KKT conditions of lpsolver.py:163-238 and
+    equals a second, independent method (dual projected gradient run to convergence
+    on a small well-conditioned case)."""
+    w, oh = _wl(40, 6, seed=5)
+    pe, ps, gm = _state(w, 1)
+    g0 = ro.utility_g0(pe, ps, gm, w.kappa)
+    vlo, vhi = ro.voltage_limits(w.vset, w.vlow, w.vhigh)
+    g, info = ro.utility_solve(w.Rn, w.node_of, g0, w.kappa, vlo, vhi, return_info=True)
+    prim, stat = ro.utility_kkt(w.Rn, w.node_of, g, g0, w.kappa, vlo, vhi)
+    assert prim < 1e-9 and stat < 1e-7
+    assert np.abs(g - np.maximum(g0, 0)).max() > 1e-3        # the voltage rows do bind
+    # independent check: accelerated dual projected gradient
+    M = w.Rn.shape[0]
+    A = np.zeros((M, w.N)); A[w.node_of, np.arange(w.N)] = 1
+    RA = w.Rn @ A
+    Lc = np.linalg.norm(RA, 2) ** 2 / w.kappa
+    mu = np.zeros((M, g0.shape[1])); y = mu.copy(); tk = 1.0
+    for _ in range(200000):
+        gg = np.maximum(0, g0 - RA.T @ y / w.kappa)
+        mu_n = np.maximum(0, y + (RA @ gg - vhi) / Lc)
+        tn = (1 + np.sqrt(1 + 4 * tk * tk)) / 2
+        y = mu_n + (tk - 1) / tn * (mu_n - mu)
+        if np.vdot(y - mu_n, mu_n - mu) > 0:
+            y, tn = mu_n.copy(), 1.0
+        if np.abs(mu_n - mu).max() < 1e-13 * max(1.0, np.abs(mu_n).max()):
+            mu = mu_n
+            break
+        mu, tk = mu_n, tn
+    g2 = np.maximum(0, g0 - RA.T @ mu / w.kappa)
+    assert np.abs(g - g2).max() < 1e-6
+
+
+def test_golden_individual(golden):
+    """Stored individual-mode results (3 cases) are optimal for the restated model:
+    same objective for every residence, same slot count, inside the window."""
+    from conftest import golden_homes
+    z, fd = golden
+    for tag, rate in [("ind_a90_r4800", 4.8), ("ind_a70_r4800", 4.8), ("ind_a90_r3600", 3.6)]:
+        oh, evi = golden_homes(z, tag, rate)
+        p, s, g = ro.solve_residence(z["tariff_shift6"], oh)
+        pref = np.zeros_like(p)
+        pref[evi] = z[tag + "_P_ev"]
+        o1 = ro.residence_objective(z["tariff_shift6"], oh, p)
+        o2 = ro.residence_objective(z["tariff_shift6"], oh, pref)
+        assert np.abs(o1 - o2).max() < 1e-12
+        assert ((p > 0).sum(1) == (pref > 1e-6).sum(1)).all()
+        np.testing.assert_allclose(z[tag + "_SOC"][:, -1], s[evi][:, -1], atol=1e-9)
+        np.testing.assert_allclose(z[tag + "_P_res"], pref + oh.LOAD, atol=1e-9)
+
+
+def test_golden_distributed_first_iteration(golden):
+    """diff[1] of the stored distributed run (267 EV homes) to 1e-12: pins the home
+    objective, the SOC slot count, the dual update and the residual definition."""
+    from conftest import golden_homes
+    z, fd = golden
+    oh, evi = golden_homes(z, "dis_a90_r4800", 4.8)
+    zero = np.zeros_like(oh.LOAD)
+    p, s, g, st = ro.home_solve_binary(z["tariff_shift6"], oh, zero, zero, zero, 5.0)
+    # iteration 1: the operator's answer to an all-zero state is zero (lpsolver.py:244-259)
+    diff1 = np.linalg.norm(0.0 - g, axis=1) / 24
+    np.testing.assert_allclose(diff1[evi], z["dis_a90_r4800_diff"][:, 0], rtol=0, atol=1e-12)
+
+
+def test_golden_distributed_final_is_feasible(golden):
+    """The stored final schedules satisfy the restated home constraints: 3 full-rate
+    slots inside 11..22, SOC 0.2 -> 0.92, P_res = LOAD + P_ev."""
+    from conftest import golden_homes
+    z, fd = golden
+    oh, evi = golden_homes(z, "dis_a90_r4800", 4.8)
+    P = z["dis_a90_r4800_P_ev"]
+    assert np.isin(np.round(P, 9), [0.0, 4.8]).all()
+    assert ((P > 1e-6).sum(1) == 3).all()      # (solver noise ~1e-15 in the file)
+    assert (np.abs(P[:, :11]) < 1e-9).all() and (np.abs(P[:, 23:]) < 1e-9).all()
+    soc = 0.2 + np.cumsum(P, 1) / 20.0
+    np.testing.assert_allclose(z["dis_a90_r4800_SOC"][:, 1:], soc, atol=1e-9)
+    np.testing.assert_allclose(z["dis_a90_r4800_P_res"][evi], P + oh.LOAD[evi], atol=1e-9)
