@@ -76,7 +76,8 @@ def test_binary_matches_oracle(gpu_lib, T, zero_state):
         pe_old, pe_new, ps, gm = _state(w, T)
     r = _run_agent(gpu_lib, w, pe_old, pe_new, ps, gm, "binary")
     p, s, g, st = ro.home_solve_binary(w.cost, oh, pe_old, ps, gm, w.kappa)
-    assert (r["status"] == 0).all() and (st == 0).all()
+    assert ((r["status"] & 0xFF) == st).all()          # same homes flagged infeasible
+    assert (st == 0).mean() > 0.9
     # the schedule is a set of slots: compare objective (ties / near-ties may pick
     # another slot of equal cost) and exact equality where the choice is unique
     obj_gpu = ro.home_objective(w.cost, oh, r["S"], pe_old, ps, gm, w.kappa)
