@@ -439,12 +439,12 @@ def utility_solve(Rn, node_of, g0, kappa, vlo, vhi, eps=1e-11, max_iter=20000,
     return g
 
 
-def utility_kkt(Rn, node_of, g, g0, kappa, vlo, vhi):
-    """KKT certificate for a candidate operator solution g: returns
-    (primal infeasibility, stationarity/complementarity residual).  The multiplier
-    of the voltage rows is recovered by non-negative least squares on the active
-    rows, so no solver state is needed -- usable on GPU output."""
-    from scipy.optimize import nnls
+def utility_kkt(Rn, node_of, g, g0, kappa, vlo, vhi, yv, yb):
+    """KKT certificate of lpsolver.py:163-238 for a candidate g with multipliers
+    (yv of the voltage rows, (M,T); yb of the g >= 0 rows, (N,T), as returned by
+    utility_solve's info).  Returns (primal infeasibility, stationarity residual
+    relative to kappa, sign/complementarity violation).  Multipliers of a
+    degenerate vertex are not unique, so they are an input, not recomputed."""
     N, T = g.shape
     M = Rn.shape[0]
     A = np.zeros((M, N))
@@ -452,24 +452,13 @@ def utility_kkt(Rn, node_of, g, g0, kappa, vlo, vhi):
     RA = Rn @ A
     v = RA @ g
     prim = max((v - vhi).max(), (vlo - v).max(), (-g).max(), 0.0)
-    stat = 0.0
-    tol_act = 1e-6 * max(abs(vhi), abs(vlo))
-    for t in range(T):
-        up = np.where(v[:, t] >= vhi - tol_act)[0]
-        dn = np.where(v[:, t] <= vlo + tol_act)[0]
-        free = g[:, t] > 1e-9
-        # kappa (g - g0) + RA_up^T mu_up - RA_dn^T mu_dn - lam = 0, lam >= 0 on clamped
-        r = -kappa * (g[:, t] - g0[:, t])
-        B = np.concatenate([RA[up].T, -RA[dn].T], axis=1) if (len(up) + len(dn)) else np.zeros((N, 0))
-        if B.shape[1]:
-            mu, _ = nnls(B[free], r[free], maxiter=50 * B.shape[1] + 100)
-            res = r - B @ mu
-        else:
-            res = r
-        # on clamped homes lam = -res must be >= 0  -> res <= 0
-        stat = max(stat, np.abs(res[free]).max(initial=0.0),
-                   np.maximum(res[~free], 0).max(initial=0.0))
-    return prim, stat / kappa
+    stat = np.abs(kappa * (g - g0) + RA.T @ yv + yb).max() / kappa
+    scale = max(abs(vhi), abs(vlo))
+    # yv > 0 only on rows at vhi, yv < 0 only on rows at vlo, yb <= 0 only where g = 0
+    comp = max(np.abs(np.maximum(yv, 0) * (vhi - v)).max() / scale,
+               np.abs(np.minimum(yv, 0) * (v - vlo)).max() / scale,
+               np.abs(yb * g).max(), np.maximum(yb, 0).max())
+    return prim, stat, comp / kappa
 
 
 # --------------------------------------------------------------------------

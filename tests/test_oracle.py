@@ -77,8 +77,9 @@ def test_utility_solver_kkt():
     g0 = ro.utility_g0(pe, ps, gm, w.kappa)
     vlo, vhi = ro.voltage_limits(w.vset, w.vlow, w.vhigh)
     g, info = ro.utility_solve(w.Rn, w.node_of, g0, w.kappa, vlo, vhi, return_info=True)
-    prim, stat = ro.utility_kkt(w.Rn, w.node_of, g, g0, w.kappa, vlo, vhi)
-    assert prim < 1e-9 and stat < 1e-7
+    prim, stat, comp = ro.utility_kkt(w.Rn, w.node_of, g, g0, w.kappa, vlo, vhi,
+                                      info["yv"], info["yb"])
+    assert prim < 1e-9 and stat < 1e-8 and comp < 1e-8
     assert np.abs(g - np.maximum(g0, 0)).max() > 1e-3        # the voltage rows do bind
     # independent check: accelerated dual projected gradient
     M = w.Rn.shape[0]
