@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""Benchmark of the REVS ADMM hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--homes H] [--T 24] [--mode pdhg]
+
+N > 1 is launched by the driver as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+(one rank per GPU, RCCL).  A "step" is ONE ADMM iteration of lpsolver.solve_ADMM
+(reference lpsolver.py:254-287) over all residences: the operator QP, every home
+QP (batched PDHG kernel), the dual update and the residual reduction.  Weak
+scaling: every GPU owns `--homes` residences (default 100 000 x T=24, the size
+BASELINE.json's metric is quoted on); the feeder's 2048 constraint nodes are
+replicated and the only collective is the all-reduce of the node aggregate.
+
+Prints ONE JSON line (rank 0).  `value` = home-QP solves per second, whole job,
+inputs resident in HBM.  `roofline` is the PDHG sweep kernel against HBM;
+`roofline_matvec` the f64 matrix-core product of the operator against the f64 MFMA
+peak; `cpu_baseline` the oracle (numpy port of the reference algorithm) timed on
+this box's host cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
+F64_MFMA_PEAK_TFLOPS = 78.6    # MI355X datasheet, dense f64 matrix
+
+
+def agent_bytes_per_home(T, write_sc):
+    """Algorithmic HBM bytes of revs_agent_step per residence:
+    reads LOAD, P_est[k], P_est[k+1], P_sch[k], G[k] (5 profiles) + the 32-byte home
+    record; writes P_sch[k+1], G[k+1] (2 profiles) + diff + status (8 bytes);
+    S and C (2T+1 floats) only on the iteration whose schedules are returned."""
+    b = 5 * 4 * T + 32 + 2 * 4 * T + 8
+    if write_sc:
+        b += 4 * T + 4 * (T + 1)
+    return b
+
+
+def cpu_baseline(w, budget_s=20.0):
+    """Oracle (numpy restatement of lpsolver.py) on the host: full ADMM iterations --
+    operator QP + home QPs + dual update -- on the first `ns` residences of the same
+    workload and the nodes they touch.  One process; numpy's BLAS may use several
+    threads for the operator's dense algebra, the home solves are single-threaded."""
+    from oracle import revs_oracle as ro
+    ns = min(w.N, 4096)
+    ms = int(w.node_of[ns - 1]) + 1
+    import copy
+    ws = copy.copy(w)
+    ws.load, ws.homes, ws.node_of, ws.Rn = w.load[:ns], w.homes[:ns], w.node_of[:ns], w.Rn[:ms, :ms]
+    oh = ro.homes_from_records(ws.load, ws.homes)
+    iters = 0
+    t0 = time.perf_counter()
+    # solve_ADMM keeps its own state; time successive whole runs of 2 iterations
+    while True:
+        ro.solve_ADMM(oh, ws.Rn, ws.node_of, ws.cost, ws.kappa, 2, ws.vset, ws.vlow, ws.vhigh,
+                      mode="relaxed", util_eps=1e-8)
+        iters += 2
+        dt = time.perf_counter() - t0
+        if dt > budget_s or iters >= 6:
+            break
+    try:
+        import threadpoolctl
+        cores = max([p["num_threads"] for p in threadpoolctl.threadpool_info()] or [1])
+    except Exception:
+        cores = 1
+    return {"value": ns * iters / dt, "unit": "solves/s", "cores": int(cores), "kind": "port",
+            "sample": f"{iters} ADMM iterations (operator QP + home QPs + dual update) on the "
+                      f"first {ns} residences / {ms} nodes of the same synthetic workload, "
+                      f"oracle/revs_oracle.py (numpy float64), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--homes", type=int, default=100_000, help="residences per GPU")
+    ap.add_argument("--T", type=int, default=24)
+    ap.add_argument("--nodes", type=int, default=2048)
+    ap.add_argument("--mode", default="pdhg", choices=["pdhg", "relaxed_exact", "binary"])
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eps", type=float, default=1e-4, help="ADMM residual target")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU")
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+    group = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+        group = dist.group.WORLD
+
+    from revs_admm_amd.engine import AdmmEngine, OperatorOptions
+    from revs_admm_amd.synthetic import make_workload
+
+    n_total = args.homes * world
+    w = make_workload(n_total, args.T, n_nodes=args.nodes, seed=args.seed,
+                      binary_feasible=(args.mode == "binary"))
+    lo, hi = w.shard(rank, world)
+    counts = np.bincount(w.node_of, minlength=w.M)
+    eng = AdmmEngine(w.cost, w.homes[lo:hi], w.load[lo:hi], w.node_of[lo:hi], w.Rn, kappa=w.kappa,
+                     vset=w.vset, vlow=w.vlow, vhigh=w.vhigh, mode=args.mode, device=dev,
+                     group=group, node_counts=counts, op=OperatorOptions())
+    n_local = hi - lo
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.step(write_sc=False)
+    barrier()
+    ev_a = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            for _ in range(args.steps)]
+    ev_o = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            for _ in range(args.steps)]
+    inner0 = len(eng.op_iters_hist)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev_o[k][0].record()
+        eng.operator_solve()
+        ev_o[k][1].record()
+        ev_a[k][0].record()
+        eng.agent_step(write_sc=False)
+        ev_a[k][1].record()
+        eng.P_est, eng.P_est_new = eng.P_est_new, eng.P_est
+        eng.iteration += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    rp, rd, dmax, conv = eng.residuals(args.eps)
+    agent_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_a]))
+    oper_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_o]))
+    inner = eng.op_iters_hist[inner0:]
+    st = eng.status.cpu().numpy()
+    pdhg_it = float((st >> 8)[(st >> 8) > 0].mean()) if args.mode == "pdhg" and ((st >> 8) > 0).any() else None
+
+    # f64 matrix-core product alone: V^T rhat, as in the operator's inner iteration
+    reps = 200
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        eng._gemm(eng.V, eng.rhat, eng.ta)
+    e1.record()
+    torch.cuda.synchronize()
+    gemm_ms = e0.elapsed_time(e1) / reps
+    gemm_flops = 2.0 * eng.M * eng.M * args.T
+
+    # how many ADMM iterations until the eps-residual (continues the same run)
+    iters_to_eps = None
+    if args.mode != "binary":
+        k = eng.iteration
+        while k < 400:
+            rp, rd, dmax, conv = eng.residuals(args.eps)
+            if conv:
+                iters_to_eps = k
+                break
+            eng.step(write_sc=False)
+            k += 1
+
+    if rank == 0:
+        bytes_per_launch = agent_bytes_per_home(args.T, False) * n_local
+        ach = bytes_per_launch / (agent_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "agent_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("homes") == n_local and tj.get("T") == args.T and tj.get("mode") == args.mode:
+                    traffic = tj["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "agent_qp_solves_per_sec",
+            "value": n_total * args.steps / dt,
+            "unit": "solves/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"synthetic {args.homes} homes/GPU x T={args.T} box+SOC home QP, "
+                            f"{args.nodes}-node radial feeder, one ADMM iteration per step "
+                            "(operator QP + all home QPs + dual update + residuals)",
+                "homes_per_gpu": args.homes, "homes_total": n_total, "T": args.T,
+                "nodes": args.nodes, "home_solver": args.mode, "kappa": w.kappa,
+                "operator_dtype": "f64", "parallelism": f"homes sharded x{world}, nodes replicated",
+            },
+            "roofline": {
+                "kernel": "agent_step_kernel (home QP sweep + dual update)",
+                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+                "bytes_per_home": agent_bytes_per_home(args.T, False),
+                "avg_launch_ms": agent_ms, "pdhg_iters_mean": pdhg_it,
+            },
+            "roofline_matvec": {
+                "kernel": "gemm_tn_kernel<double> (V^T rhat, M x M x T)",
+                "bound": "mfma", "achieved": gemm_flops / (gemm_ms * 1e-3) / 1e12,
+                "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": gemm_flops / (gemm_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS,
+                "avg_launch_ms": gemm_ms,
+            },
+            "breakdown": {
+                "operator_ms_per_step": oper_ms, "agent_ms_per_step": agent_ms,
+                "operator_inner_iters_mean": float(np.mean(inner)) if inner else 0.0,
+                "admm_residual_primal": rp, "admm_residual_dual": rd, "admm_max_diff": dmax,
+                "admm_iters_to_eps": iters_to_eps, "eps": args.eps,
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(w)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

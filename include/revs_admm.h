@@ -68,8 +68,8 @@ const char *revs_last_error(void);
 /* Defaults used when `pdhg` is NULL: 4000, 8, 1e-6, 0.25, 4.0 */
 void revs_pdhg_defaults(revs_pdhg_t *out_host);
 
-/* Number of float2 partial-residual slots revs_agent_step writes for n_homes
- * (one per workgroup); size `partials` with it. */
+/* Number of partial-residual records (3 floats each) revs_agent_step writes for
+ * n_homes, one per workgroup; size `partials` as float[3 * that]. */
 int64_t revs_agent_num_partials(int64_t n_homes, int32_t T);
 
 /* One ADMM iteration of the residence side for ALL homes:
@@ -87,7 +87,8 @@ int64_t revs_agent_num_partials(int64_t n_homes, int32_t T);
  *   s_out       float[n][T]       p_opt  (reference's S)   or NULL to skip
  *   c_out       float[n][T+1]     s_opt  (reference's C)   or NULL to skip
  *   diff        float[n]          diff[k+1]
- *   partials    float[2*np]       per-workgroup sums {|P_est-P_sch|^2, |P_sch[k+1]-P_sch[k]|^2}
+ *   partials    float[3*np]       per workgroup {sum |P_est-P_sch|^2, sum |P_sch[k+1]-P_sch[k]|^2,
+ *                                 max diff}
  *   status      int32[n]          0 ok, 1 infeasible ("No solution found", lpsolver.py:153-155),
  *                                 for PDHG: iterations used in bits 8.. ; or NULL
  */
@@ -101,9 +102,10 @@ int revs_agent_step(int64_t n_homes, int32_t T,
                     void *stream);
 
 /* Wavefront reduction of the per-workgroup partials to the global ADMM residuals
- *   out[0] = |P_est - P_sch|_2      (primal)
- *   out[1] = kappa * |P_sch[k+1] - P_sch[k]|_2   (dual)
- *   out[2] = 1.0f if both <= eps * sqrt(n*T) else 0.0f   (convergence flag)
+ *   out[0] = |P_est[k+1] - P_sch[k+1]|_2           (primal residual, all homes)
+ *   out[1] = kappa * |P_sch[k+1] - P_sch[k]|_2     (dual residual)
+ *   out[2] = max_h diff[k+1][h]   -- the reference's convergence measure (lpsolver.py:284)
+ *   out[3] = 1.0f if out[2] <= eps else 0.0f       (convergence flag, stays on device)
  * out: float[4] on the device.  Deterministic (fixed summation order).          */
 int revs_residual_finalize(const float *partials, int64_t num_partials,
                            int64_t n_homes, int32_t T, float kappa, float eps,
@@ -124,7 +126,7 @@ int revs_residence_solve(int64_t n_homes, int32_t T,
  * Solved by ADMM in OSQP form with the KKT matrix applied through the SVD
  * R diag(sqrt(n_m)) = U S V^T, so rho can be re-tuned per slot without
  * refactoring.  All operator arithmetic is double (the QP is ill conditioned:
- * cond(R)^2 ~ 5e7 on the 121144 feeder); the three products with U/V per inner
+ * cond(R)^2 ~ 5e7 on the 121144 feeder); the four products with U/V per inner
  * iteration run on v_mfma_f64_16x16x4_f64.
  */
 
@@ -138,6 +140,11 @@ int revs_gemm_tn_f64(int32_t m, int32_t n, int32_t k, const double *At, int32_t 
 int revs_gemm_tn_f32(int32_t m, int32_t n, int32_t k, const float *At, int32_t lda,
                      const float *B, int32_t ldb, float *C, int32_t ldc,
                      int32_t accumulate, void *stream);
+/* Two independent products of the same shape in ONE launch (dense leading
+ * dimensions lda = m, ldb = ldc = n, no accumulate): C0 = At0^T B0, C1 = At1^T B1. */
+int revs_gemm_tn_f64_x2(int32_t m, int32_t n, int32_t k, const double *At0, const double *B0,
+                        double *C0, const double *At1, const double *B1, double *C1,
+                        void *stream);
 
 /* V = R P : the operator's LinDistFlow voltage-sensitivity check -- `R_res @ g[:,t]`
  * of lpsolver.py:191-193 and `R@P` of drawing.py:75 -- for all slots at once.

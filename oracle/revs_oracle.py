@@ -547,6 +547,13 @@ def residence_objective(tariff, h: Homes, p):
 # --------------------------------------------------------------------------
 # synthetic workloads (shared by tests and bench so both sides see one input)
 # --------------------------------------------------------------------------
+def homes_from_records(load, rec) -> Homes:
+    """float64 view of the per-residence records the device gets (revs_home_t)."""
+    return Homes(np.asarray(load, float), rec["ev"].astype(bool), rec["rating"].astype(float),
+                 rec["capacity"].astype(float), rec["initial"].astype(float),
+                 rec["start"].astype(np.int64), rec["end"].astype(np.int64))
+
+
 def load_golden(path):
     z = np.load(path)
     fd = Feeder(z["node_label"], z["edge_u"], z["edge_v"], z["edge_r"], z["node_id"])

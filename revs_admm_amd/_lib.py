@@ -48,6 +48,7 @@ SIGNATURES = {
     "revs_residence_solve": (C.c_int, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "revs_gemm_tn_f64": (C.c_int, [_i32, _i32, _i32, _p, _i32, _p, _i32, _p, _i32, _i32, _p]),
     "revs_gemm_tn_f32": (C.c_int, [_i32, _i32, _i32, _p, _i32, _p, _i32, _p, _i32, _i32, _p]),
+    "revs_gemm_tn_f64_x2": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "revs_voltage_f32": (C.c_int, [_i32, _i32, _p, _p, _p, _p]),
     "revs_aggregate_f64": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p]),
     "revs_aggregate_f32": (C.c_int, [_i32, _i32, _p, _p, _p, _p]),
@@ -77,6 +78,11 @@ def load() -> C.CDLL:
         raise RevsError(
             f"{LIB_PATH} is missing: build it with `python -m revs_admm_amd.build` "
             "(hipcc, gfx950).  revs_admm_amd has no CPU fallback.")
+    # PyTorch-ROCm carries its own libamdhip64; load it FIRST so that this library's
+    # NEEDED libamdhip64.so.7 resolves to the runtime torch's tensors and streams live
+    # in.  (Loaded the other way round the process ends up with two HIP runtimes and
+    # the second one finds "no ROCm-capable device".)
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported

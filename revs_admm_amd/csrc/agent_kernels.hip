@@ -18,7 +18,8 @@
 // across the group -- no LDS, no T x T matrix is ever formed.
 //
 // Arithmetic: float (BASELINE north star); the residual partials are summed in
-// float per workgroup and in double by residual_finalize_kernel.
+// float per workgroup and in double by residual_finalize_kernel, which also takes
+// the maximum of diff over all homes (the reference's only convergence measure).
 #include "common.h"
 #include <math.h>
 
@@ -281,50 +282,59 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
     }
     if (live && lig == 0 && a.c_out) a.c_out[crow] = ev ? h.initial : 0.f;
     const float ssg = group_sum<LPA>(ss);
+    const float dfh = live ? sqrtf(ssg) / (float)T : 0.f;   // lpsolver.py:284
     if (live && lig == 0) {
-        a.diff[agent] = sqrtf(ssg) / (float)T;              // lpsolver.py:284
+        a.diff[agent] = dfh;
         if (a.status) a.status[agent] = status;
     }
-    // per-workgroup partial residuals
-    float wss = group_sum<64>(ss), wdd = group_sum<64>(dd);
-    __shared__ float red[2][kBlock / 64];
+    // per-workgroup partial residuals: sum |check|^2, sum |dP_sch|^2, max diff
+    float wss = group_sum<64>(ss), wdd = group_sum<64>(dd), wmx = group_max<64>(dfh);
+    __shared__ float red[3][kBlock / 64];
     const int wave = tid >> 6;
-    if ((tid & 63) == 0) { red[0][wave] = wss; red[1][wave] = wdd; }
+    if ((tid & 63) == 0) { red[0][wave] = wss; red[1][wave] = wdd; red[2][wave] = wmx; }
     __syncthreads();
     if (tid == 0) {
-        float s0 = 0.f, s1 = 0.f;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int w = 0; w < kBlock / 64; ++w) { s0 += red[0][w]; s1 += red[1][w]; }
-        a.partials[2 * (int64_t)blockIdx.x + 0] = s0;
-        a.partials[2 * (int64_t)blockIdx.x + 1] = s1;
+        for (int w = 0; w < kBlock / 64; ++w) {
+            s0 += red[0][w]; s1 += red[1][w]; s2 = fmaxf(s2, red[2][w]);
+        }
+        a.partials[3 * (int64_t)blockIdx.x + 0] = s0;
+        a.partials[3 * (int64_t)blockIdx.x + 1] = s1;
+        a.partials[3 * (int64_t)blockIdx.x + 2] = s2;
     }
 }
 
 // One wavefront-strided pass over the per-workgroup partials, double accumulation,
 // fixed order -> bitwise reproducible residual norms and convergence flag.
 __global__ __launch_bounds__(256) void residual_finalize_kernel(
-        const float *partials, int64_t np, double count, float kappa, float eps, float *out) {
+        const float *partials, int64_t np, float kappa, float eps, float *out) {
     double s0 = 0.0, s1 = 0.0;
+    float mx = 0.f;
     for (int64_t i = threadIdx.x; i < np; i += 256) {
-        s0 += (double)partials[2 * i];
-        s1 += (double)partials[2 * i + 1];
+        s0 += (double)partials[3 * i];
+        s1 += (double)partials[3 * i + 1];
+        mx = fmaxf(mx, partials[3 * i + 2]);
     }
     for (int d = 32; d >= 1; d >>= 1) {
         s0 += __shfl_xor(s0, d, 64);
         s1 += __shfl_xor(s1, d, 64);
+        mx = fmaxf(mx, __shfl_xor(mx, d, 64));
     }
     __shared__ double red[2][4];
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; }
+    __shared__ float redm[4];
+    if ((threadIdx.x & 63) == 0) {
+        red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; redm[threadIdx.x >> 6] = mx;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         s0 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
         s1 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-        const float rp = (float)sqrt(s0), rd = kappa * (float)sqrt(s1);
-        const float lim = eps * (float)sqrt(count);
-        out[0] = rp;
-        out[1] = rd;
-        out[2] = (rp <= lim && rd <= lim) ? 1.0f : 0.0f;
-        out[3] = lim;
+        mx = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+        out[0] = (float)sqrt(s0);
+        out[1] = kappa * (float)sqrt(s1);
+        out[2] = mx;
+        out[3] = (mx <= eps) ? 1.0f : 0.0f;
     }
 }
 
@@ -474,8 +484,9 @@ extern "C" int revs_residual_finalize(const float *partials, int64_t num_partial
                                       int64_t n_homes, int32_t T, float kappa, float eps,
                                       float *out, void *stream) {
     REVS_REQUIRE(partials && out && num_partials > 0, "revs_residual_finalize: bad argument");
+    (void)n_homes; (void)T;
     hipLaunchKernelGGL(residual_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
-                       partials, num_partials, (double)n_homes * (double)T, kappa, eps, out);
+                       partials, num_partials, kappa, eps, out);
     REVS_CHECK_LAUNCH("revs_residual_finalize");
     return REVS_OK;
 }

@@ -5,12 +5,8 @@ from oracle import revs_oracle as ro
 
 
 def oracle_homes(w):
-    """revs_admm_amd.synthetic.Workload -> oracle Homes (float64 view of the same
-    records the device gets)."""
-    h = w.homes
-    return ro.Homes(np.asarray(w.load, float), h["ev"].astype(bool), h["rating"].astype(float),
-                    h["capacity"].astype(float), h["initial"].astype(float),
-                    h["start"].astype(np.int64), h["end"].astype(np.int64))
+    """revs_admm_amd.synthetic.Workload -> oracle Homes."""
+    return ro.homes_from_records(w.load, w.homes)
 
 
 def f32(a):

@@ -23,7 +23,7 @@ def _run_agent(lib, w, pe_old, pe_new, ps, gm, mode, pdhg=None):
     diff = torch.zeros(n, dtype=torch.float32, device=dev)
     status = torch.zeros(n, dtype=torch.int32, device=dev)
     npart = lib.revs_agent_num_partials(n, T)
-    part = torch.zeros(2 * npart, dtype=torch.float32, device=dev)
+    part = torch.zeros(3 * npart, dtype=torch.float32, device=dev)
     pd = PDHG()
     lib.revs_pdhg_defaults(C.byref(pd))
     for k, v in (pdhg or {}).items():
@@ -122,6 +122,8 @@ def test_relaxed_matches_oracle(gpu_lib, T, mode):
     rd = w.kappa * np.sqrt(((g - ps) ** 2).sum())
     np.testing.assert_allclose(r["resid"][0], rp, rtol=1e-4)
     np.testing.assert_allclose(r["resid"][1], rd, rtol=1e-4)
+    np.testing.assert_allclose(r["resid"][2], (np.linalg.norm(chk, axis=1) / T).max(), rtol=1e-4)
+    assert r["resid"][3] == 0.0
 
 
 def test_pdhg_follows_oracle_iteration(gpu_lib):
