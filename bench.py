@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eps", type=float, default=1e-4, help="ADMM residual target")
+    ap.add_argument("--no-converge", action="store_true",
+                    help="skip the untimed run to the eps-residual (profiling runs)")
     args = ap.parse_args()
 
     import torch
@@ -176,7 +178,7 @@ def main():
 
     # how many ADMM iterations until the eps-residual (continues the same run)
     iters_to_eps = None
-    if args.mode != "binary":
+    if args.mode != "binary" and not args.no_converge:
         k = eng.iteration
         while k < 400:
             rp, rd, dmax, conv = eng.residuals(args.eps)

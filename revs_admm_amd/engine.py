@@ -92,10 +92,18 @@ class AdmmEngine:
 
     def __init__(self, cost, homes, load, node_of, Rn, kappa=5.0, vset=1.0, vlow=0.95,
                  vhigh=1.05, mode="binary", device="cuda:0", pdhg=None,
-                 op: OperatorOptions | None = None, group=None, node_counts=None):
-        self.lib = _lib.load()
-        self.dev = _dev_check(device)
-        torch.cuda.set_device(self.dev)
+                 op: OperatorOptions | None = None, group=None, node_counts=None,
+                 _kernels=None):
+        if _kernels is None:
+            self.lib = _lib.load()               # raises when the HIP library is missing
+            self.dev = _dev_check(device)        # raises without a GPU
+            torch.cuda.set_device(self.dev)
+        else:
+            # tests only (tests/fake_kernels.py): an object exposing the C ABI's entry
+            # points over host memory, so the driver logic -- sharding, all-reduce,
+            # stopping rules -- can run under gloo without a GPU.  Never set by the product.
+            self.lib = _kernels
+            self.dev = torch.device(device)
         self.group = group
         self.kappa = float(kappa)
         self.mode = MODES[mode] if isinstance(mode, str) else int(mode)
@@ -182,6 +190,8 @@ class AdmmEngine:
     # ------------------------------------------------------------------ util
     @property
     def stream(self):
+        if self.dev.type != "cuda":
+            return None
         return torch.cuda.current_stream(self.dev).cuda_stream
 
     def _gemm(self, At, B, Cout, accumulate=0):
@@ -231,7 +241,7 @@ class AdmmEngine:
             for _ in range(self.op.check_every):
                 self._node_half()
                 self._home_pass(with_update=True)
-        if self.group is not None or not self.op.use_graph:
+        if self.group is not None or not self.op.use_graph or self.dev.type != "cuda":
             return body()
         if self._graph is None:
             if not self._graph_warm:           # first block eager: warms up, loads code objects

@@ -1,0 +1,129 @@
+"""The reference's solver call surface (lpsolver.py) over the MI355X engine.
+
+Same function names, argument meaning, return shapes and error behaviour as the
+reference, so a caller of `lpsolver.solve_ADMM` / `solve_residence` /
+`compute_Rmat` can switch imports:
+
+    from revs_admm_amd.lpsolver import solve_ADMM, solve_residence, compute_Rmat
+
+`homes` is the reference's dict {home id: {"LOAD": [...], "EV": {} | {"rating",
+"capacity", "initial", "start", "end"}}} (extract.py:92-133), `graph` a networkx
+graph with node attribute 'label' and edge attribute 'r' (extract.py:41-80).
+Everything numeric runs in librevs_admm.so; this module only converts dicts to
+arrays and back.  `grbpath` (Gurobi's log directory in the reference) is accepted
+and ignored.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+from .engine import AdmmEngine, OperatorOptions, pack_homes, residence_solve
+
+__all__ = ["compute_Rmat", "solve_ADMM", "solve_residence", "solve_residences",
+           "solve_central", "homes_to_arrays"]
+
+
+def compute_Rmat(graph) -> np.ndarray:
+    """R = 2 F D F^T over the non-substation nodes, in graph.nodes order -- the
+    matrix of reference lpsolver.py:17-26.  The feeder is a tree, so instead of
+    inverting the incidence matrix R[i,j] = 2 * (sum of r over the edges shared by
+    the substation->i and substation->j paths) is accumulated down the tree
+    (O(n^2) stores instead of an O(n^3) inverse; same numbers to 1e-18)."""
+    nodes = list(graph.nodes())
+    nonsub = [n for n in nodes if graph.nodes[n]["label"] != "S"]
+    roots = [n for n in nodes if graph.nodes[n]["label"] == "S"]
+    if len(roots) != 1 or graph.number_of_edges() != len(nodes) - 1:
+        raise ValueError("compute_Rmat expects a radial feeder with one substation node")
+    pos = {n: i for i, n in enumerate(nonsub)}
+    R = np.zeros((len(nonsub), len(nonsub)))
+    order, seen, stack = [], {roots[0]}, [roots[0]]
+    parent = {}
+    while stack:
+        u = stack.pop()
+        order.append(u)
+        for v in graph.neighbors(u):
+            if v not in seen:
+                seen.add(v)
+                parent[v] = u
+                stack.append(v)
+    done = []
+    for v in order[1:]:
+        i, p = pos[v], parent[v]
+        r2 = 2.0 * graph.edges[p, v]["r"]
+        if p in pos:
+            row = R[pos[p], done]
+            R[i, done] = row
+            R[done, i] = row
+            R[i, i] = R[pos[p], pos[p]] + r2
+        else:
+            R[i, i] = r2
+        done.append(i)
+    return R
+
+
+def homes_to_arrays(homes, res):
+    """Reference `homes` dict -> (LOAD (n,T), revs_home_t records) in `res` order."""
+    load = np.array([homes[h]["LOAD"] for h in res], dtype=np.float64)
+    ev = np.array([homes[h]["EV"] != {} for h in res])
+    get = lambda k, d: np.array([homes[h]["EV"].get(k, d) if homes[h]["EV"] else d for h in res])
+    rec = pack_homes(ev, get("rating", 0.0), get("capacity", 1.0), get("initial", 0.0),
+                     get("start", 0), get("end", 0))
+    return load, rec
+
+
+def solve_ADMM(homes, graph, cost, grbpath=None, kappa=5.0, iter_max=15, vset=1.0, vlow=0.95,
+               vhigh=1.05, *, mode="binary", device="cuda:0", operator: OperatorOptions = None,
+               return_engine=False):
+    """Reference lpsolver.py:242-290.  Returns (diff, P_sch, S, C):
+        diff[k+1][h]  float      |P_est[k+1][h] - P_sch[k+1][h]| / T
+        P_sch[h]      list[T]    residence net load g_opt of the last iteration
+        S[h]          list[T]    EV charger power p_opt
+        C[h]          list[T+1]  state of charge s_opt
+    `mode="binary"` is the reference's on/off charger (its MIQP, solved exactly);
+    `mode="relaxed"` the continuous box+SOC QP solved by the batched PDHG kernel.
+    A residence whose window cannot reach 90% SOC raises RevsError where the
+    reference prints 'No solution found' and exits."""
+    res = [n for n in graph if graph.nodes[n]["label"] == "H"]          # lpsolver.py:167
+    nonsub = [n for n in graph.nodes if graph.nodes[n]["label"] != "S"]  # lpsolver.py:166
+    missing = [h for h in res if h not in homes]
+    if missing:
+        raise KeyError(f"homes lacks residence {missing[0]} of the network")
+    load, rec = homes_to_arrays(homes, res)
+    if load.shape[1] != len(cost):
+        raise ValueError("LOAD and cost must have the same number of slots")
+    R = compute_Rmat(graph)
+    pos = {n: i for i, n in enumerate(nonsub)}
+    resind = [pos[n] for n in res]                                      # lpsolver.py:188-189
+    R_res = R[np.ix_(resind, resind)]
+    eng = AdmmEngine(np.asarray(cost, float), rec, load, np.arange(len(res)), R_res, kappa=kappa,
+                     vset=vset, vlow=vlow, vhigh=vhigh, mode=mode, device=device, op=operator)
+    d = eng.run(iter_max)
+    P_sch, S, C = eng.result()
+    diff = {k + 1: {h: float(d[k, i]) for i, h in enumerate(res)} for k in range(iter_max)}
+    out = (diff, {h: P_sch[i].tolist() for i, h in enumerate(res)},
+           {h: S[i].tolist() for i, h in enumerate(res)},
+           {h: C[i].tolist() for i, h in enumerate(res)})
+    return out + (eng,) if return_engine else out
+
+
+def solve_residences(tariff, homes, device="cuda:0"):
+    """Batched form of solve_residence over a `homes` dict: {h: (p, s, g)}."""
+    keys = list(homes)
+    load, rec = homes_to_arrays(homes, keys)
+    p, s, g = residence_solve(np.asarray(tariff, float), rec, load, device)
+    return {h: (p[i], s[i], g[i]) for i, h in enumerate(keys)}
+
+
+def solve_residence(tariff, data, path=None):
+    """Reference lpsolver.py:430-460: individual optimum of one residence
+    -> (p_opt, s_opt, g_opt).  `path` (Gurobi log directory) is ignored."""
+    (p, s, g), = solve_residences(tariff, {0: data}).values()
+    return p, s, g
+
+
+def solve_central(tariff, homes, dist, path, vset, vmin, vmax):
+    """Reference lpsolver.py:463-502 (one network-wide MIQP).  Not on the ADMM hot
+    path this engine covers; see DESIGN.md 'out of scope'."""
+    raise NotImplementedError("solve_central: the centralized MIQP is outside the ADMM hot "
+                              "path (DESIGN.md, section 7)")

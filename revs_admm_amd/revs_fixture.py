@@ -1,0 +1,102 @@
+"""REVS fixture class with the reference's call surface (revs_fixture.py:60-280).
+
+    fx = REVS(**file_params)
+    tariff, homes, dist, save = fx.read_inputs(**inp_params)
+    p, ev, soc = fx.get_distributed_optimal(tariff, homes, dist, save=True, **opt_params)
+
+`get_distributed_optimal` and `get_individual_optimal` run on the MI355X engine;
+the centralized MIQP and the plotting helpers are outside the hot path."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from .extract import (GetCommunity, GetDistNet, GetHomeLoad, GetTariff, combine_result,
+                      get_homes_ev_param)
+from .lpsolver import solve_ADMM, solve_central, solve_residences
+
+
+class REVS:
+    def __init__(self, **kwargs):
+        self.netID = kwargs.get("networkID", 121144)
+        self.regID = kwargs.get("regionID", 121)
+        self.com = kwargs.get("comunityID", 2)            # (sic) revs_fixture.py:64
+        self.tariffID = kwargs.get("tariffID", "DVP")
+        self.optim = kwargs.get("optimizer_mode", "individual")
+        self.data_path = kwargs.get("data_path")
+        out_path = kwargs.get("out_path")
+        self.fig_dir = kwargs.get("fig_path")
+        self.out_dir = f"{out_path}/{self.netID}-com{self.com}/{self.optim}"
+        self.device = kwargs.get("device", "cuda:0")
+
+    def _save(self, data, adopt, rating, seed):
+        os.makedirs(self.out_dir, exist_ok=True)
+        with open(f"{self.out_dir}/adopt{adopt}-rating{rating}-seed{seed}.txt", "w") as f:
+            f.write(data)
+
+    # ---- inputs (revs_fixture.py:114-189) ----
+    def read_tariff(self, tariffID=None, shift=6):
+        return GetTariff(self.data_path, tariffID or "DVP", shift)
+
+    def read_homes(self, regionID=None, shift=6):
+        return GetHomeLoad(self.data_path, regionID or self.regID, shift=shift)
+
+    def read_network(self, networkID=None):
+        return GetDistNet(self.data_path, networkID or self.netID)
+
+    def read_community(self, networkID=None, com_index=2):
+        return GetCommunity(f"{self.data_path}/{networkID or self.netID}-com.txt", com_index)
+
+    def read_inputs(self, regionID=None, networkID=None, tariffID=None, ev_homes=None, **kwargs):
+        adoption = kwargs.get("adoption", 90)
+        rating = kwargs.get("rating", 4800)
+        capacity = kwargs.get("capacity", 20)
+        initial = kwargs.get("initial_soc", 0.2)
+        start = kwargs.get("start_time", 11)
+        end = kwargs.get("end_time", 23)
+        sh = kwargs.get("shift_time", 6)
+        seed = kwargs.get("seed", 1234)
+        tariff = self.read_tariff(tariffID=tariffID, shift=sh)
+        all_homes = self.read_homes(regionID=regionID, shift=sh)
+        dist = self.read_network(networkID=networkID)
+        com = self.read_community(networkID=networkID, com_index=self.com)
+        if ev_homes is None or len(ev_homes) == 0:
+            np.random.seed(int(seed))                      # revs_fixture.py:175-177
+            ev_homes = np.random.choice(com, int(adoption * 1e-2 * len(com)), replace=False)
+        homes = get_homes_ev_param(all_homes, dist, ev_homes, rating * 1e-3, capacity, initial,
+                                   start, end)
+        return tariff, homes, dist, dict(ev_homes=ev_homes, community=com)
+
+    # ---- optimisation modes ----
+    def get_individual_optimal(self, tariff, homes, save=False, **kwargs):
+        """revs_fixture.py:192-222."""
+        sol = solve_residences(tariff, homes, device=self.device)
+        Pev = {h: sol[h][0] for h in homes}
+        soc = {h: sol[h][1] for h in homes}
+        Pres = {h: sol[h][2] for h in homes}
+        if save:
+            self._save(combine_result(Pres, Pev, soc, kwargs.get("ev_homes")),
+                       kwargs.get("adoption", 90), kwargs.get("rating", 4800), kwargs.get("seed"))
+        return Pres, Pev, soc
+
+    def get_centralized_optimal(self, tariff, homes, dist, save=False, **kwargs):
+        """revs_fixture.py:225-249 -- outside the hot path (raises NotImplementedError)."""
+        return solve_central(tariff, homes, dist, None, kwargs.get("v0", 1.03),
+                             kwargs.get("vmin", 0.90), kwargs.get("vmax", 1.05))
+
+    def get_distributed_optimal(self, tariff, homes, dist, save=False, **kwargs):
+        """revs_fixture.py:251-280; note the reference reads 'vlow'/'vhigh' (not
+        'vmin'/'vmax') here, defaulting to 0.95 / 1.05."""
+        diff, Pres, Pev, soc = solve_ADMM(
+            homes, dist, tariff, None, kappa=kwargs.get("kappa", 5.0),
+            iter_max=kwargs.get("max_iterations", 15), vset=kwargs.get("v0", 1.03),
+            vlow=kwargs.get("vlow", 0.95), vhigh=kwargs.get("vhigh", 1.05),
+            mode=kwargs.get("mode", "binary"), device=self.device)
+        if save:
+            self._save(combine_result(Pres, Pev, soc, kwargs.get("ev_homes"), diff),
+                       kwargs.get("adoption", 90), kwargs.get("rating", 4800), kwargs.get("seed"))
+        return Pres, Pev, soc
+
+    def plot_result(self, *a, **k):
+        raise NotImplementedError("plotting (drawing.py) is outside the hot path")

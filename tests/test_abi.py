@@ -1,0 +1,85 @@
+"""The C-ABI library builds, loads, and exports exactly what include/revs_admm.h
+declares (no compute calls: there is no GPU here)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "revs_admm.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(revs_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from revs_admm_amd import _lib, build
+    build.build()                     # hipcc cross-compiles gfx950 without a GPU
+    return _lib.load()
+
+
+def test_header_and_binding_agree():
+    from revs_admm_amd import _lib
+    names = header_functions()
+    assert len(names) >= 20
+    assert names == sorted(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+
+
+def test_every_declared_symbol_is_exported(lib):
+    for name in header_functions():
+        assert hasattr(lib, name), name
+    assert lib.revs_version().decode().startswith("revs_admm_amd")
+
+
+def test_home_record_layout():
+    from revs_admm_amd._lib import HOME_DTYPE
+    assert HOME_DTYPE.itemsize == 32
+    assert [HOME_DTYPE.fields[k][1] for k in ("ev", "start", "end", "nmin", "nmax", "rating",
+                                              "capacity", "initial")] == list(range(0, 32, 4))
+
+
+def test_argument_validation_without_gpu(lib):
+    """Bad arguments are rejected on the host, before any launch."""
+    import ctypes as C
+    from revs_admm_amd._lib import PDHG
+    pd = PDHG()
+    lib.revs_pdhg_defaults(C.byref(pd))
+    assert (pd.max_iter, pd.check) == (4000, 8) and abs(pd.tol - 1e-6) < 1e-12
+    assert lib.revs_agent_num_partials(100000, 24) == 3125          # 32 homes per workgroup
+    assert lib.revs_agent_num_partials(10, 96) == 2                 # 8 homes per workgroup
+    assert lib.revs_agent_num_partials(10, 500) == 0                # T > REVS_MAX_T
+    rc = lib.revs_agent_step(0, 24, *([None] * 12), 5.0, 0, None, None)
+    assert rc == -1 and b"n_homes" in lib.revs_last_error()
+    rc = lib.revs_agent_step(10, 999, *([None] * 12), 5.0, 0, None, None)
+    assert rc == -1 and b"T=999" in lib.revs_last_error()
+    rc = lib.revs_gemm_tn_f64(4, 300, 4, None, 4, None, 300, None, 300, 0, None)
+    assert rc == -1
+
+
+def test_no_cpu_fallback(monkeypatch):
+    """Without a GPU the product refuses to compute (and never touches the oracle)."""
+    import numpy as np
+    import torch
+    from revs_admm_amd import _lib
+    from revs_admm_amd.engine import AdmmEngine, pack_homes
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    homes = pack_homes([True, False], 4.8, 20.0, 0.2, 11, 23)
+    with pytest.raises(_lib.RevsError, match="no CPU fallback"):
+        AdmmEngine(np.ones(24), homes, np.ones((2, 24)), [0, 1], np.eye(2))
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/librevs_admm.so")
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(_lib.RevsError, match="missing"):
+        _lib.load()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "revs_admm_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f

@@ -1,0 +1,71 @@
+"""N > 1 path: residences sharded over ranks, node space replicated, ONE collective
+per inner iteration (all-reduce of the node aggregate) -- run under gloo with
+world_size 2 on CPU through the test double, and compared with the 1-rank run."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _worker(rank, world, port, mode, out):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch
+    import torch.distributed as dist
+    from fake_kernels import FakeKernels
+    from helpers import f32
+    from revs_admm_amd.engine import AdmmEngine
+    from revs_admm_amd.synthetic import make_workload
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w = make_workload(240, 12, n_nodes=24, seed=6, stress=1.3, binary_feasible=(mode == "binary"))
+    w.load, w.cost = f32(w.load), f32(w.cost)
+    lo, hi = w.shard(rank, world)
+    e = AdmmEngine(w.cost, w.homes[lo:hi], w.load[lo:hi], w.node_of[lo:hi], w.Rn, kappa=w.kappa,
+                   vset=w.vset, vlow=w.vlow, vhigh=w.vhigh, mode=mode, device="cpu",
+                   group=dist.group.WORLD, _kernels=FakeKernels())
+    # global node counts came from the all-reduce in the constructor
+    assert (e.node_counts == np.bincount(w.node_of, minlength=w.M)).all()
+    d = e.run(3)
+    P, S, C = e.result()
+    rp, rd, dmax, conv = e.residuals(1e-4)
+    v = e.voltage().numpy().copy()
+    np.savez(out.format(rank=rank), d=d, S=S, P=P, lo=lo, hi=hi, res=[rp, rd, dmax], v=v,
+             iters=e.op_iters_hist)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["relaxed_exact", "binary"])
+def test_two_ranks_equal_one_rank(tmp_path, mode):
+    import torch.multiprocessing as mp
+    sys.path.insert(0, HERE)
+    from fake_kernels import FakeKernels
+    from helpers import f32
+    from revs_admm_amd.engine import AdmmEngine
+    from revs_admm_amd.synthetic import make_workload
+    port = 29500 + (os.getpid() % 2000)
+    out = str(tmp_path / "r{rank}.npz")
+    mp.spawn(_worker, args=(2, port, mode, out), nprocs=2, join=True)
+    w = make_workload(240, 12, n_nodes=24, seed=6, stress=1.3, binary_feasible=(mode == "binary"))
+    w.load, w.cost = f32(w.load), f32(w.cost)
+    e = AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, kappa=w.kappa, vset=w.vset,
+                   vlow=w.vlow, vhigh=w.vhigh, mode=mode, device="cpu", _kernels=FakeKernels())
+    d1 = e.run(3)
+    P1, S1, C1 = e.result()
+    rp, rd, dmax, _ = e.residuals(1e-4)
+    r = [np.load(out.format(rank=k)) for k in range(2)]
+    assert (r[0]["lo"], r[0]["hi"], r[1]["lo"], r[1]["hi"]) == (0, 120, 120, 240)
+    d2 = np.concatenate([r[0]["d"], r[1]["d"]], axis=1)
+    S2 = np.concatenate([r[0]["S"], r[1]["S"]], axis=0)
+    # same algorithm, same data; only the order of the floating-point node sums differs
+    assert np.abs(d2 - d1).max() < 1e-5 and np.abs(S2 - S1).max() < 1e-4
+    assert list(r[0]["iters"]) == list(r[1]["iters"])          # ranks stop together
+    np.testing.assert_allclose(r[0]["res"], [rp, rd, dmax], rtol=1e-4)
+    np.testing.assert_allclose(r[0]["res"], r[1]["res"], rtol=0, atol=0)
+    # voltage profile R.(aggregate load): identical on both ranks after the all-reduce
+    np.testing.assert_array_equal(r[0]["v"], r[1]["v"])
+    np.testing.assert_allclose(r[0]["v"], e.voltage().numpy(), rtol=1e-5, atol=1e-7)

@@ -1,0 +1,129 @@
+"""Host-side mirror of the reference interface: records, R matrix, readers/writers,
+and the engine's driver logic on the test double (tests/fake_kernels.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import revs_oracle as ro
+
+
+def _graph(fd, z):
+    import networkx as nx
+    g = nx.Graph()
+    for i, (nid, lab) in enumerate(zip(z["node_id"], fd.label)):
+        g.add_node(int(nid), label=lab.decode())
+    for u, v, r in zip(fd.edge_u, fd.edge_v, fd.edge_r):
+        g.add_edge(int(z["node_id"][u]), int(z["node_id"][v]), r=float(r))
+    return g
+
+
+def test_pack_homes_slot_counts():
+    """nmin/nmax of revs_home_t == the oracle's reading of lpsolver.py:101-109,
+    including the reference's own parameters (0.2, 20 kWh, 4.8 / 3.6 kW -> 3 / 4)."""
+    from revs_admm_amd.engine import pack_homes
+    rec = pack_homes([True, True, False, True], [4.8, 3.6, 0, 7.2], [20, 20, 1, 40],
+                     [0.2, 0.2, 0, 0.5], 11, 23)
+    assert rec["nmin"].tolist() == [3, 4, 0, 3] and rec["nmax"].tolist() == [3, 4, 0, 2]
+    oh = ro.homes_from_records(np.zeros((4, 24)), rec)
+    nmin, nmax = ro.slot_count_bounds(oh)
+    assert nmin.tolist() == rec["nmin"].tolist() and nmax.tolist() == rec["nmax"].tolist()
+    rng = np.random.default_rng(0)
+    n = 5000
+    rec = pack_homes(rng.random(n) < 0.7, rng.choice([3.6, 4.8, 7.2, 11.0], n),
+                     rng.choice([20., 40., 60., 75.], n), rng.uniform(0, 0.95, n), 10, 24)
+    nmin, nmax = ro.slot_count_bounds(ro.homes_from_records(np.zeros((n, 24)), rec))
+    assert (nmin == rec["nmin"]).all() and (nmax == rec["nmax"]).all()
+
+
+def test_compute_Rmat_matches_reference_formula(golden):
+    """Product compute_Rmat(graph) == literal 2 F D F^T (lpsolver.py:17-26)."""
+    from revs_admm_amd.lpsolver import compute_Rmat
+    z, fd = golden
+    R = compute_Rmat(_graph(fd, z))
+    assert np.abs(R - ro.compute_Rmat(fd)).max() < 1e-15
+
+
+def test_combine_result_roundtrip(golden):
+    """combine_result writes the reference's out/ text format: re-parse and compare
+    with the stored distributed file's numbers."""
+    import importlib.util, os
+    from revs_admm_amd.extract import combine_result
+    z, fd = golden
+    tag = "dis_a90_r4800"
+    res, ev = z["res_id"].tolist(), z[tag + "_ev_homes"].tolist()
+    P_res = {h: z[tag + "_P_res"][i].tolist() for i, h in enumerate(res)}
+    P_ev = {h: z[tag + "_P_ev"][i].tolist() for i, h in enumerate(ev)}
+    SOC = {h: z[tag + "_SOC"][i].tolist() for i, h in enumerate(ev)}
+    diff = {k + 1: {h: float(z[tag + "_diff"][i, k]) for i, h in enumerate(ev)} for k in range(15)}
+    txt = combine_result(P_res, P_ev, SOC, ev, diff)
+    spec = importlib.util.spec_from_file_location(
+        "mk", os.path.join(os.path.dirname(__file__), "golden", "make_fixtures.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    p = os.path.join(os.environ.get("TMPDIR", "/tmp"), "revs_combine.txt")
+    open(p, "w").write(txt)
+    s = mk.read_result(p)
+    assert list(s["Residence Usage Profile"]) == res
+    np.testing.assert_array_equal(np.array([s["EV Convergence over Iterations"][h] for h in ev]),
+                                  z[tag + "_diff"])
+    np.testing.assert_array_equal(np.array([s["EV Charger Usage Profile"][h] for h in ev]),
+                                  z[tag + "_P_ev"])
+
+
+def test_get_homes_ev_param_and_arrays(golden):
+    from revs_admm_amd.extract import get_homes_ev_param
+    from revs_admm_amd.lpsolver import homes_to_arrays
+    z, fd = golden
+    g = _graph(fd, z)
+    res = z["res_id"].tolist()
+    loads = {h: z["LOAD"][i].tolist() for i, h in enumerate(res)}
+    ev = z["dis_a90_r4800_ev_homes"]
+    homes = get_homes_ev_param(loads, g, ev, 4.8, 20, 0.2, 11, 23)
+    assert list(homes) == res and sum(1 for h in res if homes[h]["EV"]) == 267
+    assert homes[int(ev[0])]["EV"] == dict(rating=4.8, capacity=20.0, initial=0.2, start=11, end=23)
+    load, rec = homes_to_arrays(homes, res)
+    assert load.shape == (1126, 24) and rec["ev"].sum() == 267
+    assert (rec["nmin"][rec["ev"] == 1] == 3).all()
+
+
+def test_ev_charge_curve():
+    from revs_admm_amd.ev_charge import charge
+    assert charge(0.0) == 0.0 and abs(charge(3.5) - 189.0 * (1 - np.exp(-6.9077))) < 1e-12
+    assert charge(0.0, P0=50) == 50.0
+
+
+def test_synthetic_workload_invariants():
+    from revs_admm_amd.synthetic import make_workload, radial_R
+    w = make_workload(3000, 24, seed=4)
+    h = w.homes
+    ev = h["ev"] == 1
+    assert (h["nmin"][ev] <= h["nmax"][ev]).all() and (h["nmin"][ev] <= (h["end"] - h["start"])[ev]).all()
+    assert (np.diff(w.node_of) >= 0).all() and w.Rn.shape == (w.M, w.M)
+    assert np.abs(w.Rn - w.Rn.T).max() == 0 and np.linalg.eigvalsh(w.Rn).min() > 0
+    # radial_R == oracle's tree form on the same feeder
+    fd = ro.Feeder(np.array([b"S"] + [b"T"] * w.M), np.where(w.parent < 0, 0, w.parent + 1),
+                   np.arange(1, w.M + 1), w.edge_r)
+    assert np.abs(ro.compute_Rmat_tree(fd) - w.Rn).max() < 1e-12 * w.Rn.max()
+
+
+@pytest.mark.parametrize("mode,omode", [("binary", "binary"), ("relaxed_exact", "relaxed")])
+def test_engine_driver_on_fake_kernels(mode, omode):
+    """AdmmEngine's host logic (operator driver in SVD/node form, stopping rule, rho
+    adaptation, P_est swap) with the numpy test double == oracle solve_ADMM."""
+    from fake_kernels import FakeKernels
+    from helpers import f32, oracle_homes
+    from revs_admm_amd.engine import AdmmEngine
+    from revs_admm_amd.synthetic import make_workload
+    w = make_workload(150, 12, n_nodes=20, seed=2, stress=1.3, binary_feasible=(mode == "binary"))
+    w.load, w.cost = f32(w.load), f32(w.cost)
+    e = AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, kappa=w.kappa, vset=w.vset,
+                   vlow=w.vlow, vhigh=w.vhigh, mode=mode, device="cpu", _kernels=FakeKernels())
+    d = e.run(4)
+    d_ref, P_ref, S_ref, C_ref = ro.solve_ADMM(oracle_homes(w), w.Rn, w.node_of, w.cost, w.kappa, 4,
+                                               w.vset, w.vlow, w.vhigh, mode=omode)
+    P, S, Cs = e.result()
+    assert max(e.op_iters_hist) > 25
+    if mode == "binary":
+        same = np.abs(S - S_ref).max(1) == 0
+        assert same.mean() > 0.97
+    else:
+        assert np.abs(S - S_ref).max() < 1e-3 and np.abs(d - d_ref).max() < 1e-3
