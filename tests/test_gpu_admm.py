@@ -94,3 +94,56 @@ def test_golden_feeder_admm_statistics(gpu_lib, golden, feeder_R):
     P_sch, S, C = e.result()
     assert ((S[evi] > 0).sum(1) == 3).all() and (S[~oh.ev] == 0).all()
     np.testing.assert_allclose(C[evi][:, -1], 0.92, atol=1e-5)
+
+
+def _nx_graph(fd, z):
+    import networkx as nx
+    g = nx.Graph()
+    for nid, lab in zip(z["node_id"], fd.label):
+        g.add_node(int(nid), label=lab.decode())
+    for u, v, r in zip(fd.edge_u, fd.edge_v, fd.edge_r):
+        g.add_edge(int(z["node_id"][u]), int(z["node_id"][v]), r=float(r))
+    return g
+
+
+def test_reference_call_surface(gpu_lib, golden):
+    """lpsolver.solve_ADMM with the reference's own argument types (homes dict, networkx
+    graph, tariff list) on the 121144 feeder; dict-shaped results; diff[1] == stored."""
+    from revs_admm_amd.extract import get_homes_ev_param
+    from revs_admm_amd.lpsolver import solve_ADMM
+    z, fd = golden
+    g = _nx_graph(fd, z)
+    res = z["res_id"].tolist()
+    ev = z["dis_a90_r4800_ev_homes"]
+    homes = get_homes_ev_param({h: z["LOAD"][i].tolist() for i, h in enumerate(res)}, g, ev,
+                               4800 * 1e-3, 20, 0.2, 11, 23)
+    diff, P_sch, S, C = solve_ADMM(homes, g, z["tariff_shift6"].tolist(), "./gurobi", kappa=5.0,
+                                   iter_max=2, vset=1.03, vlow=0.95, vhigh=1.05)
+    assert sorted(diff) == [1, 2] and list(P_sch) == res and len(C[res[0]]) == 25
+    got = np.array([diff[1][int(h)] for h in ev])
+    np.testing.assert_allclose(got, z["dis_a90_r4800_diff"][:, 0], rtol=2e-6)
+    for h in ev[:20]:
+        assert abs(sum(S[int(h)]) - 3 * 4.8) < 1e-4 and abs(C[int(h)][-1] - 0.92) < 1e-5
+        np.testing.assert_allclose(np.array(P_sch[int(h)]) - np.array(S[int(h)]),
+                                   homes[int(h)]["LOAD"], atol=1e-5)
+
+
+def test_individual_mode_golden(gpu_lib, golden):
+    """revs_residence_solve (solve_residence, lpsolver.py:430-460) on the three stored
+    individual-mode cases: same objective per residence as the reference's stored answer."""
+    from conftest import golden_homes
+    from oracle import revs_oracle as ro
+    from revs_admm_amd.engine import pack_homes, residence_solve
+    z, fd = golden
+    for tag, rate in [("ind_a90_r4800", 4.8), ("ind_a70_r4800", 4.8), ("ind_a90_r3600", 3.6)]:
+        oh, evi = golden_homes(z, tag, rate)
+        p, soc, g = residence_solve(z["tariff_shift6"], pack_homes(oh.ev, rate, 20.0, 0.2, 11, 23),
+                                    oh.LOAD)
+        pref = np.zeros_like(oh.LOAD)
+        pref[evi] = z[tag + "_P_ev"]
+        o_gpu = ro.residence_objective(z["tariff_shift6"], oh, p.astype(float))
+        o_ref = ro.residence_objective(z["tariff_shift6"], oh, pref)
+        assert np.abs(o_gpu - o_ref).max() < 1e-6
+        p_or, s_or, _ = ro.solve_residence(z["tariff_shift6"], oh)
+        assert (np.abs(p - p_or).max(1) == 0).all()            # same tie rule as the oracle
+        np.testing.assert_allclose(soc, s_or, atol=1e-6)
