@@ -35,12 +35,15 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s ach
 F64_MFMA_PEAK_TFLOPS = 78.6    # MI355X datasheet, dense f64 matrix
 
 
-def agent_bytes_per_home(T, write_sc):
-    """Algorithmic HBM bytes of revs_agent_step per residence (DESIGN.md section 4):
+def agent_bytes_per_home(T, write_sc, pdhg_dual):
+    """Algorithmic HBM bytes of revs_agent_step per residence (DESIGN.md section 3.1):
     reads LOAD, P_est[k], P_est[k+1], P_sch[k], G[k] (5 profiles) + the 32-byte home
     record; writes P_sch[k+1], G[k+1] (2 profiles) + diff + status (8 bytes);
-    S and C (2T+1 floats) only on the iteration whose schedules are returned."""
+    the PDHG multipliers when they are carried across iterations (1 profile read,
+    1 written); S and C (2T+1 floats) only on the iteration whose schedules are returned."""
     b = 5 * 4 * T + 32 + 2 * 4 * T + 8
+    if pdhg_dual:
+        b += 2 * 4 * T
     if write_sc:
         b += 4 * T + 4 * (T + 1)
     return b
@@ -91,6 +94,12 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eps", type=float, default=1e-4, help="ADMM residual target")
+    ap.add_argument("--op-check", type=int, default=None, help="operator: residual test period")
+    ap.add_argument("--op-eps", type=float, default=None, help="operator: stopping tolerance")
+    ap.add_argument("--op-rho-v", type=float, default=None, help="operator: rho_v scale")
+    ap.add_argument("--op-rho-b", type=float, default=None, help="operator: rho_b scale")
+    ap.add_argument("--op-alpha", type=float, default=None, help="operator: over-relaxation")
+    ap.add_argument("--op-adapt", type=int, default=None, help="operator: rho update period")
     ap.add_argument("--no-converge", action="store_true",
                     help="skip the untimed run to the eps-residual (profiling runs)")
     args = ap.parse_args()
@@ -122,9 +131,23 @@ def main():
                       binary_feasible=(args.mode == "binary"))
     lo, hi = w.shard(rank, world)
     counts = np.bincount(w.node_of, minlength=w.M)
+    opts = OperatorOptions()
+    if args.op_check:
+        opts.check_every = args.op_check
+        opts.adapt_every = max(opts.check_every, (100 // opts.check_every) * opts.check_every)
+    if args.op_eps:
+        opts.eps = args.op_eps
+    if args.op_rho_v:
+        opts.rho_v_scale = args.op_rho_v
+    if args.op_rho_b:
+        opts.rho_b_scale = args.op_rho_b
+    if args.op_alpha:
+        opts.alpha = args.op_alpha
+    if args.op_adapt is not None:
+        opts.adapt_every = args.op_adapt
     eng = AdmmEngine(w.cost, w.homes[lo:hi], w.load[lo:hi], w.node_of[lo:hi], w.Rn, kappa=w.kappa,
                      vset=w.vset, vlow=w.vlow, vhigh=w.vhigh, mode=args.mode, device=dev,
-                     group=group, node_counts=counts, op=OperatorOptions())
+                     group=group, node_counts=counts, op=opts)
     n_local = hi - lo
 
     def barrier():
@@ -170,11 +193,11 @@ def main():
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        eng._gemm(eng.V, eng.rhat, eng.ta)
+        eng._gemm_cat(eng.Q, eng.rhat, eng.w, eng.ta, eng.tb)
     e1.record()
     torch.cuda.synchronize()
     gemm_ms = e0.elapsed_time(e1) / reps
-    gemm_flops = 2.0 * eng.M * eng.M * args.T
+    gemm_flops = 2.0 * eng.M * eng.M * 2 * args.T
 
     # how many ADMM iterations until the eps-residual (continues the same run)
     iters_to_eps = None
@@ -189,14 +212,18 @@ def main():
             k += 1
 
     if rank == 0:
-        bytes_per_launch = agent_bytes_per_home(args.T, False) * n_local
+        warm = eng.pdhg_dual is not None
+        bph = agent_bytes_per_home(args.T, False, warm)
+        bytes_per_launch = bph * n_local
         ach = bytes_per_launch / (agent_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "agent_traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("homes") == n_local and tj.get("T") == args.T and tj.get("mode") == args.mode:
+                if (tj.get("homes") == n_local and tj.get("T") == args.T
+                        and tj.get("mode") == args.mode
+                        and tj.get("algorithmic_bytes_per_launch") == bytes_per_launch):
                     traffic = tj["hbm_bytes_per_launch"]
             except Exception:
                 traffic = None
@@ -225,11 +252,11 @@ def main():
                 "kernel": "agent_step_kernel (home QP sweep + dual update)",
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                "bytes_per_home": agent_bytes_per_home(args.T, False),
+                "bytes_per_home": bph,
                 "avg_launch_ms": agent_ms, "pdhg_iters_mean": pdhg_it,
             },
             "roofline_matvec": {
-                "kernel": "gemm_tn_kernel<double> (V^T rhat, M x M x T)",
+                "kernel": "gemm_tn_kernel<double> (Q^T [rhat | w], M x M x 2T)",
                 "bound": "mfma", "achieved": gemm_flops / (gemm_ms * 1e-3) / 1e12,
                 "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": gemm_flops / (gemm_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS,

@@ -91,13 +91,17 @@ int64_t revs_agent_num_partials(int64_t n_homes, int32_t T);
  *                                 max diff}
  *   status      int32[n]          0 ok, 1 infeasible ("No solution found", lpsolver.py:153-155),
  *                                 for PDHG: iterations used in bits 8.. ; or NULL
+ *   pdhg_dual   float[n][T]       REVS_MODE_RELAXED_PDHG only, or NULL: the PDHG multipliers
+ *                                 of the SOC rows, kept between ADMM iterations.  When given,
+ *                                 PDHG starts from them and from the previous schedule
+ *                                 (P_sch[k] - LOAD) instead of from zero; zero-initialise it.
  */
 int revs_agent_step(int64_t n_homes, int32_t T,
                     const float *cost, const revs_home_t *homes, const float *load,
                     const float *p_est_old, const float *p_est_new,
                     float *p_sch, float *gamma,
                     float *s_out, float *c_out, float *diff,
-                    float *partials, int32_t *status,
+                    float *partials, int32_t *status, float *pdhg_dual,
                     float kappa, int32_t mode, const revs_pdhg_t *pdhg_host,
                     void *stream);
 
@@ -123,10 +127,11 @@ int revs_residence_solve(int64_t n_homes, int32_t T,
  *                        vlo <= R (A g) <= vhi   per slot,
  * g0 = (P_est + P_sch)/2 - G/kappa, A = home->node aggregation, R the LinDistFlow
  * sensitivity matrix of the constrained nodes (compute_Rmat, lpsolver.py:17-26).
- * Solved by ADMM in OSQP form with the KKT matrix applied through the SVD
- * R diag(sqrt(n_m)) = U S V^T, so rho can be re-tuned per slot without
- * refactoring.  All operator arithmetic is double (the QP is ill conditioned:
- * cond(R)^2 ~ 5e7 on the 121144 feeder); the four products with U/V per inner
+ * Solved by ADMM in OSQP form with the KKT matrix applied through the
+ * eigendecomposition D^1/2 R D^1/2 = Q L Q^T (D = diag(n_m); voltage row m is scaled by
+ * sqrt(n_m), which keeps the operator matrix symmetric), so rho can be re-tuned per
+ * slot without refactoring.  All operator arithmetic is double (the QP is ill conditioned:
+ * cond(R)^2 ~ 5e7 on the 121144 feeder); the two (concatenated) products with Q per inner
  * iteration run on v_mfma_f64_16x16x4_f64.
  */
 
@@ -140,11 +145,24 @@ int revs_gemm_tn_f64(int32_t m, int32_t n, int32_t k, const double *At, int32_t 
 int revs_gemm_tn_f32(int32_t m, int32_t n, int32_t k, const float *At, int32_t lda,
                      const float *B, int32_t ldb, float *C, int32_t ldc,
                      int32_t accumulate, void *stream);
+/* [C0 | C1] = At^T [B0 | B1]: one product whose right-hand side and result are each the
+ * horizontal concatenation of two double[k][T] / double[m][T] arrays (2T <= 192), so
+ * the matrix is streamed once for both.  With the voltage rows scaled by sqrt(n_m) the
+ * operator's matrix D^1/2 R D^1/2 = Q L Q^T is symmetric and one inner iteration is
+ *   [ta | tb] = Q^T [rhat | w]   and   [va | usa] = Q [a | sa]
+ * -- two launches instead of four products.  ksplit / slabs as for _x2. */
+int revs_gemm_tn_f64_cat(int32_t m, int32_t T, int32_t k, const double *At, const double *B0,
+                         const double *B1, double *C0, double *C1, int32_t ksplit,
+                         void *stream);
 /* Two independent products of the same shape in ONE launch (dense leading
- * dimensions lda = m, ldb = ldc = n, no accumulate): C0 = At0^T B0, C1 = At1^T B1. */
+ * dimensions lda = m, ldb = ldc = n, no accumulate): C0 = At0^T B0, C1 = At1^T B1.
+ * ksplit (1..8) cuts K over ksplit groups of workgroups so a small m still fills the
+ * chip; group s writes its PARTIAL product to slab s, i.e. C0 and C1 must each hold
+ * ksplit slabs of m*n doubles and the product is the sum of the slabs (the
+ * revs_op_node_* consumers add them, in slab order). */
 int revs_gemm_tn_f64_x2(int32_t m, int32_t n, int32_t k, const double *At0, const double *B0,
                         double *C0, const double *At1, const double *B1, double *C1,
-                        void *stream);
+                        int32_t ksplit, void *stream);
 
 /* V = R P : the operator's LinDistFlow voltage-sensitivity check -- `R_res @ g[:,t]`
  * of lpsolver.py:191-193 and `R@P` of drawing.py:75 -- for all slots at once.
@@ -167,60 +185,65 @@ int revs_aggregate_f32(int32_t m, int32_t T, const int64_t *node_ptr,
 int revs_op_g0(int64_t n_homes, int32_t T, const float *p_est, const float *p_sch,
                const float *gamma, float kappa, double *g0, void *stream);
 
-/* Cold start of the operator ADMM state: x = z_b = max(g0,0), y_b = 0;
- * z_v = clip(cx, vlo, vhi), y_v = 0, w = rho_v z_v. */
-int revs_op_init_home(int64_t n_homes, int32_t T, const double *g0, double *x, double *zb,
-                      double *yb, void *stream);
+/* Operator ADMM state.  Per home and slot ONE double s_b = z_b + y_b is kept
+ * (z_b = max(s_b,0) and y_b = min(s_b,0) are complementary); per node z_v, y_v.
+ * Cold start: s_b = max(g0,0); z_v = clip(cx, vlo, vhi), y_v = 0, w = rho_v z_v
+ * (cx = C_v x for that start, formed by the driver). */
+int revs_op_init_home(int64_t n_homes, int32_t T, const double *g0, double *sb, void *stream);
 int revs_op_init_node(int32_t m, int32_t T, const double *cx, const double *rho_v,
-                      double vlo, double vhi, double *zv, double *yv, double *w, void *stream);
+                      const double *bound_scale, double vlo, double vhi, double *zv, double *yv,
+                      double *w, void *stream);
 
-/* Home pass of one inner iteration (all double[n][T]; rho_b double[T];
- * c = kappa + sigma + rho_b[t]; node m owns homes node_ptr[m]..node_ptr[m+1]-1):
+/* Home pass of one inner iteration (sb, g0 double[n][T]; rho_b double[T];
+ * c = kappa + rho_b[t]; node m owns homes node_ptr[m]..node_ptr[m+1]-1):
+ *   z = max(s_b,0), y = min(s_b,0)
  *   if xc != NULL (double[m][T], node correction from revs_op_node_update):
- *       rhs = sigma x + kappa g0 + rho_b z_b - y_b
- *       xt  = rhs / c + inv_sqrt_n[m] xc[m]
- *       x   = alpha xt + (1-alpha) x ;  h = alpha xt + (1-alpha) z_b
- *       z_b = max(h + y_b/rho_b, 0)  ;  y_b += rho_b (h - z_b)
- *   rhat[m] = inv_sqrt_n[m] * sum_homes (sigma x + kappa g0 + rho_b z_b - y_b)
+ *       xt  = (kappa g0 + rho_b z - y) / c + inv_sqrt_n[m] xc[m]      x-update
+ *       u   = alpha xt + (1-alpha) z + y/rho_b
+ *       z   = max(u,0), y = rho_b min(u,0), s_b = z + y
+ *       if res != NULL (double[8][T], see revs_op_node_update; needs cty_node =
+ *       V S U^T y_v, double[m][T]): rows 1,2,5,6,7 get the per-slot maxima of
+ *       |xt - z|, |kappa (xt-g0) + C^T y|, |xt|, |C^T y|, |kappa g0|
+ *   rhat[m] = inv_sqrt_n[m] * sum_homes (kappa g0 + rho_b z - y)
  * With homes sharded over GPUs rhat is this rank's partial sum: all-reduce it. */
 int revs_op_home_pass(int32_t m, int32_t T, const int64_t *node_ptr,
-                      const double *inv_sqrt_n, double *x, double *zb, double *yb,
-                      const double *g0, const double *xc, const double *rho_b,
-                      double kappa, double sigma, double alpha, double *rhat, void *stream);
+                      const double *inv_sqrt_n, double *sb, const double *g0,
+                      const double *xc, const double *rho_b, double kappa, double alpha,
+                      double *rhat, const double *cty_node, double *res, void *stream);
 
 /* Node passes (double[m][T]; s double[m] singular values; rho_v, rho_b double[T]):
  *   revs_op_node_w:      w  = rho_v z_v - y_v
+ *   revs_op_row_scale:   out = s (per row) * in
  *   revs_op_node_scale:  a  = (ta + s tb) / (c + rho_v s^2),  sa = s a
- *                        with ta = V^T rhat, tb = U^T w from revs_gemm_tn_f64
- *   revs_op_node_update: xc = va - rhat/c            (va = V a)
+ *                        with ta = V^T rhat, tb = U^T w from revs_gemm_tn_f64_x2, each
+ *                        given as nslab K-split slabs (double[nslab][m][T]) that are summed
+ *   revs_op_node_update: (va, usa as nslab slabs, like ta/tb)
+ *                        xc = va - rhat/c            (va = V a)
  *                        h  = alpha usa + (1-alpha) z_v   (usa = U sa = C_v xt)
- *                        z_v = clip(h + y_v/rho_v, vlo, vhi); y_v += rho_v (h - z_v)
- *                        cx = alpha usa + (1-alpha) cx ;  w = rho_v z_v - y_v        */
+ *                        z_v = clip(h + y_v/rho_v, b vlo, b vhi); y_v += rho_v (h - z_v)
+ *                        (b = bound_scale[m], or 1 when NULL: row m of the voltage block
+ *                        is stored scaled by sqrt(n_m), see below)
+ *                        w = rho_v z_v - y_v
+ *                        if res != NULL: rows 0,3,4 get max|usa - z_v|, |usa|, |z_v|
+ * res is double[8][T], must be ZERO before the checking iteration (maxima are merged
+ * with atomicMax) and feeds the driver's stopping test and per-slot rho update. */
 int revs_op_node_w(int32_t m, int32_t T, const double *zv, const double *yv,
                    const double *rho_v, double *w, void *stream);
-int revs_op_node_scale(int32_t m, int32_t T, const double *ta, const double *tb,
+int revs_op_row_scale(int32_t m, int32_t T, const double *s, const double *in, double *out,
+                      void *stream);
+int revs_op_node_scale(int32_t m, int32_t T, int32_t nslab, const double *ta, const double *tb,
                        const double *s, const double *rho_v, const double *rho_b,
-                       double kappa, double sigma, double *a, double *sa, void *stream);
-int revs_op_node_update(int32_t m, int32_t T, const double *va, const double *rhat,
-                        const double *usa, const double *rho_v, const double *rho_b,
-                        double kappa, double sigma, double alpha, double vlo, double vhi,
-                        double *xc, double *zv, double *yv, double *cx, double *w,
+                       double kappa, double *a, double *sa, void *stream);
+int revs_op_node_update(int32_t m, int32_t T, int32_t nslab, const double *va,
+                        const double *rhat, const double *usa, const double *rho_v,
+                        const double *rho_b, const double *bound_scale, double kappa,
+                        double alpha, double vlo, double vhi,
+                        double *xc, double *zv, double *yv, double *w, double *res,
                         void *stream);
 
-/* Per-slot residual maxima for the stopping test and the rho update.
- * out double[8][T] must be ZERO on entry (maxima are merged with atomicMax):
- *   0 max|cx - z_v|  1 max|x - z_b|  2 max|kappa (x-g0) + C^T y|  3 max|cx|
- *   4 max|z_v|       5 max|x|        6 max|C^T y|                 7 max|kappa g0|
- * cty_node double[m][T] = V S U^T y_v (two revs_gemm_tn_f64 calls by the driver). */
-int revs_op_residuals(int32_t m, int32_t T, const int64_t *node_ptr,
-                      const double *inv_sqrt_n, const double *x, const double *zb,
-                      const double *yb, const double *g0, const double *cty_node,
-                      const double *cx, const double *zv, double kappa, double *out,
-                      void *stream);
-
-/* z_b (double) -> P_est (float): the operator's answer handed to the homes
+/* P_est = max(s_b, 0) as float: the operator's answer handed to the homes
  * (U_obj.g_opt, lpsolver.py:236-237, 259). */
-int revs_op_export(int64_t n_homes, int32_t T, const double *zb, float *p_est, void *stream);
+int revs_op_export(int64_t n_homes, int32_t T, const double *sb, float *p_est, void *stream);
 
 #ifdef __cplusplus
 }

@@ -16,6 +16,7 @@ import sys
 import pandas as pd
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BYTES_PER_HOME = int(os.environ.get("REVS_BYTES_PER_HOME", "904"))   # bench.py agent_bytes_per_home
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out")
 rows = []
 for tag, homes in (("pmc", 100000), ("pmc1m", 1000000)):
@@ -40,7 +41,7 @@ fetch = float(a[a.counter == "FETCH_SIZE"].bytes_corrected.iloc[0])
 write = float(a[a.counter == "WRITE_SIZE"].bytes_corrected.iloc[0])
 json.dump({"homes": 100000, "T": 24, "mode": "pdhg", "fetch_bytes_corrected": fetch,
            "write_bytes": write, "hbm_bytes_per_launch": fetch + write,
-           "algorithmic_bytes_per_launch": 712 * 100000,
+           "algorithmic_bytes_per_launch": BYTES_PER_HOME * 100000,
            "source": "profiles/r01_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, "
                      "separate passes; FETCH_SIZE x2 per MI355X_MICROARCH.md)"},
           open(os.path.join(ROOT, "profiles", "agent_traffic.json"), "w"), indent=1)

@@ -42,27 +42,27 @@ SIGNATURES = {
     "revs_last_error": (C.c_char_p, []),
     "revs_pdhg_defaults": (None, [C.POINTER(PDHG)]),
     "revs_agent_num_partials": (_i64, [_i64, _i32]),
-    "revs_agent_step": (C.c_int, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+    "revs_agent_step": (C.c_int, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                   _f32, _i32, C.POINTER(PDHG), _p]),
     "revs_residual_finalize": (C.c_int, [_p, _i64, _i64, _i32, _f32, _f32, _p, _p]),
     "revs_residence_solve": (C.c_int, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "revs_gemm_tn_f64": (C.c_int, [_i32, _i32, _i32, _p, _i32, _p, _i32, _p, _i32, _i32, _p]),
     "revs_gemm_tn_f32": (C.c_int, [_i32, _i32, _i32, _p, _i32, _p, _i32, _p, _i32, _i32, _p]),
-    "revs_gemm_tn_f64_x2": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p]),
+    "revs_gemm_tn_f64_x2": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _p]),
+    "revs_gemm_tn_f64_cat": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _p, _p, _i32, _p]),
     "revs_voltage_f32": (C.c_int, [_i32, _i32, _p, _p, _p, _p]),
     "revs_aggregate_f64": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p]),
     "revs_aggregate_f32": (C.c_int, [_i32, _i32, _p, _p, _p, _p]),
     "revs_op_g0": (C.c_int, [_i64, _i32, _p, _p, _p, _f32, _p, _p]),
-    "revs_op_init_home": (C.c_int, [_i64, _i32, _p, _p, _p, _p, _p]),
-    "revs_op_init_node": (C.c_int, [_i32, _i32, _p, _p, _f64, _f64, _p, _p, _p, _p]),
-    "revs_op_home_pass": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _f64, _f64,
-                                    _f64, _p, _p]),
-    "revs_op_node_w": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p]),
-    "revs_op_node_scale": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p, _f64, _f64, _p, _p, _p]),
-    "revs_op_node_update": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p, _f64, _f64, _f64, _f64,
-                                      _f64, _p, _p, _p, _p, _p, _p]),
-    "revs_op_residuals": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f64, _p,
+    "revs_op_init_home": (C.c_int, [_i64, _i32, _p, _p, _p]),
+    "revs_op_init_node": (C.c_int, [_i32, _i32, _p, _p, _p, _f64, _f64, _p, _p, _p, _p]),
+    "revs_op_home_pass": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p, _p, _f64, _f64, _p, _p, _p,
                                     _p]),
+    "revs_op_node_w": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p]),
+    "revs_op_row_scale": (C.c_int, [_i32, _i32, _p, _p, _p, _p]),
+    "revs_op_node_scale": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _p, _p, _f64, _p, _p, _p]),
+    "revs_op_node_update": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _f64, _f64, _f64,
+                                      _f64, _p, _p, _p, _p, _p, _p]),
     "revs_op_export": (C.c_int, [_i64, _i32, _p, _p, _p]),
 }
 

@@ -22,6 +22,7 @@
 // the maximum of diff over all homes (the reference's only convergence measure).
 #include "common.h"
 #include <math.h>
+#include <type_traits>
 
 namespace revs {
 
@@ -40,6 +41,7 @@ struct AgentArgs {
     float *diff;
     float *partials;
     int32_t *status;
+    float *y_state;
     float kappa;
     revs_pdhg_t pd;
 };
@@ -96,13 +98,17 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
     for (int j = 0; j < SPL; ++j) {
         const int t = t0 + j;
         valid[j] = live && (t < T);
-        const int64_t o = row + t;
-        L[j]   = valid[j] ? a.load[o] : 0.f;
-        pe[j]  = valid[j] ? a.pe_old[o] : 0.f;
-        pen[j] = valid[j] ? a.pe_new[o] : 0.f;
-        pso[j] = valid[j] ? a.ps[o] : 0.f;
-        gm[j]  = valid[j] ? a.gam[o] : 0.f;
-        const float c = (t < T) ? a.cost[t] : 0.f;
+        // out-of-range lanes read element 0 (always mapped) and discard it: straight-line
+        // loads instead of one exec-masked branch per element
+        const int64_t o = valid[j] ? row + t : 0;
+        const float vL = a.load[o], vpe = a.pe_old[o], vpn = a.pe_new[o], vps = a.ps[o],
+                    vg = a.gam[o], vc = a.cost[(t < T) ? t : 0];
+        L[j]   = valid[j] ? vL : 0.f;
+        pe[j]  = valid[j] ? vpe : 0.f;
+        pen[j] = valid[j] ? vpn : 0.f;
+        pso[j] = valid[j] ? vps : 0.f;
+        gm[j]  = valid[j] ? vg : 0.f;
+        const float c = (t < T) ? vc : 0.f;
         // lpsolver.py:118-119  a_t = gamma_t + (kappa/2)(p_util_t + p_res_t)
         const float at = gm[j] + 0.5f * kappa * (pe[j] + pso[j]);
         // objective in p:  (kappa/2) p^2 + q p,  q = kappa*LOAD + c - a
@@ -112,6 +118,7 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
     }
 
     int status = 0;
+    const ScanMasks<LPA> mk(lig);
 
     if constexpr (MODE == REVS_MODE_BINARY) {
         // p_t = e_t * rating, e_t binary (lpsolver.py:92-98).  Switching slot t on
@@ -155,51 +162,70 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
             b[j] = q[j] / (kappa * rate);
             w[j] = win[j] ? 1.f : 0.f;
             lo[j] = (t0 + j == T - 1) ? lo_last : 0.f;
-            x[j] = 0.f;
-            y[j] = 0.f;
+            // warm start: primal from the previous schedule (P_sch[k] - LOAD), dual from
+            // the previous iteration's multipliers when the caller keeps them
+            x[j] = a.y_state ? fminf(fmaxf((pso[j] - L[j]) / rate, 0.f), w[j]) : 0.f;
+            y[j] = (a.y_state && valid[j] && ev) ? a.y_state[row + t0 + j] : 0.f;
         }
+        // y of padded slots must stay 0: give them lo = hi = 0 ... no: v - clip(v,0,0) = v.
+        // Instead padded slots get lo = -inf, hi = +inf, so y = v - v = 0.
+        float hiv[SPL];
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+            hiv[j] = valid[j] ? hi : INFINITY;
+            lo[j] = valid[j] ? lo[j] : -INFINITY;
+        }
+        // one PDHG iteration; with RES the largest step of this iteration is returned
+        auto iterate = [&](auto res_tag) -> float {
+            constexpr bool RES = decltype(res_tag)::value;
+            // K^T y : inclusive suffix sum of y
+            float sfx[SPL], acc = 0.f;
+#pragma unroll
+            for (int j = SPL - 1; j >= 0; --j) { acc += y[j]; sfx[j] = acc; }
+            const float so = group_excl_suffix<LPA>(acc, lig, mk);
+            float xb[SPL], dmax = 0.f;
+#pragma unroll
+            for (int j = 0; j < SPL; ++j) {
+                const float kty = sd * (sfx[j] + so);
+                const float xn = clip3((x[j] - tau * (kty + b[j])) * inv1pt, 0.f, w[j]);
+                xb[j] = xn + (xn - x[j]);
+                if constexpr (RES) dmax = fmaxf(dmax, fabsf(xn - x[j]));
+                x[j] = xn;
+            }
+            // K xbar : inclusive prefix sum
+            float pfx[SPL];
+            acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < SPL; ++j) { acc += xb[j]; pfx[j] = acc; }
+            const float po = group_excl_prefix<LPA>(acc, lig, mk);
+#pragma unroll
+            for (int j = 0; j < SPL; ++j) {
+                const float v = y[j] + delta * (pfx[j] + po);
+                const float yn = v - clip3(v, lo[j], hiv[j]);
+                if constexpr (RES) dmax = fmaxf(dmax, fabsf(yn - y[j]));
+                y[j] = yn;
+            }
+            return dmax;
+        };
+        // Homes of one wavefront iterate together until all of them have converged (a
+        // converged home keeps iterating: it only moves closer to its optimum); `iters`
+        // records when each home first met the tolerance.
         bool done = !ev;
         int iters = 0;
         const int check = max(a.pd.check, 1);
         for (int it = 0; it < a.pd.max_iter; it += check) {
             if (__all(done)) break;          // wave-uniform exit every wave reaches
-            float res = 0.f;
-            for (int c = 0; c < check; ++c) {
-                // K^T y : inclusive suffix sum of y
-                float sfx[SPL], acc = 0.f;
-#pragma unroll
-                for (int j = SPL - 1; j >= 0; --j) { acc += y[j]; sfx[j] = acc; }
-                const float so = group_excl_suffix<LPA>(acc, lig);
-                float xn[SPL], xb[SPL];
-#pragma unroll
-                for (int j = 0; j < SPL; ++j) {
-                    const float kty = sd * (sfx[j] + so);
-                    xn[j] = fminf(fmaxf((x[j] - tau * (kty + b[j])) * inv1pt, 0.f), w[j]);
-                    xb[j] = xn[j] + (xn[j] - x[j]);
-                }
-                // K xbar : inclusive prefix sum
-                float pfx[SPL];
-                acc = 0.f;
-#pragma unroll
-                for (int j = 0; j < SPL; ++j) { acc += xb[j]; pfx[j] = acc; }
-                const float po = group_excl_prefix<LPA>(acc, lig);
-                float dmax = 0.f;
-#pragma unroll
-                for (int j = 0; j < SPL; ++j) {
-                    const float v = y[j] + delta * (pfx[j] + po);
-                    float yn = v - fminf(fmaxf(v, lo[j]), hi);
-                    yn = valid[j] ? yn : 0.f;
-                    dmax = fmaxf(dmax, fmaxf(fabsf(xn[j] - x[j]), fabsf(yn - y[j])));
-                    if (!done) { x[j] = xn[j]; y[j] = yn; }
-                }
-                res = dmax;
-            }
+            for (int c = 1; c < check; ++c) iterate(std::false_type{});
+            float res = iterate(std::true_type{});
             iters += done ? 0 : check;
             res = group_max<LPA>(res);
             done = done || (res <= a.pd.tol);
         }
 #pragma unroll
-        for (int j = 0; j < SPL; ++j) p[j] = ev ? x[j] * h.rating : 0.f;
+        for (int j = 0; j < SPL; ++j) {
+            p[j] = ev ? x[j] * h.rating : 0.f;
+            if (a.y_state && valid[j]) a.y_state[row + t0 + j] = ev ? y[j] : 0.f;
+        }
         status = iters << 8;
     } else {
         // closed form: p_t = clip(u_t + nu, 0, ub_t), u = -q/kappa; nu is the
@@ -260,7 +286,7 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
     float ss = 0.f, dd = 0.f, pacc = 0.f, pfx[SPL];
 #pragma unroll
     for (int j = 0; j < SPL; ++j) { pacc += p[j]; pfx[j] = pacc; }
-    const float poff = group_excl_prefix<LPA>(pacc, lig);
+    const float poff = group_excl_prefix<LPA>(pacc, lig, mk);
     const float invcap = ev ? 1.0f / h.capacity : 0.f;
     const int64_t crow = agent * (int64_t)(T + 1);
 #pragma unroll
@@ -372,7 +398,8 @@ __global__ __launch_bounds__(kBlock) void residence_kernel(
         acc += p[j];
         pfx[j] = acc;
     }
-    const float poff = group_excl_prefix<LPA>(acc, lig);
+    const ScanMasks<LPA> mk(lig);
+    const float poff = group_excl_prefix<LPA>(acc, lig, mk);
     const float invcap = ev ? 1.f / h.capacity : 0.f;
 #pragma unroll
     for (int j = 0; j < SPL; ++j) {
@@ -452,8 +479,8 @@ extern "C" int revs_agent_step(int64_t n_homes, int32_t T, const float *cost,
                                const revs_home_t *homes, const float *load,
                                const float *p_est_old, const float *p_est_new, float *p_sch,
                                float *gamma, float *s_out, float *c_out, float *diff,
-                               float *partials, int32_t *status, float kappa, int32_t mode,
-                               const revs_pdhg_t *pdhg_host, void *stream) {
+                               float *partials, int32_t *status, float *pdhg_dual, float kappa,
+                               int32_t mode, const revs_pdhg_t *pdhg_host, void *stream) {
     REVS_REQUIRE(n_homes > 0, "revs_agent_step: n_homes=%lld", (long long)n_homes);
     REVS_REQUIRE(T > 0 && T <= REVS_MAX_T, "revs_agent_step: T=%d outside 1..%d", T, REVS_MAX_T);
     REVS_REQUIRE(cost && homes && load && p_est_old && p_est_new && p_sch && gamma && diff && partials,
@@ -464,7 +491,7 @@ extern "C" int revs_agent_step(int64_t n_homes, int32_t T, const float *cost,
     a.n = n_homes; a.T = T; a.cost = cost; a.homes = homes; a.load = load;
     a.pe_old = p_est_old; a.pe_new = p_est_new; a.ps = p_sch; a.gam = gamma;
     a.s_out = s_out; a.c_out = c_out; a.diff = diff; a.partials = partials;
-    a.status = status; a.kappa = kappa;
+    a.status = status; a.y_state = pdhg_dual; a.kappa = kappa;
     if (pdhg_host) a.pd = *pdhg_host; else revs_pdhg_defaults(&a.pd);
     REVS_REQUIRE(a.pd.max_iter > 0 && a.pd.check > 0 && a.pd.tau_scale > 0 && a.pd.sigma_scale > 0,
                  "revs_agent_step: bad PDHG parameters");

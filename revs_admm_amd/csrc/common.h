@@ -62,19 +62,34 @@ __device__ __forceinline__ float group_max(float v) {
     return v;
 }
 
-// Exclusive prefix sum over the lanes of a group: lane l gets sum of v over group
-// lanes < l.  lig = lane index inside the group.
+// Exclusive prefix / suffix sums over the lanes of a group (lig = lane index inside
+// the group).  Each Hillis-Steele step is written as s = fma(dpp(s), mask, s) with a
+// 0/1 lane mask so that the compiler can fold the DPP move into one v_fmac_f32_dpp;
+// the masks keep a row_shr/row_shl from pulling in the neighbouring group's lanes.
 template <int LPA>
-__device__ __forceinline__ float group_excl_prefix(float v, int lig) {
-    float s, t;
+struct ScanMasks {
+    float up[4];    // lig >= 1, 2, 4, 8
+    float dn[4];    // lig + d < LPA for d = 1, 2, 4, 8
+    __device__ __forceinline__ explicit ScanMasks(int lig) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            up[k] = (lig >= (1 << k)) ? 1.0f : 0.0f;
+            dn[k] = (lig + (1 << k) < LPA) ? 1.0f : 0.0f;
+        }
+    }
+};
+
+template <int LPA>
+__device__ __forceinline__ float group_excl_prefix(float v, int lig, const ScanMasks<LPA> &mk) {
+    float s;
     if constexpr (LPA <= 16) {
-        s = dpp_f<0x111>(v);                                 // row_shr:1
-        s = (lig >= 1) ? s : 0.0f;
-        if constexpr (LPA >= 4) { t = dpp_f<0x111>(s); s += (lig >= 1) ? t : 0.0f; }
-        if constexpr (LPA >= 4) { t = dpp_f<0x112>(s); s += (lig >= 2) ? t : 0.0f; }
-        if constexpr (LPA >= 8) { t = dpp_f<0x114>(s); s += (lig >= 4) ? t : 0.0f; }
-        if constexpr (LPA >= 16) { t = dpp_f<0x118>(s); s += (lig >= 8) ? t : 0.0f; }
+        s = dpp_f<0x111>(v) * mk.up[0];                      // row_shr:1
+        if constexpr (LPA >= 4) s = fmaf(dpp_f<0x111>(s), mk.up[0], s);
+        if constexpr (LPA >= 4) s = fmaf(dpp_f<0x112>(s), mk.up[1], s);
+        if constexpr (LPA >= 8) s = fmaf(dpp_f<0x114>(s), mk.up[2], s);
+        if constexpr (LPA >= 16) s = fmaf(dpp_f<0x118>(s), mk.up[3], s);
     } else {
+        float t;
         s = __shfl_up(v, 1, LPA);
         s = (lig >= 1) ? s : 0.0f;
 #pragma unroll
@@ -85,18 +100,17 @@ __device__ __forceinline__ float group_excl_prefix(float v, int lig) {
     }
     return s;
 }
-// Exclusive suffix sum: lane l gets sum of v over group lanes > l.
 template <int LPA>
-__device__ __forceinline__ float group_excl_suffix(float v, int lig) {
-    float s, t;
+__device__ __forceinline__ float group_excl_suffix(float v, int lig, const ScanMasks<LPA> &mk) {
+    float s;
     if constexpr (LPA <= 16) {
-        s = dpp_f<0x101>(v);                                 // row_shl:1
-        s = (lig + 1 < LPA) ? s : 0.0f;
-        if constexpr (LPA >= 4) { t = dpp_f<0x101>(s); s += (lig + 1 < LPA) ? t : 0.0f; }
-        if constexpr (LPA >= 4) { t = dpp_f<0x102>(s); s += (lig + 2 < LPA) ? t : 0.0f; }
-        if constexpr (LPA >= 8) { t = dpp_f<0x104>(s); s += (lig + 4 < LPA) ? t : 0.0f; }
-        if constexpr (LPA >= 16) { t = dpp_f<0x108>(s); s += (lig + 8 < LPA) ? t : 0.0f; }
+        s = dpp_f<0x101>(v) * mk.dn[0];                      // row_shl:1
+        if constexpr (LPA >= 4) s = fmaf(dpp_f<0x101>(s), mk.dn[0], s);
+        if constexpr (LPA >= 4) s = fmaf(dpp_f<0x102>(s), mk.dn[1], s);
+        if constexpr (LPA >= 8) s = fmaf(dpp_f<0x104>(s), mk.dn[2], s);
+        if constexpr (LPA >= 16) s = fmaf(dpp_f<0x108>(s), mk.dn[3], s);
     } else {
+        float t;
         s = __shfl_down(v, 1, LPA);
         s = (lig + 1 < LPA) ? s : 0.0f;
 #pragma unroll
@@ -106,6 +120,11 @@ __device__ __forceinline__ float group_excl_suffix(float v, int lig) {
         }
     }
     return s;
+}
+
+// clip(v, lo, hi) as one v_med3_f32 (lo <= hi)
+__device__ __forceinline__ float clip3(float v, float lo, float hi) {
+    return __builtin_amdgcn_fmed3f(v, lo, hi);
 }
 
 }  // namespace revs

@@ -12,8 +12,8 @@
 //
 // The product is bound by streaming At (m*k elements, each used for only n <= 192
 // columns): 6 flop/byte at T=24 in f64.  Tiling for that:
-//   * one workgroup = one 16-row tile of C and ALL its column tiles (NT = ceil(n/16)
-//     accumulator tiles per wavefront), so At is read exactly once;
+//   * one workgroup = one (T<=32: two interleaved) 16-row tile(s) of C and ALL column
+//     tiles (NT = ceil(n/16) accumulator tiles per wavefront), so At is read exactly once;
 //   * the workgroup's 16 wavefronts split K; each issues its At/B loads a whole
 //     unrolled batch (8 k-steps) ahead of the MFMAs that consume them, which keeps
 //     ~64 KB per CU in flight;
@@ -47,102 +47,181 @@ template <> struct Mfma<float> {
     static __device__ __forceinline__ int row(int lane, int reg) { return 4 * (lane >> 4) + reg; }
 };
 
-// NT <= 2 (T <= 32): 16 wavefronts, loads 8 k-steps ahead (123 VGPRs in f64).
-// Wider T needs NT*8 accumulator registers per lane, so the workgroup drops to 8
-// wavefronts (256-VGPR budget) and a shorter look-ahead.
+// NT <= 2 (T <= 32): 16 wavefronts, two register stages of 4 k-steps.  Wider T needs NT*8
+// accumulator registers per lane, so the workgroup drops to 8 wavefronts (256-VGPR
+// budget) and a shorter look-ahead.
+//
+// RT = 2 makes the workgroup own TWO interleaved 16-row tiles (rows row0+2i and
+// row0+2i+1): every lane fetches its two A values as one 16-byte load and each B
+// fragment feeds two MFMAs, halving the B traffic out of L2 (at T=24 every workgroup
+// re-reads all of B, which otherwise outweighs the matrix itself).  `ksplit` cuts K
+// across gridDim.z so that the launch still fills 256 CUs; split s writes its partial
+// product to slab s of C (C + s*m*ldc) and the elementwise consumers add the slabs in
+// a fixed order, so the result stays reproducible without atomics.
 
+// One product C = At^T B.  B and C may each be the horizontal concatenation of two
+// arrays [X0 | X1] with X0 `csplit` columns wide (csplit = n: a single array), which is
+// how the operator multiplies Q^T by [rhat | w] without first packing them.
 template <typename T>
 struct GemmOperands {
     const T *At;
     const T *B;
     T *C;
+    const T *B1;
+    T *C1;
+    int csplit;
 };
 template <typename T>
 struct GemmBatch {
     GemmOperands<T> op[2];
 };
 
-template <typename T, int NT, int kGemmWaves, int kUnroll>
+template <typename T> struct Vec2;
+template <> struct Vec2<double> { using type = double2; };
+template <> struct Vec2<float> { using type = float2; };
+
+template <typename T, int NT, int RT, int kGemmWaves, int kUnroll>
 __global__ __launch_bounds__(kGemmWaves * 64) void gemm_tn_kernel(
         int m, int n, int k, GemmBatch<T> batch, int lda, int ldb, int ldc, int accumulate) {
     using M = Mfma<T>;
     using acc_t = typename M::acc_t;
+    using vec2 = typename Vec2<T>::type;
     const GemmOperands<T> op = batch.op[blockIdx.y];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int r = lane & 15;          // A: output row inside the tile / B: output column
     const int kk = lane >> 4;         // k index inside a 4-deep step
-    const int row0 = blockIdx.x * 16;
-    const bool arow_ok = (row0 + r) < m;
-    // this wave's K range in steps of 4
+    const int row0 = blockIdx.x * 16 * RT;
+    // this block's K range (gridDim.z splits), then this wave's share, in steps of 4
     const int ksteps = (k + 3) >> 2;
-    const int per = (ksteps + kGemmWaves - 1) / kGemmWaves;
-    const int s_begin = min(wave * per, ksteps);
-    const int s_end = min(s_begin + per, ksteps);
+    const int kper_blk = (ksteps + gridDim.z - 1) / gridDim.z;
+    const int b_begin = min((int)blockIdx.z * kper_blk, ksteps);
+    const int b_end = min(b_begin + kper_blk, ksteps);
+    const int per = (b_end - b_begin + kGemmWaves - 1) / kGemmWaves;
+    const int s_begin = min(b_begin + wave * per, b_end);
+    const int s_end = min(s_begin + per, b_end);
+    const int64_t slab = (int64_t)blockIdx.z * m * ldc;
 
-    acc_t acc[NT];
+    acc_t acc[RT][NT];
 #pragma unroll
-    for (int c = 0; c < NT; ++c) acc[c] = acc_t{0, 0, 0, 0};
+    for (int q = 0; q < RT; ++q)
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[q][c] = acc_t{0, 0, 0, 0};
 
     // clamp out-of-range rows/columns to a valid address and zero the value instead
-    const int arow = arow_ok ? row0 + r : 0;
-    int bcol[NT];
+    bool aok[RT];
+#pragma unroll
+    for (int q = 0; q < RT; ++q) aok[q] = (row0 + RT * r + q) < m;
+    const int arow = aok[0] ? row0 + RT * r : 0;
+    // the 16-byte A fetch needs both rows in range and an even element offset
+    const bool pair_ok = (RT == 2) && aok[RT - 1] && ((lda & 1) == 0);
+    const T *bptr[NT];      // column base of this lane's B element, per column tile
     bool bok[NT];
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
-        bok[c] = (c * 16 + r) < n;
-        bcol[c] = bok[c] ? c * 16 + r : 0;
+        const int j = c * 16 + r;
+        bok[c] = j < n;
+        const bool hi = j >= op.csplit;
+        bptr[c] = bok[c] ? (hi ? op.B1 + (j - op.csplit) : op.B + j) : op.B;
     }
 
+    auto load_a = [&](int64_t kidx, T (&out)[RT]) {
+        const T *p = op.At + kidx * lda + arow;
+        if constexpr (RT == 2) {
+            if (pair_ok) {
+                const vec2 v = *reinterpret_cast<const vec2 *>(p);
+                out[0] = v.x;
+                out[1] = v.y;
+            } else {
+                out[0] = p[0];
+                out[1] = aok[1] ? p[1] : T(0);
+            }
+        } else {
+            out[0] = p[0];
+        }
+    };
+
     int s = s_begin;
-    // full batches: every k index in range, loads issued ahead of the MFMAs
-    for (; s + kUnroll <= s_end && (s + kUnroll) * 4 <= k; s += kUnroll) {
-        T av[kUnroll], bv[kUnroll][NT];
+    // Full batches of kUnroll k-steps, software-pipelined with two register stages: the
+    // loads of batch b+1 are in flight while the MFMAs of batch b issue (the compiler's
+    // counted vmcnt waits release stage b without draining stage b+1).
+    const int nfull = (min(s_end, k >> 2) - s_begin) / kUnroll;   // batches with every k in range
+    T av[2][kUnroll][RT], bv[2][kUnroll][NT];
+    auto load_batch = [&](int st, int sb) {
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
-            const int64_t kidx = (int64_t)(s + u) * 4 + kk;
-            av[u] = op.At[kidx * lda + arow];
+            const int64_t kidx = (int64_t)(sb + u) * 4 + kk;
+            load_a(kidx, av[st][u]);
 #pragma unroll
-            for (int c = 0; c < NT; ++c) bv[u][c] = op.B[kidx * ldb + bcol[c]];
+            for (int c = 0; c < NT; ++c) bv[st][u][c] = bptr[c][kidx * ldb];
         }
+    };
+    auto mma_batch = [&](int st) {
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
-            const T a = arow_ok ? av[u] : T(0);
 #pragma unroll
-            for (int c = 0; c < NT; ++c) acc[c] = M::mma(a, bok[c] ? bv[u][c] : T(0), acc[c]);
+            for (int c = 0; c < NT; ++c) {
+                const T b = bok[c] ? bv[st][u][c] : T(0);
+#pragma unroll
+                for (int q = 0; q < RT; ++q)
+                    acc[q][c] = M::mma(aok[q] ? av[st][u][q] : T(0), b, acc[q][c]);
+            }
         }
+    };
+    if (nfull > 0) load_batch(0, s);
+    int bidx = 0;
+    for (; bidx + 2 <= nfull; bidx += 2) {
+        load_batch(1, s + kUnroll);
+        mma_batch(0);
+        if (bidx + 2 < nfull) load_batch(0, s + 2 * kUnroll);
+        mma_batch(1);
+        s += 2 * kUnroll;
+    }
+    if (bidx < nfull) {
+        mma_batch(0);
+        s += kUnroll;
     }
     // remainder (and the ragged last k-step)
     for (; s < s_end; ++s) {
         const int kidx = s * 4 + kk;
         const bool kok = kidx < k;
-        const int64_t kc = kok ? kidx : 0;
-        const T a = (kok && arow_ok) ? op.At[kc * lda + arow] : T(0);
+        T a[RT];
+        load_a(kok ? kidx : 0, a);
 #pragma unroll
         for (int c = 0; c < NT; ++c) {
-            const T b = (kok && bok[c]) ? op.B[kc * ldb + bcol[c]] : T(0);
-            acc[c] = M::mma(a, b, acc[c]);
+            const T b = (kok && bok[c]) ? bptr[c][(int64_t)kidx * ldb] : T(0);
+#pragma unroll
+            for (int q = 0; q < RT; ++q)
+                acc[q][c] = M::mma((kok && aok[q]) ? a[q] : T(0), b, acc[q][c]);
         }
     }
 
-    // fixed-order reduction of the 16 partial tiles, column tile c by wavefront c % 16
-    __shared__ T red[kGemmWaves][4][64];
+    // fixed-order reduction of the partial tiles, (row tile q, column tile c) by
+    // wavefront (q*NT + c) % kGemmWaves
+    __shared__ T red[kGemmWaves][RT][4][64];
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) red[wave][i][lane] = acc[c][i];
+        for (int q = 0; q < RT; ++q)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[wave][q][i][lane] = acc[q][c][i];
         __syncthreads();
-        if (wave == (c % kGemmWaves)) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                T v = red[0][i][lane];
+        for (int q = 0; q < RT; ++q) {
+            if (wave == ((q * NT + c) % kGemmWaves)) {
 #pragma unroll
-                for (int w = 1; w < kGemmWaves; ++w) v += red[w][i][lane];
-                const int orow = row0 + M::row(lane, i);
-                const int ocol = c * 16 + (lane & 15);
-                if (orow < m && ocol < n) {
-                    T *cp = op.C + (int64_t)orow * ldc + ocol;
-                    *cp = accumulate ? (*cp + v) : v;
+                for (int i = 0; i < 4; ++i) {
+                    T v = red[0][q][i][lane];
+#pragma unroll
+                    for (int w = 1; w < kGemmWaves; ++w) v += red[w][q][i][lane];
+                    const int orow = row0 + RT * M::row(lane, i) + q;
+                    const int ocol = c * 16 + (lane & 15);
+                    if (orow < m && ocol < n) {
+                        const bool hi = ocol >= op.csplit;
+                        T *cp = (hi ? op.C1 + (ocol - op.csplit) : op.C + ocol) + slab +
+                                (int64_t)orow * ldc;
+                        *cp = accumulate ? (*cp + v) : v;
+                    }
                 }
             }
         }
@@ -151,25 +230,30 @@ __global__ __launch_bounds__(kGemmWaves * 64) void gemm_tn_kernel(
 }
 
 template <typename T>
-static int launch_gemm(int m, int n, int k, int nbatch, const GemmBatch<T> &b, int lda, int ldb,
-                       int ldc, int accumulate, void *stream, const char *what) {
+static int launch_gemm(int m, int n, int k, int nbatch, int ksplit, const GemmBatch<T> &b,
+                       int lda, int ldb, int ldc, int accumulate, void *stream,
+                       const char *what) {
     REVS_REQUIRE(m > 0 && n > 0 && k > 0, "%s: m=%d n=%d k=%d", what, m, n, k);
     REVS_REQUIRE(n <= 192, "%s: n=%d exceeds 192 columns", what, n);
+    REVS_REQUIRE(ksplit >= 1 && ksplit <= 8, "%s: ksplit=%d", what, ksplit);
+    REVS_REQUIRE(ksplit == 1 || !accumulate, "%s: accumulate with ksplit", what);
     for (int i = 0; i < nbatch; ++i)
         REVS_REQUIRE(b.op[i].At && b.op[i].B && b.op[i].C, "%s: null pointer argument", what);
-    REVS_REQUIRE(lda >= m && ldb >= n && ldc >= n, "%s: leading dimension too small", what);
-    const dim3 grid((m + 15) / 16, nbatch);
+    REVS_REQUIRE(lda >= m && ldb >= b.op[0].csplit && ldc >= b.op[0].csplit,
+                 "%s: leading dimension too small", what);
     const int nt = (n + 15) / 16;
     hipStream_t s = (hipStream_t)stream;
-#define LAUNCH(NT, W, U)                                                                   \
-    hipLaunchKernelGGL((gemm_tn_kernel<T, NT, W, U>), grid, dim3(W * 64), 0, s, m, n, k, b, lda, \
-                       ldb, ldc, accumulate)
-    if (nt <= 1) LAUNCH(1, 16, 8);
-    else if (nt <= 2) LAUNCH(2, 16, 8);
-    else if (nt <= 4) LAUNCH(4, 8, 4);
-    else if (nt <= 6) LAUNCH(6, 8, 4);
-    else if (nt <= 8) LAUNCH(8, 8, 2);
-    else LAUNCH(12, 8, 2);
+#define LAUNCH(NT, RT, W, U)                                                                   \
+    hipLaunchKernelGGL((gemm_tn_kernel<T, NT, RT, W, U>),                                      \
+                       dim3((m + 16 * RT - 1) / (16 * RT), nbatch, ksplit), dim3(W * 64), 0, s, \
+                       m, n, k, b, lda, ldb, ldc, accumulate)
+    if (nt <= 1) LAUNCH(1, 2, 16, 4);
+    else if (nt <= 2) LAUNCH(2, 2, 16, 4);
+    else if (nt <= 3) LAUNCH(3, 2, 16, 2);
+    else if (nt <= 4) LAUNCH(4, 1, 8, 2);
+    else if (nt <= 6) LAUNCH(6, 1, 8, 2);
+    else if (nt <= 8) LAUNCH(8, 1, 8, 1);
+    else LAUNCH(12, 1, 8, 1);
 #undef LAUNCH
     REVS_CHECK_LAUNCH(what);
     return REVS_OK;
@@ -182,26 +266,37 @@ using namespace revs;
 extern "C" int revs_gemm_tn_f64(int32_t m, int32_t n, int32_t k, const double *At, int32_t lda,
                                 const double *B, int32_t ldb, double *C, int32_t ldc,
                                 int32_t accumulate, void *stream) {
-    GemmBatch<double> b{{{At, B, C}, {nullptr, nullptr, nullptr}}};
-    return launch_gemm<double>(m, n, k, 1, b, lda, ldb, ldc, accumulate, stream, "revs_gemm_tn_f64");
+    GemmBatch<double> b{{{At, B, C, nullptr, nullptr, n}, {}}};
+    return launch_gemm<double>(m, n, k, 1, 1, b, lda, ldb, ldc, accumulate, stream,
+                               "revs_gemm_tn_f64");
 }
 
 extern "C" int revs_gemm_tn_f64_x2(int32_t m, int32_t n, int32_t k, const double *At0,
                                    const double *B0, double *C0, const double *At1,
-                                   const double *B1, double *C1, void *stream) {
-    GemmBatch<double> b{{{At0, B0, C0}, {At1, B1, C1}}};
-    return launch_gemm<double>(m, n, k, 2, b, m, n, n, 0, stream, "revs_gemm_tn_f64_x2");
+                                   const double *B1, double *C1, int32_t ksplit, void *stream) {
+    GemmBatch<double> b{{{At0, B0, C0, nullptr, nullptr, n}, {At1, B1, C1, nullptr, nullptr, n}}};
+    return launch_gemm<double>(m, n, k, 2, ksplit, b, m, n, n, 0, stream, "revs_gemm_tn_f64_x2");
+}
+
+extern "C" int revs_gemm_tn_f64_cat(int32_t m, int32_t T, int32_t k, const double *At,
+                                    const double *B0, const double *B1, double *C0, double *C1,
+                                    int32_t ksplit, void *stream) {
+    REVS_REQUIRE(B1 && C1, "revs_gemm_tn_f64_cat: null pointer argument");
+    GemmBatch<double> b{{{At, B0, C0, B1, C1, T}, {}}};
+    return launch_gemm<double>(m, 2 * T, k, 1, ksplit, b, m, T, T, 0, stream,
+                               "revs_gemm_tn_f64_cat");
 }
 
 extern "C" int revs_gemm_tn_f32(int32_t m, int32_t n, int32_t k, const float *At, int32_t lda,
                                 const float *B, int32_t ldb, float *C, int32_t ldc,
                                 int32_t accumulate, void *stream) {
-    GemmBatch<float> b{{{At, B, C}, {nullptr, nullptr, nullptr}}};
-    return launch_gemm<float>(m, n, k, 1, b, lda, ldb, ldc, accumulate, stream, "revs_gemm_tn_f32");
+    GemmBatch<float> b{{{At, B, C, nullptr, nullptr, n}, {}}};
+    return launch_gemm<float>(m, n, k, 1, 1, b, lda, ldb, ldc, accumulate, stream,
+                              "revs_gemm_tn_f32");
 }
 
 extern "C" int revs_voltage_f32(int32_t m, int32_t T, const float *Rt, const float *P, float *V,
                                 void *stream) {
-    GemmBatch<float> b{{{Rt, P, V}, {nullptr, nullptr, nullptr}}};
-    return launch_gemm<float>(m, T, m, 1, b, m, T, T, 0, stream, "revs_voltage_f32");
+    GemmBatch<float> b{{{Rt, P, V, nullptr, nullptr, T}, {}}};
+    return launch_gemm<float>(m, T, m, 1, 1, b, m, T, T, 0, stream, "revs_voltage_f32");
 }

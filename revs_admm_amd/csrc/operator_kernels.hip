@@ -16,6 +16,12 @@
 // With homes sharded over GPUs the only exchange is the all-reduce of rhat
 // (m x T doubles) between the home pass and the GEMMs.
 //
+// State kept per home and slot is ONE double: s_b = z_b + y_b.  The bound rows'
+// z_b = max(u,0) and y_b = rho_b min(u,0) are complementary (one of them is zero), so
+// z_b = max(s_b,0), y_b = min(s_b,0) decode it exactly; sigma = 0 and Boyd-style
+// over-relaxation (z/y use alpha xt + (1-alpha) z, x itself is not stored) remove the
+// x array.  The home pass therefore moves 3 arrays (read s_b, g0; write s_b), not 7.
+//
 // All arrays are [rows][T] row-major doubles; one thread per (row, slot).
 #include "common.h"
 
@@ -34,21 +40,20 @@ __global__ void op_g0_kernel(int64_t total, const float *pe, const float *ps, co
     if (i < total) g0[i] = 0.5 * ((double)pe[i] + (double)ps[i]) - (double)gm[i] / kappa;
 }
 
-// cold start: x = z_b = max(g0, 0), y_b = 0
-__global__ void op_init_home_kernel(int64_t total, const double *g0, double *x, double *zb,
-                                    double *yb) {
+// cold start: s_b = max(g0, 0)  (z_b = that, y_b = 0)
+__global__ void op_init_home_kernel(int64_t total, const double *g0, double *sb) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total) {
-        const double v = fmax(g0[i], 0.0);
-        x[i] = v; zb[i] = v; yb[i] = 0.0;
-    }
+    if (i < total) sb[i] = fmax(g0[i], 0.0);
 }
 // cold start, node side: z_v = clip(Cx), y_v = 0, w = rho_v z_v
+// (row m of the voltage block is scaled by bscale[m] = sqrt(n_m), and so are its bounds)
 __global__ void op_init_node_kernel(int total, int T, const double *cx, const double *rho_v,
-                                    double vlo, double vhi, double *zv, double *yv, double *w) {
+                                    const double *bscale, double vlo, double vhi, double *zv,
+                                    double *yv, double *w) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < total) {
-        const double z = fmin(fmax(cx[i], vlo), vhi);
+        const double bs = bscale ? bscale[i / T] : 1.0;
+        const double z = fmin(fmax(cx[i], bs * vlo), bs * vhi);
         zv[i] = z; yv[i] = 0.0; w[i] = rho_v[i % T] * z;
     }
 }
@@ -65,42 +70,93 @@ __global__ void aggregate_kernel(int m, int Ts, const int64_t *node_ptr, const T
     out[idx] = scale ? scale[node] * acc : acc;
 }
 
-// Home pass.  For node m, slot t (c = kappa + sigma + rho_b[t]):
-//   if xc:  rhs  = sigma x + kappa g0 + rho_b z_b - y_b          (state before update)
-//           xt   = rhs / c + inv_sqrt_n[m] xc[m]
-//           x    = alpha xt + (1-alpha) x
-//           h    = alpha xt + (1-alpha) z_b
-//           z_b  = max(h + y_b / rho_b, 0);   y_b += rho_b (h - z_b)
-//   rhat[m] = inv_sqrt_n[m] * sum_homes (sigma x + kappa g0 + rho_b z_b - y_b)   (new state)
+// Home pass.  For node m, slot t (c = kappa + rho_b[t]), every home of the node:
+//   z = max(s_b,0), y = min(s_b,0)
+//   if xc:  rhs = kappa g0 + rho_b z - y                 (state before the update)
+//           xt  = rhs / c + inv_sqrt_n[m] xc[m]          (the x-update of ADMM)
+//           h   = alpha xt + (1-alpha) z ;  u = h + y / rho_b
+//           z   = max(u,0) ;  y = rho_b min(u,0) ;  s_b = z + y
+//           if res: per-slot maxima of |xt - z|, |kappa (xt - g0) + isn cty[m] + y|,
+//                   |xt|, |isn cty[m] + y|, |kappa g0|  -> res rows 1,2,5,6,7
+//   rhat[m] = inv_sqrt_n[m] * sum_homes (kappa g0 + rho_b z - y)        (new state)
+//
+// Mapping: one 256-thread workgroup per node; TL = pow2 >= T lanes walk the slots
+// (contiguous doubles of one home), HS = 256/TL "home lanes" stride over the node's
+// homes, so a node with 49 homes keeps 8 loads per array in flight per slot lane instead
+// of one; the HS partial sums are combined through LDS in a fixed order (reproducible).
+template <int TL>
 __global__ __launch_bounds__(256) void op_home_pass_kernel(
-        int m, int T, const int64_t *node_ptr, const double *inv_sqrt_n, double *x, double *zb,
-        double *yb, const double *g0, const double *xc, const double *rho_b, double kappa,
-        double sigma, double alpha, double *rhat) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= m * T) return;
-    const int node = idx / T, t = idx - node * T;
-    const double rb = rho_b[t];
-    const double c = kappa + sigma + rb;
+        int m, int T, const int64_t *__restrict__ node_ptr, const double *__restrict__ inv_sqrt_n,
+        double *__restrict__ sb, const double *__restrict__ g0, const double *__restrict__ xc,
+        const double *__restrict__ rho_b, double kappa, double alpha, double *__restrict__ rhat,
+        const double *__restrict__ cty, double *__restrict__ res) {
+    constexpr int HS = 256 / TL;
+    const int node = blockIdx.x;
+    const int t = threadIdx.x % TL, hs = threadIdx.x / TL;
+    const bool tok = t < T;
+    const int tc = tok ? t : 0;
+    const int idx = node * T + tc;
+    const double rb = rho_b[tc];
+    const double inv_c = 1.0 / (kappa + rb), inv_rb = 1.0 / rb;
     const double isn = inv_sqrt_n[node];
     const double corr = xc ? isn * xc[idx] : 0.0;
-    double acc = 0.0;
-    for (int64_t i = node_ptr[node]; i < node_ptr[node + 1]; ++i) {
-        const int64_t o = i * T + t;
-        double xv = x[o], zv = zb[o], yv = yb[o];
-        const double kg = kappa * g0[o];
-        if (xc) {
-            const double rhs = sigma * xv + kg + rb * zv - yv;
-            const double xt = rhs / c + corr;
-            xv = alpha * xt + (1.0 - alpha) * xv;
-            const double h = alpha * xt + (1.0 - alpha) * zv;
-            const double zn = fmax(h + yv / rb, 0.0);
-            yv += rb * (h - zn);
-            zv = zn;
-            x[o] = xv; zb[o] = zv; yb[o] = yv;
+    const double ct = res ? isn * cty[idx] : 0.0;
+    double acc = 0.0, r1 = 0, r2 = 0, r5 = 0, r6 = 0, r7 = 0;
+    const int64_t i0 = node_ptr[node], i1 = node_ptr[node + 1];
+    if (tok) {
+        for (int64_t i = i0 + hs; i < i1; i += HS) {
+            const int64_t o = i * T + t;
+            const double sv = sb[o];
+            const double kg = kappa * g0[o];
+            double z = fmax(sv, 0.0), y = fmin(sv, 0.0);
+            if (xc) {
+                const double xt = (kg + rb * z - y) * inv_c + corr;
+                const double u = alpha * xt + (1.0 - alpha) * z + y * inv_rb;
+                z = fmax(u, 0.0);
+                y = rb * fmin(u, 0.0);
+                sb[o] = z + y;
+                if (res) {
+                    const double cy = ct + y;
+                    r1 = fmax(r1, fabs(xt - z));
+                    r2 = fmax(r2, fabs(kappa * xt - kg + cy));
+                    r5 = fmax(r5, fabs(xt));
+                    r6 = fmax(r6, fabs(cy));
+                    r7 = fmax(r7, fabs(kg));
+                }
+            }
+            acc += kg + rb * z - y;
         }
-        acc += sigma * xv + kg + rb * zv - yv;
     }
-    rhat[idx] = isn * acc;
+    __shared__ double red[6][HS][TL];
+    red[0][hs][t] = acc;
+    if (res) { red[1][hs][t] = r1; red[2][hs][t] = r2; red[3][hs][t] = r5; red[4][hs][t] = r6; red[5][hs][t] = r7; }
+    __syncthreads();
+    if (hs == 0 && tok) {
+        double a = red[0][0][t];
+#pragma unroll
+        for (int k = 1; k < HS; ++k) a += red[0][k][t];
+        rhat[idx] = isn * a;
+        if (res && xc) {
+            double q1 = 0, q2 = 0, q5 = 0, q6 = 0, q7 = 0;
+#pragma unroll
+            for (int k = 0; k < HS; ++k) {
+                q1 = fmax(q1, red[1][k][t]); q2 = fmax(q2, red[2][k][t]); q5 = fmax(q5, red[3][k][t]);
+                q6 = fmax(q6, red[4][k][t]); q7 = fmax(q7, red[5][k][t]);
+            }
+            atomic_max_nonneg(res + 1 * T + t, q1);
+            atomic_max_nonneg(res + 2 * T + t, q2);
+            atomic_max_nonneg(res + 5 * T + t, q5);
+            atomic_max_nonneg(res + 6 * T + t, q6);
+            atomic_max_nonneg(res + 7 * T + t, q7);
+        }
+    }
+}
+
+// out = s (row scale) * in
+__global__ void op_row_scale_kernel(int total, int T, const double *s, const double *in,
+                                    double *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total) out[i] = s[i / T] * in[i];
 }
 
 // w = rho_v z_v - y_v
@@ -111,80 +167,57 @@ __global__ void op_node_w_kernel(int total, int T, const double *zv, const doubl
 }
 
 // t1 = ta + s tb ;  a = t1 / (c + rho_v s^2) ;  sa = s a        (row j <-> singular value s_j)
-__global__ void op_node_scale_kernel(int total, int T, const double *ta, const double *tb,
-                                     const double *s, const double *rho_v, const double *rho_b,
-                                     double kappa, double sigma, double *a, double *sa) {
+// ta, tb arrive as `nslab` K-split partial products (slab stride = total): summed here
+__global__ void op_node_scale_kernel(int total, int T, int nslab, const double *ta,
+                                     const double *tb, const double *s, const double *rho_v,
+                                     const double *rho_b, double kappa, double *a, double *sa) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int j = i / T, t = i - j * T;
     const double sj = s[j];
-    const double c = kappa + sigma + rho_b[t];
-    const double av = (ta[i] + sj * tb[i]) / (c + rho_v[t] * sj * sj);
+    const double c = kappa + rho_b[t];
+    double tav = ta[i], tbv = tb[i];
+    for (int q = 1; q < nslab; ++q) { tav += ta[i + (int64_t)q * total]; tbv += tb[i + (int64_t)q * total]; }
+    const double av = (tav + sj * tbv) / (c + rho_v[t] * sj * sj);
     a[i] = av;
     sa[i] = sj * av;
 }
 
 // xc = va - rhat / c ;  h = alpha usa + (1-alpha) z_v ;  z_v = clip(h + y_v/rho_v) ;
-// y_v += rho_v (h - z_v) ;  cx = alpha usa + (1-alpha) cx ;  w = rho_v z_v - y_v
-__global__ void op_node_update_kernel(int total, int T, const double *va, const double *rhat,
-                                      const double *usa, const double *rho_v,
-                                      const double *rho_b, double kappa, double sigma,
+// y_v += rho_v (h - z_v) ;  w = rho_v z_v - y_v ;  usa = C_v xt.
+// if res: per-slot maxima |usa - z_v|, |usa|, |z_v| -> res rows 0, 3, 4
+__global__ void op_node_update_kernel(int total, int T, int nslab, const double *va,
+                                      const double *rhat, const double *usa, const double *rho_v,
+                                      const double *rho_b, const double *bscale, double kappa,
                                       double alpha, double vlo, double vhi, double *xc,
-                                      double *zv, double *yv, double *cx, double *w) {
+                                      double *zv, double *yv, double *w, double *res) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const int t = i % T;
     const double rv = rho_v[t];
-    const double c = kappa + sigma + rho_b[t];
-    xc[i] = va[i] - rhat[i] / c;
-    const double zt = usa[i];
-    const double zo = zv[i];
-    const double h = alpha * zt + (1.0 - alpha) * zo;
+    const double c = kappa + rho_b[t];
+    double vav = va[i], zt = usa[i];
+    for (int q = 1; q < nslab; ++q) { vav += va[i + (int64_t)q * total]; zt += usa[i + (int64_t)q * total]; }
+    xc[i] = vav - rhat[i] / c;
+    const double h = alpha * zt + (1.0 - alpha) * zv[i];
     double y = yv[i];
-    const double zn = fmin(fmax(h + y / rv, vlo), vhi);
+    const double bs = bscale ? bscale[i / T] : 1.0;
+    const double zn = fmin(fmax(h + y / rv, bs * vlo), bs * vhi);
     y += rv * (h - zn);
     zv[i] = zn;
     yv[i] = y;
-    cx[i] = alpha * zt + (1.0 - alpha) * cx[i];
     w[i] = rv * zn - y;
-}
-
-// Per-slot residual maxima (out[8][T], zeroed by the caller, all entries >= 0):
-//  0 max_m |cx - z_v|     1 max_i |x - z_b|     2 max_i |kappa (x - g0) + isn cty[m] + y_b|
-//  3 max_m |cx|           4 max_m |z_v|         5 max_i |x|
-//  6 max_i |isn cty[m] + y_b|                   7 max_i |kappa g0|
-__global__ __launch_bounds__(256) void op_residuals_kernel(
-        int m, int T, const int64_t *node_ptr, const double *inv_sqrt_n, const double *x,
-        const double *zb, const double *yb, const double *g0, const double *cty,
-        const double *cx, const double *zv, double kappa, double *out) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= m * T) return;
-    const int node = idx / T, t = idx - node * T;
-    const double ct = inv_sqrt_n[node] * cty[idx];
-    double r1 = 0, r2 = 0, r5 = 0, r6 = 0, r7 = 0;
-    for (int64_t i = node_ptr[node]; i < node_ptr[node + 1]; ++i) {
-        const int64_t o = i * T + t;
-        const double xv = x[o], gv = g0[o];
-        const double cy = ct + yb[o];
-        r1 = fmax(r1, fabs(xv - zb[o]));
-        r2 = fmax(r2, fabs(kappa * (xv - gv) + cy));
-        r5 = fmax(r5, fabs(xv));
-        r6 = fmax(r6, fabs(cy));
-        r7 = fmax(r7, fabs(kappa * gv));
+    if (res) {
+        atomic_max_nonneg(res + 0 * T + t, fabs(zt - zn));
+        atomic_max_nonneg(res + 3 * T + t, fabs(zt));
+        atomic_max_nonneg(res + 4 * T + t, fabs(zn));
     }
-    atomic_max_nonneg(out + 0 * T + t, fabs(cx[idx] - zv[idx]));
-    atomic_max_nonneg(out + 1 * T + t, r1);
-    atomic_max_nonneg(out + 2 * T + t, r2);
-    atomic_max_nonneg(out + 3 * T + t, fabs(cx[idx]));
-    atomic_max_nonneg(out + 4 * T + t, fabs(zv[idx]));
-    atomic_max_nonneg(out + 5 * T + t, r5);
-    atomic_max_nonneg(out + 6 * T + t, r6);
-    atomic_max_nonneg(out + 7 * T + t, r7);
 }
 
-__global__ void op_export_kernel(int64_t total, const double *zb, float *pe) {
+// P_est = z_b = max(s_b, 0), as float
+__global__ void op_export_kernel(int64_t total, const double *sb, float *pe) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total) pe[i] = (float)zb[i];
+    if (i < total) pe[i] = (float)fmax(sb[i], 0.0);
 }
 
 static inline dim3 grid1(int64_t total) { return dim3((unsigned)((total + 255) / 256)); }
@@ -205,22 +238,21 @@ extern "C" int revs_op_g0(int64_t n_homes, int32_t T, const float *p_est, const 
     return REVS_OK;
 }
 
-extern "C" int revs_op_init_home(int64_t n_homes, int32_t T, const double *g0, double *x,
-                                 double *zb, double *yb, void *stream) {
-    REVS_REQUIRE(n_homes > 0 && T > 0 && g0 && x && zb && yb, "revs_op_init_home: bad argument");
+extern "C" int revs_op_init_home(int64_t n_homes, int32_t T, const double *g0, double *sb,
+                                 void *stream) {
+    REVS_REQUIRE(n_homes > 0 && T > 0 && g0 && sb, "revs_op_init_home: bad argument");
     const int64_t total = n_homes * T;
-    hipLaunchKernelGGL(op_init_home_kernel, grid1(total), dim3(256), 0, S_(stream), total, g0, x,
-                       zb, yb);
+    hipLaunchKernelGGL(op_init_home_kernel, grid1(total), dim3(256), 0, S_(stream), total, g0, sb);
     REVS_CHECK_LAUNCH("revs_op_init_home");
     return REVS_OK;
 }
 
 extern "C" int revs_op_init_node(int32_t m, int32_t T, const double *cx, const double *rho_v,
-                                 double vlo, double vhi, double *zv, double *yv, double *w,
-                                 void *stream) {
+                                 const double *bound_scale, double vlo, double vhi, double *zv,
+                                 double *yv, double *w, void *stream) {
     REVS_REQUIRE(m > 0 && T > 0 && cx && rho_v && zv && yv && w, "revs_op_init_node: bad argument");
     hipLaunchKernelGGL(op_init_node_kernel, grid1((int64_t)m * T), dim3(256), 0, S_(stream),
-                       m * T, T, cx, rho_v, vlo, vhi, zv, yv, w);
+                       m * T, T, cx, rho_v, bound_scale, vlo, vhi, zv, yv, w);
     REVS_CHECK_LAUNCH("revs_op_init_node");
     return REVS_OK;
 }
@@ -245,15 +277,32 @@ extern "C" int revs_aggregate_f32(int32_t m, int32_t T, const int64_t *node_ptr,
 }
 
 extern "C" int revs_op_home_pass(int32_t m, int32_t T, const int64_t *node_ptr,
-                                 const double *inv_sqrt_n, double *x, double *zb, double *yb,
-                                 const double *g0, const double *xc, const double *rho_b,
-                                 double kappa, double sigma, double alpha, double *rhat,
-                                 void *stream) {
-    REVS_REQUIRE(m > 0 && T > 0 && node_ptr && inv_sqrt_n && x && zb && yb && g0 && rho_b && rhat,
+                                 const double *inv_sqrt_n, double *sb, const double *g0,
+                                 const double *xc, const double *rho_b, double kappa,
+                                 double alpha, double *rhat, const double *cty_node,
+                                 double *res, void *stream) {
+    REVS_REQUIRE(m > 0 && T > 0 && node_ptr && inv_sqrt_n && sb && g0 && rho_b && rhat,
                  "revs_op_home_pass: bad argument");
-    hipLaunchKernelGGL(op_home_pass_kernel, grid1((int64_t)m * T), dim3(256), 0, S_(stream), m, T,
-                       node_ptr, inv_sqrt_n, x, zb, yb, g0, xc, rho_b, kappa, sigma, alpha, rhat);
+    REVS_REQUIRE(!res || (cty_node && xc), "revs_op_home_pass: res needs cty_node and xc");
+    REVS_REQUIRE(T <= 256, "revs_op_home_pass: T=%d exceeds 256", T);
+#define HP(TL)                                                                                  \
+    hipLaunchKernelGGL((op_home_pass_kernel<TL>), dim3(m), dim3(256), 0, S_(stream), m, T,      \
+                       node_ptr, inv_sqrt_n, sb, g0, xc, rho_b, kappa, alpha, rhat, cty_node, res)
+    if (T <= 32) HP(32);
+    else if (T <= 64) HP(64);
+    else if (T <= 128) HP(128);
+    else HP(256);
+#undef HP
     REVS_CHECK_LAUNCH("revs_op_home_pass");
+    return REVS_OK;
+}
+
+extern "C" int revs_op_row_scale(int32_t m, int32_t T, const double *s, const double *in,
+                                 double *out, void *stream) {
+    REVS_REQUIRE(m > 0 && T > 0 && s && in && out, "revs_op_row_scale: bad argument");
+    hipLaunchKernelGGL(op_row_scale_kernel, grid1((int64_t)m * T), dim3(256), 0, S_(stream),
+                       m * T, T, s, in, out);
+    REVS_CHECK_LAUNCH("revs_op_row_scale");
     return REVS_OK;
 }
 
@@ -266,51 +315,39 @@ extern "C" int revs_op_node_w(int32_t m, int32_t T, const double *zv, const doub
     return REVS_OK;
 }
 
-extern "C" int revs_op_node_scale(int32_t m, int32_t T, const double *ta, const double *tb,
-                                  const double *s, const double *rho_v, const double *rho_b,
-                                  double kappa, double sigma, double *a, double *sa,
+extern "C" int revs_op_node_scale(int32_t m, int32_t T, int32_t nslab, const double *ta,
+                                  const double *tb, const double *s, const double *rho_v,
+                                  const double *rho_b, double kappa, double *a, double *sa,
                                   void *stream) {
-    REVS_REQUIRE(m > 0 && T > 0 && ta && tb && s && rho_v && rho_b && a && sa,
+    REVS_REQUIRE(m > 0 && T > 0 && nslab >= 1 && ta && tb && s && rho_v && rho_b && a && sa,
                  "revs_op_node_scale: bad argument");
     hipLaunchKernelGGL(op_node_scale_kernel, grid1((int64_t)m * T), dim3(256), 0, S_(stream),
-                       m * T, T, ta, tb, s, rho_v, rho_b, kappa, sigma, a, sa);
+                       m * T, T, nslab, ta, tb, s, rho_v, rho_b, kappa, a, sa);
     REVS_CHECK_LAUNCH("revs_op_node_scale");
     return REVS_OK;
 }
 
-extern "C" int revs_op_node_update(int32_t m, int32_t T, const double *va, const double *rhat,
-                                   const double *usa, const double *rho_v, const double *rho_b,
-                                   double kappa, double sigma, double alpha, double vlo,
-                                   double vhi, double *xc, double *zv, double *yv, double *cx,
-                                   double *w, void *stream) {
-    REVS_REQUIRE(m > 0 && T > 0 && va && rhat && usa && rho_v && rho_b && xc && zv && yv && cx && w,
-                 "revs_op_node_update: bad argument");
+extern "C" int revs_op_node_update(int32_t m, int32_t T, int32_t nslab, const double *va,
+                                   const double *rhat, const double *usa, const double *rho_v,
+                                   const double *rho_b, const double *bound_scale,
+                                   double kappa, double alpha, double vlo, double vhi,
+                                   double *xc, double *zv, double *yv, double *w, double *res,
+                                   void *stream) {
+    REVS_REQUIRE(m > 0 && T > 0 && nslab >= 1 && va && rhat && usa && rho_v && rho_b && xc && zv &&
+                 yv && w, "revs_op_node_update: bad argument");
     REVS_REQUIRE(vlo <= vhi, "revs_op_node_update: vlo > vhi");
     hipLaunchKernelGGL(op_node_update_kernel, grid1((int64_t)m * T), dim3(256), 0, S_(stream),
-                       m * T, T, va, rhat, usa, rho_v, rho_b, kappa, sigma, alpha, vlo, vhi, xc,
-                       zv, yv, cx, w);
+                       m * T, T, nslab, va, rhat, usa, rho_v, rho_b, bound_scale, kappa, alpha, vlo,
+                       vhi, xc, zv, yv, w, res);
     REVS_CHECK_LAUNCH("revs_op_node_update");
     return REVS_OK;
 }
 
-extern "C" int revs_op_residuals(int32_t m, int32_t T, const int64_t *node_ptr,
-                                 const double *inv_sqrt_n, const double *x, const double *zb,
-                                 const double *yb, const double *g0, const double *cty_node,
-                                 const double *cx, const double *zv, double kappa, double *out,
-                                 void *stream) {
-    REVS_REQUIRE(m > 0 && T > 0 && node_ptr && inv_sqrt_n && x && zb && yb && g0 && cty_node &&
-                 cx && zv && out, "revs_op_residuals: bad argument");
-    hipLaunchKernelGGL(op_residuals_kernel, grid1((int64_t)m * T), dim3(256), 0, S_(stream), m, T,
-                       node_ptr, inv_sqrt_n, x, zb, yb, g0, cty_node, cx, zv, kappa, out);
-    REVS_CHECK_LAUNCH("revs_op_residuals");
-    return REVS_OK;
-}
-
-extern "C" int revs_op_export(int64_t n_homes, int32_t T, const double *zb, float *p_est,
+extern "C" int revs_op_export(int64_t n_homes, int32_t T, const double *sb, float *p_est,
                               void *stream) {
-    REVS_REQUIRE(n_homes > 0 && T > 0 && zb && p_est, "revs_op_export: bad argument");
+    REVS_REQUIRE(n_homes > 0 && T > 0 && sb && p_est, "revs_op_export: bad argument");
     const int64_t total = n_homes * T;
-    hipLaunchKernelGGL(op_export_kernel, grid1(total), dim3(256), 0, S_(stream), total, zb, p_est);
+    hipLaunchKernelGGL(op_export_kernel, grid1(total), dim3(256), 0, S_(stream), total, sb, p_est);
     REVS_CHECK_LAUNCH("revs_op_export");
     return REVS_OK;
 }

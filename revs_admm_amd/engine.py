@@ -63,11 +63,17 @@ class OperatorOptions:
     check_every: int = 25
     adapt_every: int = 100
     alpha: float = 1.6
-    sigma: float = 1e-6
     rho_b_scale: float = 1.0     # rho_b = scale * kappa
     rho_v_scale: float = 25.0    # rho_v = scale * kappa / smax^2
     warm_start: bool = True
     use_graph: bool = True       # replay a hipGraph of `check_every` inner iterations (1 GPU)
+    # The best rho depends strongly on how hard the voltage rows bind (x100 between the
+    # 121144 feeder and a mildly stressed one), and re-tuning on the fly costs iterations.
+    # So the first non-trivial solve tries each (rho_v, rho_b) scale below for two blocks
+    # from the same state and keeps the one with the smallest residual.
+    calibrate: bool = True
+    cal_rho_v: tuple = (0.1, 1.0, 10.0, 100.0)
+    cal_rho_b: tuple = (0.1, 1.0)
 
 
 def _dev_check(device):
@@ -93,7 +99,7 @@ class AdmmEngine:
     def __init__(self, cost, homes, load, node_of, Rn, kappa=5.0, vset=1.0, vlow=0.95,
                  vhigh=1.05, mode="binary", device="cuda:0", pdhg=None,
                  op: OperatorOptions | None = None, group=None, node_counts=None,
-                 _kernels=None):
+                 pdhg_warm=True, _kernels=None):
         if _kernels is None:
             self.lib = _lib.load()               # raises when the HIP library is missing
             self.dev = _dev_check(device)        # raises without a GPU
@@ -153,31 +159,46 @@ class AdmmEngine:
         self.n_part = int(self.lib.revs_agent_num_partials(n, T))
         self.partials = torch.zeros(3 * self.n_part, **f32)
         self.resid = torch.zeros(4, **f32)
+        # PDHG multipliers carried across ADMM iterations (warm start), relaxed PDHG only
+        self.pdhg_dual = (torch.zeros(n, T, **f32)
+                          if self.mode == _lib.MODE_RELAXED_PDHG and pdhg_warm else None)
         self.pdhg = PDHG()
         self.lib.revs_pdhg_defaults(C.byref(self.pdhg))
         if pdhg:
             for k, v in pdhg.items():
                 setattr(self.pdhg, k, v)
 
-        # ---- operator setup (host, double): R' = R diag(sqrt(n_m)) = U S V^T ----
+        # ---- operator setup (host, double) ----
+        # Voltage row m is scaled by sqrt(n_m) (bounds too), so the operator matrix
+        # D^1/2 R D^1/2 is symmetric PSD = Q L Q^T: one factor serves C_v and C_v^T.
+        # Nodes without residences get a zero row: voltage is constrained where
+        # residences are, as in the reference (R_res, lpsolver.py:188-189).
         sq = np.sqrt(counts.astype(np.float64))
-        U, s, Vt = np.linalg.svd(Rn * sq[None, :])
-        self.smax = float(s.max())
-        self.U, self.UT = up(U), up(U.T)
-        self.V, self.VT = up(Vt.T), up(Vt)
-        self.s = up(s)
+        lam, Q = np.linalg.eigh(sq[:, None] * Rn * sq[None, :])
+        lam = np.maximum(lam, 0.0)
+        self.smax = float(lam.max())
+        self.Q, self.QT = up(Q), up(Q.T)
+        self.s = up(lam)
+        self.sqrt_n = up(sq)
         self.inv_sqrt_n = up(np.where(counts > 0, 1.0 / np.maximum(sq, 1e-300), 0.0))
         self.g0 = torch.zeros(n, T, **f64)
-        self.x = torch.zeros(n, T, **f64)
-        self.zb = torch.zeros(n, T, **f64)
-        self.yb = torch.zeros(n, T, **f64)
+        self.sb = torch.zeros(n, T, **f64)             # z_b + y_b of the g >= 0 rows
         nz = lambda: torch.zeros(M, T, **f64)
-        (self.zv, self.yv, self.cx, self.w, self.rhat, self.xc, self.ta, self.tb, self.a,
-         self.sa, self.va, self.usa, self.cty) = (nz() for _ in range(13))
+        (self.zv, self.yv, self.cx, self.w, self.rhat, self.xc, self.a, self.sa,
+         self.cty) = (nz() for _ in range(9))
+        # GEMM outputs come as K-split partial slabs (summed by the node kernels): enough
+        # workgroups to fill 256 CUs even when M/32 row tiles x 2 products is below that
+        self.cat = 2 * T <= 192                        # [rhat | w] in one product
+        ncol = 2 * T if self.cat else T
+        tiles = ((M + 31) // 32 if ncol <= 48 else (M + 15) // 16) * (1 if self.cat else 2)
+        self.ksplit = int(min(8, max(1, -(-256 // tiles))))
+        nzs = lambda: torch.zeros(self.ksplit, M, T, **f64)
+        self.ta, self.tb, self.va, self.usa = nzs(), nzs(), nzs(), nzs()
         self.rho_v = torch.full((T,), self.op.rho_v_scale * self.kappa / self.smax ** 2, **f64)
         self.rho_b = torch.full((T,), self.op.rho_b_scale * self.kappa, **f64)
         self.res_out = torch.zeros(8, T, **f64)
         self.op_cold = True
+        self._calibrated = False
         self._graph = None
         self._graph_warm = False
         self.op_iters_hist: list[int] = []
@@ -200,47 +221,68 @@ class AdmmEngine:
         check(self.lib.revs_gemm_tn_f64(m, n, k, ptr(At), m, ptr(B), n, ptr(Cout), n,
                                         accumulate, self.stream), "revs_gemm_tn_f64")
 
+    def _gemm_cat(self, At, B0, B1, C0, C1):
+        """[C0 | C1] = At^T [B0 | B1] as K-split slabs; one launch when 2T <= 192."""
+        M, T, st = self.M, self.T, self.stream
+        if self.cat:
+            rc = self.lib.revs_gemm_tn_f64_cat(M, T, M, ptr(At), ptr(B0), ptr(B1), ptr(C0),
+                                               ptr(C1), self.ksplit, st)
+            check(rc, "revs_gemm_tn_f64_cat")
+        else:
+            rc = self.lib.revs_gemm_tn_f64_x2(M, T, M, ptr(At), ptr(B0), ptr(C0), ptr(At),
+                                              ptr(B1), ptr(C1), self.ksplit, st)
+            check(rc, "revs_gemm_tn_f64_x2")
+
     def _allreduce(self, t, op=None):
         if self.group is not None:
             torch.distributed.all_reduce(
                 t, op=op or torch.distributed.ReduceOp.SUM, group=self.group)
 
     # -------------------------------------------------------------- operator
-    def _home_pass(self, with_update: bool):
+    def _home_pass(self, with_update: bool, check: bool = False):
         o = self.op
-        check(self.lib.revs_op_home_pass(
-            self.M, self.T, ptr(self.node_ptr), ptr(self.inv_sqrt_n), ptr(self.x), ptr(self.zb),
-            ptr(self.yb), ptr(self.g0), ptr(self.xc) if with_update else None, ptr(self.rho_b),
-            self.kappa, o.sigma, o.alpha, ptr(self.rhat), self.stream), "revs_op_home_pass")
+        rc = self.lib.revs_op_home_pass(
+            self.M, self.T, ptr(self.node_ptr), ptr(self.inv_sqrt_n), ptr(self.sb), ptr(self.g0),
+            ptr(self.xc) if with_update else None, ptr(self.rho_b), self.kappa, o.alpha,
+            ptr(self.rhat), ptr(self.cty) if check else None,
+            ptr(self.res_out) if check else None, self.stream)
+        _lib.check(rc, "revs_op_home_pass")
         self._allreduce(self.rhat)
 
-    def _node_half(self):
-        """rhat -> xc, and the z_v / y_v update (GEMMs on the f64 matrix cores)."""
+    def _node_half(self, check: bool = False):
+        """rhat -> xc, and the z_v / y_v update (GEMMs on the f64 matrix cores).  On a
+        checking iteration also the node-side residual maxima and cty = C_v^T y_v."""
         o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
-        check(lib.revs_gemm_tn_f64_x2(M, T, M, ptr(self.V), ptr(self.rhat), ptr(self.ta),
-                                      ptr(self.U), ptr(self.w), ptr(self.tb), st),
-              "revs_gemm_tn_f64_x2")                                # V^T rhat | U^T w
-        check(lib.revs_op_node_scale(M, T, ptr(self.ta), ptr(self.tb), ptr(self.s),
-                                     ptr(self.rho_v), ptr(self.rho_b), self.kappa, o.sigma,
-                                     ptr(self.a), ptr(self.sa), st), "revs_op_node_scale")
-        check(lib.revs_gemm_tn_f64_x2(M, T, M, ptr(self.VT), ptr(self.a), ptr(self.va),
-                                      ptr(self.UT), ptr(self.sa), ptr(self.usa), st),
-              "revs_gemm_tn_f64_x2")                                # V a | U (s a) = C_v xt
-        check(lib.revs_op_node_update(M, T, ptr(self.va), ptr(self.rhat), ptr(self.usa),
-                                      ptr(self.rho_v), ptr(self.rho_b), self.kappa, o.sigma,
-                                      o.alpha, self.vlo, self.vhi, ptr(self.xc), ptr(self.zv),
-                                      ptr(self.yv), ptr(self.cx), ptr(self.w), st),
-              "revs_op_node_update")
+        ks = self.ksplit
+        self._gemm_cat(self.Q, self.rhat, self.w, self.ta, self.tb)        # Q^T [rhat | w]
+        _lib.check(lib.revs_op_node_scale(M, T, ks, ptr(self.ta), ptr(self.tb), ptr(self.s),
+                                          ptr(self.rho_v), ptr(self.rho_b), self.kappa,
+                                          ptr(self.a), ptr(self.sa), st), "revs_op_node_scale")
+        self._gemm_cat(self.QT, self.a, self.sa, self.va, self.usa)        # Q [a | l a]
+        _lib.check(lib.revs_op_node_update(M, T, ks, ptr(self.va), ptr(self.rhat), ptr(self.usa),
+                                           ptr(self.rho_v), ptr(self.rho_b), ptr(self.sqrt_n),
+                                           self.kappa, o.alpha, self.vlo, self.vhi, ptr(self.xc),
+                                           ptr(self.zv), ptr(self.yv), ptr(self.w),
+                                           ptr(self.res_out) if check else None, st),
+                   "revs_op_node_update")
+        if check:
+            self._gemm(self.Q, self.yv, self.tb[0])                 # Q^T y_v
+            _lib.check(lib.revs_op_row_scale(M, T, ptr(self.s), ptr(self.tb[0]),
+                                             ptr(self.ta[0]), st), "revs_op_row_scale")
+            self._gemm(self.QT, self.ta[0], self.cty)               # Q L Q^T y_v = C_v^T y_v
 
     def _inner_block(self):
-        """`check_every` inner iterations.  On one GPU the block is captured once into
-        a hipGraph (through torch.cuda.CUDAGraph: the ctypes launches go to torch's
-        current stream, which is the capture stream) and replayed: one host call instead
-        of 5 launches per iteration.  With a process group the all-reduce stays eager."""
+        """`check_every` inner iterations, the last one also accumulating the residual
+        maxima.  On one GPU the block is captured once into a hipGraph (through
+        torch.cuda.CUDAGraph: the ctypes launches go to torch's current stream, which is
+        the capture stream) and replayed: one host call instead of ~5 launches per
+        iteration.  With a process group the all-reduce stays eager."""
         def body():
-            for _ in range(self.op.check_every):
-                self._node_half()
-                self._home_pass(with_update=True)
+            self.res_out.zero_()
+            for k in range(self.op.check_every):
+                last = k == self.op.check_every - 1
+                self._node_half(check=last)
+                self._home_pass(with_update=True, check=last)
         if self.group is not None or not self.op.use_graph or self.dev.type != "cuda":
             return body()
         if self._graph is None:
@@ -254,55 +296,84 @@ class AdmmEngine:
         self._graph.replay()
 
     def _residuals(self):
-        lib, M, T, st = self.lib, self.M, self.T, self.stream
-        self._gemm(self.U, self.yv, self.tb)                        # U^T y_v
-        self.tb.mul_(self.s[:, None])
-        self._gemm(self.VT, self.tb, self.cty)                      # V S U^T y_v
-        self.res_out.zero_()
-        check(lib.revs_op_residuals(M, T, ptr(self.node_ptr), ptr(self.inv_sqrt_n), ptr(self.x),
-                                    ptr(self.zb), ptr(self.yb), ptr(self.g0), ptr(self.cty),
-                                    ptr(self.cx), ptr(self.zv), self.kappa, ptr(self.res_out),
-                                    st), "revs_op_residuals")
         self._allreduce(self.res_out, torch.distributed.ReduceOp.MAX if self.group else None)
         return self.res_out.cpu().numpy()
+
+    def _rel_residuals(self, r):
+        vscale = max(abs(self.vlo), abs(self.vhi), 1e-300)
+        n_pv = np.maximum(np.maximum(r[3], r[4]), vscale)
+        n_pb = np.maximum(r[5], 1e-12)
+        n_d = np.maximum(np.maximum(self.kappa * r[5], r[6]), np.maximum(r[7], 1e-12))
+        return np.maximum(r[0] / n_pv, r[1] / n_pb), r[2] / n_d
+
+    def _set_rho(self, rv_scale, rb_scale):
+        self.rho_v.fill_(rv_scale * self.kappa / self.smax ** 2)
+        self.rho_b.fill_(rb_scale * self.kappa)
+        _lib.check(self.lib.revs_op_node_w(self.M, self.T, ptr(self.zv), ptr(self.yv),
+                                           ptr(self.rho_v), ptr(self.w), self.stream),
+                   "revs_op_node_w")
+        self._home_pass(with_update=False)
+
+    def _calibrate_rho(self):
+        """Try each candidate (rho_v, rho_b) for two blocks from the current state, keep the
+        best.  Returns the number of inner iterations spent."""
+        o = self.op
+        snap = [t.clone() for t in (self.sb, self.zv, self.yv)]
+        best, spent = None, 0
+        for rv in o.cal_rho_v:
+            for rb in o.cal_rho_b:
+                for t, c in zip((self.sb, self.zv, self.yv), snap):
+                    t.copy_(c)
+                self._set_rho(rv, rb)
+                self._inner_block()
+                self._inner_block()
+                spent += 2 * o.check_every
+                rel_p, rel_d = self._rel_residuals(self._residuals())
+                score = float(max(rel_p.max(), rel_d.max()))
+                if np.isfinite(score) and (best is None or score < best[0]):
+                    best = (score, rv, rb)
+        for t, c in zip((self.sb, self.zv, self.yv), snap):
+            t.copy_(c)
+        self.rho_scales = best[1:]
+        self._set_rho(*self.rho_scales)
+        self._calibrated = True
+        return spent
 
     def operator_solve(self):
         """Utility(graph, P_est[k], P_sch[k], G[k]).solve() -> P_est[k+1]
         (lpsolver.py:256-259), written to self.P_est_new."""
         o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
-        check(lib.revs_op_g0(self.n, T, ptr(self.P_est), ptr(self.P_sch), ptr(self.G),
-                             self.kappa, ptr(self.g0), st), "revs_op_g0")
+        _lib.check(lib.revs_op_g0(self.n, T, ptr(self.P_est), ptr(self.P_sch), ptr(self.G),
+                                  self.kappa, ptr(self.g0), st), "revs_op_g0")
         if self.op_cold or not o.warm_start:
-            check(lib.revs_op_init_home(self.n, T, ptr(self.g0), ptr(self.x), ptr(self.zb),
-                                        ptr(self.yb), st), "revs_op_init_home")
-            check(lib.revs_aggregate_f64(M, T, ptr(self.node_ptr), ptr(self.x),
-                                         ptr(self.inv_sqrt_n), ptr(self.rhat), st),
-                  "revs_aggregate_f64")
+            _lib.check(lib.revs_op_init_home(self.n, T, ptr(self.g0), ptr(self.sb), st),
+                       "revs_op_init_home")
+            _lib.check(lib.revs_aggregate_f64(M, T, ptr(self.node_ptr), ptr(self.sb),
+                                              ptr(self.inv_sqrt_n), ptr(self.rhat), st),
+                       "revs_aggregate_f64")
             self._allreduce(self.rhat)
-            self._gemm(self.V, self.rhat, self.ta)
-            self.ta.mul_(self.s[:, None])
-            self._gemm(self.UT, self.ta, self.cx)                   # cx = C_v x
+            self._gemm(self.Q, self.rhat, self.ta[0])
+            _lib.check(lib.revs_op_row_scale(M, T, ptr(self.s), ptr(self.ta[0]),
+                                             ptr(self.tb[0]), st), "revs_op_row_scale")
+            self._gemm(self.QT, self.tb[0], self.cx)                # cx = C_v x, x = max(g0,0)
             self.rho_v.fill_(o.rho_v_scale * self.kappa / self.smax ** 2)
             self.rho_b.fill_(o.rho_b_scale * self.kappa)
-            check(lib.revs_op_init_node(M, T, ptr(self.cx), ptr(self.rho_v), self.vlo, self.vhi,
-                                        ptr(self.zv), ptr(self.yv), ptr(self.w), st),
-                  "revs_op_init_node")
+            _lib.check(lib.revs_op_init_node(M, T, ptr(self.cx), ptr(self.rho_v),
+                                             ptr(self.sqrt_n), self.vlo, self.vhi, ptr(self.zv),
+                                             ptr(self.yv), ptr(self.w), st), "revs_op_init_node")
             self.op_cold = False
         self._home_pass(with_update=False)
         it, converged = 0, False
-        vscale = max(abs(self.vlo), abs(self.vhi), 1e-300)
         while it < o.max_iter:
             self._inner_block()
             it += o.check_every
-            r = self._residuals()
-            n_pv = np.maximum(np.maximum(r[3], r[4]), vscale)
-            n_pb = np.maximum(r[5], 1e-12)
-            n_d = np.maximum(np.maximum(self.kappa * r[5], r[6]), np.maximum(r[7], 1e-12))
-            rel_p = np.maximum(r[0] / n_pv, r[1] / n_pb)
-            rel_d = r[2] / n_d
+            rel_p, rel_d = self._rel_residuals(self._residuals())
             if max(rel_p.max(), rel_d.max()) <= o.eps:
                 converged = True
                 break
+            if o.calibrate and not self._calibrated:
+                it += self._calibrate_rho()
+                continue
             if o.adapt_every and it % o.adapt_every == 0:
                 sc = np.sqrt(np.maximum(rel_p, 1e-14) / np.maximum(rel_d, 1e-14))
                 sc = np.clip(sc, 0.2, 5.0)
@@ -311,13 +382,15 @@ class AdmmEngine:
                     sct = torch.from_numpy(sc).to(self.dev)
                     self.rho_v.mul_(sct)
                     self.rho_b.mul_(sct)
-                    check(lib.revs_op_node_w(M, T, ptr(self.zv), ptr(self.yv), ptr(self.rho_v),
-                                             ptr(self.w), st), "revs_op_node_w")
+                    # y_b = min(s_b,0) is kept as is; only w and rhat depend on rho
+                    _lib.check(lib.revs_op_node_w(M, T, ptr(self.zv), ptr(self.yv),
+                                                  ptr(self.rho_v), ptr(self.w), st),
+                               "revs_op_node_w")
                     self._home_pass(with_update=False)
         self.op_iters_hist.append(it)
         self.op_converged = converged
-        check(lib.revs_op_export(self.n, T, ptr(self.zb), ptr(self.P_est_new), st),
-              "revs_op_export")
+        _lib.check(lib.revs_op_export(self.n, T, ptr(self.sb), ptr(self.P_est_new), st),
+                   "revs_op_export")
         return converged
 
     # ----------------------------------------------------------------- homes
@@ -328,7 +401,8 @@ class AdmmEngine:
             self.n, self.T, ptr(self.cost), ptr(self.homes), ptr(self.load), ptr(self.P_est),
             ptr(self.P_est_new), ptr(self.P_sch), ptr(self.G),
             ptr(self.S) if write_sc else None, ptr(self.Csoc) if write_sc else None,
-            ptr(self.diff), ptr(self.partials), ptr(self.status), self.kappa, self.mode,
+            ptr(self.diff), ptr(self.partials), ptr(self.status), ptr(self.pdhg_dual),
+            self.kappa, self.mode,
             C.byref(self.pdhg), self.stream), "revs_agent_step")
 
     def residuals(self, eps=1e-4):

@@ -29,7 +29,7 @@ class FakeKernels:
         return (n + 31) // 32
 
     def revs_agent_step(self, n, T, cost, homes, load, pe_old, pe_new, ps, gm, s_out, c_out, diff,
-                        partials, status, kappa, mode, pdhg, stream):
+                        partials, status, pdhg_dual, kappa, mode, pdhg, stream):
         f = lambda p, sh=(n, T): view(p, sh, np.float32)
         rec = view(homes, (n * HOME_DTYPE.itemsize,), np.uint8).view(HOME_DTYPE)
         oh = ro.homes_from_records(f(load).astype(float), rec)
@@ -68,16 +68,14 @@ class FakeKernels:
         view(g0, (n, T), np.float64)[:] = 0.5 * (f(pe) + f(ps)) - f(gm) / kappa
         return 0
 
-    def revs_op_init_home(self, n, T, g0, x, zb, yb, stream):
-        d = lambda p: view(p, (n, T), np.float64)
-        d(x)[:] = np.maximum(d(g0), 0)
-        d(zb)[:] = d(x)
-        d(yb)[:] = 0
+    def revs_op_init_home(self, n, T, g0, sb, stream):
+        view(sb, (n, T), np.float64)[:] = np.maximum(view(g0, (n, T), np.float64), 0)
         return 0
 
-    def revs_op_init_node(self, m, T, cx, rho_v, vlo, vhi, zv, yv, w, stream):
+    def revs_op_init_node(self, m, T, cx, rho_v, bscale, vlo, vhi, zv, yv, w, stream):
         d = lambda p: view(p, (m, T), np.float64)
-        d(zv)[:] = np.clip(d(cx), vlo, vhi)
+        bs = view(bscale, (m,), np.float64)[:, None] if bscale else 1.0
+        d(zv)[:] = np.clip(d(cx), bs * vlo, bs * vhi)
         d(yv)[:] = 0
         d(w)[:] = view(rho_v, (T,), np.float64)[None, :] * d(zv)
         return 0
@@ -103,25 +101,35 @@ class FakeKernels:
         view(out, (m, T), np.float32)[:] = acc
         return 0
 
-    def revs_op_home_pass(self, m, T, node_ptr, isn, x, zb, yb, g0, xc, rho_b, kappa, sigma,
-                          alpha, rhat, stream):
+    def revs_op_home_pass(self, m, T, node_ptr, isn, sb, g0, xc, rho_b, kappa, alpha, rhat,
+                          cty, res, stream):
         node, n = self._seg(m, node_ptr)
         d = lambda p: view(p, (n, T), np.float64)
         rb = view(rho_b, (T,), np.float64)[None, :]
         isn_ = view(isn, (m,), np.float64)
-        X, Z, Y, G0 = d(x), d(zb), d(yb), d(g0)
+        SB, G0 = d(sb), d(g0)
+        Z, Y = np.maximum(SB, 0), np.minimum(SB, 0)
         if xc:
-            c = kappa + sigma + rb
-            rhs = sigma * X + kappa * G0 + rb * Z - Y
-            xt = rhs / c + (isn_[:, None] * view(xc, (m, T), np.float64))[node]
-            X[:] = alpha * xt + (1 - alpha) * X
-            h = alpha * xt + (1 - alpha) * Z
-            zn = np.maximum(h + Y / rb, 0)
-            Y[:] = Y + rb * (h - zn)
-            Z[:] = zn
+            xt = (kappa * G0 + rb * Z - Y) / (kappa + rb) + \
+                (isn_[:, None] * view(xc, (m, T), np.float64))[node]
+            u = alpha * xt + (1 - alpha) * Z + Y / rb
+            Z, Y = np.maximum(u, 0), rb * np.minimum(u, 0)
+            SB[:] = Z + Y
+            if res:
+                cy = (isn_[:, None] * view(cty, (m, T), np.float64))[node] + Y
+                o = view(res, (8, T), np.float64)
+                mx = lambda a: np.abs(a).max(axis=0) if a.shape[0] else np.zeros(T)
+                for row, val in ((1, xt - Z), (2, kappa * (xt - G0) + cy), (5, xt), (6, cy),
+                                 (7, kappa * G0)):
+                    o[row] = np.maximum(o[row], mx(val))
         acc = np.zeros((m, T))
-        np.add.at(acc, node, sigma * X + kappa * G0 + rb * Z - Y)
+        np.add.at(acc, node, kappa * G0 + rb * Z - Y)
         view(rhat, (m, T), np.float64)[:] = isn_[:, None] * acc
+        return 0
+
+    def revs_op_row_scale(self, m, T, s, inp, out, stream):
+        view(out, (m, T), np.float64)[:] = view(s, (m,), np.float64)[:, None] * \
+            view(inp, (m, T), np.float64)
         return 0
 
     def revs_op_node_w(self, m, T, zv, yv, rho_v, w, stream):
@@ -129,44 +137,38 @@ class FakeKernels:
         d(w)[:] = view(rho_v, (T,), np.float64)[None, :] * d(zv) - d(yv)
         return 0
 
-    def revs_op_node_scale(self, m, T, ta, tb, s, rho_v, rho_b, kappa, sigma, a, sa, stream):
+    def revs_op_node_scale(self, m, T, nslab, ta, tb, s, rho_v, rho_b, kappa, a, sa, stream):
         d = lambda p: view(p, (m, T), np.float64)
+        ds = lambda p: view(p, (nslab, m, T), np.float64).sum(axis=0)
         sv = view(s, (m,), np.float64)[:, None]
-        c = kappa + sigma + view(rho_b, (T,), np.float64)[None, :]
-        av = (d(ta) + sv * d(tb)) / (c + view(rho_v, (T,), np.float64)[None, :] * sv * sv)
+        c = kappa + view(rho_b, (T,), np.float64)[None, :]
+        av = (ds(ta) + sv * ds(tb)) / (c + view(rho_v, (T,), np.float64)[None, :] * sv * sv)
         d(a)[:] = av
         d(sa)[:] = sv * av
         return 0
 
-    def revs_op_node_update(self, m, T, va, rhat, usa, rho_v, rho_b, kappa, sigma, alpha, vlo,
-                            vhi, xc, zv, yv, cx, w, stream):
+    def revs_op_node_update(self, m, T, nslab, va, rhat, usa, rho_v, rho_b, bscale, kappa, alpha,
+                            vlo, vhi, xc, zv, yv, w, res, stream):
         d = lambda p: view(p, (m, T), np.float64)
         rv = view(rho_v, (T,), np.float64)[None, :]
-        c = kappa + sigma + view(rho_b, (T,), np.float64)[None, :]
-        d(xc)[:] = d(va) - d(rhat) / c
-        h = alpha * d(usa) + (1 - alpha) * d(zv)
-        zn = np.clip(h + d(yv) / rv, vlo, vhi)
+        c = kappa + view(rho_b, (T,), np.float64)[None, :]
+        ds = lambda p: view(p, (nslab, m, T), np.float64).sum(axis=0)
+        usa_ = ds(usa)
+        d(xc)[:] = ds(va) - d(rhat) / c
+        h = alpha * usa_ + (1 - alpha) * d(zv)
+        bs = view(bscale, (m,), np.float64)[:, None] if bscale else 1.0
+        zn = np.clip(h + d(yv) / rv, bs * vlo, bs * vhi)
         d(yv)[:] = d(yv) + rv * (h - zn)
         d(zv)[:] = zn
-        d(cx)[:] = alpha * d(usa) + (1 - alpha) * d(cx)
         d(w)[:] = rv * zn - d(yv)
+        if res:
+            o = view(res, (8, T), np.float64)
+            for row, val in ((0, usa_ - zn), (3, usa_), (4, zn)):
+                o[row] = np.maximum(o[row], np.abs(val).max(axis=0))
         return 0
 
-    def revs_op_residuals(self, m, T, node_ptr, isn, x, zb, yb, g0, cty, cx, zv, kappa, out,
-                          stream):
-        node, n = self._seg(m, node_ptr)
-        d = lambda p: view(p, (n, T), np.float64)
-        dm = lambda p: view(p, (m, T), np.float64)
-        cy = (view(isn, (m,), np.float64)[:, None] * dm(cty))[node] + d(yb)
-        o = view(out, (8, T), np.float64)
-        mx = lambda a: np.abs(a).max(axis=0) if a.shape[0] else np.zeros(T)
-        new = np.stack([mx(dm(cx) - dm(zv)), mx(d(x) - d(zb)), mx(kappa * (d(x) - d(g0)) + cy),
-                        mx(dm(cx)), mx(dm(zv)), mx(d(x)), mx(cy), mx(kappa * d(g0))])
-        o[:] = np.maximum(o, new)
-        return 0
-
-    def revs_op_export(self, n, T, zb, pe, stream):
-        view(pe, (n, T), np.float32)[:] = view(zb, (n, T), np.float64)
+    def revs_op_export(self, n, T, sb, pe, stream):
+        view(pe, (n, T), np.float32)[:] = np.maximum(view(sb, (n, T), np.float64), 0)
         return 0
 
     def revs_gemm_tn_f64(self, m, n, k, At, lda, B, ldb, Cc, ldc, acc, stream):
@@ -175,10 +177,17 @@ class FakeKernels:
         c[:, :n] = c[:, :n] + r if acc else r
         return 0
 
-    def revs_gemm_tn_f64_x2(self, m, n, k, A0, B0, C0, A1, B1, C1, stream):
-        self.revs_gemm_tn_f64(m, n, k, A0, m, B0, n, C0, n, 0, stream)
-        self.revs_gemm_tn_f64(m, n, k, A1, m, B1, n, C1, n, 0, stream)
+    def revs_gemm_tn_f64_x2(self, m, n, k, A0, B0, C0, A1, B1, C1, ksplit, stream):
+        for A, B, Cc in ((A0, B0, C0), (A1, B1, C1)):
+            a, b = view(A, (k, m), np.float64), view(B, (k, n), np.float64)
+            c = view(Cc, (ksplit, m, n), np.float64)
+            edges = np.linspace(0, k, ksplit + 1).astype(int)
+            for q in range(ksplit):
+                c[q] = a[edges[q]:edges[q + 1]].T @ b[edges[q]:edges[q + 1]]
         return 0
+
+    def revs_gemm_tn_f64_cat(self, m, T, k, At, B0, B1, C0, C1, ksplit, stream):
+        return self.revs_gemm_tn_f64_x2(m, T, k, At, B0, C0, At, B1, C1, ksplit, stream)
 
     def revs_voltage_f32(self, m, T, Rt, P, V, stream):
         view(V, (m, T), np.float32)[:] = view(Rt, (m, m), np.float32).T @ view(P, (m, T), np.float32)

@@ -51,9 +51,9 @@ def test_argument_validation_without_gpu(lib):
     assert lib.revs_agent_num_partials(100000, 24) == 3125          # 32 homes per workgroup
     assert lib.revs_agent_num_partials(10, 96) == 2                 # 8 homes per workgroup
     assert lib.revs_agent_num_partials(10, 500) == 0                # T > REVS_MAX_T
-    rc = lib.revs_agent_step(0, 24, *([None] * 12), 5.0, 0, None, None)
+    rc = lib.revs_agent_step(0, 24, *([None] * 13), 5.0, 0, None, None)
     assert rc == -1 and b"n_homes" in lib.revs_last_error()
-    rc = lib.revs_agent_step(10, 999, *([None] * 12), 5.0, 0, None, None)
+    rc = lib.revs_agent_step(10, 999, *([None] * 13), 5.0, 0, None, None)
     assert rc == -1 and b"T=999" in lib.revs_last_error()
     rc = lib.revs_gemm_tn_f64(4, 300, 4, None, 4, None, 300, None, 300, 0, None)
     assert rc == -1

@@ -173,13 +173,34 @@ def test_gemm_x2_one_launch(gpu_lib):
     import torch
     from revs_admm_amd._lib import check, ptr
     rng = np.random.default_rng(9)
-    m, n = 333, 24
+    m, n = 333, 24          # odd m: the paired 16-byte A fetch falls back to scalar loads
     A0, A1 = rng.normal(size=(m, m)), rng.normal(size=(m, m))
     B0, B1 = rng.normal(size=(m, n)), rng.normal(size=(m, n))
     d = [_up(a, np.float64) for a in (A0, B0, A1, B1)]
-    C0 = torch.zeros(m, n, dtype=torch.float64, device="cuda:0")
-    C1 = torch.zeros_like(C0)
-    check(gpu_lib.revs_gemm_tn_f64_x2(m, n, m, ptr(d[0]), ptr(d[1]), ptr(C0), ptr(d[2]), ptr(d[3]),
-                                      ptr(C1), torch.cuda.current_stream().cuda_stream))
-    np.testing.assert_allclose(C0.cpu().numpy(), A0.T @ B0, rtol=1e-12, atol=1e-11)
-    np.testing.assert_allclose(C1.cpu().numpy(), A1.T @ B1, rtol=1e-12, atol=1e-11)
+    for ks in (1, 2, 5):
+        C0 = torch.full((ks, m, n), 3.0, dtype=torch.float64, device="cuda:0")
+        C1 = torch.full_like(C0, -1.0)
+        check(gpu_lib.revs_gemm_tn_f64_x2(m, n, m, ptr(d[0]), ptr(d[1]), ptr(C0), ptr(d[2]),
+                                          ptr(d[3]), ptr(C1), ks,
+                                          torch.cuda.current_stream().cuda_stream))
+        # the product is the sum of the K-split slabs
+        np.testing.assert_allclose(C0.sum(0).cpu().numpy(), A0.T @ B0, rtol=1e-12, atol=1e-11)
+        np.testing.assert_allclose(C1.sum(0).cpu().numpy(), A1.T @ B1, rtol=1e-12, atol=1e-11)
+
+
+@pytest.mark.parametrize("m,T,ks", [(333, 24, 1), (2048, 24, 4), (1126, 24, 3), (257, 96, 2), (64, 7, 1)])
+def test_gemm_cat(gpu_lib, m, T, ks):
+    """[C0 | C1] = At^T [B0 | B1] with the split at column T (tiles straddle it)."""
+    import torch
+    from revs_admm_amd._lib import check, ptr
+    rng = np.random.default_rng(m + T)
+    A = rng.integers(-3, 4, (m, m)).astype(np.float64)
+    B0 = rng.integers(-3, 4, (m, T)).astype(np.float64)
+    B1 = rng.integers(-3, 4, (m, T)).astype(np.float64)
+    dA, d0, d1 = _up(A, np.float64), _up(B0, np.float64), _up(B1, np.float64)
+    C0 = torch.full((ks, m, T), 9.0, dtype=torch.float64, device="cuda:0")
+    C1 = torch.full_like(C0, -9.0)
+    check(gpu_lib.revs_gemm_tn_f64_cat(m, T, m, ptr(dA), ptr(d0), ptr(d1), ptr(C0), ptr(C1), ks,
+                                       torch.cuda.current_stream().cuda_stream))
+    assert (C0.sum(0).cpu().numpy() == A.T @ B0).all()
+    assert (C1.sum(0).cpu().numpy() == A.T @ B1).all()
