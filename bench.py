@@ -118,8 +118,11 @@ def main():
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     group = None
-    if world > 1:
+    if world > 1 or os.environ.get("REVS_FORCE_GROUP"):      # (1-rank group: rehearsal of N>1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if "RANK" not in os.environ:
+            os.environ.update(RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device(dev))
         group = dist.group.WORLD
 
@@ -274,7 +277,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if group is not None:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -24,7 +24,7 @@ for tag, homes in (("pmc", 100000), ("pmc1m", 1000000)):
         fs = glob.glob(f"{src}/{tag}_{ctr}/*/*_counter_collection.csv")
         if not fs:
             continue
-        df = pd.read_csv(fs[0])
+        df = pd.read_csv(max(fs, key=os.path.getmtime))      # newest pass
         df = df[df["Kernel_Name"].str.contains("revs::")]
         df["kernel"] = df["Kernel_Name"].str.replace(r"\(.*", "", regex=True).str.replace("void ", "")
         df["dur_us"] = (df["End_Timestamp"] - df["Start_Timestamp"]) / 1e3

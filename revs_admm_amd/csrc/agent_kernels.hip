@@ -22,6 +22,7 @@
 // the maximum of diff over all homes (the reference's only convergence measure).
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 #include <type_traits>
 
 namespace revs {
@@ -417,6 +418,15 @@ __global__ __launch_bounds__(kBlock) void residence_kernel(
 // ---- dispatch ---------------------------------------------------------------
 struct Shape { int lpa, spl; };
 static Shape pick_shape(int T) {
+    // REVS_AGENT_SHAPE=LPAxSPL overrides the mapping for T <= 24 (tuning hook)
+    if (T <= 24) {
+        if (const char *e = getenv("REVS_AGENT_SHAPE")) {
+            int l = 0, p = 0;
+            if (sscanf(e, "%dx%d", &l, &p) == 2 && l * p >= T &&
+                ((l == 8 && p == 3) || (l == 4 && p == 6) || (l == 2 && p == 12)))
+                return {l, p};
+        }
+    }
     if (T <= 8) return {8, 1};
     if (T <= 16) return {8, 2};
     if (T <= 24) return {8, 3};
@@ -448,6 +458,8 @@ static void launch_agent(const AgentArgs &a, int mode, dim3 grid, hipStream_t s)
         if (sh.lpa == 8 && sh.spl == 1) { CALL(8, 1); }            \
         else if (sh.lpa == 8 && sh.spl == 2) { CALL(8, 2); }       \
         else if (sh.lpa == 8 && sh.spl == 3) { CALL(8, 3); }       \
+        else if (sh.lpa == 4 && sh.spl == 6) { CALL(4, 6); }       \
+        else if (sh.lpa == 2 && sh.spl == 12) { CALL(2, 12); }     \
         else if (sh.lpa == 8 && sh.spl == 4) { CALL(8, 4); }       \
         else if (sh.lpa == 16 && sh.spl == 3) { CALL(16, 3); }     \
         else if (sh.lpa == 16 && sh.spl == 4) { CALL(16, 4); }     \

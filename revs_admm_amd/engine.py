@@ -74,6 +74,7 @@ class OperatorOptions:
     calibrate: bool = True
     cal_rho_v: tuple = (0.1, 1.0, 10.0, 100.0)
     cal_rho_b: tuple = (0.1, 1.0)
+    cal_iters: int = 50
 
 
 def _dev_check(device):
@@ -273,27 +274,46 @@ class AdmmEngine:
 
     def _inner_block(self):
         """`check_every` inner iterations, the last one also accumulating the residual
-        maxima.  On one GPU the block is captured once into a hipGraph (through
-        torch.cuda.CUDAGraph: the ctypes launches go to torch's current stream, which is
-        the capture stream) and replayed: one host call instead of ~5 launches per
-        iteration.  With a process group the all-reduce stays eager."""
+        maxima.  hipGraphs (through torch.cuda.CUDAGraph: the ctypes launches go to torch's
+        current stream, which is the capture stream) cut the host work:
+          * one GPU: the whole block is one graph -- one host call per 25 iterations;
+          * sharded: the node half (2 products + 2 node passes, no communication) is a
+            graph, the home pass and the RCCL all-reduce of rhat stay eager, so an
+            iteration is 3 host calls instead of 6 and no collective is ever captured."""
+        n_it = self.op.check_every
+
         def body():
             self.res_out.zero_()
-            for k in range(self.op.check_every):
-                last = k == self.op.check_every - 1
+            for k in range(n_it):
+                last = k == n_it - 1
                 self._node_half(check=last)
                 self._home_pass(with_update=True, check=last)
-        if self.group is not None or not self.op.use_graph or self.dev.type != "cuda":
+
+        if not self.op.use_graph or self.dev.type != "cuda":
             return body()
+        if not self._graph_warm:               # first block eager: warms up, loads code objects
+            self._graph_warm = True
+            return body()
+        if self.group is None:
+            if self._graph is None:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    body()
+                self._graph = g
+            return self._graph.replay()
         if self._graph is None:
-            if not self._graph_warm:           # first block eager: warms up, loads code objects
-                self._graph_warm = True
-                return body()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                body()
-            self._graph = g
-        self._graph.replay()
+            gs = []
+            for chk in (False, True):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._node_half(check=chk)
+                gs.append(g)
+            self._graph = gs
+        self.res_out.zero_()
+        for k in range(n_it):
+            last = k == n_it - 1
+            self._graph[1 if last else 0].replay()
+            self._home_pass(with_update=True, check=last)
 
     def _residuals(self):
         self._allreduce(self.res_out, torch.distributed.ReduceOp.MAX if self.group else None)
@@ -325,9 +345,10 @@ class AdmmEngine:
                 for t, c in zip((self.sb, self.zv, self.yv), snap):
                     t.copy_(c)
                 self._set_rho(rv, rb)
-                self._inner_block()
-                self._inner_block()
-                spent += 2 * o.check_every
+                nblk = max(1, -(-o.cal_iters // o.check_every))
+                for _ in range(nblk):
+                    self._inner_block()
+                spent += nblk * o.check_every
                 rel_p, rel_d = self._rel_residuals(self._residuals())
                 score = float(max(rel_p.max(), rel_d.max()))
                 if np.isfinite(score) and (best is None or score < best[0]):

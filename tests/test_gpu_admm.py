@@ -147,3 +147,30 @@ def test_individual_mode_golden(gpu_lib, golden):
         p_or, s_or, _ = ro.solve_residence(z["tariff_shift6"], oh)
         assert ((p > 0) == (p_or > 0)).all()                   # same tie rule as the oracle
         np.testing.assert_allclose(soc, s_or, atol=1e-6)
+
+
+def test_process_group_path_on_one_gpu(gpu_lib):
+    """The sharded code path (node-half hipGraphs + eager home pass + RCCL all-reduce) with a
+    1-rank nccl group must give the same trajectory as the single-process path."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from helpers import f32
+    from revs_admm_amd.synthetic import make_workload
+    w = make_workload(800, 24, n_nodes=64, seed=13, binary_feasible=False, stress=1.25)
+    w.load, w.cost = f32(w.load), f32(w.cost)
+    a = _engine(w, "relaxed_exact")
+    da = a.run(4)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 1000))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        b = _engine(w, "relaxed_exact", group=dist.group.WORLD)
+        db = b.run(4)
+        assert isinstance(b._graph, list) and len(b._graph) == 2      # the sharded graphs ran
+        assert a.op_iters_hist == b.op_iters_hist
+        np.testing.assert_allclose(db, da, rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(b.result()[1], a.result()[1], atol=1e-5)
+        assert b.residuals(1e-4)[:3] == pytest.approx(a.residuals(1e-4)[:3], rel=1e-5)
+    finally:
+        dist.destroy_process_group()
