@@ -122,8 +122,46 @@ def solve_residence(tariff, data, path=None):
     return p, s, g
 
 
-def solve_central(tariff, homes, dist, path, vset, vmin, vmax):
-    """Reference lpsolver.py:463-502 (one network-wide MIQP).  Not on the ADMM hot
-    path this engine covers; see DESIGN.md 'out of scope'."""
-    raise NotImplementedError("solve_central: the centralized MIQP is outside the ADMM hot "
-                              "path (DESIGN.md, section 7)")
+def solve_central(tariff, homes, dist, path, vset, vmin, vmax, device="cuda:0"):
+    """Reference lpsolver.py:463-502: one network-wide model -- minimise sum_h tariff.g_h
+    with g_h = p_h + LOAD_h, binary chargers, the SOC box (but NO s_T >= 0.9 row:
+    add_home_EV, lines 338-379) and vmin^2 - vset^2 <= -R_res g[:,t] <= vmax^2 - vset^2
+    (network_constraints, lines 386-405).
+
+    Every tariff is positive and nothing rewards charging, so the optimum of that model is
+    p = 0 whenever it is feasible, and it is feasible iff the base load alone respects the
+    voltage rows (p >= 0 can only push -R g further down).  So this is the operator's
+    voltage check R.LOAD on the GPU (revs_voltage_f32) plus the trivial schedule -- which is
+    exactly what the reference stored for the 121144 feeder (all chargers off, SOC 0.2).
+    Returns (p_opt, s_opt, g_opt) dicts; raises RevsError where the reference prints
+    'No solution found' (infeasible base load)."""
+    import torch
+    from ._lib import check, load, ptr
+    from .engine import _dev_check, voltage_limits
+    if min(tariff) <= 0:
+        raise NotImplementedError("solve_central with a non-positive tariff is not the trivial "
+                                  "model (DESIGN.md section 7)")
+    lib, dev = load(), _dev_check(device)
+    res = [n for n in dist if dist.nodes[n]["label"] == "H"]
+    nonsub = [n for n in dist.nodes if dist.nodes[n]["label"] != "S"]
+    load_, rec = homes_to_arrays(homes, res)
+    T, m = len(tariff), len(res)
+    R = compute_Rmat(dist)
+    pos = {n: i for i, n in enumerate(nonsub)}
+    resind = [pos[n] for n in res]
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    dR, dP = up(R[np.ix_(resind, resind)]), up(load_)
+    dV = torch.zeros(m, T, dtype=torch.float32, device=dev)
+    check(lib.revs_voltage_f32(m, T, ptr(dR), ptr(dP), ptr(dV),
+                               torch.cuda.current_stream(dev).cuda_stream), "revs_voltage_f32")
+    v = -dV.cpu().numpy().astype(np.float64)
+    vlo, vhi = voltage_limits(vset, vmin, vmax)
+    tol = 1e-6 * max(abs(vlo), abs(vhi))
+    if v.min() < vlo - tol or v.max() > vhi + tol:
+        raise _lib.RevsError("No solution found (lpsolver.py:495-497): the base load alone "
+                             "violates the voltage limits")
+    p_opt = {h: np.zeros(T) for h in res}
+    s_opt = {h: (np.full(T + 1, float(rec["initial"][i])) if rec["ev"][i] else np.zeros(T + 1))
+             for i, h in enumerate(res)}
+    g_opt = {h: load_[i].copy() for i, h in enumerate(res)}
+    return p_opt, s_opt, g_opt

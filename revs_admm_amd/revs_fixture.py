@@ -81,9 +81,14 @@ class REVS:
         return Pres, Pev, soc
 
     def get_centralized_optimal(self, tariff, homes, dist, save=False, **kwargs):
-        """revs_fixture.py:225-249 -- outside the hot path (raises NotImplementedError)."""
-        return solve_central(tariff, homes, dist, None, kwargs.get("v0", 1.03),
-                             kwargs.get("vmin", 0.90), kwargs.get("vmax", 1.05))
+        """revs_fixture.py:225-249."""
+        Pev, soc, Pres = solve_central(tariff, homes, dist, None, kwargs.get("v0", 1.03),
+                                       kwargs.get("vmin", 0.90), kwargs.get("vmax", 1.05),
+                                       device=self.device)
+        if save:
+            self._save(combine_result(Pres, Pev, soc, kwargs.get("ev_homes")),
+                       kwargs.get("adoption", 90), kwargs.get("rating", 4800), kwargs.get("seed"))
+        return Pres, Pev, soc
 
     def get_distributed_optimal(self, tariff, homes, dist, save=False, **kwargs):
         """revs_fixture.py:251-280; note the reference reads 'vlow'/'vhigh' (not

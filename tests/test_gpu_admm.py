@@ -174,3 +174,58 @@ def test_process_group_path_on_one_gpu(gpu_lib):
         assert b.residuals(1e-4)[:3] == pytest.approx(a.residuals(1e-4)[:3], rel=1e-5)
     finally:
         dist.destroy_process_group()
+
+
+def test_centralized_mode_golden(gpu_lib, golden):
+    """solve_central (lpsolver.py:463-502) on the 121144 feeder == the reference's stored
+    centralized result (all chargers off, SOC 0.2, P_res = LOAD); an overloaded feeder raises."""
+    from revs_admm_amd import _lib
+    from revs_admm_amd.extract import get_homes_ev_param
+    from revs_admm_amd.lpsolver import solve_central
+    z, fd = golden
+    g = _nx_graph(fd, z)
+    res = z["res_id"].tolist()
+    ev = z["cen_a90_r4800_ev_homes"]
+    homes = get_homes_ev_param({h: z["LOAD"][i].tolist() for i, h in enumerate(res)}, g, ev,
+                               4.8, 20, 0.2, 11, 23)
+    p, s, gg = solve_central(z["tariff_shift6"].tolist(), homes, g, None, 1.03, 0.90, 1.05)
+    np.testing.assert_allclose(np.array([p[int(h)] for h in ev]), z["cen_a90_r4800_P_ev"], atol=1e-12)
+    np.testing.assert_allclose(np.array([s[int(h)] for h in ev]), z["cen_a90_r4800_SOC"], atol=1e-7)
+    np.testing.assert_allclose(np.array([gg[h] for h in res]), z["cen_a90_r4800_P_res"], atol=1e-9)
+    with pytest.raises(_lib.RevsError, match="No solution found"):
+        solve_central(z["tariff_shift6"].tolist(), homes, g, None, 1.03, 0.99, 1.05)
+
+
+def test_full_size_invariants(gpu_lib):
+    """BASELINE size (100k homes x T=24, 2048 nodes): properties that need no oracle run.
+    SOC rows, windows and energy bounds hold for every home; the epilogue identities
+    P_sch = LOAD + S, G += kappa/2 (P_est - P_sch), diff = |P_est - P_sch|/T hold; the
+    operator's answer is voltage-feasible and non-negative; halves of the homes solved
+    separately with the same P_est give the same schedules (sharding invariance)."""
+    import torch
+    from revs_admm_amd.engine import AdmmEngine
+    from revs_admm_amd.synthetic import make_workload
+    w = make_workload(100_000, 24, n_nodes=2048, seed=0, binary_feasible=False)
+    e = _engine(w, "pdhg")
+    for _ in range(3):
+        G_before = e.G.clone()
+        e.step()
+    P_sch, S, C = e.result()
+    h = w.homes
+    ev = h["ev"] == 1
+    t = np.arange(24)[None, :]
+    win = ev[:, None] & (t >= h["start"][:, None]) & (t < h["end"][:, None])
+    assert (S[~win] == 0).all() and (S >= 0).all() and (S <= h["rating"][:, None] * (1 + 1e-6)).all()
+    np.testing.assert_allclose(P_sch, w.load.astype(np.float32) + S, rtol=1e-6, atol=1e-6)
+    soc = np.where(ev[:, None], h["initial"][:, None] + np.cumsum(S, 1) / h["capacity"][:, None], 0)
+    np.testing.assert_allclose(C[:, 1:], soc, atol=2e-5)
+    assert (C[ev, -1] >= 0.9 - 2e-4).all() and (C <= 1 + 2e-4).all() and (np.diff(C, axis=1) >= -1e-6).all()
+    pe = e.P_est.cpu().numpy()[e.inv_perm]
+    chk = pe - P_sch
+    np.testing.assert_allclose(e.diff.cpu().numpy()[e.inv_perm], np.linalg.norm(chk, axis=1) / 24,
+                               rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(e.G.cpu().numpy()[e.inv_perm],
+                               G_before.cpu().numpy()[e.inv_perm] + 2.5 * chk, rtol=1e-4, atol=1e-4)
+    v = e.voltage(e.P_est).cpu().numpy()
+    assert pe.min() >= 0 and v.max() <= e.vhi * (1 + 1e-4)
+    assert e.residuals(1e-4)[2] == pytest.approx(np.max(np.linalg.norm(chk, axis=1) / 24), rel=1e-4)
