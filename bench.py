@@ -39,11 +39,13 @@ def agent_bytes_per_home(T, write_sc, pdhg_dual):
     """Algorithmic HBM bytes of revs_agent_step per residence:
     reads LOAD, P_est[k], P_est[k+1], P_sch[k], G[k] (5 profiles) + the 32-byte home
     record; writes P_sch[k+1], G[k+1] (2 profiles) + diff + status (8 bytes);
-    the PDHG multipliers when they are carried across iterations (1 profile read,
-    1 written); S and C (2T+1 floats) only on the iteration whose schedules are returned."""
+    the PDHG multipliers when they are carried across iterations (one float per home read
+    and written; one profile each way with full_rows); S and C (2T+1 floats) only on the iteration whose schedules are returned."""
     b = 5 * 4 * T + 32 + 2 * 4 * T + 8
-    if pdhg_dual:
+    if pdhg_dual == "full":
         b += 2 * 4 * T
+    elif pdhg_dual:
+        b += 2 * 4
     if write_sc:
         b += 4 * T + 4 * (T + 1)
     return b
@@ -215,7 +217,8 @@ def main():
             k += 1
 
     if rank == 0:
-        warm = eng.pdhg_dual is not None
+        warm = (None if eng.pdhg_dual is None else
+                ("full" if eng.pdhg_dual.dim() == 2 else "scalar"))
         bph = agent_bytes_per_home(args.T, False, warm)
         bytes_per_launch = bph * n_local
         ach = bytes_per_launch / (agent_ms * 1e-3) / 1e9

@@ -58,14 +58,19 @@ typedef struct {
     int32_t max_iter;     /* PDHG iteration cap (multiple of check)           */
     int32_t check;        /* convergence test every `check` iterations        */
     float   tol;          /* stop when max(|dx|, |dy|/sigma) <= tol           */
-    float   tau_scale;    /* tau   = tau_scale   / ||K||                      */
-    float   sigma_scale;  /* sigma = sigma_scale / ||K||                      */
+    float   tau_scale;    /* tau   = tau_scale   / ||K||   (0 = automatic)    */
+    float   sigma_scale;  /* sigma = sigma_scale / ||K||   (0 = automatic)    */
+    int32_t full_rows;    /* 0 (default): presolved -- with p >= 0 the SOC is
+                             nondecreasing, so only the terminal rows s_T in [0.9, 1]
+                             of lpsolver.py:101-109 can bind; K is that single row and
+                             the dual one scalar per home (automatic scales 0.5 / 2).
+                             1: keep all T SOC rows (K = prefix sum; scales 0.25 / 4) */
 } revs_pdhg_t;
 
 const char *revs_version(void);
 const char *revs_last_error(void);
 
-/* Defaults used when `pdhg` is NULL: 4000, 8, 1e-6, 0.25, 4.0 */
+/* Defaults used when `pdhg` is NULL: 4000, 8, 1e-6, automatic scales, presolved rows */
 void revs_pdhg_defaults(revs_pdhg_t *out_host);
 
 /* Number of partial-residual records (3 floats each) revs_agent_step writes for
@@ -91,10 +96,11 @@ int64_t revs_agent_num_partials(int64_t n_homes, int32_t T);
  *                                 max diff}
  *   status      int32[n]          0 ok, 1 infeasible ("No solution found", lpsolver.py:153-155),
  *                                 for PDHG: iterations used in bits 8.. ; or NULL
- *   pdhg_dual   float[n][T]       REVS_MODE_RELAXED_PDHG only, or NULL: the PDHG multipliers
- *                                 of the SOC rows, kept between ADMM iterations.  When given,
- *                                 PDHG starts from them and from the previous schedule
- *                                 (P_sch[k] - LOAD) instead of from zero; zero-initialise it.
+ *   pdhg_dual   float[n] (float[n][T] with full_rows)   REVS_MODE_RELAXED_PDHG only, or NULL:
+ *                                 the PDHG multipliers of the SOC rows, kept between ADMM
+ *                                 iterations.  When given, PDHG starts from them and from the
+ *                                 previous schedule (P_sch[k] - LOAD) instead of from zero;
+ *                                 zero-initialise it.
  */
 int revs_agent_step(int64_t n_homes, int32_t T,
                     const float *cost, const revs_home_t *homes, const float *load,

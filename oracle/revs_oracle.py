@@ -326,7 +326,7 @@ def pdhg_steps(h: Homes, tau_scale=0.25, sigma_scale=4.0):
 
 def home_solve_relaxed_pdhg(cost, h: Homes, p_est, p_sch, gamma, kappa=5.0,
                             iters=2000, tol=1e-7, check=8,
-                            tau_scale=0.25, sigma_scale=4.0, dtype=np.float64):
+                            tau_scale=None, sigma_scale=None, dtype=np.float64, full_rows=True):
     """PDHG (Chambolle-Pock) on the relaxed home QP, restating the HIP kernel's
     iteration so the two can be compared step for step.  x = p/rating in [0,w];
         x+ = clip((x - tau (K^T y + b)) / (1 + tau), 0, w)
@@ -339,7 +339,9 @@ def home_solve_relaxed_pdhg(cost, h: Homes, p_est, p_sch, gamma, kappa=5.0,
     rate = np.where(h.ev, h.rating, 1.0)
     b = (q / (kappa * rate[:, None])).astype(dt)
     w = h.window().astype(dt)
-    tau, sig, delta = pdhg_steps(h, tau_scale, sigma_scale)
+    if not full_rows:
+        return _pdhg_presolved(h, b, w, iters, tol, check, tau_scale or 0.5, sigma_scale or 2.0, dt)
+    tau, sig, delta = pdhg_steps(h, tau_scale or 0.25, sigma_scale or 4.0)
     tau, sig, delta = (tau.astype(dt)[:, None], sig.astype(dt)[:, None],
                        delta.astype(dt)[:, None])
     lo = np.zeros((h.N, h.T), dt)
@@ -361,6 +363,39 @@ def home_solve_relaxed_pdhg(cost, h: Homes, p_est, p_sch, gamma, kappa=5.0,
         yn = v - sig * np.clip(v / sig, lo, hi)
         dx = np.abs(xn - x).max(axis=1)
         dy = (np.abs(yn - y) / sig).max(axis=1)
+        x = np.where(act[:, None], xn, x)
+        y = np.where(act[:, None], yn, y)
+        n_it += act
+        if (k + 1) % check == 0:
+            done |= np.maximum(dx, dy) <= tol
+    p = x.astype(float) * np.where(h.ev, h.rating, 0.0)[:, None]
+    return p, _soc(h, p), p + h.LOAD, n_it
+
+
+def _pdhg_presolved(h: Homes, b, w, iters, tol, check, tau_scale, sigma_scale, dt):
+    """PDHG on the presolved home QP (the kernel's default): with p >= 0 the SOC is
+    nondecreasing, so of init <= s_t <= 1, s_T >= 0.9 only the terminal rows can bind;
+    K is the single row delta*1^T (||K|| = delta sqrt(T_w)) and the dual one scalar."""
+    Tw = np.maximum(np.minimum(h.end, h.T) - np.maximum(h.start, 0), 1).astype(dt)[:, None]
+    delta = np.where(h.ev, h.rating / h.capacity, 1.0).astype(dt)[:, None]
+    nK = delta * np.sqrt(Tw)
+    tau, sig = dt(tau_scale) / nK, dt(sigma_scale) / nK
+    lo = (np.maximum(SOC_TARGET, h.initial) - h.initial).astype(dt)[:, None]
+    hi = (SOC_MAX - h.initial).astype(dt)[:, None]
+    x = np.zeros(b.shape, dt)
+    y = np.zeros((h.N, 1), dt)
+    done = ~h.ev.copy()
+    n_it = np.zeros(h.N, np.int64)
+    one = dt(1.0)
+    for k in range(iters):
+        act = ~done
+        if not act.any():
+            break
+        xn = np.clip((x - tau * (sig * delta * y + b)) / (one + tau), 0, w)
+        v = y + delta * (xn + (xn - x)).sum(axis=1, keepdims=True, dtype=dt)
+        yn = v - np.clip(v, lo, hi)
+        dx = np.abs(xn - x).max(axis=1)
+        dy = np.abs(yn - y)[:, 0]
         x = np.where(act[:, None], xn, x)
         y = np.where(act[:, None], yn, y)
         n_it += act

@@ -151,8 +151,8 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
         const int ws = max(h.start, 0), we = min(h.end, T);
         const float Tw = (float)max(we - ws, 1);
         const float nK = delta * 0.63661977236758134f * (Tw + 1.0f);
-        const float tau = a.pd.tau_scale / nK;
-        const float sig = a.pd.sigma_scale / nK;
+        const float tau = (a.pd.tau_scale > 0.f ? a.pd.tau_scale : 0.25f) / nK;
+        const float sig = (a.pd.sigma_scale > 0.f ? a.pd.sigma_scale : 4.0f) / nK;
         const float inv1pt = 1.0f / (1.0f + tau);
         const float sd = sig * delta;
         const float hi = kSocMax - h.initial;
@@ -166,8 +166,49 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
             // warm start: primal from the previous schedule (P_sch[k] - LOAD), dual from
             // the previous iteration's multipliers when the caller keeps them
             x[j] = a.y_state ? fminf(fmaxf((pso[j] - L[j]) / rate, 0.f), w[j]) : 0.f;
-            y[j] = (a.y_state && valid[j] && ev) ? a.y_state[row + t0 + j] : 0.f;
+            y[j] = (a.pd.full_rows && a.y_state && valid[j] && ev) ? a.y_state[row + t0 + j] : 0.f;
         }
+        bool done = !ev;
+        int iters = 0;
+        const int check = max(a.pd.check, 1);
+        if (!a.pd.full_rows) {
+            // Presolved form: with p >= 0 the SOC is nondecreasing, so of the rows
+            // init <= s_t <= 1, s_T >= 0.9 only the terminal one can bind.  K is then the
+            // single row delta * 1^T (||K|| = delta sqrt(T_w)), its dual one scalar per home,
+            // and K x a group sum -- no scans.
+            const float nK1 = delta * sqrtf(Tw);
+            const float tau1 = (a.pd.tau_scale > 0.f ? a.pd.tau_scale : 0.5f) / nK1;
+            const float sig1 = (a.pd.sigma_scale > 0.f ? a.pd.sigma_scale : 2.0f) / nK1;
+            const float inv1 = 1.0f / (1.0f + tau1);
+            const float sd1 = sig1 * delta;
+            float yy = (a.y_state && live && ev) ? a.y_state[agent] : 0.f;
+            auto iterate1 = [&](auto res_tag) -> float {
+                constexpr bool RES = decltype(res_tag)::value;
+                const float kty = sd1 * yy;
+                float acc = 0.f, dmax = 0.f;
+#pragma unroll
+                for (int j = 0; j < SPL; ++j) {
+                    const float xn = clip3((x[j] - tau1 * (kty + b[j])) * inv1, 0.f, w[j]);
+                    acc += xn + (xn - x[j]);
+                    if constexpr (RES) dmax = fmaxf(dmax, fabsf(xn - x[j]));
+                    x[j] = xn;
+                }
+                const float v = yy + delta * group_sum<LPA>(acc);
+                const float yn = v - clip3(v, lo_last, hi);
+                if constexpr (RES) dmax = fmaxf(dmax, fabsf(yn - yy));
+                yy = yn;
+                return dmax;
+            };
+            for (int it = 0; it < a.pd.max_iter; it += check) {
+                if (__all(done)) break;      // wave-uniform exit every wave reaches
+                for (int c = 1; c < check; ++c) iterate1(std::false_type{});
+                float res = iterate1(std::true_type{});
+                iters += done ? 0 : check;
+                res = group_max<LPA>(res);
+                done = done || (res <= a.pd.tol);
+            }
+            if (a.y_state && live && lig == 0) a.y_state[agent] = ev ? yy : 0.f;
+        } else {
         // y of padded slots must stay 0: give them lo = hi = 0 ... no: v - clip(v,0,0) = v.
         // Instead padded slots get lo = -inf, hi = +inf, so y = v - v = 0.
         float hiv[SPL];
@@ -211,9 +252,6 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
         // Homes of one wavefront iterate together until all of them have converged (a
         // converged home keeps iterating: it only moves closer to its optimum); `iters`
         // records when each home first met the tolerance.
-        bool done = !ev;
-        int iters = 0;
-        const int check = max(a.pd.check, 1);
         for (int it = 0; it < a.pd.max_iter; it += check) {
             if (__all(done)) break;          // wave-uniform exit every wave reaches
             for (int c = 1; c < check; ++c) iterate(std::false_type{});
@@ -223,10 +261,11 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
             done = done || (res <= a.pd.tol);
         }
 #pragma unroll
-        for (int j = 0; j < SPL; ++j) {
-            p[j] = ev ? x[j] * h.rating : 0.f;
+        for (int j = 0; j < SPL; ++j)
             if (a.y_state && valid[j]) a.y_state[row + t0 + j] = ev ? y[j] : 0.f;
         }
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) p[j] = ev ? x[j] * h.rating : 0.f;
         status = iters << 8;
     } else {
         // closed form: p_t = clip(u_t + nu, 0, ub_t), u = -q/kappa; nu is the
@@ -476,8 +515,9 @@ extern "C" void revs_pdhg_defaults(revs_pdhg_t *o) {
     o->max_iter = 4000;
     o->check = 8;
     o->tol = 1e-6f;
-    o->tau_scale = 0.25f;
-    o->sigma_scale = 4.0f;
+    o->tau_scale = 0.f;      // 0 = automatic: 0.5 / 2.0 presolved, 0.25 / 4.0 with full_rows
+    o->sigma_scale = 0.f;
+    o->full_rows = 0;
 }
 
 extern "C" int64_t revs_agent_num_partials(int64_t n_homes, int32_t T) {
@@ -505,7 +545,7 @@ extern "C" int revs_agent_step(int64_t n_homes, int32_t T, const float *cost,
     a.s_out = s_out; a.c_out = c_out; a.diff = diff; a.partials = partials;
     a.status = status; a.y_state = pdhg_dual; a.kappa = kappa;
     if (pdhg_host) a.pd = *pdhg_host; else revs_pdhg_defaults(&a.pd);
-    REVS_REQUIRE(a.pd.max_iter > 0 && a.pd.check > 0 && a.pd.tau_scale > 0 && a.pd.sigma_scale > 0,
+    REVS_REQUIRE(a.pd.max_iter > 0 && a.pd.check > 0 && a.pd.tau_scale >= 0 && a.pd.sigma_scale >= 0,
                  "revs_agent_step: bad PDHG parameters");
     const Shape sh = pick_shape(T);
     const int64_t nblk = revs_agent_num_partials(n_homes, T);

@@ -161,13 +161,15 @@ class AdmmEngine:
         self.partials = torch.zeros(3 * self.n_part, **f32)
         self.resid = torch.zeros(4, **f32)
         # PDHG multipliers carried across ADMM iterations (warm start), relaxed PDHG only
-        self.pdhg_dual = (torch.zeros(n, T, **f32)
-                          if self.mode == _lib.MODE_RELAXED_PDHG and pdhg_warm else None)
+        self._pdhg_warm = bool(pdhg_warm) and self.mode == _lib.MODE_RELAXED_PDHG
+        self.pdhg_dual = None
         self.pdhg = PDHG()
         self.lib.revs_pdhg_defaults(C.byref(self.pdhg))
         if pdhg:
             for k, v in pdhg.items():
                 setattr(self.pdhg, k, v)
+        if self._pdhg_warm:      # one scalar per home, or one per SOC row with full_rows
+            self.pdhg_dual = torch.zeros((n, T) if self.pdhg.full_rows else (n,), **f32)
 
         # ---- operator setup (host, double) ----
         # Voltage row m is scaled by sqrt(n_m) (bounds too), so the operator matrix

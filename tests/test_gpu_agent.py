@@ -126,18 +126,31 @@ def test_relaxed_matches_oracle(gpu_lib, T, mode):
     assert r["resid"][3] == 0.0
 
 
-def test_pdhg_follows_oracle_iteration(gpu_lib):
-    """Same PDHG, same step sizes, fixed 64 iterations: kernel vs float32 numpy."""
+@pytest.mark.parametrize("full_rows", [0, 1])
+def test_pdhg_follows_oracle_iteration(gpu_lib, full_rows):
+    """Same PDHG, same step sizes, fixed 64 iterations: kernel vs float32 numpy, for the
+    presolved single-row form (default) and the full SOC rows."""
     from oracle import revs_oracle as ro
     n, T = 512, 24
     w, oh = _prep(n, T, seed=7, binary_feasible=False)
     pe_old, pe_new, ps, gm = _state(w, 3)
     r = _run_agent(gpu_lib, w, pe_old, pe_new, ps, gm, "pdhg",
-                   dict(max_iter=64, check=64, tol=0.0))
+                   dict(max_iter=64, check=64, tol=0.0, full_rows=full_rows))
     p, *_ = ro.home_solve_relaxed_pdhg(w.cost, oh, pe_old, ps, gm, w.kappa, iters=64, tol=0.0,
-                                       check=64, dtype=np.float32)
+                                       check=64, dtype=np.float32, full_rows=bool(full_rows))
     assert np.abs(r["S"] - p).max() < 5e-4
     assert ((r["status"] >> 8)[oh.ev] == 64).all()
+
+
+@pytest.mark.parametrize("T", [24, 96])
+def test_pdhg_full_rows_matches_oracle(gpu_lib, T):
+    """PDHG with every SOC row kept (full_rows=1) reaches the same optimum."""
+    from oracle import revs_oracle as ro
+    w, oh = _prep(1500, T, seed=40 + T, binary_feasible=False)
+    pe_old, pe_new, ps, gm = _state(w, T)
+    r = _run_agent(gpu_lib, w, pe_old, pe_new, ps, gm, "pdhg", dict(full_rows=1))
+    p, *_ = ro.home_solve_relaxed(w.cost, oh, pe_old, ps, gm, w.kappa)
+    assert np.abs(r["S"] - p).max() < 2e-4 * 7.2
 
 
 def test_no_ev_and_ragged(gpu_lib):
@@ -195,7 +208,7 @@ def test_pdhg_warm_start(gpu_lib):
     w, oh = _prep(n, T, seed=21, binary_feasible=False)
     pe_old, pe_new, ps, gm = _state(w, 5)
     cold = _run_agent(gpu_lib, w, pe_old, pe_new, ps, gm, "pdhg")
-    yd = torch.zeros(n, T, dtype=torch.float32, device="cuda:0")
+    yd = torch.zeros(n, dtype=torch.float32, device="cuda:0")        # one multiplier per home
     first = _run_agent(gpu_lib, w, pe_old, pe_new, ps, gm, "pdhg", ydual=yd)
     # same problem again, now starting from its own solution and multipliers
     again = _run_agent(gpu_lib, w, pe_old, pe_new, first["P_sch"], gm, "pdhg", ydual=yd)
