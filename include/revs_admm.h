@@ -217,6 +217,18 @@ int revs_op_home_pass(int32_t m, int32_t T, const int64_t *node_ptr,
                       const double *xc, const double *rho_b, double kappa, double alpha,
                       double *rhat, const double *cty_node, double *res, void *stream);
 
+/* revs_op_node_update (below) followed by revs_op_home_pass, in ONE launch: the workgroup
+ * of node m first updates row m of (xc, z_v, y_v, w) from the products va, usa (nslab
+ * slabs each) and the current rhat, then runs the home pass with that xc.  No residuals
+ * in this form: the checking iteration of a block uses the two separate calls. */
+int revs_op_home_pass_fused(int32_t m, int32_t T, const int64_t *node_ptr,
+                            const double *inv_sqrt_n, double *sb, const double *g0,
+                            const double *rho_b, double kappa, double alpha, double *rhat,
+                            int32_t nslab, const double *va, const double *usa,
+                            const double *rho_v, const double *bound_scale, double vlo,
+                            double vhi, double *xc, double *zv, double *yv, double *w,
+                            void *stream);
+
 /* Node passes (double[m][T]; s double[m] singular values; rho_v, rho_b double[T]):
  *   revs_op_node_w:      w  = rho_v z_v - y_v
  *   revs_op_row_scale:   out = s (per row) * in

@@ -58,6 +58,8 @@ SIGNATURES = {
     "revs_op_init_node": (C.c_int, [_i32, _i32, _p, _p, _p, _f64, _f64, _p, _p, _p, _p]),
     "revs_op_home_pass": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p, _p, _f64, _f64, _p, _p, _p,
                                     _p]),
+    "revs_op_home_pass_fused": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p, _f64, _f64, _p, _i32, _p,
+                                          _p, _p, _p, _f64, _f64, _p, _p, _p, _p, _p]),
     "revs_op_node_w": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p]),
     "revs_op_row_scale": (C.c_int, [_i32, _i32, _p, _p, _p, _p]),
     "revs_op_node_scale": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _p, _p, _f64, _p, _p, _p]),

@@ -84,12 +84,22 @@ __global__ void aggregate_kernel(int m, int Ts, const int64_t *node_ptr, const T
 // (contiguous doubles of one home), HS = 256/TL "home lanes" stride over the node's
 // homes, so a node with 49 homes keeps 8 loads per array in flight per slot lane instead
 // of one; the HS partial sums are combined through LDS in a fixed order (reproducible).
+// With `nu` (node-update operands) the workgroup first performs op_node_update for ITS
+// node row -- xc, z_v, y_v, w from the products va, usa -- and keeps xc in LDS: the node
+// pass and its launch disappear from the iteration.
+struct NodeUpd {
+    const double *va, *usa, *rho_v, *bscale;
+    double *zv, *yv, *w, *xc_out;
+    double vlo, vhi;
+    int nslab;
+};
+
 template <int TL>
 __global__ __launch_bounds__(256) void op_home_pass_kernel(
         int m, int T, const int64_t *__restrict__ node_ptr, const double *__restrict__ inv_sqrt_n,
         double *__restrict__ sb, const double *__restrict__ g0, const double *__restrict__ xc,
         const double *__restrict__ rho_b, double kappa, double alpha, double *__restrict__ rhat,
-        const double *__restrict__ cty, double *__restrict__ res) {
+        const double *__restrict__ cty, double *__restrict__ res, const NodeUpd nu) {
     constexpr int HS = 256 / TL;
     const int node = blockIdx.x;
     const int t = threadIdx.x % TL, hs = threadIdx.x / TL;
@@ -99,7 +109,29 @@ __global__ __launch_bounds__(256) void op_home_pass_kernel(
     const double rb = rho_b[tc];
     const double inv_c = 1.0 / (kappa + rb), inv_rb = 1.0 / rb;
     const double isn = inv_sqrt_n[node];
-    const double corr = xc ? isn * xc[idx] : 0.0;
+    __shared__ double xc_s[TL];
+    if (nu.va) {
+        if (hs == 0 && tok) {
+            const int64_t total = (int64_t)m * T;
+            double vav = nu.va[idx], zt = nu.usa[idx];
+            for (int q = 1; q < nu.nslab; ++q) { vav += nu.va[idx + q * total]; zt += nu.usa[idx + q * total]; }
+            const double rv = nu.rho_v[t];
+            const double xcv = vav - rhat[idx] * inv_c;
+            const double h = alpha * zt + (1.0 - alpha) * nu.zv[idx];
+            double y = nu.yv[idx];
+            const double bs = nu.bscale ? nu.bscale[node] : 1.0;
+            const double zn = fmin(fmax(h + y / rv, bs * nu.vlo), bs * nu.vhi);
+            y += rv * (h - zn);
+            nu.zv[idx] = zn;
+            nu.yv[idx] = y;
+            nu.w[idx] = rv * zn - y;
+            nu.xc_out[idx] = xcv;
+            xc_s[t] = xcv;
+        }
+        __syncthreads();
+    }
+    const double corr = nu.va ? isn * xc_s[tc] : (xc ? isn * xc[idx] : 0.0);
+    const bool upd = nu.va || xc;
     const double ct = res ? isn * cty[idx] : 0.0;
     double acc = 0.0, r1 = 0, r2 = 0, r5 = 0, r6 = 0, r7 = 0;
     const int64_t i0 = node_ptr[node], i1 = node_ptr[node + 1];
@@ -109,7 +141,7 @@ __global__ __launch_bounds__(256) void op_home_pass_kernel(
             const double sv = sb[o];
             const double kg = kappa * g0[o];
             double z = fmax(sv, 0.0), y = fmin(sv, 0.0);
-            if (xc) {
+            if (upd) {
                 const double xt = (kg + rb * z - y) * inv_c + corr;
                 const double u = alpha * xt + (1.0 - alpha) * z + y * inv_rb;
                 z = fmax(u, 0.0);
@@ -136,7 +168,7 @@ __global__ __launch_bounds__(256) void op_home_pass_kernel(
 #pragma unroll
         for (int k = 1; k < HS; ++k) a += red[0][k][t];
         rhat[idx] = isn * a;
-        if (res && xc) {
+        if (res && upd) {
             double q1 = 0, q2 = 0, q5 = 0, q6 = 0, q7 = 0;
 #pragma unroll
             for (int k = 0; k < HS; ++k) {
@@ -285,15 +317,42 @@ extern "C" int revs_op_home_pass(int32_t m, int32_t T, const int64_t *node_ptr,
                  "revs_op_home_pass: bad argument");
     REVS_REQUIRE(!res || (cty_node && xc), "revs_op_home_pass: res needs cty_node and xc");
     REVS_REQUIRE(T <= 256, "revs_op_home_pass: T=%d exceeds 256", T);
+    const NodeUpd nu{};
 #define HP(TL)                                                                                  \
     hipLaunchKernelGGL((op_home_pass_kernel<TL>), dim3(m), dim3(256), 0, S_(stream), m, T,      \
-                       node_ptr, inv_sqrt_n, sb, g0, xc, rho_b, kappa, alpha, rhat, cty_node, res)
+                       node_ptr, inv_sqrt_n, sb, g0, xc, rho_b, kappa, alpha, rhat, cty_node, res, nu)
     if (T <= 32) HP(32);
     else if (T <= 64) HP(64);
     else if (T <= 128) HP(128);
     else HP(256);
 #undef HP
     REVS_CHECK_LAUNCH("revs_op_home_pass");
+    return REVS_OK;
+}
+
+extern "C" int revs_op_home_pass_fused(int32_t m, int32_t T, const int64_t *node_ptr,
+                                       const double *inv_sqrt_n, double *sb, const double *g0,
+                                       const double *rho_b, double kappa, double alpha,
+                                       double *rhat, int32_t nslab, const double *va,
+                                       const double *usa, const double *rho_v,
+                                       const double *bound_scale, double vlo, double vhi,
+                                       double *xc, double *zv, double *yv, double *w,
+                                       void *stream) {
+    REVS_REQUIRE(m > 0 && T > 0 && T <= 256 && node_ptr && inv_sqrt_n && sb && g0 && rho_b && rhat,
+                 "revs_op_home_pass_fused: bad argument");
+    REVS_REQUIRE(nslab >= 1 && va && usa && rho_v && xc && zv && yv && w && vlo <= vhi,
+                 "revs_op_home_pass_fused: bad node-update argument");
+    const NodeUpd nu{va, usa, rho_v, bound_scale, zv, yv, w, xc, vlo, vhi, nslab};
+#define HP(TL)                                                                                  \
+    hipLaunchKernelGGL((op_home_pass_kernel<TL>), dim3(m), dim3(256), 0, S_(stream), m, T,      \
+                       node_ptr, inv_sqrt_n, sb, g0, (const double *)nullptr, rho_b, kappa,     \
+                       alpha, rhat, (const double *)nullptr, (double *)nullptr, nu)
+    if (T <= 32) HP(32);
+    else if (T <= 64) HP(64);
+    else if (T <= 128) HP(128);
+    else HP(256);
+#undef HP
+    REVS_CHECK_LAUNCH("revs_op_home_pass_fused");
     return REVS_OK;
 }
 

@@ -252,9 +252,20 @@ class AdmmEngine:
         _lib.check(rc, "revs_op_home_pass")
         self._allreduce(self.rhat)
 
-    def _node_half(self, check: bool = False):
+    def _home_pass_fused(self):
+        o = self.op
+        rc = self.lib.revs_op_home_pass_fused(
+            self.M, self.T, ptr(self.node_ptr), ptr(self.inv_sqrt_n), ptr(self.sb), ptr(self.g0),
+            ptr(self.rho_b), self.kappa, o.alpha, ptr(self.rhat), self.ksplit, ptr(self.va),
+            ptr(self.usa), ptr(self.rho_v), ptr(self.sqrt_n), self.vlo, self.vhi, ptr(self.xc),
+            ptr(self.zv), ptr(self.yv), ptr(self.w), self.stream)
+        _lib.check(rc, "revs_op_home_pass_fused")
+        self._allreduce(self.rhat)
+
+    def _node_half(self, check: bool = False, fuse: bool = False):
         """rhat -> xc, and the z_v / y_v update (GEMMs on the f64 matrix cores).  On a
-        checking iteration also the node-side residual maxima and cty = C_v^T y_v."""
+        checking iteration also the node-side residual maxima and cty = C_v^T y_v.  With
+        `fuse` the node update is left to the following fused home pass."""
         o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
         ks = self.ksplit
         self._gemm_cat(self.Q, self.rhat, self.w, self.ta, self.tb)        # Q^T [rhat | w]
@@ -262,6 +273,8 @@ class AdmmEngine:
                                           ptr(self.rho_v), ptr(self.rho_b), self.kappa,
                                           ptr(self.a), ptr(self.sa), st), "revs_op_node_scale")
         self._gemm_cat(self.QT, self.a, self.sa, self.va, self.usa)        # Q [a | l a]
+        if fuse:
+            return
         _lib.check(lib.revs_op_node_update(M, T, ks, ptr(self.va), ptr(self.rhat), ptr(self.usa),
                                            ptr(self.rho_v), ptr(self.rho_b), ptr(self.sqrt_n),
                                            self.kappa, o.alpha, self.vlo, self.vhi, ptr(self.xc),
@@ -287,9 +300,12 @@ class AdmmEngine:
         def body():
             self.res_out.zero_()
             for k in range(n_it):
-                last = k == n_it - 1
-                self._node_half(check=last)
-                self._home_pass(with_update=True, check=last)
+                if k == n_it - 1:              # checking iteration: separate passes + residuals
+                    self._node_half(check=True)
+                    self._home_pass(with_update=True, check=True)
+                else:                          # node update fused into the home pass
+                    self._node_half(fuse=True)
+                    self._home_pass_fused()
 
         if not self.op.use_graph or self.dev.type != "cuda":
             return body()
@@ -308,14 +324,17 @@ class AdmmEngine:
             for chk in (False, True):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    self._node_half(check=chk)
+                    self._node_half(check=chk, fuse=not chk)
                 gs.append(g)
             self._graph = gs
         self.res_out.zero_()
         for k in range(n_it):
-            last = k == n_it - 1
-            self._graph[1 if last else 0].replay()
-            self._home_pass(with_update=True, check=last)
+            if k == n_it - 1:
+                self._graph[1].replay()
+                self._home_pass(with_update=True, check=True)
+            else:
+                self._graph[0].replay()
+                self._home_pass_fused()
 
     def _residuals(self):
         self._allreduce(self.res_out, torch.distributed.ReduceOp.MAX if self.group else None)

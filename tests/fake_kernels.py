@@ -127,6 +127,13 @@ class FakeKernels:
         view(rhat, (m, T), np.float64)[:] = isn_[:, None] * acc
         return 0
 
+    def revs_op_home_pass_fused(self, m, T, node_ptr, isn, sb, g0, rho_b, kappa, alpha, rhat, nslab,
+                                va, usa, rho_v, bscale, vlo, vhi, xc, zv, yv, w, stream):
+        self.revs_op_node_update(m, T, nslab, va, rhat, usa, rho_v, rho_b, bscale, kappa, alpha,
+                                 vlo, vhi, xc, zv, yv, w, None, stream)
+        return self.revs_op_home_pass(m, T, node_ptr, isn, sb, g0, xc, rho_b, kappa, alpha, rhat,
+                                      None, None, stream)
+
     def revs_op_row_scale(self, m, T, s, inp, out, stream):
         view(out, (m, T), np.float64)[:] = view(s, (m,), np.float64)[:, None] * \
             view(inp, (m, T), np.float64)
