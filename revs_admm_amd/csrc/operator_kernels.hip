@@ -224,25 +224,46 @@ __global__ void op_node_update_kernel(int total, int T, int nslab, const double 
                                       double alpha, double vlo, double vhi, double *xc,
                                       double *zv, double *yv, double *w, double *res) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const int t = i % T;
-    const double rv = rho_v[t];
-    const double c = kappa + rho_b[t];
-    double vav = va[i], zt = usa[i];
-    for (int q = 1; q < nslab; ++q) { vav += va[i + (int64_t)q * total]; zt += usa[i + (int64_t)q * total]; }
-    xc[i] = vav - rhat[i] / c;
-    const double h = alpha * zt + (1.0 - alpha) * zv[i];
-    double y = yv[i];
-    const double bs = bscale ? bscale[i / T] : 1.0;
-    const double zn = fmin(fmax(h + y / rv, bs * vlo), bs * vhi);
-    y += rv * (h - zn);
-    zv[i] = zn;
-    yv[i] = y;
-    w[i] = rv * zn - y;
+    // residual maxima are merged per workgroup in LDS first (49k threads hammering 3 x T
+    // global words cost 45 us), then one global atomic per (workgroup, slot)
+    __shared__ unsigned long long smax[3][256];
     if (res) {
-        atomic_max_nonneg(res + 0 * T + t, fabs(zt - zn));
-        atomic_max_nonneg(res + 3 * T + t, fabs(zt));
-        atomic_max_nonneg(res + 4 * T + t, fabs(zn));
+        smax[0][threadIdx.x] = 0; smax[1][threadIdx.x] = 0; smax[2][threadIdx.x] = 0;
+        __syncthreads();
+    }
+    const bool live = i < total;
+    const int t = live ? i % T : 0;
+    double r0 = 0, r3 = 0, r4 = 0;
+    if (live) {
+        const double rv = rho_v[t];
+        const double c = kappa + rho_b[t];
+        double vav = va[i], zt = usa[i];
+        for (int q = 1; q < nslab; ++q) { vav += va[i + (int64_t)q * total]; zt += usa[i + (int64_t)q * total]; }
+        xc[i] = vav - rhat[i] / c;
+        const double h = alpha * zt + (1.0 - alpha) * zv[i];
+        double y = yv[i];
+        const double bs = bscale ? bscale[i / T] : 1.0;
+        const double zn = fmin(fmax(h + y / rv, bs * vlo), bs * vhi);
+        y += rv * (h - zn);
+        zv[i] = zn;
+        yv[i] = y;
+        w[i] = rv * zn - y;
+        r0 = fabs(zt - zn); r3 = fabs(zt); r4 = fabs(zn);
+    }
+    if (res) {
+        const int slot = t % 256;
+        if (live) {
+            atomicMax(&smax[0][slot], (unsigned long long)__double_as_longlong(r0));
+            atomicMax(&smax[1][slot], (unsigned long long)__double_as_longlong(r3));
+            atomicMax(&smax[2][slot], (unsigned long long)__double_as_longlong(r4));
+        }
+        __syncthreads();
+        const int tt = threadIdx.x;
+        if (tt < T && tt < 256) {
+            atomicMax(reinterpret_cast<unsigned long long *>(res + 0 * T + tt), smax[0][tt]);
+            atomicMax(reinterpret_cast<unsigned long long *>(res + 3 * T + tt), smax[1][tt]);
+            atomicMax(reinterpret_cast<unsigned long long *>(res + 4 * T + tt), smax[2][tt]);
+        }
     }
 }
 
@@ -395,6 +416,7 @@ extern "C" int revs_op_node_update(int32_t m, int32_t T, int32_t nslab, const do
     REVS_REQUIRE(m > 0 && T > 0 && nslab >= 1 && va && rhat && usa && rho_v && rho_b && xc && zv &&
                  yv && w, "revs_op_node_update: bad argument");
     REVS_REQUIRE(vlo <= vhi, "revs_op_node_update: vlo > vhi");
+    REVS_REQUIRE(T <= 256, "revs_op_node_update: T=%d exceeds 256", T);
     hipLaunchKernelGGL(op_node_update_kernel, grid1((int64_t)m * T), dim3(256), 0, S_(stream),
                        m * T, T, nslab, va, rhat, usa, rho_v, rho_b, bound_scale, kappa, alpha, vlo,
                        vhi, xc, zv, yv, w, res);

@@ -53,5 +53,6 @@ def gpu_lib():
     import torch
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
-    from revs_admm_amd import _lib
+    from revs_admm_amd import _lib, build
+    build.build()               # no-op when librevs_admm.so is up to date (hipcc, gfx950)
     return _lib.load()          # raises if the HIP library is missing: no fallback

@@ -229,3 +229,22 @@ def test_full_size_invariants(gpu_lib):
     v = e.voltage(e.P_est).cpu().numpy()
     assert pe.min() >= 0 and v.max() <= e.vhi * (1 + 1e-4)
     assert e.residuals(1e-4)[2] == pytest.approx(np.max(np.linalg.norm(chk, axis=1) / 24), rel=1e-4)
+
+
+def test_relaxed_trajectory_T96(gpu_lib):
+    """15-minute slots (BASELINE config 4/5 shape): T = 96 uses the 32-lane home groups and
+    the 192-column concatenated product; trajectory vs oracle as for T = 24."""
+    from helpers import f32, oracle_homes
+    from oracle import revs_oracle as ro
+    from revs_admm_amd.synthetic import make_workload
+    w = make_workload(300, 96, n_nodes=40, seed=17, binary_feasible=False, stress=1.25)
+    w.load, w.cost = f32(w.load), f32(w.cost)
+    e = _engine(w, "pdhg")
+    assert e.cat and e.T == 96
+    diffs = e.run(5)
+    P_sch, S, C = e.result()
+    d_ref, P_ref, S_ref, C_ref = ro.solve_ADMM(oracle_homes(w), w.Rn, w.node_of, w.cost, w.kappa, 5,
+                                               w.vset, w.vlow, w.vhigh, mode="relaxed",
+                                               util_eps=1e-10)
+    assert np.abs(diffs - d_ref).max() < 1e-3 * max(1.0, d_ref.max())
+    assert np.abs(S - S_ref).max() < 2e-3 and np.abs(C - C_ref).max() < 2e-4
