@@ -150,6 +150,10 @@ def main():
         opts.alpha = args.op_alpha
     if args.op_adapt is not None:
         opts.adapt_every = args.op_adapt
+    if os.environ.get("REVS_CAL_RHO_B"):
+        opts.cal_rho_b = tuple(float(x) for x in os.environ["REVS_CAL_RHO_B"].split(","))
+    if os.environ.get("REVS_CAL_RHO_V"):
+        opts.cal_rho_v = tuple(float(x) for x in os.environ["REVS_CAL_RHO_V"].split(","))
     eng = AdmmEngine(w.cost, w.homes[lo:hi], w.load[lo:hi], w.node_of[lo:hi], w.Rn, kappa=w.kappa,
                      vset=w.vset, vlow=w.vlow, vhigh=w.vhigh, mode=args.mode, device=dev,
                      group=group, node_counts=counts, op=opts)

@@ -23,7 +23,6 @@
 // for float.  `batch` independent products can share one launch (gridDim.y), which
 // is how the operator issues V^T rhat with U^T w, and V a with U (s a).
 #include "common.h"
-#include <stdlib.h>
 
 namespace revs {
 
@@ -250,7 +249,7 @@ static int launch_gemm(int m, int n, int k, int nbatch, int ksplit, const GemmBa
                        m, n, k, b, lda, ldb, ldc, accumulate)
     if (nt <= 1) LAUNCH(1, 2, 16, 4);
     else if (nt <= 2) LAUNCH(2, 2, 16, 4);
-    else if (nt <= 3) { if (getenv("REVS_GEMM_W8")) LAUNCH(3, 2, 8, 4); else LAUNCH(3, 2, 16, 2); }
+    else if (nt <= 3) LAUNCH(3, 2, 16, 2);
     else if (nt <= 4) LAUNCH(4, 1, 8, 2);
     else if (nt <= 6) LAUNCH(6, 1, 8, 2);
     else if (nt <= 8) LAUNCH(8, 1, 8, 1);

@@ -377,6 +377,7 @@ class AdmmEngine:
         for t, c in zip((self.sb, self.zv, self.yv), snap):
             t.copy_(c)
         self.rho_scales = best[1:]
+        self.cal_score = best[0]
         self._set_rho(*self.rho_scales)
         self._calibrated = True
         return spent
