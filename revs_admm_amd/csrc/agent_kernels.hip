@@ -168,7 +168,13 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
             x[j] = a.y_state ? fminf(fmaxf((pso[j] - L[j]) / rate, 0.f), w[j]) : 0.f;
             y[j] = (a.pd.full_rows && a.y_state && valid[j] && ev) ? a.y_state[row + t0 + j] : 0.f;
         }
-        bool done = !ev;
+        // the window cannot deliver the energy to 90 % SOC: "No solution found"
+        float wsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) wsum += w[j];
+        wsum = group_sum<LPA>(wsum);
+        const bool infeasible = ev && (lo_last > delta * wsum * (1.f + 1e-6f));
+        bool done = !ev || infeasible;
         int iters = 0;
         const int check = max(a.pd.check, 1);
         if (!a.pd.full_rows) {
@@ -265,8 +271,8 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
             if (a.y_state && valid[j]) a.y_state[row + t0 + j] = ev ? y[j] : 0.f;
         }
 #pragma unroll
-        for (int j = 0; j < SPL; ++j) p[j] = ev ? x[j] * h.rating : 0.f;
-        status = iters << 8;
+        for (int j = 0; j < SPL; ++j) p[j] = (ev && !infeasible) ? x[j] * h.rating : 0.f;
+        status = (iters << 8) | (infeasible ? 1 : 0);
     } else {
         // closed form: p_t = clip(u_t + nu, 0, ub_t), u = -q/kappa; nu is the
         // multiplier of the terminal SOC rows (the only ones that can bind when

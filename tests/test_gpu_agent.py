@@ -217,3 +217,45 @@ def test_pdhg_warm_start(gpu_lib):
     it_cold = (cold["status"] >> 8)[oh.ev].mean()
     it_warm = (again["status"] >> 8)[oh.ev].mean()
     assert it_warm < 0.95 * it_cold, (it_cold, it_warm)
+
+
+@pytest.mark.parametrize("mode", ["binary", "relaxed_exact", "pdhg"])
+def test_edge_parameters(gpu_lib, mode):
+    """Residences the reference would accept but rarely sees: already charged past 90 %
+    (no slot needed), windows reaching outside the horizon, one-slot windows, T = 1, 2, 3."""
+    from helpers import f32, oracle_homes
+    from oracle import revs_oracle as ro
+    from revs_admm_amd.engine import pack_homes
+    from revs_admm_amd.synthetic import Workload
+    rng = np.random.default_rng(3)
+    for T in (1, 2, 3, 24):
+        n = 96
+        ev = np.ones(n, bool)
+        ev[::7] = False
+        rating = rng.choice([3.6, 7.2], n)
+        cap = rng.choice([20.0, 60.0], n)
+        init = rng.choice([0.05, 0.5, 0.91, 0.97], n)
+        start = rng.integers(-3, max(T - 1, 1), n)
+        end = start + rng.integers(1, T + 6, n)
+        homes = pack_homes(ev, rating, cap, init, start, end)
+        load = f32(rng.uniform(0.2, 5, (n, T)))
+        cost = f32(rng.uniform(0.05, 0.3, T))
+        w = Workload(cost, load, homes, np.zeros(n, np.int64), np.eye(1), None, None, 1.0, 0.95,
+                     1.05, 5.0)
+        oh = oracle_homes(w)
+        pe_old, pe_new, ps, gm = _state(w, T)
+        r = _run_agent(gpu_lib, w, pe_old, pe_new, ps, gm, mode)
+        solve = ro.home_solve_binary if mode == "binary" else ro.home_solve_relaxed
+        p, s, g, st = solve(w.cost, oh, pe_old, ps, gm, w.kappa)
+        assert ((r["status"] & 0xFF) == st).all()
+        ok = st == 0
+        if mode == "binary":
+            obj_g = ro.home_objective(w.cost, oh, r["S"], pe_old, ps, gm, w.kappa)
+            obj_r = ro.home_objective(w.cost, oh, p, pe_old, ps, gm, w.kappa)
+            assert np.max(np.abs(obj_g - obj_r)[ok] / np.maximum(1, np.abs(obj_r[ok]))) < 2e-5
+            assert ((r["S"] > 0).sum(1) == (p > 0).sum(1))[ok].all()
+        else:
+            assert np.abs(r["S"] - p)[ok].max() < 2e-3
+        assert (r["S"][~oh.window()] == 0).all()
+        assert (r["S"][~ok] == 0).all()                      # flagged homes get no schedule
+        np.testing.assert_allclose(r["C"][ok][:, 0], np.where(oh.ev, oh.initial, 0)[ok], atol=1e-6)

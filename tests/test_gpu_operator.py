@@ -204,3 +204,35 @@ def test_gemm_cat(gpu_lib, m, T, ks):
                                        torch.cuda.current_stream().cuda_stream))
     assert (C0.sum(0).cpu().numpy() == A.T @ B0).all()
     assert (C1.sum(0).cpu().numpy() == A.T @ B1).all()
+
+
+def test_operator_edge_topologies(gpu_lib):
+    """One node carrying every residence; nodes without residences (their voltage rows
+    drop out, as in the reference's R_res); a residence count of 1."""
+    from helpers import f32
+    from oracle import revs_oracle as ro
+    from revs_admm_amd.synthetic import make_workload
+    rng = np.random.default_rng(2)
+    for n, M, node_of in ((40, 1, np.zeros(40, np.int64)),
+                          (30, 12, np.sort(rng.choice([1, 4, 5, 9], 30))),
+                          (1, 3, np.array([2]))):
+        w = make_workload(n, 12, n_nodes=M, seed=n, stress=1.3)
+        w.node_of = node_of.astype(np.int64)
+        ps = f32(w.load + rng.uniform(0, 3, (n, 12)))
+        pe = f32(ps * rng.uniform(0.7, 1.1, (n, 12)))
+        gm = f32(rng.normal(0, 2.0, (n, 12)))
+        A = np.zeros((M, n)); A[w.node_of, np.arange(n)] = 1
+        used = np.unique(w.node_of)
+        w.Rn = w.Rn * (1.3 * (w.vhigh ** 2 - w.vset ** 2) / (w.Rn[used] @ (A @ ps)).max())
+        e = _engine(w)
+        _set_state(e, pe, ps, gm)
+        assert e.operator_solve()
+        got = e.P_est_new.cpu().numpy()[e.inv_perm].astype(np.float64)
+        g0 = ro.utility_g0(pe, ps, gm, w.kappa)
+        vlo, vhi = ro.voltage_limits(w.vset, w.vlow, w.vhigh)
+        # the engine constrains the nodes that carry residences
+        sub = {m: i for i, m in enumerate(used)}
+        ref = ro.utility_solve(w.Rn[np.ix_(used, used)], np.array([sub[m] for m in w.node_of]), g0,
+                               w.kappa, vlo, vhi)
+        assert np.abs(ref - np.maximum(g0, 0)).max() > 1e-3
+        assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
