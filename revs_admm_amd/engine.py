@@ -242,7 +242,7 @@ class AdmmEngine:
                 t, op=op or torch.distributed.ReduceOp.SUM, group=self.group)
 
     # -------------------------------------------------------------- operator
-    def _home_pass(self, with_update: bool, check: bool = False):
+    def _home_pass(self, with_update: bool, check: bool = False, reduce: bool = True):
         o = self.op
         rc = self.lib.revs_op_home_pass(
             self.M, self.T, ptr(self.node_ptr), ptr(self.inv_sqrt_n), ptr(self.sb), ptr(self.g0),
@@ -250,9 +250,10 @@ class AdmmEngine:
             ptr(self.rhat), ptr(self.cty) if check else None,
             ptr(self.res_out) if check else None, self.stream)
         _lib.check(rc, "revs_op_home_pass")
-        self._allreduce(self.rhat)
+        if reduce:
+            self._allreduce(self.rhat)
 
-    def _home_pass_fused(self):
+    def _home_pass_fused(self, reduce: bool = True):
         o = self.op
         rc = self.lib.revs_op_home_pass_fused(
             self.M, self.T, ptr(self.node_ptr), ptr(self.inv_sqrt_n), ptr(self.sb), ptr(self.g0),
@@ -260,7 +261,8 @@ class AdmmEngine:
             ptr(self.usa), ptr(self.rho_v), ptr(self.sqrt_n), self.vlo, self.vhi, ptr(self.xc),
             ptr(self.zv), ptr(self.yv), ptr(self.w), self.stream)
         _lib.check(rc, "revs_op_home_pass_fused")
-        self._allreduce(self.rhat)
+        if reduce:
+            self._allreduce(self.rhat)
 
     def _node_half(self, check: bool = False, fuse: bool = False):
         """rhat -> xc, and the z_v / y_v update (GEMMs on the f64 matrix cores).  On a
@@ -292,9 +294,9 @@ class AdmmEngine:
         maxima.  hipGraphs (through torch.cuda.CUDAGraph: the ctypes launches go to torch's
         current stream, which is the capture stream) cut the host work:
           * one GPU: the whole block is one graph -- one host call per 25 iterations;
-          * sharded: the node half (2 products + 2 node passes, no communication) is a
-            graph, the home pass and the RCCL all-reduce of rhat stay eager, so an
-            iteration is 3 host calls instead of 6 and no collective is ever captured."""
+          * sharded: one iteration's kernels (2 products, node scale, fused home pass) are
+            a graph and only the RCCL all-reduce of rhat between iterations stays eager:
+            2 host calls per iteration, and no collective is ever captured."""
         n_it = self.op.check_every
 
         def body():
@@ -325,16 +327,16 @@ class AdmmEngine:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self._node_half(check=chk, fuse=not chk)
+                    if chk:
+                        self._home_pass(with_update=True, check=True, reduce=False)
+                    else:
+                        self._home_pass_fused(reduce=False)
                 gs.append(g)
             self._graph = gs
         self.res_out.zero_()
         for k in range(n_it):
-            if k == n_it - 1:
-                self._graph[1].replay()
-                self._home_pass(with_update=True, check=True)
-            else:
-                self._graph[0].replay()
-                self._home_pass_fused()
+            self._graph[1 if k == n_it - 1 else 0].replay()
+            self._allreduce(self.rhat)
 
     def _residuals(self):
         self._allreduce(self.res_out, torch.distributed.ReduceOp.MAX if self.group else None)
