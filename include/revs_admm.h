@@ -151,6 +151,10 @@ int revs_gemm_tn_f64(int32_t m, int32_t n, int32_t k, const double *At, int32_t 
 int revs_gemm_tn_f32(int32_t m, int32_t n, int32_t k, const float *At, int32_t lda,
                      const float *B, int32_t ldb, float *C, int32_t ldc,
                      int32_t accumulate, void *stream);
+/* C = At^T B with dense leading dimensions, K cut over `ksplit` groups of workgroups:
+ * C holds ksplit partial slabs of m*n doubles (see _x2). */
+int revs_gemm_tn_f64_split(int32_t m, int32_t n, int32_t k, const double *At, const double *B,
+                           double *C, int32_t ksplit, void *stream);
 /* [C0 | C1] = At^T [B0 | B1]: one product whose right-hand side and result are each the
  * horizontal concatenation of two double[k][T] / double[m][T] arrays (2T <= 192), so
  * the matrix is streamed once for both.  With the voltage rows scaled by sqrt(n_m) the
@@ -258,6 +262,44 @@ int revs_op_node_update(int32_t m, int32_t T, int32_t nslab, const double *va,
                         double alpha, double vlo, double vhi,
                         double *xc, double *zv, double *yv, double *w, double *res,
                         void *stream);
+
+/* ---- node-space fast path of the operator QP ------------------------------------
+ * While no residence is pushed to g = 0 the problem collapses to the M constrained nodes:
+ * g = g0 + A~^T d, cost (kappa/2)|d|^2, rows b vlo <= Rs (p0 + d) <= b vhi, p0 = A~ g0,
+ * Rs = D^1/2 R D^1/2 = Q L Q^T.  ADMM on (x = p0 + d, z = Rs x) in the eigenbasis needs two
+ * T-column products per iteration, no home-space traffic and no communication; per OUTER
+ * iteration the ranks exchange only p0 (sum) and gmin (min).  The driver accepts the
+ * answer iff slack = gmin + isn d >= 0 everywhere, else it runs the general path above.
+ *
+ *   revs_op_node_prep      p0[m] = isn[m] sum_i g0_i, gmin[m] = min_i g0_i (double[m][T]),
+ *                          g0 = (P_est + P_sch)/2 - G/kappa from the float state;
+ *                          g0_out (double[n][T]) or NULL
+ *   revs_op_nodefast_scale  xh = (kappa ph0 + l wh)/(kappa + rho_v l^2), sx = l xh
+ *                           (wh = Q^T w as nslab slabs, ph0 = Q^T p0)
+ *   revs_op_nodefast_update z_v, y_v, w from zt = Q sx (nslab slabs); res rows 0,3,4
+ *   revs_op_nodefast_dualres res rows 2,5,6,7 from yh = Q^T y_v (nslab slabs), in the
+ *                           eigenbasis: |kappa (xh - ph0) + l yh|, kappa|xh| ...
+ *   revs_op_nodefast_finish d = Q xh - p0 (x as nslab slabs), slack = gmin + isn d
+ *   revs_op_node_apply      P_est_i = max(g0_i + isn[m] d[m], 0) as float              */
+int revs_op_node_prep(int32_t m, int32_t T, const int64_t *node_ptr, const double *inv_sqrt_n,
+                      const float *p_est, const float *p_sch, const float *gamma, double kappa,
+                      double *p0, double *gmin, double *g0_out, void *stream);
+int revs_op_nodefast_scale(int32_t m, int32_t T, int32_t nslab, const double *wh,
+                           const double *ph0, const double *lam, const double *rho_v,
+                           double kappa, double *xh, double *sx, void *stream);
+int revs_op_nodefast_update(int32_t m, int32_t T, int32_t nslab, const double *zt,
+                            const double *rho_v, const double *bound_scale, double alpha,
+                            double vlo, double vhi, double *zv, double *yv, double *w,
+                            double *res, void *stream);
+int revs_op_nodefast_dualres(int32_t m, int32_t T, int32_t nslab, const double *xh,
+                             const double *ph0, const double *lam, const double *yh,
+                             double kappa, double *res, void *stream);
+int revs_op_nodefast_finish(int32_t m, int32_t T, int32_t nslab, const double *x,
+                            const double *p0, const double *gmin, const double *inv_sqrt_n,
+                            double *d, double *slack, void *stream);
+int revs_op_node_apply(int32_t m, int32_t T, const int64_t *node_ptr, const double *inv_sqrt_n,
+                       const float *p_est, const float *p_sch, const float *gamma, double kappa,
+                       const double *d, float *p_est_new, void *stream);
 
 /* P_est = max(s_b, 0) as float: the operator's answer handed to the homes
  * (U_obj.g_opt, lpsolver.py:236-237, 259). */

@@ -48,6 +48,7 @@ SIGNATURES = {
     "revs_residence_solve": (C.c_int, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "revs_gemm_tn_f64": (C.c_int, [_i32, _i32, _i32, _p, _i32, _p, _i32, _p, _i32, _i32, _p]),
     "revs_gemm_tn_f32": (C.c_int, [_i32, _i32, _i32, _p, _i32, _p, _i32, _p, _i32, _i32, _p]),
+    "revs_gemm_tn_f64_split": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _i32, _p]),
     "revs_gemm_tn_f64_x2": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _i32, _p]),
     "revs_gemm_tn_f64_cat": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _p, _p, _i32, _p]),
     "revs_voltage_f32": (C.c_int, [_i32, _i32, _p, _p, _p, _p]),
@@ -65,6 +66,13 @@ SIGNATURES = {
     "revs_op_node_scale": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _p, _p, _f64, _p, _p, _p]),
     "revs_op_node_update": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _f64, _f64, _f64,
                                       _f64, _p, _p, _p, _p, _p, _p]),
+    "revs_op_node_prep": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p, _f64, _p, _p, _p, _p]),
+    "revs_op_nodefast_scale": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _p, _f64, _p, _p, _p]),
+    "revs_op_nodefast_update": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _f64, _f64, _f64, _p, _p,
+                                          _p, _p, _p]),
+    "revs_op_nodefast_dualres": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _p, _f64, _p, _p]),
+    "revs_op_nodefast_finish": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p]),
+    "revs_op_node_apply": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p, _f64, _p, _p, _p]),
     "revs_op_export": (C.c_int, [_i64, _i32, _p, _p, _p]),
 }
 

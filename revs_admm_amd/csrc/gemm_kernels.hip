@@ -271,6 +271,12 @@ extern "C" int revs_gemm_tn_f64(int32_t m, int32_t n, int32_t k, const double *A
                                "revs_gemm_tn_f64");
 }
 
+extern "C" int revs_gemm_tn_f64_split(int32_t m, int32_t n, int32_t k, const double *At,
+                                      const double *B, double *C, int32_t ksplit, void *stream) {
+    GemmBatch<double> b{{{At, B, C, nullptr, nullptr, n}, {}}};
+    return launch_gemm<double>(m, n, k, 1, ksplit, b, m, n, n, 0, stream, "revs_gemm_tn_f64_split");
+}
+
 extern "C" int revs_gemm_tn_f64_x2(int32_t m, int32_t n, int32_t k, const double *At0,
                                    const double *B0, double *C0, const double *At1,
                                    const double *B1, double *C1, int32_t ksplit, void *stream) {

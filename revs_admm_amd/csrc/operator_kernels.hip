@@ -273,6 +273,179 @@ __global__ void op_export_kernel(int64_t total, const double *sb, float *pe) {
     if (i < total) pe[i] = (float)fmax(sb[i], 0.0);
 }
 
+// ---------------------------------------------------------------------------
+// Node-space fast path.  While no residence is pushed to g = 0, the operator QP
+// collapses to the constrained nodes: g = g0 + A~^T d with node correction d (M x T),
+// cost (kappa/2)|d|^2, rows blo <= Rs (p0 + d) <= bhi, p0 = A~ g0.  ADMM on (x = p0 + d,
+// z = Rs x) in the eigenbasis of Rs = Q L Q^T:
+//     xh  = (kappa ph0 + l wh) / (kappa + rho l^2)        wh = Q^T (rho z - y)
+//     zt  = Q (l xh)
+//     z   = clip(alpha zt + (1-alpha) z + y/rho), y += rho (alpha zt + (1-alpha) z_old - z)
+// Two T-column products per iteration, no home-space traffic and -- with residences
+// sharded -- no communication: the only exchange per OUTER iteration is the all-reduce
+// of p0 (sum) and gmin (min).  Afterwards min_i g0_i + isn d >= 0 is checked per node;
+// if a clamp would be active the caller falls back to the general home-space ADMM.
+
+// p0[m][t] = isn[m] * sum_i g0_i[t],  gmin[m][t] = min_i g0_i[t],  g0 from the float state.
+// g0_out (or NULL) also stores g0 in double for the general path.
+template <int TL>
+__global__ __launch_bounds__(256) void op_node_prep_kernel(
+        int m, int T, const int64_t *__restrict__ node_ptr, const double *__restrict__ inv_sqrt_n,
+        const float *__restrict__ pe, const float *__restrict__ ps, const float *__restrict__ gm,
+        double kappa, double *__restrict__ p0, double *__restrict__ gmin,
+        double *__restrict__ g0_out) {
+    constexpr int HS = 256 / TL;
+    const int node = blockIdx.x;
+    const int t = threadIdx.x % TL, hs = threadIdx.x / TL;
+    const bool tok = t < T;
+    double acc = 0.0, mn = INFINITY;
+    const int64_t i0 = node_ptr[node], i1 = node_ptr[node + 1];
+    const double inv_k = 1.0 / kappa;
+    if (tok) {
+        for (int64_t i = i0 + hs; i < i1; i += HS) {
+            const int64_t o = i * T + t;
+            const double g = 0.5 * ((double)pe[o] + (double)ps[o]) - (double)gm[o] * inv_k;
+            if (g0_out) g0_out[o] = g;
+            acc += g;
+            mn = fmin(mn, g);
+        }
+    }
+    __shared__ double red[2][HS][TL];
+    red[0][hs][t] = acc;
+    red[1][hs][t] = mn;
+    __syncthreads();
+    if (hs == 0 && tok) {
+        double a = red[0][0][t], b = red[1][0][t];
+#pragma unroll
+        for (int k = 1; k < HS; ++k) { a += red[0][k][t]; b = fmin(b, red[1][k][t]); }
+        p0[node * T + t] = inv_sqrt_n[node] * a;
+        gmin[node * T + t] = b;
+    }
+}
+
+// xh = (kappa ph0 + l wh) / (kappa + rho_v l^2) ;  sx = l xh      (wh as nslab slabs)
+__global__ void op_nodefast_scale_kernel(int total, int T, int nslab, const double *wh,
+                                         const double *ph0, const double *lam,
+                                         const double *rho_v, double kappa, double *xh,
+                                         double *sx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int j = i / T, t = i - j * T;
+    const double l = lam[j];
+    double w = wh[i];
+    for (int q = 1; q < nslab; ++q) w += wh[i + (int64_t)q * total];
+    const double x = (kappa * ph0[i] + l * w) / (kappa + rho_v[t] * l * l);
+    xh[i] = x;
+    sx[i] = l * x;
+}
+
+// z / y / w update from zt = Q (l xh) (nslab slabs); with res: rows 0,3,4 = max|zt - z|, |zt|, |z|
+__global__ void op_nodefast_update_kernel(int total, int T, int nslab, const double *zt_s,
+                                          const double *rho_v, const double *bscale,
+                                          double alpha, double vlo, double vhi, double *zv,
+                                          double *yv, double *w, double *res) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ unsigned long long smax[3][256];
+    if (res) {
+        smax[0][threadIdx.x] = 0; smax[1][threadIdx.x] = 0; smax[2][threadIdx.x] = 0;
+        __syncthreads();
+    }
+    const bool live = i < total;
+    const int t = live ? i % T : 0;
+    double r0 = 0, r3 = 0, r4 = 0;
+    if (live) {
+        double zt = zt_s[i];
+        for (int q = 1; q < nslab; ++q) zt += zt_s[i + (int64_t)q * total];
+        const double rv = rho_v[t];
+        const double h = alpha * zt + (1.0 - alpha) * zv[i];
+        double y = yv[i];
+        const double bs = bscale ? bscale[i / T] : 1.0;
+        const double zn = fmin(fmax(h + y / rv, bs * vlo), bs * vhi);
+        y += rv * (h - zn);
+        zv[i] = zn;
+        yv[i] = y;
+        w[i] = rv * zn - y;
+        r0 = fabs(zt - zn); r3 = fabs(zt); r4 = fabs(zn);
+    }
+    if (res) {
+        if (live) {
+            atomicMax(&smax[0][t], (unsigned long long)__double_as_longlong(r0));
+            atomicMax(&smax[1][t], (unsigned long long)__double_as_longlong(r3));
+            atomicMax(&smax[2][t], (unsigned long long)__double_as_longlong(r4));
+        }
+        __syncthreads();
+        const int tt = threadIdx.x;
+        if (tt < T) {
+            atomicMax(reinterpret_cast<unsigned long long *>(res + 0 * T + tt), smax[0][tt]);
+            atomicMax(reinterpret_cast<unsigned long long *>(res + 3 * T + tt), smax[1][tt]);
+            atomicMax(reinterpret_cast<unsigned long long *>(res + 4 * T + tt), smax[2][tt]);
+        }
+    }
+}
+
+// dual residual in the eigenbasis: rows 2,5,6,7 = max |kappa (xh - ph0) + l yh|, kappa|xh|,
+// |l yh|, kappa|ph0|   (yh = Q^T y as nslab slabs).  Row 1 (bound rows) stays 0.
+__global__ void op_nodefast_dualres_kernel(int total, int T, int nslab, const double *xh,
+                                           const double *ph0, const double *lam,
+                                           const double *yh_s, double kappa, double *res) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ unsigned long long smax[4][256];
+    smax[0][threadIdx.x] = 0; smax[1][threadIdx.x] = 0; smax[2][threadIdx.x] = 0; smax[3][threadIdx.x] = 0;
+    __syncthreads();
+    const bool live = i < total;
+    const int t = live ? i % T : 0;
+    if (live) {
+        double yh = yh_s[i];
+        for (int q = 1; q < nslab; ++q) yh += yh_s[i + (int64_t)q * total];
+        const double ly = lam[i / T] * yh;
+        atomicMax(&smax[0][t], (unsigned long long)__double_as_longlong(fabs(kappa * (xh[i] - ph0[i]) + ly)));
+        atomicMax(&smax[1][t], (unsigned long long)__double_as_longlong(fabs(xh[i])));
+        atomicMax(&smax[2][t], (unsigned long long)__double_as_longlong(fabs(ly)));
+        atomicMax(&smax[3][t], (unsigned long long)__double_as_longlong(fabs(kappa * ph0[i])));
+    }
+    __syncthreads();
+    const int tt = threadIdx.x;
+    if (tt < T) {
+        atomicMax(reinterpret_cast<unsigned long long *>(res + 2 * T + tt), smax[0][tt]);
+        atomicMax(reinterpret_cast<unsigned long long *>(res + 5 * T + tt), smax[1][tt]);
+        atomicMax(reinterpret_cast<unsigned long long *>(res + 6 * T + tt), smax[2][tt]);
+        atomicMax(reinterpret_cast<unsigned long long *>(res + 7 * T + tt), smax[3][tt]);
+    }
+}
+
+// d = x - p0 (x as nslab slabs of Q xh); slack[m][t] = gmin + isn d  (>= 0 <=> no clamp)
+__global__ void op_nodefast_finish_kernel(int total, int T, int nslab, const double *x_s,
+                                          const double *p0, const double *gmin,
+                                          const double *inv_sqrt_n, double *d, double *slack) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    double x = x_s[i];
+    for (int q = 1; q < nslab; ++q) x += x_s[i + (int64_t)q * total];
+    const double dv = x - p0[i];
+    d[i] = dv;
+    slack[i] = gmin[i] + inv_sqrt_n[i / T] * dv;
+}
+
+// P_est_i = max(g0_i + isn[m] d[m], 0) as float, g0 recomputed from the float state
+template <int TL>
+__global__ __launch_bounds__(256) void op_node_apply_kernel(
+        int m, int T, const int64_t *__restrict__ node_ptr, const double *__restrict__ inv_sqrt_n,
+        const float *__restrict__ pe, const float *__restrict__ ps, const float *__restrict__ gm,
+        double kappa, const double *__restrict__ d, float *__restrict__ pe_new) {
+    constexpr int HS = 256 / TL;
+    const int node = blockIdx.x;
+    const int t = threadIdx.x % TL, hs = threadIdx.x / TL;
+    if (t >= T) return;
+    const double corr = inv_sqrt_n[node] * d[node * T + t];
+    const double inv_k = 1.0 / kappa;
+    const int64_t i0 = node_ptr[node], i1 = node_ptr[node + 1];
+    for (int64_t i = i0 + hs; i < i1; i += HS) {
+        const int64_t o = i * T + t;
+        const double g = 0.5 * ((double)pe[o] + (double)ps[o]) - (double)gm[o] * inv_k;
+        pe_new[o] = (float)fmax(g + corr, 0.0);
+    }
+}
+
 static inline dim3 grid1(int64_t total) { return dim3((unsigned)((total + 255) / 256)); }
 
 }  // namespace revs
@@ -430,5 +603,83 @@ extern "C" int revs_op_export(int64_t n_homes, int32_t T, const double *sb, floa
     const int64_t total = n_homes * T;
     hipLaunchKernelGGL(op_export_kernel, grid1(total), dim3(256), 0, S_(stream), total, sb, p_est);
     REVS_CHECK_LAUNCH("revs_op_export");
+    return REVS_OK;
+}
+
+#define REVS_TL_DISPATCH(T, KERNEL, ...)                                                        \
+    do {                                                                                        \
+        if ((T) <= 32) hipLaunchKernelGGL((KERNEL<32>), __VA_ARGS__);                           \
+        else if ((T) <= 64) hipLaunchKernelGGL((KERNEL<64>), __VA_ARGS__);                      \
+        else if ((T) <= 128) hipLaunchKernelGGL((KERNEL<128>), __VA_ARGS__);                    \
+        else hipLaunchKernelGGL((KERNEL<256>), __VA_ARGS__);                                    \
+    } while (0)
+
+extern "C" int revs_op_node_prep(int32_t m, int32_t T, const int64_t *node_ptr,
+                                 const double *inv_sqrt_n, const float *p_est, const float *p_sch,
+                                 const float *gamma, double kappa, double *p0, double *gmin,
+                                 double *g0_out, void *stream) {
+    REVS_REQUIRE(m > 0 && T > 0 && T <= 256 && node_ptr && inv_sqrt_n && p_est && p_sch && gamma &&
+                 p0 && gmin && kappa > 0, "revs_op_node_prep: bad argument");
+    REVS_TL_DISPATCH(T, op_node_prep_kernel, dim3(m), dim3(256), 0, S_(stream), m, T, node_ptr,
+                     inv_sqrt_n, p_est, p_sch, gamma, kappa, p0, gmin, g0_out);
+    REVS_CHECK_LAUNCH("revs_op_node_prep");
+    return REVS_OK;
+}
+
+extern "C" int revs_op_nodefast_scale(int32_t m, int32_t T, int32_t nslab, const double *wh,
+                                      const double *ph0, const double *lam, const double *rho_v,
+                                      double kappa, double *xh, double *sx, void *stream) {
+    REVS_REQUIRE(m > 0 && T > 0 && nslab >= 1 && wh && ph0 && lam && rho_v && xh && sx,
+                 "revs_op_nodefast_scale: bad argument");
+    hipLaunchKernelGGL(op_nodefast_scale_kernel, grid1((int64_t)m * T), dim3(256), 0, S_(stream),
+                       m * T, T, nslab, wh, ph0, lam, rho_v, kappa, xh, sx);
+    REVS_CHECK_LAUNCH("revs_op_nodefast_scale");
+    return REVS_OK;
+}
+
+extern "C" int revs_op_nodefast_update(int32_t m, int32_t T, int32_t nslab, const double *zt,
+                                       const double *rho_v, const double *bound_scale,
+                                       double alpha, double vlo, double vhi, double *zv,
+                                       double *yv, double *w, double *res, void *stream) {
+    REVS_REQUIRE(m > 0 && T > 0 && T <= 256 && nslab >= 1 && zt && rho_v && zv && yv && w &&
+                 vlo <= vhi, "revs_op_nodefast_update: bad argument");
+    hipLaunchKernelGGL(op_nodefast_update_kernel, grid1((int64_t)m * T), dim3(256), 0, S_(stream),
+                       m * T, T, nslab, zt, rho_v, bound_scale, alpha, vlo, vhi, zv, yv, w, res);
+    REVS_CHECK_LAUNCH("revs_op_nodefast_update");
+    return REVS_OK;
+}
+
+extern "C" int revs_op_nodefast_dualres(int32_t m, int32_t T, int32_t nslab, const double *xh,
+                                        const double *ph0, const double *lam, const double *yh,
+                                        double kappa, double *res, void *stream) {
+    REVS_REQUIRE(m > 0 && T > 0 && T <= 256 && nslab >= 1 && xh && ph0 && lam && yh && res,
+                 "revs_op_nodefast_dualres: bad argument");
+    hipLaunchKernelGGL(op_nodefast_dualres_kernel, grid1((int64_t)m * T), dim3(256), 0, S_(stream),
+                       m * T, T, nslab, xh, ph0, lam, yh, kappa, res);
+    REVS_CHECK_LAUNCH("revs_op_nodefast_dualres");
+    return REVS_OK;
+}
+
+extern "C" int revs_op_nodefast_finish(int32_t m, int32_t T, int32_t nslab, const double *x,
+                                       const double *p0, const double *gmin,
+                                       const double *inv_sqrt_n, double *d, double *slack,
+                                       void *stream) {
+    REVS_REQUIRE(m > 0 && T > 0 && nslab >= 1 && x && p0 && gmin && inv_sqrt_n && d && slack,
+                 "revs_op_nodefast_finish: bad argument");
+    hipLaunchKernelGGL(op_nodefast_finish_kernel, grid1((int64_t)m * T), dim3(256), 0, S_(stream),
+                       m * T, T, nslab, x, p0, gmin, inv_sqrt_n, d, slack);
+    REVS_CHECK_LAUNCH("revs_op_nodefast_finish");
+    return REVS_OK;
+}
+
+extern "C" int revs_op_node_apply(int32_t m, int32_t T, const int64_t *node_ptr,
+                                  const double *inv_sqrt_n, const float *p_est, const float *p_sch,
+                                  const float *gamma, double kappa, const double *d,
+                                  float *p_est_new, void *stream) {
+    REVS_REQUIRE(m > 0 && T > 0 && T <= 256 && node_ptr && inv_sqrt_n && p_est && p_sch && gamma &&
+                 d && p_est_new && kappa > 0, "revs_op_node_apply: bad argument");
+    REVS_TL_DISPATCH(T, op_node_apply_kernel, dim3(m), dim3(256), 0, S_(stream), m, T, node_ptr,
+                     inv_sqrt_n, p_est, p_sch, gamma, kappa, d, p_est_new);
+    REVS_CHECK_LAUNCH("revs_op_node_apply");
     return REVS_OK;
 }

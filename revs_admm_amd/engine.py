@@ -75,6 +75,11 @@ class OperatorOptions:
     cal_rho_v: tuple = (0.1, 1.0, 10.0, 100.0)
     cal_rho_b: tuple = (0.1, 1.0)
     cal_iters: int = 50
+    # Node-space fast path: solve the QP over the M nodes only (2 T-column products per
+    # iteration, no home traffic, no per-iteration collective) and accept the answer iff
+    # no residence would be pushed below zero; otherwise fall back to the general path
+    # for the rest of the run.
+    node_fast: bool = True
 
 
 def _dev_check(device):
@@ -197,6 +202,18 @@ class AdmmEngine:
         self.ksplit = int(min(8, max(1, -(-256 // tiles))))
         nzs = lambda: torch.zeros(self.ksplit, M, T, **f64)
         self.ta, self.tb, self.va, self.usa = nzs(), nzs(), nzs(), nzs()
+        # node-space fast path
+        self.ksplit1 = int(min(8, max(1, -(-256 // ((M + 31) // 32 if T <= 32 else (M + 15) // 16)))))
+        nz1 = lambda: torch.zeros(self.ksplit1, M, T, **f64)
+        self.f_wh, self.f_zt = nz1(), nz1()
+        (self.p0, self.gmin, self.ph0, self.xh, self.sx, self.dnode, self.slack) = (nz() for _ in range(7))
+        self.rho_f = torch.full((T,), self.op.rho_v_scale * self.kappa / self.smax ** 2, **f64)
+        self._fast_ok = bool(self.op.node_fast)
+        self._fast_cold = True
+        self._fast_cal = False
+        self._fgraph = None
+        self._fgraph_warm = False
+        self.op_path_hist: list[str] = []
         self.rho_v = torch.full((T,), self.op.rho_v_scale * self.kappa / self.smax ** 2, **f64)
         self.rho_b = torch.full((T,), self.op.rho_b_scale * self.kappa, **f64)
         self.res_out = torch.zeros(8, T, **f64)
@@ -384,10 +401,144 @@ class AdmmEngine:
         self._calibrated = True
         return spent
 
+    # ------------------------------------------------- operator, node-space fast path
+    def _gemm1(self, At, B, Cslabs):
+        check(self.lib.revs_gemm_tn_f64_split(self.M, self.T, self.M, ptr(At), ptr(B),
+                                              ptr(Cslabs), self.ksplit1, self.stream),
+              "revs_gemm_tn_f64_split")
+
+    def _fast_iteration(self, chk: bool):
+        o, lib, M, T, st, ks = self.op, self.lib, self.M, self.T, self.stream, self.ksplit1
+        self._gemm1(self.Q, self.w, self.f_wh)                             # wh = Q^T w
+        check(lib.revs_op_nodefast_scale(M, T, ks, ptr(self.f_wh), ptr(self.ph0), ptr(self.s),
+                                         ptr(self.rho_f), self.kappa, ptr(self.xh), ptr(self.sx),
+                                         st), "revs_op_nodefast_scale")
+        self._gemm1(self.QT, self.sx, self.f_zt)                           # zt = Q (l xh)
+        check(lib.revs_op_nodefast_update(M, T, ks, ptr(self.f_zt), ptr(self.rho_f),
+                                          ptr(self.sqrt_n), o.alpha, self.vlo, self.vhi,
+                                          ptr(self.zv), ptr(self.yv), ptr(self.w),
+                                          ptr(self.res_out) if chk else None, st),
+              "revs_op_nodefast_update")
+        if chk:
+            self._gemm1(self.Q, self.yv, self.f_wh)                        # yh = Q^T y_v
+            check(lib.revs_op_nodefast_dualres(M, T, ks, ptr(self.xh), ptr(self.ph0),
+                                               ptr(self.s), ptr(self.f_wh), self.kappa,
+                                               ptr(self.res_out), st), "revs_op_nodefast_dualres")
+
+    def _fast_block(self):
+        n_it = self.op.check_every
+
+        def body():
+            self.res_out.zero_()
+            for k in range(n_it):
+                self._fast_iteration(k == n_it - 1)
+
+        if not self.op.use_graph or self.dev.type != "cuda":
+            return body()
+        if not self._fgraph_warm:
+            self._fgraph_warm = True
+            return body()
+        if self._fgraph is None:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                body()
+            self._fgraph = g
+        self._fgraph.replay()
+
+    def _fast_set_rho(self, scale):
+        self.rho_f.fill_(scale * self.kappa / self.smax ** 2)
+        check(self.lib.revs_op_node_w(self.M, self.T, ptr(self.zv), ptr(self.yv), ptr(self.rho_f),
+                                      ptr(self.w), self.stream), "revs_op_node_w")
+
+    def _fast_residuals(self):
+        r = self.res_out.cpu().numpy()          # identical on every rank: no reduction needed
+        vscale = max(abs(self.vlo), abs(self.vhi), 1e-300)
+        rel_p = r[0] / np.maximum(np.maximum(r[3], r[4]), vscale)
+        rel_d = r[2] / np.maximum(np.maximum(self.kappa * r[5], r[6]), np.maximum(r[7], 1e-12))
+        return rel_p, rel_d
+
+    def _operator_solve_node(self):
+        """Fast path.  Returns True when its answer (in P_est_new) is the operator's exact
+        answer, False when some residence would have to be clamped at zero."""
+        o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
+        check(lib.revs_op_node_prep(M, T, ptr(self.node_ptr), ptr(self.inv_sqrt_n), ptr(self.P_est),
+                                    ptr(self.P_sch), ptr(self.G), self.kappa, ptr(self.p0),
+                                    ptr(self.gmin), None, st), "revs_op_node_prep")
+        if self.group is not None:               # the only exchange of this outer iteration
+            self._allreduce(self.p0)
+            self._allreduce(self.gmin, torch.distributed.ReduceOp.MIN)
+        self._gemm(self.Q, self.p0, self.ph0)                              # ph0 = Q^T p0
+        if self._fast_cold:
+            check(lib.revs_op_row_scale(M, T, ptr(self.s), ptr(self.ph0), ptr(self.xh), st),
+                  "revs_op_row_scale")
+            self._gemm(self.QT, self.xh, self.cx)                          # Rs p0
+            check(lib.revs_op_init_node(M, T, ptr(self.cx), ptr(self.rho_f), ptr(self.sqrt_n),
+                                        self.vlo, self.vhi, ptr(self.zv), ptr(self.yv),
+                                        ptr(self.w), st), "revs_op_init_node")
+            self._fast_cold = False
+        it, converged = 0, False
+        while it < o.max_iter:
+            self._fast_block()
+            it += o.check_every
+            rel_p, rel_d = self._fast_residuals()
+            if max(rel_p.max(), rel_d.max()) <= o.eps:
+                converged = True
+                break
+            if o.calibrate and not self._fast_cal:
+                snap = [t.clone() for t in (self.zv, self.yv)]
+                best = None
+                nblk = max(1, -(-o.cal_iters // o.check_every))
+                for rv in o.cal_rho_v:
+                    for t, c in zip((self.zv, self.yv), snap):
+                        t.copy_(c)
+                    self._fast_set_rho(rv)
+                    for _ in range(nblk):
+                        self._fast_block()
+                    it += nblk * o.check_every
+                    rp, rd = self._fast_residuals()
+                    score = float(max(rp.max(), rd.max()))
+                    if np.isfinite(score) and (best is None or score < best[0]):
+                        best = (score, rv)
+                for t, c in zip((self.zv, self.yv), snap):
+                    t.copy_(c)
+                self._fast_set_rho(best[1])
+                self.rho_f_scale = best[1]
+                self._fast_cal = True
+                continue
+            if o.adapt_every and it % o.adapt_every == 0:
+                sc = np.sqrt(np.maximum(rel_p, 1e-14) / np.maximum(rel_d, 1e-14))
+                sc = np.clip(sc, 0.2, 5.0)
+                sc = np.where((sc > 2.0) | (sc < 0.5), sc, 1.0)
+                if (sc != 1.0).any():
+                    self.rho_f.mul_(torch.from_numpy(sc).to(self.dev))
+                    check(lib.revs_op_node_w(M, T, ptr(self.zv), ptr(self.yv), ptr(self.rho_f),
+                                             ptr(self.w), st), "revs_op_node_w")
+        self._gemm1(self.QT, self.xh, self.f_zt)                           # x = Q xh
+        check(lib.revs_op_nodefast_finish(M, T, self.ksplit1, ptr(self.f_zt), ptr(self.p0),
+                                          ptr(self.gmin), ptr(self.inv_sqrt_n), ptr(self.dnode),
+                                          ptr(self.slack), st), "revs_op_nodefast_finish")
+        # nodes without residences have gmin = +inf; a clamp is active iff some slack < 0
+        scale = max(1.0, float(self.p0.abs().max().item()))
+        if float(self.slack.min().item()) < -1e-9 * scale:
+            return False
+        check(lib.revs_op_node_apply(M, T, ptr(self.node_ptr), ptr(self.inv_sqrt_n), ptr(self.P_est),
+                                     ptr(self.P_sch), ptr(self.G), self.kappa, ptr(self.dnode),
+                                     ptr(self.P_est_new), st), "revs_op_node_apply")
+        self.op_iters_hist.append(it)
+        self.op_path_hist.append("node")
+        self.op_converged = converged
+        return True
+
     def operator_solve(self):
         """Utility(graph, P_est[k], P_sch[k], G[k]).solve() -> P_est[k+1]
         (lpsolver.py:256-259), written to self.P_est_new."""
         o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
+        if self._fast_ok:
+            if self._operator_solve_node():
+                return self.op_converged
+            # some residence would go negative: the g >= 0 rows matter on this feeder, so
+            # the general home-space ADMM takes over for the rest of the run
+            self._fast_ok = False
         _lib.check(lib.revs_op_g0(self.n, T, ptr(self.P_est), ptr(self.P_sch), ptr(self.G),
                                   self.kappa, ptr(self.g0), st), "revs_op_g0")
         if self.op_cold or not o.warm_start:
@@ -433,6 +584,7 @@ class AdmmEngine:
                                "revs_op_node_w")
                     self._home_pass(with_update=False)
         self.op_iters_hist.append(it)
+        self.op_path_hist.append("home")
         self.op_converged = converged
         _lib.check(lib.revs_op_export(self.n, T, ptr(self.sb), ptr(self.P_est_new), st),
                    "revs_op_export")

@@ -196,6 +196,78 @@ class FakeKernels:
     def revs_gemm_tn_f64_cat(self, m, T, k, At, B0, B1, C0, C1, ksplit, stream):
         return self.revs_gemm_tn_f64_x2(m, T, k, At, B0, C0, At, B1, C1, ksplit, stream)
 
+    def revs_gemm_tn_f64_split(self, m, n, k, At, B, Cc, ksplit, stream):
+        a, b = view(At, (k, m), np.float64), view(B, (k, n), np.float64)
+        c = view(Cc, (ksplit, m, n), np.float64)
+        edges = np.linspace(0, k, ksplit + 1).astype(int)
+        for q in range(ksplit):
+            c[q] = a[edges[q]:edges[q + 1]].T @ b[edges[q]:edges[q + 1]]
+        return 0
+
+    # ---- node-space fast path ----
+    def revs_op_node_prep(self, m, T, node_ptr, isn, pe, ps, gm, kappa, p0, gmin, g0_out, stream):
+        node, n = self._seg(m, node_ptr)
+        f = lambda p: view(p, (n, T), np.float32).astype(float)
+        g = 0.5 * (f(pe) + f(ps)) - f(gm) / kappa
+        acc = np.zeros((m, T))
+        np.add.at(acc, node, g)
+        mn = np.full((m, T), np.inf)
+        np.minimum.at(mn, node, g)
+        view(p0, (m, T), np.float64)[:] = view(isn, (m,), np.float64)[:, None] * acc
+        view(gmin, (m, T), np.float64)[:] = mn
+        if g0_out:
+            view(g0_out, (n, T), np.float64)[:] = g
+        return 0
+
+    def revs_op_nodefast_scale(self, m, T, nslab, wh, ph0, lam, rho_v, kappa, xh, sx, stream):
+        d = lambda p: view(p, (m, T), np.float64)
+        l = view(lam, (m,), np.float64)[:, None]
+        w = view(wh, (nslab, m, T), np.float64).sum(axis=0)
+        x = (kappa * d(ph0) + l * w) / (kappa + view(rho_v, (T,), np.float64)[None, :] * l * l)
+        d(xh)[:] = x
+        d(sx)[:] = l * x
+        return 0
+
+    def revs_op_nodefast_update(self, m, T, nslab, zt, rho_v, bscale, alpha, vlo, vhi, zv, yv, w,
+                                res, stream):
+        d = lambda p: view(p, (m, T), np.float64)
+        ztv = view(zt, (nslab, m, T), np.float64).sum(axis=0)
+        rv = view(rho_v, (T,), np.float64)[None, :]
+        bs = view(bscale, (m,), np.float64)[:, None] if bscale else 1.0
+        h = alpha * ztv + (1 - alpha) * d(zv)
+        zn = np.clip(h + d(yv) / rv, bs * vlo, bs * vhi)
+        d(yv)[:] = d(yv) + rv * (h - zn)
+        d(zv)[:] = zn
+        d(w)[:] = rv * zn - d(yv)
+        if res:
+            o = view(res, (8, T), np.float64)
+            for row, val in ((0, ztv - zn), (3, ztv), (4, zn)):
+                o[row] = np.maximum(o[row], np.abs(val).max(axis=0))
+        return 0
+
+    def revs_op_nodefast_dualres(self, m, T, nslab, xh, ph0, lam, yh, kappa, res, stream):
+        d = lambda p: view(p, (m, T), np.float64)
+        ly = view(lam, (m,), np.float64)[:, None] * view(yh, (nslab, m, T), np.float64).sum(axis=0)
+        o = view(res, (8, T), np.float64)
+        for row, val in ((2, kappa * (d(xh) - d(ph0)) + ly), (5, d(xh)), (6, ly), (7, kappa * d(ph0))):
+            o[row] = np.maximum(o[row], np.abs(val).max(axis=0))
+        return 0
+
+    def revs_op_nodefast_finish(self, m, T, nslab, x, p0, gmin, isn, dd, slack, stream):
+        d = lambda p: view(p, (m, T), np.float64)
+        dv = view(x, (nslab, m, T), np.float64).sum(axis=0) - d(p0)
+        d(dd)[:] = dv
+        d(slack)[:] = d(gmin) + view(isn, (m,), np.float64)[:, None] * dv
+        return 0
+
+    def revs_op_node_apply(self, m, T, node_ptr, isn, pe, ps, gm, kappa, dd, pe_new, stream):
+        node, n = self._seg(m, node_ptr)
+        f = lambda p: view(p, (n, T), np.float32).astype(float)
+        g = 0.5 * (f(pe) + f(ps)) - f(gm) / kappa
+        corr = (view(isn, (m,), np.float64)[:, None] * view(dd, (m, T), np.float64))[node]
+        view(pe_new, (n, T), np.float32)[:] = np.maximum(g + corr, 0)
+        return 0
+
     def revs_voltage_f32(self, m, T, Rt, P, V, stream):
         view(V, (m, T), np.float32)[:] = view(Rt, (m, m), np.float32).T @ view(P, (m, T), np.float32)
         return 0

@@ -159,19 +159,24 @@ def test_process_group_path_on_one_gpu(gpu_lib):
     from revs_admm_amd.synthetic import make_workload
     w = make_workload(800, 24, n_nodes=64, seed=13, binary_feasible=False, stress=1.25)
     w.load, w.cost = f32(w.load), f32(w.cost)
-    a = _engine(w, "relaxed_exact")
-    da = a.run(4)
+    from revs_admm_amd.engine import OperatorOptions
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 1000))
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     try:
-        b = _engine(w, "relaxed_exact", group=dist.group.WORLD)
-        db = b.run(4)
-        assert isinstance(b._graph, list) and len(b._graph) == 2      # the sharded graphs ran
-        assert a.op_iters_hist == b.op_iters_hist
-        np.testing.assert_allclose(db, da, rtol=1e-6, atol=1e-7)
-        np.testing.assert_allclose(b.result()[1], a.result()[1], atol=1e-5)
-        assert b.residuals(1e-4)[:3] == pytest.approx(a.residuals(1e-4)[:3], rel=1e-5)
+        for fast in (True, False):          # node-space fast path, then the general path
+            a = _engine(w, "relaxed_exact", op=OperatorOptions(node_fast=fast))
+            da = a.run(4)
+            b = _engine(w, "relaxed_exact", group=dist.group.WORLD,
+                        op=OperatorOptions(node_fast=fast))
+            db = b.run(4)
+            assert set(b.op_path_hist) == ({"node"} if fast else {"home"})
+            if not fast:
+                assert isinstance(b._graph, list) and len(b._graph) == 2   # sharded graphs ran
+            assert a.op_iters_hist == b.op_iters_hist
+            np.testing.assert_allclose(db, da, rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(b.result()[1], a.result()[1], atol=1e-5)
+            assert b.residuals(1e-4)[:3] == pytest.approx(a.residuals(1e-4)[:3], rel=1e-5)
     finally:
         dist.destroy_process_group()
 

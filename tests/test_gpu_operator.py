@@ -112,15 +112,23 @@ def test_operator_matches_oracle(gpu_lib, n, M, T):
         w.Rn = w.Rn * (1.3 * (w.vhigh ** 2 - w.vset ** 2) / (w.Rn @ ps).max())
     pe = f32(ps * rng.uniform(0.7, 1.1, (n, T)))
     gm = f32(rng.normal(0, 2.0, (n, T)))
-    e = _engine(w)
-    _set_state(e, pe, ps, gm)
-    assert e.operator_solve()
-    got = e.P_est_new.cpu().numpy()[e.inv_perm].astype(np.float64)
     g0 = ro.utility_g0(pe, ps, gm, w.kappa)
     vlo, vhi = ro.voltage_limits(w.vset, w.vlow, w.vhigh)
     ref, info = ro.utility_solve(w.Rn, w.node_of, g0, w.kappa, vlo, vhi, return_info=True)
     assert np.abs(ref - np.maximum(g0, 0)).max() > 1e-2          # constraints bind
-    assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+    # both operator paths must give the oracle's answer: the node-space fast path (taken
+    # when no residence is clamped at zero) and the general home-space ADMM
+    from revs_admm_amd.engine import OperatorOptions
+    for fast in (True, False):
+        e = _engine(w, op=OperatorOptions(node_fast=fast))
+        _set_state(e, pe, ps, gm)
+        assert e.operator_solve()
+        got = e.P_est_new.cpu().numpy()[e.inv_perm].astype(np.float64)
+        assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max()), (fast, e.op_path_hist)
+        if not fast:
+            assert e.op_path_hist == ["home"]
+        elif ref.min() > 1e-6:
+            assert e.op_path_hist == ["node"]
     # feasibility of the GPU answer itself, in double
     A = np.zeros((w.M, n)); A[w.node_of, np.arange(n)] = 1
     v = w.Rn @ (A @ got)

@@ -127,3 +127,27 @@ def test_engine_driver_on_fake_kernels(mode, omode):
         assert same.mean() > 0.97
     else:
         assert np.abs(S - S_ref).max() < 1e-3 and np.abs(d - d_ref).max() < 1e-3
+
+
+@pytest.mark.parametrize("stress,paths", [(1.3, {"node"}), (4.0, {"node", "home"})])
+def test_operator_paths_on_fake_kernels(stress, paths):
+    """Driver logic of the two operator paths: the node-space fast path is kept while no
+    residence is pushed to zero, and the general home-space ADMM takes over (for the rest of
+    the run) on a feeder stressed so hard that some are -- same answers as the oracle."""
+    from fake_kernels import FakeKernels
+    from helpers import f32, oracle_homes
+    from revs_admm_amd.engine import AdmmEngine
+    from revs_admm_amd.synthetic import make_workload
+    w = make_workload(150, 12, n_nodes=20, seed=2, stress=stress, binary_feasible=False)
+    w.load, w.cost = f32(w.load), f32(w.cost)
+    e = AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, kappa=w.kappa, vset=w.vset,
+                   vlow=w.vlow, vhigh=w.vhigh, mode="relaxed_exact", device="cpu",
+                   _kernels=FakeKernels())
+    d = e.run(4)
+    d_ref, P_ref, S_ref, C_ref = ro.solve_ADMM(oracle_homes(w), w.Rn, w.node_of, w.cost, w.kappa, 4,
+                                               w.vset, w.vlow, w.vhigh, mode="relaxed")
+    assert set(e.op_path_hist) == paths
+    if "home" in paths:                         # once fallen back, it stays on the general path
+        k = e.op_path_hist.index("home")
+        assert set(e.op_path_hist[k:]) == {"home"} and e.P_est.min().item() == 0.0
+    assert np.abs(e.result()[1] - S_ref).max() < 1e-5 and np.abs(d - d_ref).max() < 1e-6
