@@ -10,7 +10,8 @@ N > 1 is launched by the driver as
 QP (batched PDHG kernel), the dual update and the residual reduction.  Weak
 scaling: every GPU owns `--homes` residences (default 100 000 x T=24, the size
 BASELINE.json's metric is quoted on); the feeder's 2048 constraint nodes are
-replicated and the only collective is the all-reduce of the node aggregate.
+replicated and the only collective is the all-reduce of the node aggregate (once per
+ADMM iteration on the operator's node-space fast path).
 
 Prints ONE JSON line (rank 0).  `value` = home-QP solves per second, whole job,
 inputs resident in HBM.  `roofline` is the PDHG sweep kernel against HBM;
@@ -87,8 +88,8 @@ def cpu_baseline(w, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--homes", type=int, default=100_000, help="residences per GPU")
     ap.add_argument("--T", type=int, default=24)
     ap.add_argument("--nodes", type=int, default=2048)
@@ -196,17 +197,22 @@ def main():
     st = eng.status.cpu().numpy()
     pdhg_it = float((st >> 8)[(st >> 8) > 0].mean()) if args.mode == "pdhg" and ((st >> 8) > 0).any() else None
 
-    # f64 matrix-core product alone: V^T rhat, as in the operator's inner iteration
+    # the f64 matrix-core product of the operator path that actually ran: Q^T w (T columns)
+    # on the node-space fast path, Q^T [rhat | w] (2T columns) on the general path
+    fast = eng.op_path_hist[-1] == "node"
     reps = 200
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        eng._gemm_cat(eng.Q, eng.rhat, eng.w, eng.ta, eng.tb)
+        if fast:
+            eng._gemm1(eng.Q, eng.w, eng.f_wh)
+        else:
+            eng._gemm_cat(eng.Q, eng.rhat, eng.w, eng.ta, eng.tb)
     e1.record()
     torch.cuda.synchronize()
     gemm_ms = e0.elapsed_time(e1) / reps
-    gemm_flops = 2.0 * eng.M * eng.M * 2 * args.T
+    gemm_flops = 2.0 * eng.M * eng.M * args.T * (1 if fast else 2)
 
     # how many ADMM iterations until the eps-residual (continues the same run)
     iters_to_eps = None
@@ -266,7 +272,7 @@ def main():
                 "avg_launch_ms": agent_ms, "pdhg_iters_mean": pdhg_it,
             },
             "roofline_matvec": {
-                "kernel": "gemm_tn_kernel<double> (Q^T [rhat | w], M x M x 2T)",
+                "kernel": "gemm_tn_kernel<double> (" + ("Q^T w, M x M x T" if fast else "Q^T [rhat | w], M x M x 2T") + ")",
                 "bound": "mfma", "achieved": gemm_flops / (gemm_ms * 1e-3) / 1e12,
                 "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": gemm_flops / (gemm_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS,
@@ -275,6 +281,7 @@ def main():
             "breakdown": {
                 "operator_ms_per_step": oper_ms, "agent_ms_per_step": agent_ms,
                 "operator_inner_iters_mean": float(np.mean(inner)) if inner else 0.0,
+                "operator_path": eng.op_path_hist[-1],
                 "admm_residual_primal": rp, "admm_residual_dual": rd, "admm_max_diff": dmax,
                 "admm_iters_to_eps": iters_to_eps, "eps": args.eps,
             },

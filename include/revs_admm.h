@@ -279,7 +279,8 @@ int revs_op_node_update(int32_t m, int32_t T, int32_t nslab, const double *va,
  *   revs_op_nodefast_update z_v, y_v, w from zt = Q sx (nslab slabs); res rows 0,3,4
  *   revs_op_nodefast_dualres res rows 2,5,6,7 from yh = Q^T y_v (nslab slabs), in the
  *                           eigenbasis: |kappa (xh - ph0) + l yh|, kappa|xh| ...
- *   revs_op_nodefast_finish d = Q xh - p0 (x as nslab slabs), slack = gmin + isn d
+ *   revs_op_nodefast_finish d = Q xh - p0 (x as nslab slabs), slack = gmin + isn d;
+ *                           stats (double[2], ZERO on entry) = {max(0, -min slack), max|p0|}
  *   revs_op_node_apply      P_est_i = max(g0_i + isn[m] d[m], 0) as float              */
 int revs_op_node_prep(int32_t m, int32_t T, const int64_t *node_ptr, const double *inv_sqrt_n,
                       const float *p_est, const float *p_sch, const float *gamma, double kappa,
@@ -296,7 +297,7 @@ int revs_op_nodefast_dualres(int32_t m, int32_t T, int32_t nslab, const double *
                              double kappa, double *res, void *stream);
 int revs_op_nodefast_finish(int32_t m, int32_t T, int32_t nslab, const double *x,
                             const double *p0, const double *gmin, const double *inv_sqrt_n,
-                            double *d, double *slack, void *stream);
+                            double *d, double *slack, double *stats, void *stream);
 int revs_op_node_apply(int32_t m, int32_t T, const int64_t *node_ptr, const double *inv_sqrt_n,
                        const float *p_est, const float *p_sch, const float *gamma, double kappa,
                        const double *d, float *p_est_new, void *stream);

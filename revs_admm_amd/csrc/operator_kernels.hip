@@ -414,16 +414,31 @@ __global__ void op_nodefast_dualres_kernel(int total, int T, int nslab, const do
 }
 
 // d = x - p0 (x as nslab slabs of Q xh); slack[m][t] = gmin + isn d  (>= 0 <=> no clamp)
+// stats[0] = max(0, -min slack), stats[1] = max |p0|   (stats zeroed by the caller)
 __global__ void op_nodefast_finish_kernel(int total, int T, int nslab, const double *x_s,
                                           const double *p0, const double *gmin,
-                                          const double *inv_sqrt_n, double *d, double *slack) {
+                                          const double *inv_sqrt_n, double *d, double *slack,
+                                          double *stats) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    double x = x_s[i];
-    for (int q = 1; q < nslab; ++q) x += x_s[i + (int64_t)q * total];
-    const double dv = x - p0[i];
-    d[i] = dv;
-    slack[i] = gmin[i] + inv_sqrt_n[i / T] * dv;
+    double viol = 0.0, pabs = 0.0;
+    if (i < total) {
+        double x = x_s[i];
+        for (int q = 1; q < nslab; ++q) x += x_s[i + (int64_t)q * total];
+        const double dv = x - p0[i];
+        d[i] = dv;
+        const double sl = gmin[i] + inv_sqrt_n[i / T] * dv;
+        slack[i] = sl;
+        viol = fmax(-sl, 0.0);
+        pabs = fabs(p0[i]);
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+        viol = fmax(viol, __shfl_xor(viol, o, 64));
+        pabs = fmax(pabs, __shfl_xor(pabs, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomic_max_nonneg(stats + 0, viol);
+        atomic_max_nonneg(stats + 1, pabs);
+    }
 }
 
 // P_est_i = max(g0_i + isn[m] d[m], 0) as float, g0 recomputed from the float state
@@ -663,11 +678,11 @@ extern "C" int revs_op_nodefast_dualres(int32_t m, int32_t T, int32_t nslab, con
 extern "C" int revs_op_nodefast_finish(int32_t m, int32_t T, int32_t nslab, const double *x,
                                        const double *p0, const double *gmin,
                                        const double *inv_sqrt_n, double *d, double *slack,
-                                       void *stream) {
-    REVS_REQUIRE(m > 0 && T > 0 && nslab >= 1 && x && p0 && gmin && inv_sqrt_n && d && slack,
-                 "revs_op_nodefast_finish: bad argument");
+                                       double *stats, void *stream) {
+    REVS_REQUIRE(m > 0 && T > 0 && nslab >= 1 && x && p0 && gmin && inv_sqrt_n && d && slack &&
+                 stats, "revs_op_nodefast_finish: bad argument");
     hipLaunchKernelGGL(op_nodefast_finish_kernel, grid1((int64_t)m * T), dim3(256), 0, S_(stream),
-                       m * T, T, nslab, x, p0, gmin, inv_sqrt_n, d, slack);
+                       m * T, T, nslab, x, p0, gmin, inv_sqrt_n, d, slack, stats);
     REVS_CHECK_LAUNCH("revs_op_nodefast_finish");
     return REVS_OK;
 }

@@ -207,6 +207,7 @@ class AdmmEngine:
         nz1 = lambda: torch.zeros(self.ksplit1, M, T, **f64)
         self.f_wh, self.f_zt = nz1(), nz1()
         (self.p0, self.gmin, self.ph0, self.xh, self.sx, self.dnode, self.slack) = (nz() for _ in range(7))
+        self.f_stats = torch.zeros(2, **f64)
         self.rho_f = torch.full((T,), self.op.rho_v_scale * self.kappa / self.smax ** 2, **f64)
         self._fast_ok = bool(self.op.node_fast)
         self._fast_cold = True
@@ -514,12 +515,14 @@ class AdmmEngine:
                     check(lib.revs_op_node_w(M, T, ptr(self.zv), ptr(self.yv), ptr(self.rho_f),
                                              ptr(self.w), st), "revs_op_node_w")
         self._gemm1(self.QT, self.xh, self.f_zt)                           # x = Q xh
+        self.f_stats.zero_()
         check(lib.revs_op_nodefast_finish(M, T, self.ksplit1, ptr(self.f_zt), ptr(self.p0),
                                           ptr(self.gmin), ptr(self.inv_sqrt_n), ptr(self.dnode),
-                                          ptr(self.slack), st), "revs_op_nodefast_finish")
+                                          ptr(self.slack), ptr(self.f_stats), st),
+              "revs_op_nodefast_finish")
         # nodes without residences have gmin = +inf; a clamp is active iff some slack < 0
-        scale = max(1.0, float(self.p0.abs().max().item()))
-        if float(self.slack.min().item()) < -1e-9 * scale:
+        viol, pmax = self.f_stats.cpu().tolist()
+        if viol > 1e-9 * max(1.0, pmax):
             return False
         check(lib.revs_op_node_apply(M, T, ptr(self.node_ptr), ptr(self.inv_sqrt_n), ptr(self.P_est),
                                      ptr(self.P_sch), ptr(self.G), self.kappa, ptr(self.dnode),

@@ -253,11 +253,14 @@ class FakeKernels:
             o[row] = np.maximum(o[row], np.abs(val).max(axis=0))
         return 0
 
-    def revs_op_nodefast_finish(self, m, T, nslab, x, p0, gmin, isn, dd, slack, stream):
+    def revs_op_nodefast_finish(self, m, T, nslab, x, p0, gmin, isn, dd, slack, stats, stream):
         d = lambda p: view(p, (m, T), np.float64)
         dv = view(x, (nslab, m, T), np.float64).sum(axis=0) - d(p0)
         d(dd)[:] = dv
         d(slack)[:] = d(gmin) + view(isn, (m,), np.float64)[:, None] * dv
+        st = view(stats, (2,), np.float64)
+        st[0] = max(st[0], np.maximum(-d(slack), 0).max())
+        st[1] = max(st[1], np.abs(d(p0)).max())
         return 0
 
     def revs_op_node_apply(self, m, T, node_ptr, isn, pe, ps, gm, kappa, dd, pe_new, stream):
