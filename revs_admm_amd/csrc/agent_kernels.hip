@@ -72,7 +72,7 @@ __device__ __forceinline__ void group_rank(const float (&key)[SPL], int t0, int 
     }
 }
 
-template <int LPA, int SPL, int MODE>
+template <int LPA, int SPL, int MODE, bool FULL_ROWS = false>
 __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
     constexpr int kHomesPerBlock = kBlock / LPA;
     const int tid = threadIdx.x;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
             // warm start: primal from the previous schedule (P_sch[k] - LOAD), dual from
             // the previous iteration's multipliers when the caller keeps them
             x[j] = a.y_state ? fminf(fmaxf((pso[j] - L[j]) / rate, 0.f), w[j]) : 0.f;
-            y[j] = (a.pd.full_rows && a.y_state && valid[j] && ev) ? a.y_state[row + t0 + j] : 0.f;
+            y[j] = (FULL_ROWS && a.y_state && valid[j] && ev) ? a.y_state[row + t0 + j] : 0.f;
         }
         // the window cannot deliver the energy to 90 % SOC: "No solution found"
         float wsum = 0.f;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
         bool done = !ev || infeasible;
         int iters = 0;
         const int check = max(a.pd.check, 1);
-        if (!a.pd.full_rows) {
+        if constexpr (!FULL_ROWS) {
             // Presolved form: with p >= 0 the SOC is nondecreasing, so of the rows
             // init <= s_t <= 1, s_T >= 0.9 only the terminal one can bind.  K is then the
             // single row delta * 1^T (||K|| = delta sqrt(T_w)), its dual one scalar per home,
@@ -490,7 +490,10 @@ static void launch_agent(const AgentArgs &a, int mode, dim3 grid, hipStream_t s)
             hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_BINARY>), grid, dim3(kBlock), 0, s, a);
             break;
         case REVS_MODE_RELAXED_PDHG:
-            hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_RELAXED_PDHG>), grid, dim3(kBlock), 0, s, a);
+            if (a.pd.full_rows)
+                hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_RELAXED_PDHG, true>), grid, dim3(kBlock), 0, s, a);
+            else
+                hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_RELAXED_PDHG, false>), grid, dim3(kBlock), 0, s, a);
             break;
         default:
             hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_RELAXED_EXACT>), grid, dim3(kBlock), 0, s, a);
