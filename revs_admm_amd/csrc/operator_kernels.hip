@@ -435,8 +435,13 @@ __global__ void op_nodefast_finish_kernel(int total, int T, int nslab, const dou
         viol = fmax(viol, __shfl_xor(viol, o, 64));
         pabs = fmax(pabs, __shfl_xor(pabs, o, 64));
     }
-    if ((threadIdx.x & 63) == 0) {
-        atomic_max_nonneg(stats + 0, viol);
+    __shared__ double red[2][4];
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = viol; red[1][threadIdx.x >> 6] = pabs; }
+    __syncthreads();
+    if (threadIdx.x == 0) {       // one pair of global atomics per workgroup, and only if needed
+        viol = fmax(fmax(red[0][0], red[0][1]), fmax(red[0][2], red[0][3]));
+        pabs = fmax(fmax(red[1][0], red[1][1]), fmax(red[1][2], red[1][3]));
+        if (viol > 0.0) atomic_max_nonneg(stats + 0, viol);
         atomic_max_nonneg(stats + 1, pabs);
     }
 }
