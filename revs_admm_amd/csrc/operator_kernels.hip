@@ -4,17 +4,20 @@
 //     min  sum_i (kappa/2)|g_i|^2 + g_i . a_i           a_i = gamma_i - (kappa/2)(P_est_i + P_sch_i)
 //     s.t. g >= 0 (Gurobi default lb),  vlo <= R_res g[:,t] <= vhi  for every slot t
 // is the projection of g0 = -a/kappa onto the voltage-feasible set.  Here it is
-// solved by ADMM in OSQP form (x, z = Cx, y) on C = [R' A~ ; I]:
-//     A~ = diag(1/sqrt(n_m)) A   (A = home->node aggregation, n_m homes on node m)
-//     R' = R diag(sqrt(n_m)) = U S V^T
-// so that (P + sigma I + C^T rho C)^-1 is applied through U, S, V: per-slot rho can
-// change without refactoring anything.  One inner iteration =
-//     home pass   (this file)   update x, z_b, y_b of every home from the node
-//                               correction xc; form rhs and aggregate it to nodes
-//     4 skinny GEMMs (gemm_kernels.hip)   V^T rhat, U^T w, V a, U (s a)
-//     2 node passes (this file)
-// With homes sharded over GPUs the only exchange is the all-reduce of rhat
-// (m x T doubles) between the home pass and the GEMMs.
+// solved by ADMM in OSQP form (x, z = Cx, y) on C = [C_v ; I]:
+//     A~  = diag(1/sqrt(n_m)) A      (A = home->node aggregation, n_m homes on node m)
+//     C_v = D^1/2 R D^1/2 A~         (voltage row m scaled by sqrt(n_m), bounds too)
+//     D^1/2 R D^1/2 = Q L Q^T        symmetric PSD, eigendecomposed once on the host
+// so that (kappa I + rho_b I + rho_v C_v^T C_v)^-1 is applied through Q and L: per-slot
+// rho can change without refactoring anything.  One inner iteration of the GENERAL path =
+//     home pass   (this file)   node update for the workgroup's own node row (fused),
+//                               then z_b / y_b of every home of that node; form rhs and
+//                               aggregate it to the node
+//     2 products  (gemm_kernels.hip)   Q^T [rhat | w]  and  Q [a | l a]
+//     1 node pass (this file)   a = (ta + l tb) / (c + rho_v l^2)
+// With homes sharded over GPUs its only exchange is the all-reduce of rhat (m x T
+// doubles) after the home pass.  The NODE-SPACE FAST PATH further down needs no home
+// pass inside the loop at all.
 //
 // State kept per home and slot is ONE double: s_b = z_b + y_b.  The bound rows'
 // z_b = max(u,0) and y_b = rho_b min(u,0) are complementary (one of them is zero), so

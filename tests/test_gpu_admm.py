@@ -253,3 +253,42 @@ def test_relaxed_trajectory_T96(gpu_lib):
                                                util_eps=1e-10)
     assert np.abs(diffs - d_ref).max() < 1e-3 * max(1.0, d_ref.max())
     assert np.abs(S - S_ref).max() < 2e-3 and np.abs(C - C_ref).max() < 2e-4
+
+
+def test_config0_com2_30pct_adoption(gpu_lib, golden, feeder_R):
+    """BASELINE config 0: 121144 feeder, community 2, 30 % adoption, 4.8 kW, T = 24 (the
+    reference's test-optimizer.py case; no stored result exists for it).  EV homes are drawn
+    as revs_fixture.py:174-177 does; iteration 1 must equal the oracle exactly and iteration
+    2's operator answer must equal the oracle's QP solution."""
+    from helpers import f32
+    from oracle import revs_oracle as ro
+    from revs_admm_amd.engine import AdmmEngine, pack_homes
+    z, fd = golden
+    res_ids = z["res_id"]
+    com2 = z["com_flat"][z["com_offsets"][1]:z["com_offsets"][2]]
+    np.random.seed(1234)
+    ev_homes = np.random.choice(com2, int(30 * 1e-2 * len(com2)), replace=False)
+    idx = {h: i for i, h in enumerate(res_ids)}
+    ev = np.zeros(len(res_ids), bool)
+    ev[[idx[h] for h in ev_homes]] = True
+    assert ev.sum() == 89
+    oh = ro.Homes.uniform(f32(z["LOAD"]), ev, 4.8, 20.0, 0.2, 11, 23)
+    cost = f32(z["tariff_shift6"])
+    n, T = oh.LOAD.shape
+    e = AdmmEngine(cost, pack_homes(ev, 4.8, 20.0, 0.2, 11, 23), oh.LOAD, np.arange(n), feeder_R,
+                   kappa=5.0, vset=1.03, vlow=0.95, vhigh=1.05, mode="binary")
+    d = e.run(2)
+    zero = np.zeros((n, T))
+    p1, s1, g1, st = ro.home_solve_binary(cost, oh, zero, zero, zero, 5.0)
+    np.testing.assert_allclose(d[0], np.linalg.norm(g1, axis=1) / T, rtol=2e-6)
+    # iteration 2: operator projects g0 = P_sch[1]; homes repeat iteration 1's problem
+    g1f = f32(g1)
+    vlo, vhi = ro.voltage_limits(1.03, 0.95, 1.05)
+    ref = ro.utility_solve(feeder_R, np.arange(n), ro.utility_g0(zero, g1f, f32(-2.5 * g1f), 5.0),
+                           5.0, vlo, vhi, eps=1e-10)
+    pe2 = e.P_est.cpu().numpy()[e.inv_perm].astype(np.float64)
+    assert np.abs(pe2 - ref).max() < 5e-5
+    P_sch, S, C = e.result()
+    assert (np.abs(S - p1) < 1e-6).all()             # same home problem as iteration 1
+    np.testing.assert_allclose(d[1], np.linalg.norm(ref - g1, axis=1) / T, atol=2e-5)
+    assert e.op_path_hist[-1] == "home"              # this feeder clamps residences at zero
