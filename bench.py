@@ -95,6 +95,8 @@ def main():
     ap.add_argument("--nodes", type=int, default=2048)
     ap.add_argument("--mode", default="pdhg", choices=["pdhg", "relaxed_exact", "binary"])
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--stress", type=float, default=1.15,
+                    help="uncoordinated peak voltage / limit of the synthetic feeder")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eps", type=float, default=1e-4, help="ADMM residual target")
     ap.add_argument("--op-check", type=int, default=None, help="operator: residual test period")
@@ -134,7 +136,7 @@ def main():
 
     n_total = args.homes * world
     w = make_workload(n_total, args.T, n_nodes=args.nodes, seed=args.seed,
-                      binary_feasible=(args.mode == "binary"))
+                      binary_feasible=(args.mode == "binary"), stress=args.stress)
     lo, hi = w.shard(rank, world)
     counts = np.bincount(w.node_of, minlength=w.M)
     opts = OperatorOptions()
