@@ -210,6 +210,8 @@ class AdmmEngine:
         self.f_stats = torch.zeros(2, **f64)
         self.rho_f = torch.full((T,), self.op.rho_v_scale * self.kappa / self.smax ** 2, **f64)
         self._fast_ok = bool(self.op.node_fast)
+        self._fast_wait = 0
+        self._fast_backoff = 1
         self._fast_cold = True
         self._fast_cal = False
         self._fgraph = None
@@ -458,9 +460,10 @@ class AdmmEngine:
         rel_d = r[2] / np.maximum(np.maximum(self.kappa * r[5], r[6]), np.maximum(r[7], 1e-12))
         return rel_p, rel_d
 
-    def _operator_solve_node(self):
+    def _operator_solve_node(self, precheck=False):
         """Fast path.  Returns True when its answer (in P_est_new) is the operator's exact
-        answer, False when some residence would have to be clamped at zero."""
+        answer; "pre" when the pre-check found a residence with g0 < 0 (nothing solved yet),
+        "post" when the node solve finished but some residence would have to be clamped."""
         o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
         check(lib.revs_op_node_prep(M, T, ptr(self.node_ptr), ptr(self.inv_sqrt_n), ptr(self.P_est),
                                     ptr(self.P_sch), ptr(self.G), self.kappa, ptr(self.p0),
@@ -468,6 +471,8 @@ class AdmmEngine:
         if self.group is not None:               # the only exchange of this outer iteration
             self._allreduce(self.p0)
             self._allreduce(self.gmin, torch.distributed.ReduceOp.MIN)
+        if precheck and float(self.gmin.min().item()) < 0.0:
+            return "pre"
         self._gemm(self.Q, self.p0, self.ph0)                              # ph0 = Q^T p0
         if self._fast_cold:
             check(lib.revs_op_row_scale(M, T, ptr(self.s), ptr(self.ph0), ptr(self.xh), st),
@@ -523,7 +528,7 @@ class AdmmEngine:
         # nodes without residences have gmin = +inf; a clamp is active iff some slack < 0
         viol, pmax = self.f_stats.cpu().tolist()
         if viol > 1e-9 * max(1.0, pmax):
-            return False
+            return "post"
         check(lib.revs_op_node_apply(M, T, ptr(self.node_ptr), ptr(self.inv_sqrt_n), ptr(self.P_est),
                                      ptr(self.P_sch), ptr(self.G), self.kappa, ptr(self.dnode),
                                      ptr(self.P_est_new), st), "revs_op_node_apply")
@@ -537,11 +542,23 @@ class AdmmEngine:
         (lpsolver.py:256-259), written to self.P_est_new."""
         o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
         if self._fast_ok:
-            if self._operator_solve_node():
-                return self.op_converged
-            # some residence would go negative: the g >= 0 rows matter on this feeder, so
-            # the general home-space ADMM takes over for the rest of the run
-            self._fast_ok = False
+            if self._fast_wait > 0:
+                self._fast_wait -= 1
+            else:
+                r = self._operator_solve_node(precheck=self._fast_backoff > 1)
+                if r is True:
+                    self._fast_backoff = 1
+                    return self.op_converged
+                # Some residence would go to zero: the g >= 0 rows matter for this state, so
+                # the general home-space ADMM solves it.  The fast path is tried again later
+                # (clamps are typical of the first ADMM iterations and often disappear): at
+                # once when only the free pre-check g0 >= 0 failed, after an exponentially
+                # growing number of iterations when a whole fast solve was wasted.
+                if r == "post":
+                    self._fast_backoff = min(2 * self._fast_backoff, 64)
+                    self._fast_wait = self._fast_backoff
+                self._fast_cold = True
+                self.op_cold = True
         _lib.check(lib.revs_op_g0(self.n, T, ptr(self.P_est), ptr(self.P_sch), ptr(self.G),
                                   self.kappa, ptr(self.g0), st), "revs_op_g0")
         if self.op_cold or not o.warm_start:

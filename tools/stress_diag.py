@@ -12,16 +12,12 @@ from revs_admm_amd.synthetic import make_workload
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 M = int(sys.argv[2]) if len(sys.argv) > 2 else 512
-for stress in (3.0,):
+for stress in (1.15, 1.5, 2.0, 3.0):
     w = make_workload(n, 24, n_nodes=M, seed=0, binary_feasible=False, stress=stress)
-    for tag, op in (("default", OperatorOptions(max_iter=4000)),
-                    ("rv100-rb10", OperatorOptions(max_iter=4000, calibrate=False, rho_v_scale=100.0, rho_b_scale=10.0)),
-                    ("rv1000-rb10", OperatorOptions(max_iter=4000, calibrate=False, rho_v_scale=1000.0, rho_b_scale=10.0)),
-                    ("rv1000-rb100", OperatorOptions(max_iter=4000, calibrate=False, rho_v_scale=1000.0, rho_b_scale=100.0)),
-                    ("rv10-rb1-a1.0", OperatorOptions(max_iter=4000, calibrate=False, rho_v_scale=10.0, rho_b_scale=1.0, alpha=1.0))):
+    for tag, op in (("default", OperatorOptions(max_iter=4000)),):
         e = AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, kappa=w.kappa, vset=w.vset,
                        vlow=w.vlow, vhigh=w.vhigh, mode="relaxed_exact", op=op)
-        for _ in range(6):
+        for _ in range(30):
             e.step(write_sc=False)
         clamped = int((e.P_est == 0).sum().item())
         print(f"stress {stress} {tag:13s} paths {''.join(p[0] for p in e.op_path_hist)} iters "
