@@ -292,3 +292,53 @@ def test_config0_com2_30pct_adoption(gpu_lib, golden, feeder_R):
     assert (np.abs(S - p1) < 1e-6).all()             # same home problem as iteration 1
     np.testing.assert_allclose(d[1], np.linalg.norm(ref - g1, axis=1) / T, atol=2e-5)
     assert e.op_path_hist[-1] == "home"              # this feeder clamps residences at zero
+
+
+def test_revs_fixture_end_to_end(gpu_lib, golden, tmp_path):
+    """The reference's driver flow (test-optimizer.py): REVS(**file_params).read_inputs(...)
+    -> get_individual_optimal / get_distributed_optimal / get_centralized_optimal(save=True),
+    on input files written in the reference's formats (tariff txt, community txt, home-load
+    csv in W with hour1..hour24 columns, pickled networkx feeder)."""
+    import pickle
+    from revs_admm_amd.revs_fixture import REVS
+    z, fd = golden
+    data = tmp_path / "input"
+    data.mkdir()
+    res = z["res_id"].tolist()
+    (data / "DVP-tariff.txt").write_text(" ".join(repr(float(x)) for x in z["tariff_raw"]))
+    offs = z["com_offsets"]
+    (data / "121144-com.txt").write_text("\n".join(
+        " ".join(str(int(h)) for h in z["com_flat"][offs[i]:offs[i + 1]]) for i in range(5)))
+    unshift = np.roll(z["LOAD"], 6, axis=1) * 1e3               # file is unshifted, in W
+    with open(data / "121-home-load.csv", "w") as f:
+        f.write("hid," + ",".join(f"hour{i + 1}" for i in range(24)) + "\n")
+        for h, row in zip(res, unshift):
+            f.write(str(h) + "," + ",".join(repr(float(v)) for v in row) + "\n")
+    with open(data / "121144-dist-net.gpickle", "wb") as f:
+        pickle.dump(_nx_graph(fd, z), f)
+    fx = REVS(networkID=121144, regionID=121, comunityID=2, tariffID="DVP",
+              optimizer_mode="distributed", data_path=str(data), out_path=str(tmp_path / "out"),
+              fig_path=str(tmp_path / "figs"))
+    inp = dict(adoption=90, rating=4800, seed=1234, capacity=20, initial_soc=0.2, start_time=11,
+               end_time=23, shift_time=6)
+    tariff, homes, dist, save = fx.read_inputs(**inp)
+    np.testing.assert_allclose(tariff, z["tariff_shift6"])
+    assert list(save["ev_homes"]) == z["dis_a90_r4800_ev_homes"].tolist()
+    np.testing.assert_allclose(homes[res[5]]["LOAD"], z["LOAD"][5], rtol=1e-12)
+    opt = dict(v0=1.03, vmin=0.90, vmax=1.05, max_iterations=3, kappa=5.0, **save, **inp)
+    Pres, Pev, soc = fx.get_distributed_optimal(tariff, homes, dist, save=True, **opt)
+    out = tmp_path / "out" / "121144-com2" / "distributed" / "adopt90-rating4800-seed1234.txt"
+    txt = out.read_text()
+    assert sum(l.startswith("####") for l in txt.split("\n")) == 8
+    assert "EV Convergence over Iterations" in txt
+    ev0 = int(save["ev_homes"][0])
+    line = [l for l in txt.split("\n") if l.startswith(f"{ev0}:\t")][-1]        # diff row
+    d1 = float(line.split("\t")[1].split(" ")[0])
+    assert abs(d1 - z["dis_a90_r4800_diff"][0, 0]) < 2e-6 * d1
+    assert abs(sum(Pev[ev0]) - 14.4) < 1e-4 and abs(soc[ev0][-1] - 0.92) < 1e-5
+    # the other two modes of the fixture
+    fx.optim = "individual"
+    Pres_i, Pev_i, soc_i = fx.get_individual_optimal(tariff, homes, **opt)
+    assert abs(sum(Pev_i[ev0]) - 14.4) < 1e-4
+    Pres_c, Pev_c, soc_c = fx.get_centralized_optimal(tariff, homes, dist, **opt)
+    assert sum(Pev_c[ev0]) == 0.0 and soc_c[ev0][-1] == pytest.approx(0.2)
