@@ -95,8 +95,8 @@ def main():
     ap.add_argument("--nodes", type=int, default=2048)
     ap.add_argument("--mode", default="pdhg", choices=["pdhg", "relaxed_exact", "binary"])
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--stress", type=float, default=1.15,
-                    help="uncoordinated peak voltage / limit of the synthetic feeder")
+    ap.add_argument("--stress", type=float, default=1.1,
+                    help="coordinated-profile voltage / limit of the synthetic feeder")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eps", type=float, default=1e-4, help="ADMM residual target")
     ap.add_argument("--op-check", type=int, default=None, help="operator: residual test period")
@@ -284,6 +284,8 @@ def main():
                 "operator_ms_per_step": oper_ms, "agent_ms_per_step": agent_ms,
                 "operator_inner_iters_mean": float(np.mean(inner)) if inner else 0.0,
                 "operator_path": eng.op_path_hist[-1],
+                "operator_active_rows": int((eng.yv != 0).sum().item()),
+                "operator_rows": int(eng.M * args.T),
                 "admm_residual_primal": rp, "admm_residual_dual": rd, "admm_max_diff": dmax,
                 "admm_iters_to_eps": iters_to_eps, "eps": args.eps,
             },

@@ -274,6 +274,11 @@ int revs_op_node_update(int32_t m, int32_t T, int32_t nslab, const double *va,
  *   revs_op_node_prep      p0[m] = isn[m] sum_i g0_i, gmin[m] = min_i g0_i (double[m][T]),
  *                          g0 = (P_est + P_sch)/2 - G/kappa from the float state;
  *                          g0_out (double[n][T]) or NULL
+ *   revs_op_nodefast_feas   the operator's voltage check proper: v0 = Rs p0 (nslab slabs of
+ *                           Q (l ph0)) against the bounds; cx = v0; stats (double[2], ZERO on
+ *                           entry): [0] = largest row violation (0 <=> g0 already respects
+ *                           every voltage row), [1] = max(0, -min gmin) (> 0 <=> some
+ *                           residence has g0 < 0).  Both 0 <=> the answer is g0 itself
  *   revs_op_nodefast_scale  xh = (kappa ph0 + l wh)/(kappa + rho_v l^2), sx = l xh
  *                           (wh = Q^T w as nslab slabs, ph0 = Q^T p0)
  *   revs_op_nodefast_update z_v, y_v, w from zt = Q sx (nslab slabs); res rows 0,3,4
@@ -285,6 +290,9 @@ int revs_op_node_update(int32_t m, int32_t T, int32_t nslab, const double *va,
 int revs_op_node_prep(int32_t m, int32_t T, const int64_t *node_ptr, const double *inv_sqrt_n,
                       const float *p_est, const float *p_sch, const float *gamma, double kappa,
                       double *p0, double *gmin, double *g0_out, void *stream);
+int revs_op_nodefast_feas(int32_t m, int32_t T, int32_t nslab, const double *v0,
+                          const double *bound_scale, const double *gmin, double vlo, double vhi,
+                          double *cx, double *stats, void *stream);
 int revs_op_nodefast_scale(int32_t m, int32_t T, int32_t nslab, const double *wh,
                            const double *ph0, const double *lam, const double *rho_v,
                            double kappa, double *xh, double *sx, void *stream);

@@ -416,6 +416,37 @@ __global__ void op_nodefast_dualres_kernel(int total, int T, int nslab, const do
     }
 }
 
+// v0 = Rs p0 (nslab slabs) against the scaled bounds: stats[0] = max over rows of the
+// violation max(v0 - b vhi, b vlo - v0, 0); cx = v0.  Zero violation <=> d = 0 is optimal.
+// stats[1] = max(0, -min gmin): > 0 <=> some residence has g0 < 0 (a clamp is certain).
+__global__ void op_nodefast_feas_kernel(int total, int T, int nslab, const double *v_s,
+                                        const double *bscale, const double *gmin, double vlo,
+                                        double vhi, double *cx, double *stats) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double viol = 0.0, neg = 0.0;
+    if (i < total) {
+        double v = v_s[i];
+        for (int q = 1; q < nslab; ++q) v += v_s[i + (int64_t)q * total];
+        cx[i] = v;
+        const double bs = bscale ? bscale[i / T] : 1.0;
+        viol = fmax(fmax(v - bs * vhi, bs * vlo - v), 0.0);
+        neg = fmax(-gmin[i], 0.0);
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+        viol = fmax(viol, __shfl_xor(viol, o, 64));
+        neg = fmax(neg, __shfl_xor(neg, o, 64));
+    }
+    __shared__ double red[2][4];
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = viol; red[1][threadIdx.x >> 6] = neg; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        viol = fmax(fmax(red[0][0], red[0][1]), fmax(red[0][2], red[0][3]));
+        neg = fmax(fmax(red[1][0], red[1][1]), fmax(red[1][2], red[1][3]));
+        if (viol > 0.0) atomic_max_nonneg(stats, viol);
+        if (neg > 0.0) atomic_max_nonneg(stats + 1, neg);
+    }
+}
+
 // d = x - p0 (x as nslab slabs of Q xh); slack[m][t] = gmin + isn d  (>= 0 <=> no clamp)
 // stats[0] = max(0, -min slack), stats[1] = max |p0|   (stats zeroed by the caller)
 __global__ void op_nodefast_finish_kernel(int total, int T, int nslab, const double *x_s,
@@ -680,6 +711,17 @@ extern "C" int revs_op_nodefast_dualres(int32_t m, int32_t T, int32_t nslab, con
     hipLaunchKernelGGL(op_nodefast_dualres_kernel, grid1((int64_t)m * T), dim3(256), 0, S_(stream),
                        m * T, T, nslab, xh, ph0, lam, yh, kappa, res);
     REVS_CHECK_LAUNCH("revs_op_nodefast_dualres");
+    return REVS_OK;
+}
+
+extern "C" int revs_op_nodefast_feas(int32_t m, int32_t T, int32_t nslab, const double *v0,
+                                     const double *bound_scale, const double *gmin, double vlo,
+                                     double vhi, double *cx, double *stats, void *stream) {
+    REVS_REQUIRE(m > 0 && T > 0 && nslab >= 1 && v0 && gmin && cx && stats && vlo <= vhi,
+                 "revs_op_nodefast_feas: bad argument");
+    hipLaunchKernelGGL(op_nodefast_feas_kernel, grid1((int64_t)m * T), dim3(256), 0, S_(stream),
+                       m * T, T, nslab, v0, bound_scale, gmin, vlo, vhi, cx, stats);
+    REVS_CHECK_LAUNCH("revs_op_nodefast_feas");
     return REVS_OK;
 }
 

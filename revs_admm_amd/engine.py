@@ -471,17 +471,35 @@ class AdmmEngine:
         if self.group is not None:               # the only exchange of this outer iteration
             self._allreduce(self.p0)
             self._allreduce(self.gmin, torch.distributed.ReduceOp.MIN)
-        if precheck and float(self.gmin.min().item()) < 0.0:
-            return "pre"
         self._gemm(self.Q, self.p0, self.ph0)                              # ph0 = Q^T p0
-        if self._fast_cold:
-            check(lib.revs_op_row_scale(M, T, ptr(self.s), ptr(self.ph0), ptr(self.xh), st),
-                  "revs_op_row_scale")
-            self._gemm(self.QT, self.xh, self.cx)                          # Rs p0
+        # The voltage check proper: if R.(aggregate of g0) already respects every row, the
+        # projection is g0 itself (d = 0) and no iteration is needed.
+        check(lib.revs_op_row_scale(M, T, ptr(self.s), ptr(self.ph0), ptr(self.sx), st),
+              "revs_op_row_scale")
+        self._gemm1(self.QT, self.sx, self.f_zt)                           # Rs p0
+        self.f_stats.zero_()
+        check(lib.revs_op_nodefast_feas(M, T, self.ksplit1, ptr(self.f_zt), ptr(self.sqrt_n),
+                                        ptr(self.gmin), self.vlo, self.vhi, ptr(self.cx),
+                                        ptr(self.f_stats), st), "revs_op_nodefast_feas")
+        viol0, neg0 = self.f_stats.cpu().tolist()        # the one host sync of the easy case
+        if neg0 > 0.0 and (precheck or viol0 == 0.0):
+            return "pre"                     # a residence with g0 < 0 has to be clamped anyway
+        feasible = viol0 == 0.0
+        if feasible or self._fast_cold:
             check(lib.revs_op_init_node(M, T, ptr(self.cx), ptr(self.rho_f), ptr(self.sqrt_n),
                                         self.vlo, self.vhi, ptr(self.zv), ptr(self.yv),
-                                        ptr(self.w), st), "revs_op_init_node")
+                                        ptr(self.w), st), "revs_op_init_node")   # z = Rs p0, y = 0
             self._fast_cold = False
+        if feasible:
+            self.dnode.zero_()
+            check(lib.revs_op_node_apply(M, T, ptr(self.node_ptr), ptr(self.inv_sqrt_n),
+                                         ptr(self.P_est), ptr(self.P_sch), ptr(self.G), self.kappa,
+                                         ptr(self.dnode), ptr(self.P_est_new), st),
+                  "revs_op_node_apply")
+            self.op_iters_hist.append(0)
+            self.op_path_hist.append("node")
+            self.op_converged = True
+            return True
         it, converged = 0, False
         while it < o.max_iter:
             self._fast_block()

@@ -219,6 +219,15 @@ class FakeKernels:
             view(g0_out, (n, T), np.float64)[:] = g
         return 0
 
+    def revs_op_nodefast_feas(self, m, T, nslab, v0, bscale, gmin, vlo, vhi, cx, stats, stream):
+        v = view(v0, (nslab, m, T), np.float64).sum(axis=0)
+        bs = view(bscale, (m,), np.float64)[:, None] if bscale else 1.0
+        view(cx, (m, T), np.float64)[:] = v
+        st = view(stats, (2,), np.float64)
+        st[0] = max(st[0], np.maximum(np.maximum(v - bs * vhi, bs * vlo - v), 0).max())
+        st[1] = max(st[1], np.maximum(-view(gmin, (m, T), np.float64), 0).max())
+        return 0
+
     def revs_op_nodefast_scale(self, m, T, nslab, wh, ph0, lam, rho_v, kappa, xh, sx, stream):
         d = lambda p: view(p, (m, T), np.float64)
         l = view(lam, (m,), np.float64)[:, None]

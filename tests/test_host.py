@@ -129,7 +129,7 @@ def test_engine_driver_on_fake_kernels(mode, omode):
         assert np.abs(S - S_ref).max() < 1e-3 and np.abs(d - d_ref).max() < 1e-3
 
 
-@pytest.mark.parametrize("stress,paths", [(1.3, {"node"}), (4.0, {"node", "home"})])
+@pytest.mark.parametrize("stress,paths", [(0.9, {"node"}), (2.0, {"node", "home"})])
 def test_operator_paths_on_fake_kernels(stress, paths):
     """Driver logic of the two operator paths: the node-space fast path is kept while no
     residence is pushed to zero, and the general home-space ADMM takes over (for the rest of
@@ -143,10 +143,10 @@ def test_operator_paths_on_fake_kernels(stress, paths):
     e = AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, kappa=w.kappa, vset=w.vset,
                    vlow=w.vlow, vhigh=w.vhigh, mode="relaxed_exact", device="cpu",
                    _kernels=FakeKernels())
-    d = e.run(4)
-    d_ref, P_ref, S_ref, C_ref = ro.solve_ADMM(oracle_homes(w), w.Rn, w.node_of, w.cost, w.kappa, 4,
+    d = e.run(6)
+    d_ref, P_ref, S_ref, C_ref = ro.solve_ADMM(oracle_homes(w), w.Rn, w.node_of, w.cost, w.kappa, 6,
                                                w.vset, w.vlow, w.vhigh, mode="relaxed")
-    assert set(e.op_path_hist) == paths
+    assert set(e.op_path_hist) == paths and max(e.op_iters_hist) > 0     # the rows do bind
     if "home" in paths:           # after a wasted fast solve the retry backs off (2, 4, ... steps)
         k = e.op_path_hist.index("home")
         assert set(e.op_path_hist[k:]) == {"home"} and e.P_est.min().item() == 0.0
