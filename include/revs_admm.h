@@ -273,7 +273,10 @@ int revs_op_node_update(int32_t m, int32_t T, int32_t nslab, const double *va,
  *
  *   revs_op_node_prep      p0[m] = isn[m] sum_i g0_i, gmin[m] = min_i g0_i (double[m][T]),
  *                          g0 = (P_est + P_sch)/2 - G/kappa from the float state;
- *                          g0_out (double[n][T]) or NULL
+ *                          g0_out (double[n][T]) or NULL.  preclamp != 0 uses max(g0, 0):
+ *                          an exact presolve when R >= 0 entrywise and vlo <= 0 (only upper
+ *                          rows can bind, so every node shift is <= 0 and a residence with
+ *                          g0 < 0 sits at zero whatever the voltage rows do)
  *   revs_op_nodefast_feas   the operator's voltage check proper: v0 = Rs p0 (nslab slabs of
  *                           Q (l ph0)) against the bounds; cx = v0; stats (double[2], ZERO on
  *                           entry): [0] = largest row violation (0 <=> g0 already respects
@@ -286,10 +289,10 @@ int revs_op_node_update(int32_t m, int32_t T, int32_t nslab, const double *va,
  *                           eigenbasis: |kappa (xh - ph0) + l yh|, kappa|xh| ...
  *   revs_op_nodefast_finish d = Q xh - p0 (x as nslab slabs), slack = gmin + isn d;
  *                           stats (double[2], ZERO on entry) = {max(0, -min slack), max|p0|}
- *   revs_op_node_apply      P_est_i = max(g0_i + isn[m] d[m], 0) as float              */
+ *   revs_op_node_apply      P_est_i = max(g0_i + isn[m] d[m], 0) as float (g0 as in prep)   */
 int revs_op_node_prep(int32_t m, int32_t T, const int64_t *node_ptr, const double *inv_sqrt_n,
                       const float *p_est, const float *p_sch, const float *gamma, double kappa,
-                      double *p0, double *gmin, double *g0_out, void *stream);
+                      int32_t preclamp, double *p0, double *gmin, double *g0_out, void *stream);
 int revs_op_nodefast_feas(int32_t m, int32_t T, int32_t nslab, const double *v0,
                           const double *bound_scale, const double *gmin, double vlo, double vhi,
                           double *cx, double *stats, void *stream);
@@ -308,7 +311,7 @@ int revs_op_nodefast_finish(int32_t m, int32_t T, int32_t nslab, const double *x
                             double *d, double *slack, double *stats, void *stream);
 int revs_op_node_apply(int32_t m, int32_t T, const int64_t *node_ptr, const double *inv_sqrt_n,
                        const float *p_est, const float *p_sch, const float *gamma, double kappa,
-                       const double *d, float *p_est_new, void *stream);
+                       int32_t preclamp, const double *d, float *p_est_new, void *stream);
 
 /* P_est = max(s_b, 0) as float: the operator's answer handed to the homes
  * (U_obj.g_opt, lpsolver.py:236-237, 259). */

@@ -66,14 +66,14 @@ SIGNATURES = {
     "revs_op_node_scale": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _p, _p, _f64, _p, _p, _p]),
     "revs_op_node_update": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _f64, _f64, _f64,
                                       _f64, _p, _p, _p, _p, _p, _p]),
-    "revs_op_node_prep": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p, _f64, _p, _p, _p, _p]),
+    "revs_op_node_prep": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p, _f64, _i32, _p, _p, _p, _p]),
     "revs_op_nodefast_feas": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _f64, _f64, _p, _p, _p]),
     "revs_op_nodefast_scale": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _p, _f64, _p, _p, _p]),
     "revs_op_nodefast_update": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _f64, _f64, _f64, _p, _p,
                                           _p, _p, _p]),
     "revs_op_nodefast_dualres": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _p, _f64, _p, _p]),
     "revs_op_nodefast_finish": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p]),
-    "revs_op_node_apply": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p, _f64, _p, _p, _p]),
+    "revs_op_node_apply": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p, _f64, _i32, _p, _p, _p]),
     "revs_op_export": (C.c_int, [_i64, _i32, _p, _p, _p]),
 }
 

@@ -295,7 +295,7 @@ template <int TL>
 __global__ __launch_bounds__(256) void op_node_prep_kernel(
         int m, int T, const int64_t *__restrict__ node_ptr, const double *__restrict__ inv_sqrt_n,
         const float *__restrict__ pe, const float *__restrict__ ps, const float *__restrict__ gm,
-        double kappa, double *__restrict__ p0, double *__restrict__ gmin,
+        double kappa, int preclamp, double *__restrict__ p0, double *__restrict__ gmin,
         double *__restrict__ g0_out) {
     constexpr int HS = 256 / TL;
     const int node = blockIdx.x;
@@ -307,8 +307,12 @@ __global__ __launch_bounds__(256) void op_node_prep_kernel(
     if (tok) {
         for (int64_t i = i0 + hs; i < i1; i += HS) {
             const int64_t o = i * T + t;
-            const double g = 0.5 * ((double)pe[o] + (double)ps[o]) - (double)gm[o] * inv_k;
+            double g = 0.5 * ((double)pe[o] + (double)ps[o]) - (double)gm[o] * inv_k;
             if (g0_out) g0_out[o] = g;
+            // R >= 0 entrywise and vlo <= 0: only upper rows can bind, the node shift is
+            // <= 0, so max(g0 - theta, 0) = max(max(g0,0) - theta, 0): residences with
+            // g0 < 0 are at zero whatever the voltage rows do (exact presolve)
+            if (preclamp) g = fmax(g, 0.0);
             acc += g;
             mn = fmin(mn, g);
         }
@@ -485,7 +489,7 @@ template <int TL>
 __global__ __launch_bounds__(256) void op_node_apply_kernel(
         int m, int T, const int64_t *__restrict__ node_ptr, const double *__restrict__ inv_sqrt_n,
         const float *__restrict__ pe, const float *__restrict__ ps, const float *__restrict__ gm,
-        double kappa, const double *__restrict__ d, float *__restrict__ pe_new) {
+        double kappa, int preclamp, const double *__restrict__ d, float *__restrict__ pe_new) {
     constexpr int HS = 256 / TL;
     const int node = blockIdx.x;
     const int t = threadIdx.x % TL, hs = threadIdx.x / TL;
@@ -495,7 +499,8 @@ __global__ __launch_bounds__(256) void op_node_apply_kernel(
     const int64_t i0 = node_ptr[node], i1 = node_ptr[node + 1];
     for (int64_t i = i0 + hs; i < i1; i += HS) {
         const int64_t o = i * T + t;
-        const double g = 0.5 * ((double)pe[o] + (double)ps[o]) - (double)gm[o] * inv_k;
+        double g = 0.5 * ((double)pe[o] + (double)ps[o]) - (double)gm[o] * inv_k;
+        if (preclamp) g = fmax(g, 0.0);
         pe_new[o] = (float)fmax(g + corr, 0.0);
     }
 }
@@ -670,12 +675,12 @@ extern "C" int revs_op_export(int64_t n_homes, int32_t T, const double *sb, floa
 
 extern "C" int revs_op_node_prep(int32_t m, int32_t T, const int64_t *node_ptr,
                                  const double *inv_sqrt_n, const float *p_est, const float *p_sch,
-                                 const float *gamma, double kappa, double *p0, double *gmin,
-                                 double *g0_out, void *stream) {
+                                 const float *gamma, double kappa, int32_t preclamp, double *p0,
+                                 double *gmin, double *g0_out, void *stream) {
     REVS_REQUIRE(m > 0 && T > 0 && T <= 256 && node_ptr && inv_sqrt_n && p_est && p_sch && gamma &&
                  p0 && gmin && kappa > 0, "revs_op_node_prep: bad argument");
     REVS_TL_DISPATCH(T, op_node_prep_kernel, dim3(m), dim3(256), 0, S_(stream), m, T, node_ptr,
-                     inv_sqrt_n, p_est, p_sch, gamma, kappa, p0, gmin, g0_out);
+                     inv_sqrt_n, p_est, p_sch, gamma, kappa, preclamp, p0, gmin, g0_out);
     REVS_CHECK_LAUNCH("revs_op_node_prep");
     return REVS_OK;
 }
@@ -739,12 +744,12 @@ extern "C" int revs_op_nodefast_finish(int32_t m, int32_t T, int32_t nslab, cons
 
 extern "C" int revs_op_node_apply(int32_t m, int32_t T, const int64_t *node_ptr,
                                   const double *inv_sqrt_n, const float *p_est, const float *p_sch,
-                                  const float *gamma, double kappa, const double *d,
-                                  float *p_est_new, void *stream) {
+                                  const float *gamma, double kappa, int32_t preclamp,
+                                  const double *d, float *p_est_new, void *stream) {
     REVS_REQUIRE(m > 0 && T > 0 && T <= 256 && node_ptr && inv_sqrt_n && p_est && p_sch && gamma &&
                  d && p_est_new && kappa > 0, "revs_op_node_apply: bad argument");
     REVS_TL_DISPATCH(T, op_node_apply_kernel, dim3(m), dim3(256), 0, S_(stream), m, T, node_ptr,
-                     inv_sqrt_n, p_est, p_sch, gamma, kappa, d, p_est_new);
+                     inv_sqrt_n, p_est, p_sch, gamma, kappa, preclamp, d, p_est_new);
     REVS_CHECK_LAUNCH("revs_op_node_apply");
     return REVS_OK;
 }

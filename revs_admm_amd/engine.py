@@ -210,6 +210,8 @@ class AdmmEngine:
         self.f_stats = torch.zeros(2, **f64)
         self.rho_f = torch.full((T,), self.op.rho_v_scale * self.kappa / self.smax ** 2, **f64)
         self._fast_ok = bool(self.op.node_fast)
+        # exact presolve of the fast path (see revs_op_node_prep): needs R >= 0 and vlo <= 0
+        self.preclamp = int(bool(Rn.min() >= 0.0 and self.vlo <= 0.0))
         self._fast_wait = 0
         self._fast_backoff = 1
         self._fast_cold = True
@@ -466,8 +468,8 @@ class AdmmEngine:
         "post" when the node solve finished but some residence would have to be clamped."""
         o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
         check(lib.revs_op_node_prep(M, T, ptr(self.node_ptr), ptr(self.inv_sqrt_n), ptr(self.P_est),
-                                    ptr(self.P_sch), ptr(self.G), self.kappa, ptr(self.p0),
-                                    ptr(self.gmin), None, st), "revs_op_node_prep")
+                                    ptr(self.P_sch), ptr(self.G), self.kappa, self.preclamp,
+                                    ptr(self.p0), ptr(self.gmin), None, st), "revs_op_node_prep")
         if self.group is not None:               # the only exchange of this outer iteration
             self._allreduce(self.p0)
             self._allreduce(self.gmin, torch.distributed.ReduceOp.MIN)
@@ -494,7 +496,7 @@ class AdmmEngine:
             self.dnode.zero_()
             check(lib.revs_op_node_apply(M, T, ptr(self.node_ptr), ptr(self.inv_sqrt_n),
                                          ptr(self.P_est), ptr(self.P_sch), ptr(self.G), self.kappa,
-                                         ptr(self.dnode), ptr(self.P_est_new), st),
+                                         self.preclamp, ptr(self.dnode), ptr(self.P_est_new), st),
                   "revs_op_node_apply")
             self.op_iters_hist.append(0)
             self.op_path_hist.append("node")
@@ -548,8 +550,8 @@ class AdmmEngine:
         if viol > 1e-9 * max(1.0, pmax):
             return "post"
         check(lib.revs_op_node_apply(M, T, ptr(self.node_ptr), ptr(self.inv_sqrt_n), ptr(self.P_est),
-                                     ptr(self.P_sch), ptr(self.G), self.kappa, ptr(self.dnode),
-                                     ptr(self.P_est_new), st), "revs_op_node_apply")
+                                     ptr(self.P_sch), ptr(self.G), self.kappa, self.preclamp,
+                                     ptr(self.dnode), ptr(self.P_est_new), st), "revs_op_node_apply")
         self.op_iters_hist.append(it)
         self.op_path_hist.append("node")
         self.op_converged = converged

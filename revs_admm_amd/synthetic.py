@@ -67,7 +67,7 @@ def radial_R(parent, edge_r):
 
 
 def make_workload(n_homes, T=24, n_nodes=None, seed=0, adoption=0.5, binary_feasible=True,
-                  stress=1.1, vset=1.0, vlow=0.95, vhigh=1.05, kappa=5.0) -> Workload:
+                  stress=1.0, vset=1.0, vlow=0.95, vhigh=1.05, kappa=5.0) -> Workload:
     """Random feeder + residences.  `stress` scales the line resistances so that the
     coordinated profile (base load + every EV's energy spread evenly over its window) sits
     at stress x the upper voltage limit at the worst node: with stress > 1 the operator

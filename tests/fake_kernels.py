@@ -205,18 +205,21 @@ class FakeKernels:
         return 0
 
     # ---- node-space fast path ----
-    def revs_op_node_prep(self, m, T, node_ptr, isn, pe, ps, gm, kappa, p0, gmin, g0_out, stream):
+    def revs_op_node_prep(self, m, T, node_ptr, isn, pe, ps, gm, kappa, preclamp, p0, gmin, g0_out,
+                          stream):
         node, n = self._seg(m, node_ptr)
         f = lambda p: view(p, (n, T), np.float32).astype(float)
         g = 0.5 * (f(pe) + f(ps)) - f(gm) / kappa
+        if g0_out:
+            view(g0_out, (n, T), np.float64)[:] = g
+        if preclamp:
+            g = np.maximum(g, 0)
         acc = np.zeros((m, T))
         np.add.at(acc, node, g)
         mn = np.full((m, T), np.inf)
         np.minimum.at(mn, node, g)
         view(p0, (m, T), np.float64)[:] = view(isn, (m,), np.float64)[:, None] * acc
         view(gmin, (m, T), np.float64)[:] = mn
-        if g0_out:
-            view(g0_out, (n, T), np.float64)[:] = g
         return 0
 
     def revs_op_nodefast_feas(self, m, T, nslab, v0, bscale, gmin, vlo, vhi, cx, stats, stream):
@@ -272,10 +275,13 @@ class FakeKernels:
         st[1] = max(st[1], np.abs(d(p0)).max())
         return 0
 
-    def revs_op_node_apply(self, m, T, node_ptr, isn, pe, ps, gm, kappa, dd, pe_new, stream):
+    def revs_op_node_apply(self, m, T, node_ptr, isn, pe, ps, gm, kappa, preclamp, dd, pe_new,
+                           stream):
         node, n = self._seg(m, node_ptr)
         f = lambda p: view(p, (n, T), np.float32).astype(float)
         g = 0.5 * (f(pe) + f(ps)) - f(gm) / kappa
+        if preclamp:
+            g = np.maximum(g, 0)
         corr = (view(isn, (m,), np.float64)[:, None] * view(dd, (m, T), np.float64))[node]
         view(pe_new, (n, T), np.float32)[:] = np.maximum(g + corr, 0)
         return 0
