@@ -9,8 +9,8 @@
  * hipStream_t passed as void* (NULL = the null stream).  All pointers are DEVICE
  * pointers unless the name ends in `_host`.  Every entry point returns 0 on
  * success and a negative REVS_E* code otherwise; revs_last_error() gives the text.
- * Nothing here allocates, frees or synchronises (safe under hipGraph capture),
- * except the revs_op_* setup/teardown pair, which says so.
+ * Nothing here allocates, frees or synchronises: every entry point only enqueues
+ * kernels on `stream` and is safe under hipGraph capture.
  *
  * Layout in HBM: home-major, slot-contiguous.  A "profile" is float[n_homes][T].
  */
