@@ -472,7 +472,9 @@ class AdmmEngine:
                                     ptr(self.p0), ptr(self.gmin), None, st), "revs_op_node_prep")
         if self.group is not None:               # the only exchange of this outer iteration
             self._allreduce(self.p0)
-            self._allreduce(self.gmin, torch.distributed.ReduceOp.MIN)
+            if not self.preclamp:                # with the pre-clamp gmin >= 0 is known, and its
+                self._allreduce(self.gmin, torch.distributed.ReduceOp.MIN)   # exact value is
+                                                 # only needed if rows bind (below)
         self._gemm(self.Q, self.p0, self.ph0)                              # ph0 = Q^T p0
         # The voltage check proper: if R.(aggregate of g0) already respects every row, the
         # projection is g0 itself (d = 0) and no iteration is needed.
@@ -487,6 +489,8 @@ class AdmmEngine:
         if neg0 > 0.0 and (precheck or viol0 == 0.0):
             return "pre"                     # a residence with g0 < 0 has to be clamped anyway
         feasible = viol0 == 0.0
+        if not feasible and self.group is not None and self.preclamp:
+            self._allreduce(self.gmin, torch.distributed.ReduceOp.MIN)   # for the slack test
         if feasible or self._fast_cold:
             check(lib.revs_op_init_node(M, T, ptr(self.cx), ptr(self.rho_f), ptr(self.sqrt_n),
                                         self.vlo, self.vhi, ptr(self.zv), ptr(self.yv),
