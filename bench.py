@@ -219,8 +219,9 @@ def main():
     st = eng.status.cpu().numpy()
     pdhg_it = float((st >> 8)[(st >> 8) > 0].mean()) if args.mode == "pdhg" and ((st >> 8) > 0).any() else None
 
-    # the f64 matrix-core product of the operator path that actually ran: Q^T w (T columns)
-    # on the node-space fast path, Q^T [rhat | w] (2T columns) on the general path
+    # the f64 matrix-core product of the operator path that actually ran: the voltage check
+    # Rs.p0 / Q^T w (M x M x T) on the node-space fast path, Q^T [rhat | w] (2T columns) on
+    # the general path
     fast = eng.op_path_hist[-1] == "node"
     reps = 200
     torch.cuda.synchronize()
@@ -228,7 +229,7 @@ def main():
     e0.record()
     for _ in range(reps):
         if fast:
-            eng._gemm1(eng.Q, eng.w, eng.f_wh)
+            eng._gemm1(eng.Rs, eng.p0, eng.f_wh)
         else:
             eng._gemm_cat(eng.Q, eng.rhat, eng.w, eng.ta, eng.tb)
     e1.record()
@@ -297,7 +298,7 @@ def main():
                 "avg_launch_ms": agent_ms, "pdhg_iters_mean": pdhg_it,
             },
             "roofline_matvec": {
-                "kernel": "gemm_tn_kernel<double> (" + ("Q^T w, M x M x T" if fast else "Q^T [rhat | w], M x M x 2T") + ")",
+                "kernel": "gemm_tn_kernel<double> (" + ("voltage check Rs.p0, M x M x T" if fast else "Q^T [rhat | w], M x M x 2T") + ")",
                 "bound": "mfma", "achieved": gemm_flops / (gemm_ms * 1e-3) / 1e12,
                 "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": gemm_flops / (gemm_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS,

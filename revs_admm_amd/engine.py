@@ -186,6 +186,8 @@ class AdmmEngine:
         lam = np.maximum(lam, 0.0)
         self.smax = float(lam.max())
         self.Q, self.QT = up(Q), up(Q.T)
+        # the scaled sensitivity matrix itself, for the one-product voltage check Rs.p0
+        self.Rs = up((Q * lam[None, :]) @ Q.T)
         self.s = up(lam)
         self.sqrt_n = up(sq)
         self.inv_sqrt_n = up(np.where(counts > 0, 1.0 / np.maximum(sq, 1e-300), 0.0))
@@ -210,6 +212,7 @@ class AdmmEngine:
         self.f_stats = torch.zeros(2, **f64)
         self.rho_f = torch.full((T,), self.op.rho_v_scale * self.kappa / self.smax ** 2, **f64)
         self._fast_ok = bool(self.op.node_fast)
+        self._dnode_zero = False
         # exact presolve of the fast path (see revs_op_node_prep): needs R >= 0 and vlo <= 0
         self.preclamp = int(bool(Rn.min() >= 0.0 and self.vlo <= 0.0))
         self._fast_wait = 0
@@ -475,12 +478,9 @@ class AdmmEngine:
             if not self.preclamp:                # with the pre-clamp gmin >= 0 is known, and its
                 self._allreduce(self.gmin, torch.distributed.ReduceOp.MIN)   # exact value is
                                                  # only needed if rows bind (below)
-        self._gemm(self.Q, self.p0, self.ph0)                              # ph0 = Q^T p0
-        # The voltage check proper: if R.(aggregate of g0) already respects every row, the
-        # projection is g0 itself (d = 0) and no iteration is needed.
-        check(lib.revs_op_row_scale(M, T, ptr(self.s), ptr(self.ph0), ptr(self.sx), st),
-              "revs_op_row_scale")
-        self._gemm1(self.QT, self.sx, self.f_zt)                           # Rs p0
+        # The voltage check proper: v0 = Rs.p0, one product on the f64 matrix cores.  If it
+        # already respects every row, the projection is g0 itself (d = 0): no iteration.
+        self._gemm1(self.Rs, self.p0, self.f_zt)                           # Rs symmetric: At = Rs
         self.f_stats.zero_()
         check(lib.revs_op_nodefast_feas(M, T, self.ksplit1, ptr(self.f_zt), ptr(self.sqrt_n),
                                         ptr(self.gmin), self.vlo, self.vhi, ptr(self.cx),
@@ -488,24 +488,28 @@ class AdmmEngine:
         viol0, neg0 = self.f_stats.cpu().tolist()        # the one host sync of the easy case
         if neg0 > 0.0 and (precheck or viol0 == 0.0):
             return "pre"                     # a residence with g0 < 0 has to be clamped anyway
-        feasible = viol0 == 0.0
-        if not feasible and self.group is not None and self.preclamp:
-            self._allreduce(self.gmin, torch.distributed.ReduceOp.MIN)   # for the slack test
-        if feasible or self._fast_cold:
-            check(lib.revs_op_init_node(M, T, ptr(self.cx), ptr(self.rho_f), ptr(self.sqrt_n),
-                                        self.vlo, self.vhi, ptr(self.zv), ptr(self.yv),
-                                        ptr(self.w), st), "revs_op_init_node")   # z = Rs p0, y = 0
-            self._fast_cold = False
-        if feasible:
-            self.dnode.zero_()
+        if viol0 == 0.0:
+            if not self._dnode_zero:
+                self.dnode.zero_()
+                self._dnode_zero = True
             check(lib.revs_op_node_apply(M, T, ptr(self.node_ptr), ptr(self.inv_sqrt_n),
                                          ptr(self.P_est), ptr(self.P_sch), ptr(self.G), self.kappa,
                                          self.preclamp, ptr(self.dnode), ptr(self.P_est_new), st),
                   "revs_op_node_apply")
+            self._fast_cold = True           # z = Rs p0, y = 0 is re-made when rows bind again
             self.op_iters_hist.append(0)
             self.op_path_hist.append("node")
             self.op_converged = True
             return True
+        if self.group is not None and self.preclamp:
+            self._allreduce(self.gmin, torch.distributed.ReduceOp.MIN)   # for the slack test
+        self._dnode_zero = False
+        self._gemm(self.Q, self.p0, self.ph0)                              # ph0 = Q^T p0
+        if self._fast_cold:
+            check(lib.revs_op_init_node(M, T, ptr(self.cx), ptr(self.rho_f), ptr(self.sqrt_n),
+                                        self.vlo, self.vhi, ptr(self.zv), ptr(self.yv),
+                                        ptr(self.w), st), "revs_op_init_node")   # z = clip(Rs p0), y = 0
+            self._fast_cold = False
         it, converged = 0, False
         while it < o.max_iter:
             self._fast_block()
