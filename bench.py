@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--op-rho-b", type=float, default=None, help="operator: rho_b scale")
     ap.add_argument("--op-alpha", type=float, default=None, help="operator: over-relaxation")
     ap.add_argument("--op-adapt", type=int, default=None, help="operator: rho update period")
+    ap.add_argument("--pdhg-check", type=int, default=None, help="PDHG: convergence test period")
     ap.add_argument("--no-converge", action="store_true",
                     help="skip the untimed run to the eps-residual (profiling runs)")
     args = ap.parse_args()
@@ -166,7 +167,8 @@ def main():
         opts.cal_rho_v = tuple(float(x) for x in os.environ["REVS_CAL_RHO_V"].split(","))
     eng = AdmmEngine(w.cost, w.homes[lo:hi], w.load[lo:hi], w.node_of[lo:hi], w.Rn, kappa=w.kappa,
                      vset=w.vset, vlow=w.vlow, vhigh=w.vhigh, mode=args.mode, device=dev,
-                     group=group, node_counts=counts, op=opts)
+                     group=group, node_counts=counts, op=opts,
+                     pdhg=({"check": args.pdhg_check} if args.pdhg_check else None))
     n_local = hi - lo
 
     def barrier():
@@ -308,8 +310,7 @@ def main():
                 "operator_ms_per_step": oper_ms, "agent_ms_per_step": agent_ms,
                 "operator_inner_iters_mean": float(np.mean(inner)) if inner else 0.0,
                 "operator_path": eng.op_path_hist[-1],
-                "operator_active_rows": int((eng.yv != 0).sum().item()),
-                "operator_rows": int(eng.M * args.T),
+                "operator_voltage_rows": int(eng.M * args.T),
                 "admm_residual_primal": rp, "admm_residual_dual": rd, "admm_max_diff": dmax,
                 "admm_iters_to_eps": iters_to_eps, "eps": args.eps,
                 # whole-run view: transient + steady iterations of a 400-iteration run

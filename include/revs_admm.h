@@ -70,7 +70,7 @@ typedef struct {
 const char *revs_version(void);
 const char *revs_last_error(void);
 
-/* Defaults used when `pdhg` is NULL: 4000, 8, 1e-6, automatic scales, presolved rows */
+/* Defaults used when `pdhg` is NULL: 4000, 4, 1e-6, automatic scales, presolved rows */
 void revs_pdhg_defaults(revs_pdhg_t *out_host);
 
 /* Number of partial-residual records (3 floats each) revs_agent_step writes for

@@ -522,7 +522,7 @@ using namespace revs;
 
 extern "C" void revs_pdhg_defaults(revs_pdhg_t *o) {
     o->max_iter = 4000;
-    o->check = 8;
+    o->check = 4;
     o->tol = 1e-6f;
     o->tau_scale = 0.f;      // 0 = automatic: 0.5 / 2.0 presolved, 0.25 / 4.0 with full_rows
     o->sigma_scale = 0.f;

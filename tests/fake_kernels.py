@@ -23,7 +23,7 @@ def view(p, shape, dt):
 class FakeKernels:
     def revs_pdhg_defaults(self, ref):
         o = ref._obj
-        o.max_iter, o.check, o.tol, o.tau_scale, o.sigma_scale = 4000, 8, 1e-6, 0.25, 4.0
+        o.max_iter, o.check, o.tol, o.tau_scale, o.sigma_scale = 4000, 4, 1e-6, 0.0, 0.0
 
     def revs_agent_num_partials(self, n, T):
         return (n + 31) // 32

@@ -47,7 +47,7 @@ def test_argument_validation_without_gpu(lib):
     from revs_admm_amd._lib import PDHG
     pd = PDHG()
     lib.revs_pdhg_defaults(C.byref(pd))
-    assert (pd.max_iter, pd.check) == (4000, 8) and abs(pd.tol - 1e-6) < 1e-12
+    assert (pd.max_iter, pd.check) == (4000, 4) and abs(pd.tol - 1e-6) < 1e-12
     assert lib.revs_agent_num_partials(100000, 24) == 3125          # 32 homes per workgroup
     assert lib.revs_agent_num_partials(10, 96) == 2                 # 8 homes per workgroup
     assert lib.revs_agent_num_partials(10, 500) == 0                # T > REVS_MAX_T
