@@ -317,6 +317,55 @@ int revs_op_node_apply(int32_t m, int32_t T, const int64_t *node_ptr, const doub
  * (U_obj.g_opt, lpsolver.py:236-237, 259). */
 int revs_op_export(int64_t n_homes, int32_t T, const double *sb, float *p_est, void *stream);
 
+/* ---- dual Newton path of the operator QP (the default) --------------------------
+ * Utility.solve (lpsolver.py:163-238) through its dual.  With y (double[m][T]) the
+ * multipliers of the voltage rows, every residence of node m answers
+ *     g_i = max(g0_i - d_m, 0),   d = R^T y / kappa,
+ * so the dual function of slot t is
+ *     D_t(y) = -(kappa/2) sum_i g_i^2 - sum_m max(vhi y_m, vlo y_m)   (+ a constant),
+ * concave and C^1 with piecewise-linear gradient dD/dy_m = (R p)_m - b_m, p = A g,
+ * b_m = vhi / vlo for an upper / lower row.  Each Newton iteration solves the
+ * sign-constrained quadratic model on a candidate set of at most REVS_DUAL_AMAX rows per
+ * slot (rows with y != 0 plus the most violated ones) with generalised Hessian
+ * K = R_F N R_F^T / kappa (N_m = residences of node m not clamped at zero) by block
+ * principal pivoting, then takes an Armijo step on D_t.  The slots are independent
+ * problems that share R and run side by side.  Per evaluation the ranks exchange pnq
+ * (one all-reduce of 3 m T doubles); everything else is replicated and deterministic.
+ *
+ *   revs_op_dual_eval    d = (sum of the nslab slabs of R^T y)/kappa, or 0 when dsl is NULL;
+ *                        g0 = (P_est + P_sch)/2 - G/kappa from the float state;
+ *                        pnq[0] = p (node sums of g), pnq[1] = N (free residences),
+ *                        pnq[2] = -(kappa/2) sum g^2 (double[3][m][T]); P_est_new = g (float)
+ *                        when p_est_new != NULL
+ *   revs_op_dual_select  v = sum of the nslab slabs of R p; per slot t: candidate rows
+ *                        (cand_idx int64[T][AMAX], cand_cnt int32[T], -1 when more than AMAX
+ *                        rows carry a multiplier), cand_val double[T][3][AMAX] = sign (+1
+ *                        upper row, -1 lower row), gradient v - b, current y;
+ *                        stats double[T][8]: [0] largest |v - b| over rows with y != 0 and
+ *                        bound violation over the others, [1] D_t, [2] rows with y != 0,
+ *                        [3] violated rows with y = 0 ([4] is left to revs_op_dual_step).
+ *                        vfull double[m][T] receives v; viol double[T][m] is workspace.
+ *   revs_op_dual_bpp     K double[T][AMAX][AMAX] (R_F N R_F^T / kappa of the candidates,
+ *                        unsigned): yhat double[T][AMAX] = maximiser of the model over the
+ *                        sign constraints; info int32[T] = pivots (negative: limit hit)
+ *   revs_op_dual_step    y_trial = y at the candidates moved by alpha[t] towards yhat (all
+ *                        other entries of y_trial must already equal y);
+ *                        lin_out[8 t] = gradient . (y_trial - y)                         */
+#define REVS_DUAL_AMAX 64
+int revs_op_dual_eval(int32_t m, int32_t T, const int64_t *node_ptr, const float *p_est,
+                      const float *p_sch, const float *gamma, int32_t nslab, const double *dsl,
+                      double kappa, double *pnq, float *p_est_new, void *stream);
+int revs_op_dual_select(int32_t m, int32_t T, int32_t nslab, const double *vsl,
+                        const double *pnq, const double *y, double vlo, double vhi,
+                        int32_t kadd, double *vfull, double *viol, int64_t *cand_idx,
+                        int32_t *cand_cnt, double *cand_val, double *stats, void *stream);
+int revs_op_dual_bpp(int32_t T, const double *K, const int32_t *cand_cnt,
+                     const double *cand_val, double delta, int32_t max_pivots, double *yhat,
+                     int32_t *info, void *stream);
+int revs_op_dual_step(int32_t T, const int64_t *cand_idx, const int32_t *cand_cnt,
+                      const double *cand_val, const double *yhat, const double *alpha,
+                      double *y_trial, double *lin_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,7 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librevs_admm.so")
-SOURCES = ["runtime.cpp", "agent_kernels.hip", "operator_kernels.hip", "gemm_kernels.hip"]
+SOURCES = ["runtime.cpp", "agent_kernels.hip", "operator_kernels.hip", "newton_kernels.hip",
+           "gemm_kernels.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "revs_admm.h")]
 
 

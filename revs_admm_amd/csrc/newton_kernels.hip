@@ -1,0 +1,415 @@
+// Operator ("Utility") QP through its dual: semismooth Newton on the voltage-row
+// multipliers -- gfx950, double precision.
+//
+// Reference: class Utility, lpsolver.py:163-238 (Gurobi's barrier solves it there).
+//     min (kappa/2)|g - g0|^2   s.t.  g >= 0,  vlo <= R (A g)[:,t] <= vhi  for every slot t
+// With y[m][t] the multiplier of row (m,t), the residences of node m answer
+//     g_i = max(g0_i - d_m, 0),   d = R^T y / kappa
+// -- the g >= 0 rows are handled exactly inside this closed form, they never enter the
+// iteration.  The dual of slot t,
+//     D_t(y) = -(kappa/2) sum_i g_i^2 - sum_m max(vhi y_m, vlo y_m),
+// is concave, C^1, piecewise quadratic; dD/dy_m = (R p)_m - b_m with p = A g.  A Newton
+// iteration maximises the quadratic model with generalised Hessian -K, K = R_F N R_F^T/kappa
+// (N_m = number of unclamped residences of node m), over the sign constraints of a
+// candidate set F_t of at most 64 rows (rows with y != 0 and the most violated ones), and
+// takes an Armijo step on D_t.  Only a handful of rows of a radial feeder bind, so the
+// small dense problems live in one workgroup's LDS; the heavy parts are
+//     2 products  R^T y, R p      gemm_kernels.hip, f64 matrix cores
+//     1 home pass                 op_dual_eval_kernel, HBM bound (3 float reads + 1 write)
+// per evaluation, and a run needs 5-15 evaluations where the ADMM form needed 10^2-10^4
+// iterations of the same cost.
+#include "common.h"
+
+namespace revs {
+
+constexpr int kAmax = REVS_DUAL_AMAX;
+static_assert(kAmax == 64, "candidate masks are one 64-bit word / one wavefront");
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmax(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
+// ---- home pass: p, N, -(kappa/2) sum g^2 per node and slot; P_est_new = g ----------
+// Mapping as op_home_pass_kernel: one workgroup per node, TL slot lanes x HS home lanes,
+// partial sums combined through LDS in a fixed order.
+template <int TL>
+__global__ __launch_bounds__(256) void op_dual_eval_kernel(
+        int m, int T, const int64_t *__restrict__ node_ptr, const float *__restrict__ pe,
+        const float *__restrict__ ps, const float *__restrict__ gm, int nslab,
+        const double *__restrict__ dsl, double kappa, double *__restrict__ pnq,
+        float *__restrict__ pe_new) {
+    constexpr int HS = 256 / TL;
+    const int node = blockIdx.x;
+    const int t = threadIdx.x % TL, hs = threadIdx.x / TL;
+    const bool tok = t < T;
+    const int64_t total = (int64_t)m * T;
+    const int idx = node * T + (tok ? t : 0);
+    const double inv_k = 1.0 / kappa;
+    double d = 0.0;
+    if (dsl) {
+        for (int q = 0; q < nslab; ++q) d += dsl[idx + q * total];
+        d *= inv_k;
+    }
+    double ap = 0.0, an = 0.0, aq = 0.0;
+    const int64_t i0 = node_ptr[node], i1 = node_ptr[node + 1];
+    if (tok) {
+        for (int64_t i = i0 + hs; i < i1; i += HS) {
+            const int64_t o = i * T + t;
+            const double g0 = 0.5 * ((double)pe[o] + (double)ps[o]) - (double)gm[o] * inv_k;
+            const bool fr = g0 > d;
+            const double g = fr ? g0 - d : 0.0;
+            ap += g;
+            an += fr ? 1.0 : 0.0;
+            aq += g * g;
+            if (pe_new) pe_new[o] = (float)g;
+        }
+    }
+    __shared__ double red[3][HS][TL];
+    red[0][hs][t] = ap; red[1][hs][t] = an; red[2][hs][t] = aq;
+    __syncthreads();
+    if (hs == 0 && tok) {
+        double a = red[0][0][t], b = red[1][0][t], c = red[2][0][t];
+#pragma unroll
+        for (int k = 1; k < HS; ++k) { a += red[0][k][t]; b += red[1][k][t]; c += red[2][k][t]; }
+        pnq[idx] = a;
+        pnq[idx + total] = b;
+        pnq[idx + 2 * total] = -0.5 * kappa * c;
+    }
+}
+
+// ---- per-slot bookkeeping: v, residual, D_t, candidate rows ------------------------
+// One workgroup per slot.  Thread j owns the contiguous rows [j R, (j+1) R), R = ceil(m/256),
+// so the rows with a multiplier are compacted in row order (deterministic: every rank
+// builds the same lists); the most violated rows without a multiplier are then appended
+// by `kadd` rounds of a block-wide arg-max (ties to the lower row).
+__global__ __launch_bounds__(256) void op_dual_select_kernel(
+        int m, int T, int nslab, const double *__restrict__ vsl, const double *__restrict__ pnq,
+        const double *__restrict__ y, double vlo, double vhi, int kadd,
+        double *__restrict__ vfull, double *__restrict__ viol, int64_t *__restrict__ cidx,
+        int32_t *__restrict__ ccnt, double *__restrict__ cval, double *__restrict__ stats) {
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int64_t total = (int64_t)m * T;
+    const int per = (m + 255) / 256;
+    const int r0 = min(m, tid * per), r1 = min(m, r0 + per);
+    double *vw = viol + (int64_t)t * m;
+    int nsup = 0, nvio = 0;
+    double rmax = 0.0, dsum = 0.0;
+    for (int r = r0; r < r1; ++r) {
+        const int64_t i = (int64_t)r * T + t;
+        double v = 0.0;
+        for (int q = 0; q < nslab; ++q) v += vsl[i + q * total];
+        vfull[i] = v;
+        const double yv = y[i];
+        const bool up = yv > 0.0 || (yv == 0.0 && v > vhi);
+        const double b = up ? vhi : vlo;
+        const double vi = fmax(fmax(v - vhi, vlo - v), 0.0);
+        rmax = fmax(rmax, yv != 0.0 ? fabs(v - b) : vi);
+        dsum += pnq[i + 2 * total] - fmax(vhi * yv, vlo * yv);
+        if (yv != 0.0) { ++nsup; vw[r] = 0.0; }
+        else { vw[r] = vi; nvio += vi > 0.0 ? 1 : 0; }
+    }
+    __shared__ int cnt_s[256];
+    __shared__ double red_s[2][4];
+    __shared__ int redi_s[2][4];
+    __shared__ double best_v[4];
+    __shared__ int best_i[4];
+    cnt_s[tid] = nsup;
+    // fixed-order block reductions: lanes by xor-shuffle, the 4 wavefronts in order
+    const double wm = wave_max_d(rmax), wsum = wave_sum_d(dsum);
+    int wv = nvio;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) wv += __shfl_xor(wv, d, 64);
+    if ((tid & 63) == 0) { red_s[0][tid >> 6] = wm; red_s[1][tid >> 6] = wsum; redi_s[0][tid >> 6] = wv; }
+    __syncthreads();
+    int pos = 0, ns = 0;
+    for (int j = 0; j < 256; ++j) { const int c = cnt_s[j]; pos += j < tid ? c : 0; ns += c; }
+    if (tid == 0) {
+        stats[t * 8 + 0] = fmax(fmax(red_s[0][0], red_s[0][1]), fmax(red_s[0][2], red_s[0][3]));
+        stats[t * 8 + 1] = ((red_s[1][0] + red_s[1][1]) + red_s[1][2]) + red_s[1][3];
+        stats[t * 8 + 2] = (double)ns;
+        stats[t * 8 + 3] = (double)(redi_s[0][0] + redi_s[0][1] + redi_s[0][2] + redi_s[0][3]);
+    }
+    int64_t *ci = cidx + (int64_t)t * kAmax;
+    double *cs = cval + (int64_t)t * 3 * kAmax, *cg = cs + kAmax, *cy = cg + kAmax;
+    if (ns > kAmax) {                       // uniform: more multipliers than the model holds
+        if (tid == 0) ccnt[t] = -1;
+        if (tid < kAmax) { ci[tid] = 0; cs[tid] = 1.0; cg[tid] = 0.0; cy[tid] = 0.0; }
+        return;
+    }
+    for (int r = r0; r < r1; ++r) {
+        const int64_t i = (int64_t)r * T + t;
+        const double yv = y[i];
+        if (yv != 0.0) {
+            ci[pos] = r;
+            cs[pos] = yv > 0.0 ? 1.0 : -1.0;
+            cg[pos] = vfull[i] - (yv > 0.0 ? vhi : vlo);
+            cy[pos] = yv;
+            ++pos;
+        }
+    }
+    const int room = min(kadd, kAmax - ns);
+    int added = 0;
+    for (int k = 0; k < room; ++k) {
+        __syncthreads();                    // vw updates of the previous round are visible
+        double bv = 0.0;
+        int bi = m;
+        for (int r = tid; r < m; r += 256) {
+            const double x = vw[r];
+            if (x > bv) { bv = x; bi = r; }      // ascending r: ties keep the lower row
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const double ov = __shfl_xor(bv, d, 64);
+            const int oi = __shfl_xor(bi, d, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if ((tid & 63) == 0) { best_v[tid >> 6] = bv; best_i[tid >> 6] = bi; }
+        __syncthreads();
+        bv = best_v[0]; bi = best_i[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (best_v[w] > bv || (best_v[w] == bv && best_i[w] < bi)) { bv = best_v[w]; bi = best_i[w]; }
+        if (!(bv > 0.0)) break;             // uniform
+        if (tid == 0) {
+            const double v = vfull[(int64_t)bi * T + t];
+            const bool up = v > vhi;
+            ci[ns + added] = bi;
+            cs[ns + added] = up ? 1.0 : -1.0;
+            cg[ns + added] = v - (up ? vhi : vlo);
+            cy[ns + added] = 0.0;
+            vw[bi] = 0.0;
+        }
+        ++added;
+    }
+    const int cnt = ns + added;
+    if (tid == 0) ccnt[t] = cnt;
+    if (tid >= cnt && tid < kAmax) { ci[tid] = 0; cs[tid] = 1.0; cg[tid] = 0.0; cy[tid] = 0.0; }
+}
+
+// ---- the model problem of one slot: block principal pivoting in LDS ------------------
+// In sign-normalised variables u = s y >= 0 the model is the LCP
+//     u >= 0,  w = K' u - c >= 0,  u . w = 0,   K' = S K S + delta I,  c = s grad + K' u_cur.
+// Block principal pivoting (Judice & Pires) with the single-exchange backup rule: basic
+// set B (u free, w = 0) as a 64-bit mask; solve K'_BB u_B = c_B by Cholesky in LDS, swap
+// every infeasible index (u_i < 0 in B, w_i < 0 outside) while that shrinks their number,
+// else only the highest one -- finite for a positive definite K'.
+__global__ __launch_bounds__(256) void op_dual_bpp_kernel(
+        const double *__restrict__ Kall, const int32_t *__restrict__ ccnt,
+        const double *__restrict__ cval, double delta, int max_pivots, double *__restrict__ yhat,
+        int32_t *__restrict__ info) {
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int a = ccnt[t];
+    const double *cs = cval + (int64_t)t * 3 * kAmax, *cg = cs + kAmax, *cy = cg + kAmax;
+    double *yo = yhat + (int64_t)t * kAmax;
+    if (a <= 0) {                           // uniform
+        if (tid < kAmax) yo[tid] = cy[tid];
+        if (tid == 0) info[t] = 0;
+        return;
+    }
+    const double *Kt = Kall + (int64_t)t * kAmax * kAmax;
+    __shared__ double Ls[kAmax][kAmax + 1];
+    __shared__ double s_s[kAmax], c_s[kAmax], u_s[kAmax], w_s[kAmax];
+    __shared__ int bl[kAmax];
+    __shared__ unsigned long long Bsh;
+    __shared__ double dl_s, tolw_s;
+    __shared__ int done_s, piv_s;
+
+    if (tid < kAmax) {
+        const bool in = tid < a;
+        const double s = in ? cs[tid] : 1.0;
+        s_s[tid] = s;
+        u_s[tid] = in ? fmax(s * cy[tid], 0.0) : 0.0;
+        const double tr = wave_sum_d(in ? Kt[tid * kAmax + tid] : 0.0);
+        if (tid == 0) { dl_s = delta * tr / a + 1e-300; done_s = 0; piv_s = 0; }
+    }
+    __syncthreads();
+    const double dl = dl_s;
+    auto kp = [&](int i, int j) -> double {
+        return s_s[i] * s_s[j] * Kt[i * kAmax + j] + (i == j ? dl : 0.0);
+    };
+    // out_i = sum_j K'_ij u_j : 4 lanes per row, 16 columns each
+    const int mi = tid >> 2, mp = tid & 3;
+    auto matvec_row = [&]() -> double {
+        double acc = 0.0;
+        if (mi < a)
+            for (int j = mp * 16; j < mp * 16 + 16 && j < a; ++j) acc += kp(mi, j) * u_s[j];
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        return acc;
+    };
+    {
+        const double ku = matvec_row();
+        if (mp == 0 && mi < a) c_s[mi] = s_s[mi] * cg[mi] + ku;
+        if (mp == 0 && mi >= a) c_s[mi] = 0.0;
+    }
+    if (tid < kAmax) {
+        const unsigned long long B0 = __ballot(tid < a && u_s[tid] > 0.0);
+        if (tid == 0) Bsh = B0;
+    }
+    __syncthreads();
+    if (tid < kAmax) {
+        const double cm = wave_max_d(fabs(c_s[tid]));
+        if (tid == 0) tolw_s = 1e-13 * cm;
+    }
+    int ninf = kAmax + 1, pcount = 3;       // thread 0's pivoting state
+    for (;;) {
+        __syncthreads();
+        const unsigned long long B = Bsh;
+        const int nb = __popcll(B);
+        if (tid < kAmax && ((B >> tid) & 1ull)) bl[__popcll(B & ((1ull << tid) - 1ull))] = tid;
+        __syncthreads();
+        for (int e = tid; e < nb * nb; e += 256) {
+            const int k = e / nb, l = e - k * nb;
+            Ls[k][l] = kp(bl[k], bl[l]);
+        }
+        __syncthreads();
+        // Cholesky, lower triangle in place
+        for (int k = 0; k < nb; ++k) {
+            if (tid == 0) {
+                const double pv = Ls[k][k];
+                Ls[k][k] = sqrt(fmax(pv, dl * 1e-6));
+            }
+            __syncthreads();
+            const double pk = Ls[k][k];
+            for (int i = k + 1 + tid; i < nb; i += 256) Ls[i][k] /= pk;
+            __syncthreads();
+            const int rem = nb - k - 1;
+            for (int e = tid; e < rem * rem; e += 256) {
+                const int i = k + 1 + e / rem, j = k + 1 + e % rem;
+                if (j <= i) Ls[i][j] -= Ls[i][k] * Ls[j][k];
+            }
+            __syncthreads();
+        }
+        // triangular solves in wavefront 0: lane k holds component k
+        if (tid < kAmax) {
+            double val = tid < nb ? c_s[bl[tid]] : 0.0;
+            for (int k = 0; k < nb; ++k) {
+                const double zk = __shfl(val, k, 64) / Ls[k][k];
+                if (tid == k) val = zk;
+                else if (tid > k && tid < nb) val -= Ls[tid][k] * zk;
+            }
+            for (int k = nb - 1; k >= 0; --k) {
+                const double xk = __shfl(val, k, 64) / Ls[k][k];
+                if (tid == k) val = xk;
+                else if (tid < k) val -= Ls[k][tid] * xk;
+            }
+            u_s[tid] = 0.0;
+            __builtin_amdgcn_wave_barrier();
+            if (tid < nb) u_s[bl[tid]] = val;
+        }
+        __syncthreads();
+        {
+            const double ku = matvec_row();
+            if (mp == 0) w_s[mi] = mi < a ? ku - c_s[mi] : 0.0;
+        }
+        __syncthreads();
+        if (tid < kAmax) {
+            const bool inB = (B >> tid) & 1ull;
+            const double um = wave_max_d(fabs(u_s[tid]));
+            const bool bad = tid < a && (inB ? (u_s[tid] < -1e-13 * um) : (w_s[tid] < -tolw_s));
+            const unsigned long long V = __ballot(bad);
+            if (tid == 0) {
+                const int nv = __popcll(V);
+                const int pv = ++piv_s;
+                if (nv == 0) done_s = 1;
+                else if (pv >= max_pivots) done_s = 2;
+                else if (nv < ninf) { ninf = nv; pcount = 3; Bsh = B ^ V; }
+                else if (pcount > 0) { --pcount; Bsh = B ^ V; }
+                else Bsh = B ^ (1ull << (63 - __clzll((long long)V)));
+            }
+        }
+        __syncthreads();
+        if (done_s) break;
+    }
+    if (tid < kAmax) yo[tid] = tid < a ? s_s[tid] * fmax(u_s[tid], 0.0) : 0.0;
+    if (tid == 0) info[t] = done_s == 1 ? piv_s : -piv_s;
+}
+
+// y_trial[cand] = y + alpha_t (yhat - y); lin_out[8 t] = grad . (y_trial - y)
+__global__ __launch_bounds__(64) void op_dual_step_kernel(
+        int T, const int64_t *__restrict__ cidx, const int32_t *__restrict__ ccnt,
+        const double *__restrict__ cval, const double *__restrict__ yhat,
+        const double *__restrict__ alpha, double *__restrict__ ytrial,
+        double *__restrict__ lin_out) {
+    const int t = blockIdx.x, i = threadIdx.x;
+    const int a = ccnt[t];
+    const double al = alpha[t];
+    const double *cs = cval + (int64_t)t * 3 * kAmax, *cg = cs + kAmax, *cy = cg + kAmax;
+    double lin = 0.0;
+    if (i < a) {
+        const double yo = cy[i], yh = yhat[(int64_t)t * kAmax + i];
+        // a full step lands exactly on yhat, so a multiplier that leaves is exactly zero
+        const double yn = al == 1.0 ? yh : (al == 0.0 ? yo : yo + al * (yh - yo));
+        ytrial[cidx[(int64_t)t * kAmax + i] * T + t] = yn;
+        lin = cg[i] * (yn - yo);
+    }
+    lin = wave_sum_d(lin);
+    if (i == 0) lin_out[t * 8] = lin;
+}
+
+}  // namespace revs
+
+using namespace revs;
+#define S_(stream) ((hipStream_t)(stream))
+
+extern "C" int revs_op_dual_eval(int32_t m, int32_t T, const int64_t *node_ptr,
+                                 const float *p_est, const float *p_sch, const float *gamma,
+                                 int32_t nslab, const double *dsl, double kappa, double *pnq,
+                                 float *p_est_new, void *stream) {
+    REVS_REQUIRE(m > 0 && T > 0 && T <= 256 && node_ptr && p_est && p_sch && gamma && pnq &&
+                 kappa > 0, "revs_op_dual_eval: bad argument");
+    REVS_REQUIRE(!dsl || nslab >= 1, "revs_op_dual_eval: nslab=%d", nslab);
+#define EV(TL)                                                                                 \
+    hipLaunchKernelGGL((op_dual_eval_kernel<TL>), dim3(m), dim3(256), 0, S_(stream), m, T,     \
+                       node_ptr, p_est, p_sch, gamma, nslab, dsl, kappa, pnq, p_est_new)
+    if (T <= 32) EV(32);
+    else if (T <= 64) EV(64);
+    else if (T <= 128) EV(128);
+    else EV(256);
+#undef EV
+    REVS_CHECK_LAUNCH("revs_op_dual_eval");
+    return REVS_OK;
+}
+
+extern "C" int revs_op_dual_select(int32_t m, int32_t T, int32_t nslab, const double *vsl,
+                                   const double *pnq, const double *y, double vlo, double vhi,
+                                   int32_t kadd, double *vfull, double *viol, int64_t *cand_idx,
+                                   int32_t *cand_cnt, double *cand_val, double *stats,
+                                   void *stream) {
+    REVS_REQUIRE(m > 0 && T > 0 && nslab >= 1 && vsl && pnq && y && vfull && viol && cand_idx &&
+                 cand_cnt && cand_val && stats && vlo <= vhi && kadd >= 0,
+                 "revs_op_dual_select: bad argument");
+    hipLaunchKernelGGL(op_dual_select_kernel, dim3(T), dim3(256), 0, S_(stream), m, T, nslab, vsl,
+                       pnq, y, vlo, vhi, kadd, vfull, viol, cand_idx, cand_cnt, cand_val, stats);
+    REVS_CHECK_LAUNCH("revs_op_dual_select");
+    return REVS_OK;
+}
+
+extern "C" int revs_op_dual_bpp(int32_t T, const double *K, const int32_t *cand_cnt,
+                                const double *cand_val, double delta, int32_t max_pivots,
+                                double *yhat, int32_t *info, void *stream) {
+    REVS_REQUIRE(T > 0 && K && cand_cnt && cand_val && yhat && info && delta >= 0 &&
+                 max_pivots > 0, "revs_op_dual_bpp: bad argument");
+    hipLaunchKernelGGL(op_dual_bpp_kernel, dim3(T), dim3(256), 0, S_(stream), K, cand_cnt,
+                       cand_val, delta, max_pivots, yhat, info);
+    REVS_CHECK_LAUNCH("revs_op_dual_bpp");
+    return REVS_OK;
+}
+
+extern "C" int revs_op_dual_step(int32_t T, const int64_t *cand_idx, const int32_t *cand_cnt,
+                                 const double *cand_val, const double *yhat, const double *alpha,
+                                 double *y_trial, double *lin_out, void *stream) {
+    REVS_REQUIRE(T > 0 && cand_idx && cand_cnt && cand_val && yhat && alpha && y_trial && lin_out,
+                 "revs_op_dual_step: bad argument");
+    hipLaunchKernelGGL(op_dual_step_kernel, dim3(T), dim3(64), 0, S_(stream), T, cand_idx,
+                       cand_cnt, cand_val, yhat, alpha, y_trial, lin_out);
+    REVS_CHECK_LAUNCH("revs_op_dual_step");
+    return REVS_OK;
+}

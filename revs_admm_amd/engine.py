@@ -80,6 +80,15 @@ class OperatorOptions:
     # no residence would be pushed below zero; otherwise fall back to the general path
     # for the rest of the run.
     node_fast: bool = True
+    # "newton": semismooth Newton on the dual (voltage-row multipliers), the default;
+    # "admm": the OSQP-form iterations above only.  The Newton path hands an iteration to
+    # the ADMM forms when it cannot finish (more than 64 binding rows in a slot, ...).
+    solver: str = "newton"
+    newton_max: int = 60         # Newton iterations per operator solve
+    newton_kadd: int = 16        # violated rows admitted to a slot's model per iteration
+    newton_delta: float = 1e-10  # relative diagonal shift of the model Hessian
+    newton_pivots: int = 300     # block-pivoting limit per model problem
+    newton_ls: int = 30          # Armijo halvings
 
 
 def _dev_check(device):
@@ -231,6 +240,26 @@ class AdmmEngine:
         self._graph_warm = False
         self.op_iters_hist: list[int] = []
         self.iteration = 0
+        # dual Newton path: R itself (d = R^T y; candidate rows of K), and R^T with the rows
+        # of nodes without residences zeroed (v = R p is constrained where residences are)
+        has = (counts > 0).astype(np.float64)
+        self.R64 = up(Rn)
+        self.R64T = up((Rn * has[:, None]).T)
+        A = _lib.DUAL_AMAX
+        self.yd = [nz(), nz()]                         # multipliers: current, trial
+        self.pnq = torch.zeros(3, M, T, **f64)
+        self.d_sl, self.v_sl = nz1(), nz1()
+        self.vfull = nz()
+        self.violw = torch.zeros(T, M, **f64)
+        self.c_idx = [torch.zeros(T, A, dtype=torch.int64, device=self.dev) for _ in range(2)]
+        self.c_cnt = [torch.zeros(T, dtype=torch.int32, device=self.dev) for _ in range(2)]
+        self.c_val = [torch.zeros(T, 3, A, **f64) for _ in range(2)]
+        self.n_stats = [torch.zeros(T, 8, **f64) for _ in range(2)]
+        self.yhat = torch.zeros(T, A, **f64)
+        self.bpp_info = torch.zeros(T, dtype=torch.int32, device=self.dev)
+        self.alpha_d = torch.zeros(T, **f64)
+        self._y_support = False
+        self.newton_hist: list[tuple] = []
         # R (float) for the voltage check
         self.R32 = up(Rn.astype(np.float32))
         self.node_load = torch.zeros(M, T, **f32)
@@ -565,10 +594,98 @@ class AdmmEngine:
         self.op_converged = converged
         return True
 
+    # ------------------------------------------------- operator, dual Newton path
+    def _dual_evaluate(self, y, use_y: bool, k: int):
+        """p, N, D and the voltage rows for the multipliers y; candidate lists and stats
+        into buffer set k.  Also writes P_est_new = max(g0 - R^T y / kappa, 0)."""
+        lib, M, T, st, ks = self.lib, self.M, self.T, self.stream, self.ksplit1
+        if use_y:
+            self._gemm1(self.R64, y, self.d_sl)                            # R^T y
+        check(lib.revs_op_dual_eval(M, T, ptr(self.node_ptr), ptr(self.P_est), ptr(self.P_sch),
+                                    ptr(self.G), ks, ptr(self.d_sl) if use_y else None,
+                                    self.kappa, ptr(self.pnq), ptr(self.P_est_new), st),
+              "revs_op_dual_eval")
+        self._allreduce(self.pnq)                # the only exchange of an evaluation
+        self._gemm1(self.R64T, self.pnq[0], self.v_sl)                     # R p
+        check(lib.revs_op_dual_select(M, T, ks, ptr(self.v_sl), ptr(self.pnq), ptr(y), self.vlo,
+                                      self.vhi, self.op.newton_kadd, ptr(self.vfull),
+                                      ptr(self.violw), ptr(self.c_idx[k]), ptr(self.c_cnt[k]),
+                                      ptr(self.c_val[k]), ptr(self.n_stats[k]), st),
+              "revs_op_dual_select")
+        return self.n_stats[k].cpu().numpy()
+
+    def _operator_solve_newton(self):
+        """Utility.solve through the dual (see csrc/newton_kernels.hip).  True when
+        P_est_new holds the answer to tolerance; False hands the iteration to ADMM."""
+        o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
+        A = _lib.DUAL_AMAX
+        scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
+        ycur, ytrial = self.yd
+        cur = 0
+        stt = self._dual_evaluate(ycur, self._y_support, cur)
+        evals, newton, pivots, ok_all = 1, 0, 0, False
+        while True:
+            if (stt[:, 2] > A).any():
+                break                                    # more multipliers than a model holds
+            rmax = stt[:, 0] / scale
+            if rmax.max() <= o.eps:
+                ok_all = True
+                break
+            if newton >= o.newton_max:
+                break
+            newton += 1
+            # model Hessian of every slot: K_t = R_F N_t R_F^T / kappa  (candidates x candidates)
+            Rg = self.R64.index_select(0, self.c_idx[cur].view(-1)).view(T, A, M)
+            K = torch.bmm(Rg * self.pnq[1].t().unsqueeze(1), Rg.transpose(1, 2))
+            K.div_(self.kappa)
+            check(lib.revs_op_dual_bpp(T, ptr(K), ptr(self.c_cnt[cur]), ptr(self.c_val[cur]),
+                                       o.newton_delta, o.newton_pivots, ptr(self.yhat),
+                                       ptr(self.bpp_info), st), "revs_op_dual_bpp")
+            D = stt[:, 1]
+            pending = rmax > o.eps
+            alpha = pending.astype(np.float64)
+            nxt = 1 - cur
+            for _ in range(o.newton_ls):
+                self.alpha_d.copy_(torch.from_numpy(alpha))
+                ytrial.copy_(ycur)
+                check(lib.revs_op_dual_step(T, ptr(self.c_idx[cur]), ptr(self.c_cnt[cur]),
+                                            ptr(self.c_val[cur]), ptr(self.yhat),
+                                            ptr(self.alpha_d), ptr(ytrial),
+                                            self.n_stats[nxt].data_ptr() + 32, st),
+                      "revs_op_dual_step")
+                stn = self._dual_evaluate(ytrial, True, nxt)
+                evals += 1
+                okk = stn[:, 1] >= D + 1e-4 * stn[:, 4] - 1e-13 * np.abs(D)
+                pending &= ~okk
+                if not pending.any():
+                    break
+                alpha[pending] *= 0.5
+            pivots += int(np.abs(self.bpp_info.cpu().numpy()).sum())
+            if pending.any():
+                break                                    # no ascent found: leave it to ADMM
+            ycur, ytrial = ytrial, ycur
+            cur, stt = nxt, stn
+        self.yd = [ycur, ytrial]
+        self.newton_hist.append((newton, evals, pivots))
+        if not ok_all:
+            ycur.zero_()
+            self._y_support = False
+            return False
+        self._y_support = bool(stt[:, 2].sum() > 0)
+        self.op_iters_hist.append(evals)
+        self.op_path_hist.append("dual")
+        self.op_converged = True
+        return True
+
     def operator_solve(self):
         """Utility(graph, P_est[k], P_sch[k], G[k]).solve() -> P_est[k+1]
         (lpsolver.py:256-259), written to self.P_est_new."""
         o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
+        if o.solver == "newton":
+            if self._operator_solve_newton():
+                return True
+            self._fast_cold = True
+            self.op_cold = True
         if self._fast_ok:
             if self._fast_wait > 0:
                 self._fast_wait -= 1

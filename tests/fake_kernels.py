@@ -286,6 +286,120 @@ class FakeKernels:
         view(pe_new, (n, T), np.float32)[:] = np.maximum(g + corr, 0)
         return 0
 
+    # ---- dual Newton path ----
+    def revs_op_dual_eval(self, m, T, node_ptr, pe, ps, gm, nslab, dsl, kappa, pnq, pe_new, stream):
+        node, n = self._seg(m, node_ptr)
+        f = lambda p: view(p, (n, T), np.float32).astype(float)
+        g0 = 0.5 * (f(pe) + f(ps)) - f(gm) / kappa
+        d = view(dsl, (nslab, m, T), np.float64).sum(axis=0) / kappa if dsl else np.zeros((m, T))
+        dh = d[node]
+        free = g0 > dh
+        g = np.where(free, g0 - dh, 0.0)
+        out = view(pnq, (3, m, T), np.float64)
+        out[:] = 0.0
+        np.add.at(out[0], node, g)
+        np.add.at(out[1], node, free.astype(float))
+        np.add.at(out[2], node, -0.5 * kappa * g * g)
+        if pe_new:
+            view(pe_new, (n, T), np.float32)[:] = g
+        return 0
+
+    def revs_op_dual_select(self, m, T, nslab, vsl, pnq, y, vlo, vhi, kadd, vfull, viol, cidx, ccnt,
+                            cval, stats, stream):
+        A = 64
+        v = view(vsl, (nslab, m, T), np.float64).sum(axis=0)
+        view(vfull, (m, T), np.float64)[:] = v
+        yv = view(y, (m, T), np.float64)
+        q = view(pnq, (3, m, T), np.float64)[2]
+        ci, cc = view(cidx, (T, A), np.int64), view(ccnt, (T,), np.int32)
+        cv, st = view(cval, (T, 3, A), np.float64), view(stats, (T, 8), np.float64)
+        up = (yv > 0) | ((yv == 0) & (v > vhi))
+        b = np.where(up, vhi, vlo)
+        vi = np.maximum(np.maximum(v - vhi, vlo - v), 0.0)
+        res = np.where(yv != 0, np.abs(v - b), vi)
+        st[:, 0] = res.max(axis=0)
+        st[:, 1] = (q - np.maximum(vhi * yv, vlo * yv)).sum(axis=0)
+        st[:, 2] = (yv != 0).sum(axis=0)
+        st[:, 3] = ((yv == 0) & (vi > 0)).sum(axis=0)
+        ci[:] = 0
+        cv[:] = 0.0
+        cv[:, 0, :] = 1.0
+        for t in range(T):
+            sup = np.nonzero(yv[:, t])[0]
+            if len(sup) > A:
+                cc[t] = -1
+                continue
+            w = np.where(yv[:, t] == 0, vi[:, t], 0.0)
+            order = sorted(np.nonzero(w > 0)[0], key=lambda r: (-w[r], r))
+            rows = list(sup) + order[:min(kadd, A - len(sup))]
+            cc[t] = len(rows)
+            for i, r in enumerate(rows):
+                ci[t, i] = r
+                cv[t, 0, i] = 1.0 if up[r, t] else -1.0
+                cv[t, 1, i] = v[r, t] - b[r, t]
+                cv[t, 2, i] = yv[r, t]
+        return 0
+
+    def revs_op_dual_bpp(self, T, K, ccnt, cval, delta, max_pivots, yhat, info, stream):
+        A = 64
+        Kv, cc = view(K, (T, A, A), np.float64), view(ccnt, (T,), np.int32)
+        cv, yh = view(cval, (T, 3, A), np.float64), view(yhat, (T, A), np.float64)
+        inf = view(info, (T,), np.int32)
+        for t in range(T):
+            a = int(cc[t])
+            if a <= 0:
+                yh[t] = cv[t, 2]
+                inf[t] = 0
+                continue
+            s = cv[t, 0, :a]
+            Kp = Kv[t, :a, :a] * s[:, None] * s[None, :]
+            Kp = Kp + (delta * np.trace(Kv[t, :a, :a]) / a + 1e-300) * np.eye(a)
+            u = np.maximum(s * cv[t, 2, :a], 0.0)
+            c = s * cv[t, 1, :a] + Kp @ u
+            B = u > 0
+            ninf, p, piv, done = a + 1, 3, 0, False
+            while not done and piv < max_pivots:
+                piv += 1
+                u = np.zeros(a)
+                idx = np.nonzero(B)[0]
+                if len(idx):
+                    u[idx] = np.linalg.solve(Kp[np.ix_(idx, idx)], c[idx])
+                w = Kp @ u - c
+                V = np.where(B, u < -1e-13 * np.abs(u).max(initial=0.0),
+                             w < -1e-13 * np.abs(c).max(initial=0.0))
+                nv = int(V.sum())
+                if nv == 0:
+                    done = True
+                elif nv < ninf:
+                    ninf, p = nv, 3
+                    B = B ^ V
+                elif p > 0:
+                    p -= 1
+                    B = B ^ V
+                else:
+                    i = np.nonzero(V)[0].max()
+                    B[i] = not B[i]
+            yh[t] = 0.0
+            yh[t, :a] = s * np.maximum(u, 0.0)
+            inf[t] = piv if done else -piv
+        return 0
+
+    def revs_op_dual_step(self, T, cidx, ccnt, cval, yhat, alpha, ytrial, lin_out, stream):
+        A = 64
+        ci, cc = view(cidx, (T, A), np.int64), view(ccnt, (T,), np.int32)
+        cv, yh = view(cval, (T, 3, A), np.float64), view(yhat, (T, A), np.float64)
+        al = view(alpha, (T,), np.float64)
+        m = None
+        for t in range(T):
+            a, lin = max(int(cc[t]), 0), 0.0
+            for i in range(a):
+                yo = cv[t, 2, i]
+                yn = yh[t, i] if al[t] == 1.0 else (yo if al[t] == 0.0 else yo + al[t] * (yh[t, i] - yo))
+                C.c_double.from_address(int(ytrial) + 8 * (int(ci[t, i]) * T + t)).value = yn
+                lin += cv[t, 1, i] * (yn - yo)
+            C.c_double.from_address(int(lin_out) + 8 * 8 * t).value = lin
+        return 0
+
     def revs_voltage_f32(self, m, T, Rt, P, V, stream):
         view(V, (m, T), np.float32)[:] = view(Rt, (m, m), np.float32).T @ view(P, (m, T), np.float32)
         return 0

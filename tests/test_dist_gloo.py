@@ -10,14 +10,14 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _worker(rank, world, port, mode, out):
+def _worker(rank, world, port, mode, solver, out):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     import torch
     import torch.distributed as dist
     from fake_kernels import FakeKernels
     from helpers import f32
-    from revs_admm_amd.engine import AdmmEngine
+    from revs_admm_amd.engine import AdmmEngine, OperatorOptions
     from revs_admm_amd.synthetic import make_workload
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -26,7 +26,8 @@ def _worker(rank, world, port, mode, out):
     lo, hi = w.shard(rank, world)
     e = AdmmEngine(w.cost, w.homes[lo:hi], w.load[lo:hi], w.node_of[lo:hi], w.Rn, kappa=w.kappa,
                    vset=w.vset, vlow=w.vlow, vhigh=w.vhigh, mode=mode, device="cpu",
-                   group=dist.group.WORLD, _kernels=FakeKernels())
+                   group=dist.group.WORLD, _kernels=FakeKernels(),
+                   op=OperatorOptions(solver=solver))
     # global node counts came from the all-reduce in the constructor
     assert (e.node_counts == np.bincount(w.node_of, minlength=w.M)).all()
     d = e.run(3)
@@ -39,21 +40,23 @@ def _worker(rank, world, port, mode, out):
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("solver", ["newton", "admm"])
 @pytest.mark.parametrize("mode", ["relaxed_exact", "binary"])
-def test_two_ranks_equal_one_rank(tmp_path, mode):
+def test_two_ranks_equal_one_rank(tmp_path, mode, solver):
     import torch.multiprocessing as mp
     sys.path.insert(0, HERE)
     from fake_kernels import FakeKernels
     from helpers import f32
-    from revs_admm_amd.engine import AdmmEngine
+    from revs_admm_amd.engine import AdmmEngine, OperatorOptions
     from revs_admm_amd.synthetic import make_workload
     port = 29500 + (os.getpid() % 2000)
     out = str(tmp_path / "r{rank}.npz")
-    mp.spawn(_worker, args=(2, port, mode, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, mode, solver, out), nprocs=2, join=True)
     w = make_workload(240, 12, n_nodes=24, seed=6, stress=1.3, binary_feasible=(mode == "binary"))
     w.load, w.cost = f32(w.load), f32(w.cost)
     e = AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, kappa=w.kappa, vset=w.vset,
-                   vlow=w.vlow, vhigh=w.vhigh, mode=mode, device="cpu", _kernels=FakeKernels())
+                   vlow=w.vlow, vhigh=w.vhigh, mode=mode, device="cpu", _kernels=FakeKernels(),
+                   op=OperatorOptions(solver=solver))
     d1 = e.run(3)
     P1, S1, C1 = e.result()
     rp, rd, dmax, _ = e.residuals(1e-4)

@@ -11,9 +11,10 @@ def _engine(w, mode, **kw):
                       vlow=w.vlow, vhigh=w.vhigh, mode=mode, **kw)
 
 
+@pytest.mark.parametrize("solver", ["newton", "admm"])
 @pytest.mark.parametrize("stress", [0.9, 1.5])
 @pytest.mark.parametrize("mode,omode", [("relaxed_exact", "relaxed"), ("pdhg", "relaxed")])
-def test_relaxed_trajectory(gpu_lib, mode, omode, stress):
+def test_relaxed_trajectory(gpu_lib, mode, omode, stress, solver):
     """Continuous homes: the iteration map is Lipschitz, so the whole trajectory must
     follow the oracle.  Tolerance: 2e-3 kW on schedules, 1e-3 relative on diff."""
     from helpers import f32, oracle_homes
@@ -22,7 +23,8 @@ def test_relaxed_trajectory(gpu_lib, mode, omode, stress):
     w = make_workload(600, 24, n_nodes=60, seed=11, binary_feasible=False, stress=stress)
     w.load, w.cost = f32(w.load), f32(w.cost)
     iters = 8
-    e = _engine(w, mode)
+    from revs_admm_amd.engine import OperatorOptions
+    e = _engine(w, mode, op=OperatorOptions(solver=solver))
     diffs = e.run(iters)
     P_sch, S, C = e.result()
     d_ref, P_ref, S_ref, C_ref = ro.solve_ADMM(oracle_homes(w), w.Rn, w.node_of, w.cost, w.kappa,
@@ -34,8 +36,12 @@ def test_relaxed_trajectory(gpu_lib, mode, omode, stress):
     assert np.abs(C - C_ref).max() < 2e-4
     # the run is doing real work: operator rows bind, and the first iterations (where some
     # g0 go negative) pass through the general home-space path before the fast path resumes
-    assert max(e.op_iters_hist) >= 25 and d_ref[-1].mean() < d_ref[0].mean()
-    assert {"node", "home"} <= set(e.op_path_hist)
+    assert d_ref[-1].mean() < d_ref[0].mean()
+    if solver == "newton":
+        assert set(e.op_path_hist) == {"dual"} and max(n for n, _, _ in e.newton_hist) >= 1
+        assert e.P_est.min().item() == 0.0 or stress < 1.0
+    else:
+        assert max(e.op_iters_hist) >= 25 and {"node", "home"} <= set(e.op_path_hist)
 
 
 def test_binary_teacher_forced(gpu_lib):
@@ -167,15 +173,20 @@ def test_process_group_path_on_one_gpu(gpu_lib):
     os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 1000))
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
     try:
-        for fast in (True, False):          # node-space fast path, then the general path
-            a = _engine(w, "relaxed_exact", op=OperatorOptions(node_fast=fast))
+        # dual Newton path, node-space ADMM fast path, general ADMM path
+        for solver, fast in (("newton", True), ("admm", True), ("admm", False)):
+            a = _engine(w, "relaxed_exact", op=OperatorOptions(solver=solver, node_fast=fast))
             da = a.run(5)
             b = _engine(w, "relaxed_exact", group=dist.group.WORLD,
-                        op=OperatorOptions(node_fast=fast))
+                        op=OperatorOptions(solver=solver, node_fast=fast))
             db = b.run(5)
-            assert max(b.op_iters_hist) >= 25                     # rows bind on the way
-            assert set(b.op_path_hist) == {"home"} if not fast else "node" in b.op_path_hist
-            if not fast:
+            if solver == "newton":
+                assert set(b.op_path_hist) == {"dual"} and a.newton_hist == b.newton_hist
+                assert max(n for n, _, _ in b.newton_hist) >= 1   # rows bind on the way
+            else:
+                assert max(b.op_iters_hist) >= 25                 # rows bind on the way
+                assert set(b.op_path_hist) == {"home"} if not fast else "node" in b.op_path_hist
+            if solver == "admm" and not fast:
                 assert isinstance(b._graph, list) and len(b._graph) == 2   # sharded graphs ran
             assert a.op_iters_hist == b.op_iters_hist
             np.testing.assert_allclose(db, da, rtol=1e-6, atol=1e-7)
@@ -226,6 +237,28 @@ def _operator_kkt_f64(e):
     return int(act_hi.sum())
 
 
+def _dual_kkt_f64(e, w, pe0, ps0, gm0):
+    """KKT certificate of the dual Newton path's last answer, recomputed in float64 on the
+    host from the multipliers y and the state the operator was given: stationarity
+    g = max(g0 - (R^T y / kappa)[node], 0) is the answer handed to the homes, the rows of
+    R.(A g) respect their bounds, y is non-zero only on rows at a bound, with the right
+    sign.  Returns the number of rows at the upper bound."""
+    y = e.yd[0].cpu().numpy()
+    node = w.node_of[e.perm]
+    g0 = 0.5 * (pe0.astype(np.float64) + ps0) - gm0.astype(np.float64) / e.kappa
+    g = np.maximum(g0 - (w.Rn.T @ y / e.kappa)[node], 0.0)
+    got = e.P_est.cpu().numpy().astype(np.float64)       # after the swap: the operator's answer
+    assert np.abs(got - g).max() < 1e-6 * max(1.0, np.abs(g).max())
+    p = np.zeros((e.M, e.T))
+    np.add.at(p, node, g)
+    v = w.Rn @ p
+    scale = max(abs(e.vlo), abs(e.vhi))
+    assert v.max() <= e.vhi + 1e-7 * scale and v.min() >= e.vlo - 1e-7 * scale
+    act_hi, act_lo = v >= e.vhi - 1e-6 * scale, v <= e.vlo + 1e-6 * scale
+    assert (y[~(act_hi | act_lo)] == 0).all() and (y[act_hi] >= 0).all() and (y[act_lo] <= 0).all()
+    return int(act_hi.sum())
+
+
 def test_full_size_invariants(gpu_lib):
     """BASELINE size (100k homes x T=24, 2048 nodes): properties that need no oracle run.
     SOC rows, windows and energy bounds hold for every home; the epilogue identities
@@ -240,10 +273,18 @@ def test_full_size_invariants(gpu_lib):
     n_active = []
     for _ in range(3):
         G_before = e.G.clone()
+        pe0, ps0 = e.P_est.cpu().numpy(), e.P_sch.cpu().numpy()
         e.step()
-        if e.op_path_hist[-1] == "node":            # certificate of every fast-path answer
-            n_active.append(_operator_kkt_f64(e))
-    assert n_active and max(n_active) > 0           # the voltage rows do bind on the way
+        assert e.op_path_hist[-1] == "dual"
+        n_active.append(_dual_kkt_f64(e, w, pe0, ps0, G_before.cpu().numpy()))
+    assert max(n_active) > 0                        # the voltage rows do bind on the way
+    # the same state through the ADMM forms' node-space fast path carries its own certificate
+    from revs_admm_amd.engine import OperatorOptions
+    ea = _engine(w, "pdhg", op=OperatorOptions(solver="admm"))
+    for _ in range(2):
+        ea.step()
+        if ea.op_path_hist[-1] == "node":
+            _operator_kkt_f64(ea)
     P_sch, S, C = e.result()
     h = w.homes
     ev = h["ev"] == 1
@@ -321,7 +362,7 @@ def test_config0_com2_30pct_adoption(gpu_lib, golden, feeder_R):
     P_sch, S, C = e.result()
     assert (np.abs(S - p1) < 1e-6).all()             # same home problem as iteration 1
     np.testing.assert_allclose(d[1], np.linalg.norm(ref - g1, axis=1) / T, atol=2e-5)
-    assert e.op_path_hist[-1] == "home"              # this feeder clamps residences at zero
+    assert e.op_path_hist[-1] == "dual" and pe2.min() == 0.0   # residences clamped at zero
 
 
 def test_revs_fixture_end_to_end(gpu_lib, golden, tmp_path):

@@ -116,16 +116,21 @@ def test_operator_matches_oracle(gpu_lib, n, M, T):
     vlo, vhi = ro.voltage_limits(w.vset, w.vlow, w.vhigh)
     ref, info = ro.utility_solve(w.Rn, w.node_of, g0, w.kappa, vlo, vhi, return_info=True)
     assert np.abs(ref - np.maximum(g0, 0)).max() > 1e-2          # constraints bind
-    # both operator paths must give the oracle's answer: the node-space fast path (taken
-    # when no residence is clamped at zero) and the general home-space ADMM
+    # every operator path must give the oracle's answer: the dual Newton path (default),
+    # the node-space ADMM fast path (taken when no residence is clamped at zero) and the
+    # general home-space ADMM
     from revs_admm_amd.engine import OperatorOptions
-    for fast in (True, False):
-        e = _engine(w, op=OperatorOptions(node_fast=fast))
+    for solver, fast in (("admm", True), ("admm", False), ("newton", True)):
+        e = _engine(w, op=OperatorOptions(solver=solver, node_fast=fast))
         _set_state(e, pe, ps, gm)
         assert e.operator_solve()
         got = e.P_est_new.cpu().numpy()[e.inv_perm].astype(np.float64)
         assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max()), (fast, e.op_path_hist)
-        if not fast:
+        if solver == "newton":
+            assert e.op_path_hist == ["dual"] and e.newton_hist[-1][0] >= 1
+            # float64 all the way: the Newton answer is the oracle's to float32 rounding
+            assert np.abs(got - ref).max() < 2e-6 * max(1.0, np.abs(ref).max())
+        elif not fast:
             assert e.op_path_hist == ["home"]
         elif ref.min() > 1e-6:
             assert e.op_path_hist == ["node"]

@@ -105,23 +105,29 @@ def test_synthetic_workload_invariants():
     assert np.abs(ro.compute_Rmat_tree(fd) - w.Rn).max() < 1e-12 * w.Rn.max()
 
 
+@pytest.mark.parametrize("solver", ["newton", "admm"])
 @pytest.mark.parametrize("mode,omode", [("binary", "binary"), ("relaxed_exact", "relaxed")])
-def test_engine_driver_on_fake_kernels(mode, omode):
-    """AdmmEngine's host logic (operator driver in SVD/node form, stopping rule, rho
-    adaptation, P_est swap) with the numpy test double == oracle solve_ADMM."""
+def test_engine_driver_on_fake_kernels(mode, omode, solver):
+    """AdmmEngine's host logic (operator driver -- dual Newton with its line search, or the
+    ADMM forms with stopping rule and rho adaptation -- and the P_est swap) with the numpy
+    test double == oracle solve_ADMM."""
     from fake_kernels import FakeKernels
     from helpers import f32, oracle_homes
-    from revs_admm_amd.engine import AdmmEngine
+    from revs_admm_amd.engine import AdmmEngine, OperatorOptions
     from revs_admm_amd.synthetic import make_workload
     w = make_workload(150, 12, n_nodes=20, seed=2, stress=1.3, binary_feasible=(mode == "binary"))
     w.load, w.cost = f32(w.load), f32(w.cost)
     e = AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, kappa=w.kappa, vset=w.vset,
-                   vlow=w.vlow, vhigh=w.vhigh, mode=mode, device="cpu", _kernels=FakeKernels())
+                   vlow=w.vlow, vhigh=w.vhigh, mode=mode, device="cpu", _kernels=FakeKernels(),
+                   op=OperatorOptions(solver=solver))
     d = e.run(4)
     d_ref, P_ref, S_ref, C_ref = ro.solve_ADMM(oracle_homes(w), w.Rn, w.node_of, w.cost, w.kappa, 4,
                                                w.vset, w.vlow, w.vhigh, mode=omode)
     P, S, Cs = e.result()
-    assert max(e.op_iters_hist) > 25
+    if solver == "newton":       # the rows bind: Newton iterations were needed, none failed
+        assert set(e.op_path_hist) == {"dual"} and max(n for n, _, _ in e.newton_hist) >= 1
+    else:
+        assert max(e.op_iters_hist) > 25
     if mode == "binary":
         same = np.abs(S - S_ref).max(1) == 0
         assert same.mean() > 0.97
@@ -129,11 +135,12 @@ def test_engine_driver_on_fake_kernels(mode, omode):
         assert np.abs(S - S_ref).max() < 1e-3 and np.abs(d - d_ref).max() < 1e-3
 
 
-@pytest.mark.parametrize("stress,paths", [(0.9, {"node"}), (2.0, {"node", "home"})])
-def test_operator_paths_on_fake_kernels(stress, paths):
-    """Driver logic of the two operator paths: the node-space fast path is kept while no
-    residence is pushed to zero, and the general home-space ADMM takes over (for the rest of
-    the run) on a feeder stressed so hard that some are -- same answers as the oracle."""
+@pytest.mark.parametrize("stress", [0.9, 2.0, 4.0])
+def test_dual_newton_on_fake_kernels(stress):
+    """Driver logic of the dual Newton path (candidate sets, model solves, Armijo steps,
+    warm start of the multipliers) from a feeder whose rows barely bind to one stressed so
+    hard that whole subtrees are clamped at zero -- same answers as the oracle's
+    home-space ADMM, to the oracle's own tolerance."""
     from fake_kernels import FakeKernels
     from helpers import f32, oracle_homes
     from revs_admm_amd.engine import AdmmEngine
@@ -143,6 +150,30 @@ def test_operator_paths_on_fake_kernels(stress, paths):
     e = AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, kappa=w.kappa, vset=w.vset,
                    vlow=w.vlow, vhigh=w.vhigh, mode="relaxed_exact", device="cpu",
                    _kernels=FakeKernels())
+    d = e.run(6)
+    d_ref, P_ref, S_ref, C_ref = ro.solve_ADMM(oracle_homes(w), w.Rn, w.node_of, w.cost, w.kappa, 6,
+                                               w.vset, w.vlow, w.vhigh, mode="relaxed")
+    assert set(e.op_path_hist) == {"dual"}
+    assert max(n for n, _, _ in e.newton_hist) >= 1                       # the rows do bind
+    if stress >= 2.0:
+        assert e.P_est.min().item() == 0.0                               # clamped residences
+    assert np.abs(e.result()[1] - S_ref).max() < 1e-5 and np.abs(d - d_ref).max() < 1e-6
+
+
+@pytest.mark.parametrize("stress,paths", [(0.9, {"node"}), (2.0, {"node", "home"})])
+def test_operator_paths_on_fake_kernels(stress, paths):
+    """Driver logic of the two ADMM operator paths (OperatorOptions.solver = "admm"): the node-space fast path is kept while no
+    residence is pushed to zero, and the general home-space ADMM takes over (for the rest of
+    the run) on a feeder stressed so hard that some are -- same answers as the oracle."""
+    from fake_kernels import FakeKernels
+    from helpers import f32, oracle_homes
+    from revs_admm_amd.engine import AdmmEngine, OperatorOptions
+    from revs_admm_amd.synthetic import make_workload
+    w = make_workload(150, 12, n_nodes=20, seed=2, stress=stress, binary_feasible=False)
+    w.load, w.cost = f32(w.load), f32(w.cost)
+    e = AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, kappa=w.kappa, vset=w.vset,
+                   vlow=w.vlow, vhigh=w.vhigh, mode="relaxed_exact", device="cpu",
+                   _kernels=FakeKernels(), op=OperatorOptions(solver="admm"))
     d = e.run(6)
     d_ref, P_ref, S_ref, C_ref = ro.solve_ADMM(oracle_homes(w), w.Rn, w.node_of, w.cost, w.kappa, 6,
                                                w.vset, w.vlow, w.vhigh, mode="relaxed")
