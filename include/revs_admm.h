@@ -344,10 +344,14 @@ int revs_op_export(int64_t n_homes, int32_t T, const double *sb, float *p_est, v
  *                        stats double[T][8]: [0] largest |v - b| over rows with y != 0 and
  *                        bound violation over the others, [1] D_t, [2] rows with y != 0,
  *                        [3] violated rows with y = 0 ([4] is left to revs_op_dual_step).
- *                        vfull double[m][T] receives v; viol double[T][m] is workspace.
- *   revs_op_dual_bpp     K double[T][AMAX][AMAX] (R_F N R_F^T / kappa of the candidates,
- *                        unsigned): yhat double[T][AMAX] = maximiser of the model over the
- *                        sign constraints; info int32[T] = pivots (negative: limit hit)
+ *                        vfull double[m][T] receives v; viol double[m][T] and partial
+ *                        double[revs_op_dual_blocks(m)][T][4] are workspace.
+ *   revs_op_dual_model   the model of every slot: K = R_F N R_F^T / kappa over its candidates
+ *                        (R double[m][m] row-major, n_free = pnq[1]; accumulated as nks
+ *                        column slabs k_slabs double[T][nks][AMAX][AMAX], summed in order
+ *                        into k_full double[T][AMAX][AMAX]), then its maximiser over the sign
+ *                        constraints by block principal pivoting in LDS: yhat double[T][AMAX];
+ *                        info int32[T] = pivots (negative: limit hit)
  *   revs_op_dual_step    y_trial = y at the candidates moved by alpha[t] towards yhat (all
  *                        other entries of y_trial must already equal y);
  *                        lin_out[8 t] = gradient . (y_trial - y)                         */
@@ -355,13 +359,17 @@ int revs_op_export(int64_t n_homes, int32_t T, const double *sb, float *p_est, v
 int revs_op_dual_eval(int32_t m, int32_t T, const int64_t *node_ptr, const float *p_est,
                       const float *p_sch, const float *gamma, int32_t nslab, const double *dsl,
                       double kappa, double *pnq, float *p_est_new, void *stream);
+int32_t revs_op_dual_blocks(int32_t m);
 int revs_op_dual_select(int32_t m, int32_t T, int32_t nslab, const double *vsl,
                         const double *pnq, const double *y, double vlo, double vhi,
-                        int32_t kadd, double *vfull, double *viol, int64_t *cand_idx,
-                        int32_t *cand_cnt, double *cand_val, double *stats, void *stream);
-int revs_op_dual_bpp(int32_t T, const double *K, const int32_t *cand_cnt,
-                     const double *cand_val, double delta, int32_t max_pivots, double *yhat,
-                     int32_t *info, void *stream);
+                        int32_t kadd, double *vfull, double *viol, double *partial,
+                        int64_t *cand_idx, int32_t *cand_cnt, double *cand_val, double *stats,
+                        void *stream);
+int revs_op_dual_model(int32_t m, int32_t T, const double *R, const double *n_free,
+                       const int64_t *cand_idx, const int32_t *cand_cnt, const double *cand_val,
+                       double kappa, double delta, int32_t max_pivots, int32_t nks,
+                       double *k_slabs, double *k_full, double *yhat, int32_t *info,
+                       void *stream);
 int revs_op_dual_step(int32_t T, const int64_t *cand_idx, const int32_t *cand_cnt,
                       const double *cand_val, const double *yhat, const double *alpha,
                       double *y_trial, double *lin_out, void *stream);

@@ -76,9 +76,11 @@ SIGNATURES = {
     "revs_op_node_apply": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p, _f64, _i32, _p, _p, _p]),
     "revs_op_export": (C.c_int, [_i64, _i32, _p, _p, _p]),
     "revs_op_dual_eval": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _i32, _p, _f64, _p, _p, _p]),
+    "revs_op_dual_blocks": (_i32, [_i32]),
     "revs_op_dual_select": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _f64, _f64, _i32, _p, _p, _p,
-                                      _p, _p, _p, _p]),
-    "revs_op_dual_bpp": (C.c_int, [_i32, _p, _p, _p, _f64, _i32, _p, _p, _p]),
+                                      _p, _p, _p, _p, _p]),
+    "revs_op_dual_model": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p, _f64, _f64, _i32, _i32, _p,
+                                     _p, _p, _p, _p]),
     "revs_op_dual_step": (C.c_int, [_i32, _p, _p, _p, _p, _p, _p, _p, _p]),
 }
 DUAL_AMAX = 64           # REVS_DUAL_AMAX

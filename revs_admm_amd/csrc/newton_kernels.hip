@@ -85,65 +85,104 @@ __global__ __launch_bounds__(256) void op_dual_eval_kernel(
 }
 
 // ---- per-slot bookkeeping: v, residual, D_t, candidate rows ------------------------
-// One workgroup per slot.  Thread j owns the contiguous rows [j R, (j+1) R), R = ceil(m/256),
-// so the rows with a multiplier are compacted in row order (deterministic: every rank
-// builds the same lists); the most violated rows without a multiplier are then appended
-// by `kadd` rounds of a block-wide arg-max (ties to the lower row).
-__global__ __launch_bounds__(256) void op_dual_select_kernel(
+// Stage 1, all rows in parallel: v = sum of the product's K-split slabs, the residual /
+// violation of every row, and per-(row block, slot) partial reductions in a fixed order.
+// Workgroup = 8 rows x TL slot lanes; partial[blk][t] = {max residual, sum D terms,
+// rows with y != 0, violated rows with y = 0}.
+template <int TL>
+__global__ __launch_bounds__(256) void op_dual_rows_kernel(
         int m, int T, int nslab, const double *__restrict__ vsl, const double *__restrict__ pnq,
-        const double *__restrict__ y, double vlo, double vhi, int kadd,
-        double *__restrict__ vfull, double *__restrict__ viol, int64_t *__restrict__ cidx,
-        int32_t *__restrict__ ccnt, double *__restrict__ cval, double *__restrict__ stats) {
-    const int t = blockIdx.x, tid = threadIdx.x;
+        const double *__restrict__ y, double vlo, double vhi, double *__restrict__ vfull,
+        double *__restrict__ viol, double *__restrict__ partial) {
+    constexpr int HS = 256 / TL;
+    const int t = threadIdx.x % TL, hs = threadIdx.x / TL;
+    const int rows_per = HS * ((m + HS * (int)gridDim.x - 1) / (HS * (int)gridDim.x));
+    const int rb = blockIdx.x * rows_per;
     const int64_t total = (int64_t)m * T;
-    const int per = (m + 255) / 256;
-    const int r0 = min(m, tid * per), r1 = min(m, r0 + per);
-    double *vw = viol + (int64_t)t * m;
-    int nsup = 0, nvio = 0;
-    double rmax = 0.0, dsum = 0.0;
-    for (int r = r0; r < r1; ++r) {
-        const int64_t i = (int64_t)r * T + t;
-        double v = 0.0;
-        for (int q = 0; q < nslab; ++q) v += vsl[i + q * total];
-        vfull[i] = v;
-        const double yv = y[i];
-        const bool up = yv > 0.0 || (yv == 0.0 && v > vhi);
-        const double b = up ? vhi : vlo;
-        const double vi = fmax(fmax(v - vhi, vlo - v), 0.0);
-        rmax = fmax(rmax, yv != 0.0 ? fabs(v - b) : vi);
-        dsum += pnq[i + 2 * total] - fmax(vhi * yv, vlo * yv);
-        if (yv != 0.0) { ++nsup; vw[r] = 0.0; }
-        else { vw[r] = vi; nvio += vi > 0.0 ? 1 : 0; }
+    double rmax = 0.0, dsum = 0.0, nsup = 0.0, nvio = 0.0;
+    if (t < T) {
+        for (int r = rb + hs; r < min(m, rb + rows_per); r += HS) {
+            const int64_t i = (int64_t)r * T + t;
+            double v = 0.0;
+            for (int q = 0; q < nslab; ++q) v += vsl[i + q * total];
+            vfull[i] = v;
+            const double yv = y[i];
+            const bool up = yv > 0.0 || (yv == 0.0 && v > vhi);
+            const double b = up ? vhi : vlo;
+            const double vi = fmax(fmax(v - vhi, vlo - v), 0.0);
+            rmax = fmax(rmax, yv != 0.0 ? fabs(v - b) : vi);
+            dsum += pnq[i + 2 * total] - fmax(vhi * yv, vlo * yv);
+            nsup += yv != 0.0 ? 1.0 : 0.0;
+            nvio += (yv == 0.0 && vi > 0.0) ? 1.0 : 0.0;
+            viol[i] = yv != 0.0 ? 0.0 : vi;
+        }
     }
+    __shared__ double red[4][HS][TL];
+    red[0][hs][t] = rmax; red[1][hs][t] = dsum; red[2][hs][t] = nsup; red[3][hs][t] = nvio;
+    __syncthreads();
+    if (hs == 0 && t < T) {
+        double a = red[0][0][t], b = red[1][0][t], c = red[2][0][t], d = red[3][0][t];
+#pragma unroll
+        for (int k = 1; k < HS; ++k) {
+            a = fmax(a, red[0][k][t]); b += red[1][k][t]; c += red[2][k][t]; d += red[3][k][t];
+        }
+        double *o = partial + ((int64_t)blockIdx.x * T + t) * 4;
+        o[0] = a; o[1] = b; o[2] = c; o[3] = d;
+    }
+}
+
+// Stage 2, one workgroup per slot: fold the partials (fixed order), and -- only for a slot
+// that has multipliers or violated rows -- build its candidate list.  Thread j owns the
+// contiguous rows [j R, (j+1) R), R = ceil(m/256), so the rows with a multiplier are
+// compacted in row order (deterministic: every rank builds the same lists); the most
+// violated rows without a multiplier are appended by `kadd` rounds of a block-wide
+// arg-max (ties to the lower row).
+__global__ __launch_bounds__(256) void op_dual_select_kernel(
+        int m, int T, int nblk, const double *__restrict__ partial, const double *__restrict__ y,
+        double vlo, double vhi, int kadd, const double *__restrict__ vfull,
+        double *__restrict__ viol, int64_t *__restrict__ cidx, int32_t *__restrict__ ccnt,
+        double *__restrict__ cval, double *__restrict__ stats) {
+    const int t = blockIdx.x, tid = threadIdx.x;
     __shared__ int cnt_s[256];
-    __shared__ double red_s[2][4];
-    __shared__ int redi_s[2][4];
+    __shared__ double red_s[4][4];
     __shared__ double best_v[4];
     __shared__ int best_i[4];
-    cnt_s[tid] = nsup;
-    // fixed-order block reductions: lanes by xor-shuffle, the 4 wavefronts in order
-    const double wm = wave_max_d(rmax), wsum = wave_sum_d(dsum);
-    int wv = nvio;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) wv += __shfl_xor(wv, d, 64);
-    if ((tid & 63) == 0) { red_s[0][tid >> 6] = wm; red_s[1][tid >> 6] = wsum; redi_s[0][tid >> 6] = wv; }
+    {
+        double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
+        for (int k = tid; k < nblk; k += 256) {
+            const double *o = partial + ((int64_t)k * T + t) * 4;
+            a = fmax(a, o[0]); b += o[1]; c += o[2]; d += o[3];
+        }
+        a = wave_max_d(a); b = wave_sum_d(b); c = wave_sum_d(c); d = wave_sum_d(d);
+        if ((tid & 63) == 0) {
+            red_s[0][tid >> 6] = a; red_s[1][tid >> 6] = b; red_s[2][tid >> 6] = c; red_s[3][tid >> 6] = d;
+        }
+    }
     __syncthreads();
-    int pos = 0, ns = 0;
-    for (int j = 0; j < 256; ++j) { const int c = cnt_s[j]; pos += j < tid ? c : 0; ns += c; }
+    const int ns = (int)(((red_s[2][0] + red_s[2][1]) + red_s[2][2]) + red_s[2][3]);
+    const int nv = (int)(((red_s[3][0] + red_s[3][1]) + red_s[3][2]) + red_s[3][3]);
     if (tid == 0) {
         stats[t * 8 + 0] = fmax(fmax(red_s[0][0], red_s[0][1]), fmax(red_s[0][2], red_s[0][3]));
         stats[t * 8 + 1] = ((red_s[1][0] + red_s[1][1]) + red_s[1][2]) + red_s[1][3];
         stats[t * 8 + 2] = (double)ns;
-        stats[t * 8 + 3] = (double)(redi_s[0][0] + redi_s[0][1] + redi_s[0][2] + redi_s[0][3]);
+        stats[t * 8 + 3] = (double)nv;
     }
     int64_t *ci = cidx + (int64_t)t * kAmax;
     double *cs = cval + (int64_t)t * 3 * kAmax, *cg = cs + kAmax, *cy = cg + kAmax;
-    if (ns > kAmax) {                       // uniform: more multipliers than the model holds
-        if (tid == 0) ccnt[t] = -1;
+    if (ns > kAmax || (ns == 0 && nv == 0)) {   // uniform: too many multipliers / nothing to do
+        if (tid == 0) ccnt[t] = ns > kAmax ? -1 : 0;
         if (tid < kAmax) { ci[tid] = 0; cs[tid] = 1.0; cg[tid] = 0.0; cy[tid] = 0.0; }
         return;
     }
-    for (int r = r0; r < r1; ++r) {
+    const int per = (m + 255) / 256;
+    const int r0 = min(m, tid * per), r1 = min(m, r0 + per);
+    int nsup = 0;
+    for (int r = r0; r < r1; ++r) nsup += y[(int64_t)r * T + t] != 0.0 ? 1 : 0;
+    cnt_s[tid] = nsup;
+    __syncthreads();
+    int pos = 0;
+    for (int j = 0; j < tid; ++j) pos += cnt_s[j];
+    for (int r = r0; r < r1 && nsup > 0; ++r) {
         const int64_t i = (int64_t)r * T + t;
         const double yv = y[i];
         if (yv != 0.0) {
@@ -154,14 +193,14 @@ __global__ __launch_bounds__(256) void op_dual_select_kernel(
             ++pos;
         }
     }
-    const int room = min(kadd, kAmax - ns);
+    const int room = min(min(kadd, kAmax - ns), nv);
     int added = 0;
     for (int k = 0; k < room; ++k) {
-        __syncthreads();                    // vw updates of the previous round are visible
+        __syncthreads();                    // viol updates of the previous round are visible
         double bv = 0.0;
         int bi = m;
         for (int r = tid; r < m; r += 256) {
-            const double x = vw[r];
+            const double x = viol[(int64_t)r * T + t];
             if (x > bv) { bv = x; bi = r; }      // ascending r: ties keep the lower row
         }
 #pragma unroll
@@ -184,13 +223,69 @@ __global__ __launch_bounds__(256) void op_dual_select_kernel(
             cs[ns + added] = up ? 1.0 : -1.0;
             cg[ns + added] = v - (up ? vhi : vlo);
             cy[ns + added] = 0.0;
-            vw[bi] = 0.0;
+            viol[(int64_t)bi * T + t] = 0.0;
         }
         ++added;
     }
     const int cnt = ns + added;
     if (tid == 0) ccnt[t] = cnt;
     if (tid >= cnt && tid < kAmax) { ci[tid] = 0; cs[tid] = 1.0; cg[tid] = 0.0; cy[tid] = 0.0; }
+}
+
+// ---- model Hessian: K_t = R_F N_t R_F^T (candidates x candidates), K-split slabs ------
+// Workgroup (t, ks) covers columns [ks, ks+1) * m/nks of R in chunks of 32: the candidate
+// rows of R (and the same rows scaled by N[.,t]) are staged in LDS with coalesced loads,
+// and thread (ti, tj) accumulates a 4 x 4 block of the 64 x 64 product.  Slabs are summed
+// (fixed order) by op_dual_bpp_kernel.
+__global__ __launch_bounds__(256) void op_dual_gram_kernel(
+        int m, int T, const double *__restrict__ R, const double *__restrict__ Nn,
+        const int64_t *__restrict__ cidx, const int32_t *__restrict__ ccnt, int nks,
+        double *__restrict__ Kslab) {
+    const int t = blockIdx.x, ks = blockIdx.y, tid = threadIdx.x;
+    const int a = ccnt[t];
+    if (a <= 0) return;
+    constexpr int KC = 32;
+    __shared__ double Ws[kAmax][KC + 1], Rs_[kAmax][KC + 1];
+    __shared__ int64_t rows_s[kAmax];
+    if (tid < kAmax) rows_s[tid] = tid < a ? cidx[(int64_t)t * kAmax + tid] : 0;
+    __syncthreads();
+    const int a4 = (a + 3) & ~3;
+    const int ti = tid >> 4, tj = tid & 15;
+    const bool mine = ti * 4 < a4 && tj * 4 < a4;
+    double acc[4][4] = {};
+    const int chunk = (m + nks - 1) / nks;
+    const int k0 = ks * chunk, k1 = min(m, k0 + chunk);
+    for (int kk = k0; kk < k1; kk += KC) {
+        // stage: 256 threads = 8 rows x 32 columns per pass
+        for (int rr = tid >> 5; rr < a4; rr += 8) {
+            const int c = kk + (tid & 31);
+            double rv = 0.0, nv = 0.0;
+            if (rr < a && c < k1) { rv = R[rows_s[rr] * m + c]; nv = Nn[(int64_t)c * T + t]; }
+            Rs_[rr][tid & 31] = rv;
+            Ws[rr][tid & 31] = rv * nv;
+        }
+        __syncthreads();
+        if (mine) {
+#pragma unroll 8
+            for (int c = 0; c < KC; ++c) {
+                double wv[4], rv[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) { wv[x] = Ws[ti * 4 + x][c]; rv[x] = Rs_[tj * 4 + x][c]; }
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int z = 0; z < 4; ++z) acc[x][z] += wv[x] * rv[z];
+            }
+        }
+        __syncthreads();
+    }
+    if (mine) {
+        double *o = Kslab + ((int64_t)t * nks + ks) * kAmax * kAmax;
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int z = 0; z < 4; ++z) o[(ti * 4 + x) * kAmax + tj * 4 + z] = acc[x][z];
+    }
 }
 
 // ---- the model problem of one slot: block principal pivoting in LDS ------------------
@@ -201,9 +296,9 @@ __global__ __launch_bounds__(256) void op_dual_select_kernel(
 // every infeasible index (u_i < 0 in B, w_i < 0 outside) while that shrinks their number,
 // else only the highest one -- finite for a positive definite K'.
 __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
-        const double *__restrict__ Kall, const int32_t *__restrict__ ccnt,
-        const double *__restrict__ cval, double delta, int max_pivots, double *__restrict__ yhat,
-        int32_t *__restrict__ info) {
+        const double *__restrict__ Kslab, int nks, double inv_kappa, double *__restrict__ Kall,
+        const int32_t *__restrict__ ccnt, const double *__restrict__ cval, double delta,
+        int max_pivots, double *__restrict__ yhat, int32_t *__restrict__ info) {
     const int t = blockIdx.x, tid = threadIdx.x;
     const int a = ccnt[t];
     const double *cs = cval + (int64_t)t * 3 * kAmax, *cg = cs + kAmax, *cy = cg + kAmax;
@@ -213,7 +308,19 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
         if (tid == 0) info[t] = 0;
         return;
     }
-    const double *Kt = Kall + (int64_t)t * kAmax * kAmax;
+    // K = (sum of the K-split slabs) / kappa, rows and columns < a (rounded up to 4)
+    double *Kt = Kall + (int64_t)t * kAmax * kAmax;
+    {
+        const int a4 = (a + 3) & ~3;
+        for (int e = tid; e < a4 * a4; e += 256) {
+            const int i = e / a4, j = e - i * a4;
+            const double *src = Kslab + (int64_t)t * nks * kAmax * kAmax + i * kAmax + j;
+            double acc = 0.0;
+            for (int q = 0; q < nks; ++q) acc += src[(int64_t)q * kAmax * kAmax];
+            Kt[i * kAmax + j] = acc * inv_kappa;
+        }
+    }
+    __syncthreads();
     __shared__ double Ls[kAmax][kAmax + 1];
     __shared__ double s_s[kAmax], c_s[kAmax], u_s[kAmax], w_s[kAmax];
     __shared__ int bl[kAmax];
@@ -378,28 +485,46 @@ extern "C" int revs_op_dual_eval(int32_t m, int32_t T, const int64_t *node_ptr,
     return REVS_OK;
 }
 
+extern "C" int32_t revs_op_dual_blocks(int32_t m) {
+    return m <= 0 ? 0 : (m + 7) / 8 < 256 ? (m + 7) / 8 : 256;
+}
+
 extern "C" int revs_op_dual_select(int32_t m, int32_t T, int32_t nslab, const double *vsl,
                                    const double *pnq, const double *y, double vlo, double vhi,
-                                   int32_t kadd, double *vfull, double *viol, int64_t *cand_idx,
-                                   int32_t *cand_cnt, double *cand_val, double *stats,
-                                   void *stream) {
-    REVS_REQUIRE(m > 0 && T > 0 && nslab >= 1 && vsl && pnq && y && vfull && viol && cand_idx &&
-                 cand_cnt && cand_val && stats && vlo <= vhi && kadd >= 0,
+                                   int32_t kadd, double *vfull, double *viol, double *partial,
+                                   int64_t *cand_idx, int32_t *cand_cnt, double *cand_val,
+                                   double *stats, void *stream) {
+    REVS_REQUIRE(m > 0 && T > 0 && T <= 256 && nslab >= 1 && vsl && pnq && y && vfull && viol &&
+                 partial && cand_idx && cand_cnt && cand_val && stats && vlo <= vhi && kadd >= 0,
                  "revs_op_dual_select: bad argument");
-    hipLaunchKernelGGL(op_dual_select_kernel, dim3(T), dim3(256), 0, S_(stream), m, T, nslab, vsl,
-                       pnq, y, vlo, vhi, kadd, vfull, viol, cand_idx, cand_cnt, cand_val, stats);
+    const int nblk = revs_op_dual_blocks(m);
+#define RW(TL)                                                                                 \
+    hipLaunchKernelGGL((op_dual_rows_kernel<TL>), dim3(nblk), dim3(256), 0, S_(stream), m, T,  \
+                       nslab, vsl, pnq, y, vlo, vhi, vfull, viol, partial)
+    if (T <= 32) RW(32);
+    else if (T <= 64) RW(64);
+    else if (T <= 128) RW(128);
+    else RW(256);
+#undef RW
+    hipLaunchKernelGGL(op_dual_select_kernel, dim3(T), dim3(256), 0, S_(stream), m, T, nblk,
+                       partial, y, vlo, vhi, kadd, vfull, viol, cand_idx, cand_cnt, cand_val, stats);
     REVS_CHECK_LAUNCH("revs_op_dual_select");
     return REVS_OK;
 }
 
-extern "C" int revs_op_dual_bpp(int32_t T, const double *K, const int32_t *cand_cnt,
-                                const double *cand_val, double delta, int32_t max_pivots,
-                                double *yhat, int32_t *info, void *stream) {
-    REVS_REQUIRE(T > 0 && K && cand_cnt && cand_val && yhat && info && delta >= 0 &&
-                 max_pivots > 0, "revs_op_dual_bpp: bad argument");
-    hipLaunchKernelGGL(op_dual_bpp_kernel, dim3(T), dim3(256), 0, S_(stream), K, cand_cnt,
-                       cand_val, delta, max_pivots, yhat, info);
-    REVS_CHECK_LAUNCH("revs_op_dual_bpp");
+extern "C" int revs_op_dual_model(int32_t m, int32_t T, const double *R, const double *n_free,
+                                  const int64_t *cand_idx, const int32_t *cand_cnt,
+                                  const double *cand_val, double kappa, double delta,
+                                  int32_t max_pivots, int32_t nks, double *k_slabs, double *k_full,
+                                  double *yhat, int32_t *info, void *stream) {
+    REVS_REQUIRE(m > 0 && T > 0 && R && n_free && cand_idx && cand_cnt && cand_val && k_slabs &&
+                 k_full && yhat && info && kappa > 0 && delta >= 0 && max_pivots > 0 &&
+                 nks >= 1 && nks <= 64, "revs_op_dual_model: bad argument");
+    hipLaunchKernelGGL(op_dual_gram_kernel, dim3(T, nks), dim3(256), 0, S_(stream), m, T, R, n_free,
+                       cand_idx, cand_cnt, nks, k_slabs);
+    hipLaunchKernelGGL(op_dual_bpp_kernel, dim3(T), dim3(256), 0, S_(stream), k_slabs, nks,
+                       1.0 / kappa, k_full, cand_cnt, cand_val, delta, max_pivots, yhat, info);
+    REVS_CHECK_LAUNCH("revs_op_dual_model");
     return REVS_OK;
 }
 

@@ -250,7 +250,11 @@ class AdmmEngine:
         self.pnq = torch.zeros(3, M, T, **f64)
         self.d_sl, self.v_sl = nz1(), nz1()
         self.vfull = nz()
-        self.violw = torch.zeros(T, M, **f64)
+        self.violw = nz()
+        self.d_part = torch.zeros(int(self.lib.revs_op_dual_blocks(M)), T, 4, **f64)
+        self.nks = int(min(16, max(1, M // 256)))       # column slabs of the model Hessian
+        self.k_slabs = torch.zeros(T, self.nks, A, A, **f64)
+        self.k_full = torch.zeros(T, A, A, **f64)
         self.c_idx = [torch.zeros(T, A, dtype=torch.int64, device=self.dev) for _ in range(2)]
         self.c_cnt = [torch.zeros(T, dtype=torch.int32, device=self.dev) for _ in range(2)]
         self.c_val = [torch.zeros(T, 3, A, **f64) for _ in range(2)]
@@ -609,7 +613,8 @@ class AdmmEngine:
         self._gemm1(self.R64T, self.pnq[0], self.v_sl)                     # R p
         check(lib.revs_op_dual_select(M, T, ks, ptr(self.v_sl), ptr(self.pnq), ptr(y), self.vlo,
                                       self.vhi, self.op.newton_kadd, ptr(self.vfull),
-                                      ptr(self.violw), ptr(self.c_idx[k]), ptr(self.c_cnt[k]),
+                                      ptr(self.violw), ptr(self.d_part), ptr(self.c_idx[k]),
+                                      ptr(self.c_cnt[k]),
                                       ptr(self.c_val[k]), ptr(self.n_stats[k]), st),
               "revs_op_dual_select")
         return self.n_stats[k].cpu().numpy()
@@ -634,13 +639,14 @@ class AdmmEngine:
             if newton >= o.newton_max:
                 break
             newton += 1
-            # model Hessian of every slot: K_t = R_F N_t R_F^T / kappa  (candidates x candidates)
-            Rg = self.R64.index_select(0, self.c_idx[cur].view(-1)).view(T, A, M)
-            K = torch.bmm(Rg * self.pnq[1].t().unsqueeze(1), Rg.transpose(1, 2))
-            K.div_(self.kappa)
-            check(lib.revs_op_dual_bpp(T, ptr(K), ptr(self.c_cnt[cur]), ptr(self.c_val[cur]),
-                                       o.newton_delta, o.newton_pivots, ptr(self.yhat),
-                                       ptr(self.bpp_info), st), "revs_op_dual_bpp")
+            # model of every slot: K_t = R_F N_t R_F^T / kappa over its candidates, maximised
+            # over the sign constraints (block principal pivoting, one workgroup per slot)
+            check(lib.revs_op_dual_model(M, T, ptr(self.R64), ptr(self.pnq[1]),
+                                         ptr(self.c_idx[cur]), ptr(self.c_cnt[cur]),
+                                         ptr(self.c_val[cur]), self.kappa, o.newton_delta,
+                                         o.newton_pivots, self.nks, ptr(self.k_slabs),
+                                         ptr(self.k_full), ptr(self.yhat), ptr(self.bpp_info), st),
+                  "revs_op_dual_model")
             D = stt[:, 1]
             pending = rmax > o.eps
             alpha = pending.astype(np.float64)

@@ -304,8 +304,11 @@ class FakeKernels:
             view(pe_new, (n, T), np.float32)[:] = g
         return 0
 
-    def revs_op_dual_select(self, m, T, nslab, vsl, pnq, y, vlo, vhi, kadd, vfull, viol, cidx, ccnt,
-                            cval, stats, stream):
+    def revs_op_dual_blocks(self, m):
+        return min(256, (m + 7) // 8)
+
+    def revs_op_dual_select(self, m, T, nslab, vsl, pnq, y, vlo, vhi, kadd, vfull, viol, partial,
+                            cidx, ccnt, cval, stats, stream):
         A = 64
         v = view(vsl, (nslab, m, T), np.float64).sum(axis=0)
         view(vfull, (m, T), np.float64)[:] = v
@@ -340,9 +343,11 @@ class FakeKernels:
                 cv[t, 2, i] = yv[r, t]
         return 0
 
-    def revs_op_dual_bpp(self, T, K, ccnt, cval, delta, max_pivots, yhat, info, stream):
+    def revs_op_dual_model(self, m, T, R, n_free, cidx, ccnt, cval, kappa, delta, max_pivots, nks,
+                           k_slabs, k_full, yhat, info, stream):
         A = 64
-        Kv, cc = view(K, (T, A, A), np.float64), view(ccnt, (T,), np.int32)
+        Rm, Nf = view(R, (m, m), np.float64), view(n_free, (m, T), np.float64)
+        ci, cc = view(cidx, (T, A), np.int64), view(ccnt, (T,), np.int32)
         cv, yh = view(cval, (T, 3, A), np.float64), view(yhat, (T, A), np.float64)
         inf = view(info, (T,), np.int32)
         for t in range(T):
@@ -352,8 +357,10 @@ class FakeKernels:
                 inf[t] = 0
                 continue
             s = cv[t, 0, :a]
-            Kp = Kv[t, :a, :a] * s[:, None] * s[None, :]
-            Kp = Kp + (delta * np.trace(Kv[t, :a, :a]) / a + 1e-300) * np.eye(a)
+            RF = Rm[ci[t, :a]]
+            K0 = (RF * Nf[:, t][None, :]) @ RF.T / kappa
+            Kp = K0 * s[:, None] * s[None, :]
+            Kp = Kp + (delta * np.trace(K0) / a + 1e-300) * np.eye(a)
             u = np.maximum(s * cv[t, 2, :a], 0.0)
             c = s * cv[t, 1, :a] + Kp @ u
             B = u > 0
