@@ -193,21 +193,14 @@ def main():
     for _ in range(args.warmup):
         eng.step(write_sc=False)
     barrier()
-    ev_a = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            for _ in range(args.steps)]
-    ev_o = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            for _ in range(args.steps)]
+    # HIP events on the stream the kernels run on: before the operator part, between it
+    # and the home sweep, after the sweep
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
     inner0 = len(eng.op_iters_hist)
+    spec0 = list(eng.spec_hist)
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev_o[k][0].record()
-        eng.operator_solve()
-        ev_o[k][1].record()
-        ev_a[k][0].record()
-        eng.agent_step(write_sc=False)
-        ev_a[k][1].record()
-        eng.P_est, eng.P_est_new = eng.P_est_new, eng.P_est
-        eng.iteration += 1
+        eng.step(write_sc=False, events=evs[k])
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -215,22 +208,25 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     rp, rd, dmax, conv = eng.residuals(args.eps)
-    agent_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_a]))
-    oper_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_o]))
+    agent_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in evs]))
+    oper_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in evs]))
     inner = eng.op_iters_hist[inner0:]
     st = eng.status.cpu().numpy()
     pdhg_it = float((st >> 8)[(st >> 8) > 0].mean()) if args.mode == "pdhg" and ((st >> 8) > 0).any() else None
 
-    # the f64 matrix-core product of the operator path that actually ran: the voltage check
-    # Rs.p0 / Q^T w (M x M x T) on the node-space fast path, Q^T [rhat | w] (2T columns) on
-    # the general path
-    fast = eng.op_path_hist[-1] == "node"
+    # the f64 matrix-core product of the operator path that actually ran: the voltage rows
+    # R.p of the dual Newton path (M x M x T), Rs.p0 / Q^T w (M x M x T) on the node-space
+    # ADMM fast path, Q^T [rhat | w] (2T columns) on the general ADMM path
+    path = eng.op_path_hist[-1]
+    fast = path in ("node", "dual")
     reps = 200
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        if fast:
+        if path == "dual":
+            eng._gemm1(eng.R64T, eng.pnq[0], eng.v_sl)
+        elif fast:
             eng._gemm1(eng.Rs, eng.p0, eng.f_wh)
         else:
             eng._gemm_cat(eng.Q, eng.rhat, eng.w, eng.ta, eng.tb)
@@ -284,7 +280,7 @@ def main():
             "config": {
                 "workload": f"synthetic {args.homes} homes/GPU x T={args.T} box+SOC home QP, "
                             f"{args.nodes}-node radial feeder, one ADMM iteration per step "
-                            "(operator voltage check / QP + all home QPs + dual update + "
+                            "(operator QP by dual Newton + all home QPs + dual update + "
                             f"residuals), timed from a state {args.spinup + args.warmup} ADMM "
                             "iterations into the run; the transient before it is in "
                             "breakdown.transient",
@@ -300,7 +296,7 @@ def main():
                 "avg_launch_ms": agent_ms, "pdhg_iters_mean": pdhg_it,
             },
             "roofline_matvec": {
-                "kernel": "gemm_tn_kernel<double> (" + ("voltage check Rs.p0, M x M x T" if fast else "Q^T [rhat | w], M x M x 2T") + ")",
+                "kernel": "gemm_tn_kernel<double> (" + ("voltage rows R.p, M x M x T" if path == "dual" else "voltage check Rs.p0, M x M x T" if fast else "Q^T [rhat | w], M x M x 2T") + ")",
                 "bound": "mfma", "achieved": gemm_flops / (gemm_ms * 1e-3) / 1e12,
                 "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": gemm_flops / (gemm_ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS,
@@ -310,6 +306,10 @@ def main():
                 "operator_ms_per_step": oper_ms, "agent_ms_per_step": agent_ms,
                 "operator_inner_iters_mean": float(np.mean(inner)) if inner else 0.0,
                 "operator_path": eng.op_path_hist[-1],
+                "operator_newton_iters_mean": (float(np.mean([h[0] for h in eng.newton_hist[-args.steps:]]))
+                                               if eng.newton_hist else None),
+                "speculative_sweeps_kept_discarded": [eng.spec_hist[0] - spec0[0],
+                                                      eng.spec_hist[1] - spec0[1]],
                 "operator_voltage_rows": int(eng.M * args.T),
                 "admm_residual_primal": rp, "admm_residual_dual": rd, "admm_max_diff": dmax,
                 "admm_iters_to_eps": iters_to_eps, "eps": args.eps,

@@ -111,6 +111,20 @@ int revs_agent_step(int64_t n_homes, int32_t T,
                     float kappa, int32_t mode, const revs_pdhg_t *pdhg_host,
                     void *stream);
 
+/* The same iteration with P_sch[k+1] and G[k+1] written to separate buffers (p_sch and
+ * gamma are only read), so a caller may launch it speculatively -- e.g. before it knows
+ * whether the operator's first answer will stand -- and discard the result.
+ * revs_agent_step is this call with p_sch_out = p_sch, gamma_out = gamma. */
+int revs_agent_step_out(int64_t n_homes, int32_t T,
+                        const float *cost, const revs_home_t *homes, const float *load,
+                        const float *p_est_old, const float *p_est_new,
+                        const float *p_sch, const float *gamma,
+                        float *p_sch_out, float *gamma_out,
+                        float *s_out, float *c_out, float *diff,
+                        float *partials, int32_t *status, float *pdhg_dual,
+                        float kappa, int32_t mode, const revs_pdhg_t *pdhg_host,
+                        void *stream);
+
 /* Wavefront reduction of the per-workgroup partials to the global ADMM residuals
  *   out[0] = |P_est[k+1] - P_sch[k+1]|_2           (primal residual, all homes)
  *   out[1] = kappa * |P_sch[k+1] - P_sch[k]|_2     (dual residual)

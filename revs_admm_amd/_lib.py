@@ -44,6 +44,8 @@ SIGNATURES = {
     "revs_agent_num_partials": (_i64, [_i64, _i32]),
     "revs_agent_step": (C.c_int, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                   _f32, _i32, C.POINTER(PDHG), _p]),
+    "revs_agent_step_out": (C.c_int, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                      _p, _p, _f32, _i32, C.POINTER(PDHG), _p]),
     "revs_residual_finalize": (C.c_int, [_p, _i64, _i64, _i32, _f32, _f32, _p, _p]),
     "revs_residence_solve": (C.c_int, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "revs_gemm_tn_f64": (C.c_int, [_i32, _i32, _i32, _p, _i32, _p, _i32, _p, _i32, _i32, _p]),

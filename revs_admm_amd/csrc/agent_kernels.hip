@@ -35,8 +35,10 @@ struct AgentArgs {
     const float *load;
     const float *pe_old;
     const float *pe_new;
-    float *ps;
-    float *gam;
+    float *ps;             // P_sch[k] in
+    float *gam;            // G[k] in
+    float *ps_out;         // P_sch[k+1] out (== ps for the in-place form)
+    float *gam_out;        // G[k+1] out
     float *s_out;
     float *c_out;
     float *diff;
@@ -342,8 +344,8 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
             const int64_t o = row + t;
             const float g = p[j] + L[j];                    // lpsolver.py:64-65
             const float chk = pen[j] - g;                   // lpsolver.py:280
-            a.ps[o] = g;
-            a.gam[o] = gm[j] + 0.5f * kappa * chk;          // lpsolver.py:282
+            a.ps_out[o] = g;
+            a.gam_out[o] = gm[j] + 0.5f * kappa * chk;      // lpsolver.py:282
             ss += chk * chk;
             const float dg = g - pso[j];
             dd += dg * dg;
@@ -536,21 +538,25 @@ extern "C" int64_t revs_agent_num_partials(int64_t n_homes, int32_t T) {
     return (n_homes + per - 1) / per;
 }
 
-extern "C" int revs_agent_step(int64_t n_homes, int32_t T, const float *cost,
-                               const revs_home_t *homes, const float *load,
-                               const float *p_est_old, const float *p_est_new, float *p_sch,
-                               float *gamma, float *s_out, float *c_out, float *diff,
-                               float *partials, int32_t *status, float *pdhg_dual, float kappa,
-                               int32_t mode, const revs_pdhg_t *pdhg_host, void *stream) {
+extern "C" int revs_agent_step_out(int64_t n_homes, int32_t T, const float *cost,
+                                   const revs_home_t *homes, const float *load,
+                                   const float *p_est_old, const float *p_est_new,
+                                   const float *p_sch, const float *gamma, float *p_sch_out,
+                                   float *gamma_out, float *s_out, float *c_out, float *diff,
+                                   float *partials, int32_t *status, float *pdhg_dual,
+                                   float kappa, int32_t mode, const revs_pdhg_t *pdhg_host,
+                                   void *stream) {
     REVS_REQUIRE(n_homes > 0, "revs_agent_step: n_homes=%lld", (long long)n_homes);
     REVS_REQUIRE(T > 0 && T <= REVS_MAX_T, "revs_agent_step: T=%d outside 1..%d", T, REVS_MAX_T);
-    REVS_REQUIRE(cost && homes && load && p_est_old && p_est_new && p_sch && gamma && diff && partials,
-                 "revs_agent_step: null pointer argument");
+    REVS_REQUIRE(cost && homes && load && p_est_old && p_est_new && p_sch && gamma && p_sch_out &&
+                 gamma_out && diff && partials, "revs_agent_step: null pointer argument");
     REVS_REQUIRE(mode >= 0 && mode <= 2, "revs_agent_step: mode=%d", mode);
     REVS_REQUIRE(kappa > 0.f, "revs_agent_step: kappa=%g must be positive", (double)kappa);
     AgentArgs a;
     a.n = n_homes; a.T = T; a.cost = cost; a.homes = homes; a.load = load;
-    a.pe_old = p_est_old; a.pe_new = p_est_new; a.ps = p_sch; a.gam = gamma;
+    a.pe_old = p_est_old; a.pe_new = p_est_new;
+    a.ps = const_cast<float *>(p_sch); a.gam = const_cast<float *>(gamma);
+    a.ps_out = p_sch_out; a.gam_out = gamma_out;
     a.s_out = s_out; a.c_out = c_out; a.diff = diff; a.partials = partials;
     a.status = status; a.y_state = pdhg_dual; a.kappa = kappa;
     if (pdhg_host) a.pd = *pdhg_host; else revs_pdhg_defaults(&a.pd);
@@ -566,6 +572,17 @@ extern "C" int revs_agent_step(int64_t n_homes, int32_t T, const float *cost,
 #undef CALL
     REVS_CHECK_LAUNCH("revs_agent_step");
     return REVS_OK;
+}
+
+extern "C" int revs_agent_step(int64_t n_homes, int32_t T, const float *cost,
+                               const revs_home_t *homes, const float *load,
+                               const float *p_est_old, const float *p_est_new, float *p_sch,
+                               float *gamma, float *s_out, float *c_out, float *diff,
+                               float *partials, int32_t *status, float *pdhg_dual, float kappa,
+                               int32_t mode, const revs_pdhg_t *pdhg_host, void *stream) {
+    return revs_agent_step_out(n_homes, T, cost, homes, load, p_est_old, p_est_new, p_sch, gamma,
+                               p_sch, gamma, s_out, c_out, diff, partials, status, pdhg_dual,
+                               kappa, mode, pdhg_host, stream);
 }
 
 extern "C" int revs_residual_finalize(const float *partials, int64_t num_partials,

@@ -89,6 +89,11 @@ class OperatorOptions:
     newton_delta: float = 1e-10  # relative diagonal shift of the model Hessian
     newton_pivots: int = 300     # block-pivoting limit per model problem
     newton_ls: int = 30          # Armijo halvings
+    # After an operator solve that needed no Newton iteration, the next ADMM iteration
+    # launches the home sweep right behind the operator's first evaluation, before the host
+    # has seen that evaluation's verdict (P_sch / G go to spare buffers): the GPU never
+    # waits for the host.  If rows turn out to need work, the sweep is simply run again.
+    speculate: bool = True
 
 
 def _dev_check(device):
@@ -263,6 +268,13 @@ class AdmmEngine:
         self.bpp_info = torch.zeros(T, dtype=torch.int32, device=self.dev)
         self.alpha_d = torch.zeros(T, **f64)
         self._y_support = False
+        self._spec_ok = False
+        self.spec_hist = [0, 0]                        # speculative sweeps kept / discarded
+        self.P_sch_alt = torch.zeros(n, T, **f32) if self.op.solver == "newton" else None
+        self.G_alt = torch.zeros(n, T, **f32) if self.op.solver == "newton" else None
+        cuda = self.dev.type == "cuda"
+        self.stats_host = [torch.zeros(T, 8, dtype=torch.float64, pin_memory=cuda) for _ in range(2)]
+        self.stats_ev = [torch.cuda.Event() if cuda else None for _ in range(2)]
         self.newton_hist: list[tuple] = []
         # R (float) for the voltage check
         self.R32 = up(Rn.astype(np.float32))
@@ -599,9 +611,10 @@ class AdmmEngine:
         return True
 
     # ------------------------------------------------- operator, dual Newton path
-    def _dual_evaluate(self, y, use_y: bool, k: int):
-        """p, N, D and the voltage rows for the multipliers y; candidate lists and stats
-        into buffer set k.  Also writes P_est_new = max(g0 - R^T y / kappa, 0)."""
+    def _dual_launch(self, y, use_y: bool, k: int):
+        """Enqueue one evaluation: p, N, D and the voltage rows for the multipliers y;
+        candidate lists and stats into buffer set k, stats on their way to pinned host
+        memory.  Also writes P_est_new = max(g0 - R^T y / kappa, 0).  Does not wait."""
         lib, M, T, st, ks = self.lib, self.M, self.T, self.stream, self.ksplit1
         if use_y:
             self._gemm1(self.R64, y, self.d_sl)                            # R^T y
@@ -617,17 +630,29 @@ class AdmmEngine:
                                       ptr(self.c_cnt[k]),
                                       ptr(self.c_val[k]), ptr(self.n_stats[k]), st),
               "revs_op_dual_select")
-        return self.n_stats[k].cpu().numpy()
+        self.stats_host[k].copy_(self.n_stats[k], non_blocking=True)
+        if self.stats_ev[k] is not None:
+            self.stats_ev[k].record()
 
-    def _operator_solve_newton(self):
+    def _dual_wait(self, k: int):
+        if self.stats_ev[k] is not None:
+            self.stats_ev[k].synchronize()
+        return self.stats_host[k].numpy().copy()
+
+    def _dual_evaluate(self, y, use_y: bool, k: int):
+        self._dual_launch(y, use_y, k)
+        return self._dual_wait(k)
+
+    def _operator_solve_newton(self, first=None):
         """Utility.solve through the dual (see csrc/newton_kernels.hip).  True when
-        P_est_new holds the answer to tolerance; False hands the iteration to ADMM."""
+        P_est_new holds the answer to tolerance; False hands the iteration to ADMM.
+        `first`: stats of an evaluation of the current multipliers already made (buffer 0)."""
         o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
         A = _lib.DUAL_AMAX
         scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
         ycur, ytrial = self.yd
         cur = 0
-        stt = self._dual_evaluate(ycur, self._y_support, cur)
+        stt = self._dual_evaluate(ycur, self._y_support, cur) if first is None else first
         evals, newton, pivots, ok_all = 1, 0, 0, False
         while True:
             if (stt[:, 2] > A).any():
@@ -673,6 +698,7 @@ class AdmmEngine:
             cur, stt = nxt, stn
         self.yd = [ycur, ytrial]
         self.newton_hist.append((newton, evals, pivots))
+        self._spec_ok = ok_all and newton == 0
         if not ok_all:
             ycur.zero_()
             self._y_support = False
@@ -762,16 +788,18 @@ class AdmmEngine:
         return converged
 
     # ----------------------------------------------------------------- homes
-    def agent_step(self, write_sc=True):
+    def agent_step(self, write_sc=True, to_alt=False):
         """All Home(...).solve() of one iteration + dual update + diff
-        (lpsolver.py:269-284) in one kernel launch."""
-        check(self.lib.revs_agent_step(
+        (lpsolver.py:269-284) in one kernel launch.  With `to_alt` P_sch[k+1] and G[k+1] go
+        to the spare buffers (speculative launch, see step)."""
+        ps_out, g_out = (self.P_sch_alt, self.G_alt) if to_alt else (self.P_sch, self.G)
+        check(self.lib.revs_agent_step_out(
             self.n, self.T, ptr(self.cost), ptr(self.homes), ptr(self.load), ptr(self.P_est),
-            ptr(self.P_est_new), ptr(self.P_sch), ptr(self.G),
+            ptr(self.P_est_new), ptr(self.P_sch), ptr(self.G), ptr(ps_out), ptr(g_out),
             ptr(self.S) if write_sc else None, ptr(self.Csoc) if write_sc else None,
             ptr(self.diff), ptr(self.partials), ptr(self.status), ptr(self.pdhg_dual),
             self.kappa, self.mode,
-            C.byref(self.pdhg), self.stream), "revs_agent_step")
+            C.byref(self.pdhg), self.stream), "revs_agent_step_out")
 
     def residuals(self, eps=1e-4):
         """Residuals of the iteration just finished, reduced on the device:
@@ -791,10 +819,45 @@ class AdmmEngine:
                     bool(mx.item() <= eps))
         return r[0], r[1], r[2], bool(r[3] > 0.5)
 
-    def step(self, write_sc=True):
-        """One iteration of the while-loop of lpsolver.py:254-287."""
-        self.operator_solve()
-        self.agent_step(write_sc)
+    def step(self, write_sc=True, events=None):
+        """One iteration of the while-loop of lpsolver.py:254-287.  `events`: three HIP
+        events recorded before the operator part, between it and the home sweep, and after
+        (bench.py's per-kernel timing)."""
+        rec = (lambda i: events[i].record()) if events else (lambda i: None)
+        o = self.op
+        rec(0)
+        if o.solver == "newton" and o.speculate and self._spec_ok:
+            # steady state: the multipliers of the last iteration are expected to stand
+            self._dual_launch(self.yd[0], self._y_support, 0)
+            rec(1)
+            self.agent_step(write_sc, to_alt=True)
+            rec(2)
+            stt = self._dual_wait(0)
+            scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
+            if stt[:, 0].max() / scale <= o.eps:
+                self.P_sch, self.P_sch_alt = self.P_sch_alt, self.P_sch
+                self.G, self.G_alt = self.G_alt, self.G
+                self.op_iters_hist.append(1)
+                self.op_path_hist.append("dual")
+                self.newton_hist.append((0, 1, 0))
+                self.op_converged = True
+                self.spec_hist[0] += 1
+            else:                          # rows need work: finish the solve, redo the sweep
+                self.spec_hist[1] += 1
+                if not self._operator_solve_newton(first=stt):
+                    self._fast_cold = True
+                    self.op_cold = True
+                    saved, o.solver = o.solver, "admm"
+                    try:
+                        self.operator_solve()
+                    finally:
+                        o.solver = saved
+                self.agent_step(write_sc)
+        else:
+            self.operator_solve()
+            rec(1)
+            self.agent_step(write_sc)
+            rec(2)
         self.P_est, self.P_est_new = self.P_est_new, self.P_est
         self.iteration += 1
 

@@ -30,6 +30,13 @@ class FakeKernels:
 
     def revs_agent_step(self, n, T, cost, homes, load, pe_old, pe_new, ps, gm, s_out, c_out, diff,
                         partials, status, pdhg_dual, kappa, mode, pdhg, stream):
+        return self.revs_agent_step_out(n, T, cost, homes, load, pe_old, pe_new, ps, gm, ps, gm,
+                                        s_out, c_out, diff, partials, status, pdhg_dual, kappa,
+                                        mode, pdhg, stream)
+
+    def revs_agent_step_out(self, n, T, cost, homes, load, pe_old, pe_new, ps, gm, ps_out, gm_out,
+                            s_out, c_out, diff, partials, status, pdhg_dual, kappa, mode, pdhg,
+                            stream):
         f = lambda p, sh=(n, T): view(p, sh, np.float32)
         rec = view(homes, (n * HOME_DTYPE.itemsize,), np.uint8).view(HOME_DTYPE)
         oh = ro.homes_from_records(f(load).astype(float), rec)
@@ -38,8 +45,8 @@ class FakeKernels:
         p, s, g, st = (ro.home_solve_binary if mode == 0 else ro.home_solve_relaxed)(*args)
         chk = f(pe_new).astype(float) - g
         dg = g - f(ps).astype(float)
-        f(gm)[:] = f(gm) + 0.5 * kappa * chk
-        f(ps)[:] = g
+        f(gm_out)[:] = f(gm) + 0.5 * kappa * chk
+        f(ps_out)[:] = g
         if s_out:
             f(s_out)[:] = p
         if c_out:

@@ -160,6 +160,30 @@ def test_dual_newton_on_fake_kernels(stress):
     assert np.abs(e.result()[1] - S_ref).max() < 1e-5 and np.abs(d - d_ref).max() < 1e-6
 
 
+def test_speculative_sweep_on_fake_kernels():
+    """step() launches the home sweep behind the operator's first evaluation when the last
+    solve needed no Newton iteration.  Kept or discarded, the trajectory is the one of the
+    non-speculative driver, bit for bit."""
+    from fake_kernels import FakeKernels
+    from helpers import f32
+    from revs_admm_amd.engine import AdmmEngine, OperatorOptions
+    from revs_admm_amd.synthetic import make_workload
+    w = make_workload(150, 12, n_nodes=20, seed=2, stress=1.02, binary_feasible=False)
+    w.load, w.cost = f32(w.load), f32(w.cost)
+    runs = []
+    for spec in (True, False):
+        e = AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, kappa=w.kappa, vset=w.vset,
+                       vlow=w.vlow, vhigh=w.vhigh, mode="relaxed_exact", device="cpu",
+                       _kernels=FakeKernels(), op=OperatorOptions(speculate=spec))
+        runs.append((e.run(12), e.result(), e))
+    (d1, r1, e1), (d0, r0, e0) = runs
+    assert e1.spec_hist[0] > 0 and e1.spec_hist[1] > 0 and e0.spec_hist == [0, 0]
+    np.testing.assert_array_equal(d1, d0)
+    for a, b in zip(r1, r0):
+        np.testing.assert_array_equal(a, b)
+    assert [h[0] for h in e1.newton_hist] == [h[0] for h in e0.newton_hist]
+
+
 @pytest.mark.parametrize("stress,paths", [(0.9, {"node"}), (2.0, {"node", "home"})])
 def test_operator_paths_on_fake_kernels(stress, paths):
     """Driver logic of the two ADMM operator paths (OperatorOptions.solver = "admm"): the node-space fast path is kept while no
