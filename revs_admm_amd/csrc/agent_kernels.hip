@@ -49,6 +49,25 @@ struct AgentArgs {
     revs_pdhg_t pd;
 };
 
+// SPL consecutive floats of one lane as ONE global_load/store_dwordxSPL: the 64 lanes of a
+// wavefront then cover one contiguous 64*SPL*4-byte span per instruction instead of SPL
+// interleaved stride-SPL passes over it (global memory only needs dword alignment).
+template <int SPL>
+struct alignas(4) PackF { float v[SPL]; };
+template <int SPL>
+__device__ __forceinline__ void ld_pack(const float *p, float (&o)[SPL]) {
+    const PackF<SPL> t = *reinterpret_cast<const PackF<SPL> *>(p);
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) o[j] = t.v[j];
+}
+template <int SPL>
+__device__ __forceinline__ void st_pack(float *p, const float (&v)[SPL]) {
+    PackF<SPL> t;
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) t.v[j] = v[j];
+    *reinterpret_cast<PackF<SPL> *>(p) = t;
+}
+
 constexpr int kBlock = 256;
 constexpr float kSocTarget = 0.9f;   // lpsolver.py:109
 constexpr float kSocMax = 1.0f;      // lpsolver.py:102-103
@@ -95,27 +114,48 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
     const bool ev = h.ev != 0;
     const int64_t row = agent * (int64_t)T;
 
-    float L[SPL], pe[SPL], pso[SPL], gm[SPL], pen[SPL], q[SPL], p[SPL];
+    float L[SPL], pe[SPL], pso[SPL], gm[SPL], pen[SPL], q[SPL], p[SPL], cst[SPL];
     bool valid[SPL], win[SPL];
+    // a lane whose SPL slots all exist moves them as one dwordxSPL per profile
+    const bool full = live && (t0 + SPL <= T);
+    if (full) {
+        ld_pack<SPL>(a.load + row + t0, L);
+        ld_pack<SPL>(a.pe_old + row + t0, pe);
+        ld_pack<SPL>(a.pe_new + row + t0, pen);
+        ld_pack<SPL>(a.ps + row + t0, pso);
+        ld_pack<SPL>(a.gam + row + t0, gm);
+        ld_pack<SPL>(a.cost + t0, cst);
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) valid[j] = true;
+    } else {
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+            const int t = t0 + j;
+            valid[j] = live && (t < T);
+            // out-of-range lanes read element 0 (always mapped) and discard it: straight-line
+            // loads instead of one exec-masked branch per element
+            const int64_t o = valid[j] ? row + t : 0;
+            const float vL = a.load[o], vpe = a.pe_old[o], vpn = a.pe_new[o], vps = a.ps[o],
+                        vg = a.gam[o], vc = a.cost[(t < T) ? t : 0];
+            L[j]   = valid[j] ? vL : 0.f;
+            pe[j]  = valid[j] ? vpe : 0.f;
+            pen[j] = valid[j] ? vpn : 0.f;
+            pso[j] = valid[j] ? vps : 0.f;
+            gm[j]  = valid[j] ? vg : 0.f;
+            cst[j] = (t < T) ? vc : 0.f;
+        }
+    }
+    // No FMA contraction in the linear term and the keys: every slot must go through the
+    // same rounding steps, so that equal inputs give equal keys ("ties to the earlier slot"
+    // is the reference-visible rule) whatever the unrolled code looks like.
 #pragma unroll
     for (int j = 0; j < SPL; ++j) {
+#pragma clang fp contract(off)
         const int t = t0 + j;
-        valid[j] = live && (t < T);
-        // out-of-range lanes read element 0 (always mapped) and discard it: straight-line
-        // loads instead of one exec-masked branch per element
-        const int64_t o = valid[j] ? row + t : 0;
-        const float vL = a.load[o], vpe = a.pe_old[o], vpn = a.pe_new[o], vps = a.ps[o],
-                    vg = a.gam[o], vc = a.cost[(t < T) ? t : 0];
-        L[j]   = valid[j] ? vL : 0.f;
-        pe[j]  = valid[j] ? vpe : 0.f;
-        pen[j] = valid[j] ? vpn : 0.f;
-        pso[j] = valid[j] ? vps : 0.f;
-        gm[j]  = valid[j] ? vg : 0.f;
-        const float c = (t < T) ? vc : 0.f;
         // lpsolver.py:118-119  a_t = gamma_t + (kappa/2)(p_util_t + p_res_t)
         const float at = gm[j] + 0.5f * kappa * (pe[j] + pso[j]);
         // objective in p:  (kappa/2) p^2 + q p,  q = kappa*LOAD + c - a
-        q[j] = kappa * L[j] + c - at;
+        q[j] = kappa * L[j] + cst[j] - at;
         win[j] = ev && valid[j] && (t >= h.start) && (t < h.end);
         p[j] = 0.f;
     }
@@ -132,6 +172,7 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
         int nwin = 0;
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
+#pragma clang fp contract(off)
             key[j] = win[j] ? h.rating * (0.5f * kappa * h.rating + q[j]) : INFINITY;
             nwin += win[j] ? 1 : 0;
         }
@@ -337,21 +378,34 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
     const float poff = group_excl_prefix<LPA>(pacc, lig, mk);
     const float invcap = ev ? 1.0f / h.capacity : 0.f;
     const int64_t crow = agent * (int64_t)(T + 1);
+    float gn[SPL], gmn[SPL], socv[SPL];
 #pragma unroll
     for (int j = 0; j < SPL; ++j) {
-        const int t = t0 + j;
-        if (valid[j]) {
-            const int64_t o = row + t;
-            const float g = p[j] + L[j];                    // lpsolver.py:64-65
-            const float chk = pen[j] - g;                   // lpsolver.py:280
-            a.ps_out[o] = g;
-            a.gam_out[o] = gm[j] + 0.5f * kappa * chk;      // lpsolver.py:282
-            ss += chk * chk;
-            const float dg = g - pso[j];
-            dd += dg * dg;
-            if (a.s_out) a.s_out[o] = p[j];
-            if (a.c_out)
-                a.c_out[crow + t + 1] = ev ? h.initial + (pfx[j] + poff) * invcap : 0.f;
+        const float g = p[j] + L[j];                        // lpsolver.py:64-65
+        const float chk = pen[j] - g;                       // lpsolver.py:280
+        gn[j] = g;
+        gmn[j] = gm[j] + 0.5f * kappa * chk;                // lpsolver.py:282
+        socv[j] = ev ? h.initial + (pfx[j] + poff) * invcap : 0.f;
+        const float dg = g - pso[j];
+        ss += valid[j] ? chk * chk : 0.f;
+        dd += valid[j] ? dg * dg : 0.f;
+    }
+    if (full) {
+        st_pack<SPL>(a.ps_out + row + t0, gn);
+        st_pack<SPL>(a.gam_out + row + t0, gmn);
+        if (a.s_out) st_pack<SPL>(a.s_out + row + t0, p);
+        if (a.c_out) st_pack<SPL>(a.c_out + crow + t0 + 1, socv);
+    } else {
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+            const int t = t0 + j;
+            if (valid[j]) {
+                const int64_t o = row + t;
+                a.ps_out[o] = gn[j];
+                a.gam_out[o] = gmn[j];
+                if (a.s_out) a.s_out[o] = p[j];
+                if (a.c_out) a.c_out[crow + t + 1] = socv[j];
+            }
         }
     }
     if (live && lig == 0 && a.c_out) a.c_out[crow] = ev ? h.initial : 0.f;
@@ -433,6 +487,7 @@ __global__ __launch_bounds__(kBlock) void residence_kernel(
     bool win[SPL];
 #pragma unroll
     for (int j = 0; j < SPL; ++j) {
+#pragma clang fp contract(off)
         const int t = t0 + j;
         win[j] = ev && live && t < T && t >= h.start && t < h.end;
         const float c = (t < T) ? tariff[t] : 0.f;
