@@ -70,6 +70,11 @@ typedef struct {
 const char *revs_version(void);
 const char *revs_last_error(void);
 
+/* Device-side address of PINNED host memory (hipHostMalloc, torch pin_memory), so that a
+ * kernel can write a few result words where the host reads them (revs_op_dual_select's
+ * stats).  Fails with REVS_EINVAL when host_ptr is not mapped pinned memory. */
+int revs_host_device_ptr(void *host_ptr, void **dev_ptr_out);
+
 /* Defaults used when `pdhg` is NULL: 4000, 4, 1e-6, automatic scales, presolved rows */
 void revs_pdhg_defaults(revs_pdhg_t *out_host);
 
@@ -384,6 +389,18 @@ int revs_op_dual_model(int32_t m, int32_t T, const double *R, const double *n_fr
                        double kappa, double delta, int32_t max_pivots, int32_t nks,
                        double *k_slabs, double *k_full, double *yhat, int32_t *info,
                        void *stream);
+/* One evaluation as a single host call: phase bit 0 = [R^T y into d_slabs when use_y,]
+ * revs_op_dual_eval; phase bit 1 = R p into v_slabs (Rt = R^T, row-major), revs_op_dual_select,
+ * and an asynchronous copy of stats to stats_host (pinned HOST memory, double[T][8], or NULL).
+ * A driver that shards residences runs phase 1, all-reduces pnq, then phase 2. */
+int revs_op_dual_evaluate(int32_t phase, int32_t m, int32_t T, const int64_t *node_ptr,
+                          const float *p_est, const float *p_sch, const float *gamma,
+                          const double *R, const double *Rt, const double *y, int32_t use_y,
+                          double kappa, double vlo, double vhi, int32_t kadd, int32_t ksplit,
+                          double *d_slabs, double *v_slabs, double *pnq, float *p_est_new,
+                          double *vfull, double *viol, double *partial, int64_t *cand_idx,
+                          int32_t *cand_cnt, double *cand_val, double *stats,
+                          double *stats_host, void *stream);
 int revs_op_dual_step(int32_t T, const int64_t *cand_idx, const int32_t *cand_cnt,
                       const double *cand_val, const double *yhat, const double *alpha,
                       double *y_trial, double *lin_out, void *stream);

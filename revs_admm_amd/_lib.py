@@ -40,6 +40,7 @@ _i32, _i64, _f32, _f64 = C.c_int32, C.c_int64, C.c_float, C.c_double
 SIGNATURES = {
     "revs_version": (C.c_char_p, []),
     "revs_last_error": (C.c_char_p, []),
+    "revs_host_device_ptr": (C.c_int, [_p, C.POINTER(C.c_void_p)]),
     "revs_pdhg_defaults": (None, [C.POINTER(PDHG)]),
     "revs_agent_num_partials": (_i64, [_i64, _i32]),
     "revs_agent_step": (C.c_int, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
@@ -83,6 +84,9 @@ SIGNATURES = {
                                       _p, _p, _p, _p, _p]),
     "revs_op_dual_model": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p, _f64, _f64, _i32, _i32, _p,
                                      _p, _p, _p, _p]),
+    "revs_op_dual_evaluate": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _f64,
+                                        _f64, _f64, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                        _p, _p, _p, _p]),
     "revs_op_dual_step": (C.c_int, [_i32, _p, _p, _p, _p, _p, _p, _p, _p]),
 }
 DUAL_AMAX = 64           # REVS_DUAL_AMAX

@@ -538,3 +538,48 @@ extern "C" int revs_op_dual_step(int32_t T, const int64_t *cand_idx, const int32
     REVS_CHECK_LAUNCH("revs_op_dual_step");
     return REVS_OK;
 }
+
+// One evaluation of the dual function as a single host call (the driver's steady state is
+// host-bound otherwise: five launches of 3-12 us each).  phase bit 0: R^T y (when use_y)
+// and the home pass; phase bit 1: R p, row bookkeeping, candidate lists and the copy of
+// stats to pinned host memory.  A driver that shards residences runs phase 1, all-reduces
+// pnq, then runs phase 2.
+extern "C" int revs_op_dual_evaluate(int32_t phase, int32_t m, int32_t T, const int64_t *node_ptr,
+                                     const float *p_est, const float *p_sch, const float *gamma,
+                                     const double *R, const double *Rt, const double *y,
+                                     int32_t use_y, double kappa, double vlo, double vhi,
+                                     int32_t kadd, int32_t ksplit, double *d_slabs,
+                                     double *v_slabs, double *pnq, float *p_est_new,
+                                     double *vfull, double *viol, double *partial,
+                                     int64_t *cand_idx, int32_t *cand_cnt, double *cand_val,
+                                     double *stats, double *stats_host, void *stream) {
+    REVS_REQUIRE(phase >= 1 && phase <= 3 && y && pnq, "revs_op_dual_evaluate: bad argument");
+    int rc;
+    if (phase & 1) {
+        if (use_y) {
+            REVS_REQUIRE(R && d_slabs, "revs_op_dual_evaluate: R / d_slabs missing");
+            rc = revs_gemm_tn_f64_split(m, T, m, R, y, d_slabs, ksplit, stream);
+            if (rc != REVS_OK) return rc;
+        }
+        rc = revs_op_dual_eval(m, T, node_ptr, p_est, p_sch, gamma, ksplit,
+                               use_y ? d_slabs : nullptr, kappa, pnq, p_est_new, stream);
+        if (rc != REVS_OK) return rc;
+    }
+    if (phase & 2) {
+        REVS_REQUIRE(Rt && v_slabs, "revs_op_dual_evaluate: Rt / v_slabs missing");
+        rc = revs_gemm_tn_f64_split(m, T, m, Rt, pnq, v_slabs, ksplit, stream);
+        if (rc != REVS_OK) return rc;
+        rc = revs_op_dual_select(m, T, ksplit, v_slabs, pnq, y, vlo, vhi, kadd, vfull, viol,
+                                 partial, cand_idx, cand_cnt, cand_val, stats, stream);
+        if (rc != REVS_OK) return rc;
+        if (stats_host) {
+            const hipError_t e = hipMemcpyAsync(stats_host, stats, sizeof(double) * 8 * T,
+                                                hipMemcpyDeviceToHost, S_(stream));
+            if (e != hipSuccess) {
+                revs::set_error("revs_op_dual_evaluate: %s", hipGetErrorString(e));
+                return REVS_ELAUNCH;
+            }
+        }
+    }
+    return REVS_OK;
+}

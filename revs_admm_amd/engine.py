@@ -263,7 +263,6 @@ class AdmmEngine:
         self.c_idx = [torch.zeros(T, A, dtype=torch.int64, device=self.dev) for _ in range(2)]
         self.c_cnt = [torch.zeros(T, dtype=torch.int32, device=self.dev) for _ in range(2)]
         self.c_val = [torch.zeros(T, 3, A, **f64) for _ in range(2)]
-        self.n_stats = [torch.zeros(T, 8, **f64) for _ in range(2)]
         self.yhat = torch.zeros(T, A, **f64)
         self.bpp_info = torch.zeros(T, dtype=torch.int32, device=self.dev)
         self.alpha_d = torch.zeros(T, **f64)
@@ -273,7 +272,17 @@ class AdmmEngine:
         self.P_sch_alt = torch.zeros(n, T, **f32) if self.op.solver == "newton" else None
         self.G_alt = torch.zeros(n, T, **f32) if self.op.solver == "newton" else None
         cuda = self.dev.type == "cuda"
+        # per-slot stats are written by the select kernel straight into pinned host memory
         self.stats_host = [torch.zeros(T, 8, dtype=torch.float64, pin_memory=cuda) for _ in range(2)]
+        self.stats_dev = []
+        for t in self.stats_host:
+            if cuda:
+                dp = C.c_void_p()
+                check(self.lib.revs_host_device_ptr(t.data_ptr(), C.byref(dp)),
+                      "revs_host_device_ptr")
+                self.stats_dev.append(int(dp.value))
+            else:
+                self.stats_dev.append(t.data_ptr())
         self.stats_ev = [torch.cuda.Event() if cuda else None for _ in range(2)]
         self.newton_hist: list[tuple] = []
         # R (float) for the voltage check
@@ -611,35 +620,29 @@ class AdmmEngine:
         return True
 
     # ------------------------------------------------- operator, dual Newton path
-    def _dual_kernels_a(self, y, use_y: bool):
-        lib, M, T, st, ks = self.lib, self.M, self.T, self.stream, self.ksplit1
-        if use_y:
-            self._gemm1(self.R64, y, self.d_sl)                            # R^T y
-        check(lib.revs_op_dual_eval(M, T, ptr(self.node_ptr), ptr(self.P_est), ptr(self.P_sch),
-                                    ptr(self.G), ks, ptr(self.d_sl) if use_y else None,
-                                    self.kappa, ptr(self.pnq), ptr(self.P_est_new), st),
-              "revs_op_dual_eval")
-
-    def _dual_kernels_b(self, y, k: int):
-        lib, M, T, st, ks = self.lib, self.M, self.T, self.stream, self.ksplit1
-        self._gemm1(self.R64T, self.pnq[0], self.v_sl)                     # R p
-        check(lib.revs_op_dual_select(M, T, ks, ptr(self.v_sl), ptr(self.pnq), ptr(y), self.vlo,
-                                      self.vhi, self.op.newton_kadd, ptr(self.vfull),
-                                      ptr(self.violw), ptr(self.d_part), ptr(self.c_idx[k]),
-                                      ptr(self.c_cnt[k]),
-                                      ptr(self.c_val[k]), ptr(self.n_stats[k]), st),
-              "revs_op_dual_select")
-        self.stats_host[k].copy_(self.n_stats[k], non_blocking=True)
+    def _dual_phase(self, phase: int, y, use_y: bool, k: int):
+        lib, M, T = self.lib, self.M, self.T
+        check(lib.revs_op_dual_evaluate(
+            phase, M, T, ptr(self.node_ptr), ptr(self.P_est), ptr(self.P_sch), ptr(self.G),
+            ptr(self.R64), ptr(self.R64T), ptr(y), int(use_y), self.kappa, self.vlo, self.vhi,
+            self.op.newton_kadd, self.ksplit1, ptr(self.d_sl), ptr(self.v_sl), ptr(self.pnq),
+            ptr(self.P_est_new), ptr(self.vfull), ptr(self.violw), ptr(self.d_part),
+            ptr(self.c_idx[k]), ptr(self.c_cnt[k]), ptr(self.c_val[k]), self.stats_dev[k],
+            None, self.stream), "revs_op_dual_evaluate")
 
     def _dual_launch(self, y, use_y: bool, k: int):
         """Enqueue one evaluation: p, N, D and the voltage rows for the multipliers y;
         candidate lists and stats into buffer set k, stats on their way to pinned host
         memory.  Also writes P_est_new = max(g0 - R^T y / kappa, 0).  Does not wait.
-        (Replaying these five launches as a hipGraph was measured and is slower than
-        launching them: 44 vs 37 us per evaluation.)"""
-        self._dual_kernels_a(y, use_y)
-        self._allreduce(self.pnq)                # the only exchange of an evaluation
-        self._dual_kernels_b(y, k)
+        One host call; two around the all-reduce of pnq when residences are sharded.
+        (Replaying the launches as a hipGraph was measured and is slower than issuing
+        them: 44 vs 37 us per evaluation.)"""
+        if self.group is None:
+            self._dual_phase(3, y, use_y, k)
+        else:
+            self._dual_phase(1, y, use_y, k)
+            self._allreduce(self.pnq)            # the only exchange of an evaluation
+            self._dual_phase(2, y, use_y, k)
         if self.stats_ev[k] is not None:
             self.stats_ev[k].record()
 
@@ -691,7 +694,7 @@ class AdmmEngine:
                 check(lib.revs_op_dual_step(T, ptr(self.c_idx[cur]), ptr(self.c_cnt[cur]),
                                             ptr(self.c_val[cur]), ptr(self.yhat),
                                             ptr(self.alpha_d), ptr(ytrial),
-                                            self.n_stats[nxt].data_ptr() + 32, st),
+                                            self.stats_dev[nxt] + 32, st),
                       "revs_op_dual_step")
                 stn = self._dual_evaluate(ytrial, True, nxt)
                 evals += 1
