@@ -189,26 +189,31 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
     } else if constexpr (MODE == REVS_MODE_RELAXED_PDHG) {
         // PDHG on  min x^2/2 + b x,  0 <= x <= w,  lo <= K x <= hi,  x = p/rating,
         // K = delta * inclusive prefix sum (rows j: s_{j+1} - initial).
+        // Per-home scalars are computed redundantly by the LPA lanes of the group: use the
+        // 1-ulp hardware reciprocal / square root instead of IEEE division (10 instructions
+        // each) -- step sizes need no exactness, and b, x0 only to the PDHG tolerance.
         const float rate = ev ? h.rating : 1.f;
-        const float delta = ev ? h.rating / h.capacity : 1.f;
+        const float inv_rate = __builtin_amdgcn_rcpf(rate);
+        const float delta = ev ? h.rating * __builtin_amdgcn_rcpf(h.capacity) : 1.f;
         const int ws = max(h.start, 0), we = min(h.end, T);
         const float Tw = (float)max(we - ws, 1);
-        const float nK = delta * 0.63661977236758134f * (Tw + 1.0f);
-        const float tau = (a.pd.tau_scale > 0.f ? a.pd.tau_scale : 0.25f) / nK;
-        const float sig = (a.pd.sigma_scale > 0.f ? a.pd.sigma_scale : 4.0f) / nK;
-        const float inv1pt = 1.0f / (1.0f + tau);
+        const float inv_nK = __builtin_amdgcn_rcpf(delta * 0.63661977236758134f * (Tw + 1.0f));
+        const float tau = (a.pd.tau_scale > 0.f ? a.pd.tau_scale : 0.25f) * inv_nK;
+        const float sig = (a.pd.sigma_scale > 0.f ? a.pd.sigma_scale : 4.0f) * inv_nK;
+        const float inv1pt = __builtin_amdgcn_rcpf(1.0f + tau);
         const float sd = sig * delta;
         const float hi = kSocMax - h.initial;
         const float lo_last = fmaxf(kSocTarget, h.initial) - h.initial;
+        const float inv_kr = __builtin_amdgcn_rcpf(kappa * rate);
         float b[SPL], w[SPL], x[SPL], y[SPL], lo[SPL];
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
-            b[j] = q[j] / (kappa * rate);
+            b[j] = q[j] * inv_kr;
             w[j] = win[j] ? 1.f : 0.f;
             lo[j] = (t0 + j == T - 1) ? lo_last : 0.f;
             // warm start: primal from the previous schedule (P_sch[k] - LOAD), dual from
             // the previous iteration's multipliers when the caller keeps them
-            x[j] = a.y_state ? fminf(fmaxf((pso[j] - L[j]) / rate, 0.f), w[j]) : 0.f;
+            x[j] = a.y_state ? fminf(fmaxf((pso[j] - L[j]) * inv_rate, 0.f), w[j]) : 0.f;
             y[j] = (FULL_ROWS && a.y_state && valid[j] && ev) ? a.y_state[row + t0 + j] : 0.f;
         }
         // the window cannot deliver the energy to 90 % SOC: "No solution found"
@@ -225,10 +230,10 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
             // init <= s_t <= 1, s_T >= 0.9 only the terminal one can bind.  K is then the
             // single row delta * 1^T (||K|| = delta sqrt(T_w)), its dual one scalar per home,
             // and K x a group sum -- no scans.
-            const float nK1 = delta * sqrtf(Tw);
-            const float tau1 = (a.pd.tau_scale > 0.f ? a.pd.tau_scale : 0.5f) / nK1;
-            const float sig1 = (a.pd.sigma_scale > 0.f ? a.pd.sigma_scale : 2.0f) / nK1;
-            const float inv1 = 1.0f / (1.0f + tau1);
+            const float inv_nK1 = __builtin_amdgcn_rcpf(delta * __builtin_amdgcn_sqrtf(Tw));
+            const float tau1 = (a.pd.tau_scale > 0.f ? a.pd.tau_scale : 0.5f) * inv_nK1;
+            const float sig1 = (a.pd.sigma_scale > 0.f ? a.pd.sigma_scale : 2.0f) * inv_nK1;
+            const float inv1 = __builtin_amdgcn_rcpf(1.0f + tau1);
             const float sd1 = sig1 * delta;
             float yy = (a.y_state && live && ev) ? a.y_state[agent] : 0.f;
             auto iterate1 = [&](auto res_tag) -> float {
