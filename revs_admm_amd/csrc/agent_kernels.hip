@@ -104,14 +104,6 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
     const int t0 = lig * SPL;
     const float kappa = a.kappa;
 
-    revs_home_t h;
-    if (live) {
-        h = a.homes[agent];
-    } else {
-        h.ev = 0; h.start = 0; h.end = 0; h.nmin = 0; h.nmax = 0;
-        h.rating = 0.f; h.capacity = 1.f; h.initial = 0.f;
-    }
-    const bool ev = h.ev != 0;
     const int64_t row = agent * (int64_t)T;
 
     float L[SPL], pe[SPL], pso[SPL], gm[SPL], pen[SPL], q[SPL], p[SPL], cst[SPL];
@@ -145,6 +137,21 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
             cst[j] = (t < T) ? vc : 0.f;
         }
     }
+    // Every global load of the kernel is issued before the first use of any of them (one
+    // exposed memory latency per wavefront, not three): profiles above, then the home
+    // record and the carried PDHG multiplier.
+    revs_home_t h;
+    float yy_in = 0.f;
+    if (live) {
+        h = a.homes[agent];
+        if constexpr (MODE == REVS_MODE_RELAXED_PDHG && !FULL_ROWS)
+            if (a.y_state) yy_in = a.y_state[agent];
+    } else {
+        h.ev = 0; h.start = 0; h.end = 0; h.nmin = 0; h.nmax = 0;
+        h.rating = 0.f; h.capacity = 1.f; h.initial = 0.f;
+    }
+    const bool ev = h.ev != 0;
+
     // No FMA contraction in the linear term and the keys: every slot must go through the
     // same rounding steps, so that equal inputs give equal keys ("ties to the earlier slot"
     // is the reference-visible rule) whatever the unrolled code looks like.
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
             const float sig1 = (a.pd.sigma_scale > 0.f ? a.pd.sigma_scale : 2.0f) * inv_nK1;
             const float inv1 = __builtin_amdgcn_rcpf(1.0f + tau1);
             const float sd1 = sig1 * delta;
-            float yy = (a.y_state && live && ev) ? a.y_state[agent] : 0.f;
+            float yy = ev ? yy_in : 0.f;
             auto iterate1 = [&](auto res_tag) -> float {
                 constexpr bool RES = decltype(res_tag)::value;
                 const float kty = sd1 * yy;
