@@ -630,21 +630,34 @@ class AdmmEngine:
             ptr(self.c_idx[k]), ptr(self.c_cnt[k]), ptr(self.c_val[k]), self.stats_dev[k],
             None, self.stream), "revs_op_dual_evaluate")
 
-    def _dual_launch(self, y, use_y: bool, k: int):
+    def _dual_launch(self, y, use_y: bool, k: int, full: bool = True):
         """Enqueue one evaluation: p, N, D and the voltage rows for the multipliers y;
         candidate lists and stats into buffer set k, stats on their way to pinned host
         memory.  Also writes P_est_new = max(g0 - R^T y / kappa, 0).  Does not wait.
-        One host call; two around the all-reduce of pnq when residences are sharded.
+        One host call; two around the all-reduce of pnq when residences are sharded.  With
+        full=False only p is exchanged (enough to judge the voltage rows: the steady-state
+        case); N and the dual value follow through _dual_complete if the solve goes on.
         (Replaying the launches as a hipGraph was measured and is slower than issuing
         them: 44 vs 37 us per evaluation.)"""
         if self.group is None:
             self._dual_phase(3, y, use_y, k)
         else:
             self._dual_phase(1, y, use_y, k)
-            self._allreduce(self.pnq)            # the only exchange of an evaluation
+            self._allreduce(self.pnq if full else self.pnq[0])   # the only exchange
             self._dual_phase(2, y, use_y, k)
         if self.stats_ev[k] is not None:
             self.stats_ev[k].record()
+
+    def _dual_complete(self, y, use_y: bool, k: int):
+        """After a full=False evaluation that did not settle the solve: exchange N and the
+        dual value too and redo the row bookkeeping (the stats' D_t needs the global sum)."""
+        if self.group is None:
+            return self._dual_wait(k)
+        self._allreduce(self.pnq[1:])
+        self._dual_phase(2, y, use_y, k)
+        if self.stats_ev[k] is not None:
+            self.stats_ev[k].record()
+        return self._dual_wait(k)
 
     def _dual_wait(self, k: int):
         if self.stats_ev[k] is not None:
@@ -840,7 +853,7 @@ class AdmmEngine:
         rec(0)
         if o.solver == "newton" and o.speculate and self._spec_ok:
             # steady state: the multipliers of the last iteration are expected to stand
-            self._dual_launch(self.yd[0], self._y_support, 0)
+            self._dual_launch(self.yd[0], self._y_support, 0, full=False)
             rec(1)
             self.agent_step(write_sc, to_alt=True)
             rec(2)
@@ -856,6 +869,7 @@ class AdmmEngine:
                 self.spec_hist[0] += 1
             else:                          # rows need work: finish the solve, redo the sweep
                 self.spec_hist[1] += 1
+                stt = self._dual_complete(self.yd[0], self._y_support, 0)
                 if not self._operator_solve_newton(first=stt):
                     self._fast_cold = True
                     self.op_cold = True

@@ -10,7 +10,7 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _worker(rank, world, port, mode, solver, out):
+def _worker(rank, world, port, mode, solver, stress, iters, out):
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     import torch
@@ -21,7 +21,7 @@ def _worker(rank, world, port, mode, solver, out):
     from revs_admm_amd.synthetic import make_workload
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    w = make_workload(240, 12, n_nodes=24, seed=6, stress=1.3, binary_feasible=(mode == "binary"))
+    w = make_workload(240, 12, n_nodes=24, seed=6, stress=stress, binary_feasible=(mode == "binary"))
     w.load, w.cost = f32(w.load), f32(w.cost)
     lo, hi = w.shard(rank, world)
     e = AdmmEngine(w.cost, w.homes[lo:hi], w.load[lo:hi], w.node_of[lo:hi], w.Rn, kappa=w.kappa,
@@ -30,19 +30,23 @@ def _worker(rank, world, port, mode, solver, out):
                    op=OperatorOptions(solver=solver))
     # global node counts came from the all-reduce in the constructor
     assert (e.node_counts == np.bincount(w.node_of, minlength=w.M)).all()
-    d = e.run(3)
+    d = e.run(iters)
     P, S, C = e.result()
     rp, rd, dmax, conv = e.residuals(1e-4)
     v = e.voltage().numpy().copy()
     np.savez(out.format(rank=rank), d=d, S=S, P=P, lo=lo, hi=hi, res=[rp, rd, dmax], v=v,
-             iters=e.op_iters_hist)
+             iters=e.op_iters_hist, spec=e.spec_hist)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("solver", ["newton", "admm"])
-@pytest.mark.parametrize("mode", ["relaxed_exact", "binary"])
-def test_two_ranks_equal_one_rank(tmp_path, mode, solver):
+@pytest.mark.parametrize("mode,solver,stress,iters", [
+    ("relaxed_exact", "newton", 1.3, 3), ("binary", "newton", 1.3, 3),
+    ("relaxed_exact", "admm", 1.3, 3), ("binary", "admm", 1.3, 3),
+    # long enough for the steady state: speculative home sweeps kept AND discarded, with only
+    # p exchanged in the speculative evaluation
+    ("relaxed_exact", "newton", 1.02, 12)])
+def test_two_ranks_equal_one_rank(tmp_path, mode, solver, stress, iters):
     import torch.multiprocessing as mp
     sys.path.insert(0, HERE)
     from fake_kernels import FakeKernels
@@ -51,13 +55,13 @@ def test_two_ranks_equal_one_rank(tmp_path, mode, solver):
     from revs_admm_amd.synthetic import make_workload
     port = 29500 + (os.getpid() % 2000)
     out = str(tmp_path / "r{rank}.npz")
-    mp.spawn(_worker, args=(2, port, mode, solver, out), nprocs=2, join=True)
-    w = make_workload(240, 12, n_nodes=24, seed=6, stress=1.3, binary_feasible=(mode == "binary"))
+    mp.spawn(_worker, args=(2, port, mode, solver, stress, iters, out), nprocs=2, join=True)
+    w = make_workload(240, 12, n_nodes=24, seed=6, stress=stress, binary_feasible=(mode == "binary"))
     w.load, w.cost = f32(w.load), f32(w.cost)
     e = AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, kappa=w.kappa, vset=w.vset,
                    vlow=w.vlow, vhigh=w.vhigh, mode=mode, device="cpu", _kernels=FakeKernels(),
                    op=OperatorOptions(solver=solver))
-    d1 = e.run(3)
+    d1 = e.run(iters)
     P1, S1, C1 = e.result()
     rp, rd, dmax, _ = e.residuals(1e-4)
     r = [np.load(out.format(rank=k)) for k in range(2)]
@@ -67,6 +71,9 @@ def test_two_ranks_equal_one_rank(tmp_path, mode, solver):
     # same algorithm, same data; only the order of the floating-point node sums differs
     assert np.abs(d2 - d1).max() < 1e-5 and np.abs(S2 - S1).max() < 1e-4
     assert list(r[0]["iters"]) == list(r[1]["iters"])          # ranks stop together
+    assert list(r[0]["spec"]) == list(r[1]["spec"]) == list(e.spec_hist)
+    if iters > 3:
+        assert e.spec_hist[0] > 0 and e.spec_hist[1] > 0
     np.testing.assert_allclose(r[0]["res"], [rp, rd, dmax], rtol=1e-4)
     np.testing.assert_allclose(r[0]["res"], r[1]["res"], rtol=0, atol=0)
     # voltage profile R.(aggregate load): identical on both ranks after the all-reduce
