@@ -11,11 +11,12 @@ QP (batched PDHG kernel), the dual update and the residual reduction.  Weak
 scaling: every GPU owns `--homes` residences (default 100 000 x T=24, the size
 BASELINE.json's metric is quoted on).  The timed steps start `--spinup` (30) iterations
 into the ADMM run: the first ~10 iterations are a transient in which voltage rows bind
-hard and residences are clamped (operator QP: up to thousands of inner iterations);
-afterwards R.(aggregate load) respects every row and the operator side is its voltage
-check.  The transient's cost is reported beside the headline.  The feeder's 2048 constraint nodes are
-replicated and the only collective is the all-reduce of the node aggregate (once per
-ADMM iteration on the operator's node-space fast path).
+hard and residences are clamped (operator QP: a few Newton iterations on its dual);
+afterwards R.(aggregate load) respects every row and the operator side is one evaluation
+of its dual -- home pass, one f64 product, row check.  The transient's cost is reported
+beside the headline.  The feeder's 2048 constraint nodes are replicated and the only
+collective is the all-reduce of the node aggregate (once per evaluation: once per ADMM
+iteration in the steady state).
 
 Prints ONE JSON line (rank 0).  `value` = home-QP solves per second, whole job,
 inputs resident in HBM.  `roofline` is the PDHG sweep kernel against HBM;

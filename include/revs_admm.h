@@ -344,7 +344,7 @@ int revs_op_export(int64_t n_homes, int32_t T, const double *sb, float *p_est, v
  *     D_t(y) = -(kappa/2) sum_i g_i^2 - sum_m max(vhi y_m, vlo y_m)   (+ a constant),
  * concave and C^1 with piecewise-linear gradient dD/dy_m = (R p)_m - b_m, p = A g,
  * b_m = vhi / vlo for an upper / lower row.  Each Newton iteration solves the
- * sign-constrained quadratic model on a candidate set of at most REVS_DUAL_AMAX rows per
+ * sign-constrained quadratic model on a candidate set of at most REVS_DUAL_AMAX (128) rows per
  * slot (rows with y != 0 plus the most violated ones) with generalised Hessian
  * K = R_F N R_F^T / kappa (N_m = residences of node m not clamped at zero) by block
  * principal pivoting, then takes an Armijo step on D_t.  The slots are independent
@@ -374,7 +374,7 @@ int revs_op_export(int64_t n_homes, int32_t T, const double *sb, float *p_est, v
  *   revs_op_dual_step    y_trial = y at the candidates moved by alpha[t] towards yhat (all
  *                        other entries of y_trial must already equal y);
  *                        lin_out[8 t] = gradient . (y_trial - y)                         */
-#define REVS_DUAL_AMAX 64
+#define REVS_DUAL_AMAX 128
 int revs_op_dual_eval(int32_t m, int32_t T, const int64_t *node_ptr, const float *p_est,
                       const float *p_sch, const float *gamma, int32_t nslab, const double *dsl,
                       double kappa, double *pnq, float *p_est_new, void *stream);

@@ -21,7 +21,7 @@ src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out")
 rows = []
 for tag, homes in (("pmc", 100000), ("pmc1m", 1000000)):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-        fs = glob.glob(f"{src}/{tag}_{ctr}/*/*_counter_collection.csv")
+        fs = glob.glob(f"{src}/{tag}_{ctr}/**/*counter_collection.csv", recursive=True)
         if not fs:
             continue
         df = pd.read_csv(max(fs, key=os.path.getmtime))      # newest pass

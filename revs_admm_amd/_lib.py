@@ -89,7 +89,7 @@ SIGNATURES = {
                                         _p, _p, _p, _p]),
     "revs_op_dual_step": (C.c_int, [_i32, _p, _p, _p, _p, _p, _p, _p, _p]),
 }
-DUAL_AMAX = 64           # REVS_DUAL_AMAX
+DUAL_AMAX = 128          # REVS_DUAL_AMAX
 
 _lib = None
 

@@ -11,7 +11,7 @@
 // is concave, C^1, piecewise quadratic; dD/dy_m = (R p)_m - b_m with p = A g.  A Newton
 // iteration maximises the quadratic model with generalised Hessian -K, K = R_F N R_F^T/kappa
 // (N_m = number of unclamped residences of node m), over the sign constraints of a
-// candidate set F_t of at most 64 rows (rows with y != 0 and the most violated ones), and
+// candidate set F_t of at most 128 rows (rows with y != 0 and the most violated ones), and
 // takes an Armijo step on D_t.  Only a handful of rows of a radial feeder bind, so the
 // small dense problems live in one workgroup's LDS; the heavy parts are
 //     2 products  R^T y, R p      gemm_kernels.hip, f64 matrix cores
@@ -23,7 +23,8 @@
 namespace revs {
 
 constexpr int kAmax = REVS_DUAL_AMAX;
-static_assert(kAmax == 64, "candidate masks are one 64-bit word / one wavefront");
+static_assert(kAmax == 128, "candidate sets are two 64-bit words / two wavefronts");
+constexpr int kWords = kAmax / 64;
 
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
@@ -140,7 +141,7 @@ __global__ __launch_bounds__(256) void op_dual_rows_kernel(
 __global__ __launch_bounds__(256) void op_dual_select_kernel(
         int m, int T, int nblk, const double *__restrict__ partial, const double *__restrict__ y,
         double vlo, double vhi, int kadd, const double *__restrict__ vfull,
-        double *__restrict__ viol, int64_t *__restrict__ cidx, int32_t *__restrict__ ccnt,
+        const double *__restrict__ viol, int64_t *__restrict__ cidx, int32_t *__restrict__ ccnt,
         double *__restrict__ cval, double *__restrict__ stats) {
     const int t = blockIdx.x, tid = threadIdx.x;
     __shared__ int cnt_s[256];
@@ -195,13 +196,15 @@ __global__ __launch_bounds__(256) void op_dual_select_kernel(
     }
     const int room = min(min(kadd, kAmax - ns), nv);
     int added = 0;
+    // Row r is always scanned by thread r % 256, which remembers in a register mask which
+    // of its rows were taken -- no global store has to become visible between rounds.
+    unsigned long long took = 0ull;
     for (int k = 0; k < room; ++k) {
-        __syncthreads();                    // viol updates of the previous round are visible
         double bv = 0.0;
         int bi = m;
-        for (int r = tid; r < m; r += 256) {
+        for (int r = tid, i = 0; r < m; r += 256, ++i) {
             const double x = viol[(int64_t)r * T + t];
-            if (x > bv) { bv = x; bi = r; }      // ascending r: ties keep the lower row
+            if (x > bv && !((took >> i) & 1ull)) { bv = x; bi = r; }   // ascending r: ties keep the lower row
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
@@ -209,6 +212,7 @@ __global__ __launch_bounds__(256) void op_dual_select_kernel(
             const int oi = __shfl_xor(bi, d, 64);
             if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         }
+        __syncthreads();                    // best_v / best_i of the previous round were read
         if ((tid & 63) == 0) { best_v[tid >> 6] = bv; best_i[tid >> 6] = bi; }
         __syncthreads();
         bv = best_v[0]; bi = best_i[0];
@@ -216,6 +220,7 @@ __global__ __launch_bounds__(256) void op_dual_select_kernel(
         for (int w = 1; w < 4; ++w)
             if (best_v[w] > bv || (best_v[w] == bv && best_i[w] < bi)) { bv = best_v[w]; bi = best_i[w]; }
         if (!(bv > 0.0)) break;             // uniform
+        if (tid == (bi & 255)) took |= 1ull << (bi >> 8);
         if (tid == 0) {
             const double v = vfull[(int64_t)bi * T + t];
             const bool up = v > vhi;
@@ -223,7 +228,6 @@ __global__ __launch_bounds__(256) void op_dual_select_kernel(
             cs[ns + added] = up ? 1.0 : -1.0;
             cg[ns + added] = v - (up ? vhi : vlo);
             cy[ns + added] = 0.0;
-            viol[(int64_t)bi * T + t] = 0.0;
         }
         ++added;
     }
@@ -233,44 +237,49 @@ __global__ __launch_bounds__(256) void op_dual_select_kernel(
 }
 
 // ---- model Hessian: K_t = R_F N_t R_F^T (candidates x candidates), K-split slabs ------
-// Workgroup (t, ks) covers columns [ks, ks+1) * m/nks of R in chunks of 32: the candidate
-// rows of R (and the same rows scaled by N[.,t]) are staged in LDS with coalesced loads,
-// and thread (ti, tj) accumulates a 4 x 4 block of the 64 x 64 product.  Slabs are summed
-// (fixed order) by op_dual_bpp_kernel.
+// Workgroup (t, ks, tile) computes one 64 x 64 tile (tile = 2 bi + bj) over the columns
+// [ks, ks+1) * m/nks of R in chunks of 32: the candidate rows of R (and the same rows scaled
+// by N[.,t]) are staged in LDS with coalesced loads, and thread (ti, tj) accumulates a 4 x 4
+// block.  Tiles beyond the slot's candidate count exit at once.  Slabs are summed (fixed
+// order) by op_dual_bpp_kernel.
 __global__ __launch_bounds__(256) void op_dual_gram_kernel(
         int m, int T, const double *__restrict__ R, const double *__restrict__ Nn,
         const int64_t *__restrict__ cidx, const int32_t *__restrict__ ccnt, int nks,
         double *__restrict__ Kslab) {
     const int t = blockIdx.x, ks = blockIdx.y, tid = threadIdx.x;
+    const int bi = blockIdx.z >> 1, bj = blockIdx.z & 1;
     const int a = ccnt[t];
-    if (a <= 0) return;
+    if (a <= 0 || bi * 64 >= a || bj * 64 >= a) return;
     constexpr int KC = 32;
-    __shared__ double Ws[kAmax][KC + 1], Rs_[kAmax][KC + 1];
-    __shared__ int64_t rows_s[kAmax];
-    if (tid < kAmax) rows_s[tid] = tid < a ? cidx[(int64_t)t * kAmax + tid] : 0;
+    __shared__ double Ws[64][KC + 1], Rs_[64][KC + 1];
+    __shared__ int64_t rows_i[64], rows_j[64];
+    if (tid < 64) {
+        rows_i[tid] = bi * 64 + tid < a ? cidx[(int64_t)t * kAmax + bi * 64 + tid] : -1;
+        rows_j[tid] = bj * 64 + tid < a ? cidx[(int64_t)t * kAmax + bj * 64 + tid] : -1;
+    }
     __syncthreads();
-    const int a4 = (a + 3) & ~3;
+    const int ai = min(64, (a - bi * 64 + 3) & ~3), aj = min(64, (a - bj * 64 + 3) & ~3);
     const int ti = tid >> 4, tj = tid & 15;
-    const bool mine = ti * 4 < a4 && tj * 4 < a4;
+    const bool mine = ti * 4 < ai && tj * 4 < aj;
     double acc[4][4] = {};
     const int chunk = (m + nks - 1) / nks;
     const int k0 = ks * chunk, k1 = min(m, k0 + chunk);
     for (int kk = k0; kk < k1; kk += KC) {
         // stage: 256 threads = 8 rows x 32 columns per pass
-        for (int rr = tid >> 5; rr < a4; rr += 8) {
-            const int c = kk + (tid & 31);
-            double rv = 0.0, nv = 0.0;
-            if (rr < a && c < k1) { rv = R[rows_s[rr] * m + c]; nv = Nn[(int64_t)c * T + t]; }
-            Rs_[rr][tid & 31] = rv;
-            Ws[rr][tid & 31] = rv * nv;
+        const int c = kk + (tid & 31);
+        const double nv = c < k1 ? Nn[(int64_t)c * T + t] : 0.0;
+        for (int rr = tid >> 5; rr < 64; rr += 8) {
+            const int64_t ri = rows_i[rr], rj = rows_j[rr];
+            Ws[rr][tid & 31] = (ri >= 0 && c < k1) ? R[ri * m + c] * nv : 0.0;
+            Rs_[rr][tid & 31] = (rj >= 0 && c < k1) ? R[rj * m + c] : 0.0;
         }
         __syncthreads();
         if (mine) {
 #pragma unroll 8
-            for (int c = 0; c < KC; ++c) {
+            for (int cc = 0; cc < KC; ++cc) {
                 double wv[4], rv[4];
 #pragma unroll
-                for (int x = 0; x < 4; ++x) { wv[x] = Ws[ti * 4 + x][c]; rv[x] = Rs_[tj * 4 + x][c]; }
+                for (int x = 0; x < 4; ++x) { wv[x] = Ws[ti * 4 + x][cc]; rv[x] = Rs_[tj * 4 + x][cc]; }
 #pragma unroll
                 for (int x = 0; x < 4; ++x)
 #pragma unroll
@@ -284,7 +293,8 @@ __global__ __launch_bounds__(256) void op_dual_gram_kernel(
 #pragma unroll
         for (int x = 0; x < 4; ++x)
 #pragma unroll
-            for (int z = 0; z < 4; ++z) o[(ti * 4 + x) * kAmax + tj * 4 + z] = acc[x][z];
+            for (int z = 0; z < 4; ++z)
+                o[(bi * 64 + ti * 4 + x) * kAmax + bj * 64 + tj * 4 + z] = acc[x][z];
     }
 }
 
@@ -292,7 +302,8 @@ __global__ __launch_bounds__(256) void op_dual_gram_kernel(
 // In sign-normalised variables u = s y >= 0 the model is the LCP
 //     u >= 0,  w = K' u - c >= 0,  u . w = 0,   K' = S K S + delta I,  c = s grad + K' u_cur.
 // Block principal pivoting (Judice & Pires) with the single-exchange backup rule: basic
-// set B (u free, w = 0) as a 64-bit mask; solve K'_BB u_B = c_B by Cholesky in LDS, swap
+// set B (u free, w = 0) as two 64-bit words; solve K'_BB u_B = c_B by Cholesky in LDS (the
+// workgroup's dynamic LDS holds the 128 x 129 factor: 129 KB of the CU's 160 KB), swap
 // every infeasible index (u_i < 0 in B, w_i < 0 outside) while that shrinks their number,
 // else only the highest one -- finite for a positive definite K'.
 __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
@@ -321,12 +332,14 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
         }
     }
     __syncthreads();
-    __shared__ double Ls[kAmax][kAmax + 1];
-    __shared__ double s_s[kAmax], c_s[kAmax], u_s[kAmax], w_s[kAmax];
+    extern __shared__ double Ls_dyn[];                    // [kAmax][kAmax + 1]
+    auto Ls = [&](int i, int j) -> double & { return Ls_dyn[i * (kAmax + 1) + j]; };
+    __shared__ double s_s[kAmax], c_s[kAmax], u_s[kAmax], w_s[kAmax], wred[4];
     __shared__ int bl[kAmax];
-    __shared__ unsigned long long Bsh;
-    __shared__ double dl_s, tolw_s;
+    __shared__ unsigned long long Bsh[kWords], Vsh[kWords];
+    __shared__ double dl_s, tolw_s, tolu_s;
     __shared__ int done_s, piv_s;
+    const int lane = tid & 63, wave = tid >> 6;
 
     if (tid < kAmax) {
         const bool in = tid < a;
@@ -334,102 +347,142 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
         s_s[tid] = s;
         u_s[tid] = in ? fmax(s * cy[tid], 0.0) : 0.0;
         const double tr = wave_sum_d(in ? Kt[tid * kAmax + tid] : 0.0);
-        if (tid == 0) { dl_s = delta * tr / a + 1e-300; done_s = 0; piv_s = 0; }
+        if (lane == 0) wred[wave] = tr;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double tr = 0.0;
+        for (int w = 0; w < kWords; ++w) tr += wred[w];
+        dl_s = delta * tr / a + 1e-300; done_s = 0; piv_s = 0;
     }
     __syncthreads();
     const double dl = dl_s;
     auto kp = [&](int i, int j) -> double {
         return s_s[i] * s_s[j] * Kt[i * kAmax + j] + (i == j ? dl : 0.0);
     };
-    // out_i = sum_j K'_ij u_j : 4 lanes per row, 16 columns each
-    const int mi = tid >> 2, mp = tid & 3;
+    // out_i = sum_j K'_ij u_j : 2 lanes per row, kAmax/2 columns each
+    const int mi = tid >> 1, mp = tid & 1;
     auto matvec_row = [&]() -> double {
         double acc = 0.0;
         if (mi < a)
-            for (int j = mp * 16; j < mp * 16 + 16 && j < a; ++j) acc += kp(mi, j) * u_s[j];
+            for (int j = mp * (kAmax / 2); j < (mp + 1) * (kAmax / 2) && j < a; ++j)
+                acc += kp(mi, j) * u_s[j];
         acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
         return acc;
     };
     {
         const double ku = matvec_row();
-        if (mp == 0 && mi < a) c_s[mi] = s_s[mi] * cg[mi] + ku;
-        if (mp == 0 && mi >= a) c_s[mi] = 0.0;
+        if (mp == 0) c_s[mi] = mi < a ? s_s[mi] * cg[mi] + ku : 0.0;
     }
     if (tid < kAmax) {
         const unsigned long long B0 = __ballot(tid < a && u_s[tid] > 0.0);
-        if (tid == 0) Bsh = B0;
+        if (lane == 0) Bsh[wave] = B0;
     }
     __syncthreads();
     if (tid < kAmax) {
         const double cm = wave_max_d(fabs(c_s[tid]));
-        if (tid == 0) tolw_s = 1e-13 * cm;
+        if (lane == 0) wred[wave] = cm;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double cm = 0.0;
+        for (int w = 0; w < kWords; ++w) cm = fmax(cm, wred[w]);
+        tolw_s = 1e-13 * cm;
     }
     int ninf = kAmax + 1, pcount = 3;       // thread 0's pivoting state
     for (;;) {
         __syncthreads();
-        const unsigned long long B = Bsh;
-        const int nb = __popcll(B);
-        if (tid < kAmax && ((B >> tid) & 1ull)) bl[__popcll(B & ((1ull << tid) - 1ull))] = tid;
+        unsigned long long B[kWords];
+        int nb = 0;
+#pragma unroll
+        for (int w = 0; w < kWords; ++w) { B[w] = Bsh[w]; nb += __popcll(B[w]); }
+        if (tid < kAmax && ((B[wave] >> lane) & 1ull)) {
+            int pos = __popcll(B[wave] & ((1ull << lane) - 1ull));
+            for (int w = 0; w < wave; ++w) pos += __popcll(B[w]);
+            bl[pos] = tid;
+        }
         __syncthreads();
         for (int e = tid; e < nb * nb; e += 256) {
             const int k = e / nb, l = e - k * nb;
-            Ls[k][l] = kp(bl[k], bl[l]);
+            Ls(k, l) = kp(bl[k], bl[l]);
         }
         __syncthreads();
         // Cholesky, lower triangle in place
         for (int k = 0; k < nb; ++k) {
-            if (tid == 0) {
-                const double pv = Ls[k][k];
-                Ls[k][k] = sqrt(fmax(pv, dl * 1e-6));
-            }
+            if (tid == 0) Ls(k, k) = sqrt(fmax(Ls(k, k), dl * 1e-6));
             __syncthreads();
-            const double pk = Ls[k][k];
-            for (int i = k + 1 + tid; i < nb; i += 256) Ls[i][k] /= pk;
+            const double pk = Ls(k, k);
+            for (int i = k + 1 + tid; i < nb; i += 256) Ls(i, k) /= pk;
             __syncthreads();
             const int rem = nb - k - 1;
             for (int e = tid; e < rem * rem; e += 256) {
                 const int i = k + 1 + e / rem, j = k + 1 + e % rem;
-                if (j <= i) Ls[i][j] -= Ls[i][k] * Ls[j][k];
+                if (j <= i) Ls(i, j) -= Ls(i, k) * Ls(j, k);
             }
             __syncthreads();
         }
-        // triangular solves in wavefront 0: lane k holds component k
-        if (tid < kAmax) {
-            double val = tid < nb ? c_s[bl[tid]] : 0.0;
+        // triangular solves in wavefront 0: lane l holds components l and l + 64
+        if (tid < 64) {
+            double v0 = lane < nb ? c_s[bl[lane]] : 0.0;
+            double v1 = lane + 64 < nb ? c_s[bl[lane + 64]] : 0.0;
             for (int k = 0; k < nb; ++k) {
-                const double zk = __shfl(val, k, 64) / Ls[k][k];
-                if (tid == k) val = zk;
-                else if (tid > k && tid < nb) val -= Ls[tid][k] * zk;
+                const double src = k < 64 ? __shfl(v0, k, 64) : __shfl(v1, k - 64, 64);
+                const double zk = src / Ls(k, k);
+                if (lane == k) v0 = zk;
+                else if (lane > k && lane < nb) v0 -= Ls(lane, k) * zk;
+                if (lane + 64 == k) v1 = zk;
+                else if (lane + 64 > k && lane + 64 < nb) v1 -= Ls(lane + 64, k) * zk;
             }
             for (int k = nb - 1; k >= 0; --k) {
-                const double xk = __shfl(val, k, 64) / Ls[k][k];
-                if (tid == k) val = xk;
-                else if (tid < k) val -= Ls[k][tid] * xk;
+                const double src = k < 64 ? __shfl(v0, k, 64) : __shfl(v1, k - 64, 64);
+                const double xk = src / Ls(k, k);
+                if (lane == k) v0 = xk;
+                else if (lane < k) v0 -= Ls(k, lane) * xk;
+                if (lane + 64 == k) v1 = xk;
+                else if (lane + 64 < k) v1 -= Ls(k, lane + 64) * xk;
             }
-            u_s[tid] = 0.0;
+            u_s[lane] = 0.0; u_s[lane + 64] = 0.0;
             __builtin_amdgcn_wave_barrier();
-            if (tid < nb) u_s[bl[tid]] = val;
+            if (lane < nb) u_s[bl[lane]] = v0;
+            if (lane + 64 < nb) u_s[bl[lane + 64]] = v1;
         }
         __syncthreads();
         {
             const double ku = matvec_row();
             if (mp == 0) w_s[mi] = mi < a ? ku - c_s[mi] : 0.0;
         }
+        if (tid < kAmax) {
+            const double um = wave_max_d(fabs(u_s[tid]));
+            if (lane == 0) wred[wave] = um;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            double um = 0.0;
+            for (int w = 0; w < kWords; ++w) um = fmax(um, wred[w]);
+            tolu_s = 1e-13 * um;
+        }
         __syncthreads();
         if (tid < kAmax) {
-            const bool inB = (B >> tid) & 1ull;
-            const double um = wave_max_d(fabs(u_s[tid]));
-            const bool bad = tid < a && (inB ? (u_s[tid] < -1e-13 * um) : (w_s[tid] < -tolw_s));
+            const bool inB = (B[wave] >> lane) & 1ull;
+            const bool bad = tid < a && (inB ? (u_s[tid] < -tolu_s) : (w_s[tid] < -tolw_s));
             const unsigned long long V = __ballot(bad);
-            if (tid == 0) {
-                const int nv = __popcll(V);
-                const int pv = ++piv_s;
-                if (nv == 0) done_s = 1;
-                else if (pv >= max_pivots) done_s = 2;
-                else if (nv < ninf) { ninf = nv; pcount = 3; Bsh = B ^ V; }
-                else if (pcount > 0) { --pcount; Bsh = B ^ V; }
-                else Bsh = B ^ (1ull << (63 - __clzll((long long)V)));
+            if (lane == 0) Vsh[wave] = V;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int nv = 0, top = -1;
+            for (int w = 0; w < kWords; ++w) {
+                nv += __popcll(Vsh[w]);
+                if (Vsh[w]) top = w * 64 + 63 - __clzll((long long)Vsh[w]);
+            }
+            const int pv = ++piv_s;
+            if (nv == 0) done_s = 1;
+            else if (pv >= max_pivots) done_s = 2;
+            else if (nv < ninf || pcount > 0) {
+                if (nv < ninf) { ninf = nv; pcount = 3; } else --pcount;
+                for (int w = 0; w < kWords; ++w) Bsh[w] = B[w] ^ Vsh[w];
+            } else {
+                Bsh[top >> 6] = B[top >> 6] ^ (1ull << (top & 63));
             }
         }
         __syncthreads();
@@ -445,20 +498,20 @@ __global__ __launch_bounds__(64) void op_dual_step_kernel(
         const double *__restrict__ cval, const double *__restrict__ yhat,
         const double *__restrict__ alpha, double *__restrict__ ytrial,
         double *__restrict__ lin_out) {
-    const int t = blockIdx.x, i = threadIdx.x;
+    const int t = blockIdx.x;
     const int a = ccnt[t];
     const double al = alpha[t];
     const double *cs = cval + (int64_t)t * 3 * kAmax, *cg = cs + kAmax, *cy = cg + kAmax;
     double lin = 0.0;
-    if (i < a) {
+    for (int i = threadIdx.x; i < a; i += 64) {
         const double yo = cy[i], yh = yhat[(int64_t)t * kAmax + i];
         // a full step lands exactly on yhat, so a multiplier that leaves is exactly zero
         const double yn = al == 1.0 ? yh : (al == 0.0 ? yo : yo + al * (yh - yo));
         ytrial[cidx[(int64_t)t * kAmax + i] * T + t] = yn;
-        lin = cg[i] * (yn - yo);
+        lin += cg[i] * (yn - yo);
     }
     lin = wave_sum_d(lin);
-    if (i == 0) lin_out[t * 8] = lin;
+    if (threadIdx.x == 0) lin_out[t * 8] = lin;
 }
 
 }  // namespace revs
@@ -494,6 +547,7 @@ extern "C" int revs_op_dual_select(int32_t m, int32_t T, int32_t nslab, const do
                                    int32_t kadd, double *vfull, double *viol, double *partial,
                                    int64_t *cand_idx, int32_t *cand_cnt, double *cand_val,
                                    double *stats, void *stream) {
+    REVS_REQUIRE(m <= 16384, "revs_op_dual_select: m=%d exceeds 16384 rows", m);
     REVS_REQUIRE(m > 0 && T > 0 && T <= 256 && nslab >= 1 && vsl && pnq && y && vfull && viol &&
                  partial && cand_idx && cand_cnt && cand_val && stats && vlo <= vhi && kadd >= 0,
                  "revs_op_dual_select: bad argument");
@@ -520,9 +574,18 @@ extern "C" int revs_op_dual_model(int32_t m, int32_t T, const double *R, const d
     REVS_REQUIRE(m > 0 && T > 0 && R && n_free && cand_idx && cand_cnt && cand_val && k_slabs &&
                  k_full && yhat && info && kappa > 0 && delta >= 0 && max_pivots > 0 &&
                  nks >= 1 && nks <= 64, "revs_op_dual_model: bad argument");
-    hipLaunchKernelGGL(op_dual_gram_kernel, dim3(T, nks), dim3(256), 0, S_(stream), m, T, R, n_free,
-                       cand_idx, cand_cnt, nks, k_slabs);
-    hipLaunchKernelGGL(op_dual_bpp_kernel, dim3(T), dim3(256), 0, S_(stream), k_slabs, nks,
+    static const size_t lds = sizeof(double) * kAmax * (kAmax + 1);
+    static const hipError_t attr = hipFuncSetAttribute(
+        reinterpret_cast<const void *>(&op_dual_bpp_kernel),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) {
+        revs::set_error("revs_op_dual_model: %zu bytes of LDS refused: %s", lds,
+                        hipGetErrorString(attr));
+        return REVS_ELAUNCH;
+    }
+    hipLaunchKernelGGL(op_dual_gram_kernel, dim3(T, nks, kWords * kWords), dim3(256), 0, S_(stream),
+                       m, T, R, n_free, cand_idx, cand_cnt, nks, k_slabs);
+    hipLaunchKernelGGL(op_dual_bpp_kernel, dim3(T), dim3(256), lds, S_(stream), k_slabs, nks,
                        1.0 / kappa, k_full, cand_cnt, cand_val, delta, max_pivots, yhat, info);
     REVS_CHECK_LAUNCH("revs_op_dual_model");
     return REVS_OK;

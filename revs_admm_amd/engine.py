@@ -13,6 +13,7 @@ built library raises.
 from __future__ import annotations
 
 import ctypes as C
+import dataclasses
 import math
 from dataclasses import dataclass
 
@@ -134,6 +135,8 @@ class AdmmEngine:
         self.kappa = float(kappa)
         self.mode = MODES[mode] if isinstance(mode, str) else int(mode)
         self.op = op or OperatorOptions()
+        if self.op.solver == "newton" and np.asarray(Rn).shape[0] > 16384:
+            self.op = dataclasses.replace(self.op, solver="admm")   # revs_op_dual_select's limit
         self.vlo, self.vhi = voltage_limits(vset, vlow, vhigh)
 
         load = np.ascontiguousarray(load, np.float32)
@@ -257,15 +260,13 @@ class AdmmEngine:
         self.vfull = nz()
         self.violw = nz()
         self.d_part = torch.zeros(int(self.lib.revs_op_dual_blocks(M)), T, 4, **f64)
-        self.nks = int(min(16, max(1, M // 256)))       # column slabs of the model Hessian
+        self.nks = int(min(16, max(1, M // 128)))       # column slabs of the model Hessian
         self.k_slabs = torch.zeros(T, self.nks, A, A, **f64)
         self.k_full = torch.zeros(T, A, A, **f64)
         self.c_idx = [torch.zeros(T, A, dtype=torch.int64, device=self.dev) for _ in range(2)]
         self.c_cnt = [torch.zeros(T, dtype=torch.int32, device=self.dev) for _ in range(2)]
         self.c_val = [torch.zeros(T, 3, A, **f64) for _ in range(2)]
         self.yhat = torch.zeros(T, A, **f64)
-        self.bpp_info = torch.zeros(T, dtype=torch.int32, device=self.dev)
-        self.alpha_d = torch.zeros(T, **f64)
         self._y_support = False
         self._spec_ok = False
         self.spec_hist = [0, 0]                        # speculative sweeps kept / discarded
@@ -284,6 +285,17 @@ class AdmmEngine:
             else:
                 self.stats_dev.append(t.data_ptr())
         self.stats_ev = [torch.cuda.Event() if cuda else None for _ in range(2)]
+        # step lengths (host -> kernel) and pivot counts (kernel -> host) live in pinned host
+        # memory as well: no copy launches inside a Newton iteration
+        self.alpha_h = torch.zeros(T, dtype=torch.float64, pin_memory=cuda)
+        self.info_h = torch.zeros(T, dtype=torch.int32, pin_memory=cuda)
+        self.alpha_dev, self.info_dev = self.alpha_h.data_ptr(), self.info_h.data_ptr()
+        if cuda:
+            for name, t in (("alpha_dev", self.alpha_h), ("info_dev", self.info_h)):
+                dp = C.c_void_p()
+                check(self.lib.revs_host_device_ptr(t.data_ptr(), C.byref(dp)),
+                      "revs_host_device_ptr")
+                setattr(self, name, int(dp.value))
         self.newton_hist: list[tuple] = []
         # R (float) for the voltage check
         self.R32 = up(Rn.astype(np.float32))
@@ -679,6 +691,7 @@ class AdmmEngine:
         cur = 0
         stt = self._dual_evaluate(ycur, self._y_support, cur) if first is None else first
         evals, newton, pivots, ok_all = 1, 0, 0, False
+        best, stall = np.inf, 0
         while True:
             if (stt[:, 2] > A).any():
                 break                                    # more multipliers than a model holds
@@ -688,6 +701,16 @@ class AdmmEngine:
                 break
             if newton >= o.newton_max:
                 break
+            # a slot whose model is full of multipliers while rows are still violated cannot
+            # take them in; and a solve that stopped improving is not worth more iterations
+            if ((stt[:, 2] >= A) & (stt[:, 3] > 0) & (rmax > o.eps)).any():
+                break
+            if rmax.max() < 0.5 * best:
+                best, stall = rmax.max(), 0
+            else:
+                stall += 1
+                if stall >= 10:
+                    break
             newton += 1
             # model of every slot: K_t = R_F N_t R_F^T / kappa over its candidates, maximised
             # over the sign constraints (block principal pivoting, one workgroup per slot)
@@ -695,18 +718,18 @@ class AdmmEngine:
                                          ptr(self.c_idx[cur]), ptr(self.c_cnt[cur]),
                                          ptr(self.c_val[cur]), self.kappa, o.newton_delta,
                                          o.newton_pivots, self.nks, ptr(self.k_slabs),
-                                         ptr(self.k_full), ptr(self.yhat), ptr(self.bpp_info), st),
+                                         ptr(self.k_full), ptr(self.yhat), self.info_dev, st),
                   "revs_op_dual_model")
             D = stt[:, 1]
             pending = rmax > o.eps
             alpha = pending.astype(np.float64)
             nxt = 1 - cur
             for _ in range(o.newton_ls):
-                self.alpha_d.copy_(torch.from_numpy(alpha))
+                self.alpha_h.numpy()[:] = alpha      # read by the step kernel through its mapping
                 ytrial.copy_(ycur)
                 check(lib.revs_op_dual_step(T, ptr(self.c_idx[cur]), ptr(self.c_cnt[cur]),
                                             ptr(self.c_val[cur]), ptr(self.yhat),
-                                            ptr(self.alpha_d), ptr(ytrial),
+                                            self.alpha_dev, ptr(ytrial),
                                             self.stats_dev[nxt] + 32, st),
                       "revs_op_dual_step")
                 stn = self._dual_evaluate(ytrial, True, nxt)
@@ -716,7 +739,7 @@ class AdmmEngine:
                 if not pending.any():
                     break
                 alpha[pending] *= 0.5
-            pivots += int(np.abs(self.bpp_info.cpu().numpy()).sum())
+            pivots += int(np.abs(self.info_h.numpy()).sum())     # (the evaluation was waited for)
             if pending.any():
                 break                                    # no ascent found: leave it to ADMM
             ycur, ytrial = ytrial, ycur

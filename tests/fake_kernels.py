@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from oracle import revs_oracle as ro
-from revs_admm_amd._lib import HOME_DTYPE
+from revs_admm_amd._lib import DUAL_AMAX, HOME_DTYPE
 
 _F = {np.float32: C.c_float, np.float64: C.c_double, np.int64: C.c_int64, np.int32: C.c_int32,
       np.uint8: C.c_uint8}
@@ -332,7 +332,7 @@ class FakeKernels:
 
     def revs_op_dual_select(self, m, T, nslab, vsl, pnq, y, vlo, vhi, kadd, vfull, viol, partial,
                             cidx, ccnt, cval, stats, stream):
-        A = 64
+        A = DUAL_AMAX
         v = view(vsl, (nslab, m, T), np.float64).sum(axis=0)
         view(vfull, (m, T), np.float64)[:] = v
         yv = view(y, (m, T), np.float64)
@@ -368,7 +368,7 @@ class FakeKernels:
 
     def revs_op_dual_model(self, m, T, R, n_free, cidx, ccnt, cval, kappa, delta, max_pivots, nks,
                            k_slabs, k_full, yhat, info, stream):
-        A = 64
+        A = DUAL_AMAX
         Rm, Nf = view(R, (m, m), np.float64), view(n_free, (m, T), np.float64)
         ci, cc = view(cidx, (T, A), np.int64), view(ccnt, (T,), np.int32)
         cv, yh = view(cval, (T, 3, A), np.float64), view(yhat, (T, A), np.float64)
@@ -415,7 +415,7 @@ class FakeKernels:
         return 0
 
     def revs_op_dual_step(self, T, cidx, ccnt, cval, yhat, alpha, ytrial, lin_out, stream):
-        A = 64
+        A = DUAL_AMAX
         ci, cc = view(cidx, (T, A), np.int64), view(ccnt, (T,), np.int32)
         cv, yh = view(cval, (T, 3, A), np.float64), view(yhat, (T, A), np.float64)
         al = view(alpha, (T,), np.float64)

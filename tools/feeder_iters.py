@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Operator inner-iteration counts on the reference's 121144 feeder (binary homes, 15 ADMM
-iterations) for a few initial rho scales.  python tools/feeder_iters.py"""
+"""The reference's own case on the GPU: 15 ADMM iterations on the 121144 feeder (1126
+residences, one per node, binary homes) -- wall time and operator work per iteration.
+python tools/feeder_iters.py [--admm]"""
 import os
 import sys
 import time
@@ -23,15 +24,29 @@ pos[nonsub] = np.arange(len(nonsub))
 Rr = R[np.ix_(pos[res], pos[res])]
 oh, evi = golden_homes(z, "dis_a90_r4800", 4.8)
 n = oh.LOAD.shape[0]
-for rv in (0.1, 1.0, 5.0, 25.0, 100.0):
-    for rb in (0.1, 1.0):
-        op = OperatorOptions(rho_v_scale=rv, rho_b_scale=rb)
-        e = AdmmEngine(z["tariff_shift6"], pack_homes(oh.ev, 4.8, 20.0, 0.2, 11, 23), oh.LOAD,
-                       np.arange(n), Rr, kappa=5.0, vset=1.03, vlow=0.95, vhigh=1.05, mode="binary",
-                       op=op)
+def run(label, op):
+    e = AdmmEngine(z["tariff_shift6"], pack_homes(oh.ev, 4.8, 20.0, 0.2, 11, 23), oh.LOAD,
+                   np.arange(n), Rr, kappa=5.0, vset=1.03, vlow=0.95, vhigh=1.05, mode="binary",
+                   op=op)
+    for rep in range(2):                      # second run: code objects loaded
+        for t in (e.P_est, e.P_sch, e.G):
+            t.zero_()
+        for y in e.yd:
+            y.zero_()
+        e._y_support = e._spec_ok = False
+        e.op_cold = e._fast_cold = True
+        e.op_iters_hist.clear(); e.newton_hist.clear()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        d = e.run(15)
+        e.run(15)
         torch.cuda.synchronize()
-        print(f"rho_v {rv:6.1f} rho_b {rb:4.1f}: {time.perf_counter() - t0:6.2f} s  inner its "
-              f"{sum(e.op_iters_hist):6d}  {e.op_iters_hist}", flush=True)
+        dt = time.perf_counter() - t0
+    print(f"{label}: {dt * 1e3:8.1f} ms for 15 ADMM iterations; operator evaluations / inner "
+          f"iterations {sum(e.op_iters_hist)}  {e.op_iters_hist}  newton {[h[0] for h in e.newton_hist]}",
+          flush=True)
+
+
+run("dual Newton (default)", OperatorOptions())
+if "--admm" in sys.argv:
+    for rv in (1.0, 25.0):
+        run(f"ADMM forms, rho_v {rv}", OperatorOptions(solver="admm", rho_v_scale=rv))
