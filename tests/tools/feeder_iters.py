@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """The reference's own case on the GPU: 15 ADMM iterations on the 121144 feeder (1126
 residences, one per node, binary homes) -- wall time and operator work per iteration.
-python tools/feeder_iters.py [--admm]"""
+python tests/tools/feeder_iters.py [--admm]"""
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

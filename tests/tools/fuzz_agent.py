@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Differential fuzz of revs_agent_step against the oracle over seeds, horizons and modes.
-    python tools/fuzz_agent.py [n_seeds]"""
+    python tests/tools/fuzz_agent.py [n_seeds]"""
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
