@@ -120,13 +120,18 @@ def test_operator_matches_oracle(gpu_lib, n, M, T):
     # the node-space ADMM fast path (taken when no residence is clamped at zero) and the
     # general home-space ADMM
     from revs_admm_amd.engine import OperatorOptions
-    for solver, fast in (("admm", True), ("admm", False), ("newton", True)):
-        e = _engine(w, op=OperatorOptions(solver=solver, node_fast=fast))
+    for solver, fast in (("admm", True), ("admm", False), ("newton-handoff", True), ("newton", True)):
+        # "newton-handoff": a Newton solve that is not allowed to finish hands the iteration
+        # to the ADMM forms, which must still deliver the answer
+        e = _engine(w, op=(OperatorOptions(newton_max=1) if solver == "newton-handoff" else
+                           OperatorOptions(solver=solver, node_fast=fast)))
         _set_state(e, pe, ps, gm)
         assert e.operator_solve()
         got = e.P_est_new.cpu().numpy()[e.inv_perm].astype(np.float64)
         assert np.abs(got - ref).max() < 2e-5 * max(1.0, np.abs(ref).max()), (fast, e.op_path_hist)
-        if solver == "newton":
+        if solver == "newton-handoff":
+            assert e.newton_hist[-1][0] == 1 and e.op_path_hist[-1] in ("node", "home")
+        elif solver == "newton":
             assert e.op_path_hist == ["dual"] and e.newton_hist[-1][0] >= 1
             # float64 all the way: the Newton answer is the oracle's to float32 rounding
             assert np.abs(got - ref).max() < 2e-6 * max(1.0, np.abs(ref).max())

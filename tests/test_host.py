@@ -160,6 +160,26 @@ def test_dual_newton_on_fake_kernels(stress):
     assert np.abs(e.result()[1] - S_ref).max() < 1e-5 and np.abs(d - d_ref).max() < 1e-6
 
 
+def test_newton_handoff_to_admm_on_fake_kernels():
+    """A Newton solve that cannot finish (here: not allowed more than one iteration) hands the
+    ADMM iteration to the ADMM forms and starts from zero multipliers next time; the run still
+    follows the oracle."""
+    from fake_kernels import FakeKernels
+    from helpers import f32, oracle_homes
+    from revs_admm_amd.engine import AdmmEngine, OperatorOptions
+    from revs_admm_amd.synthetic import make_workload
+    w = make_workload(150, 12, n_nodes=20, seed=2, stress=2.0, binary_feasible=False)
+    w.load, w.cost = f32(w.load), f32(w.cost)
+    e = AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, kappa=w.kappa, vset=w.vset,
+                   vlow=w.vlow, vhigh=w.vhigh, mode="relaxed_exact", device="cpu",
+                   _kernels=FakeKernels(), op=OperatorOptions(newton_max=1))
+    d = e.run(5)
+    d_ref, P_ref, S_ref, C_ref = ro.solve_ADMM(oracle_homes(w), w.Rn, w.node_of, w.cost, w.kappa, 5,
+                                               w.vset, w.vlow, w.vhigh, mode="relaxed")
+    assert {"node", "home"} & set(e.op_path_hist) and max(h[0] for h in e.newton_hist) == 1
+    assert np.abs(e.result()[1] - S_ref).max() < 1e-5 and np.abs(d - d_ref).max() < 1e-6
+
+
 def test_speculative_sweep_on_fake_kernels():
     """step() launches the home sweep behind the operator's first evaluation when the last
     solve needed no Newton iteration.  Kept or discarded, the trajectory is the one of the
