@@ -193,61 +193,20 @@ class AdmmEngine:
         if self._pdhg_warm:      # one scalar per home, or one per SOC row with full_rows
             self.pdhg_dual = torch.zeros((n, T) if self.pdhg.full_rows else (n,), **f32)
 
-        # ---- operator setup (host, double) ----
-        # Voltage row m is scaled by sqrt(n_m) (bounds too), so the operator matrix
-        # D^1/2 R D^1/2 is symmetric PSD = Q L Q^T: one factor serves C_v and C_v^T.
-        # Nodes without residences get a zero row: voltage is constrained where
-        # residences are, as in the reference (R_res, lpsolver.py:188-189).
-        sq = np.sqrt(counts.astype(np.float64))
-        lam, Q = np.linalg.eigh(sq[:, None] * Rn * sq[None, :])
-        lam = np.maximum(lam, 0.0)
-        self.smax = float(lam.max())
-        self.Q, self.QT = up(Q), up(Q.T)
-        # the scaled sensitivity matrix itself, for the one-product voltage check Rs.p0
-        self.Rs = up((Q * lam[None, :]) @ Q.T)
-        self.s = up(lam)
-        self.sqrt_n = up(sq)
-        self.inv_sqrt_n = up(np.where(counts > 0, 1.0 / np.maximum(sq, 1e-300), 0.0))
-        self.g0 = torch.zeros(n, T, **f64)
-        self.sb = torch.zeros(n, T, **f64)             # z_b + y_b of the g >= 0 rows
+        # ---- operator setup ----
+        self._Rn_host, self._counts_host = Rn, counts
+        self._admm_ready = False
         nz = lambda: torch.zeros(M, T, **f64)
-        (self.zv, self.yv, self.cx, self.w, self.rhat, self.xc, self.a, self.sa,
-         self.cty) = (nz() for _ in range(9))
-        # GEMM outputs come as K-split partial slabs (summed by the node kernels): enough
-        # workgroups to fill 256 CUs even when M/32 row tiles x 2 products is below that
-        self.cat = 2 * T <= 192                        # [rhat | w] in one product
-        ncol = 2 * T if self.cat else T
-        tiles = ((M + 31) // 32 if ncol <= 48 else (M + 15) // 16) * (1 if self.cat else 2)
-        self.ksplit = int(min(8, max(1, -(-256 // tiles))))
-        nzs = lambda: torch.zeros(self.ksplit, M, T, **f64)
-        self.ta, self.tb, self.va, self.usa = nzs(), nzs(), nzs(), nzs()
-        # node-space fast path
         self.ksplit1 = int(min(8, max(1, -(-256 // ((M + 31) // 32 if T <= 32 else (M + 15) // 16)))))
         nz1 = lambda: torch.zeros(self.ksplit1, M, T, **f64)
-        self.f_wh, self.f_zt = nz1(), nz1()
-        (self.p0, self.gmin, self.ph0, self.xh, self.sx, self.dnode, self.slack) = (nz() for _ in range(7))
-        self.f_stats = torch.zeros(2, **f64)
-        self.rho_f = torch.full((T,), self.op.rho_v_scale * self.kappa / self.smax ** 2, **f64)
         self._fast_ok = bool(self.op.node_fast)
-        self._dnode_zero = False
-        # exact presolve of the fast path (see revs_op_node_prep): needs R >= 0 and vlo <= 0
-        self.preclamp = int(bool(Rn.min() >= 0.0 and self.vlo <= 0.0))
-        self._fast_wait = 0
-        self._fast_backoff = 1
         self._fast_cold = True
-        self._fast_cal = False
-        self._fgraph = None
-        self._fgraph_warm = False
-        self.op_path_hist: list[str] = []
-        self.rho_v = torch.full((T,), self.op.rho_v_scale * self.kappa / self.smax ** 2, **f64)
-        self.rho_b = torch.full((T,), self.op.rho_b_scale * self.kappa, **f64)
-        self.res_out = torch.zeros(8, T, **f64)
         self.op_cold = True
-        self._calibrated = False
-        self._graph = None
-        self._graph_warm = False
+        self.op_path_hist: list[str] = []
         self.op_iters_hist: list[int] = []
         self.iteration = 0
+        if self.op.solver != "newton":
+            self._ensure_admm()
         # dual Newton path: R itself (d = R^T y; candidate rows of K), and R^T with the rows
         # of nodes without residences zeroed (v = R p is constrained where residences are)
         has = (counts > 0).astype(np.float64)
@@ -301,6 +260,64 @@ class AdmmEngine:
         self.R32 = up(Rn.astype(np.float32))
         self.node_load = torch.zeros(M, T, **f32)
         self.volt = torch.zeros(M, T, **f32)
+
+    def _ensure_admm(self):
+        """State of the ADMM forms (eigendecomposition of the scaled R on the host, per-home
+        double arrays): built on first use -- the default dual Newton path never needs it."""
+        if self._admm_ready:
+            return
+        self._admm_ready = True
+        Rn, counts = self._Rn_host, self._counts_host
+        n, T, M = self.n, self.T, self.M
+        f64 = dict(dtype=torch.float64, device=self.dev)
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
+        # Voltage row m is scaled by sqrt(n_m) (bounds too), so the operator matrix
+        # D^1/2 R D^1/2 is symmetric PSD = Q L Q^T: one factor serves C_v and C_v^T.
+        # Nodes without residences get a zero row: voltage is constrained where
+        # residences are, as in the reference (R_res, lpsolver.py:188-189).
+        sq = np.sqrt(counts.astype(np.float64))
+        lam, Q = np.linalg.eigh(sq[:, None] * Rn * sq[None, :])
+        lam = np.maximum(lam, 0.0)
+        self.smax = float(lam.max())
+        self.Q, self.QT = up(Q), up(Q.T)
+        # the scaled sensitivity matrix itself, for the one-product voltage check Rs.p0
+        self.Rs = up((Q * lam[None, :]) @ Q.T)
+        self.s = up(lam)
+        self.sqrt_n = up(sq)
+        self.inv_sqrt_n = up(np.where(counts > 0, 1.0 / np.maximum(sq, 1e-300), 0.0))
+        self.g0 = torch.zeros(n, T, **f64)
+        self.sb = torch.zeros(n, T, **f64)             # z_b + y_b of the g >= 0 rows
+        nz = lambda: torch.zeros(M, T, **f64)
+        (self.zv, self.yv, self.cx, self.w, self.rhat, self.xc, self.a, self.sa,
+         self.cty) = (nz() for _ in range(9))
+        # GEMM outputs come as K-split partial slabs (summed by the node kernels): enough
+        # workgroups to fill 256 CUs even when M/32 row tiles x 2 products is below that
+        self.cat = 2 * T <= 192                        # [rhat | w] in one product
+        ncol = 2 * T if self.cat else T
+        tiles = ((M + 31) // 32 if ncol <= 48 else (M + 15) // 16) * (1 if self.cat else 2)
+        self.ksplit = int(min(8, max(1, -(-256 // tiles))))
+        nzs = lambda: torch.zeros(self.ksplit, M, T, **f64)
+        self.ta, self.tb, self.va, self.usa = nzs(), nzs(), nzs(), nzs()
+        # node-space fast path
+        nz1 = lambda: torch.zeros(self.ksplit1, M, T, **f64)
+        self.f_wh, self.f_zt = nz1(), nz1()
+        (self.p0, self.gmin, self.ph0, self.xh, self.sx, self.dnode, self.slack) = (nz() for _ in range(7))
+        self.f_stats = torch.zeros(2, **f64)
+        self.rho_f = torch.full((T,), self.op.rho_v_scale * self.kappa / self.smax ** 2, **f64)
+        self._dnode_zero = False
+        # exact presolve of the fast path (see revs_op_node_prep): needs R >= 0 and vlo <= 0
+        self.preclamp = int(bool(Rn.min() >= 0.0 and self.vlo <= 0.0))
+        self._fast_wait = 0
+        self._fast_backoff = 1
+        self._fast_cal = False
+        self._fgraph = None
+        self._fgraph_warm = False
+        self.rho_v = torch.full((T,), self.op.rho_v_scale * self.kappa / self.smax ** 2, **f64)
+        self.rho_b = torch.full((T,), self.op.rho_b_scale * self.kappa, **f64)
+        self.res_out = torch.zeros(8, T, **f64)
+        self._calibrated = False
+        self._graph = None
+        self._graph_warm = False
 
     # ------------------------------------------------------------------ util
     @property
@@ -766,6 +783,7 @@ class AdmmEngine:
                 return True
             self._fast_cold = True
             self.op_cold = True
+        self._ensure_admm()
         if self._fast_ok:
             if self._fast_wait > 0:
                 self._fast_wait -= 1

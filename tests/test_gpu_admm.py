@@ -307,17 +307,21 @@ def test_full_size_invariants(gpu_lib):
 
 
 
-def test_relaxed_trajectory_T96(gpu_lib):
-    """15-minute slots (BASELINE config 4/5 shape): T = 96 uses the 32-lane home groups and
-    the 192-column concatenated product; trajectory vs oracle as for T = 24."""
+@pytest.mark.parametrize("solver", ["newton", "admm"])
+def test_relaxed_trajectory_T96(gpu_lib, solver):
+    """15-minute slots (BASELINE config 4/5 shape): T = 96 uses the 32-lane home groups, 96
+    independent slot problems in the dual Newton path and the 192-column concatenated product
+    in the ADMM forms; trajectory vs oracle as for T = 24."""
     from helpers import f32, oracle_homes
     from oracle import revs_oracle as ro
     from revs_admm_amd.synthetic import make_workload
     w = make_workload(300, 96, n_nodes=40, seed=17, binary_feasible=False, stress=0.9)
     w.load, w.cost = f32(w.load), f32(w.cost)
-    e = _engine(w, "pdhg")
-    assert e.cat and e.T == 96
+    from revs_admm_amd.engine import OperatorOptions
+    e = _engine(w, "pdhg", op=OperatorOptions(solver=solver))
+    assert e.T == 96 and (solver == "newton" or e.cat)
     diffs = e.run(5)
+    assert set(e.op_path_hist) == ({"dual"} if solver == "newton" else {"node", "home"} & set(e.op_path_hist))
     P_sch, S, C = e.result()
     d_ref, P_ref, S_ref, C_ref = ro.solve_ADMM(oracle_homes(w), w.Rn, w.node_of, w.cost, w.kappa, 5,
                                                w.vset, w.vlow, w.vhigh, mode="relaxed",
