@@ -10,7 +10,8 @@
  * pointers unless the name ends in `_host`.  Every entry point returns 0 on
  * success and a negative REVS_E* code otherwise; revs_last_error() gives the text.
  * Nothing here allocates, frees or synchronises: every entry point only enqueues
- * kernels on `stream` and is safe under hipGraph capture.
+ * kernels on `stream` and is safe under hipGraph capture -- except the revs_plan_*
+ * functions at the end (they own one hipEvent and revs_plan_spec_step waits on it).
  *
  * Layout in HBM: home-major, slot-contiguous.  A "profile" is float[n_homes][T].
  */
@@ -362,7 +363,9 @@ int revs_op_export(int64_t n_homes, int32_t T, const double *sb, float *p_est, v
  *                        upper row, -1 lower row), gradient v - b, current y;
  *                        stats double[T][8]: [0] largest |v - b| over rows with y != 0 and
  *                        bound violation over the others, [1] D_t, [2] rows with y != 0,
- *                        [3] violated rows with y = 0 ([4] is left to revs_op_dual_step).
+ *                        [3] violated rows with y = 0 ([4] is left to revs_op_dual_step),
+ *                        [5] = seq, written last behind a system-scope fence: when stats is
+ *                        pinned host memory the host may poll it instead of an event.
  *                        vfull double[m][T] receives v; viol double[m][T] and partial
  *                        double[revs_op_dual_blocks(m)][T][4] are workspace.
  *   revs_op_dual_model   the model of every slot: K = R_F N R_F^T / kappa over its candidates
@@ -383,7 +386,7 @@ int revs_op_dual_select(int32_t m, int32_t T, int32_t nslab, const double *vsl,
                         const double *pnq, const double *y, double vlo, double vhi,
                         int32_t kadd, double *vfull, double *viol, double *partial,
                         int64_t *cand_idx, int32_t *cand_cnt, double *cand_val, double *stats,
-                        void *stream);
+                        double seq, void *stream);
 int revs_op_dual_model(int32_t m, int32_t T, const double *R, const double *n_free,
                        const int64_t *cand_idx, const int32_t *cand_cnt, const double *cand_val,
                        double kappa, double delta, int32_t max_pivots, int32_t nks,
@@ -399,11 +402,47 @@ int revs_op_dual_evaluate(int32_t phase, int32_t m, int32_t T, const int64_t *no
                           double kappa, double vlo, double vhi, int32_t kadd, int32_t ksplit,
                           double *d_slabs, double *v_slabs, double *pnq, float *p_est_new,
                           double *vfull, double *viol, double *partial, int64_t *cand_idx,
-                          int32_t *cand_cnt, double *cand_val, double *stats,
+                          int32_t *cand_cnt, double *cand_val, double *stats, double seq,
                           double *stats_host, void *stream);
 int revs_op_dual_step(int32_t T, const int64_t *cand_idx, const int32_t *cand_cnt,
                       const double *cand_val, const double *yhat, const double *alpha,
                       double *y_trial, double *lin_out, void *stream);
+
+/* ---- steady-state ADMM iteration as one host call ---------------------------------
+ * The driver's loop of lpsolver.py:254-287 for the case "the operator's multipliers are
+ * expected to stand" (revs_admm_amd/engine.py: AdmmEngine.step): enqueue one evaluation of
+ * the operator's dual (revs_op_dual_evaluate, phase 3) and, right behind it, the home sweep
+ * with P_sch[k+1], G[k+1] going to spare buffers (revs_agent_step_out); then wait for the
+ * evaluation's stats only and report the largest row residual.  The caller keeps the
+ * sweep's output iff that residual is within tolerance, else finishes the Newton solve and
+ * runs the sweep again.  The plan holds the pointers that do not change between iterations;
+ * the ping-pong buffers are passed per call.  One GPU only (a sharded driver has an
+ * all-reduce between the two phases of the evaluation and uses the separate calls). */
+typedef struct {
+    int64_t n_homes; int32_t m; int32_t T;
+    const int64_t *node_ptr;
+    const double *R; const double *Rt;
+    double kappa, vlo, vhi;
+    int32_t kadd, ksplit;
+    double *d_slabs, *v_slabs, *pnq, *vfull, *viol, *partial;
+    int64_t *cand_idx; int32_t *cand_cnt; double *cand_val;
+    double *stats;               /* device-side address of stats_host */
+    const double *stats_host;    /* pinned host memory, double[T][8] */
+    const float *cost; const revs_home_t *homes; const float *load;
+    float *diff, *partials; int32_t *status; float *pdhg_dual;
+    int32_t mode;
+    revs_pdhg_t pdhg;
+} revs_plan_desc_t;
+typedef struct revs_plan revs_plan_t;
+revs_plan_t *revs_plan_create(const revs_plan_desc_t *desc_host);
+void revs_plan_destroy(revs_plan_t *plan);
+/* rmax_out_host: largest entry [t][0] of stats (row residual, absolute).  ev_mid / ev_end:
+ * optional hipEvent_t handles recorded between evaluation and sweep / after the sweep. */
+int revs_plan_spec_step(revs_plan_t *plan, const double *y, int32_t use_y,
+                        const float *p_est, float *p_est_new, const float *p_sch,
+                        const float *gamma, float *p_sch_out, float *gamma_out,
+                        float *s_out, float *c_out, double *rmax_out_host,
+                        void *ev_mid, void *ev_end, void *stream);
 
 #ifdef __cplusplus
 }

@@ -29,6 +29,21 @@ class PDHG(C.Structure):
                 ("tau_scale", C.c_float), ("sigma_scale", C.c_float), ("full_rows", C.c_int32)]
 
 
+class PlanDesc(C.Structure):
+    """revs_plan_desc_t"""
+    _fields_ = [("n_homes", C.c_int64), ("m", C.c_int32), ("T", C.c_int32),
+                ("node_ptr", C.c_void_p), ("R", C.c_void_p), ("Rt", C.c_void_p),
+                ("kappa", C.c_double), ("vlo", C.c_double), ("vhi", C.c_double),
+                ("kadd", C.c_int32), ("ksplit", C.c_int32),
+                ("d_slabs", C.c_void_p), ("v_slabs", C.c_void_p), ("pnq", C.c_void_p),
+                ("vfull", C.c_void_p), ("viol", C.c_void_p), ("partial", C.c_void_p),
+                ("cand_idx", C.c_void_p), ("cand_cnt", C.c_void_p), ("cand_val", C.c_void_p),
+                ("stats", C.c_void_p), ("stats_host", C.c_void_p),
+                ("cost", C.c_void_p), ("homes", C.c_void_p), ("load", C.c_void_p),
+                ("diff", C.c_void_p), ("partials", C.c_void_p), ("status", C.c_void_p),
+                ("pdhg_dual", C.c_void_p), ("mode", C.c_int32), ("pdhg", PDHG)]
+
+
 class RevsError(RuntimeError):
     pass
 
@@ -41,6 +56,10 @@ SIGNATURES = {
     "revs_version": (C.c_char_p, []),
     "revs_last_error": (C.c_char_p, []),
     "revs_host_device_ptr": (C.c_int, [_p, C.POINTER(C.c_void_p)]),
+    "revs_plan_create": (C.c_void_p, [C.POINTER(PlanDesc)]),
+    "revs_plan_destroy": (None, [_p]),
+    "revs_plan_spec_step": (C.c_int, [_p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p,
+                                      C.POINTER(C.c_double), _p, _p, _p]),
     "revs_pdhg_defaults": (None, [C.POINTER(PDHG)]),
     "revs_agent_num_partials": (_i64, [_i64, _i32]),
     "revs_agent_step": (C.c_int, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
@@ -81,12 +100,12 @@ SIGNATURES = {
     "revs_op_dual_eval": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _i32, _p, _f64, _p, _p, _p]),
     "revs_op_dual_blocks": (_i32, [_i32]),
     "revs_op_dual_select": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _f64, _f64, _i32, _p, _p, _p,
-                                      _p, _p, _p, _p, _p]),
+                                      _p, _p, _p, _p, _f64, _p]),
     "revs_op_dual_model": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p, _f64, _f64, _i32, _i32, _p,
                                      _p, _p, _p, _p]),
     "revs_op_dual_evaluate": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _i32, _f64,
                                         _f64, _f64, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p,
-                                        _p, _p, _p, _p]),
+                                        _p, _p, _f64, _p, _p]),
     "revs_op_dual_step": (C.c_int, [_i32, _p, _p, _p, _p, _p, _p, _p, _p]),
 }
 DUAL_AMAX = 128          # REVS_DUAL_AMAX

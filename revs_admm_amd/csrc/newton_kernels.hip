@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void op_dual_select_kernel(
         int m, int T, int nblk, const double *__restrict__ partial, const double *__restrict__ y,
         double vlo, double vhi, int kadd, const double *__restrict__ vfull,
         const double *__restrict__ viol, int64_t *__restrict__ cidx, int32_t *__restrict__ ccnt,
-        double *__restrict__ cval, double *__restrict__ stats) {
+        double *__restrict__ cval, double *__restrict__ stats, double seq) {
     const int t = blockIdx.x, tid = threadIdx.x;
     __shared__ int cnt_s[256];
     __shared__ double red_s[4][4];
@@ -167,6 +167,10 @@ __global__ __launch_bounds__(256) void op_dual_select_kernel(
         stats[t * 8 + 1] = ((red_s[1][0] + red_s[1][1]) + red_s[1][2]) + red_s[1][3];
         stats[t * 8 + 2] = (double)ns;
         stats[t * 8 + 3] = (double)nv;
+        // stats may live in pinned host memory: a host that polls [5] for this evaluation's
+        // sequence number sees [0..3] complete (system-scope release before the tag)
+        __threadfence_system();
+        reinterpret_cast<volatile double *>(stats)[t * 8 + 5] = seq;
     }
     int64_t *ci = cidx + (int64_t)t * kAmax;
     double *cs = cval + (int64_t)t * 3 * kAmax, *cg = cs + kAmax, *cy = cg + kAmax;
@@ -546,7 +550,7 @@ extern "C" int revs_op_dual_select(int32_t m, int32_t T, int32_t nslab, const do
                                    const double *pnq, const double *y, double vlo, double vhi,
                                    int32_t kadd, double *vfull, double *viol, double *partial,
                                    int64_t *cand_idx, int32_t *cand_cnt, double *cand_val,
-                                   double *stats, void *stream) {
+                                   double *stats, double seq, void *stream) {
     REVS_REQUIRE(m <= 16384, "revs_op_dual_select: m=%d exceeds 16384 rows", m);
     REVS_REQUIRE(m > 0 && T > 0 && T <= 256 && nslab >= 1 && vsl && pnq && y && vfull && viol &&
                  partial && cand_idx && cand_cnt && cand_val && stats && vlo <= vhi && kadd >= 0,
@@ -561,7 +565,7 @@ extern "C" int revs_op_dual_select(int32_t m, int32_t T, int32_t nslab, const do
     else RW(256);
 #undef RW
     hipLaunchKernelGGL(op_dual_select_kernel, dim3(T), dim3(256), 0, S_(stream), m, T, nblk,
-                       partial, y, vlo, vhi, kadd, vfull, viol, cand_idx, cand_cnt, cand_val, stats);
+                       partial, y, vlo, vhi, kadd, vfull, viol, cand_idx, cand_cnt, cand_val, stats, seq);
     REVS_CHECK_LAUNCH("revs_op_dual_select");
     return REVS_OK;
 }
@@ -615,7 +619,8 @@ extern "C" int revs_op_dual_evaluate(int32_t phase, int32_t m, int32_t T, const 
                                      double *v_slabs, double *pnq, float *p_est_new,
                                      double *vfull, double *viol, double *partial,
                                      int64_t *cand_idx, int32_t *cand_cnt, double *cand_val,
-                                     double *stats, double *stats_host, void *stream) {
+                                     double *stats, double seq, double *stats_host,
+                                     void *stream) {
     REVS_REQUIRE(phase >= 1 && phase <= 3 && y && pnq, "revs_op_dual_evaluate: bad argument");
     int rc;
     if (phase & 1) {
@@ -633,7 +638,7 @@ extern "C" int revs_op_dual_evaluate(int32_t phase, int32_t m, int32_t T, const 
         rc = revs_gemm_tn_f64_split(m, T, m, Rt, pnq, v_slabs, ksplit, stream);
         if (rc != REVS_OK) return rc;
         rc = revs_op_dual_select(m, T, ksplit, v_slabs, pnq, y, vlo, vhi, kadd, vfull, viol,
-                                 partial, cand_idx, cand_cnt, cand_val, stats, stream);
+                                 partial, cand_idx, cand_cnt, cand_val, stats, seq, stream);
         if (rc != REVS_OK) return rc;
         if (stats_host) {
             const hipError_t e = hipMemcpyAsync(stats_host, stats, sizeof(double) * 8 * T,

@@ -1,6 +1,8 @@
 // Error reporting and version string of librevs_admm.so.
 #include "common.h"
 #include <stdarg.h>
+#include <atomic>
+#include <chrono>
 
 namespace revs {
 static thread_local char g_err[512] = "";
@@ -24,5 +26,79 @@ extern "C" int revs_host_device_ptr(void *host_ptr, void **dev_ptr) {
         revs::set_error("revs_host_device_ptr: %s", hipGetErrorString(e));
         return REVS_EINVAL;
     }
+    return REVS_OK;
+}
+
+// ---- steady-state ADMM iteration as one host call (see revs_admm.h) -------------------
+struct revs_plan {
+    revs_plan_desc_t d;
+    hipEvent_t ev;
+    double seq;
+};
+
+extern "C" revs_plan_t *revs_plan_create(const revs_plan_desc_t *desc) {
+    if (!desc || !desc->stats || !desc->stats_host || !desc->pnq || desc->T <= 0 || desc->m <= 0) {
+        revs::set_error("revs_plan_create: bad descriptor");
+        return nullptr;
+    }
+    revs_plan *p = new revs_plan{*desc, nullptr, 0.0};
+    if (hipEventCreateWithFlags(&p->ev, hipEventDisableTiming) != hipSuccess) {
+        revs::set_error("revs_plan_create: hipEventCreate failed");
+        delete p;
+        return nullptr;
+    }
+    return p;
+}
+
+extern "C" void revs_plan_destroy(revs_plan_t *plan) {
+    if (!plan) return;
+    (void)hipEventDestroy(plan->ev);
+    delete plan;
+}
+
+extern "C" int revs_plan_spec_step(revs_plan_t *plan, const double *y, int32_t use_y,
+                                   const float *p_est, float *p_est_new, const float *p_sch,
+                                   const float *gamma, float *p_sch_out, float *gamma_out,
+                                   float *s_out, float *c_out, double *rmax_out, void *ev_mid,
+                                   void *ev_end, void *stream) {
+    REVS_REQUIRE(plan && y && p_est && p_est_new && p_sch && gamma && p_sch_out && gamma_out &&
+                 rmax_out, "revs_plan_spec_step: null argument");
+    const revs_plan_desc_t &d = plan->d;
+    hipStream_t s = (hipStream_t)stream;
+    const double seq = (plan->seq += 1.0);
+    int rc = revs_op_dual_evaluate(3, d.m, d.T, d.node_ptr, p_est, p_sch, gamma, d.R, d.Rt, y, use_y,
+                                   d.kappa, d.vlo, d.vhi, d.kadd, d.ksplit, d.d_slabs, d.v_slabs,
+                                   d.pnq, p_est_new, d.vfull, d.viol, d.partial, d.cand_idx,
+                                   d.cand_cnt, d.cand_val, d.stats, seq, nullptr, stream);
+    if (rc != REVS_OK) return rc;
+    if (ev_mid) (void)hipEventRecord((hipEvent_t)ev_mid, s);
+    rc = revs_agent_step_out(d.n_homes, d.T, d.cost, d.homes, d.load, p_est, p_est_new, p_sch, gamma,
+                             p_sch_out, gamma_out, s_out, c_out, d.diff, d.partials, d.status,
+                             d.pdhg_dual, (float)d.kappa, d.mode, &d.pdhg, stream);
+    if (rc != REVS_OK) return rc;
+    if (ev_end) (void)hipEventRecord((hipEvent_t)ev_end, s);
+    // Wait for the evaluation, not the sweep: poll the sequence tag the select kernel writes
+    // into the pinned stats block of every slot (lower latency than an event wait).
+    const volatile double *st = d.stats_host;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int t = 0; t < d.T; ++t) {
+        unsigned spins = 0;
+        while (st[8 * t + 5] != seq) {
+            if ((++spins & 0xFFFF) == 0) {
+                if (hipStreamQuery(s) == hipSuccess && st[8 * t + 5] != seq) {
+                    revs::set_error("revs_plan_spec_step: stream idle but stats tag missing");
+                    return REVS_ELAUNCH;
+                }
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+                    revs::set_error("revs_plan_spec_step: timed out waiting for the evaluation");
+                    return REVS_ELAUNCH;
+                }
+            }
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    double mx = 0.0;
+    for (int t = 0; t < d.T; ++t) mx = st[8 * t] > mx ? st[8 * t] : mx;
+    *rmax_out = mx;
     return REVS_OK;
 }

@@ -313,7 +313,7 @@ class FakeKernels:
 
     def revs_op_dual_evaluate(self, phase, m, T, node_ptr, pe, ps, gm, R, Rt, y, use_y, kappa, vlo,
                               vhi, kadd, ksplit, d_sl, v_sl, pnq, pe_new, vfull, viol, partial,
-                              cidx, ccnt, cval, stats, stats_host, stream):
+                              cidx, ccnt, cval, stats, seq, stats_host, stream):
         if phase & 1:
             if use_y:
                 self.revs_gemm_tn_f64_split(m, T, m, R, y, d_sl, ksplit, stream)
@@ -322,7 +322,7 @@ class FakeKernels:
         if phase & 2:
             self.revs_gemm_tn_f64_split(m, T, m, Rt, pnq, v_sl, ksplit, stream)
             self.revs_op_dual_select(m, T, ksplit, v_sl, pnq, y, vlo, vhi, kadd, vfull, viol,
-                                     partial, cidx, ccnt, cval, stats, stream)
+                                     partial, cidx, ccnt, cval, stats, seq, stream)
             if stats_host:
                 view(stats_host, (T, 8), np.float64)[:] = view(stats, (T, 8), np.float64)
         return 0
@@ -331,7 +331,7 @@ class FakeKernels:
         return min(256, (m + 7) // 8)
 
     def revs_op_dual_select(self, m, T, nslab, vsl, pnq, y, vlo, vhi, kadd, vfull, viol, partial,
-                            cidx, ccnt, cval, stats, stream):
+                            cidx, ccnt, cval, stats, seq, stream):
         A = DUAL_AMAX
         v = view(vsl, (nslab, m, T), np.float64).sum(axis=0)
         view(vfull, (m, T), np.float64)[:] = v
@@ -347,6 +347,7 @@ class FakeKernels:
         st[:, 1] = (q - np.maximum(vhi * yv, vlo * yv)).sum(axis=0)
         st[:, 2] = (yv != 0).sum(axis=0)
         st[:, 3] = ((yv == 0) & (vi > 0)).sum(axis=0)
+        st[:, 5] = seq
         ci[:] = 0
         cv[:] = 0.0
         cv[:, 0, :] = 1.0

@@ -52,7 +52,7 @@ def _run_evaluate(lib, fake, xp, host_ptr, M, T, ptr_, pe, ps, gm, R, y, kappa, 
         3, M, T, p(ins["ptr"]), p(ins["pe"]), p(ins["ps"]), p(ins["gm"]), p(ins["R"]), p(ins["Rt"]),
         p(ins["y"]), 1, kappa, vlo, vhi, kadd, ks, p(bufs["d_sl"]), p(bufs["v_sl"]), p(bufs["pnq"]),
         p(bufs["pe_new"]), p(bufs["vfull"]), p(bufs["viol"]), p(bufs["part"]), p(bufs["cidx"]),
-        p(bufs["ccnt"]), p(bufs["cval"]), p(bufs["stats"]), None, None)
+        p(bufs["ccnt"]), p(bufs["cval"]), p(bufs["stats"]), 7.0, None, None)
     assert rc == 0
     return ins, bufs
 
@@ -87,6 +87,7 @@ def test_dual_evaluate_and_model_match_numpy(gpu_lib, n, M, T, n_mult):
     np.testing.assert_allclose(g["vfull"], cb["vfull"], rtol=1e-11, atol=1e-13)
     np.testing.assert_allclose(g["stats"][:, :2], cb["stats"][:, :2], rtol=1e-10)
     np.testing.assert_array_equal(g["stats"][:, 2:4], cb["stats"][:, 2:4])
+    assert (g["stats"][:, 5] == 7.0).all()                                 # the sequence tag
     assert (g["stats"][:, 2] == min(n_mult, M)).all() and (g["stats"][:, 3] > 0).any()
     # candidates: same rows in the same order, same signs, gradients, multipliers
     np.testing.assert_array_equal(g["ccnt"], cb["ccnt"])
