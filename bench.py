@@ -93,7 +93,7 @@ def cpu_baseline(w, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--spinup", type=int, default=30,
                     help="ADMM iterations run (untimed, but reported) before the warm-up so that "

@@ -131,6 +131,24 @@ int revs_agent_step_out(int64_t n_homes, int32_t T,
                         float kappa, int32_t mode, const revs_pdhg_t *pdhg_host,
                         void *stream);
 
+/* revs_agent_step_out with the operator's candidate selection (the second kernel of
+ * revs_op_dual_select; arguments as there, T slots) running as the first T workgroups of the
+ * same launch: independent of the sweep, it overlaps it and its stats -- the operator's
+ * verdict -- reach the host while the sweep is still running.  The caller must have run
+ * revs_op_dual_evaluate with phase bits 2|4 (rows done, selection deferred) before. */
+int revs_agent_step_select(int64_t n_homes, int32_t T,
+                           const float *cost, const revs_home_t *homes, const float *load,
+                           const float *p_est_old, const float *p_est_new,
+                           const float *p_sch, const float *gamma,
+                           float *p_sch_out, float *gamma_out,
+                           float *s_out, float *c_out, float *diff,
+                           float *partials, int32_t *status, float *pdhg_dual,
+                           float kappa, int32_t mode, const revs_pdhg_t *pdhg_host,
+                           int32_t m, const double *sel_partial, const double *y, double vlo,
+                           double vhi, int32_t kadd, const double *vfull, const double *viol,
+                           int64_t *cand_idx, int32_t *cand_cnt, double *cand_val,
+                           double *stats, double seq, void *stream);
+
 /* Wavefront reduction of the per-workgroup partials to the global ADMM residuals
  *   out[0] = |P_est[k+1] - P_sch[k+1]|_2           (primal residual, all homes)
  *   out[1] = kappa * |P_sch[k+1] - P_sch[k]|_2     (dual residual)
@@ -394,7 +412,8 @@ int revs_op_dual_model(int32_t m, int32_t T, const double *R, const double *n_fr
                        void *stream);
 /* One evaluation as a single host call: phase bit 0 = [R^T y into d_slabs when use_y,]
  * revs_op_dual_eval; phase bit 1 = R p into v_slabs (Rt = R^T, row-major), revs_op_dual_select,
- * and an asynchronous copy of stats to stats_host (pinned HOST memory, double[T][8], or NULL).
+ * and an asynchronous copy of stats to stats_host (pinned HOST memory, double[T][8], or NULL);
+ * with phase bit 2 (value 4) the selection kernel is left to revs_agent_step_select.
  * A driver that shards residences runs phase 1, all-reduces pnq, then phase 2. */
 int revs_op_dual_evaluate(int32_t phase, int32_t m, int32_t T, const int64_t *node_ptr,
                           const float *p_est, const float *p_sch, const float *gamma,

@@ -21,6 +21,7 @@
 // float per workgroup and in double by residual_finalize_kernel, which also takes
 // the maximum of diff over all homes (the reference's only convergence measure).
 #include "common.h"
+#include "select_body.h"
 #include <math.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -47,6 +48,11 @@ struct AgentArgs {
     float *y_state;
     float kappa;
     revs_pdhg_t pd;
+    // nsel > 0: the first nsel workgroups of the launch run the operator's candidate
+    // selection (one slot each, select_body.h) instead of homes -- independent work that
+    // overlaps the sweep and delivers the operator's verdict while the sweep is running
+    int32_t nsel;
+    SelectArgs sel;
 };
 
 // SPL consecutive floats of one lane as ONE global_load/store_dwordxSPL: the 64 lanes of a
@@ -96,9 +102,14 @@ __device__ __forceinline__ void group_rank(const float (&key)[SPL], int t0, int 
 template <int LPA, int SPL, int MODE, bool FULL_ROWS = false>
 __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
     constexpr int kHomesPerBlock = kBlock / LPA;
+    if (a.nsel > 0 && (int)blockIdx.x < a.nsel) {          // uniform per workgroup
+        dual_select_body(a.sel, (int)blockIdx.x);
+        return;
+    }
+    const int bid = (int)blockIdx.x - a.nsel;
     const int tid = threadIdx.x;
     const int lig = tid & (LPA - 1);
-    const int64_t agent = (int64_t)blockIdx.x * kHomesPerBlock + tid / LPA;
+    const int64_t agent = (int64_t)bid * kHomesPerBlock + tid / LPA;
     const bool live = agent < a.n;
     const int T = a.T;
     const int t0 = lig * SPL;
@@ -439,9 +450,9 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
         for (int w = 0; w < kBlock / 64; ++w) {
             s0 += red[0][w]; s1 += red[1][w]; s2 = fmaxf(s2, red[2][w]);
         }
-        a.partials[3 * (int64_t)blockIdx.x + 0] = s0;
-        a.partials[3 * (int64_t)blockIdx.x + 1] = s1;
-        a.partials[3 * (int64_t)blockIdx.x + 2] = s2;
+        a.partials[3 * (int64_t)bid + 0] = s0;
+        a.partials[3 * (int64_t)bid + 1] = s1;
+        a.partials[3 * (int64_t)bid + 2] = s2;
     }
 }
 
@@ -605,14 +616,14 @@ extern "C" int64_t revs_agent_num_partials(int64_t n_homes, int32_t T) {
     return (n_homes + per - 1) / per;
 }
 
-extern "C" int revs_agent_step_out(int64_t n_homes, int32_t T, const float *cost,
-                                   const revs_home_t *homes, const float *load,
-                                   const float *p_est_old, const float *p_est_new,
-                                   const float *p_sch, const float *gamma, float *p_sch_out,
-                                   float *gamma_out, float *s_out, float *c_out, float *diff,
-                                   float *partials, int32_t *status, float *pdhg_dual,
-                                   float kappa, int32_t mode, const revs_pdhg_t *pdhg_host,
-                                   void *stream) {
+static int agent_step_impl(int64_t n_homes, int32_t T, const float *cost,
+                           const revs_home_t *homes, const float *load,
+                           const float *p_est_old, const float *p_est_new,
+                           const float *p_sch, const float *gamma, float *p_sch_out,
+                           float *gamma_out, float *s_out, float *c_out, float *diff,
+                           float *partials, int32_t *status, float *pdhg_dual,
+                           float kappa, int32_t mode, const revs_pdhg_t *pdhg_host,
+                           const SelectArgs *sel, void *stream) {
     REVS_REQUIRE(n_homes > 0, "revs_agent_step: n_homes=%lld", (long long)n_homes);
     REVS_REQUIRE(T > 0 && T <= REVS_MAX_T, "revs_agent_step: T=%d outside 1..%d", T, REVS_MAX_T);
     REVS_REQUIRE(cost && homes && load && p_est_old && p_est_new && p_sch && gamma && p_sch_out &&
@@ -626,19 +637,56 @@ extern "C" int revs_agent_step_out(int64_t n_homes, int32_t T, const float *cost
     a.ps_out = p_sch_out; a.gam_out = gamma_out;
     a.s_out = s_out; a.c_out = c_out; a.diff = diff; a.partials = partials;
     a.status = status; a.y_state = pdhg_dual; a.kappa = kappa;
+    a.nsel = 0;
+    a.sel = SelectArgs{};
+    if (sel) { a.nsel = sel->T; a.sel = *sel; }
     if (pdhg_host) a.pd = *pdhg_host; else revs_pdhg_defaults(&a.pd);
     REVS_REQUIRE(a.pd.max_iter > 0 && a.pd.check > 0 && a.pd.tau_scale >= 0 && a.pd.sigma_scale >= 0,
                  "revs_agent_step: bad PDHG parameters");
     const Shape sh = pick_shape(T);
     const int64_t nblk = revs_agent_num_partials(n_homes, T);
     REVS_REQUIRE(nblk < (1ll << 31), "revs_agent_step: too many homes for one launch");
-    const dim3 grid((unsigned)nblk);
+    const dim3 grid((unsigned)(nblk + a.nsel));
     hipStream_t s = (hipStream_t)stream;
 #define CALL(LPA, SPL) launch_agent<LPA, SPL>(a, mode, grid, s)
     REVS_FOR_SHAPE(sh, CALL);
 #undef CALL
     REVS_CHECK_LAUNCH("revs_agent_step");
     return REVS_OK;
+}
+
+extern "C" int revs_agent_step_out(int64_t n_homes, int32_t T, const float *cost,
+                                   const revs_home_t *homes, const float *load,
+                                   const float *p_est_old, const float *p_est_new,
+                                   const float *p_sch, const float *gamma, float *p_sch_out,
+                                   float *gamma_out, float *s_out, float *c_out, float *diff,
+                                   float *partials, int32_t *status, float *pdhg_dual,
+                                   float kappa, int32_t mode, const revs_pdhg_t *pdhg_host,
+                                   void *stream) {
+    return agent_step_impl(n_homes, T, cost, homes, load, p_est_old, p_est_new, p_sch, gamma,
+                           p_sch_out, gamma_out, s_out, c_out, diff, partials, status, pdhg_dual,
+                           kappa, mode, pdhg_host, nullptr, stream);
+}
+
+extern "C" int revs_agent_step_select(int64_t n_homes, int32_t T, const float *cost,
+                                      const revs_home_t *homes, const float *load,
+                                      const float *p_est_old, const float *p_est_new,
+                                      const float *p_sch, const float *gamma, float *p_sch_out,
+                                      float *gamma_out, float *s_out, float *c_out, float *diff,
+                                      float *partials, int32_t *status, float *pdhg_dual,
+                                      float kappa, int32_t mode, const revs_pdhg_t *pdhg_host,
+                                      int32_t m, const double *sel_partial, const double *y,
+                                      double vlo, double vhi, int32_t kadd, const double *vfull,
+                                      const double *viol, int64_t *cand_idx, int32_t *cand_cnt,
+                                      double *cand_val, double *stats, double seq, void *stream) {
+    REVS_REQUIRE(m > 0 && m <= 16384 && sel_partial && y && vfull && viol && cand_idx && cand_cnt &&
+                 cand_val && stats && vlo <= vhi && kadd >= 0,
+                 "revs_agent_step_select: bad selection argument");
+    const SelectArgs sa{m, T, revs_op_dual_blocks(m), kadd, sel_partial, y, vfull, viol, vlo, vhi,
+                        seq, cand_idx, cand_cnt, cand_val, stats};
+    return agent_step_impl(n_homes, T, cost, homes, load, p_est_old, p_est_new, p_sch, gamma,
+                           p_sch_out, gamma_out, s_out, c_out, diff, partials, status, pdhg_dual,
+                           kappa, mode, pdhg_host, &sa, stream);
 }
 
 extern "C" int revs_agent_step(int64_t n_homes, int32_t T, const float *cost,

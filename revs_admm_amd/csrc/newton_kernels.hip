@@ -19,23 +19,9 @@
 // per evaluation, and a run needs 5-15 evaluations where the ADMM form needed 10^2-10^4
 // iterations of the same cost.
 #include "common.h"
+#include "select_body.h"
 
 namespace revs {
-
-constexpr int kAmax = REVS_DUAL_AMAX;
-static_assert(kAmax == 128, "candidate sets are two 64-bit words / two wavefronts");
-constexpr int kWords = kAmax / 64;
-
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
-__device__ __forceinline__ double wave_max_d(double v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = fmax(v, __shfl_xor(v, d, 64));
-    return v;
-}
 
 // ---- home pass: p, N, -(kappa/2) sum g^2 per node and slot; P_est_new = g ----------
 // Mapping as op_home_pass_kernel: one workgroup per node, TL slot lanes x HS home lanes,
@@ -132,112 +118,9 @@ __global__ __launch_bounds__(256) void op_dual_rows_kernel(
     }
 }
 
-// Stage 2, one workgroup per slot: fold the partials (fixed order), and -- only for a slot
-// that has multipliers or violated rows -- build its candidate list.  Thread j owns the
-// contiguous rows [j R, (j+1) R), R = ceil(m/256), so the rows with a multiplier are
-// compacted in row order (deterministic: every rank builds the same lists); the most
-// violated rows without a multiplier are appended by `kadd` rounds of a block-wide
-// arg-max (ties to the lower row).
-__global__ __launch_bounds__(256) void op_dual_select_kernel(
-        int m, int T, int nblk, const double *__restrict__ partial, const double *__restrict__ y,
-        double vlo, double vhi, int kadd, const double *__restrict__ vfull,
-        const double *__restrict__ viol, int64_t *__restrict__ cidx, int32_t *__restrict__ ccnt,
-        double *__restrict__ cval, double *__restrict__ stats, double seq) {
-    const int t = blockIdx.x, tid = threadIdx.x;
-    __shared__ int cnt_s[256];
-    __shared__ double red_s[4][4];
-    __shared__ double best_v[4];
-    __shared__ int best_i[4];
-    {
-        double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
-        for (int k = tid; k < nblk; k += 256) {
-            const double *o = partial + ((int64_t)k * T + t) * 4;
-            a = fmax(a, o[0]); b += o[1]; c += o[2]; d += o[3];
-        }
-        a = wave_max_d(a); b = wave_sum_d(b); c = wave_sum_d(c); d = wave_sum_d(d);
-        if ((tid & 63) == 0) {
-            red_s[0][tid >> 6] = a; red_s[1][tid >> 6] = b; red_s[2][tid >> 6] = c; red_s[3][tid >> 6] = d;
-        }
-    }
-    __syncthreads();
-    const int ns = (int)(((red_s[2][0] + red_s[2][1]) + red_s[2][2]) + red_s[2][3]);
-    const int nv = (int)(((red_s[3][0] + red_s[3][1]) + red_s[3][2]) + red_s[3][3]);
-    if (tid == 0) {
-        stats[t * 8 + 0] = fmax(fmax(red_s[0][0], red_s[0][1]), fmax(red_s[0][2], red_s[0][3]));
-        stats[t * 8 + 1] = ((red_s[1][0] + red_s[1][1]) + red_s[1][2]) + red_s[1][3];
-        stats[t * 8 + 2] = (double)ns;
-        stats[t * 8 + 3] = (double)nv;
-        // stats may live in pinned host memory: a host that polls [5] for this evaluation's
-        // sequence number sees [0..3] complete (system-scope release before the tag)
-        __threadfence_system();
-        reinterpret_cast<volatile double *>(stats)[t * 8 + 5] = seq;
-    }
-    int64_t *ci = cidx + (int64_t)t * kAmax;
-    double *cs = cval + (int64_t)t * 3 * kAmax, *cg = cs + kAmax, *cy = cg + kAmax;
-    if (ns > kAmax || (ns == 0 && nv == 0)) {   // uniform: too many multipliers / nothing to do
-        if (tid == 0) ccnt[t] = ns > kAmax ? -1 : 0;
-        if (tid < kAmax) { ci[tid] = 0; cs[tid] = 1.0; cg[tid] = 0.0; cy[tid] = 0.0; }
-        return;
-    }
-    const int per = (m + 255) / 256;
-    const int r0 = min(m, tid * per), r1 = min(m, r0 + per);
-    int nsup = 0;
-    for (int r = r0; r < r1; ++r) nsup += y[(int64_t)r * T + t] != 0.0 ? 1 : 0;
-    cnt_s[tid] = nsup;
-    __syncthreads();
-    int pos = 0;
-    for (int j = 0; j < tid; ++j) pos += cnt_s[j];
-    for (int r = r0; r < r1 && nsup > 0; ++r) {
-        const int64_t i = (int64_t)r * T + t;
-        const double yv = y[i];
-        if (yv != 0.0) {
-            ci[pos] = r;
-            cs[pos] = yv > 0.0 ? 1.0 : -1.0;
-            cg[pos] = vfull[i] - (yv > 0.0 ? vhi : vlo);
-            cy[pos] = yv;
-            ++pos;
-        }
-    }
-    const int room = min(min(kadd, kAmax - ns), nv);
-    int added = 0;
-    // Row r is always scanned by thread r % 256, which remembers in a register mask which
-    // of its rows were taken -- no global store has to become visible between rounds.
-    unsigned long long took = 0ull;
-    for (int k = 0; k < room; ++k) {
-        double bv = 0.0;
-        int bi = m;
-        for (int r = tid, i = 0; r < m; r += 256, ++i) {
-            const double x = viol[(int64_t)r * T + t];
-            if (x > bv && !((took >> i) & 1ull)) { bv = x; bi = r; }   // ascending r: ties keep the lower row
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const double ov = __shfl_xor(bv, d, 64);
-            const int oi = __shfl_xor(bi, d, 64);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-        }
-        __syncthreads();                    // best_v / best_i of the previous round were read
-        if ((tid & 63) == 0) { best_v[tid >> 6] = bv; best_i[tid >> 6] = bi; }
-        __syncthreads();
-        bv = best_v[0]; bi = best_i[0];
-#pragma unroll
-        for (int w = 1; w < 4; ++w)
-            if (best_v[w] > bv || (best_v[w] == bv && best_i[w] < bi)) { bv = best_v[w]; bi = best_i[w]; }
-        if (!(bv > 0.0)) break;             // uniform
-        if (tid == (bi & 255)) took |= 1ull << (bi >> 8);
-        if (tid == 0) {
-            const double v = vfull[(int64_t)bi * T + t];
-            const bool up = v > vhi;
-            ci[ns + added] = bi;
-            cs[ns + added] = up ? 1.0 : -1.0;
-            cg[ns + added] = v - (up ? vhi : vlo);
-            cy[ns + added] = 0.0;
-        }
-        ++added;
-    }
-    const int cnt = ns + added;
-    if (tid == 0) ccnt[t] = cnt;
-    if (tid >= cnt && tid < kAmax) { ci[tid] = 0; cs[tid] = 1.0; cg[tid] = 0.0; cy[tid] = 0.0; }
+// Stage 2 (select_body.h), one workgroup per slot, as its own kernel.
+__global__ __launch_bounds__(256) void op_dual_select_kernel(const SelectArgs sa) {
+    dual_select_body(sa, blockIdx.x);
 }
 
 // ---- model Hessian: K_t = R_F N_t R_F^T (candidates x candidates), K-split slabs ------
@@ -546,11 +429,11 @@ extern "C" int32_t revs_op_dual_blocks(int32_t m) {
     return m <= 0 ? 0 : (m + 7) / 8 < 256 ? (m + 7) / 8 : 256;
 }
 
-extern "C" int revs_op_dual_select(int32_t m, int32_t T, int32_t nslab, const double *vsl,
-                                   const double *pnq, const double *y, double vlo, double vhi,
-                                   int32_t kadd, double *vfull, double *viol, double *partial,
-                                   int64_t *cand_idx, int32_t *cand_cnt, double *cand_val,
-                                   double *stats, double seq, void *stream) {
+static int dual_rows_select(int32_t m, int32_t T, int32_t nslab, const double *vsl,
+                            const double *pnq, const double *y, double vlo, double vhi,
+                            int32_t kadd, double *vfull, double *viol, double *partial,
+                            int64_t *cand_idx, int32_t *cand_cnt, double *cand_val, double *stats,
+                            double seq, bool defer_select, void *stream) {
     REVS_REQUIRE(m <= 16384, "revs_op_dual_select: m=%d exceeds 16384 rows", m);
     REVS_REQUIRE(m > 0 && T > 0 && T <= 256 && nslab >= 1 && vsl && pnq && y && vfull && viol &&
                  partial && cand_idx && cand_cnt && cand_val && stats && vlo <= vhi && kadd >= 0,
@@ -564,10 +447,22 @@ extern "C" int revs_op_dual_select(int32_t m, int32_t T, int32_t nslab, const do
     else if (T <= 128) RW(128);
     else RW(256);
 #undef RW
-    hipLaunchKernelGGL(op_dual_select_kernel, dim3(T), dim3(256), 0, S_(stream), m, T, nblk,
-                       partial, y, vlo, vhi, kadd, vfull, viol, cand_idx, cand_cnt, cand_val, stats, seq);
+    if (!defer_select) {
+        const SelectArgs sa{m, T, nblk, kadd, partial, y, vfull, viol, vlo, vhi, seq,
+                            cand_idx, cand_cnt, cand_val, stats};
+        hipLaunchKernelGGL(op_dual_select_kernel, dim3(T), dim3(256), 0, S_(stream), sa);
+    }
     REVS_CHECK_LAUNCH("revs_op_dual_select");
     return REVS_OK;
+}
+
+extern "C" int revs_op_dual_select(int32_t m, int32_t T, int32_t nslab, const double *vsl,
+                                   const double *pnq, const double *y, double vlo, double vhi,
+                                   int32_t kadd, double *vfull, double *viol, double *partial,
+                                   int64_t *cand_idx, int32_t *cand_cnt, double *cand_val,
+                                   double *stats, double seq, void *stream) {
+    return dual_rows_select(m, T, nslab, vsl, pnq, y, vlo, vhi, kadd, vfull, viol, partial, cand_idx,
+                            cand_cnt, cand_val, stats, seq, false, stream);
 }
 
 extern "C" int revs_op_dual_model(int32_t m, int32_t T, const double *R, const double *n_free,
@@ -609,7 +504,8 @@ extern "C" int revs_op_dual_step(int32_t T, const int64_t *cand_idx, const int32
 // One evaluation of the dual function as a single host call (the driver's steady state is
 // host-bound otherwise: five launches of 3-12 us each).  phase bit 0: R^T y (when use_y)
 // and the home pass; phase bit 1: R p, row bookkeeping, candidate lists and the copy of
-// stats to pinned host memory.  A driver that shards residences runs phase 1, all-reduces
+// stats to pinned host memory; with phase bit 2 the candidate-list kernel is left to the
+// caller (revs_agent_step_select runs it inside the home sweep's launch).  A driver that shards residences runs phase 1, all-reduces
 // pnq, then runs phase 2.
 extern "C" int revs_op_dual_evaluate(int32_t phase, int32_t m, int32_t T, const int64_t *node_ptr,
                                      const float *p_est, const float *p_sch, const float *gamma,
@@ -621,7 +517,8 @@ extern "C" int revs_op_dual_evaluate(int32_t phase, int32_t m, int32_t T, const 
                                      int64_t *cand_idx, int32_t *cand_cnt, double *cand_val,
                                      double *stats, double seq, double *stats_host,
                                      void *stream) {
-    REVS_REQUIRE(phase >= 1 && phase <= 3 && y && pnq, "revs_op_dual_evaluate: bad argument");
+    REVS_REQUIRE(phase >= 1 && phase <= 7 && (!(phase & 4) || (phase & 2)) && y && pnq,
+                 "revs_op_dual_evaluate: bad argument");
     int rc;
     if (phase & 1) {
         if (use_y) {
@@ -637,8 +534,8 @@ extern "C" int revs_op_dual_evaluate(int32_t phase, int32_t m, int32_t T, const 
         REVS_REQUIRE(Rt && v_slabs, "revs_op_dual_evaluate: Rt / v_slabs missing");
         rc = revs_gemm_tn_f64_split(m, T, m, Rt, pnq, v_slabs, ksplit, stream);
         if (rc != REVS_OK) return rc;
-        rc = revs_op_dual_select(m, T, ksplit, v_slabs, pnq, y, vlo, vhi, kadd, vfull, viol,
-                                 partial, cand_idx, cand_cnt, cand_val, stats, seq, stream);
+        rc = dual_rows_select(m, T, ksplit, v_slabs, pnq, y, vlo, vhi, kadd, vfull, viol, partial,
+                              cand_idx, cand_cnt, cand_val, stats, seq, (phase & 4) != 0, stream);
         if (rc != REVS_OK) return rc;
         if (stats_host) {
             const hipError_t e = hipMemcpyAsync(stats_host, stats, sizeof(double) * 8 * T,

@@ -66,15 +66,18 @@ extern "C" int revs_plan_spec_step(revs_plan_t *plan, const double *y, int32_t u
     const revs_plan_desc_t &d = plan->d;
     hipStream_t s = (hipStream_t)stream;
     const double seq = (plan->seq += 1.0);
-    int rc = revs_op_dual_evaluate(3, d.m, d.T, d.node_ptr, p_est, p_sch, gamma, d.R, d.Rt, y, use_y,
+    int rc = revs_op_dual_evaluate(2 | 1 | 4, d.m, d.T, d.node_ptr, p_est, p_sch, gamma, d.R, d.Rt, y, use_y,
                                    d.kappa, d.vlo, d.vhi, d.kadd, d.ksplit, d.d_slabs, d.v_slabs,
                                    d.pnq, p_est_new, d.vfull, d.viol, d.partial, d.cand_idx,
                                    d.cand_cnt, d.cand_val, d.stats, seq, nullptr, stream);
     if (rc != REVS_OK) return rc;
     if (ev_mid) (void)hipEventRecord((hipEvent_t)ev_mid, s);
-    rc = revs_agent_step_out(d.n_homes, d.T, d.cost, d.homes, d.load, p_est, p_est_new, p_sch, gamma,
-                             p_sch_out, gamma_out, s_out, c_out, d.diff, d.partials, d.status,
-                             d.pdhg_dual, (float)d.kappa, d.mode, &d.pdhg, stream);
+    // the candidate selection rides in the sweep's launch (its first T workgroups)
+    rc = revs_agent_step_select(d.n_homes, d.T, d.cost, d.homes, d.load, p_est, p_est_new, p_sch,
+                                gamma, p_sch_out, gamma_out, s_out, c_out, d.diff, d.partials,
+                                d.status, d.pdhg_dual, (float)d.kappa, d.mode, &d.pdhg, d.m,
+                                d.partial, y, d.vlo, d.vhi, d.kadd, d.vfull, d.viol, d.cand_idx,
+                                d.cand_cnt, d.cand_val, d.stats, seq, stream);
     if (rc != REVS_OK) return rc;
     if (ev_end) (void)hipEventRecord((hipEvent_t)ev_end, s);
     // Wait for the evaluation, not the sweep: poll the sequence tag the select kernel writes

@@ -1,0 +1,144 @@
+// Candidate selection of the operator's dual Newton path as a device function: it runs as
+// its own kernel (op_dual_select_kernel) or as the first T workgroups of the home sweep's
+// launch (agent_step_kernel with AgentArgs::nsel > 0), where it overlaps the sweep.
+#pragma once
+#include "common.h"
+
+namespace revs {
+
+constexpr int kAmax = REVS_DUAL_AMAX;
+static_assert(kAmax == 128, "candidate sets are two 64-bit words / two wavefronts");
+constexpr int kWords = kAmax / 64;
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmax(v, __shfl_xor(v, d, 64));
+    return v;
+}
+
+struct SelectArgs {
+    int m, T, nblk, kadd;
+    const double *partial, *y, *vfull, *viol;
+    double vlo, vhi, seq;
+    int64_t *cidx;
+    int32_t *ccnt;
+    double *cval, *stats;
+};
+
+// Stage 2, one workgroup per slot: fold the partials (fixed order), and -- only for a slot
+// that has multipliers or violated rows -- build its candidate list.  Thread j owns the
+// contiguous rows [j R, (j+1) R), R = ceil(m/256), so the rows with a multiplier are
+// compacted in row order (deterministic: every rank builds the same lists); the most
+// violated rows without a multiplier are appended by `kadd` rounds of a block-wide
+// arg-max (ties to the lower row).
+__device__ __forceinline__ void dual_select_body(const SelectArgs &sa, const int t) {
+    const int m = sa.m, T = sa.T, nblk = sa.nblk, kadd = sa.kadd;
+    const double *__restrict__ partial = sa.partial, *__restrict__ y = sa.y;
+    const double *__restrict__ vfull = sa.vfull, *__restrict__ viol = sa.viol;
+    const double vlo = sa.vlo, vhi = sa.vhi, seq = sa.seq;
+    int64_t *__restrict__ cidx = sa.cidx;
+    int32_t *__restrict__ ccnt = sa.ccnt;
+    double *__restrict__ cval = sa.cval, *__restrict__ stats = sa.stats;
+    const int tid = threadIdx.x;
+    __shared__ int cnt_s[256];
+    __shared__ double red_s[4][4];
+    __shared__ double best_v[4];
+    __shared__ int best_i[4];
+    {
+        double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
+        for (int k = tid; k < nblk; k += 256) {
+            const double *o = partial + ((int64_t)k * T + t) * 4;
+            a = fmax(a, o[0]); b += o[1]; c += o[2]; d += o[3];
+        }
+        a = wave_max_d(a); b = wave_sum_d(b); c = wave_sum_d(c); d = wave_sum_d(d);
+        if ((tid & 63) == 0) {
+            red_s[0][tid >> 6] = a; red_s[1][tid >> 6] = b; red_s[2][tid >> 6] = c; red_s[3][tid >> 6] = d;
+        }
+    }
+    __syncthreads();
+    const int ns = (int)(((red_s[2][0] + red_s[2][1]) + red_s[2][2]) + red_s[2][3]);
+    const int nv = (int)(((red_s[3][0] + red_s[3][1]) + red_s[3][2]) + red_s[3][3]);
+    if (tid == 0) {
+        stats[t * 8 + 0] = fmax(fmax(red_s[0][0], red_s[0][1]), fmax(red_s[0][2], red_s[0][3]));
+        stats[t * 8 + 1] = ((red_s[1][0] + red_s[1][1]) + red_s[1][2]) + red_s[1][3];
+        stats[t * 8 + 2] = (double)ns;
+        stats[t * 8 + 3] = (double)nv;
+        // stats may live in pinned host memory: a host that polls [5] for this evaluation's
+        // sequence number sees [0..3] complete (system-scope release before the tag)
+        __threadfence_system();
+        reinterpret_cast<volatile double *>(stats)[t * 8 + 5] = seq;
+    }
+    int64_t *ci = cidx + (int64_t)t * kAmax;
+    double *cs = cval + (int64_t)t * 3 * kAmax, *cg = cs + kAmax, *cy = cg + kAmax;
+    if (ns > kAmax || (ns == 0 && nv == 0)) {   // uniform: too many multipliers / nothing to do
+        if (tid == 0) ccnt[t] = ns > kAmax ? -1 : 0;
+        if (tid < kAmax) { ci[tid] = 0; cs[tid] = 1.0; cg[tid] = 0.0; cy[tid] = 0.0; }
+        return;
+    }
+    const int per = (m + 255) / 256;
+    const int r0 = min(m, tid * per), r1 = min(m, r0 + per);
+    int nsup = 0;
+    for (int r = r0; r < r1; ++r) nsup += y[(int64_t)r * T + t] != 0.0 ? 1 : 0;
+    cnt_s[tid] = nsup;
+    __syncthreads();
+    int pos = 0;
+    for (int j = 0; j < tid; ++j) pos += cnt_s[j];
+    for (int r = r0; r < r1 && nsup > 0; ++r) {
+        const int64_t i = (int64_t)r * T + t;
+        const double yv = y[i];
+        if (yv != 0.0) {
+            ci[pos] = r;
+            cs[pos] = yv > 0.0 ? 1.0 : -1.0;
+            cg[pos] = vfull[i] - (yv > 0.0 ? vhi : vlo);
+            cy[pos] = yv;
+            ++pos;
+        }
+    }
+    const int room = min(min(kadd, kAmax - ns), nv);
+    int added = 0;
+    // Row r is always scanned by thread r % 256, which remembers in a register mask which
+    // of its rows were taken -- no global store has to become visible between rounds.
+    unsigned long long took = 0ull;
+    for (int k = 0; k < room; ++k) {
+        double bv = 0.0;
+        int bi = m;
+        for (int r = tid, i = 0; r < m; r += 256, ++i) {
+            const double x = viol[(int64_t)r * T + t];
+            if (x > bv && !((took >> i) & 1ull)) { bv = x; bi = r; }   // ascending r: ties keep the lower row
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const double ov = __shfl_xor(bv, d, 64);
+            const int oi = __shfl_xor(bi, d, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        __syncthreads();                    // best_v / best_i of the previous round were read
+        if ((tid & 63) == 0) { best_v[tid >> 6] = bv; best_i[tid >> 6] = bi; }
+        __syncthreads();
+        bv = best_v[0]; bi = best_i[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (best_v[w] > bv || (best_v[w] == bv && best_i[w] < bi)) { bv = best_v[w]; bi = best_i[w]; }
+        if (!(bv > 0.0)) break;             // uniform
+        if (tid == (bi & 255)) took |= 1ull << (bi >> 8);
+        if (tid == 0) {
+            const double v = vfull[(int64_t)bi * T + t];
+            const bool up = v > vhi;
+            ci[ns + added] = bi;
+            cs[ns + added] = up ? 1.0 : -1.0;
+            cg[ns + added] = v - (up ? vhi : vlo);
+            cy[ns + added] = 0.0;
+        }
+        ++added;
+    }
+    const int cnt = ns + added;
+    if (tid == 0) ccnt[t] = cnt;
+    if (tid >= cnt && tid < kAmax) { ci[tid] = 0; cs[tid] = 1.0; cg[tid] = 0.0; cy[tid] = 0.0; }
+}
+
+}  // namespace revs
