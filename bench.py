@@ -19,7 +19,9 @@ collective is the all-reduce of the node aggregate (once per evaluation: once pe
 iteration in the steady state).
 
 Prints ONE JSON line (rank 0).  `value` = home-QP solves per second, whole job,
-inputs resident in HBM.  `roofline` is the PDHG sweep kernel against HBM;
+inputs resident in HBM, from K steps with nothing else on the stream; the per-kernel
+durations come from an instrumented repeat of the same K steps (HIP event records cost GPU
+time, see DESIGN.md section 6).  `roofline` is the PDHG sweep kernel against HBM;
 `roofline_matvec` the f64 matrix-core product of the operator against the f64 MFMA
 peak; `cpu_baseline` the oracle (numpy port of the reference algorithm) timed on
 this box's host cores on a bounded sample of the same workload.
