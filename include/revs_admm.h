@@ -135,7 +135,12 @@ int revs_agent_step_out(int64_t n_homes, int32_t T,
  * revs_op_dual_select; arguments as there, T slots) running as the first T workgroups of the
  * same launch: independent of the sweep, it overlaps it and its stats -- the operator's
  * verdict -- reach the host while the sweep is still running.  The caller must have run
- * revs_op_dual_evaluate with phase bits 2|4 (rows done, selection deferred) before. */
+ * revs_op_dual_evaluate with phase bits 2|4 (rows done, selection deferred) before.
+ * With p_next != NULL the sweep also performs the home pass of the NEXT evaluation for
+ * multipliers y = 0 on the state it has just produced (revs_op_dual_eval with dsl = NULL):
+ * p_est_next float[n][T] = max(g0', 0), g0' = (P_est[k+1] + P_sch[k+1])/2 - G[k+1]/kappa, and
+ * p_next double[m][T] += node sums of it (ZERO on entry: revs_op_dual_rows can clear it);
+ * node_of int32[n] = node of every residence (residences sorted by node). */
 int revs_agent_step_select(int64_t n_homes, int32_t T,
                            const float *cost, const revs_home_t *homes, const float *load,
                            const float *p_est_old, const float *p_est_new,
@@ -147,7 +152,9 @@ int revs_agent_step_select(int64_t n_homes, int32_t T,
                            int32_t m, const double *sel_partial, const double *y, double vlo,
                            double vhi, int32_t kadd, const double *vfull, const double *viol,
                            int64_t *cand_idx, int32_t *cand_cnt, double *cand_val,
-                           double *stats, double seq, void *stream);
+                           double *stats, double seq,
+                           const int32_t *node_of, double *p_next, float *p_est_next,
+                           void *stream);
 
 /* Wavefront reduction of the per-workgroup partials to the global ADMM residuals
  *   out[0] = |P_est[k+1] - P_sch[k+1]|_2           (primal residual, all homes)
@@ -405,6 +412,11 @@ int revs_op_dual_select(int32_t m, int32_t T, int32_t nslab, const double *vsl,
                         int32_t kadd, double *vfull, double *viol, double *partial,
                         int64_t *cand_idx, int32_t *cand_cnt, double *cand_val, double *stats,
                         double seq, void *stream);
+/* The first kernel of revs_op_dual_select alone (the selection left to
+ * revs_agent_step_select); zero_out double[m][T] or NULL is cleared on the way. */
+int revs_op_dual_rows(int32_t m, int32_t T, int32_t nslab, const double *vsl, const double *pnq,
+                      const double *y, double vlo, double vhi, double *vfull, double *viol,
+                      double *partial, double *zero_out, void *stream);
 int revs_op_dual_model(int32_t m, int32_t T, const double *R, const double *n_free,
                        const int64_t *cand_idx, const int32_t *cand_cnt, const double *cand_val,
                        double kappa, double delta, int32_t max_pivots, int32_t nks,
@@ -451,16 +463,22 @@ typedef struct {
     float *diff, *partials; int32_t *status; float *pdhg_dual;
     int32_t mode;
     revs_pdhg_t pdhg;
+    const int32_t *node_of;      /* node of every residence, or NULL (no fused home pass) */
 } revs_plan_desc_t;
 typedef struct revs_plan revs_plan_t;
 revs_plan_t *revs_plan_create(const revs_plan_desc_t *desc_host);
 void revs_plan_destroy(revs_plan_t *plan);
 /* rmax_out_host: largest entry [t][0] of stats (row residual, absolute).  ev_mid / ev_end:
- * optional hipEvent_t handles recorded between evaluation and sweep / after the sweep. */
+ * optional hipEvent_t handles recorded between evaluation and sweep / after the sweep.
+ * fused_in != 0: the previous call (fuse_out != 0, its sweep kept) has already done this
+ * evaluation's home pass -- p_est_new and pnq[0] are in place, only product, rows and
+ * selection run, and stats[t][1] (D_t) is not meaningful.  fuse_out != 0 (needs use_y = 0):
+ * this call's sweep does the next evaluation's home pass into p_est_next / pnq[0]. */
 int revs_plan_spec_step(revs_plan_t *plan, const double *y, int32_t use_y,
                         const float *p_est, float *p_est_new, const float *p_sch,
                         const float *gamma, float *p_sch_out, float *gamma_out,
-                        float *s_out, float *c_out, double *rmax_out_host,
+                        float *s_out, float *c_out, int32_t fused_in, int32_t fuse_out,
+                        float *p_est_next, double *rmax_out_host,
                         void *ev_mid, void *ev_end, void *stream);
 
 #ifdef __cplusplus

@@ -53,6 +53,14 @@ struct AgentArgs {
     // overlaps the sweep and delivers the operator's verdict while the sweep is running
     int32_t nsel;
     SelectArgs sel;
+    // p_next != NULL: the sweep also does the home pass of the NEXT operator evaluation for
+    // multipliers y = 0 (revs_op_dual_eval with dsl = NULL on the state it has just produced):
+    // pe2_out = max(g0', 0) as float, g0' = (P_est[k+1] + P_sch[k+1])/2 - G[k+1]/kappa, and
+    // p_next[node][t] += g (double; must be zero on entry) -- one pass over the homes per
+    // ADMM iteration instead of two while the operator's rows stay slack
+    const int32_t *node_of;
+    double *p_next;
+    float *pe2_out;
 };
 
 // SPL consecutive floats of one lane as ONE global_load/store_dwordxSPL: the 64 lanes of a
@@ -413,11 +421,24 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
         ss += valid[j] ? chk * chk : 0.f;
         dd += valid[j] ? dg * dg : 0.f;
     }
+    // next evaluation's home pass (same arithmetic as op_dual_eval_kernel with d = 0)
+    float pe2[SPL];
+    double gnext[SPL];
+    if (a.p_next) {
+        const double inv_k = 1.0 / (double)kappa;
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+            const double g0 = 0.5 * ((double)pen[j] + (double)gn[j]) - (double)gmn[j] * inv_k;
+            gnext[j] = (valid[j] && g0 > 0.0) ? g0 : 0.0;
+            pe2[j] = (float)gnext[j];
+        }
+    }
     if (full) {
         st_pack<SPL>(a.ps_out + row + t0, gn);
         st_pack<SPL>(a.gam_out + row + t0, gmn);
         if (a.s_out) st_pack<SPL>(a.s_out + row + t0, p);
         if (a.c_out) st_pack<SPL>(a.c_out + crow + t0 + 1, socv);
+        if (a.p_next) st_pack<SPL>(a.pe2_out + row + t0, pe2);
     } else {
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
@@ -428,6 +449,7 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
                 a.gam_out[o] = gmn[j];
                 if (a.s_out) a.s_out[o] = p[j];
                 if (a.c_out) a.c_out[crow + t + 1] = socv[j];
+                if (a.p_next) a.pe2_out[o] = pe2[j];
             }
         }
     }
@@ -441,9 +463,36 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
     // per-workgroup partial residuals: sum |check|^2, sum |dP_sch|^2, max diff
     float wss = group_sum<64>(ss), wdd = group_sum<64>(dd), wmx = group_max<64>(dfh);
     __shared__ float red[3][kBlock / 64];
+    // node sums of the next home pass: residences are sorted by node, so a workgroup's homes
+    // sit on a few consecutive nodes -- accumulate in LDS, flush one global add per (node, slot)
+    constexpr int kNodeLoc = 4, kSlots = LPA * SPL;
+    __shared__ double nacc[kNodeLoc][kSlots];
+    if (a.p_next)
+        for (int i = tid; i < kNodeLoc * kSlots; i += kBlock) (&nacc[0][0])[i] = 0.0;
     const int wave = tid >> 6;
     if ((tid & 63) == 0) { red[0][wave] = wss; red[1][wave] = wdd; red[2][wave] = wmx; }
     __syncthreads();
+    if (a.p_next) {
+        const int64_t first = (int64_t)bid * kHomesPerBlock;
+        const int base = a.node_of[first < a.n ? first : a.n - 1];
+        if (live) {
+            const int node = a.node_of[agent];
+            const int loc = node - base;
+#pragma unroll
+            for (int j = 0; j < SPL; ++j) {
+                if (gnext[j] > 0.0) {
+                    if (loc < kNodeLoc) unsafeAtomicAdd(&nacc[loc][t0 + j], gnext[j]);
+                    else unsafeAtomicAdd(&a.p_next[(int64_t)node * T + t0 + j], gnext[j]);
+                }
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < kNodeLoc * T; i += kBlock) {
+            const int l = i / T, t = i - l * T;
+            const double v = nacc[l][t];
+            if (v != 0.0) unsafeAtomicAdd(&a.p_next[(int64_t)(base + l) * T + t], v);
+        }
+    }
     if (tid == 0) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -623,7 +672,8 @@ static int agent_step_impl(int64_t n_homes, int32_t T, const float *cost,
                            float *gamma_out, float *s_out, float *c_out, float *diff,
                            float *partials, int32_t *status, float *pdhg_dual,
                            float kappa, int32_t mode, const revs_pdhg_t *pdhg_host,
-                           const SelectArgs *sel, void *stream) {
+                           const SelectArgs *sel, const int32_t *node_of, double *p_next,
+                           float *pe2_out, void *stream) {
     REVS_REQUIRE(n_homes > 0, "revs_agent_step: n_homes=%lld", (long long)n_homes);
     REVS_REQUIRE(T > 0 && T <= REVS_MAX_T, "revs_agent_step: T=%d outside 1..%d", T, REVS_MAX_T);
     REVS_REQUIRE(cost && homes && load && p_est_old && p_est_new && p_sch && gamma && p_sch_out &&
@@ -640,6 +690,8 @@ static int agent_step_impl(int64_t n_homes, int32_t T, const float *cost,
     a.nsel = 0;
     a.sel = SelectArgs{};
     if (sel) { a.nsel = sel->T; a.sel = *sel; }
+    a.node_of = node_of; a.p_next = p_next; a.pe2_out = pe2_out;
+    REVS_REQUIRE(!p_next || (node_of && pe2_out), "revs_agent_step: node_of / pe2_out missing");
     if (pdhg_host) a.pd = *pdhg_host; else revs_pdhg_defaults(&a.pd);
     REVS_REQUIRE(a.pd.max_iter > 0 && a.pd.check > 0 && a.pd.tau_scale >= 0 && a.pd.sigma_scale >= 0,
                  "revs_agent_step: bad PDHG parameters");
@@ -665,7 +717,7 @@ extern "C" int revs_agent_step_out(int64_t n_homes, int32_t T, const float *cost
                                    void *stream) {
     return agent_step_impl(n_homes, T, cost, homes, load, p_est_old, p_est_new, p_sch, gamma,
                            p_sch_out, gamma_out, s_out, c_out, diff, partials, status, pdhg_dual,
-                           kappa, mode, pdhg_host, nullptr, stream);
+                           kappa, mode, pdhg_host, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int revs_agent_step_select(int64_t n_homes, int32_t T, const float *cost,
@@ -678,7 +730,9 @@ extern "C" int revs_agent_step_select(int64_t n_homes, int32_t T, const float *c
                                       int32_t m, const double *sel_partial, const double *y,
                                       double vlo, double vhi, int32_t kadd, const double *vfull,
                                       const double *viol, int64_t *cand_idx, int32_t *cand_cnt,
-                                      double *cand_val, double *stats, double seq, void *stream) {
+                                      double *cand_val, double *stats, double seq,
+                                      const int32_t *node_of, double *p_next, float *p_est_next,
+                                      void *stream) {
     REVS_REQUIRE(m > 0 && m <= 16384 && sel_partial && y && vfull && viol && cand_idx && cand_cnt &&
                  cand_val && stats && vlo <= vhi && kadd >= 0,
                  "revs_agent_step_select: bad selection argument");
@@ -686,7 +740,7 @@ extern "C" int revs_agent_step_select(int64_t n_homes, int32_t T, const float *c
                         seq, cand_idx, cand_cnt, cand_val, stats};
     return agent_step_impl(n_homes, T, cost, homes, load, p_est_old, p_est_new, p_sch, gamma,
                            p_sch_out, gamma_out, s_out, c_out, diff, partials, status, pdhg_dual,
-                           kappa, mode, pdhg_host, &sa, stream);
+                           kappa, mode, pdhg_host, &sa, node_of, p_next, p_est_next, stream);
 }
 
 extern "C" int revs_agent_step(int64_t n_homes, int32_t T, const float *cost,

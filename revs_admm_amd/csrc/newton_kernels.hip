@@ -80,7 +80,7 @@ template <int TL>
 __global__ __launch_bounds__(256) void op_dual_rows_kernel(
         int m, int T, int nslab, const double *__restrict__ vsl, const double *__restrict__ pnq,
         const double *__restrict__ y, double vlo, double vhi, double *__restrict__ vfull,
-        double *__restrict__ viol, double *__restrict__ partial) {
+        double *__restrict__ viol, double *__restrict__ partial, double *__restrict__ zero_out) {
     constexpr int HS = 256 / TL;
     const int t = threadIdx.x % TL, hs = threadIdx.x / TL;
     const int rows_per = HS * ((m + HS * (int)gridDim.x - 1) / (HS * (int)gridDim.x));
@@ -102,6 +102,7 @@ __global__ __launch_bounds__(256) void op_dual_rows_kernel(
             nsup += yv != 0.0 ? 1.0 : 0.0;
             nvio += (yv == 0.0 && vi > 0.0) ? 1.0 : 0.0;
             viol[i] = yv != 0.0 ? 0.0 : vi;
+            if (zero_out) zero_out[i] = 0.0;
         }
     }
     __shared__ double red[4][HS][TL];
@@ -433,7 +434,7 @@ static int dual_rows_select(int32_t m, int32_t T, int32_t nslab, const double *v
                             const double *pnq, const double *y, double vlo, double vhi,
                             int32_t kadd, double *vfull, double *viol, double *partial,
                             int64_t *cand_idx, int32_t *cand_cnt, double *cand_val, double *stats,
-                            double seq, bool defer_select, void *stream) {
+                            double seq, bool defer_select, double *zero_out, void *stream) {
     REVS_REQUIRE(m <= 16384, "revs_op_dual_select: m=%d exceeds 16384 rows", m);
     REVS_REQUIRE(m > 0 && T > 0 && T <= 256 && nslab >= 1 && vsl && pnq && y && vfull && viol &&
                  partial && cand_idx && cand_cnt && cand_val && stats && vlo <= vhi && kadd >= 0,
@@ -441,7 +442,7 @@ static int dual_rows_select(int32_t m, int32_t T, int32_t nslab, const double *v
     const int nblk = revs_op_dual_blocks(m);
 #define RW(TL)                                                                                 \
     hipLaunchKernelGGL((op_dual_rows_kernel<TL>), dim3(nblk), dim3(256), 0, S_(stream), m, T,  \
-                       nslab, vsl, pnq, y, vlo, vhi, vfull, viol, partial)
+                       nslab, vsl, pnq, y, vlo, vhi, vfull, viol, partial, zero_out)
     if (T <= 32) RW(32);
     else if (T <= 64) RW(64);
     else if (T <= 128) RW(128);
@@ -462,7 +463,16 @@ extern "C" int revs_op_dual_select(int32_t m, int32_t T, int32_t nslab, const do
                                    int64_t *cand_idx, int32_t *cand_cnt, double *cand_val,
                                    double *stats, double seq, void *stream) {
     return dual_rows_select(m, T, nslab, vsl, pnq, y, vlo, vhi, kadd, vfull, viol, partial, cand_idx,
-                            cand_cnt, cand_val, stats, seq, false, stream);
+                            cand_cnt, cand_val, stats, seq, false, nullptr, stream);
+}
+
+extern "C" int revs_op_dual_rows(int32_t m, int32_t T, int32_t nslab, const double *vsl,
+                                 const double *pnq, const double *y, double vlo, double vhi,
+                                 double *vfull, double *viol, double *partial, double *zero_out,
+                                 void *stream) {
+    int64_t ci = 0; int32_t cc = 0; double cv = 0.0, st = 0.0;   // unused: selection deferred
+    return dual_rows_select(m, T, nslab, vsl, pnq, y, vlo, vhi, 0, vfull, viol, partial, &ci, &cc,
+                            &cv, &st, 0.0, true, zero_out, stream);
 }
 
 extern "C" int revs_op_dual_model(int32_t m, int32_t T, const double *R, const double *n_free,
@@ -535,7 +545,8 @@ extern "C" int revs_op_dual_evaluate(int32_t phase, int32_t m, int32_t T, const 
         rc = revs_gemm_tn_f64_split(m, T, m, Rt, pnq, v_slabs, ksplit, stream);
         if (rc != REVS_OK) return rc;
         rc = dual_rows_select(m, T, ksplit, v_slabs, pnq, y, vlo, vhi, kadd, vfull, viol, partial,
-                              cand_idx, cand_cnt, cand_val, stats, seq, (phase & 4) != 0, stream);
+                              cand_idx, cand_cnt, cand_val, stats, seq, (phase & 4) != 0, nullptr,
+                              stream);
         if (rc != REVS_OK) return rc;
         if (stats_host) {
             const hipError_t e = hipMemcpyAsync(stats_host, stats, sizeof(double) * 8 * T,

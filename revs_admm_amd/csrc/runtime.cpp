@@ -59,17 +59,28 @@ extern "C" void revs_plan_destroy(revs_plan_t *plan) {
 extern "C" int revs_plan_spec_step(revs_plan_t *plan, const double *y, int32_t use_y,
                                    const float *p_est, float *p_est_new, const float *p_sch,
                                    const float *gamma, float *p_sch_out, float *gamma_out,
-                                   float *s_out, float *c_out, double *rmax_out, void *ev_mid,
+                                   float *s_out, float *c_out, int32_t fused_in, int32_t fuse_out,
+                                   float *p_est_next, double *rmax_out, void *ev_mid,
                                    void *ev_end, void *stream) {
     REVS_REQUIRE(plan && y && p_est && p_est_new && p_sch && gamma && p_sch_out && gamma_out &&
                  rmax_out, "revs_plan_spec_step: null argument");
     const revs_plan_desc_t &d = plan->d;
+    REVS_REQUIRE(!(fuse_out || fused_in) || (!use_y && d.node_of && (!fuse_out || p_est_next)),
+                 "revs_plan_spec_step: fused home pass needs y = 0, node_of and p_est_next");
     hipStream_t s = (hipStream_t)stream;
     const double seq = (plan->seq += 1.0);
-    int rc = revs_op_dual_evaluate(2 | 1 | 4, d.m, d.T, d.node_ptr, p_est, p_sch, gamma, d.R, d.Rt, y, use_y,
+    int rc;
+    if (!fused_in) {                 // home pass of this evaluation (else: the last sweep did it)
+        rc = revs_op_dual_evaluate(1, d.m, d.T, d.node_ptr, p_est, p_sch, gamma, d.R, d.Rt, y, use_y,
                                    d.kappa, d.vlo, d.vhi, d.kadd, d.ksplit, d.d_slabs, d.v_slabs,
                                    d.pnq, p_est_new, d.vfull, d.viol, d.partial, d.cand_idx,
                                    d.cand_cnt, d.cand_val, d.stats, seq, nullptr, stream);
+        if (rc != REVS_OK) return rc;
+    }
+    rc = revs_gemm_tn_f64_split(d.m, d.T, d.m, d.Rt, d.pnq, d.v_slabs, d.ksplit, stream);   // R p
+    if (rc != REVS_OK) return rc;
+    rc = revs_op_dual_rows(d.m, d.T, d.ksplit, d.v_slabs, d.pnq, y, d.vlo, d.vhi, d.vfull, d.viol,
+                           d.partial, fuse_out ? d.pnq : nullptr, stream);
     if (rc != REVS_OK) return rc;
     if (ev_mid) (void)hipEventRecord((hipEvent_t)ev_mid, s);
     // the candidate selection rides in the sweep's launch (its first T workgroups)
@@ -77,7 +88,8 @@ extern "C" int revs_plan_spec_step(revs_plan_t *plan, const double *y, int32_t u
                                 gamma, p_sch_out, gamma_out, s_out, c_out, d.diff, d.partials,
                                 d.status, d.pdhg_dual, (float)d.kappa, d.mode, &d.pdhg, d.m,
                                 d.partial, y, d.vlo, d.vhi, d.kadd, d.vfull, d.viol, d.cand_idx,
-                                d.cand_cnt, d.cand_val, d.stats, seq, stream);
+                                d.cand_cnt, d.cand_val, d.stats, seq, fuse_out ? d.node_of : nullptr,
+                                fuse_out ? d.pnq : nullptr, fuse_out ? p_est_next : nullptr, stream);
     if (rc != REVS_OK) return rc;
     if (ev_end) (void)hipEventRecord((hipEvent_t)ev_end, s);
     // Wait for the evaluation, not the sweep: poll the sequence tag the select kernel writes

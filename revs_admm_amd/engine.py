@@ -96,6 +96,9 @@ class OperatorOptions:
     # has seen that evaluation's verdict (P_sch / G go to spare buffers): the GPU never
     # waits for the host.  If rows turn out to need work, the sweep is simply run again.
     speculate: bool = True
+    # One GPU, multipliers all zero: the speculative sweep also does the home pass of the NEXT
+    # operator evaluation (one pass over the homes per ADMM iteration instead of two).
+    fuse_home_pass: bool = True
 
 
 def _dev_check(device):
@@ -259,6 +262,7 @@ class AdmmEngine:
         self.newton_hist: list[tuple] = []
         # steady-state iteration as ONE native call (one GPU; see revs_plan_spec_step)
         self._plan = None
+        self._fused_ready = False        # the last kept sweep did the next evaluation's home pass
         if (cuda and self.group is None and self.op.solver == "newton" and _kernels is None
                 and not os.environ.get("REVS_NO_PLAN")):
             d = _lib.PlanDesc()
@@ -274,6 +278,9 @@ class AdmmEngine:
             d.cost, d.homes, d.load = ptr(self.cost), ptr(self.homes), ptr(self.load)
             d.diff, d.partials, d.status = ptr(self.diff), ptr(self.partials), ptr(self.status)
             d.pdhg_dual, d.mode, d.pdhg = ptr(self.pdhg_dual), self.mode, self.pdhg
+            self.node_of_dev = up(node_of[self.perm].astype(np.int32))
+            self.P_est_alt = torch.zeros(n, T, **f32)
+            d.node_of = ptr(self.node_of_dev)
             self._plan_desc = d
             self._plan = self.lib.revs_plan_create(C.byref(d))
             if not self._plan:
@@ -801,6 +808,7 @@ class AdmmEngine:
         """Utility(graph, P_est[k], P_sch[k], G[k]).solve() -> P_est[k+1]
         (lpsolver.py:256-259), written to self.P_est_new."""
         o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
+        self._fused_ready = False
         if o.solver == "newton":
             if self._operator_solve_newton():
                 return True
@@ -881,6 +889,7 @@ class AdmmEngine:
         """All Home(...).solve() of one iteration + dual update + diff
         (lpsolver.py:269-284) in one kernel launch.  With `to_alt` P_sch[k+1] and G[k+1] go
         to the spare buffers (speculative launch, see step)."""
+        self._fused_ready = False
         ps_out, g_out = (self.P_sch_alt, self.G_alt) if to_alt else (self.P_sch, self.G)
         check(self.lib.revs_agent_step_out(
             self.n, self.T, ptr(self.cost), ptr(self.homes), ptr(self.load), ptr(self.P_est),
@@ -925,14 +934,22 @@ class AdmmEngine:
                         if not events[i].cuda_event:
                             events[i].record()       # creates the hipEvent behind the object
                         evh[i - 1] = events[i].cuda_event
+                fused_in = self._fused_ready
+                fuse_out = bool(o.fuse_home_pass and not self._y_support)
+                self._fused_ready = False
                 check(self.lib.revs_plan_spec_step(
                     self._plan, ptr(self.yd[0]), int(self._y_support), ptr(self.P_est),
                     ptr(self.P_est_new), ptr(self.P_sch), ptr(self.G), ptr(self.P_sch_alt),
                     ptr(self.G_alt), ptr(self.S) if write_sc else None,
-                    ptr(self.Csoc) if write_sc else None, C.byref(rm), evh[0], evh[1],
+                    ptr(self.Csoc) if write_sc else None, int(fused_in), int(fuse_out),
+                    ptr(self.P_est_alt), C.byref(rm), evh[0], evh[1],
                     self.stream), "revs_plan_spec_step")
                 kept = rm.value / scale <= o.eps
-                stt = None if kept else self.stats_host[0].numpy().copy()
+                # after a fused home pass the stats carry no dual value: a discarded sweep is
+                # followed by a fresh evaluation instead of a continuation from these stats
+                stt = None if (kept or fused_in) else self.stats_host[0].numpy().copy()
+                if kept and fuse_out:
+                    self._fused_ready = True
             else:
                 self._dual_launch(self.yd[0], self._y_support, 0, full=False)
                 rec(1)
@@ -950,7 +967,8 @@ class AdmmEngine:
                 self.spec_hist[0] += 1
             else:                          # rows need work: finish the solve, redo the sweep
                 self.spec_hist[1] += 1
-                stt = self._dual_complete(self.yd[0], self._y_support, 0)
+                if stt is not None:
+                    stt = self._dual_complete(self.yd[0], self._y_support, 0)
                 if not self._operator_solve_newton(first=stt):
                     self._fast_cold = True
                     self.op_cold = True
@@ -961,11 +979,14 @@ class AdmmEngine:
                         o.solver = saved
                 self.agent_step(write_sc)
         else:
+            self._fused_ready = False
             self.operator_solve()
             rec(1)
             self.agent_step(write_sc)
             rec(2)
         self.P_est, self.P_est_new = self.P_est_new, self.P_est
+        if self._fused_ready:             # the next P_est_new is already in the spare buffer
+            self.P_est_new, self.P_est_alt = self.P_est_alt, self.P_est_new
         self.iteration += 1
 
     def __del__(self):

@@ -417,3 +417,35 @@ def test_revs_fixture_end_to_end(gpu_lib, golden, tmp_path):
     assert abs(sum(Pev_i[ev0]) - 14.4) < 1e-4
     Pres_c, Pev_c, soc_c = fx.get_centralized_optimal(tariff, homes, dist, **opt)
     assert sum(Pev_c[ev0]) == 0.0 and soc_c[ev0][-1] == pytest.approx(0.2)
+
+
+@pytest.mark.parametrize("mode", ["pdhg", "binary"])
+def test_native_step_and_fused_home_pass_change_nothing(gpu_lib, mode, monkeypatch):
+    """The steady-state iteration as one native call (revs_plan_spec_step), with and without
+    the next evaluation's home pass folded into the sweep, against the Python-issued
+    iteration: same speculation history, same schedules and residuals bit for bit (the
+    fused node sums are accumulated with atomics, but with y = 0 nothing depends on their
+    last bits), over a run with kept AND discarded speculative sweeps."""
+    from revs_admm_amd.engine import OperatorOptions
+    from revs_admm_amd.synthetic import make_workload
+    w = make_workload(3000, 24, n_nodes=100, seed=5, binary_feasible=(mode == "binary"), stress=1.02)
+    runs = []
+    for plan, fuse in ((True, True), (True, False), (False, False)):
+        if plan:
+            monkeypatch.delenv("REVS_NO_PLAN", raising=False)
+        else:
+            monkeypatch.setenv("REVS_NO_PLAN", "1")
+        e = _engine(w, mode, op=OperatorOptions(fuse_home_pass=fuse))
+        assert (e._plan is not None) == plan
+        d = e.run(25)
+        runs.append((d, e.result(), e.P_est.cpu().numpy(), list(e.spec_hist),
+                     [h[0] for h in e.newton_hist]))
+    ref = runs[-1]
+    if mode == "pdhg":                   # (binary schedules keep the rows moving: no steady state)
+        assert ref[3][0] > 0 and ref[3][1] > 0
+    for r in runs[:-1]:
+        assert r[3] == ref[3] and r[4] == ref[4]
+        np.testing.assert_array_equal(r[0], ref[0])
+        for a, b in zip(r[1], ref[1]):
+            np.testing.assert_array_equal(a, b)
+        np.testing.assert_array_equal(r[2], ref[2])
