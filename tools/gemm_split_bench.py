@@ -3,7 +3,8 @@
 for every K-split.  (Measured this round: workgroup shapes 16x4, 16x2, 8x4, 8x8, 4x8, 4x4
 waves x unroll and a contiguous row-panel layout of R all land at 10.6-12 us for M = 2048,
 T = 24 -- the product is bound by launch + two memory round trips + the LDS reduction,
-not by the access pattern.)
+not by the access pattern.  A float variant of the product (float R, B rounded on the fly, as
+a screening pass) took 8.7 us against 12.0 us: not worth a second code path.)
     python tools/gemm_split_bench.py [M] [T]"""
 import os
 import sys
