@@ -140,7 +140,9 @@ int revs_agent_step_out(int64_t n_homes, int32_t T,
  * multipliers y = 0 on the state it has just produced (revs_op_dual_eval with dsl = NULL):
  * p_est_next float[n][T] = max(g0', 0), g0' = (P_est[k+1] + P_sch[k+1])/2 - G[k+1]/kappa, and
  * p_next double[m][T] += node sums of it (ZERO on entry: revs_op_dual_rows can clear it);
- * node_of int32[n] = node of every residence (residences sorted by node). */
+ * node_of int32[n] = node of every residence (residences sorted by node).
+ * sel_nblk: number of partial blocks the selection folds (0 = revs_op_dual_blocks(m), the
+ * count revs_op_dual_select / _rows write; (m + 31) / 32 after revs_op_dual_product_rows). */
 int revs_agent_step_select(int64_t n_homes, int32_t T,
                            const float *cost, const revs_home_t *homes, const float *load,
                            const float *p_est_old, const float *p_est_new,
@@ -154,7 +156,7 @@ int revs_agent_step_select(int64_t n_homes, int32_t T,
                            int64_t *cand_idx, int32_t *cand_cnt, double *cand_val,
                            double *stats, double seq,
                            const int32_t *node_of, double *p_next, float *p_est_next,
-                           void *stream);
+                           int32_t sel_nblk, void *stream);
 
 /* Wavefront reduction of the per-workgroup partials to the global ADMM residuals
  *   out[0] = |P_est[k+1] - P_sch[k+1]|_2           (primal residual, all homes)
@@ -417,6 +419,18 @@ int revs_op_dual_select(int32_t m, int32_t T, int32_t nslab, const double *vsl,
 int revs_op_dual_rows(int32_t m, int32_t T, int32_t nslab, const double *vsl, const double *pnq,
                       const double *y, double vlo, double vhi, double *vfull, double *viol,
                       double *partial, double *zero_out, void *stream);
+/* v_slabs = R p (Rt = R^T row-major, p double[m][T]) as `ksplit` K-split slabs AND the row
+ * bookkeeping of revs_op_dual_rows in one launch: the last K-split workgroup of every
+ * 32-row tile sums the tile's slabs and writes vfull, viol, partial (here
+ * double[(m + 31) / 32][T][4]: pass that block count to revs_agent_step_select as
+ * sel_nblk; the dual-value terms come from pnq[2]) and clears its rows of zero_out (NULL, or
+ * a double[m][T] array other than p, which every workgroup reads to the end).  counters:
+ * uint32[(m + 31) / 32], zero before the first use, left zero.  T <= 32. */
+int revs_op_dual_product_rows(int32_t m, int32_t T, const double *Rt, const double *p,
+                              const double *pnq, const double *y, double vlo, double vhi,
+                              int32_t ksplit,
+                              double *v_slabs, double *vfull, double *viol, double *partial,
+                              double *zero_out, uint32_t *counters, void *stream);
 int revs_op_dual_model(int32_t m, int32_t T, const double *R, const double *n_free,
                        const int64_t *cand_idx, const int32_t *cand_cnt, const double *cand_val,
                        double kappa, double delta, int32_t max_pivots, int32_t nks,

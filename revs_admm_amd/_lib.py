@@ -71,7 +71,9 @@ SIGNATURES = {
     "revs_agent_step_select": (C.c_int, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                          _p, _p, _p, _f32, _i32, C.POINTER(PDHG), _i32, _p, _p,
                                          _f64, _f64, _i32, _p, _p, _p, _p, _p, _p, _f64, _p, _p, _p,
-                                         _p]),
+                                         _i32, _p]),
+    "revs_op_dual_product_rows": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _f64, _f64, _i32, _p, _p, _p,
+                                            _p, _p, _p, _p]),
     "revs_residual_finalize": (C.c_int, [_p, _i64, _i64, _i32, _f32, _f32, _p, _p]),
     "revs_residence_solve": (C.c_int, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "revs_gemm_tn_f64": (C.c_int, [_i32, _i32, _i32, _p, _i32, _p, _i32, _p, _i32, _i32, _p]),

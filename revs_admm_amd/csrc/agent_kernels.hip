@@ -732,11 +732,12 @@ extern "C" int revs_agent_step_select(int64_t n_homes, int32_t T, const float *c
                                       const double *viol, int64_t *cand_idx, int32_t *cand_cnt,
                                       double *cand_val, double *stats, double seq,
                                       const int32_t *node_of, double *p_next, float *p_est_next,
-                                      void *stream) {
+                                      int32_t sel_nblk, void *stream) {
     REVS_REQUIRE(m > 0 && m <= 16384 && sel_partial && y && vfull && viol && cand_idx && cand_cnt &&
                  cand_val && stats && vlo <= vhi && kadd >= 0,
                  "revs_agent_step_select: bad selection argument");
-    const SelectArgs sa{m, T, revs_op_dual_blocks(m), kadd, sel_partial, y, vfull, viol, vlo, vhi,
+    REVS_REQUIRE(sel_nblk >= 0 && sel_nblk <= 256, "revs_agent_step_select: sel_nblk=%d", sel_nblk);
+    const SelectArgs sa{m, T, sel_nblk ? sel_nblk : revs_op_dual_blocks(m), kadd, sel_partial, y, vfull, viol, vlo, vhi,
                         seq, cand_idx, cand_cnt, cand_val, stats};
     return agent_step_impl(n_homes, T, cost, homes, load, p_est_old, p_est_new, p_sch, gamma,
                            p_sch_out, gamma_out, s_out, c_out, diff, partials, status, pdhg_dual,

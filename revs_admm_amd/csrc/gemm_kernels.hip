@@ -23,6 +23,7 @@
 // for float.  `batch` independent products can share one launch (gridDim.y), which
 // is how the operator issues V^T rhat with U^T w, and V a with U (s a).
 #include "common.h"
+#include <type_traits>
 
 namespace revs {
 
@@ -76,13 +77,27 @@ struct GemmBatch {
     GemmOperands<T> op[2];
 };
 
+// Optional epilogue of the dual Newton path's product R p (ROWS instantiation): the LAST of
+// the gridDim.z K-split workgroups of a row tile to finish sums the slabs of its 32 rows and
+// does the row bookkeeping of op_dual_rows_kernel for them on the spot -- v, residual /
+// violation, per-(tile, slot) partials -- so that no separate rows kernel is launched.  The
+// slabs are handed over inside the launch through the agent-wide coherence point (sc1 stores
+// and loads; the workgroup's barrier completes them before it is counted): no fence.
+struct GemmRows {
+    const double *qpart, *y;      // pnq + 2 m T; multipliers
+    double vlo, vhi;
+    double *vfull, *viol, *partial, *zero_out;
+    unsigned int *counters;       // one per row tile, zero between launches
+};
+
 template <typename T> struct Vec2;
 template <> struct Vec2<double> { using type = double2; };
 template <> struct Vec2<float> { using type = float2; };
 
-template <typename T, int NT, int RT, int kGemmWaves, int kUnroll>
+template <typename T, int NT, int RT, int kGemmWaves, int kUnroll, bool ROWS = false>
 __global__ __launch_bounds__(kGemmWaves * 64) void gemm_tn_kernel(
-        int m, int n, int k, GemmBatch<T> batch, int lda, int ldb, int ldc, int accumulate) {
+        int m, int n, int k, GemmBatch<T> batch, int lda, int ldb, int ldc, int accumulate,
+        GemmRows rw = GemmRows{}) {
     using M = Mfma<T>;
     using acc_t = typename M::acc_t;
     using vec2 = typename Vec2<T>::type;
@@ -220,12 +235,67 @@ __global__ __launch_bounds__(kGemmWaves * 64) void gemm_tn_kernel(
                         const bool hi = ocol >= op.csplit;
                         T *cp = (hi ? op.C1 + (ocol - op.csplit) : op.C + ocol) + slab +
                                 (int64_t)orow * ldc;
-                        *cp = accumulate ? (*cp + v) : v;
+                        if constexpr (ROWS)
+                            __hip_atomic_store(cp, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        else
+                            *cp = accumulate ? (*cp + v) : v;
                     }
                 }
             }
         }
         __syncthreads();
+    }
+    if constexpr (ROWS && std::is_same_v<T, double>) {
+        // (the loop's last barrier waited for this workgroup's stores: vmcnt(0))
+        __shared__ int last_s;
+        if (threadIdx.x == 0) {
+            const unsigned int old = __hip_atomic_fetch_add(rw.counters + blockIdx.x, 1u, __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT);
+            last_s = old == gridDim.z - 1;
+            if (last_s)
+                __hip_atomic_store(rw.counters + blockIdx.x, 0u, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (!last_s) return;                                  // uniform
+        constexpr int kRows = 16 * RT;
+        double(*buf)[kRows][32] = reinterpret_cast<double(*)[kRows][32]>(&red[0][0][0][0]);
+        static_assert(sizeof(red) >= 4 * kRows * 32 * sizeof(double), "epilogue scratch");
+        const int64_t total = (int64_t)m * ldc;
+        for (int e = threadIdx.x; e < kRows * 32; e += kGemmWaves * 64) {
+            const int rr = e >> 5, t = e & 31;
+            const int r = row0 + rr;
+            double res = 0.0, dterm = 0.0, sup = 0.0, vio = 0.0;
+            if (r < m && t < n) {
+                const int64_t i = (int64_t)r * ldc + t;
+                double v = 0.0;
+                for (unsigned q = 0; q < gridDim.z; ++q)
+                    v += __hip_atomic_load(op.C + i + q * total, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                rw.vfull[i] = v;
+                const double yv = rw.y[i];
+                const bool up = yv > 0.0 || (yv == 0.0 && v > rw.vhi);
+                const double b = up ? rw.vhi : rw.vlo;
+                const double vi = fmax(fmax(v - rw.vhi, rw.vlo - v), 0.0);
+                res = yv != 0.0 ? fabs(v - b) : vi;
+                dterm = rw.qpart[i] - fmax(rw.vhi * yv, rw.vlo * yv);
+                sup = yv != 0.0 ? 1.0 : 0.0;
+                vio = (yv == 0.0 && vi > 0.0) ? 1.0 : 0.0;
+                rw.viol[i] = yv != 0.0 ? 0.0 : vi;
+                if (rw.zero_out) rw.zero_out[i] = 0.0;
+            }
+            buf[0][rr][t] = res; buf[1][rr][t] = dterm; buf[2][rr][t] = sup; buf[3][rr][t] = vio;
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < n) {
+            const int t = threadIdx.x;
+            double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
+            for (int rr = 0; rr < kRows; ++rr) {              // fixed order
+                a = fmax(a, buf[0][rr][t]); b += buf[1][rr][t]; c += buf[2][rr][t]; d += buf[3][rr][t];
+            }
+            double *o = rw.partial + ((int64_t)blockIdx.x * n + t) * 4;
+            o[0] = a; o[1] = b; o[2] = c; o[3] = d;
+        }
     }
 }
 
@@ -275,6 +345,24 @@ extern "C" int revs_gemm_tn_f64_split(int32_t m, int32_t n, int32_t k, const dou
                                       const double *B, double *C, int32_t ksplit, void *stream) {
     GemmBatch<double> b{{{At, B, C, nullptr, nullptr, n}, {}}};
     return launch_gemm<double>(m, n, k, 1, ksplit, b, m, n, n, 0, stream, "revs_gemm_tn_f64_split");
+}
+
+extern "C" int revs_op_dual_product_rows(int32_t m, int32_t T, const double *Rt, const double *p,
+                                         const double *pnq, const double *y, double vlo,
+                                         double vhi, int32_t ksplit,
+                                         double *v_slabs, double *vfull, double *viol,
+                                         double *partial, double *zero_out, uint32_t *counters,
+                                         void *stream) {
+    REVS_REQUIRE(m > 0 && T > 0 && T <= 32 && Rt && p && pnq && y && v_slabs && vfull && viol &&
+                 partial && counters && ksplit >= 1 && ksplit <= 8 && vlo <= vhi,
+                 "revs_op_dual_product_rows: bad argument (T <= 32)");
+    REVS_REQUIRE(zero_out != p, "revs_op_dual_product_rows: zero_out must not be the operand p");
+    GemmBatch<double> b{{{Rt, p, v_slabs, nullptr, nullptr, T}, {}}};
+    const GemmRows rw{pnq + 2 * (int64_t)m * T, y, vlo, vhi, vfull, viol, partial, zero_out, counters};
+    hipLaunchKernelGGL((gemm_tn_kernel<double, 2, 2, 16, 4, true>), dim3((m + 31) / 32, 1, ksplit),
+                       dim3(16 * 64), 0, (hipStream_t)stream, m, T, m, b, m, T, T, 0, rw);
+    REVS_CHECK_LAUNCH("revs_op_dual_product_rows");
+    return REVS_OK;
 }
 
 extern "C" int revs_gemm_tn_f64_x2(int32_t m, int32_t n, int32_t k, const double *At0,

@@ -34,6 +34,9 @@ struct revs_plan {
     revs_plan_desc_t d;
     hipEvent_t ev;
     double seq;
+    uint32_t *counters;     // device, one per 32-row tile: K-split workgroups of R p done
+    double *p_alt;          // device double[m][T]: second buffer of the fused node sums
+    double *fused_p;        // where the last fuse_out sweep accumulated p (pnq[0] or p_alt)
 };
 
 extern "C" revs_plan_t *revs_plan_create(const revs_plan_desc_t *desc) {
@@ -41,9 +44,15 @@ extern "C" revs_plan_t *revs_plan_create(const revs_plan_desc_t *desc) {
         revs::set_error("revs_plan_create: bad descriptor");
         return nullptr;
     }
-    revs_plan *p = new revs_plan{*desc, nullptr, 0.0};
-    if (hipEventCreateWithFlags(&p->ev, hipEventDisableTiming) != hipSuccess) {
-        revs::set_error("revs_plan_create: hipEventCreate failed");
+    revs_plan *p = new revs_plan{*desc, nullptr, 0.0, nullptr, nullptr, nullptr};
+    const size_t nb = sizeof(uint32_t) * ((desc->m + 31) / 32);
+    const size_t np = sizeof(double) * (size_t)desc->m * desc->T;
+    if (hipEventCreateWithFlags(&p->ev, hipEventDisableTiming) != hipSuccess ||
+        hipMalloc((void **)&p->counters, nb) != hipSuccess ||
+        hipMemset(p->counters, 0, nb) != hipSuccess ||
+        hipMalloc((void **)&p->p_alt, np) != hipSuccess ||
+        hipMemset(p->p_alt, 0, np) != hipSuccess) {
+        revs::set_error("revs_plan_create: hipEventCreate / hipMalloc failed");
         delete p;
         return nullptr;
     }
@@ -53,6 +62,8 @@ extern "C" revs_plan_t *revs_plan_create(const revs_plan_desc_t *desc) {
 extern "C" void revs_plan_destroy(revs_plan_t *plan) {
     if (!plan) return;
     (void)hipEventDestroy(plan->ev);
+    (void)hipFree(plan->counters);
+    (void)hipFree(plan->p_alt);
     delete plan;
 }
 
@@ -77,11 +88,27 @@ extern "C" int revs_plan_spec_step(revs_plan_t *plan, const double *y, int32_t u
                                    d.cand_cnt, d.cand_val, d.stats, seq, nullptr, stream);
         if (rc != REVS_OK) return rc;
     }
-    rc = revs_gemm_tn_f64_split(d.m, d.T, d.m, d.Rt, d.pnq, d.v_slabs, d.ksplit, stream);   // R p
-    if (rc != REVS_OK) return rc;
-    rc = revs_op_dual_rows(d.m, d.T, d.ksplit, d.v_slabs, d.pnq, y, d.vlo, d.vhi, d.vfull, d.viol,
-                           d.partial, fuse_out ? d.pnq : nullptr, stream);
-    if (rc != REVS_OK) return rc;
+    // node sums: this evaluation's (from the home pass above, or from the last fused sweep)
+    // and the buffer the next fused sweep will accumulate into -- never the same array, so
+    // that clearing the latter cannot race with the product reading the former
+    REVS_REQUIRE(!fused_in || plan->fused_p, "revs_plan_spec_step: fused_in without a fused sweep");
+    double *p_in = fused_in ? plan->fused_p : d.pnq;
+    double *p_out = fuse_out ? (p_in == d.pnq ? plan->p_alt : d.pnq) : nullptr;
+    plan->fused_p = p_out;
+    int sel_nblk = 0;
+    if (d.T <= 32 && (d.m + 31) / 32 <= 256) {      // R p and the row bookkeeping in one launch
+        rc = revs_op_dual_product_rows(d.m, d.T, d.Rt, p_in, d.pnq, y, d.vlo, d.vhi, d.ksplit,
+                                       d.v_slabs, d.vfull, d.viol, d.partial, p_out, plan->counters,
+                                       stream);
+        if (rc != REVS_OK) return rc;
+        sel_nblk = (d.m + 31) / 32;
+    } else {
+        rc = revs_gemm_tn_f64_split(d.m, d.T, d.m, d.Rt, p_in, d.v_slabs, d.ksplit, stream);
+        if (rc != REVS_OK) return rc;
+        rc = revs_op_dual_rows(d.m, d.T, d.ksplit, d.v_slabs, d.pnq, y, d.vlo, d.vhi, d.vfull,
+                               d.viol, d.partial, p_out, stream);
+        if (rc != REVS_OK) return rc;
+    }
     if (ev_mid) (void)hipEventRecord((hipEvent_t)ev_mid, s);
     // the candidate selection rides in the sweep's launch (its first T workgroups)
     rc = revs_agent_step_select(d.n_homes, d.T, d.cost, d.homes, d.load, p_est, p_est_new, p_sch,
@@ -89,7 +116,7 @@ extern "C" int revs_plan_spec_step(revs_plan_t *plan, const double *y, int32_t u
                                 d.status, d.pdhg_dual, (float)d.kappa, d.mode, &d.pdhg, d.m,
                                 d.partial, y, d.vlo, d.vhi, d.kadd, d.vfull, d.viol, d.cand_idx,
                                 d.cand_cnt, d.cand_val, d.stats, seq, fuse_out ? d.node_of : nullptr,
-                                fuse_out ? d.pnq : nullptr, fuse_out ? p_est_next : nullptr, stream);
+                                p_out, fuse_out ? p_est_next : nullptr, sel_nblk, stream);
     if (rc != REVS_OK) return rc;
     if (ev_end) (void)hipEventRecord((hipEvent_t)ev_end, s);
     // Wait for the evaluation, not the sweep: poll the sequence tag the select kernel writes
