@@ -43,12 +43,14 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s ach
 F64_MFMA_PEAK_TFLOPS = 78.6    # MI355X datasheet, dense f64 matrix
 
 
-def agent_bytes_per_home(T, write_sc, pdhg_dual):
+def agent_bytes_per_home(T, write_sc, pdhg_dual, fused=False):
     """Algorithmic HBM bytes of revs_agent_step per residence:
     reads LOAD, P_est[k], P_est[k+1], P_sch[k], G[k] (5 profiles) + the 32-byte home
     record; writes P_sch[k+1], G[k+1] (2 profiles) + diff + status (8 bytes);
     the PDHG multipliers when they are carried across iterations (one float per home read
-    and written; one profile each way with full_rows); S and C (2T+1 floats) only on the iteration whose schedules are returned."""
+    and written; one profile each way with full_rows); S and C (2T+1 floats) only on the
+    iteration whose schedules are returned; with the next operator home pass folded in
+    (`fused`) the node index (4 bytes) and the P_est[k+2] candidate (one profile written)."""
     b = 5 * 4 * T + 32 + 2 * 4 * T + 8
     if pdhg_dual == "full":
         b += 2 * 4 * T
@@ -56,6 +58,8 @@ def agent_bytes_per_home(T, write_sc, pdhg_dual):
         b += 2 * 4
     if write_sc:
         b += 4 * T + 4 * (T + 1)
+    if fused:       # the sweep also does the next operator home pass: node index in, P_est out
+        b += 4 + 4 * T
     return b
 
 
@@ -266,7 +270,7 @@ def main():
     if rank == 0:
         warm = (None if eng.pdhg_dual is None else
                 ("full" if eng.pdhg_dual.dim() == 2 else "scalar"))
-        bph = agent_bytes_per_home(args.T, False, warm)
+        bph = agent_bytes_per_home(args.T, False, warm, fused=bool(getattr(eng, "_fused_ready", False)))
         bytes_per_launch = bph * n_local
         ach = bytes_per_launch / (agent_ms * 1e-3) / 1e9
         traffic = None
@@ -306,7 +310,8 @@ def main():
                 "operator_dtype": "f64", "parallelism": f"homes sharded x{world}, nodes replicated",
             },
             "roofline": {
-                "kernel": "agent_step_kernel (home QP sweep + dual update)",
+                "kernel": "agent_step_kernel (home QP sweep + dual update"
+                          + (" + next operator home pass" if getattr(eng, "_fused_ready", False) else "") + ")",
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                 "bytes_per_home": bph,
