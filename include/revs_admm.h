@@ -461,8 +461,7 @@ int revs_op_dual_step(int32_t T, const int64_t *cand_idx, const int32_t *cand_cn
  * evaluation's stats only and report the largest row residual.  The caller keeps the
  * sweep's output iff that residual is within tolerance, else finishes the Newton solve and
  * runs the sweep again.  The plan holds the pointers that do not change between iterations;
- * the ping-pong buffers are passed per call.  One GPU only (a sharded driver has an
- * all-reduce between the two phases of the evaluation and uses the separate calls). */
+ * the ping-pong buffers are passed per call. */
 typedef struct {
     int64_t n_homes; int32_t m; int32_t T;
     const int64_t *node_ptr;
@@ -482,17 +481,24 @@ typedef struct {
 typedef struct revs_plan revs_plan_t;
 revs_plan_t *revs_plan_create(const revs_plan_desc_t *desc_host);
 void revs_plan_destroy(revs_plan_t *plan);
-/* rmax_out_host: largest entry [t][0] of stats (row residual, absolute).  ev_mid / ev_end:
- * optional hipEvent_t handles recorded between evaluation and sweep / after the sweep.
- * fused_in != 0: the previous call (fuse_out != 0, its sweep kept) has already done this
- * evaluation's home pass -- p_est_new and pnq[0] are in place, only product, rows and
- * selection run, and stats[t][1] (D_t) is not meaningful.  fuse_out != 0 (needs use_y = 0):
- * this call's sweep does the next evaluation's home pass into p_est_next / pnq[0]. */
-int revs_plan_spec_step(revs_plan_t *plan, const double *y, int32_t use_y,
+/* phase bit 0: the home pass of the evaluation (revs_op_dual_eval into pnq / p_est_new),
+ * skipped when fused_in != 0: the previous call's sweep (kept by the caller) has already done
+ * it -- p_est_new and the node sums are in place.  phase bit 1: product R p_in with the row
+ * bookkeeping, the sweep with the selection in its launch, then wait for the verdict:
+ * rmax_out_host = largest entry [t][0] of stats (row residual, absolute; stats[t][1] is not
+ * meaningful after a fused home pass).  A driver that shards residences calls phase 1,
+ * all-reduces p_in, calls phase 2.
+ *   p_in    node sums of this evaluation: pnq[0] unless fused_in
+ *   p_out   NULL, or (needs use_y = 0) the array -- not p_in -- into which this call's sweep
+ *           accumulates the NEXT evaluation's node sums while writing p_est_next; it is
+ *           cleared on the way
+ * ev_mid / ev_end: optional hipEvent_t handles recorded between evaluation and sweep / after
+ * the sweep. */
+int revs_plan_spec_step(revs_plan_t *plan, int32_t phase, const double *y, int32_t use_y,
                         const float *p_est, float *p_est_new, const float *p_sch,
                         const float *gamma, float *p_sch_out, float *gamma_out,
-                        float *s_out, float *c_out, int32_t fused_in, int32_t fuse_out,
-                        float *p_est_next, double *rmax_out_host,
+                        float *s_out, float *c_out, int32_t fused_in, const double *p_in,
+                        double *p_out, float *p_est_next, double *rmax_out_host,
                         void *ev_mid, void *ev_end, void *stream);
 
 #ifdef __cplusplus

@@ -59,8 +59,8 @@ SIGNATURES = {
     "revs_host_device_ptr": (C.c_int, [_p, C.POINTER(C.c_void_p)]),
     "revs_plan_create": (C.c_void_p, [C.POINTER(PlanDesc)]),
     "revs_plan_destroy": (None, [_p]),
-    "revs_plan_spec_step": (C.c_int, [_p, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p,
-                                      C.POINTER(C.c_double), _p, _p, _p]),
+    "revs_plan_spec_step": (C.c_int, [_p, _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p,
+                                      _p, _p, C.POINTER(C.c_double), _p, _p, _p]),
     "revs_op_dual_rows": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _f64, _f64, _p, _p, _p, _p, _p]),
     "revs_pdhg_defaults": (None, [C.POINTER(PDHG)]),
     "revs_agent_num_partials": (_i64, [_i64, _i32]),

@@ -35,8 +35,6 @@ struct revs_plan {
     hipEvent_t ev;
     double seq;
     uint32_t *counters;     // device, one per 32-row tile: K-split workgroups of R p done
-    double *p_alt;          // device double[m][T]: second buffer of the fused node sums
-    double *fused_p;        // where the last fuse_out sweep accumulated p (pnq[0] or p_alt)
 };
 
 extern "C" revs_plan_t *revs_plan_create(const revs_plan_desc_t *desc) {
@@ -44,14 +42,11 @@ extern "C" revs_plan_t *revs_plan_create(const revs_plan_desc_t *desc) {
         revs::set_error("revs_plan_create: bad descriptor");
         return nullptr;
     }
-    revs_plan *p = new revs_plan{*desc, nullptr, 0.0, nullptr, nullptr, nullptr};
+    revs_plan *p = new revs_plan{*desc, nullptr, 0.0, nullptr};
     const size_t nb = sizeof(uint32_t) * ((desc->m + 31) / 32);
-    const size_t np = sizeof(double) * (size_t)desc->m * desc->T;
     if (hipEventCreateWithFlags(&p->ev, hipEventDisableTiming) != hipSuccess ||
         hipMalloc((void **)&p->counters, nb) != hipSuccess ||
-        hipMemset(p->counters, 0, nb) != hipSuccess ||
-        hipMalloc((void **)&p->p_alt, np) != hipSuccess ||
-        hipMemset(p->p_alt, 0, np) != hipSuccess) {
+        hipMemset(p->counters, 0, nb) != hipSuccess) {
         revs::set_error("revs_plan_create: hipEventCreate / hipMalloc failed");
         delete p;
         return nullptr;
@@ -63,38 +58,38 @@ extern "C" void revs_plan_destroy(revs_plan_t *plan) {
     if (!plan) return;
     (void)hipEventDestroy(plan->ev);
     (void)hipFree(plan->counters);
-    (void)hipFree(plan->p_alt);
     delete plan;
 }
 
-extern "C" int revs_plan_spec_step(revs_plan_t *plan, const double *y, int32_t use_y,
-                                   const float *p_est, float *p_est_new, const float *p_sch,
-                                   const float *gamma, float *p_sch_out, float *gamma_out,
-                                   float *s_out, float *c_out, int32_t fused_in, int32_t fuse_out,
-                                   float *p_est_next, double *rmax_out, void *ev_mid,
-                                   void *ev_end, void *stream) {
-    REVS_REQUIRE(plan && y && p_est && p_est_new && p_sch && gamma && p_sch_out && gamma_out &&
-                 rmax_out, "revs_plan_spec_step: null argument");
+extern "C" int revs_plan_spec_step(revs_plan_t *plan, int32_t phase, const double *y,
+                                   int32_t use_y, const float *p_est, float *p_est_new,
+                                   const float *p_sch, const float *gamma, float *p_sch_out,
+                                   float *gamma_out, float *s_out, float *c_out, int32_t fused_in,
+                                   const double *p_in, double *p_out, float *p_est_next,
+                                   double *rmax_out, void *ev_mid, void *ev_end, void *stream) {
+    REVS_REQUIRE(plan && phase >= 1 && phase <= 3 && y && p_est && p_est_new && p_sch && gamma &&
+                 p_sch_out && gamma_out && rmax_out && p_in, "revs_plan_spec_step: bad argument");
     const revs_plan_desc_t &d = plan->d;
+    const bool fuse_out = p_out != nullptr;
     REVS_REQUIRE(!(fuse_out || fused_in) || (!use_y && d.node_of && (!fuse_out || p_est_next)),
                  "revs_plan_spec_step: fused home pass needs y = 0, node_of and p_est_next");
+    REVS_REQUIRE(p_out != p_in && (fused_in || p_in == d.pnq),
+                 "revs_plan_spec_step: p_in / p_out inconsistent");
     hipStream_t s = (hipStream_t)stream;
-    const double seq = (plan->seq += 1.0);
     int rc;
-    if (!fused_in) {                 // home pass of this evaluation (else: the last sweep did it)
+    if ((phase & 1) && !fused_in) {  // home pass of this evaluation (else: the last sweep did it)
         rc = revs_op_dual_evaluate(1, d.m, d.T, d.node_ptr, p_est, p_sch, gamma, d.R, d.Rt, y, use_y,
                                    d.kappa, d.vlo, d.vhi, d.kadd, d.ksplit, d.d_slabs, d.v_slabs,
                                    d.pnq, p_est_new, d.vfull, d.viol, d.partial, d.cand_idx,
-                                   d.cand_cnt, d.cand_val, d.stats, seq, nullptr, stream);
+                                   d.cand_cnt, d.cand_val, d.stats, 0.0, nullptr, stream);
         if (rc != REVS_OK) return rc;
     }
-    // node sums: this evaluation's (from the home pass above, or from the last fused sweep)
-    // and the buffer the next fused sweep will accumulate into -- never the same array, so
-    // that clearing the latter cannot race with the product reading the former
-    REVS_REQUIRE(!fused_in || plan->fused_p, "revs_plan_spec_step: fused_in without a fused sweep");
-    double *p_in = fused_in ? plan->fused_p : d.pnq;
-    double *p_out = fuse_out ? (p_in == d.pnq ? plan->p_alt : d.pnq) : nullptr;
-    plan->fused_p = p_out;
+    if (!(phase & 2)) return REVS_OK;
+    const double seq = (plan->seq += 1.0);
+    // node sums p_in: this evaluation's (from the home pass above, or from the last fused
+    // sweep; all-reduced by a sharded caller between the phases); p_out: where this sweep
+    // accumulates the next ones -- never the same array, so that clearing the latter cannot
+    // race with the product reading the former
     int sel_nblk = 0;
     if (d.T <= 32 && (d.m + 31) / 32 <= 256) {      // R p and the row bookkeeping in one launch
         rc = revs_op_dual_product_rows(d.m, d.T, d.Rt, p_in, d.pnq, y, d.vlo, d.vhi, d.ksplit,

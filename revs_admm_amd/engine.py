@@ -263,7 +263,8 @@ class AdmmEngine:
         # steady-state iteration as ONE native call (one GPU; see revs_plan_spec_step)
         self._plan = None
         self._fused_ready = False        # the last kept sweep did the next evaluation's home pass
-        if (cuda and self.group is None and self.op.solver == "newton" and _kernels is None
+        self._fused_p = None             # ... and where it left the node sums
+        if (cuda and self.op.solver == "newton" and _kernels is None
                 and not os.environ.get("REVS_NO_PLAN")):
             d = _lib.PlanDesc()
             d.n_homes, d.m, d.T = n, M, T
@@ -280,6 +281,7 @@ class AdmmEngine:
             d.pdhg_dual, d.mode, d.pdhg = ptr(self.pdhg_dual), self.mode, self.pdhg
             self.node_of_dev = up(node_of[self.perm].astype(np.int32))
             self.P_est_alt = torch.zeros(n, T, **f32)
+            self.p_alt = nz()                         # second buffer of the fused node sums
             d.node_of = ptr(self.node_of_dev)
             self._plan_desc = d
             self._plan = self.lib.revs_plan_create(C.byref(d))
@@ -935,21 +937,35 @@ class AdmmEngine:
                             events[i].record()       # creates the hipEvent behind the object
                         evh[i - 1] = events[i].cuda_event
                 fused_in = self._fused_ready
-                fuse_out = bool(o.fuse_home_pass and not self._y_support)
+                p0 = self.pnq[0]
+                p_in = self._fused_p if fused_in else p0
+                p_out = None
+                if o.fuse_home_pass and not self._y_support:
+                    p_out = self.p_alt if p_in.data_ptr() == p0.data_ptr() else p0
                 self._fused_ready = False
-                check(self.lib.revs_plan_spec_step(
-                    self._plan, ptr(self.yd[0]), int(self._y_support), ptr(self.P_est),
-                    ptr(self.P_est_new), ptr(self.P_sch), ptr(self.G), ptr(self.P_sch_alt),
-                    ptr(self.G_alt), ptr(self.S) if write_sc else None,
-                    ptr(self.Csoc) if write_sc else None, int(fused_in), int(fuse_out),
-                    ptr(self.P_est_alt), C.byref(rm), evh[0], evh[1],
-                    self.stream), "revs_plan_spec_step")
+
+                def call(phase):
+                    check(self.lib.revs_plan_spec_step(
+                        self._plan, phase, ptr(self.yd[0]), int(self._y_support), ptr(self.P_est),
+                        ptr(self.P_est_new), ptr(self.P_sch), ptr(self.G), ptr(self.P_sch_alt),
+                        ptr(self.G_alt), ptr(self.S) if write_sc else None,
+                        ptr(self.Csoc) if write_sc else None, int(fused_in), ptr(p_in), ptr(p_out),
+                        ptr(self.P_est_alt), C.byref(rm), evh[0], evh[1],
+                        self.stream), "revs_plan_spec_step")
+                if self.group is None:
+                    call(3)
+                else:                                # home pass, exchange of p, the rest
+                    if not fused_in:
+                        call(1)
+                    self._allreduce(p_in)            # the only exchange of the iteration
+                    call(2)
+                fuse_out = p_out is not None
                 kept = rm.value / scale <= o.eps
                 # after a fused home pass the stats carry no dual value: a discarded sweep is
                 # followed by a fresh evaluation instead of a continuation from these stats
                 stt = None if (kept or fused_in) else self.stats_host[0].numpy().copy()
                 if kept and fuse_out:
-                    self._fused_ready = True
+                    self._fused_ready, self._fused_p = True, p_out
             else:
                 self._dual_launch(self.yd[0], self._y_support, 0, full=False)
                 rec(1)

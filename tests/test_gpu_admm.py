@@ -192,6 +192,15 @@ def test_process_group_path_on_one_gpu(gpu_lib):
             np.testing.assert_allclose(db, da, rtol=1e-6, atol=1e-7)
             np.testing.assert_allclose(b.result()[1], a.result()[1], atol=1e-5)
             assert b.residuals(1e-4)[:3] == pytest.approx(a.residuals(1e-4)[:3], rel=1e-5)
+        # long enough for the steady state: the native two-phase iteration around the all-reduce
+        # of p (home pass folded into the sweep, kept and discarded sweeps) == the one-GPU run
+        w2 = make_workload(3000, 24, n_nodes=100, seed=5, binary_feasible=False, stress=1.02)
+        a = _engine(w2, "pdhg")
+        b = _engine(w2, "pdhg", group=dist.group.WORLD)
+        da, db = a.run(25), b.run(25)
+        assert b._plan is not None and b.spec_hist == a.spec_hist and a.spec_hist[0] > 0 < a.spec_hist[1]
+        np.testing.assert_array_equal(db, da)
+        np.testing.assert_array_equal(b.result()[0], a.result()[0])
     finally:
         dist.destroy_process_group()
 
