@@ -172,3 +172,129 @@ def test_more_multipliers_than_the_model_holds(gpu_lib):
     torch.cuda.synchronize()
     cnt, st = gb["ccnt"].cpu().numpy(), gb["stats"].cpu().numpy()
     assert cnt[1] == -1 and st[1, 2] == (y[:, 1] != 0).sum() > A and (cnt[[0, 2, 3]] > 0).all()
+
+
+def test_product_rows_in_one_launch_equals_two_kernels(gpu_lib):
+    """revs_op_dual_product_rows (rows epilogue in the last K-split workgroup of every row
+    tile) against revs_gemm_tn_f64_split + revs_op_dual_rows: v and the violations bit for
+    bit (same slab order), the per-slot folds of the partials equal, the cleared array
+    cleared, the tile counters back at zero."""
+    import torch
+    from revs_admm_amd._lib import check, ptr
+    M, T, ks = 300, 24, 4
+    node_of, ptr_, R, pe, ps, gm, y = _case(3, 2500, M, T, 7)
+    rng = np.random.default_rng(0)
+    f64 = dict(dtype=torch.float64, device="cuda:0")
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    Rt, yd = up(R.T), up(y)
+    pnq = up(np.stack([rng.uniform(0, 30, (M, T)), rng.integers(0, 9, (M, T)).astype(float),
+                       -rng.uniform(0, 50, (M, T))]))
+    vlo, vhi = -0.05, 0.06
+    nblk_a, nblk_b = int(gpu_lib.revs_op_dual_blocks(M)), (M + 31) // 32
+    out = {}
+    for tag, nblk in (("two", nblk_a), ("one", nblk_b)):
+        vs = torch.zeros(ks, M, T, **f64)
+        vf, vi = torch.zeros(M, T, **f64), torch.zeros(M, T, **f64)
+        part = torch.zeros(nblk, T, 4, **f64)
+        zero = torch.full((M, T), 3.0, **f64)
+        if tag == "two":
+            check(gpu_lib.revs_gemm_tn_f64_split(M, T, M, ptr(Rt), ptr(pnq), ptr(vs), ks, None))
+            check(gpu_lib.revs_op_dual_rows(M, T, ks, ptr(vs), ptr(pnq), ptr(yd), vlo, vhi, ptr(vf),
+                                            ptr(vi), ptr(part), ptr(zero), None))
+        else:
+            cnt = torch.zeros(nblk, dtype=torch.int32, device="cuda:0")
+            for _ in range(2):           # twice: the counters must reset themselves
+                check(gpu_lib.revs_op_dual_product_rows(M, T, ptr(Rt), ptr(pnq), ptr(pnq), ptr(yd), vlo,
+                                                        vhi, ks, ptr(vs), ptr(vf), ptr(vi), ptr(part),
+                                                        ptr(zero), ptr(cnt), None))
+            torch.cuda.synchronize()
+            assert (cnt == 0).all()
+        torch.cuda.synchronize()
+        assert (zero == 0).all()
+        out[tag] = (vf.cpu().numpy(), vi.cpu().numpy(), part.cpu().numpy())
+    np.testing.assert_array_equal(out["one"][0], out["two"][0])
+    np.testing.assert_array_equal(out["one"][1], out["two"][1])
+    assert np.abs(out["one"][0] - R @ pnq[0].cpu().numpy()).max() < 1e-12 * np.abs(out["one"][0]).max()
+    pa, pb = out["two"][2], out["one"][2]
+    np.testing.assert_array_equal(pa[:, :, 0].max(0), pb[:, :, 0].max(0))
+    np.testing.assert_allclose(pa[:, :, 1].sum(0), pb[:, :, 1].sum(0), rtol=1e-13)
+    np.testing.assert_array_equal(pa[:, :, 2:].sum(0), pb[:, :, 2:].sum(0))
+    assert pb[:, :, 2].sum() == (y != 0).sum() and pb[:, :, 3].sum() > 0
+
+
+@pytest.mark.parametrize("mode", [1, 0])
+def test_sweep_with_selection_and_next_home_pass(gpu_lib, mode):
+    """revs_agent_step_select against its parts: the sweep's own outputs equal
+    revs_agent_step_out's bit for bit; the selection riding in its launch equals
+    revs_op_dual_select's; the folded home pass equals revs_op_dual_eval run afterwards on
+    the new state (P_est candidate bit for bit, node sums to rounding: atomics)."""
+    import torch
+    from revs_admm_amd import _lib
+    from revs_admm_amd._lib import check, ptr
+    from revs_admm_amd.engine import pack_homes
+    from revs_admm_amd.synthetic import make_workload
+    w = make_workload(5000, 24, n_nodes=120, seed=9, binary_feasible=(mode == 0), stress=1.0)
+    n, T, M = w.N, 24, w.M
+    rng = np.random.default_rng(4)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    f32 = dict(dtype=torch.float32, device="cuda:0")
+    f64 = dict(dtype=torch.float64, device="cuda:0")
+    order = np.argsort(w.node_of, kind="stable")
+    homes = up(w.homes[order].view(np.uint8).reshape(n, _lib.HOME_DTYPE.itemsize))
+    load, node32 = up(w.load[order].astype(np.float32)), up(w.node_of[order].astype(np.int32))
+    cnt = np.bincount(w.node_of, minlength=M)
+    nptr = up(np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64))
+    cost = up(w.cost.astype(np.float32))
+    pe, pen = up(rng.uniform(0, 3, (n, T)).astype(np.float32)), up(rng.uniform(0, 3, (n, T)).astype(np.float32))
+    ps, gm = up(rng.uniform(0, 3, (n, T)).astype(np.float32)), up(rng.normal(0, 1, (n, T)).astype(np.float32))
+    npart = int(gpu_lib.revs_agent_num_partials(n, T))
+    pd = _lib.PDHG()
+    gpu_lib.revs_pdhg_defaults(C.byref(pd))
+    # selection inputs: a bookkeeping state with violations and a few multipliers
+    y = np.zeros((M, T)); y[rng.choice(M, 5, replace=False), 3] = 50.0
+    yd = up(y)
+    vs = up(rng.uniform(0.0, 0.03, (2, M, T)))
+    pnq = up(np.stack([rng.uniform(0, 30, (M, T)), np.ones((M, T)), -rng.uniform(0, 5, (M, T))]))
+    nblk = int(gpu_lib.revs_op_dual_blocks(M))
+    A_ = 128
+
+    def sel_buffers():
+        return dict(vf=torch.zeros(M, T, **f64), vi=torch.zeros(M, T, **f64),
+                    part=torch.zeros(nblk, T, 4, **f64),
+                    cidx=torch.zeros(T, A_, dtype=torch.int64, device="cuda:0"),
+                    ccnt=torch.zeros(T, dtype=torch.int32, device="cuda:0"),
+                    cval=torch.zeros(T, 3, A_, **f64), st=torch.zeros(T, 8, **f64))
+    ref, fus = sel_buffers(), sel_buffers()
+    check(gpu_lib.revs_op_dual_select(M, T, 2, ptr(vs), ptr(pnq), ptr(yd), -0.05, 0.06, 16, ptr(ref["vf"]),
+                                      ptr(ref["vi"]), ptr(ref["part"]), ptr(ref["cidx"]), ptr(ref["ccnt"]),
+                                      ptr(ref["cval"]), ptr(ref["st"]), 5.0, None))
+    check(gpu_lib.revs_op_dual_rows(M, T, 2, ptr(vs), ptr(pnq), ptr(yd), -0.05, 0.06, ptr(fus["vf"]),
+                                    ptr(fus["vi"]), ptr(fus["part"]), None, None))
+
+    def outs():
+        return dict(ps=torch.zeros(n, T, **f32), g=torch.zeros(n, T, **f32), diff=torch.zeros(n, **f32),
+                    part=torch.zeros(3 * npart, **f32), status=torch.zeros(n, dtype=torch.int32, device="cuda:0"))
+    a, b = outs(), outs()
+    common = lambda o: (n, T, ptr(cost), ptr(homes), ptr(load), ptr(pe), ptr(pen), ptr(ps), ptr(gm),
+                        ptr(o["ps"]), ptr(o["g"]), None, None, ptr(o["diff"]), ptr(o["part"]),
+                        ptr(o["status"]), None, 5.0, mode, C.byref(pd))
+    check(gpu_lib.revs_agent_step_out(*common(a), None))
+    p_next, pe2 = torch.zeros(M, T, **f64), torch.zeros(n, T, **f32)
+    check(gpu_lib.revs_agent_step_select(*common(b), M, ptr(fus["part"]), ptr(yd), -0.05, 0.06, 16,
+                                         ptr(fus["vf"]), ptr(fus["vi"]), ptr(fus["cidx"]), ptr(fus["ccnt"]),
+                                         ptr(fus["cval"]), ptr(fus["st"]), 5.0, ptr(node32), ptr(p_next),
+                                         ptr(pe2), 0, None))
+    torch.cuda.synchronize()
+    for k in ("ps", "g", "diff", "part", "status"):
+        assert torch.equal(a[k], b[k]), k
+    for k in ("cidx", "ccnt", "cval"):
+        assert torch.equal(ref[k], fus[k]), k
+    assert torch.equal(ref["st"][:, :4], fus["st"][:, :4]) and (fus["st"][:, 5] == 5.0).all()
+    assert (fus["ccnt"] > 0).any()
+    # the folded home pass == revs_op_dual_eval on (P_est[k+1], P_sch[k+1], G[k+1])
+    pnq2, pe_ref = torch.zeros(3, M, T, **f64), torch.zeros(n, T, **f32)
+    check(gpu_lib.revs_op_dual_eval(M, T, ptr(nptr), ptr(pen), ptr(b["ps"]), ptr(b["g"]), 1, None, 5.0,
+                                    ptr(pnq2), ptr(pe_ref), None))
+    torch.cuda.synchronize()
+    assert torch.equal(pe2, pe_ref) and (pe2 == 0).any() and (pe2 > 0).any()
+    np.testing.assert_allclose(p_next.cpu().numpy(), pnq2[0].cpu().numpy(), rtol=1e-13, atol=1e-12)
