@@ -1,4 +1,7 @@
-// Operator ("Utility") side of one ADMM iteration -- gfx950, double precision.
+// Operator ("Utility") side of one ADMM iteration by ADMM in OSQP form -- gfx950, double
+// precision.  FALLBACK: the default path is the dual Newton solver of newton_kernels.hip;
+// these kernels run under OperatorOptions(solver="admm") or when a Newton solve hands an
+// iteration over (more than 128 binding rows in a slot, ...).
 //
 // Reference: class Utility, lpsolver.py:163-238.  The operator's problem
 //     min  sum_i (kappa/2)|g_i|^2 + g_i . a_i           a_i = gamma_i - (kappa/2)(P_est_i + P_sch_i)
