@@ -18,7 +18,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librevs_admm.so")
 SOURCES = ["runtime.cpp", "agent_kernels.hip", "operator_kernels.hip", "newton_kernels.hip",
            "gemm_kernels.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(ROOT, "include", "revs_admm.h")]
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "select_body.h"),
+           os.path.join(ROOT, "include", "revs_admm.h")]
 
 
 def hipcc() -> str:
