@@ -437,7 +437,9 @@ def test_native_step_and_fused_home_pass_change_nothing(gpu_lib, mode, monkeypat
     last bits), over a run with kept AND discarded speculative sweeps."""
     from revs_admm_amd.engine import OperatorOptions
     from revs_admm_amd.synthetic import make_workload
-    w = make_workload(3000, 24, n_nodes=100, seed=5, binary_feasible=(mode == "binary"), stress=1.02)
+    # (binary schedules at stress 1 keep the rows moving: no steady state; at 0.5 the rows stay slack)
+    w = make_workload(3000, 24, n_nodes=100, seed=5, binary_feasible=(mode == "binary"),
+                      stress=1.02 if mode == "pdhg" else 0.5)
     runs = []
     for plan, fuse in ((True, True), (True, False), (False, False)):
         if plan:
@@ -450,8 +452,7 @@ def test_native_step_and_fused_home_pass_change_nothing(gpu_lib, mode, monkeypat
         runs.append((d, e.result(), e.P_est.cpu().numpy(), list(e.spec_hist),
                      [h[0] for h in e.newton_hist]))
     ref = runs[-1]
-    if mode == "pdhg":                   # (binary schedules keep the rows moving: no steady state)
-        assert ref[3][0] > 0 and ref[3][1] > 0
+    assert ref[3][0] > 0 and (mode == "binary" or ref[3][1] > 0)
     for r in runs[:-1]:
         assert r[3] == ref[3] and r[4] == ref[4]
         np.testing.assert_array_equal(r[0], ref[0])
