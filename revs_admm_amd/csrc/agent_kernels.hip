@@ -262,18 +262,29 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
             const float inv1 = __builtin_amdgcn_rcpf(1.0f + tau1);
             const float sd1 = sig1 * delta;
             float yy = ev ? yy_in : 0.f;
+            // The sweep is VALU-issue bound and half of its instructions are this loop, so the
+            // iteration is arranged for the fewest operations:
+            //   x+ = clip((x - tau (sd y + b)) / (1 + tau), 0, w) = clip(a x - cb - s, 0, w),
+            //        a = 1/(1+tau), cb = tau a b (per slot, once), s = tau a sd y (one multiply)
+            //   K (2 x+ - x) = delta (2 sum x+ - sum x), with sum x carried from the last pass
+            const float ts = tau1 * inv1 * sd1;
+            float cb[SPL], sx = 0.f;
+#pragma unroll
+            for (int j = 0; j < SPL; ++j) { cb[j] = tau1 * inv1 * b[j]; sx += x[j]; }
             auto iterate1 = [&](auto res_tag) -> float {
                 constexpr bool RES = decltype(res_tag)::value;
-                const float kty = sd1 * yy;
-                float acc = 0.f, dmax = 0.f;
+                const float s = ts * yy;
+                float sn = 0.f, dmax = 0.f;
 #pragma unroll
                 for (int j = 0; j < SPL; ++j) {
-                    const float xn = clip3((x[j] - tau1 * (kty + b[j])) * inv1, 0.f, w[j]);
-                    acc += xn + (xn - x[j]);
+                    const float xn = clip3(fmaf(inv1, x[j], -cb[j]) - s, 0.f, w[j]);
+                    sn += xn;
                     if constexpr (RES) dmax = fmaxf(dmax, fabsf(xn - x[j]));
                     x[j] = xn;
                 }
-                const float v = yy + delta * group_sum<LPA>(acc);
+                const float acc = fmaf(2.0f, sn, -sx);
+                sx = sn;
+                const float v = fmaf(delta, group_sum<LPA>(acc), yy);
                 const float yn = v - clip3(v, lo_last, hi);
                 if constexpr (RES) dmax = fmaxf(dmax, fabsf(yn - yy));
                 yy = yn;
