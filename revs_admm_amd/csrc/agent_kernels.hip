@@ -418,7 +418,7 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
 #pragma unroll
     for (int j = 0; j < SPL; ++j) { pacc += p[j]; pfx[j] = pacc; }
     const float poff = group_excl_prefix<LPA>(pacc, lig, mk);
-    const float invcap = ev ? 1.0f / h.capacity : 0.f;
+    const float invcap = ev ? __builtin_amdgcn_rcpf(h.capacity) : 0.f;    // (1 ulp; SOC only)
     const int64_t crow = agent * (int64_t)(T + 1);
     float gn[SPL], gmn[SPL], socv[SPL];
 #pragma unroll
@@ -466,7 +466,8 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
     }
     if (live && lig == 0 && a.c_out) a.c_out[crow] = ev ? h.initial : 0.f;
     const float ssg = group_sum<LPA>(ss);
-    const float dfh = live ? sqrtf(ssg) / (float)T : 0.f;   // lpsolver.py:284
+    // lpsolver.py:284; hardware sqrt and reciprocal (1 ulp each) instead of the IEEE sequences
+    const float dfh = live ? __builtin_amdgcn_sqrtf(ssg) * __builtin_amdgcn_rcpf((float)T) : 0.f;
     if (live && lig == 0) {
         a.diff[agent] = dfh;
         if (a.status) a.status[agent] = status;
