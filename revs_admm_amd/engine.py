@@ -84,7 +84,7 @@ class OperatorOptions:
     node_fast: bool = True
     # "newton": semismooth Newton on the dual (voltage-row multipliers), the default;
     # "admm": the OSQP-form iterations above only.  The Newton path hands an iteration to
-    # the ADMM forms when it cannot finish (more than 64 binding rows in a slot, ...).
+    # the ADMM forms when it cannot finish (more than 128 binding rows in a slot, ...).
     solver: str = "newton"
     newton_max: int = 60         # Newton iterations per operator solve
     newton_kadd: int = 16        # violated rows admitted to a slot's model per iteration
