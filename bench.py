@@ -46,12 +46,12 @@ F64_MFMA_PEAK_TFLOPS = 78.6    # MI355X datasheet, dense f64 matrix
 def agent_bytes_per_home(T, write_sc, pdhg_dual, fused=False):
     """Algorithmic HBM bytes of revs_agent_step per residence:
     reads LOAD, P_est[k], P_est[k+1], P_sch[k], G[k] (5 profiles) + the 32-byte home
-    record; writes P_sch[k+1], G[k+1] (2 profiles) + diff + status (8 bytes);
+    record; writes P_sch[k+1], G[k+1] (2 profiles) + diff + dsq + status (12 bytes);
     the PDHG multipliers when they are carried across iterations (one float per home read
     and written; one profile each way with full_rows); S and C (2T+1 floats) only on the
     iteration whose schedules are returned; with the next operator home pass folded in
     (`fused`) the node index (4 bytes) and the P_est[k+2] candidate (one profile written)."""
-    b = 5 * 4 * T + 32 + 2 * 4 * T + 8
+    b = 5 * 4 * T + 32 + 2 * 4 * T + 12
     if pdhg_dual == "full":
         b += 2 * 4 * T
     elif pdhg_dual:

@@ -79,9 +79,9 @@ int revs_host_device_ptr(void *host_ptr, void **dev_ptr_out);
 /* Defaults used when `pdhg` is NULL: 4000, 4, 1e-6, automatic scales, presolved rows */
 void revs_pdhg_defaults(revs_pdhg_t *out_host);
 
-/* Number of partial-residual records (3 floats each) revs_agent_step writes for
- * n_homes, one per workgroup; size `partials` as float[3 * that]. */
-int64_t revs_agent_num_partials(int64_t n_homes, int32_t T);
+/* Number of chunk records (3 doubles each) revs_residual_finalize uses for n_homes; size its
+ * `scratch` as double[3 * that]. */
+int32_t revs_residual_num_chunks(int64_t n_homes);
 
 /* One ADMM iteration of the residence side for ALL homes:
  *   Home(cost, homes[h], P_est[k][h], P_sch[k][h], G[k][h]).solve()  lpsolver.py:273-277
@@ -98,8 +98,9 @@ int64_t revs_agent_num_partials(int64_t n_homes, int32_t T);
  *   s_out       float[n][T]       p_opt  (reference's S)   or NULL to skip
  *   c_out       float[n][T+1]     s_opt  (reference's C)   or NULL to skip
  *   diff        float[n]          diff[k+1]
- *   partials    float[3*np]       per workgroup {sum |P_est-P_sch|^2, sum |P_sch[k+1]-P_sch[k]|^2,
- *                                 max diff}
+ *   dsq         float[n]          per home sum_t (P_sch[k+1] - P_sch[k])^2 (the dual residual's
+ *                                 terms; folded with diff by revs_residual_finalize on request --
+ *                                 the sweep itself does no reduction across homes)
  *   status      int32[n]          0 ok, 1 infeasible ("No solution found", lpsolver.py:153-155),
  *                                 for PDHG: iterations used in bits 8.. ; or NULL
  *   pdhg_dual   float[n] (float[n][T] with full_rows)   REVS_MODE_RELAXED_PDHG only, or NULL:
@@ -113,7 +114,7 @@ int revs_agent_step(int64_t n_homes, int32_t T,
                     const float *p_est_old, const float *p_est_new,
                     float *p_sch, float *gamma,
                     float *s_out, float *c_out, float *diff,
-                    float *partials, int32_t *status, float *pdhg_dual,
+                    float *dsq, int32_t *status, float *pdhg_dual,
                     float kappa, int32_t mode, const revs_pdhg_t *pdhg_host,
                     void *stream);
 
@@ -127,7 +128,7 @@ int revs_agent_step_out(int64_t n_homes, int32_t T,
                         const float *p_sch, const float *gamma,
                         float *p_sch_out, float *gamma_out,
                         float *s_out, float *c_out, float *diff,
-                        float *partials, int32_t *status, float *pdhg_dual,
+                        float *dsq, int32_t *status, float *pdhg_dual,
                         float kappa, int32_t mode, const revs_pdhg_t *pdhg_host,
                         void *stream);
 
@@ -149,7 +150,7 @@ int revs_agent_step_select(int64_t n_homes, int32_t T,
                            const float *p_sch, const float *gamma,
                            float *p_sch_out, float *gamma_out,
                            float *s_out, float *c_out, float *diff,
-                           float *partials, int32_t *status, float *pdhg_dual,
+                           float *dsq, int32_t *status, float *pdhg_dual,
                            float kappa, int32_t mode, const revs_pdhg_t *pdhg_host,
                            int32_t m, const double *sel_partial, const double *y, double vlo,
                            double vhi, int32_t kadd, const double *vfull, const double *viol,
@@ -158,15 +159,15 @@ int revs_agent_step_select(int64_t n_homes, int32_t T,
                            const int32_t *node_of, double *p_next, float *p_est_next,
                            int32_t sel_nblk, void *stream);
 
-/* Wavefront reduction of the per-workgroup partials to the global ADMM residuals
- *   out[0] = |P_est[k+1] - P_sch[k+1]|_2           (primal residual, all homes)
- *   out[1] = kappa * |P_sch[k+1] - P_sch[k]|_2     (dual residual)
+/* The global ADMM residuals from the per-home terms of the last sweep (two small kernels,
+ * double accumulation in a fixed order: bitwise reproducible):
+ *   out[0] = |P_est[k+1] - P_sch[k+1]|_2 = sqrt(sum (T diff)^2)   (primal residual)
+ *   out[1] = kappa * |P_sch[k+1] - P_sch[k]|_2 = kappa sqrt(sum dsq)   (dual residual)
  *   out[2] = max_h diff[k+1][h]   -- the reference's convergence measure (lpsolver.py:284)
  *   out[3] = 1.0f if out[2] <= eps else 0.0f       (convergence flag, stays on device)
- * out: float[4] on the device.  Deterministic (fixed summation order).          */
-int revs_residual_finalize(const float *partials, int64_t num_partials,
-                           int64_t n_homes, int32_t T, float kappa, float eps,
-                           float *out, void *stream);
+ * out: float[4] on the device; scratch: double[3 * revs_residual_num_chunks(n_homes)].   */
+int revs_residual_finalize(const float *diff, const float *dsq, int64_t n_homes, int32_t T,
+                           float kappa, float eps, double *scratch, float *out, void *stream);
 
 /* Individual mode, lpsolver.py:430-460 (solve_residence): min 0.01 tariff.g +
  * 0.99 (1 - s_T), binary charger, SOC box, no s_T >= 0.9 row.
@@ -473,7 +474,7 @@ typedef struct {
     double *stats;               /* device-side address of stats_host */
     const double *stats_host;    /* pinned host memory, double[T][8] */
     const float *cost; const revs_home_t *homes; const float *load;
-    float *diff, *partials; int32_t *status; float *pdhg_dual;
+    float *diff, *dsq; int32_t *status; float *pdhg_dual;
     int32_t mode;
     revs_pdhg_t pdhg;
     const int32_t *node_of;      /* node of every residence, or NULL (no fused home pass) */

@@ -16,7 +16,7 @@ import sys
 import pandas as pd
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BYTES_PER_HOME = int(os.environ.get("REVS_BYTES_PER_HOME", "820"))   # bench.py agent_bytes_per_home
+BYTES_PER_HOME = int(os.environ.get("REVS_BYTES_PER_HOME", "824"))   # bench.py agent_bytes_per_home
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out")
 rows = []
 for tag, homes in (("pmc", 100000), ("pmc1m", 1000000)):

@@ -40,7 +40,7 @@ class PlanDesc(C.Structure):
                 ("cand_idx", C.c_void_p), ("cand_cnt", C.c_void_p), ("cand_val", C.c_void_p),
                 ("stats", C.c_void_p), ("stats_host", C.c_void_p),
                 ("cost", C.c_void_p), ("homes", C.c_void_p), ("load", C.c_void_p),
-                ("diff", C.c_void_p), ("partials", C.c_void_p), ("status", C.c_void_p),
+                ("diff", C.c_void_p), ("dsq", C.c_void_p), ("status", C.c_void_p),
                 ("pdhg_dual", C.c_void_p), ("mode", C.c_int32), ("pdhg", PDHG),
                 ("node_of", C.c_void_p)]
 
@@ -63,7 +63,7 @@ SIGNATURES = {
                                       _p, _p, C.POINTER(C.c_double), _p, _p, _p]),
     "revs_op_dual_rows": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _f64, _f64, _p, _p, _p, _p, _p]),
     "revs_pdhg_defaults": (None, [C.POINTER(PDHG)]),
-    "revs_agent_num_partials": (_i64, [_i64, _i32]),
+    "revs_residual_num_chunks": (_i32, [_i64]),
     "revs_agent_step": (C.c_int, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                   _f32, _i32, C.POINTER(PDHG), _p]),
     "revs_agent_step_out": (C.c_int, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
@@ -74,7 +74,7 @@ SIGNATURES = {
                                          _i32, _p]),
     "revs_op_dual_product_rows": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _f64, _f64, _i32, _p, _p, _p,
                                             _p, _p, _p, _p]),
-    "revs_residual_finalize": (C.c_int, [_p, _i64, _i64, _i32, _f32, _f32, _p, _p]),
+    "revs_residual_finalize": (C.c_int, [_p, _p, _i64, _i32, _f32, _f32, _p, _p, _p]),
     "revs_residence_solve": (C.c_int, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p]),
     "revs_gemm_tn_f64": (C.c_int, [_i32, _i32, _i32, _p, _i32, _p, _i32, _p, _i32, _i32, _p]),
     "revs_gemm_tn_f32": (C.c_int, [_i32, _i32, _i32, _p, _i32, _p, _i32, _p, _i32, _i32, _p]),

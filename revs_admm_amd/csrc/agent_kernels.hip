@@ -17,9 +17,9 @@
 // transpose (suffix sum) are an in-lane scan plus a log2(LPA)-step DPP scan
 // across the group -- no LDS, no T x T matrix is ever formed.
 //
-// Arithmetic: float (BASELINE north star); the residual partials are summed in
-// float per workgroup and in double by residual_finalize_kernel, which also takes
-// the maximum of diff over all homes (the reference's only convergence measure).
+// Arithmetic: float (BASELINE north star); the per-home residual terms (diff, dsq) are
+// summed in double by the residual kernels on request, which also take the maximum of
+// diff over all homes (the reference's only convergence measure).
 #include "common.h"
 #include "select_body.h"
 #include <math.h>
@@ -43,7 +43,7 @@ struct AgentArgs {
     float *s_out;
     float *c_out;
     float *diff;
-    float *partials;
+    float *dsq;            // per home: sum_t (P_sch[k+1] - P_sch[k])^2
     int32_t *status;
     float *y_state;
     float kappa;
@@ -465,26 +465,25 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
         }
     }
     if (live && lig == 0 && a.c_out) a.c_out[crow] = ev ? h.initial : 0.f;
+    // per-home residual terms; the norms over all homes are folded by revs_residual_finalize
+    // only when somebody asks for them (no workgroup reduction in the sweep, which is VALU
+    // issue bound)
     const float ssg = group_sum<LPA>(ss);
+    const float ddg = group_sum<LPA>(dd);
     // lpsolver.py:284; hardware sqrt and reciprocal (1 ulp each) instead of the IEEE sequences
     const float dfh = live ? __builtin_amdgcn_sqrtf(ssg) * __builtin_amdgcn_rcpf((float)T) : 0.f;
     if (live && lig == 0) {
         a.diff[agent] = dfh;
+        a.dsq[agent] = ddg;
         if (a.status) a.status[agent] = status;
     }
-    // per-workgroup partial residuals: sum |check|^2, sum |dP_sch|^2, max diff
-    float wss = group_sum<64>(ss), wdd = group_sum<64>(dd), wmx = group_max<64>(dfh);
-    __shared__ float red[3][kBlock / 64];
     // node sums of the next home pass: residences are sorted by node, so a workgroup's homes
     // sit on a few consecutive nodes -- accumulate in LDS, flush one global add per (node, slot)
     constexpr int kNodeLoc = 4, kSlots = LPA * SPL;
     __shared__ double nacc[kNodeLoc][kSlots];
-    if (a.p_next)
-        for (int i = tid; i < kNodeLoc * kSlots; i += kBlock) (&nacc[0][0])[i] = 0.0;
-    const int wave = tid >> 6;
-    if ((tid & 63) == 0) { red[0][wave] = wss; red[1][wave] = wdd; red[2][wave] = wmx; }
-    __syncthreads();
     if (a.p_next) {
+        for (int i = tid; i < kNodeLoc * kSlots; i += kBlock) (&nacc[0][0])[i] = 0.0;
+        __syncthreads();
         const int64_t first = (int64_t)bid * kHomesPerBlock;
         const int base = a.node_of[first < a.n ? first : a.n - 1];
         if (live) {
@@ -505,48 +504,52 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
             if (v != 0.0) unsafeAtomicAdd(&a.p_next[(int64_t)(base + l) * T + t], v);
         }
     }
-    if (tid == 0) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < kBlock / 64; ++w) {
-            s0 += red[0][w]; s1 += red[1][w]; s2 = fmaxf(s2, red[2][w]);
-        }
-        a.partials[3 * (int64_t)bid + 0] = s0;
-        a.partials[3 * (int64_t)bid + 1] = s1;
-        a.partials[3 * (int64_t)bid + 2] = s2;
-    }
 }
 
-// One wavefront-strided pass over the per-workgroup partials, double accumulation,
-// fixed order -> bitwise reproducible residual norms and convergence flag.
-__global__ __launch_bounds__(256) void residual_finalize_kernel(
-        const float *partials, int64_t np, float kappa, float eps, float *out) {
-    double s0 = 0.0, s1 = 0.0;
-    float mx = 0.f;
-    for (int64_t i = threadIdx.x; i < np; i += 256) {
-        s0 += (double)partials[3 * i];
-        s1 += (double)partials[3 * i + 1];
-        mx = fmaxf(mx, partials[3 * i + 2]);
+// Residual norms from the per-home terms, on request only (not part of the sweep):
+// stage 1, workgroup b folds the contiguous chunk b of homes into scratch[b] =
+// {sum (T diff)^2, sum dsq, max diff} in double, fixed order; stage 2 folds the chunks.
+// Bitwise reproducible.
+__global__ __launch_bounds__(256) void residual_chunks_kernel(
+        const float *__restrict__ diff, const float *__restrict__ dsq, int64_t n, int32_t T,
+        double *__restrict__ scratch) {
+    const int64_t chunk = (n + gridDim.x - 1) / gridDim.x;
+    const int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
+    double s0 = 0.0, s1 = 0.0, mx = 0.0;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const double d = (double)diff[i] * T;
+        s0 += d * d;
+        s1 += (double)dsq[i];
+        mx = fmax(mx, (double)diff[i]);
     }
     for (int d = 32; d >= 1; d >>= 1) {
         s0 += __shfl_xor(s0, d, 64);
         s1 += __shfl_xor(s1, d, 64);
-        mx = fmaxf(mx, __shfl_xor(mx, d, 64));
+        mx = fmax(mx, __shfl_xor(mx, d, 64));
     }
-    __shared__ double red[2][4];
-    __shared__ float redm[4];
+    __shared__ double red[3][4];
     if ((threadIdx.x & 63) == 0) {
-        red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; redm[threadIdx.x >> 6] = mx;
+        red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; red[2][threadIdx.x >> 6] = mx;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        s0 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        s1 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-        mx = fmaxf(fmaxf(redm[0], redm[1]), fmaxf(redm[2], redm[3]));
+        scratch[3 * blockIdx.x + 0] = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+        scratch[3 * blockIdx.x + 1] = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+        scratch[3 * blockIdx.x + 2] = fmax(fmax(red[2][0], red[2][1]), fmax(red[2][2], red[2][3]));
+    }
+}
+
+__global__ __launch_bounds__(64) void residual_finalize_kernel(
+        const double *__restrict__ scratch, int nchunk, float kappa, float eps, float *out) {
+    if (threadIdx.x == 0) {
+        double s0 = 0.0, s1 = 0.0, mx = 0.0;
+        for (int b = 0; b < nchunk; ++b) {
+            s0 += scratch[3 * b]; s1 += scratch[3 * b + 1]; mx = fmax(mx, scratch[3 * b + 2]);
+        }
         out[0] = (float)sqrt(s0);
         out[1] = kappa * (float)sqrt(s1);
-        out[2] = mx;
-        out[3] = (mx <= eps) ? 1.0f : 0.0f;
+        out[2] = (float)mx;
+        out[3] = ((float)mx <= eps) ? 1.0f : 0.0f;
     }
 }
 
@@ -670,11 +673,17 @@ extern "C" void revs_pdhg_defaults(revs_pdhg_t *o) {
     o->full_rows = 0;
 }
 
-extern "C" int64_t revs_agent_num_partials(int64_t n_homes, int32_t T) {
+static int64_t agent_num_blocks(int64_t n_homes, int32_t T) {
     if (n_homes <= 0 || T <= 0 || T > REVS_MAX_T) return 0;
     const Shape sh = pick_shape(T);
     const int64_t per = kBlock / sh.lpa;
     return (n_homes + per - 1) / per;
+}
+
+extern "C" int32_t revs_residual_num_chunks(int64_t n_homes) {
+    if (n_homes <= 0) return 0;
+    const int64_t c = (n_homes + 4095) / 4096;
+    return (int32_t)(c < 256 ? c : 256);
 }
 
 static int agent_step_impl(int64_t n_homes, int32_t T, const float *cost,
@@ -682,14 +691,14 @@ static int agent_step_impl(int64_t n_homes, int32_t T, const float *cost,
                            const float *p_est_old, const float *p_est_new,
                            const float *p_sch, const float *gamma, float *p_sch_out,
                            float *gamma_out, float *s_out, float *c_out, float *diff,
-                           float *partials, int32_t *status, float *pdhg_dual,
+                           float *dsq, int32_t *status, float *pdhg_dual,
                            float kappa, int32_t mode, const revs_pdhg_t *pdhg_host,
                            const SelectArgs *sel, const int32_t *node_of, double *p_next,
                            float *pe2_out, void *stream) {
     REVS_REQUIRE(n_homes > 0, "revs_agent_step: n_homes=%lld", (long long)n_homes);
     REVS_REQUIRE(T > 0 && T <= REVS_MAX_T, "revs_agent_step: T=%d outside 1..%d", T, REVS_MAX_T);
     REVS_REQUIRE(cost && homes && load && p_est_old && p_est_new && p_sch && gamma && p_sch_out &&
-                 gamma_out && diff && partials, "revs_agent_step: null pointer argument");
+                 gamma_out && diff && dsq, "revs_agent_step: null pointer argument");
     REVS_REQUIRE(mode >= 0 && mode <= 2, "revs_agent_step: mode=%d", mode);
     REVS_REQUIRE(kappa > 0.f, "revs_agent_step: kappa=%g must be positive", (double)kappa);
     AgentArgs a;
@@ -697,7 +706,7 @@ static int agent_step_impl(int64_t n_homes, int32_t T, const float *cost,
     a.pe_old = p_est_old; a.pe_new = p_est_new;
     a.ps = const_cast<float *>(p_sch); a.gam = const_cast<float *>(gamma);
     a.ps_out = p_sch_out; a.gam_out = gamma_out;
-    a.s_out = s_out; a.c_out = c_out; a.diff = diff; a.partials = partials;
+    a.s_out = s_out; a.c_out = c_out; a.diff = diff; a.dsq = dsq;
     a.status = status; a.y_state = pdhg_dual; a.kappa = kappa;
     a.nsel = 0;
     a.sel = SelectArgs{};
@@ -708,7 +717,7 @@ static int agent_step_impl(int64_t n_homes, int32_t T, const float *cost,
     REVS_REQUIRE(a.pd.max_iter > 0 && a.pd.check > 0 && a.pd.tau_scale >= 0 && a.pd.sigma_scale >= 0,
                  "revs_agent_step: bad PDHG parameters");
     const Shape sh = pick_shape(T);
-    const int64_t nblk = revs_agent_num_partials(n_homes, T);
+    const int64_t nblk = agent_num_blocks(n_homes, T);
     REVS_REQUIRE(nblk < (1ll << 31), "revs_agent_step: too many homes for one launch");
     const dim3 grid((unsigned)(nblk + a.nsel));
     hipStream_t s = (hipStream_t)stream;
@@ -724,11 +733,11 @@ extern "C" int revs_agent_step_out(int64_t n_homes, int32_t T, const float *cost
                                    const float *p_est_old, const float *p_est_new,
                                    const float *p_sch, const float *gamma, float *p_sch_out,
                                    float *gamma_out, float *s_out, float *c_out, float *diff,
-                                   float *partials, int32_t *status, float *pdhg_dual,
+                                   float *dsq, int32_t *status, float *pdhg_dual,
                                    float kappa, int32_t mode, const revs_pdhg_t *pdhg_host,
                                    void *stream) {
     return agent_step_impl(n_homes, T, cost, homes, load, p_est_old, p_est_new, p_sch, gamma,
-                           p_sch_out, gamma_out, s_out, c_out, diff, partials, status, pdhg_dual,
+                           p_sch_out, gamma_out, s_out, c_out, diff, dsq, status, pdhg_dual,
                            kappa, mode, pdhg_host, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
@@ -737,7 +746,7 @@ extern "C" int revs_agent_step_select(int64_t n_homes, int32_t T, const float *c
                                       const float *p_est_old, const float *p_est_new,
                                       const float *p_sch, const float *gamma, float *p_sch_out,
                                       float *gamma_out, float *s_out, float *c_out, float *diff,
-                                      float *partials, int32_t *status, float *pdhg_dual,
+                                      float *dsq, int32_t *status, float *pdhg_dual,
                                       float kappa, int32_t mode, const revs_pdhg_t *pdhg_host,
                                       int32_t m, const double *sel_partial, const double *y,
                                       double vlo, double vhi, int32_t kadd, const double *vfull,
@@ -752,7 +761,7 @@ extern "C" int revs_agent_step_select(int64_t n_homes, int32_t T, const float *c
     const SelectArgs sa{m, T, sel_nblk ? sel_nblk : revs_op_dual_blocks(m), kadd, sel_partial, y, vfull, viol, vlo, vhi,
                         seq, cand_idx, cand_cnt, cand_val, stats};
     return agent_step_impl(n_homes, T, cost, homes, load, p_est_old, p_est_new, p_sch, gamma,
-                           p_sch_out, gamma_out, s_out, c_out, diff, partials, status, pdhg_dual,
+                           p_sch_out, gamma_out, s_out, c_out, diff, dsq, status, pdhg_dual,
                            kappa, mode, pdhg_host, &sa, node_of, p_next, p_est_next, stream);
 }
 
@@ -760,20 +769,23 @@ extern "C" int revs_agent_step(int64_t n_homes, int32_t T, const float *cost,
                                const revs_home_t *homes, const float *load,
                                const float *p_est_old, const float *p_est_new, float *p_sch,
                                float *gamma, float *s_out, float *c_out, float *diff,
-                               float *partials, int32_t *status, float *pdhg_dual, float kappa,
+                               float *dsq, int32_t *status, float *pdhg_dual, float kappa,
                                int32_t mode, const revs_pdhg_t *pdhg_host, void *stream) {
     return revs_agent_step_out(n_homes, T, cost, homes, load, p_est_old, p_est_new, p_sch, gamma,
-                               p_sch, gamma, s_out, c_out, diff, partials, status, pdhg_dual,
+                               p_sch, gamma, s_out, c_out, diff, dsq, status, pdhg_dual,
                                kappa, mode, pdhg_host, stream);
 }
 
-extern "C" int revs_residual_finalize(const float *partials, int64_t num_partials,
-                                      int64_t n_homes, int32_t T, float kappa, float eps,
+extern "C" int revs_residual_finalize(const float *diff, const float *dsq, int64_t n_homes,
+                                      int32_t T, float kappa, float eps, double *scratch,
                                       float *out, void *stream) {
-    REVS_REQUIRE(partials && out && num_partials > 0, "revs_residual_finalize: bad argument");
-    (void)n_homes; (void)T;
-    hipLaunchKernelGGL(residual_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream,
-                       partials, num_partials, kappa, eps, out);
+    REVS_REQUIRE(diff && dsq && scratch && out && n_homes > 0 && T > 0,
+                 "revs_residual_finalize: bad argument");
+    const int nchunk = revs_residual_num_chunks(n_homes);
+    hipLaunchKernelGGL(residual_chunks_kernel, dim3(nchunk), dim3(256), 0, (hipStream_t)stream, diff,
+                       dsq, n_homes, T, scratch);
+    hipLaunchKernelGGL(residual_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, scratch,
+                       nchunk, kappa, eps, out);
     REVS_CHECK_LAUNCH("revs_residual_finalize");
     return REVS_OK;
 }

@@ -183,8 +183,9 @@ class AdmmEngine:
         self.Csoc = torch.zeros(n, T + 1, **f32)
         self.diff = torch.zeros(n, **f32)
         self.status = torch.zeros(n, dtype=torch.int32, device=self.dev)
-        self.n_part = int(self.lib.revs_agent_num_partials(n, T))
-        self.partials = torch.zeros(3 * self.n_part, **f32)
+        self.dsq = torch.zeros(n, **f32)
+        self.res_scratch = torch.zeros(3 * int(self.lib.revs_residual_num_chunks(n)),
+                                       dtype=torch.float64, device=self.dev)
         self.resid = torch.zeros(4, **f32)
         # PDHG multipliers carried across ADMM iterations (warm start), relaxed PDHG only
         self._pdhg_warm = bool(pdhg_warm) and self.mode == _lib.MODE_RELAXED_PDHG
@@ -277,7 +278,7 @@ class AdmmEngine:
                                                   ptr(self.c_val[0]))
             d.stats, d.stats_host = self.stats_dev[0], self.stats_host[0].data_ptr()
             d.cost, d.homes, d.load = ptr(self.cost), ptr(self.homes), ptr(self.load)
-            d.diff, d.partials, d.status = ptr(self.diff), ptr(self.partials), ptr(self.status)
+            d.diff, d.dsq, d.status = ptr(self.diff), ptr(self.dsq), ptr(self.status)
             d.pdhg_dual, d.mode, d.pdhg = ptr(self.pdhg_dual), self.mode, self.pdhg
             self.node_of_dev = up(node_of[self.perm].astype(np.int32))
             self.P_est_alt = torch.zeros(n, T, **f32)
@@ -897,7 +898,7 @@ class AdmmEngine:
             self.n, self.T, ptr(self.cost), ptr(self.homes), ptr(self.load), ptr(self.P_est),
             ptr(self.P_est_new), ptr(self.P_sch), ptr(self.G), ptr(ps_out), ptr(g_out),
             ptr(self.S) if write_sc else None, ptr(self.Csoc) if write_sc else None,
-            ptr(self.diff), ptr(self.partials), ptr(self.status), ptr(self.pdhg_dual),
+            ptr(self.diff), ptr(self.dsq), ptr(self.status), ptr(self.pdhg_dual),
             self.kappa, self.mode,
             C.byref(self.pdhg), self.stream), "revs_agent_step_out")
 
@@ -906,8 +907,9 @@ class AdmmEngine:
         (|P_est - P_sch|_2, kappa |dP_sch|_2, max_h diff[h], converged) where converged
         means max_h diff[h] <= eps -- diff (lpsolver.py:284) is the reference's only
         convergence measure."""
-        check(self.lib.revs_residual_finalize(ptr(self.partials), self.n_part, self.n, self.T,
-                                              self.kappa, eps, ptr(self.resid), self.stream),
+        check(self.lib.revs_residual_finalize(ptr(self.diff), ptr(self.dsq), self.n, self.T,
+                                              self.kappa, eps, ptr(self.res_scratch),
+                                              ptr(self.resid), self.stream),
               "revs_residual_finalize")
         r = self.resid.cpu().numpy().astype(np.float64)
         if self.group is not None:

@@ -25,17 +25,17 @@ class FakeKernels:
         o = ref._obj
         o.max_iter, o.check, o.tol, o.tau_scale, o.sigma_scale = 4000, 4, 1e-6, 0.0, 0.0
 
-    def revs_agent_num_partials(self, n, T):
-        return (n + 31) // 32
+    def revs_residual_num_chunks(self, n):
+        return min(256, (n + 4095) // 4096)
 
     def revs_agent_step(self, n, T, cost, homes, load, pe_old, pe_new, ps, gm, s_out, c_out, diff,
-                        partials, status, pdhg_dual, kappa, mode, pdhg, stream):
+                        dsq, status, pdhg_dual, kappa, mode, pdhg, stream):
         return self.revs_agent_step_out(n, T, cost, homes, load, pe_old, pe_new, ps, gm, ps, gm,
-                                        s_out, c_out, diff, partials, status, pdhg_dual, kappa,
+                                        s_out, c_out, diff, dsq, status, pdhg_dual, kappa,
                                         mode, pdhg, stream)
 
     def revs_agent_step_out(self, n, T, cost, homes, load, pe_old, pe_new, ps, gm, ps_out, gm_out,
-                            s_out, c_out, diff, partials, status, pdhg_dual, kappa, mode, pdhg,
+                            s_out, c_out, diff, dsq, status, pdhg_dual, kappa, mode, pdhg,
                             stream):
         f = lambda p, sh=(n, T): view(p, sh, np.float32)
         rec = view(homes, (n * HOME_DTYPE.itemsize,), np.uint8).view(HOME_DTYPE)
@@ -55,21 +55,19 @@ class FakeKernels:
         view(diff, (n,), np.float32)[:] = d
         if status:
             view(status, (n,), np.int32)[:] = st
-        npart = self.revs_agent_num_partials(n, T)
-        part = view(partials, (npart, 3), np.float32)
-        part[:] = 0
-        part[0] = [(chk ** 2).sum(), (dg ** 2).sum(), d.max()]
+        view(dsq, (n,), np.float32)[:] = (dg ** 2).sum(axis=1)
         return 0
 
-    def revs_residual_finalize(self, partials, npart, n, T, kappa, eps, out, stream):
-        part = view(partials, (npart, 3), np.float32).astype(float)
+    def revs_residual_finalize(self, diff, dsq, n, T, kappa, eps, scratch, out, stream):
+        d = view(diff, (n,), np.float32).astype(float)
+        q = view(dsq, (n,), np.float32).astype(float)
         o = view(out, (4,), np.float32)
-        o[0], o[1] = np.sqrt(part[:, 0].sum()), kappa * np.sqrt(part[:, 1].sum())
-        o[2] = part[:, 2].max()
-        o[3] = float(o[2] <= eps)
+        o[0] = np.sqrt(((d * T) ** 2).sum())
+        o[1] = kappa * np.sqrt(q.sum())
+        o[2] = d.max()
+        o[3] = 1.0 if o[2] <= eps else 0.0
         return 0
 
-    # ---- operator ----
     def revs_op_g0(self, n, T, pe, ps, gm, kappa, g0, stream):
         f = lambda p: view(p, (n, T), np.float32).astype(float)
         view(g0, (n, T), np.float64)[:] = 0.5 * (f(pe) + f(ps)) - f(gm) / kappa

@@ -48,9 +48,9 @@ def test_argument_validation_without_gpu(lib):
     pd = PDHG()
     lib.revs_pdhg_defaults(C.byref(pd))
     assert (pd.max_iter, pd.check) == (4000, 4) and abs(pd.tol - 1e-6) < 1e-12
-    assert lib.revs_agent_num_partials(100000, 24) == 3125          # 32 homes per workgroup
-    assert lib.revs_agent_num_partials(10, 96) == 2                 # 8 homes per workgroup
-    assert lib.revs_agent_num_partials(10, 500) == 0                # T > REVS_MAX_T
+    assert lib.revs_residual_num_chunks(100000) == 25               # 4096 homes per chunk
+    assert lib.revs_residual_num_chunks(10) == 1 and lib.revs_residual_num_chunks(10 ** 7) == 256
+    assert lib.revs_residual_num_chunks(0) == 0
     rc = lib.revs_agent_step(0, 24, *([None] * 13), 5.0, 0, None, None)
     assert rc == -1 and b"n_homes" in lib.revs_last_error()
     rc = lib.revs_agent_step(10, 999, *([None] * 13), 5.0, 0, None, None)

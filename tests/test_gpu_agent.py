@@ -22,8 +22,8 @@ def _run_agent(lib, w, pe_old, pe_new, ps, gm, mode, pdhg=None, ydual=None):
     Cs = torch.zeros(n, T + 1, dtype=torch.float32, device=dev)
     diff = torch.zeros(n, dtype=torch.float32, device=dev)
     status = torch.zeros(n, dtype=torch.int32, device=dev)
-    npart = lib.revs_agent_num_partials(n, T)
-    part = torch.zeros(3 * npart, dtype=torch.float32, device=dev)
+    part = torch.zeros(n, dtype=torch.float32, device=dev)          # dsq: per-home |dP_sch|^2
+    scratch = torch.zeros(3 * lib.revs_residual_num_chunks(n), dtype=torch.float64, device=dev)
     pd = PDHG()
     lib.revs_pdhg_defaults(C.byref(pd))
     for k, v in (pdhg or {}).items():
@@ -33,12 +33,12 @@ def _run_agent(lib, w, pe_old, pe_new, ps, gm, mode, pdhg=None, ydual=None):
                               ptr(status), ptr(ydual), w.kappa, _lib.MODES[mode], C.byref(pd),
                               torch.cuda.current_stream().cuda_stream), "agent_step")
     out = torch.zeros(4, dtype=torch.float32, device=dev)
-    check(lib.revs_residual_finalize(ptr(part), npart, n, T, w.kappa, 1e-4, ptr(out),
+    check(lib.revs_residual_finalize(ptr(diff), ptr(part), n, T, w.kappa, 1e-4, ptr(scratch), ptr(out),
                                      torch.cuda.current_stream().cuda_stream), "finalize")
     torch.cuda.synchronize()
     g = lambda t: t.cpu().numpy().astype(np.float64)
     return dict(P_sch=g(d_ps), G=g(d_gm), S=g(S), C=g(Cs), diff=g(diff), ydual=ydual,
-                status=status.cpu().numpy(), resid=g(out))
+                status=status.cpu().numpy(), resid=g(out), dsq=g(part))
 
 
 def _state(w, seed, scale=1.0):
@@ -117,7 +117,8 @@ def test_relaxed_matches_oracle(gpu_lib, T, mode):
     chk = pe_new - g
     np.testing.assert_allclose(r["G"], gm + 0.5 * w.kappa * chk, atol=2e-3, rtol=1e-5)
     np.testing.assert_allclose(r["diff"], np.linalg.norm(chk, axis=1) / T, atol=1e-4, rtol=1e-4)
-    # global residuals from the wavefront reduction
+    np.testing.assert_allclose(r["dsq"], ((g - ps) ** 2).sum(axis=1), rtol=2e-3, atol=1e-6)
+    # global residuals from the per-home terms (revs_residual_finalize)
     rp = np.sqrt((chk ** 2).sum())
     rd = w.kappa * np.sqrt(((g - ps) ** 2).sum())
     np.testing.assert_allclose(r["resid"][0], rp, rtol=1e-4)

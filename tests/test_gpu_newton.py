@@ -247,7 +247,6 @@ def test_sweep_with_selection_and_next_home_pass(gpu_lib, mode):
     cost = up(w.cost.astype(np.float32))
     pe, pen = up(rng.uniform(0, 3, (n, T)).astype(np.float32)), up(rng.uniform(0, 3, (n, T)).astype(np.float32))
     ps, gm = up(rng.uniform(0, 3, (n, T)).astype(np.float32)), up(rng.normal(0, 1, (n, T)).astype(np.float32))
-    npart = int(gpu_lib.revs_agent_num_partials(n, T))
     pd = _lib.PDHG()
     gpu_lib.revs_pdhg_defaults(C.byref(pd))
     # selection inputs: a bookkeeping state with violations and a few multipliers
@@ -273,7 +272,7 @@ def test_sweep_with_selection_and_next_home_pass(gpu_lib, mode):
 
     def outs():
         return dict(ps=torch.zeros(n, T, **f32), g=torch.zeros(n, T, **f32), diff=torch.zeros(n, **f32),
-                    part=torch.zeros(3 * npart, **f32), status=torch.zeros(n, dtype=torch.int32, device="cuda:0"))
+                    part=torch.zeros(n, **f32), status=torch.zeros(n, dtype=torch.int32, device="cuda:0"))
     a, b = outs(), outs()
     common = lambda o: (n, T, ptr(cost), ptr(homes), ptr(load), ptr(pe), ptr(pen), ptr(ps), ptr(gm),
                         ptr(o["ps"]), ptr(o["g"]), None, None, ptr(o["diff"]), ptr(o["part"]),
