@@ -153,8 +153,11 @@ class AdmmEngine:
         assert homes.dtype == HOME_DTYPE and len(homes) == n and len(node_of) == n
         assert node_of.min(initial=0) >= 0 and node_of.max(initial=0) < M
 
-        # residences sorted by node -> CSR; remember the permutation
-        self.perm = np.argsort(node_of, kind="stable")
+        # residences sorted by node -> CSR; remember the permutation.  Inside a node the
+        # residences with an EV come first, then the others (whose home problem is trivial:
+        # no PDHG pass): a wavefront of the sweep carries 8 consecutive homes and iterates until
+        # the slowest has converged, so like-with-like keeps whole wavefronts out of the loop.
+        self.perm = np.lexsort((np.arange(n), homes["ev"] == 0, node_of))
         self.inv_perm = np.empty_like(self.perm)
         self.inv_perm[self.perm] = np.arange(n)
         local_counts = np.bincount(node_of, minlength=M).astype(np.int64)
