@@ -810,12 +810,13 @@ class AdmmEngine:
         self.op_converged = True
         return True
 
-    def operator_solve(self):
+    def operator_solve(self, admm_only=False):
         """Utility(graph, P_est[k], P_sch[k], G[k]).solve() -> P_est[k+1]
-        (lpsolver.py:256-259), written to self.P_est_new."""
+        (lpsolver.py:256-259), written to self.P_est_new.  `admm_only`: skip the dual
+        Newton attempt (the caller has just seen it fail for this state)."""
         o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
         self._fused_ready = False
-        if o.solver == "newton":
+        if o.solver == "newton" and not admm_only:
             if self._operator_solve_newton():
                 return True
             self._fast_cold = True
@@ -993,11 +994,7 @@ class AdmmEngine:
                 if not self._operator_solve_newton(first=stt):
                     self._fast_cold = True
                     self.op_cold = True
-                    saved, o.solver = o.solver, "admm"
-                    try:
-                        self.operator_solve()
-                    finally:
-                        o.solver = saved
+                    self.operator_solve(admm_only=True)
                 self.agent_step(write_sc)
         else:
             self._fused_ready = False
