@@ -157,7 +157,9 @@ class AdmmEngine:
         # residences with an EV come first, then the others (whose home problem is trivial:
         # no PDHG pass): a wavefront of the sweep carries 8 consecutive homes and iterates until
         # the slowest has converged, so like-with-like keeps whole wavefronts out of the loop.
-        self.perm = np.lexsort((np.arange(n), homes["ev"] == 0, node_of))
+        # (EV homes first on even nodes, last on odd ones: the like runs of neighbouring nodes
+        # join up, which halves the number of mixed wavefronts)
+        self.perm = np.lexsort((np.arange(n), (homes["ev"] == 0) ^ ((node_of & 1) == 1), node_of))
         self.inv_perm = np.empty_like(self.perm)
         self.inv_perm[self.perm] = np.arange(n)
         local_counts = np.bincount(node_of, minlength=M).astype(np.int64)
