@@ -438,8 +438,10 @@ int revs_op_dual_model(int32_t m, int32_t T, const double *R, const double *n_fr
                        double *k_slabs, double *k_full, double *yhat, int32_t *info,
                        void *stream);
 /* One evaluation as a single host call: phase bit 0 = [R^T y into d_slabs when use_y,]
- * revs_op_dual_eval; phase bit 1 = R p into v_slabs (Rt = R^T, row-major), revs_op_dual_select,
- * and an asynchronous copy of stats to stats_host (pinned HOST memory, double[T][8], or NULL);
+ * revs_op_dual_eval; phase bit 1 = R p into v_slabs (Rt = R^T, row-major) and
+ * revs_op_dual_select -- product and row bookkeeping as ONE launch when tile_counters
+ * (uint32[(m + 31) / 32], zero before the first use, left zero) is given and T <= 32, see
+ * revs_op_dual_product_rows (`partial` then holds (m + 31) / 32 blocks);
  * with phase bit 2 (value 4) the selection kernel is left to revs_agent_step_select.
  * A driver that shards residences runs phase 1, all-reduces pnq, then phase 2. */
 int revs_op_dual_evaluate(int32_t phase, int32_t m, int32_t T, const int64_t *node_ptr,
@@ -449,7 +451,7 @@ int revs_op_dual_evaluate(int32_t phase, int32_t m, int32_t T, const int64_t *no
                           double *d_slabs, double *v_slabs, double *pnq, float *p_est_new,
                           double *vfull, double *viol, double *partial, int64_t *cand_idx,
                           int32_t *cand_cnt, double *cand_val, double *stats, double seq,
-                          double *stats_host, void *stream);
+                          uint32_t *tile_counters, void *stream);
 int revs_op_dual_step(int32_t T, const int64_t *cand_idx, const int32_t *cand_cnt,
                       const double *cand_val, const double *yhat, const double *alpha,
                       double *y_trial, double *lin_out, void *stream);

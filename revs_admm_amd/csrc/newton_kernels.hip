@@ -513,8 +513,8 @@ extern "C" int revs_op_dual_step(int32_t T, const int64_t *cand_idx, const int32
 
 // One evaluation of the dual function as a single host call (the driver's steady state is
 // host-bound otherwise: five launches of 3-12 us each).  phase bit 0: R^T y (when use_y)
-// and the home pass; phase bit 1: R p, row bookkeeping, candidate lists and the copy of
-// stats to pinned host memory; with phase bit 2 the candidate-list kernel is left to the
+// and the home pass; phase bit 1: R p, row bookkeeping (one launch with tile_counters and
+// T <= 32, see revs_op_dual_product_rows) and candidate lists; with phase bit 2 the candidate-list kernel is left to the
 // caller (revs_agent_step_select runs it inside the home sweep's launch).  A driver that shards residences runs phase 1, all-reduces
 // pnq, then runs phase 2.
 extern "C" int revs_op_dual_evaluate(int32_t phase, int32_t m, int32_t T, const int64_t *node_ptr,
@@ -525,7 +525,7 @@ extern "C" int revs_op_dual_evaluate(int32_t phase, int32_t m, int32_t T, const 
                                      double *v_slabs, double *pnq, float *p_est_new,
                                      double *vfull, double *viol, double *partial,
                                      int64_t *cand_idx, int32_t *cand_cnt, double *cand_val,
-                                     double *stats, double seq, double *stats_host,
+                                     double *stats, double seq, uint32_t *tile_counters,
                                      void *stream) {
     REVS_REQUIRE(phase >= 1 && phase <= 7 && (!(phase & 4) || (phase & 2)) && y && pnq,
                  "revs_op_dual_evaluate: bad argument");
@@ -542,19 +542,26 @@ extern "C" int revs_op_dual_evaluate(int32_t phase, int32_t m, int32_t T, const 
     }
     if (phase & 2) {
         REVS_REQUIRE(Rt && v_slabs, "revs_op_dual_evaluate: Rt / v_slabs missing");
-        rc = revs_gemm_tn_f64_split(m, T, m, Rt, pnq, v_slabs, ksplit, stream);
-        if (rc != REVS_OK) return rc;
-        rc = dual_rows_select(m, T, ksplit, v_slabs, pnq, y, vlo, vhi, kadd, vfull, viol, partial,
-                              cand_idx, cand_cnt, cand_val, stats, seq, (phase & 4) != 0, nullptr,
-                              stream);
-        if (rc != REVS_OK) return rc;
-        if (stats_host) {
-            const hipError_t e = hipMemcpyAsync(stats_host, stats, sizeof(double) * 8 * T,
-                                                hipMemcpyDeviceToHost, S_(stream));
-            if (e != hipSuccess) {
-                revs::set_error("revs_op_dual_evaluate: %s", hipGetErrorString(e));
-                return REVS_ELAUNCH;
+        if (tile_counters && T <= 32 && (m + 31) / 32 <= 256) {
+            // product and row bookkeeping in one launch, then the selection over its tiles
+            REVS_REQUIRE(m <= 16384 && vfull && viol && partial && cand_idx && cand_cnt && cand_val &&
+                         stats && vlo <= vhi && kadd >= 0, "revs_op_dual_evaluate: bad argument");
+            rc = revs_op_dual_product_rows(m, T, Rt, pnq, pnq, y, vlo, vhi, ksplit, v_slabs, vfull,
+                                           viol, partial, nullptr, tile_counters, stream);
+            if (rc != REVS_OK) return rc;
+            if (!(phase & 4)) {
+                const SelectArgs sa{m, T, (m + 31) / 32, kadd, partial, y, vfull, viol, vlo, vhi, seq,
+                                    cand_idx, cand_cnt, cand_val, stats};
+                hipLaunchKernelGGL(op_dual_select_kernel, dim3(T), dim3(256), 0, S_(stream), sa);
+                REVS_CHECK_LAUNCH("revs_op_dual_evaluate");
             }
+        } else {
+            rc = revs_gemm_tn_f64_split(m, T, m, Rt, pnq, v_slabs, ksplit, stream);
+            if (rc != REVS_OK) return rc;
+            rc = dual_rows_select(m, T, ksplit, v_slabs, pnq, y, vlo, vhi, kadd, vfull, viol, partial,
+                                  cand_idx, cand_cnt, cand_val, stats, seq, (phase & 4) != 0, nullptr,
+                                  stream);
+            if (rc != REVS_OK) return rc;
         }
     }
     return REVS_OK;

@@ -232,6 +232,7 @@ class AdmmEngine:
         self.nks = int(min(16, max(1, M // 128)))       # column slabs of the model Hessian
         self.k_slabs = torch.zeros(T, self.nks, A, A, **f64)
         self.k_full = torch.zeros(T, A, A, **f64)
+        self.tile_cnt = torch.zeros((M + 31) // 32, dtype=torch.int32, device=self.dev)
         self.c_idx = [torch.zeros(T, A, dtype=torch.int64, device=self.dev) for _ in range(2)]
         self.c_cnt = [torch.zeros(T, dtype=torch.int32, device=self.dev) for _ in range(2)]
         self.c_val = [torch.zeros(T, 3, A, **f64) for _ in range(2)]
@@ -695,7 +696,7 @@ class AdmmEngine:
             self.op.newton_kadd, self.ksplit1, ptr(self.d_sl), ptr(self.v_sl), ptr(self.pnq),
             ptr(self.P_est_new), ptr(self.vfull), ptr(self.violw), ptr(self.d_part),
             ptr(self.c_idx[k]), ptr(self.c_cnt[k]), ptr(self.c_val[k]), self.stats_dev[k],
-            0.0, None, self.stream), "revs_op_dual_evaluate")
+            0.0, ptr(self.tile_cnt), self.stream), "revs_op_dual_evaluate")
 
     def _dual_launch(self, y, use_y: bool, k: int, full: bool = True):
         """Enqueue one evaluation: p, N, D and the voltage rows for the multipliers y;

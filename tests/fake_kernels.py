@@ -311,7 +311,7 @@ class FakeKernels:
 
     def revs_op_dual_evaluate(self, phase, m, T, node_ptr, pe, ps, gm, R, Rt, y, use_y, kappa, vlo,
                               vhi, kadd, ksplit, d_sl, v_sl, pnq, pe_new, vfull, viol, partial,
-                              cidx, ccnt, cval, stats, seq, stats_host, stream):
+                              cidx, ccnt, cval, stats, seq, tile_counters, stream):
         if phase & 1:
             if use_y:
                 self.revs_gemm_tn_f64_split(m, T, m, R, y, d_sl, ksplit, stream)
@@ -321,8 +321,6 @@ class FakeKernels:
             self.revs_gemm_tn_f64_split(m, T, m, Rt, pnq, v_sl, ksplit, stream)
             self.revs_op_dual_select(m, T, ksplit, v_sl, pnq, y, vlo, vhi, kadd, vfull, viol,
                                      partial, cidx, ccnt, cval, stats, seq, stream)
-            if stats_host:
-                view(stats_host, (T, 8), np.float64)[:] = view(stats, (T, 8), np.float64)
         return 0
 
     def revs_op_dual_blocks(self, m):
