@@ -325,9 +325,9 @@ def main():
                 "avg_launch_ms": gemm_ms,
                 # 6 flop per byte of R at T = 24: the product streams the matrix, so its own
                 # roofline is HBM -- reported beside the matrix-core utilisation
-                "matrix_stream_GBs": 8.0 * eng.M * eng.M * (1 if fast else 2) / (gemm_ms * 1e-3) / 1e9,
-                "matrix_stream_frac_of_hbm_peak": 8.0 * eng.M * eng.M * (1 if fast else 2)
-                                                  / (gemm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "matrix_stream_GBs": 8.0 * eng.M * eng.M / (gemm_ms * 1e-3) / 1e9,
+                "matrix_stream_frac_of_hbm_peak": 8.0 * eng.M * eng.M / (gemm_ms * 1e-3) / 1e9
+                                                  / HBM_PEAK_GBS,
             },
             "breakdown": {
                 "operator_ms_per_step": oper_ms, "agent_ms_per_step": agent_ms,
