@@ -242,8 +242,14 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
         double tr = 0.0;
         for (int w = 0; w < kWords; ++w) tr += wred[w];
         dl_s = delta * tr / a + 1e-300; done_s = 0; piv_s = 0;
+        if (!(tr > 0.0)) done_s = 3;       // K = 0: no residence answers to these rows
     }
     __syncthreads();
+    if (done_s == 3) {                      // uniform: leave the multipliers where they are
+        if (tid < kAmax) yo[tid] = tid < a ? cy[tid] : 0.0;
+        if (tid == 0) info[t] = 0;
+        return;
+    }
     const double dl = dl_s;
     auto kp = [&](int i, int j) -> double {
         return s_s[i] * s_s[j] * Kt[i * kAmax + j] + (i == j ? dl : 0.0);

@@ -297,3 +297,72 @@ def test_sweep_with_selection_and_next_home_pass(gpu_lib, mode):
     torch.cuda.synchronize()
     assert torch.equal(pe2, pe_ref) and (pe2 == 0).any() and (pe2 > 0).any()
     np.testing.assert_allclose(p_next.cpu().numpy(), pnq2[0].cpu().numpy(), rtol=1e-13, atol=1e-12)
+
+
+@pytest.mark.parametrize("a", [1, 2, 31, 63, 64, 65, 100, 127, 128])
+def test_model_problem_sizes(gpu_lib, a):
+    """revs_op_dual_model at every interesting candidate count (one row, the 64/65 boundary of
+    the two mask words, the full 128): the returned point satisfies the LCP of the model and
+    equals the numpy block-pivoting solution.  K = R R^T / kappa with R a x a, so K is the
+    Gram matrix of the candidate rows themselves; two slots get mirrored signs."""
+    import torch
+    from fake_kernels import FakeKernels
+    from revs_admm_amd._lib import check, ptr
+    rng = np.random.default_rng(a)
+    M, T, kappa, delta, nks = a, 3, 5.0, 1e-10, 2
+    R = rng.normal(size=(M, M)) * (rng.uniform(size=(M, M)) < 0.5) + np.eye(M) * 0.1
+    if a > 4:
+        R[3] = R[1]                                    # an exactly repeated row: singular K
+    nfree = np.ones((M, T))
+    if a > 4:                                          # some nodes fully clamped in slot 1
+        nfree[rng.integers(0, M, M // 5), 1] = 0.0
+    cidx = np.tile(np.arange(A, dtype=np.int64), (T, 1)); cidx[:, a:] = 0
+    ccnt = np.full(T, a, np.int32)
+    cval = np.zeros((T, 3, A))
+    sgn = np.where(rng.uniform(size=a) < 0.7, 1.0, -1.0)
+    for t in range(T):
+        s = sgn if t != 2 else -sgn
+        cval[t, 0, :a] = s
+        cval[t, 1, :a] = rng.normal(size=a)                       # gradient v - b
+        cval[t, 2, :a] = s * np.maximum(rng.normal(size=a), 0.0)  # current y, right sign
+    cval[:, 0, a:] = 1.0
+    up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to("cuda:0")
+    dR, dN, dci, dcc, dcv = up(R), up(nfree), up(cidx), up(ccnt), up(cval)
+    f64 = dict(dtype=torch.float64, device="cuda:0")
+    ksl, kf = torch.zeros(T, nks, A, A, **f64), torch.zeros(T, A, A, **f64)
+    yh, info = torch.zeros(T, A, **f64), torch.zeros(T, dtype=torch.int32, device="cuda:0")
+    check(gpu_lib.revs_op_dual_model(M, T, ptr(dR), ptr(dN), ptr(dci), ptr(dcc), ptr(dcv), kappa, delta,
+                                     400, nks, ptr(ksl), ptr(kf), ptr(yh), ptr(info), None), "model")
+    torch.cuda.synchronize()
+    yh, inf, Kg = yh.cpu().numpy(), info.cpu().numpy(), kf.cpu().numpy()
+    assert (inf > 0).all()
+    # a model without curvature (every residence behind its rows clamped) moves nothing
+    y0, none_free = torch.zeros(T, A, **f64), torch.zeros_like(dN)
+    check(gpu_lib.revs_op_dual_model(M, T, ptr(dR), ptr(none_free), ptr(dci), ptr(dcc), ptr(dcv),
+                                     kappa, delta, 400, nks, ptr(ksl), ptr(kf), ptr(y0), ptr(info), None),
+          "model")
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(y0.cpu().numpy()[:, :a], cval[:, 2, :a])
+    assert (info.cpu().numpy() == 0).all()
+    ref, inf_ref = np.zeros((T, A)), np.zeros(T, np.int32)
+    ksl_r, kf_r = np.zeros((T, nks, A, A)), np.zeros((T, A, A))
+    Rc, Nc = np.ascontiguousarray(R), np.ascontiguousarray(nfree)
+    FakeKernels().revs_op_dual_model(M, T, Rc.ctypes.data, Nc.ctypes.data, cidx.ctypes.data,
+                                     ccnt.ctypes.data, cval.ctypes.data, kappa, delta, 400, nks,
+                                     ksl_r.ctypes.data, kf_r.ctypes.data, ref.ctypes.data,
+                                     inf_ref.ctypes.data, None)
+    for t in range(T):
+        s, grad, ycur = cval[t, 0, :a], cval[t, 1, :a], cval[t, 2, :a]
+        K0 = (R * nfree[:, t][None, :]) @ R.T / kappa
+        np.testing.assert_allclose(Kg[t, :a, :a], K0, rtol=1e-11, atol=1e-15)
+        Kp = K0 * s[:, None] * s[None, :] + (delta * np.trace(K0) / a) * np.eye(a)
+        c = s * grad + Kp @ np.maximum(s * ycur, 0.0)
+        u = s * yh[t, :a]
+        w = Kp @ u - c
+        tol = 1e-8 * (np.abs(Kp).sum(axis=1).max() * max(u.max(), 1e-300) + np.abs(c).max())
+        assert u.min() >= 0.0 and w.min() >= -tol and np.abs(w[u > 0]).max(initial=0.0) <= tol
+        assert (yh[t, a:] == 0).all()
+        obj = lambda z: 0.5 * z @ Kp @ z - c @ z                  # same optimal value as numpy's
+        # (the repeated row with unrelated gradients leaves the delta shift in charge of a huge
+        # component: objective values agree to its conditioning, not to rounding)
+        assert obj(u) <= obj(s * ref[t, :a]) + 1e-5 * (abs(obj(s * ref[t, :a])) + 1e-300)
