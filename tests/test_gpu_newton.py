@@ -166,12 +166,16 @@ def test_more_multipliers_than_the_model_holds(gpu_lib):
     n, M, T = 1500, 200, 4
     node_of, ptr_, R, pe, ps, gm, y = _case(1, n, M, T, 10)
     y[:150, 1] = 1.0
+    y[:, 2] = 0.0
+    y[40:168, 2] = -1.0                               # exactly REVS_DUAL_AMAX: served, no room left
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
     gi, gb = _run_evaluate(gpu_lib, FakeKernels(), up, ptr, M, T, ptr_, pe, ps, gm, R, y, 5.0, -0.05,
                            0.06, 16, 2)
     torch.cuda.synchronize()
     cnt, st = gb["ccnt"].cpu().numpy(), gb["stats"].cpu().numpy()
     assert cnt[1] == -1 and st[1, 2] == (y[:, 1] != 0).sum() > A and (cnt[[0, 2, 3]] > 0).all()
+    assert cnt[2] == A and (gb["cidx"].cpu().numpy()[2] == np.arange(40, 168)).all()
+    assert (gb["cval"].cpu().numpy()[2, 0] == -1.0).all()
 
 
 def test_product_rows_in_one_launch_equals_two_kernels(gpu_lib):
