@@ -267,6 +267,20 @@ class AdmmEngine:
                       "revs_host_device_ptr")
                 setattr(self, name, int(dp.value))
         self.newton_hist: list[tuple] = []
+        if cuda and self.op.solver == "newton" and _kernels is None:
+            # first use of a kernel loads its code object (1-2 ms each on this stack): touch the
+            # Newton-iteration kernels now, with empty candidate lists, not inside the first solve
+            check(self.lib.revs_op_dual_model(M, T, ptr(self.R64), ptr(self.pnq[1]), ptr(self.c_idx[0]),
+                                              ptr(self.c_cnt[0]), ptr(self.c_val[0]), self.kappa,
+                                              self.op.newton_delta, self.op.newton_pivots, self.nks,
+                                              ptr(self.k_slabs), ptr(self.k_full), ptr(self.yhat),
+                                              self.info_dev, self.stream), "revs_op_dual_model")
+            check(self.lib.revs_op_dual_step(T, ptr(self.c_idx[0]), ptr(self.c_cnt[0]),
+                                             ptr(self.c_val[0]), ptr(self.yhat), self.alpha_dev,
+                                             ptr(self.yd[1]), self.stats_dev[1] + 32, self.stream),
+                  "revs_op_dual_step")
+            self._gemm1(self.R64, self.yd[0], self.d_sl)
+            torch.cuda.synchronize(self.dev)
         # steady-state iteration as ONE native call (one GPU; see revs_plan_spec_step)
         self._plan = None
         self._fused_ready = False        # the last kept sweep did the next evaluation's home pass
