@@ -461,3 +461,23 @@ def test_native_step_and_fused_home_pass_change_nothing(gpu_lib, mode, T, monkey
         for a, b in zip(r[1], ref[1]):
             np.testing.assert_array_equal(a, b)
         np.testing.assert_array_equal(r[2], ref[2])
+
+
+@pytest.mark.parametrize("n,M,T", [(1, 1, 24), (5, 2, 24), (9, 9, 7), (40, 3, 33)])
+def test_tiny_runs_match_oracle(gpu_lib, n, M, T):
+    """Degenerate sizes through the whole engine (one residence, fewer residences than a
+    wavefront holds, one residence per node, a slot count that fills no lane group): 20
+    iterations, so that the native steady-state step with its folded home pass runs too."""
+    from helpers import f32, oracle_homes
+    from oracle import revs_oracle as ro
+    from revs_admm_amd.synthetic import make_workload
+    w = make_workload(n, T, n_nodes=M, seed=n + T, binary_feasible=False, stress=0.9)
+    w.load, w.cost = f32(w.load), f32(w.cost)
+    e = _engine(w, "relaxed_exact")
+    d = e.run(20)
+    d_ref, P_ref, S_ref, C_ref = ro.solve_ADMM(oracle_homes(w), w.Rn, w.node_of, w.cost, w.kappa, 20,
+                                               w.vset, w.vlow, w.vhigh, mode="relaxed", util_eps=1e-10)
+    P, S, C = e.result()
+    assert e.spec_hist[0] > 0                                     # the native step did run
+    assert np.abs(d - d_ref).max() < 1e-3 * max(1.0, d_ref.max())
+    assert np.abs(S - S_ref).max() < 2e-3 and np.abs(P - P_ref).max() < 2e-3
