@@ -239,6 +239,7 @@ class AdmmEngine:
         self.yhat = torch.zeros(T, A, **f64)
         self._y_support = False
         self._spec_ok = False
+        self._spec_wait, self._spec_back = 0, 1
         self.spec_hist = [0, 0]                        # speculative sweeps kept / discarded
         self.P_sch_alt = torch.zeros(n, T, **f32) if self.op.solver == "newton" else None
         self.G_alt = torch.zeros(n, T, **f32) if self.op.solver == "newton" else None
@@ -816,7 +817,14 @@ class AdmmEngine:
             cur, stt = nxt, stn
         self.yd = [ycur, ytrial]
         self.newton_hist.append((newton, evals, pivots))
-        self._spec_ok = ok_all and newton == 0
+        # speculate on the next iteration after a solve that needed no Newton iteration -- but
+        # after a discarded sweep only once 2, 4, ... 64 such solves have gone by (rows that
+        # keep moving in and out of their limits would otherwise cost a wasted sweep each time)
+        if ok_all and newton == 0:
+            self._spec_wait = max(self._spec_wait - 1, 0)
+            self._spec_ok = self._spec_wait == 0
+        else:
+            self._spec_ok = False
         if not ok_all:
             ycur.zero_()
             self._y_support = False
@@ -1004,8 +1012,11 @@ class AdmmEngine:
                 self.newton_hist.append((0, 1, 0))
                 self.op_converged = True
                 self.spec_hist[0] += 1
+                self._spec_back = 1
             else:                          # rows need work: finish the solve, redo the sweep
                 self.spec_hist[1] += 1
+                self._spec_back = min(2 * self._spec_back, 64)
+                self._spec_wait = self._spec_back
                 if stt is not None:
                     stt = self._dual_complete(self.yd[0], self._y_support, 0)
                 if not self._operator_solve_newton(first=stt):
