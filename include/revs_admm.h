@@ -409,6 +409,14 @@ int revs_op_export(int64_t n_homes, int32_t T, const double *sb, float *p_est, v
 int revs_op_dual_eval(int32_t m, int32_t T, const int64_t *node_ptr, const float *p_est,
                       const float *p_sch, const float *gamma, int32_t nslab, const double *dsl,
                       double kappa, double *pnq, float *p_est_new, void *stream);
+/* revs_op_dual_eval with d = R^T y / kappa taken from the few rows of R that carry a
+ * multiplier instead of the slabs of a dense product: sup_idx int64[T][AMAX] / sup_cnt
+ * int32[T] (all >= 0) list, per slot, rows that include every row with y != 0 -- e.g. the
+ * candidate lists of the selection that produced or last judged this y. */
+int revs_op_dual_eval_rows(int32_t m, int32_t T, const int64_t *node_ptr, const float *p_est,
+                           const float *p_sch, const float *gamma, const double *R,
+                           const int64_t *sup_idx, const int32_t *sup_cnt, const double *y,
+                           double kappa, double *pnq, float *p_est_new, void *stream);
 int32_t revs_op_dual_blocks(int32_t m);
 int revs_op_dual_select(int32_t m, int32_t T, int32_t nslab, const double *vsl,
                         const double *pnq, const double *y, double vlo, double vhi,

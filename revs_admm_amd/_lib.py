@@ -106,6 +106,7 @@ SIGNATURES = {
     "revs_op_node_apply": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p, _f64, _i32, _p, _p, _p]),
     "revs_op_export": (C.c_int, [_i64, _i32, _p, _p, _p]),
     "revs_op_dual_eval": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _i32, _p, _f64, _p, _p, _p]),
+    "revs_op_dual_eval_rows": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _f64, _p, _p, _p]),
     "revs_op_dual_blocks": (_i32, [_i32]),
     "revs_op_dual_select": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _f64, _f64, _i32, _p, _p, _p,
                                       _p, _p, _p, _p, _f64, _p]),

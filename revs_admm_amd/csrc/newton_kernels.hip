@@ -26,12 +26,23 @@ namespace revs {
 // ---- home pass: p, N, -(kappa/2) sum g^2 per node and slot; P_est_new = g ----------
 // Mapping as op_home_pass_kernel: one workgroup per node, TL slot lanes x HS home lanes,
 // partial sums combined through LDS in a fixed order.
+// d = R^T y / kappa either from the K-split slabs of the dense product (dsl) or, while only a
+// few rows carry a multiplier, straight from those rows of R (SparseD: the candidate list of
+// the last selection covers every row with y != 0) -- a dozen loads per node and slot
+// instead of a 12 us product.
+struct SparseD {
+    const double *R;          // row-major [m][m]
+    const int64_t *sidx;      // [T][kAmax] candidate rows
+    const int32_t *scnt;      // [T]
+    const double *y;          // [m][T]
+};
+
 template <int TL>
 __global__ __launch_bounds__(256) void op_dual_eval_kernel(
         int m, int T, const int64_t *__restrict__ node_ptr, const float *__restrict__ pe,
         const float *__restrict__ ps, const float *__restrict__ gm, int nslab,
         const double *__restrict__ dsl, double kappa, double *__restrict__ pnq,
-        float *__restrict__ pe_new) {
+        float *__restrict__ pe_new, const SparseD sp) {
     constexpr int HS = 256 / TL;
     const int node = blockIdx.x;
     const int t = threadIdx.x % TL, hs = threadIdx.x / TL;
@@ -42,6 +53,14 @@ __global__ __launch_bounds__(256) void op_dual_eval_kernel(
     double d = 0.0;
     if (dsl) {
         for (int q = 0; q < nslab; ++q) d += dsl[idx + q * total];
+        d *= inv_k;
+    } else if (sp.R && tok) {
+        const int cnt = sp.scnt[t];
+        const int64_t *si = sp.sidx + (int64_t)t * kAmax;
+        for (int i = 0; i < cnt; ++i) {
+            const int64_t f = si[i];
+            d += sp.R[f * m + node] * sp.y[f * T + t];
+        }
         d *= inv_k;
     }
     double ap = 0.0, an = 0.0, aq = 0.0;
@@ -413,16 +432,16 @@ __global__ __launch_bounds__(64) void op_dual_step_kernel(
 using namespace revs;
 #define S_(stream) ((hipStream_t)(stream))
 
-extern "C" int revs_op_dual_eval(int32_t m, int32_t T, const int64_t *node_ptr,
-                                 const float *p_est, const float *p_sch, const float *gamma,
-                                 int32_t nslab, const double *dsl, double kappa, double *pnq,
-                                 float *p_est_new, void *stream) {
+static int dual_eval_impl(int32_t m, int32_t T, const int64_t *node_ptr, const float *p_est,
+                          const float *p_sch, const float *gamma, int32_t nslab, const double *dsl,
+                          double kappa, double *pnq, float *p_est_new, const SparseD &sp,
+                          void *stream) {
     REVS_REQUIRE(m > 0 && T > 0 && T <= 256 && node_ptr && p_est && p_sch && gamma && pnq &&
                  kappa > 0, "revs_op_dual_eval: bad argument");
     REVS_REQUIRE(!dsl || nslab >= 1, "revs_op_dual_eval: nslab=%d", nslab);
 #define EV(TL)                                                                                 \
     hipLaunchKernelGGL((op_dual_eval_kernel<TL>), dim3(m), dim3(256), 0, S_(stream), m, T,     \
-                       node_ptr, p_est, p_sch, gamma, nslab, dsl, kappa, pnq, p_est_new)
+                       node_ptr, p_est, p_sch, gamma, nslab, dsl, kappa, pnq, p_est_new, sp)
     if (T <= 32) EV(32);
     else if (T <= 64) EV(64);
     else if (T <= 128) EV(128);
@@ -430,6 +449,24 @@ extern "C" int revs_op_dual_eval(int32_t m, int32_t T, const int64_t *node_ptr,
 #undef EV
     REVS_CHECK_LAUNCH("revs_op_dual_eval");
     return REVS_OK;
+}
+
+extern "C" int revs_op_dual_eval(int32_t m, int32_t T, const int64_t *node_ptr,
+                                 const float *p_est, const float *p_sch, const float *gamma,
+                                 int32_t nslab, const double *dsl, double kappa, double *pnq,
+                                 float *p_est_new, void *stream) {
+    return dual_eval_impl(m, T, node_ptr, p_est, p_sch, gamma, nslab, dsl, kappa, pnq, p_est_new,
+                          SparseD{nullptr, nullptr, nullptr, nullptr}, stream);
+}
+
+extern "C" int revs_op_dual_eval_rows(int32_t m, int32_t T, const int64_t *node_ptr,
+                                      const float *p_est, const float *p_sch, const float *gamma,
+                                      const double *R, const int64_t *sup_idx,
+                                      const int32_t *sup_cnt, const double *y, double kappa,
+                                      double *pnq, float *p_est_new, void *stream) {
+    REVS_REQUIRE(R && sup_idx && sup_cnt && y, "revs_op_dual_eval_rows: null argument");
+    return dual_eval_impl(m, T, node_ptr, p_est, p_sch, gamma, 0, nullptr, kappa, pnq, p_est_new,
+                          SparseD{R, sup_idx, sup_cnt, y}, stream);
 }
 
 extern "C" int32_t revs_op_dual_blocks(int32_t m) {

@@ -240,6 +240,7 @@ class AdmmEngine:
         self._y_support = False
         self._spec_ok = False
         self._spec_wait, self._spec_back = 0, 1
+        self._sup = None
         self.spec_hist = [0, 0]                        # speculative sweeps kept / discarded
         self.P_sch_alt = torch.zeros(n, T, **f32) if self.op.solver == "newton" else None
         self.G_alt = torch.zeros(n, T, **f32) if self.op.solver == "newton" else None
@@ -713,7 +714,15 @@ class AdmmEngine:
             ptr(self.c_idx[k]), ptr(self.c_cnt[k]), ptr(self.c_val[k]), self.stats_dev[k],
             0.0, ptr(self.tile_cnt), self.stream), "revs_op_dual_evaluate")
 
-    def _dual_launch(self, y, use_y: bool, k: int, full: bool = True):
+    def _dual_home_pass_rows(self, y, sup: int):
+        """Phase 1 of an evaluation with d = R^T y / kappa taken from the few rows listed in
+        candidate set `sup` (they include every row with y != 0) instead of a dense product."""
+        check(self.lib.revs_op_dual_eval_rows(
+            self.M, self.T, ptr(self.node_ptr), ptr(self.P_est), ptr(self.P_sch), ptr(self.G),
+            ptr(self.R64), ptr(self.c_idx[sup]), ptr(self.c_cnt[sup]), ptr(y), self.kappa,
+            ptr(self.pnq), ptr(self.P_est_new), self.stream), "revs_op_dual_eval_rows")
+
+    def _dual_launch(self, y, use_y: bool, k: int, full: bool = True, sup=None):
         """Enqueue one evaluation: p, N, D and the voltage rows for the multipliers y;
         candidate lists and stats into buffer set k, stats on their way to pinned host
         memory.  Also writes P_est_new = max(g0 - R^T y / kappa, 0).  Does not wait.
@@ -722,7 +731,12 @@ class AdmmEngine:
         case); N and the dual value follow through _dual_complete if the solve goes on.
         (Replaying the launches as a hipGraph was measured and is slower than issuing
         them: 44 vs 37 us per evaluation.)"""
-        if self.group is None:
+        if use_y and sup is not None:            # few multipliers: no dense product for d
+            self._dual_home_pass_rows(y, sup)
+            if self.group is not None:
+                self._allreduce(self.pnq if full else self.pnq[0])
+            self._dual_phase(2, y, use_y, k)
+        elif self.group is None:
             self._dual_phase(3, y, use_y, k)
         else:
             self._dual_phase(1, y, use_y, k)
@@ -747,8 +761,8 @@ class AdmmEngine:
             self.stats_ev[k].synchronize()
         return self.stats_host[k].numpy().copy()
 
-    def _dual_evaluate(self, y, use_y: bool, k: int):
-        self._dual_launch(y, use_y, k)
+    def _dual_evaluate(self, y, use_y: bool, k: int, sup=None):
+        self._dual_launch(y, use_y, k, sup=sup)
         return self._dual_wait(k)
 
     def _operator_solve_newton(self, first=None):
@@ -760,7 +774,10 @@ class AdmmEngine:
         scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
         ycur, ytrial = self.yd
         cur = 0
-        stt = self._dual_evaluate(ycur, self._y_support, cur) if first is None else first
+        # (`_sup`: a candidate set that lists every row of the current multipliers, while there
+        # are few enough of them for the row-wise home pass)
+        stt = (self._dual_evaluate(ycur, self._y_support, cur, sup=self._sup)
+               if first is None else first)
         evals, newton, pivots, ok_all = 1, 0, 0, False
         best, stall = np.inf, 0
         while True:
@@ -803,7 +820,8 @@ class AdmmEngine:
                                             self.alpha_dev, ptr(ytrial),
                                             self.stats_dev[nxt] + 32, st),
                       "revs_op_dual_step")
-                stn = self._dual_evaluate(ytrial, True, nxt)
+                few = stt[:, 2].max() + o.newton_kadd <= 48
+                stn = self._dual_evaluate(ytrial, True, nxt, sup=cur if few else None)
                 evals += 1
                 okk = stn[:, 1] >= D + 1e-4 * stn[:, 4] - 1e-13 * np.abs(D)
                 pending &= ~okk
@@ -828,8 +846,11 @@ class AdmmEngine:
         if not ok_all:
             ycur.zero_()
             self._y_support = False
+            self._sup = None
             return False
         self._y_support = bool(stt[:, 2].sum() > 0)
+        # the accepted evaluation's candidate set `cur` lists the rows with y != 0 first
+        self._sup = cur if (self._y_support and stt[:, 2].max() + o.newton_kadd <= 48) else None
         self.op_iters_hist.append(evals)
         self.op_path_hist.append("dual")
         self.op_converged = True

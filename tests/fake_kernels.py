@@ -323,6 +323,19 @@ class FakeKernels:
                                      partial, cidx, ccnt, cval, stats, seq, stream)
         return 0
 
+    def revs_op_dual_eval_rows(self, m, T, node_ptr, pe, ps, gm, R, sup_idx, sup_cnt, y, kappa, pnq,
+                               pe_new, stream):
+        Rm, yv = view(R, (m, m), np.float64), view(y, (m, T), np.float64)
+        si, sc = view(sup_idx, (T, DUAL_AMAX), np.int64), view(sup_cnt, (T,), np.int32)
+        d = np.zeros((1, m, T))
+        for t in range(T):
+            for i in range(int(sc[t])):
+                f = int(si[t, i])
+                d[0, :, t] += Rm[f, :] * yv[f, t]
+        d = np.ascontiguousarray(d)
+        return self.revs_op_dual_eval(m, T, node_ptr, pe, ps, gm, 1, d.ctypes.data, kappa, pnq, pe_new,
+                                      stream)
+
     def revs_op_dual_blocks(self, m):
         return min(256, (m + 7) // 8)
 

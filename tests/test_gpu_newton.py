@@ -97,6 +97,18 @@ def test_dual_evaluate_and_model_match_numpy(gpu_lib, n, M, T, n_mult):
     np.testing.assert_allclose(g["cval"][:, 1], cb["cval"][:, 1], rtol=1e-9, atol=1e-13)
     np.testing.assert_array_equal(g["cval"][:, 2], cb["cval"][:, 2])
 
+    # ---- the home pass with d from the listed rows of R instead of the dense product ----
+    pnq_r = torch.zeros(3, M, T, dtype=torch.float64, device="cuda:0")
+    pe_r = torch.zeros(n, T, dtype=torch.float32, device="cuda:0")
+    check(gpu_lib.revs_op_dual_eval_rows(M, T, ptr(gi["ptr"]), ptr(gi["pe"]), ptr(gi["ps"]), ptr(gi["gm"]),
+                                         ptr(gi["R"]), ptr(gb["cidx"]), ptr(gb["ccnt"]), ptr(gi["y"]), kappa,
+                                         ptr(pnq_r), ptr(pe_r), None), "revs_op_dual_eval_rows")
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(pnq_r[1].cpu().numpy(), g["pnq"][1])
+    np.testing.assert_allclose(pnq_r[0].cpu().numpy(), g["pnq"][0], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(pnq_r[2].cpu().numpy(), g["pnq"][2], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(pe_r.cpu().numpy(), g["pe_new"], rtol=1e-6, atol=1e-6)
+
     # ---- the model problem: Gram kernel + block principal pivoting ----
     nks, delta = 4, 1e-10
     kslab = torch.zeros(T, nks, A, A, dtype=torch.float64, device="cuda:0")
