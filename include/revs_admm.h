@@ -460,6 +460,15 @@ int revs_op_dual_evaluate(int32_t phase, int32_t m, int32_t T, const int64_t *no
                           double *vfull, double *viol, double *partial, int64_t *cand_idx,
                           int32_t *cand_cnt, double *cand_val, double *stats, double seq,
                           uint32_t *tile_counters, void *stream);
+/* revs_op_dual_model for slots with at most 8 candidates each (the caller knows the counts
+ * from the stats: rows with y != 0 plus the violated rows admitted), Gram matrix and pivoting
+ * in one small kernel.  A slot with more than 8 candidates is left unmoved and flagged
+ * info = -999.  k_full as in revs_op_dual_model (top-left block written). */
+int revs_op_dual_model_small(int32_t m, int32_t T, const double *R, const double *n_free,
+                             const int64_t *cand_idx, const int32_t *cand_cnt,
+                             const double *cand_val, double kappa, double delta,
+                             int32_t max_pivots, double *k_full, double *yhat, int32_t *info,
+                             void *stream);
 int revs_op_dual_step(int32_t T, const int64_t *cand_idx, const int32_t *cand_cnt,
                       const double *cand_val, const double *yhat, const double *alpha,
                       double *y_trial, double *lin_out, void *stream);

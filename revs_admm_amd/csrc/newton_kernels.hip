@@ -405,6 +405,161 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
     if (tid == 0) info[t] = done_s == 1 ? piv_s : -piv_s;
 }
 
+// ---- the model problem when a slot has at most 8 candidates (the binding steady state:
+// one to three multipliers per slot) -- Gram matrix and pivoting in ONE small kernel instead
+// of the tiled Gram kernel + the 128-row pivoting kernel (37 us -> ~8 us per Newton step).
+// The whole workgroup accumulates the 36 upper-triangular entries of R_F N R_F^T over the
+// columns (coalesced row reads), one thread then runs the same block principal pivoting
+// (same regularisation, tolerances and backup rule) on the 8 x 8 problem in LDS.
+constexpr int kSmall = 8;
+__global__ __launch_bounds__(256) void op_dual_model_small_kernel(
+        int m, int T, const double *__restrict__ R, const double *__restrict__ Nn,
+        const int64_t *__restrict__ cidx, const int32_t *__restrict__ ccnt,
+        const double *__restrict__ cval, double inv_kappa, double delta, int max_pivots,
+        double *__restrict__ Kall, double *__restrict__ yhat, int32_t *__restrict__ info) {
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int a = ccnt[t];
+    const double *cs = cval + (int64_t)t * 3 * kAmax, *cg = cs + kAmax, *cy = cg + kAmax;
+    double *yo = yhat + (int64_t)t * kAmax;
+    if (a <= 0 || a > kSmall) {             // uniform; a > 8 means the caller's count was wrong
+        if (tid < kAmax) yo[tid] = cy[tid];
+        if (tid == 0) info[t] = a <= 0 ? 0 : -999;
+        return;
+    }
+    int64_t f[kSmall];
+#pragma unroll
+    for (int i = 0; i < kSmall; ++i) f[i] = i < a ? cidx[(int64_t)t * kAmax + i] : -1;
+    double acc[kSmall * (kSmall + 1) / 2];
+#pragma unroll
+    for (int p = 0; p < kSmall * (kSmall + 1) / 2; ++p) acc[p] = 0.0;
+    for (int mm = tid; mm < m; mm += 256) {
+        const double nv = Nn[(int64_t)mm * T + t];
+        double r[kSmall];
+#pragma unroll
+        for (int i = 0; i < kSmall; ++i) r[i] = f[i] >= 0 ? R[f[i] * m + mm] : 0.0;
+        int p = 0;
+#pragma unroll
+        for (int i = 0; i < kSmall; ++i) {
+            const double rn = r[i] * nv;
+#pragma unroll
+            for (int j = i; j < kSmall; ++j) acc[p++] += rn * r[j];
+        }
+    }
+    __shared__ double part[4][kSmall * (kSmall + 1) / 2];
+    __shared__ double Ks[kSmall][kSmall];
+#pragma unroll
+    for (int p = 0; p < kSmall * (kSmall + 1) / 2; ++p) {
+        const double v = wave_sum_d(acc[p]);
+        if ((tid & 63) == 0) part[tid >> 6][p] = v;
+    }
+    __syncthreads();
+    if (tid < kSmall * kSmall) {
+        const int i = tid / kSmall, j = tid % kSmall;
+        const int lo = i < j ? i : j, hi = i < j ? j : i;
+        const int p = lo * kSmall - lo * (lo - 1) / 2 + (hi - lo);
+        const double v = (((part[0][p] + part[1][p]) + part[2][p]) + part[3][p]) * inv_kappa;
+        Ks[i][j] = v;
+        if (i < a && j < a) Kall[(int64_t)t * kAmax * kAmax + i * kAmax + j] = v;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    // One thread, everything in registers: rows >= a and non-basic rows are masked to the
+    // identity, so every loop below has compile-time bounds.
+    double s[kSmall], c[kSmall], u[kSmall], cyv[kSmall], K[kSmall][kSmall];
+    double tr = 0.0;
+#pragma unroll
+    for (int i = 0; i < kSmall; ++i) {
+        const bool in = i < a;
+        s[i] = in ? cs[i] : 1.0;
+        cyv[i] = in ? cy[i] : 0.0;
+        u[i] = in ? fmax(s[i] * cyv[i], 0.0) : 0.0;
+        tr += in ? Ks[i][i] : 0.0;
+    }
+    if (!(tr > 0.0)) {                      // K = 0: leave the multipliers where they are
+        for (int i = 0; i < kAmax; ++i) yo[i] = i < a ? cy[i] : 0.0;
+        info[t] = 0;
+        return;
+    }
+    const double dl = delta * tr / a + 1e-300;
+#pragma unroll
+    for (int i = 0; i < kSmall; ++i)
+#pragma unroll
+        for (int j = 0; j < kSmall; ++j)
+            K[i][j] = (i < a && j < a) ? s[i] * s[j] * Ks[i][j] + (i == j ? dl : 0.0) : 0.0;
+    double cmax = 0.0;
+#pragma unroll
+    for (int i = 0; i < kSmall; ++i) {
+        double ku = 0.0;
+#pragma unroll
+        for (int j = 0; j < kSmall; ++j) ku += K[i][j] * u[j];
+        c[i] = i < a ? s[i] * cg[i < a ? i : 0] + ku : 0.0;
+        cmax = fmax(cmax, fabs(c[i]));
+    }
+    const double tolw = 1e-13 * cmax;
+    unsigned B = 0;
+#pragma unroll
+    for (int i = 0; i < kSmall; ++i) B |= (i < a && u[i] > 0.0) ? (1u << i) : 0u;
+    int ninf = kSmall + 1, pcount = 3, piv = 0, done = 0;
+    while (!done) {
+        double L[kSmall][kSmall], z[kSmall];
+#pragma unroll
+        for (int k = 0; k < kSmall; ++k)
+#pragma unroll
+            for (int l = 0; l <= k; ++l)
+                L[k][l] = (((B >> k) & 1u) && ((B >> l) & 1u)) ? K[k][l] : (k == l ? 1.0 : 0.0);
+#pragma unroll
+        for (int k = 0; k < kSmall; ++k) {  // Cholesky, lower triangle in place
+            const double pk = sqrt(fmax(L[k][k], dl * 1e-6));
+            L[k][k] = pk;
+            const double ipk = 1.0 / pk;
+#pragma unroll
+            for (int i = k + 1; i < kSmall; ++i) L[i][k] *= ipk;
+#pragma unroll
+            for (int i = k + 1; i < kSmall; ++i)
+#pragma unroll
+                for (int j = k + 1; j <= i; ++j) L[i][j] -= L[i][k] * L[j][k];
+        }
+#pragma unroll
+        for (int k = 0; k < kSmall; ++k) {
+            double v = ((B >> k) & 1u) ? c[k] : 0.0;
+#pragma unroll
+            for (int l = 0; l < k; ++l) v -= L[k][l] * z[l];
+            z[k] = v / L[k][k];
+        }
+#pragma unroll
+        for (int k = kSmall - 1; k >= 0; --k) {
+            double v = z[k];
+#pragma unroll
+            for (int l = k + 1; l < kSmall; ++l) v -= L[l][k] * z[l];
+            z[k] = v / L[k][k];
+        }
+        double umax = 0.0;
+#pragma unroll
+        for (int i = 0; i < kSmall; ++i) { u[i] = ((B >> i) & 1u) ? z[i] : 0.0; umax = fmax(umax, fabs(u[i])); }
+        unsigned V = 0;
+#pragma unroll
+        for (int i = 0; i < kSmall; ++i) {
+            double ku = 0.0;
+#pragma unroll
+            for (int j = 0; j < kSmall; ++j) ku += K[i][j] * u[j];
+            const double wi = ku - c[i];
+            const bool inB = (B >> i) & 1u;
+            if (i < a && (inB ? (u[i] < -1e-13 * umax) : (wi < -tolw))) V |= 1u << i;
+        }
+        ++piv;
+        const int nv = __popc(V);
+        if (nv == 0) done = 1;
+        else if (piv >= max_pivots) done = 2;
+        else if (nv < ninf) { ninf = nv; pcount = 3; B ^= V; }
+        else if (pcount > 0) { --pcount; B ^= V; }
+        else B ^= 1u << (31 - __clz((int)V));
+    }
+#pragma unroll
+    for (int i = 0; i < kSmall; ++i) if (i < a) yo[i] = s[i] * fmax(u[i], 0.0);
+    for (int i = a; i < kAmax; ++i) yo[i] = 0.0;
+    info[t] = done == 1 ? piv : -piv;
+}
+
 // y_trial[cand] = y + alpha_t (yhat - y); lin_out[8 t] = grad . (y_trial - y)
 __global__ __launch_bounds__(64) void op_dual_step_kernel(
         int T, const int64_t *__restrict__ cidx, const int32_t *__restrict__ ccnt,
@@ -540,6 +695,20 @@ extern "C" int revs_op_dual_model(int32_t m, int32_t T, const double *R, const d
     hipLaunchKernelGGL(op_dual_bpp_kernel, dim3(T), dim3(256), lds, S_(stream), k_slabs, nks,
                        1.0 / kappa, k_full, cand_cnt, cand_val, delta, max_pivots, yhat, info);
     REVS_CHECK_LAUNCH("revs_op_dual_model");
+    return REVS_OK;
+}
+
+extern "C" int revs_op_dual_model_small(int32_t m, int32_t T, const double *R, const double *n_free,
+                                        const int64_t *cand_idx, const int32_t *cand_cnt,
+                                        const double *cand_val, double kappa, double delta,
+                                        int32_t max_pivots, double *k_full, double *yhat,
+                                        int32_t *info, void *stream) {
+    REVS_REQUIRE(m > 0 && T > 0 && R && n_free && cand_idx && cand_cnt && cand_val && k_full && yhat &&
+                 info && kappa > 0 && delta >= 0 && max_pivots > 0,
+                 "revs_op_dual_model_small: bad argument");
+    hipLaunchKernelGGL(op_dual_model_small_kernel, dim3(T), dim3(256), 0, S_(stream), m, T, R, n_free,
+                       cand_idx, cand_cnt, cand_val, 1.0 / kappa, delta, max_pivots, k_full, yhat, info);
+    REVS_CHECK_LAUNCH("revs_op_dual_model_small");
     return REVS_OK;
 }
 

@@ -101,15 +101,35 @@ __device__ __forceinline__ void dual_select_body(const SelectArgs &sa, const int
     }
     const int room = min(min(kadd, kAmax - ns), nv);
     int added = 0;
-    // Row r is always scanned by thread r % 256, which remembers in a register mask which
-    // of its rows were taken -- no global store has to become visible between rounds.
+    // Row r is always scanned by thread r % 256.  Up to 4096 rows a thread keeps its (at most
+    // 16) violations in registers and zeroes the one that is taken; beyond that it re-reads
+    // them and remembers the taken ones in a register mask -- either way no global store has
+    // to become visible between rounds.  One barrier per round (results ping-pong in LDS).
+    constexpr int kLoc = 16;
+    const bool inreg = m <= 256 * kLoc;
+    double loc[kLoc];
+    if (inreg) {
+#pragma unroll
+        for (int i = 0; i < kLoc; ++i) {
+            const int r = tid + 256 * i;
+            loc[i] = r < m ? viol[(int64_t)r * T + t] : 0.0;
+        }
+    }
     unsigned long long took = 0ull;
+    __shared__ double best_v2[2][4];
+    __shared__ int best_i2[2][4];
     for (int k = 0; k < room; ++k) {
         double bv = 0.0;
         int bi = m;
-        for (int r = tid, i = 0; r < m; r += 256, ++i) {
-            const double x = viol[(int64_t)r * T + t];
-            if (x > bv && !((took >> i) & 1ull)) { bv = x; bi = r; }   // ascending r: ties keep the lower row
+        if (inreg) {
+#pragma unroll
+            for (int i = 0; i < kLoc; ++i)
+                if (loc[i] > bv) { bv = loc[i]; bi = tid + 256 * i; }   // ascending r: ties keep the lower row
+        } else {
+            for (int r = tid, i = 0; r < m; r += 256, ++i) {
+                const double x = viol[(int64_t)r * T + t];
+                if (x > bv && !((took >> i) & 1ull)) { bv = x; bi = r; }
+            }
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
@@ -117,15 +137,24 @@ __device__ __forceinline__ void dual_select_body(const SelectArgs &sa, const int
             const int oi = __shfl_xor(bi, d, 64);
             if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
         }
-        __syncthreads();                    // best_v / best_i of the previous round were read
-        if ((tid & 63) == 0) { best_v[tid >> 6] = bv; best_i[tid >> 6] = bi; }
+        const int pp = k & 1;
+        if ((tid & 63) == 0) { best_v2[pp][tid >> 6] = bv; best_i2[pp][tid >> 6] = bi; }
         __syncthreads();
-        bv = best_v[0]; bi = best_i[0];
+        bv = best_v2[pp][0]; bi = best_i2[pp][0];
 #pragma unroll
         for (int w = 1; w < 4; ++w)
-            if (best_v[w] > bv || (best_v[w] == bv && best_i[w] < bi)) { bv = best_v[w]; bi = best_i[w]; }
+            if (best_v2[pp][w] > bv || (best_v2[pp][w] == bv && best_i2[pp][w] < bi)) {
+                bv = best_v2[pp][w]; bi = best_i2[pp][w];
+            }
         if (!(bv > 0.0)) break;             // uniform
-        if (tid == (bi & 255)) took |= 1ull << (bi >> 8);
+        if (tid == (bi & 255)) {
+            if (inreg) {
+#pragma unroll
+                for (int i = 0; i < kLoc; ++i) if (i == (bi >> 8)) loc[i] = 0.0;
+            } else {
+                took |= 1ull << (bi >> 8);
+            }
+        }
         if (tid == 0) {
             const double v = vfull[(int64_t)bi * T + t];
             const bool up = v > vhi;

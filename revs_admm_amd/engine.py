@@ -241,6 +241,7 @@ class AdmmEngine:
         self._spec_ok = False
         self._spec_wait, self._spec_back = 0, 1
         self._sup = None
+        self.model_calls = [0, 0]                      # small / general model kernels used
         self.spec_hist = [0, 0]                        # speculative sweeps kept / discarded
         self.P_sch_alt = torch.zeros(n, T, **f32) if self.op.solver == "newton" else None
         self.G_alt = torch.zeros(n, T, **f32) if self.op.solver == "newton" else None
@@ -281,6 +282,12 @@ class AdmmEngine:
                                              ptr(self.c_val[0]), ptr(self.yhat), self.alpha_dev,
                                              ptr(self.yd[1]), self.stats_dev[1] + 32, self.stream),
                   "revs_op_dual_step")
+            check(self.lib.revs_op_dual_model_small(M, T, ptr(self.R64), ptr(self.pnq[1]),
+                                                    ptr(self.c_idx[0]), ptr(self.c_cnt[0]),
+                                                    ptr(self.c_val[0]), self.kappa,
+                                                    self.op.newton_delta, self.op.newton_pivots,
+                                                    ptr(self.k_full), ptr(self.yhat), self.info_dev,
+                                                    self.stream), "revs_op_dual_model_small")
             self._gemm1(self.R64, self.yd[0], self.d_sl)
             torch.cuda.synchronize(self.dev)
         # steady-state iteration as ONE native call (one GPU; see revs_plan_spec_step)
@@ -802,12 +809,22 @@ class AdmmEngine:
             newton += 1
             # model of every slot: K_t = R_F N_t R_F^T / kappa over its candidates, maximised
             # over the sign constraints (block principal pivoting, one workgroup per slot)
-            check(lib.revs_op_dual_model(M, T, ptr(self.R64), ptr(self.pnq[1]),
-                                         ptr(self.c_idx[cur]), ptr(self.c_cnt[cur]),
-                                         ptr(self.c_val[cur]), self.kappa, o.newton_delta,
-                                         o.newton_pivots, self.nks, ptr(self.k_slabs),
-                                         ptr(self.k_full), ptr(self.yhat), self.info_dev, st),
-                  "revs_op_dual_model")
+            # (candidates of a slot = its rows with a multiplier + the violated rows admitted)
+            ncand = stt[:, 2] + np.minimum(stt[:, 3], np.minimum(o.newton_kadd, A - stt[:, 2]))
+            self.model_calls[0 if ncand.max() <= 8 else 1] += 1
+            if ncand.max() <= 8:                 # the binding steady state: one small kernel
+                check(lib.revs_op_dual_model_small(M, T, ptr(self.R64), ptr(self.pnq[1]),
+                                                   ptr(self.c_idx[cur]), ptr(self.c_cnt[cur]),
+                                                   ptr(self.c_val[cur]), self.kappa, o.newton_delta,
+                                                   o.newton_pivots, ptr(self.k_full), ptr(self.yhat),
+                                                   self.info_dev, st), "revs_op_dual_model_small")
+            else:
+                check(lib.revs_op_dual_model(M, T, ptr(self.R64), ptr(self.pnq[1]),
+                                             ptr(self.c_idx[cur]), ptr(self.c_cnt[cur]),
+                                             ptr(self.c_val[cur]), self.kappa, o.newton_delta,
+                                             o.newton_pivots, self.nks, ptr(self.k_slabs),
+                                             ptr(self.k_full), ptr(self.yhat), self.info_dev, st),
+                      "revs_op_dual_model")
             D = stt[:, 1]
             pending = rmax > o.eps
             alpha = pending.astype(np.float64)

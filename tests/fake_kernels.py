@@ -424,6 +424,12 @@ class FakeKernels:
             inf[t] = piv if done else -piv
         return 0
 
+    def revs_op_dual_model_small(self, m, T, R, n_free, cidx, ccnt, cval, kappa, delta, max_pivots,
+                                 k_full, yhat, info, stream):
+        ks = np.zeros((T, 1, DUAL_AMAX, DUAL_AMAX))
+        return self.revs_op_dual_model(m, T, R, n_free, cidx, ccnt, cval, kappa, delta, max_pivots, 1,
+                                       ks.ctypes.data, k_full, yhat, info, stream)
+
     def revs_op_dual_step(self, T, cidx, ccnt, cval, yhat, alpha, ytrial, lin_out, stream):
         A = DUAL_AMAX
         ci, cc = view(cidx, (T, A), np.int64), view(ccnt, (T,), np.int32)

@@ -315,7 +315,7 @@ def test_sweep_with_selection_and_next_home_pass(gpu_lib, mode):
     np.testing.assert_allclose(p_next.cpu().numpy(), pnq2[0].cpu().numpy(), rtol=1e-13, atol=1e-12)
 
 
-@pytest.mark.parametrize("a", [1, 2, 31, 63, 64, 65, 100, 127, 128])
+@pytest.mark.parametrize("a", [1, 2, 5, 8, 31, 63, 64, 65, 100, 127, 128])
 def test_model_problem_sizes(gpu_lib, a):
     """revs_op_dual_model at every interesting candidate count (one row, the 64/65 boundary of
     the two mask words, the full 128): the returned point satisfies the LCP of the model and
@@ -360,6 +360,18 @@ def test_model_problem_sizes(gpu_lib, a):
     torch.cuda.synchronize()
     np.testing.assert_array_equal(y0.cpu().numpy()[:, :a], cval[:, 2, :a])
     assert (info.cpu().numpy() == 0).all()
+    # the one-kernel form for at most 8 candidates per slot: same Gram matrix, same solution
+    kf2, yh2 = torch.zeros(T, A, A, **f64), torch.zeros(T, A, **f64)
+    check(gpu_lib.revs_op_dual_model_small(M, T, ptr(dR), ptr(dN), ptr(dci), ptr(dcc), ptr(dcv), kappa,
+                                           delta, 400, ptr(kf2), ptr(yh2), ptr(info), None), "small")
+    torch.cuda.synchronize()
+    if a <= 8:
+        assert (info.cpu().numpy() > 0).all()
+        np.testing.assert_allclose(kf2.cpu().numpy()[:, :a, :a], Kg[:, :a, :a], rtol=1e-11, atol=1e-15)
+        np.testing.assert_allclose(yh2.cpu().numpy(), yh, rtol=1e-5, atol=1e-6 * np.abs(yh).max())
+    else:                                   # too many candidates: flagged, nothing moved
+        assert (info.cpu().numpy() == -999).all()
+        np.testing.assert_array_equal(yh2.cpu().numpy()[:, :a], cval[:, 2, :a])
     ref, inf_ref = np.zeros((T, A)), np.zeros(T, np.int32)
     ksl_r, kf_r = np.zeros((T, nks, A, A)), np.zeros((T, A, A))
     Rc, Nc = np.ascontiguousarray(R), np.ascontiguousarray(nfree)
