@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--op-alpha", type=float, default=None, help="operator: over-relaxation")
     ap.add_argument("--op-adapt", type=int, default=None, help="operator: rho update period")
     ap.add_argument("--pdhg-check", type=int, default=None, help="PDHG: convergence test period")
+    ap.add_argument("--op-kadd", type=int, default=None,
+                    help="operator: violated rows admitted to a slot's model per Newton iteration")
     ap.add_argument("--no-converge", action="store_true",
                     help="skip the untimed run to the eps-residual (profiling runs)")
     args = ap.parse_args()
@@ -168,6 +170,8 @@ def main():
         opts.alpha = args.op_alpha
     if args.op_adapt is not None:
         opts.adapt_every = args.op_adapt
+    if args.op_kadd is not None:
+        opts.newton_kadd = args.op_kadd
     if os.environ.get("REVS_CAL_RHO_B"):
         opts.cal_rho_b = tuple(float(x) for x in os.environ["REVS_CAL_RHO_B"].split(","))
     if os.environ.get("REVS_CAL_RHO_V"):

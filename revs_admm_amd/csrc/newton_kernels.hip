@@ -432,6 +432,7 @@ __global__ __launch_bounds__(256) void op_dual_model_small_kernel(
     double acc[kSmall * (kSmall + 1) / 2];
 #pragma unroll
     for (int p = 0; p < kSmall * (kSmall + 1) / 2; ++p) acc[p] = 0.0;
+#pragma unroll 4
     for (int mm = tid; mm < m; mm += 256) {
         const double nv = Nn[(int64_t)mm * T + t];
         double r[kSmall];

@@ -87,7 +87,7 @@ class OperatorOptions:
     # the ADMM forms when it cannot finish (more than 128 binding rows in a slot, ...).
     solver: str = "newton"
     newton_max: int = 60         # Newton iterations per operator solve
-    newton_kadd: int = 16        # violated rows admitted to a slot's model per iteration
+    newton_kadd: int = 6         # violated rows admitted to a slot's model per iteration
     newton_delta: float = 1e-10  # relative diagonal shift of the model Hessian
     newton_pivots: int = 300     # block-pivoting limit per model problem
     newton_ls: int = 30          # Armijo halvings
