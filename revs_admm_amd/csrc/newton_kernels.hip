@@ -57,9 +57,20 @@ __global__ __launch_bounds__(256) void op_dual_eval_kernel(
     } else if (sp.R && tok) {
         const int cnt = sp.scnt[t];
         const int64_t *si = sp.sidx + (int64_t)t * kAmax;
-        for (int i = 0; i < cnt; ++i) {
-            const int64_t f = si[i];
-            d += sp.R[f * m + node] * sp.y[f * T + t];
+        // eight rows at a time, predicated: the index loads, then the R and y loads of a batch
+        // are all in flight together (two memory round trips per batch, not two per row)
+        for (int i0 = 0; i0 < cnt; i0 += 8) {
+            int64_t f[8];
+            double rv[8], yv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] = i0 + k < cnt ? si[i0 + k] : 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                rv[k] = sp.R[f[k] * m + node];
+                yv[k] = i0 + k < cnt ? sp.y[f[k] * T + t] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d += rv[k] * yv[k];
         }
         d *= inv_k;
     }
@@ -405,6 +416,108 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
     if (tid == 0) info[t] = done_s == 1 ? piv_s : -piv_s;
 }
 
+// The LCP of at most 8 candidates by one thread, everything in registers (loops sized by the
+// template parameter): same regularisation, tolerances and pivoting rule as op_dual_bpp_kernel.
+template <int A>
+__device__ __forceinline__ void small_bpp(const double (&Ks)[8][8], const double *cs,
+                                          const double *cg, const double *cy, double delta,
+                                          int max_pivots, double *yo, int32_t *info) {
+    // One thread, everything in registers: rows >= a and non-basic rows are masked to the
+    // identity, so every loop below has compile-time bounds.
+    double s[A], c[A], u[A], cyv[A], K[A][A];
+    double tr = 0.0;
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+        s[i] = cs[i];
+        cyv[i] = cy[i];
+        u[i] = fmax(s[i] * cyv[i], 0.0);
+        tr += Ks[i][i];
+    }
+    if (!(tr > 0.0)) {                      // K = 0: leave the multipliers where they are
+        for (int i = 0; i < kAmax; ++i) yo[i] = i < A ? cy[i] : 0.0;
+        *info = 0;
+        return;
+    }
+    const double dl = delta * tr / A + 1e-300;
+#pragma unroll
+    for (int i = 0; i < A; ++i)
+#pragma unroll
+        for (int j = 0; j < A; ++j)
+            K[i][j] = s[i] * s[j] * Ks[i][j] + (i == j ? dl : 0.0);
+    double cmax = 0.0;
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+        double ku = 0.0;
+#pragma unroll
+        for (int j = 0; j < A; ++j) ku += K[i][j] * u[j];
+        c[i] = s[i] * cg[i] + ku;
+        cmax = fmax(cmax, fabs(c[i]));
+    }
+    const double tolw = 1e-13 * cmax;
+    unsigned B = 0;
+#pragma unroll
+    for (int i = 0; i < A; ++i) B |= (u[i] > 0.0) ? (1u << i) : 0u;
+    int ninf = A + 1, pcount = 3, piv = 0, done = 0;
+    while (!done) {
+        double L[A][A], z[A], ipk[A];
+#pragma unroll
+        for (int k = 0; k < A; ++k)
+#pragma unroll
+            for (int l = 0; l <= k; ++l)
+                L[k][l] = (((B >> k) & 1u) && ((B >> l) & 1u)) ? K[k][l] : (k == l ? 1.0 : 0.0);
+#pragma unroll
+        for (int k = 0; k < A; ++k) {  // Cholesky, lower triangle in place; 1/pivot kept
+            const double pk = sqrt(fmax(L[k][k], dl * 1e-6));
+            ipk[k] = 1.0 / pk;              // (the only divisions: f64 division is ~12 dependent ops)
+#pragma unroll
+            for (int i = k + 1; i < A; ++i) L[i][k] *= ipk[k];
+#pragma unroll
+            for (int i = k + 1; i < A; ++i)
+#pragma unroll
+                for (int j = k + 1; j <= i; ++j) L[i][j] -= L[i][k] * L[j][k];
+        }
+#pragma unroll
+        for (int k = 0; k < A; ++k) {
+            double v = ((B >> k) & 1u) ? c[k] : 0.0;
+#pragma unroll
+            for (int l = 0; l < k; ++l) v -= L[k][l] * z[l];
+            z[k] = v * ipk[k];
+        }
+#pragma unroll
+        for (int k = A - 1; k >= 0; --k) {
+            double v = z[k];
+#pragma unroll
+            for (int l = k + 1; l < A; ++l) v -= L[l][k] * z[l];
+            z[k] = v * ipk[k];
+        }
+        double umax = 0.0;
+#pragma unroll
+        for (int i = 0; i < A; ++i) { u[i] = ((B >> i) & 1u) ? z[i] : 0.0; umax = fmax(umax, fabs(u[i])); }
+        unsigned V = 0;
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+            double ku = 0.0;
+#pragma unroll
+            for (int j = 0; j < A; ++j) ku += K[i][j] * u[j];
+            const double wi = ku - c[i];
+            const bool inB = (B >> i) & 1u;
+            if (inB ? (u[i] < -1e-13 * umax) : (wi < -tolw)) V |= 1u << i;
+        }
+        ++piv;
+        const int nv = __popc(V);
+        if (nv == 0) done = 1;
+        else if (piv >= max_pivots) done = 2;
+        else if (nv < ninf) { ninf = nv; pcount = 3; B ^= V; }
+        else if (pcount > 0) { --pcount; B ^= V; }
+        else B ^= 1u << (31 - __clz((int)V));
+    }
+#pragma unroll
+    for (int i = 0; i < A; ++i) yo[i] = s[i] * fmax(u[i], 0.0);
+    for (int i = A; i < kAmax; ++i) yo[i] = 0.0;
+    *info = done == 1 ? piv : -piv;
+}
+
+
 // ---- the model problem when a slot has at most 8 candidates (the binding steady state:
 // one to three multipliers per slot) -- Gram matrix and pivoting in ONE small kernel instead
 // of the tiled Gram kernel + the 128-row pivoting kernel (37 us -> ~8 us per Newton step).
@@ -464,101 +577,16 @@ __global__ __launch_bounds__(256) void op_dual_model_small_kernel(
     }
     __syncthreads();
     if (tid != 0) return;
-    // One thread, everything in registers: rows >= a and non-basic rows are masked to the
-    // identity, so every loop below has compile-time bounds.
-    double s[kSmall], c[kSmall], u[kSmall], cyv[kSmall], K[kSmall][kSmall];
-    double tr = 0.0;
-#pragma unroll
-    for (int i = 0; i < kSmall; ++i) {
-        const bool in = i < a;
-        s[i] = in ? cs[i] : 1.0;
-        cyv[i] = in ? cy[i] : 0.0;
-        u[i] = in ? fmax(s[i] * cyv[i], 0.0) : 0.0;
-        tr += in ? Ks[i][i] : 0.0;
+    switch (a) {                            // one thread; loops sized by the candidate count
+        case 1: small_bpp<1>(Ks, cs, cg, cy, delta, max_pivots, yo, info + t); break;
+        case 2: small_bpp<2>(Ks, cs, cg, cy, delta, max_pivots, yo, info + t); break;
+        case 3: small_bpp<3>(Ks, cs, cg, cy, delta, max_pivots, yo, info + t); break;
+        case 4: small_bpp<4>(Ks, cs, cg, cy, delta, max_pivots, yo, info + t); break;
+        case 5: small_bpp<5>(Ks, cs, cg, cy, delta, max_pivots, yo, info + t); break;
+        case 6: small_bpp<6>(Ks, cs, cg, cy, delta, max_pivots, yo, info + t); break;
+        case 7: small_bpp<7>(Ks, cs, cg, cy, delta, max_pivots, yo, info + t); break;
+        default: small_bpp<8>(Ks, cs, cg, cy, delta, max_pivots, yo, info + t); break;
     }
-    if (!(tr > 0.0)) {                      // K = 0: leave the multipliers where they are
-        for (int i = 0; i < kAmax; ++i) yo[i] = i < a ? cy[i] : 0.0;
-        info[t] = 0;
-        return;
-    }
-    const double dl = delta * tr / a + 1e-300;
-#pragma unroll
-    for (int i = 0; i < kSmall; ++i)
-#pragma unroll
-        for (int j = 0; j < kSmall; ++j)
-            K[i][j] = (i < a && j < a) ? s[i] * s[j] * Ks[i][j] + (i == j ? dl : 0.0) : 0.0;
-    double cmax = 0.0;
-#pragma unroll
-    for (int i = 0; i < kSmall; ++i) {
-        double ku = 0.0;
-#pragma unroll
-        for (int j = 0; j < kSmall; ++j) ku += K[i][j] * u[j];
-        c[i] = i < a ? s[i] * cg[i < a ? i : 0] + ku : 0.0;
-        cmax = fmax(cmax, fabs(c[i]));
-    }
-    const double tolw = 1e-13 * cmax;
-    unsigned B = 0;
-#pragma unroll
-    for (int i = 0; i < kSmall; ++i) B |= (i < a && u[i] > 0.0) ? (1u << i) : 0u;
-    int ninf = kSmall + 1, pcount = 3, piv = 0, done = 0;
-    while (!done) {
-        double L[kSmall][kSmall], z[kSmall];
-#pragma unroll
-        for (int k = 0; k < kSmall; ++k)
-#pragma unroll
-            for (int l = 0; l <= k; ++l)
-                L[k][l] = (((B >> k) & 1u) && ((B >> l) & 1u)) ? K[k][l] : (k == l ? 1.0 : 0.0);
-#pragma unroll
-        for (int k = 0; k < kSmall; ++k) {  // Cholesky, lower triangle in place
-            const double pk = sqrt(fmax(L[k][k], dl * 1e-6));
-            L[k][k] = pk;
-            const double ipk = 1.0 / pk;
-#pragma unroll
-            for (int i = k + 1; i < kSmall; ++i) L[i][k] *= ipk;
-#pragma unroll
-            for (int i = k + 1; i < kSmall; ++i)
-#pragma unroll
-                for (int j = k + 1; j <= i; ++j) L[i][j] -= L[i][k] * L[j][k];
-        }
-#pragma unroll
-        for (int k = 0; k < kSmall; ++k) {
-            double v = ((B >> k) & 1u) ? c[k] : 0.0;
-#pragma unroll
-            for (int l = 0; l < k; ++l) v -= L[k][l] * z[l];
-            z[k] = v / L[k][k];
-        }
-#pragma unroll
-        for (int k = kSmall - 1; k >= 0; --k) {
-            double v = z[k];
-#pragma unroll
-            for (int l = k + 1; l < kSmall; ++l) v -= L[l][k] * z[l];
-            z[k] = v / L[k][k];
-        }
-        double umax = 0.0;
-#pragma unroll
-        for (int i = 0; i < kSmall; ++i) { u[i] = ((B >> i) & 1u) ? z[i] : 0.0; umax = fmax(umax, fabs(u[i])); }
-        unsigned V = 0;
-#pragma unroll
-        for (int i = 0; i < kSmall; ++i) {
-            double ku = 0.0;
-#pragma unroll
-            for (int j = 0; j < kSmall; ++j) ku += K[i][j] * u[j];
-            const double wi = ku - c[i];
-            const bool inB = (B >> i) & 1u;
-            if (i < a && (inB ? (u[i] < -1e-13 * umax) : (wi < -tolw))) V |= 1u << i;
-        }
-        ++piv;
-        const int nv = __popc(V);
-        if (nv == 0) done = 1;
-        else if (piv >= max_pivots) done = 2;
-        else if (nv < ninf) { ninf = nv; pcount = 3; B ^= V; }
-        else if (pcount > 0) { --pcount; B ^= V; }
-        else B ^= 1u << (31 - __clz((int)V));
-    }
-#pragma unroll
-    for (int i = 0; i < kSmall; ++i) if (i < a) yo[i] = s[i] * fmax(u[i], 0.0);
-    for (int i = a; i < kAmax; ++i) yo[i] = 0.0;
-    info[t] = done == 1 ? piv : -piv;
 }
 
 // y_trial[cand] = y + alpha_t (yhat - y); lin_out[8 t] = grad . (y_trial - y)
