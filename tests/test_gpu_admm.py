@@ -339,6 +339,40 @@ def test_relaxed_trajectory_T96(gpu_lib, solver):
     assert np.abs(S - S_ref).max() < 2e-3 and np.abs(C - C_ref).max() < 2e-4
 
 
+def test_config3_all_communities_90pct_T96(gpu_lib, golden, feeder_R):
+    """BASELINE config 3: 121144 feeder, ALL communities, 90 % adoption (1013 EVs, drawn as
+    revs_fixture.py:174-177 does), 4.8 kW, T = 96 -- hourly load and tariff held over four
+    15-minute slots, window 44..92.  Every slot has binding voltage rows (up to ~50 multipliers
+    per slot); three ADMM iterations of the relaxed problem vs the oracle, all operator solves
+    on the dual Newton path (tests/tools/feeder_config3.py times the 15-iteration run)."""
+    from helpers import f32
+    from oracle import revs_oracle as ro
+    from revs_admm_amd.engine import AdmmEngine, pack_homes
+    z, fd = golden
+    res_ids = z["res_id"]
+    n = len(res_ids)
+    np.random.seed(1234)
+    ev_homes = np.random.choice(res_ids, int(90 * 1e-2 * n), replace=False)
+    idx = {h: i for i, h in enumerate(res_ids)}
+    ev = np.zeros(n, bool)
+    ev[[idx[h] for h in ev_homes]] = True
+    assert ev.sum() == 1013
+    LOAD = f32(np.repeat(z["LOAD"], 4, axis=1))
+    cost = f32(np.repeat(z["tariff_shift6"], 4))
+    oh = ro.Homes.uniform(LOAD, ev, 4.8, 20.0, 0.2, 44, 92)
+    e = AdmmEngine(cost, pack_homes(ev, 4.8, 20.0, 0.2, 44, 92), LOAD, np.arange(n), feeder_R,
+                   kappa=5.0, vset=1.03, vlow=0.95, vhigh=1.05, mode="relaxed_exact")
+    diffs = e.run(3)
+    assert set(e.op_path_hist) == {"dual"}
+    y = e.yd[0].cpu().numpy()
+    assert 8 < (y != 0).sum(0 if y.shape[0] == n else 1).max() <= 128
+    P_sch, S, C = e.result()
+    d_ref, P_ref, S_ref, C_ref = ro.solve_ADMM(oh, feeder_R, np.arange(n), cost, 5.0, 3, 1.03,
+                                               0.95, 1.05, mode="relaxed", util_eps=1e-10)
+    assert np.abs(diffs - d_ref).max() < 1e-3 * max(1.0, d_ref.max())
+    assert np.abs(S - S_ref).max() < 2e-3 and np.abs(C - C_ref).max() < 2e-4
+
+
 def test_config0_com2_30pct_adoption(gpu_lib, golden, feeder_R):
     """BASELINE config 0: 121144 feeder, community 2, 30 % adoption, 4.8 kW, T = 24 (the
     reference's test-optimizer.py case; no stored result exists for it).  EV homes are drawn
