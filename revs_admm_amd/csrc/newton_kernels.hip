@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void op_dual_rows_kernel(
 
 // Stage 2 (select_body.h), one workgroup per slot, as its own kernel.
 __global__ __launch_bounds__(256) void op_dual_select_kernel(const SelectArgs sa) {
-    dual_select_body(sa, blockIdx.x);
+    dual_select_body<true>(sa, blockIdx.x);
 }
 
 // ---- model Hessian: K_t = R_F N_t R_F^T (candidates x candidates), K-split slabs ------
@@ -532,6 +532,9 @@ __global__ __launch_bounds__(256) void op_dual_model_small_kernel(
         double *__restrict__ Kall, double *__restrict__ yhat, int32_t *__restrict__ info) {
     const int t = blockIdx.x, tid = threadIdx.x;
     const int a = ccnt[t];
+    int64_t f[kSmall];                      // (entries beyond the count hold row 0: loadable)
+#pragma unroll
+    for (int i = 0; i < kSmall; ++i) f[i] = cidx[(int64_t)t * kAmax + i];
     const double *cs = cval + (int64_t)t * 3 * kAmax, *cg = cs + kAmax, *cy = cg + kAmax;
     double *yo = yhat + (int64_t)t * kAmax;
     if (a <= 0 || a > kSmall) {             // uniform; a > 8 means the caller's count was wrong
@@ -539,13 +542,15 @@ __global__ __launch_bounds__(256) void op_dual_model_small_kernel(
         if (tid == 0) info[t] = a <= 0 ? 0 : -999;
         return;
     }
-    int64_t f[kSmall];
+    // (the solve's inputs are fetched now, not when thread 0 gets to them)
+    __shared__ double cvs[3][kSmall];
+    if (tid < 3 * kSmall) cvs[tid / kSmall][tid % kSmall] = cs[(tid / kSmall) * kAmax + tid % kSmall];
 #pragma unroll
-    for (int i = 0; i < kSmall; ++i) f[i] = i < a ? cidx[(int64_t)t * kAmax + i] : -1;
+    for (int i = 0; i < kSmall; ++i) f[i] = i < a ? f[i] : -1;
     double acc[kSmall * (kSmall + 1) / 2];
 #pragma unroll
     for (int p = 0; p < kSmall * (kSmall + 1) / 2; ++p) acc[p] = 0.0;
-#pragma unroll 4
+#pragma unroll 8
     for (int mm = tid; mm < m; mm += 256) {
         const double nv = Nn[(int64_t)mm * T + t];
         double r[kSmall];
@@ -578,14 +583,14 @@ __global__ __launch_bounds__(256) void op_dual_model_small_kernel(
     __syncthreads();
     if (tid != 0) return;
     switch (a) {                            // one thread; loops sized by the candidate count
-        case 1: small_bpp<1>(Ks, cs, cg, cy, delta, max_pivots, yo, info + t); break;
-        case 2: small_bpp<2>(Ks, cs, cg, cy, delta, max_pivots, yo, info + t); break;
-        case 3: small_bpp<3>(Ks, cs, cg, cy, delta, max_pivots, yo, info + t); break;
-        case 4: small_bpp<4>(Ks, cs, cg, cy, delta, max_pivots, yo, info + t); break;
-        case 5: small_bpp<5>(Ks, cs, cg, cy, delta, max_pivots, yo, info + t); break;
-        case 6: small_bpp<6>(Ks, cs, cg, cy, delta, max_pivots, yo, info + t); break;
-        case 7: small_bpp<7>(Ks, cs, cg, cy, delta, max_pivots, yo, info + t); break;
-        default: small_bpp<8>(Ks, cs, cg, cy, delta, max_pivots, yo, info + t); break;
+        case 1: small_bpp<1>(Ks, cvs[0], cvs[1], cvs[2], delta, max_pivots, yo, info + t); break;
+        case 2: small_bpp<2>(Ks, cvs[0], cvs[1], cvs[2], delta, max_pivots, yo, info + t); break;
+        case 3: small_bpp<3>(Ks, cvs[0], cvs[1], cvs[2], delta, max_pivots, yo, info + t); break;
+        case 4: small_bpp<4>(Ks, cvs[0], cvs[1], cvs[2], delta, max_pivots, yo, info + t); break;
+        case 5: small_bpp<5>(Ks, cvs[0], cvs[1], cvs[2], delta, max_pivots, yo, info + t); break;
+        case 6: small_bpp<6>(Ks, cvs[0], cvs[1], cvs[2], delta, max_pivots, yo, info + t); break;
+        case 7: small_bpp<7>(Ks, cvs[0], cvs[1], cvs[2], delta, max_pivots, yo, info + t); break;
+        default: small_bpp<8>(Ks, cvs[0], cvs[1], cvs[2], delta, max_pivots, yo, info + t); break;
     }
 }
 

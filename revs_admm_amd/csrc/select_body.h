@@ -36,6 +36,11 @@ struct SelectArgs {
 // compacted in row order (deterministic: every rank builds the same lists); the most
 // violated rows without a multiplier are appended by `kadd` rounds of a block-wide
 // arg-max (ties to the lower row).
+// EAGER (the stand-alone kernel, which is a chain of memory round trips otherwise): every load
+// whose address does not depend on data -- partials, this thread's multipliers, voltages and
+// violations -- is issued at the top.  Not inside the sweep's launch: the registers would set
+// the sweep's occupancy, and a slot with nothing to do (its usual case there) needs none.
+template <bool EAGER = false>
 __device__ __forceinline__ void dual_select_body(const SelectArgs &sa, const int t) {
     const int m = sa.m, T = sa.T, nblk = sa.nblk, kadd = sa.kadd;
     const double *__restrict__ partial = sa.partial, *__restrict__ y = sa.y;
@@ -45,15 +50,34 @@ __device__ __forceinline__ void dual_select_body(const SelectArgs &sa, const int
     int32_t *__restrict__ ccnt = sa.ccnt;
     double *__restrict__ cval = sa.cval, *__restrict__ stats = sa.stats;
     const int tid = threadIdx.x;
-    __shared__ int cnt_s[256];
+    __shared__ int cnt_s[4];
     __shared__ double red_s[4][4];
     __shared__ double best_v[4];
     __shared__ int best_i[4];
+    const int per = (m + 255) / 256;
+    const int r0 = min(m, tid * per), r1 = min(m, r0 + per);
+    constexpr int kLoc = 16, kPer = 8;
+    const bool inreg = m <= 256 * kLoc;
+    const bool eager = EAGER && inreg && per <= kPer;
+    double loc[kLoc], ysv[kPer], vsv[kPer];
     {
         double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
         for (int k = tid; k < nblk; k += 256) {
             const double *o = partial + ((int64_t)k * T + t) * 4;
             a = fmax(a, o[0]); b += o[1]; c += o[2]; d += o[3];
+        }
+        if (eager) {
+#pragma unroll
+            for (int j = 0; j < kPer; ++j) {
+                const int r = r0 + j;
+                ysv[j] = r < r1 ? y[(int64_t)r * T + t] : 0.0;
+                vsv[j] = r < r1 ? vfull[(int64_t)r * T + t] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < kLoc; ++i) {
+                const int r = tid + 256 * i;
+                loc[i] = r < m ? viol[(int64_t)r * T + t] : 0.0;
+            }
         }
         a = wave_max_d(a); b = wave_sum_d(b); c = wave_sum_d(c); d = wave_sum_d(d);
         if ((tid & 63) == 0) {
@@ -80,23 +104,47 @@ __device__ __forceinline__ void dual_select_body(const SelectArgs &sa, const int
         if (tid < kAmax) { ci[tid] = 0; cs[tid] = 1.0; cg[tid] = 0.0; cy[tid] = 0.0; }
         return;
     }
-    const int per = (m + 255) / 256;
-    const int r0 = min(m, tid * per), r1 = min(m, r0 + per);
     int nsup = 0;
-    for (int r = r0; r < r1; ++r) nsup += y[(int64_t)r * T + t] != 0.0 ? 1 : 0;
-    cnt_s[tid] = nsup;
+    if (eager) {
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) nsup += ysv[j] != 0.0 ? 1 : 0;
+    } else {
+        for (int r = r0; r < r1; ++r) nsup += y[(int64_t)r * T + t] != 0.0 ? 1 : 0;
+    }
+    // exclusive prefix over the workgroup: scan inside the wavefront, then the wavefronts' totals
+    int incl = nsup;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d, 64);
+        if ((tid & 63) >= d) incl += o;
+    }
+    if ((tid & 63) == 63) cnt_s[tid >> 6] = incl;
     __syncthreads();
-    int pos = 0;
-    for (int j = 0; j < tid; ++j) pos += cnt_s[j];
-    for (int r = r0; r < r1 && nsup > 0; ++r) {
-        const int64_t i = (int64_t)r * T + t;
-        const double yv = y[i];
-        if (yv != 0.0) {
-            ci[pos] = r;
-            cs[pos] = yv > 0.0 ? 1.0 : -1.0;
-            cg[pos] = vfull[i] - (yv > 0.0 ? vhi : vlo);
-            cy[pos] = yv;
-            ++pos;
+    int pos = incl - nsup;
+    for (int w = 0; w < (tid >> 6); ++w) pos += cnt_s[w];
+    if (eager) {
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const double yv = ysv[j];
+            if (yv != 0.0) {
+                ci[pos] = r0 + j;
+                cs[pos] = yv > 0.0 ? 1.0 : -1.0;
+                cg[pos] = vsv[j] - (yv > 0.0 ? vhi : vlo);
+                cy[pos] = yv;
+                ++pos;
+            }
+        }
+    } else {
+        for (int r = r0; r < r1 && nsup > 0; ++r) {
+            const int64_t i = (int64_t)r * T + t;
+            const double yv = y[i];
+            if (yv != 0.0) {
+                ci[pos] = r;
+                cs[pos] = yv > 0.0 ? 1.0 : -1.0;
+                cg[pos] = vfull[i] - (yv > 0.0 ? vhi : vlo);
+                cy[pos] = yv;
+                ++pos;
+            }
         }
     }
     const int room = min(min(kadd, kAmax - ns), nv);
@@ -105,10 +153,7 @@ __device__ __forceinline__ void dual_select_body(const SelectArgs &sa, const int
     // 16) violations in registers and zeroes the one that is taken; beyond that it re-reads
     // them and remembers the taken ones in a register mask -- either way no global store has
     // to become visible between rounds.  One barrier per round (results ping-pong in LDS).
-    constexpr int kLoc = 16;
-    const bool inreg = m <= 256 * kLoc;
-    double loc[kLoc];
-    if (inreg) {
+    if (inreg && !eager) {
 #pragma unroll
         for (int i = 0; i < kLoc; ++i) {
             const int r = tid + 256 * i;
@@ -118,6 +163,7 @@ __device__ __forceinline__ void dual_select_body(const SelectArgs &sa, const int
     unsigned long long took = 0ull;
     __shared__ double best_v2[2][4];
     __shared__ int best_i2[2][4];
+    __shared__ int chosen[kAmax];
     for (int k = 0; k < room; ++k) {
         double bv = 0.0;
         int bi = m;
@@ -155,15 +201,20 @@ __device__ __forceinline__ void dual_select_body(const SelectArgs &sa, const int
                 took |= 1ull << (bi >> 8);
             }
         }
-        if (tid == 0) {
-            const double v = vfull[(int64_t)bi * T + t];
-            const bool up = v > vhi;
-            ci[ns + added] = bi;
-            cs[ns + added] = up ? 1.0 : -1.0;
-            cg[ns + added] = v - (up ? vhi : vlo);
-            cy[ns + added] = 0.0;
-        }
+        if (tid == 0) chosen[k] = bi;         // (visible after the next barrier)
         ++added;
+    }
+    // the chosen rows' entries, one thread each: a global load inside the round loop would
+    // cost every round a memory latency (the other wavefronts wait at the barrier)
+    __syncthreads();
+    if (tid < added) {
+        const int bi = chosen[tid];
+        const double v = vfull[(int64_t)bi * T + t];
+        const bool up = v > vhi;
+        ci[ns + tid] = bi;
+        cs[ns + tid] = up ? 1.0 : -1.0;
+        cg[ns + tid] = v - (up ? vhi : vlo);
+        cy[ns + tid] = 0.0;
     }
     const int cnt = ns + added;
     if (tid == 0) ccnt[t] = cnt;
