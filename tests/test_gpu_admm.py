@@ -318,7 +318,7 @@ def test_full_size_invariants(gpu_lib):
 
 @pytest.mark.parametrize("solver", ["newton", "admm"])
 def test_relaxed_trajectory_T96(gpu_lib, solver):
-    """15-minute slots (BASELINE config 4/5 shape): T = 96 uses the 32-lane home groups, 96
+    """15-minute slots (BASELINE config 4/5 shape): T = 96 uses the 16-lane x 6-slot home groups, 96
     independent slot problems in the dual Newton path and the 192-column concatenated product
     in the ADMM forms; trajectory vs oracle as for T = 24."""
     from helpers import f32, oracle_homes
@@ -472,7 +472,7 @@ def test_native_step_and_fused_home_pass_change_nothing(gpu_lib, mode, T, monkey
     from revs_admm_amd.engine import OperatorOptions
     from revs_admm_amd.synthetic import make_workload
     # (binary schedules at stress 1 keep the rows moving: no steady state; at 0.5 the rows stay slack)
-    # T = 96: 32-lane home groups, product and rows as two kernels (the one-launch form is for
+    # T = 96: 16-lane x 6-slot home groups, product and rows as two kernels (the one-launch form is for
     # T <= 32); T = 12: half-empty lane groups
     w = make_workload(3000 if T <= 24 else 1500, T, n_nodes=100, seed=5,
                       binary_feasible=(mode == "binary"), stress=0.5 if mode == "binary" else 1.02)
