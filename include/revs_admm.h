@@ -472,6 +472,26 @@ int revs_op_dual_model_small(int32_t m, int32_t T, const double *R, const double
 int revs_op_dual_step(int32_t T, const int64_t *cand_idx, const int32_t *cand_cnt,
                       const double *cand_val, const double *yhat, const double *alpha,
                       double *y_trial, double *lin_out, void *stream);
+/* revs_op_dual_step with alpha_t decided on the device from the stats of the evaluation the
+ * model was built on: alpha_t = 1 if stats_prev[8 t] / scale > eps (rows of slot t not yet
+ * within tolerance), else 0 -- what a driver that had read those stats would pass.  Lets a
+ * driver enqueue evaluation, model, step and the next evaluation without reading anything in
+ * between (engine.py: the binding steady state). */
+int revs_op_dual_step_pending(int32_t T, const int64_t *cand_idx, const int32_t *cand_cnt,
+                              const double *cand_val, const double *yhat,
+                              const double *stats_prev, double scale, double eps,
+                              double *y_trial, double *lin_out, void *stream);
+/* Host only (no GPU work): the acceptance test of such a chained iteration on the two stats
+ * blocks (double[T][8], as revs_op_dual_select writes them; s1[8 t + 4] = the step kernel's
+ * linear term) -- returns 1 iff the driver's own checks (engine.py:
+ * AdmmEngine._operator_solve_newton) would find: evaluation 0 not yet within eps, at most 8
+ * candidates per slot (the small model), the row-wise/dense choice `chain_few` right, the
+ * Armijo test passed by the full step in every pending slot, and evaluation 1 within eps.
+ * Then *nsup_sum / *nsup_max = total / largest number of multipliers per slot in s1.  Any
+ * other outcome returns 0 and is left to the driver's general loop. */
+int revs_newton_chain_accept(int32_t T, const double *s0, const double *s1, double scale, double eps,
+                             int32_t amax, int32_t kadd, int32_t chain_few, int32_t *nsup_sum,
+                             int32_t *nsup_max);
 
 /* ---- steady-state ADMM iteration as one host call ---------------------------------
  * The driver's loop of lpsolver.py:254-287 for the case "the operator's multipliers are

@@ -37,6 +37,47 @@ struct revs_plan {
     uint32_t *counters;     // device, one per 32-row tile: K-split workgroups of R p done
 };
 
+// Host-side acceptance test of a chained Newton iteration (engine.py: _chain_launch): the
+// checks AdmmEngine._operator_solve_newton would make on the two evaluations' stats, for the
+// one outcome that needs no further launch.  See include/revs_admm.h.
+extern "C" int revs_newton_chain_accept(int32_t T, const double *s0, const double *s1, double scale,
+                                        double eps, int32_t amax, int32_t kadd, int32_t chain_few,
+                                        int32_t *nsup_sum, int32_t *nsup_max) {
+    if (!s0 || !s1 || T <= 0 || !(scale > 0.0) || !nsup_sum || !nsup_max) return 0;
+    double rmax0 = 0.0, ns_max = 0.0, ncand_max = 0.0;
+    for (int t = 0; t < T; ++t) {
+        const double *a = s0 + 8 * t;
+        if (a[2] > amax) return 0;                       // more multipliers than a model holds
+        const double r = a[0] / scale;
+        rmax0 = r > rmax0 ? r : rmax0;
+        if (a[2] >= amax && a[3] > 0 && r > eps) return 0;
+        const double room = kadd < amax - a[2] ? kadd : amax - a[2];
+        const double nc = a[2] + (a[3] < room ? a[3] : room);
+        ncand_max = nc > ncand_max ? nc : ncand_max;
+        ns_max = a[2] > ns_max ? a[2] : ns_max;
+    }
+    if (!(rmax0 > eps)) return 0;                        // already converged: the general path
+    if (ncand_max > 8) return 0;                         // not the small model
+    if ((ns_max + kadd <= 48) != (chain_few != 0)) return 0;
+    double rmax1 = 0.0, sum = 0.0, mx = 0.0;
+    for (int t = 0; t < T; ++t) {
+        const double *a = s0 + 8 * t, *b = s1 + 8 * t;
+        const double D = a[1];
+        if (a[0] / scale > eps &&                        // pending slot: Armijo on the full step
+            !(b[1] >= D + 1e-4 * b[4] - 1e-13 * (D < 0 ? -D : D)))
+            return 0;
+        if (b[2] > amax) return 0;
+        const double r = b[0] / scale;
+        rmax1 = r > rmax1 ? r : rmax1;
+        sum += b[2];
+        mx = b[2] > mx ? b[2] : mx;
+    }
+    if (!(rmax1 <= eps)) return 0;                       // needs another iteration
+    *nsup_sum = (int32_t)sum;
+    *nsup_max = (int32_t)mx;
+    return 1;
+}
+
 extern "C" revs_plan_t *revs_plan_create(const revs_plan_desc_t *desc) {
     if (!desc || !desc->stats || !desc->stats_host || !desc->pnq || desc->T <= 0 || desc->m <= 0) {
         revs::set_error("revs_plan_create: bad descriptor");

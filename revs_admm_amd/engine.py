@@ -88,6 +88,7 @@ class OperatorOptions:
     solver: str = "newton"
     newton_max: int = 60         # Newton iterations per operator solve
     newton_kadd: int = 6         # violated rows admitted to a slot's model per iteration
+    chain: bool = True           # binding steady state: one Newton iteration enqueued unread
     newton_delta: float = 1e-10  # relative diagonal shift of the model Hessian
     newton_pivots: int = 300     # block-pivoting limit per model problem
     newton_ls: int = 30          # Armijo halvings
@@ -238,6 +239,8 @@ class AdmmEngine:
         self.c_val = [torch.zeros(T, 3, A, **f64) for _ in range(2)]
         self.yhat = torch.zeros(T, A, **f64)
         self._y_support = False
+        self._chain_ok, self._chain_few, self._pre_kept = False, False, False
+        self.chain_hist = [0, 0]                       # chained Newton iterations kept / redone
         self._spec_ok = False
         self._spec_wait, self._spec_back = 0, 1
         self._sup = None
@@ -772,10 +775,15 @@ class AdmmEngine:
         self._dual_launch(y, use_y, k, sup=sup)
         return self._dual_wait(k)
 
-    def _operator_solve_newton(self, first=None):
+    def _operator_solve_newton(self, first=None, pre=None):
         """Utility.solve through the dual (see csrc/newton_kernels.hip).  True when
         P_est_new holds the answer to tolerance; False hands the iteration to ADMM.
-        `first`: stats of an evaluation of the current multipliers already made (buffer 0)."""
+        `first`: stats of an evaluation of the current multipliers already made (buffer 0).
+        `pre`: stats of the evaluation (buffer 1) that `_chain_launch` enqueued behind `first`
+        without reading it -- small model on candidate set 0, a full step for the slots not
+        yet within tolerance -- i.e. the first line-search trial of the first Newton iteration
+        if that iteration turns out to be the one this loop would have run.  Sets
+        `_pre_kept`: the accepted state is exactly the one `pre` (or `first`) left behind."""
         o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
         A = _lib.DUAL_AMAX
         scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
@@ -787,6 +795,8 @@ class AdmmEngine:
                if first is None else first)
         evals, newton, pivots, ok_all = 1, 0, 0, False
         best, stall = np.inf, 0
+        last_small = False
+        from_pre = pre is not None       # P_est_new is what `pre` (== `first` if nothing moved) wrote
         while True:
             if (stt[:, 2] > A).any():
                 break                                    # more multipliers than a model holds
@@ -812,7 +822,15 @@ class AdmmEngine:
             # (candidates of a slot = its rows with a multiplier + the violated rows admitted)
             ncand = stt[:, 2] + np.minimum(stt[:, 3], np.minimum(o.newton_kadd, A - stt[:, 2]))
             self.model_calls[0 if ncand.max() <= 8 else 1] += 1
-            if ncand.max() <= 8:                 # the binding steady state: one small kernel
+            last_small = bool(ncand.max() <= 8)
+            few = stt[:, 2].max() + o.newton_kadd <= 48
+            # (the chain guessed how its trial's home pass gets d = R^T y / kappa -- row-wise or
+            # dense; another choice here would differ in the last bits: then redo the trial)
+            use_pre = (pre is not None and newton == 1 and last_small
+                       and bool(few) == self._chain_few)
+            if use_pre:
+                pass                             # (the chain ran this model on this set)
+            elif ncand.max() <= 8:               # the binding steady state: one small kernel
                 check(lib.revs_op_dual_model_small(M, T, ptr(self.R64), ptr(self.pnq[1]),
                                                    ptr(self.c_idx[cur]), ptr(self.c_cnt[cur]),
                                                    ptr(self.c_val[cur]), self.kappa, o.newton_delta,
@@ -829,16 +847,19 @@ class AdmmEngine:
             pending = rmax > o.eps
             alpha = pending.astype(np.float64)
             nxt = 1 - cur
-            for _ in range(o.newton_ls):
-                self.alpha_h.numpy()[:] = alpha      # read by the step kernel through its mapping
-                ytrial.copy_(ycur)
-                check(lib.revs_op_dual_step(T, ptr(self.c_idx[cur]), ptr(self.c_cnt[cur]),
-                                            ptr(self.c_val[cur]), ptr(self.yhat),
-                                            self.alpha_dev, ptr(ytrial),
-                                            self.stats_dev[nxt] + 32, st),
-                      "revs_op_dual_step")
-                few = stt[:, 2].max() + o.newton_kadd <= 48
-                stn = self._dual_evaluate(ytrial, True, nxt, sup=cur if few else None)
+            for ls in range(o.newton_ls):
+                if use_pre and ls == 0:
+                    stn = pre                    # that trial and its evaluation: already there
+                else:
+                    from_pre = False
+                    self.alpha_h.numpy()[:] = alpha  # read by the step kernel through its mapping
+                    ytrial.copy_(ycur)
+                    check(lib.revs_op_dual_step(T, ptr(self.c_idx[cur]), ptr(self.c_cnt[cur]),
+                                                ptr(self.c_val[cur]), ptr(self.yhat),
+                                                self.alpha_dev, ptr(ytrial),
+                                                self.stats_dev[nxt] + 32, st),
+                          "revs_op_dual_step")
+                    stn = self._dual_evaluate(ytrial, True, nxt, sup=cur if few else None)
                 evals += 1
                 okk = stn[:, 1] >= D + 1e-4 * stn[:, 4] - 1e-13 * np.abs(D)
                 pending &= ~okk
@@ -852,6 +873,11 @@ class AdmmEngine:
             cur, stt = nxt, stn
         self.yd = [ycur, ytrial]
         self.newton_hist.append((newton, evals, pivots))
+        self._pre_kept = bool(ok_all and from_pre and newton <= 1)
+        # a solve of exactly one Newton iteration on the small model tends to repeat: the next
+        # one is enqueued whole (_chain_launch)
+        self._chain_ok = bool(ok_all and newton == 1 and last_small and evals == 2)
+        self._chain_few = bool(few) if newton >= 1 else False
         # speculate on the next iteration after a solve that needed no Newton iteration -- but
         # after a discarded sweep only once 2, 4, ... 64 such solves have gone by (rows that
         # keep moving in and out of their limits would otherwise cost a wasted sweep each time)
@@ -869,6 +895,54 @@ class AdmmEngine:
         # the accepted evaluation's candidate set `cur` lists the rows with y != 0 first
         self._sup = cur if (self._y_support and stt[:, 2].max() + o.newton_kadd <= 48) else None
         self.op_iters_hist.append(evals)
+        self.op_path_hist.append("dual")
+        self.op_converged = True
+        return True
+
+    def _chain_launch(self):
+        """The binding steady state without the host in the loop: evaluation of the current
+        multipliers (set 0), small model, full step for the slots that evaluation leaves
+        pending (decided on the device, revs_op_dual_step_pending) and the evaluation of the
+        trial (set 1), all enqueued; nothing is read."""
+        o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
+        scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
+        ycur, ytrial = self.yd
+        self._dual_launch(ycur, self._y_support, 0, sup=self._sup)
+        check(lib.revs_op_dual_model_small(M, T, ptr(self.R64), ptr(self.pnq[1]), ptr(self.c_idx[0]),
+                                           ptr(self.c_cnt[0]), ptr(self.c_val[0]), self.kappa,
+                                           o.newton_delta, o.newton_pivots, ptr(self.k_full),
+                                           ptr(self.yhat), self.info_dev, st),
+              "revs_op_dual_model_small")
+        ytrial.copy_(ycur)
+        check(lib.revs_op_dual_step_pending(T, ptr(self.c_idx[0]), ptr(self.c_cnt[0]),
+                                            ptr(self.c_val[0]), ptr(self.yhat), self.stats_dev[0],
+                                            scale, o.eps, ptr(ytrial), self.stats_dev[1] + 32, st),
+              "revs_op_dual_step_pending")
+        self._dual_launch(ytrial, True, 1, sup=0 if self._chain_few else None)
+
+    def _chain_accept(self):
+        """Wait for the chain's two evaluations and, if they are the usual outcome -- one
+        Newton iteration on the small model, full step accepted, converged -- do the
+        bookkeeping _operator_solve_newton would do for it (revs_newton_chain_accept makes
+        the same checks in one native call).  False: nothing was changed."""
+        o = self.op
+        for ev in self.stats_ev:
+            if ev is not None:
+                ev.synchronize()
+        nsum, nmax = C.c_int32(), C.c_int32()
+        scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
+        if not self.lib.revs_newton_chain_accept(
+                self.T, self.stats_host[0].data_ptr(), self.stats_host[1].data_ptr(), scale, o.eps,
+                _lib.DUAL_AMAX, o.newton_kadd, int(self._chain_few), C.addressof(nsum),
+                C.addressof(nmax)):
+            return False
+        self.yd = [self.yd[1], self.yd[0]]
+        self.model_calls[0] += 1
+        self.newton_hist.append((1, 2, int(np.abs(self.info_h.numpy()).sum())))
+        self._pre_kept, self._chain_ok, self._spec_ok = True, True, False
+        self._y_support = nsum.value > 0
+        self._sup = 1 if (self._y_support and nmax.value + o.newton_kadd <= 48) else None
+        self.op_iters_hist.append(2)
         self.op_path_hist.append("dual")
         self.op_converged = True
         return True
@@ -1058,6 +1132,30 @@ class AdmmEngine:
                 if stt is not None:
                     stt = self._dual_complete(self.yd[0], self._y_support, 0)
                 if not self._operator_solve_newton(first=stt):
+                    self._fast_cold = True
+                    self.op_cold = True
+                    self.operator_solve(admm_only=True)
+                self.agent_step(write_sc)
+        elif o.solver == "newton" and o.chain and self._chain_ok:
+            # binding steady state: the last solve was one Newton iteration on the small model;
+            # enqueue the same again, and the sweep behind it, before reading anything
+            self._fused_ready = False
+            self._chain_launch()
+            rec(1)
+            self.agent_step(write_sc, to_alt=True)
+            rec(2)
+            if self._chain_accept():             # the usual outcome, judged natively
+                ok = True
+            else:
+                stt0, stn = self._dual_wait(0), self._dual_wait(1)
+                ok = self._operator_solve_newton(first=stt0, pre=stn)
+            if ok and self._pre_kept:
+                self.P_sch, self.P_sch_alt = self.P_sch_alt, self.P_sch
+                self.G, self.G_alt = self.G_alt, self.G
+                self.chain_hist[0] += 1
+            else:
+                self.chain_hist[1] += 1
+                if not ok:
                     self._fast_cold = True
                     self.op_cold = True
                     self.operator_solve(admm_only=True)

@@ -446,6 +446,28 @@ class FakeKernels:
             C.c_double.from_address(int(lin_out) + 8 * 8 * t).value = lin
         return 0
 
+    def revs_op_dual_step_pending(self, T, cidx, ccnt, cval, yhat, stats_prev, scale, eps, ytrial,
+                                  lin_out, stream):
+        st = view(stats_prev, (T, 8), np.float64)
+        al = (st[:, 0] / scale > eps).astype(np.float64)
+        return self.revs_op_dual_step(T, cidx, ccnt, cval, yhat, al.ctypes.data, ytrial, lin_out, stream)
+
+    def revs_newton_chain_accept(self, T, s0, s1, scale, eps, amax, kadd, chain_few, nsup_sum, nsup_max):
+        a, b = view(s0, (T, 8), np.float64), view(s1, (T, 8), np.float64)
+        r0, r1 = a[:, 0] / scale, b[:, 0] / scale
+        if (a[:, 2] > amax).any() or ((a[:, 2] >= amax) & (a[:, 3] > 0) & (r0 > eps)).any():
+            return 0
+        ncand = a[:, 2] + np.minimum(a[:, 3], np.minimum(kadd, amax - a[:, 2]))
+        if not r0.max() > eps or ncand.max() > 8 or (a[:, 2].max() + kadd <= 48) != bool(chain_few):
+            return 0
+        pend = r0 > eps
+        okk = b[:, 1] >= a[:, 1] + 1e-4 * b[:, 4] - 1e-13 * np.abs(a[:, 1])
+        if (pend & ~okk).any() or (b[:, 2] > amax).any() or not r1.max() <= eps:
+            return 0
+        C.c_int32.from_address(int(nsup_sum)).value = int(b[:, 2].sum())
+        C.c_int32.from_address(int(nsup_max)).value = int(b[:, 2].max())
+        return 1
+
     def revs_voltage_f32(self, m, T, Rt, P, V, stream):
         view(V, (m, T), np.float32)[:] = view(Rt, (m, m), np.float32).T @ view(P, (m, T), np.float32)
         return 0

@@ -497,6 +497,34 @@ def test_native_step_and_fused_home_pass_change_nothing(gpu_lib, mode, T, monkey
         np.testing.assert_array_equal(r[2], ref[2])
 
 
+@pytest.mark.parametrize("mode,stress", [("binary", 1.0), ("relaxed_exact", 1.3), ("pdhg", 1.3)])
+def test_chained_newton_iteration_changes_nothing(gpu_lib, mode, stress):
+    """The binding steady state enqueued whole (evaluation, small model, step decided on the
+    device, evaluation, sweep: engine._chain_launch) against the driver that reads every
+    evaluation before going on: same schedules and multipliers, bit for bit.  (PDHG homes: to
+    1e-5 -- a sweep that is redone starts from the multipliers the discarded one left, another
+    warm start of the same home problems.)"""
+    from helpers import f32
+    from revs_admm_amd.engine import OperatorOptions
+    from revs_admm_amd.synthetic import make_workload
+    w = make_workload(6000, 24, n_nodes=150, seed=5, binary_feasible=(mode == "binary"), stress=stress)
+    w.load, w.cost = f32(w.load), f32(w.cost)
+    runs = []
+    for chain in (True, False):
+        e = _engine(w, mode, op=OperatorOptions(chain=chain))
+        d = e.run(60)
+        runs.append((d, e.result(), e.yd[0].cpu().numpy(), e))
+    (d1, r1, y1, e1), (d0, r0, y0, e0) = runs
+    assert e1.chain_hist[0] > 5 and e0.chain_hist == [0, 0], (e1.chain_hist, e1.newton_hist[-20:])
+    if mode == "pdhg":
+        assert np.abs(d1 - d0).max() < 1e-5 and max(np.abs(a - b).max() for a, b in zip(r1, r0)) < 1e-4
+        return
+    np.testing.assert_array_equal(d1, d0)
+    for a, b in zip(r1, r0):
+        np.testing.assert_array_equal(a, b)
+    np.testing.assert_array_equal(y1, y0)
+
+
 @pytest.mark.parametrize("n,M,T", [(1, 1, 24), (5, 2, 24), (9, 9, 7), (40, 3, 33)])
 def test_tiny_runs_match_oracle(gpu_lib, n, M, T):
     """Degenerate sizes through the whole engine (one residence, fewer residences than a

@@ -204,6 +204,31 @@ def test_speculative_sweep_on_fake_kernels():
     assert [h[0] for h in e1.newton_hist] == [h[0] for h in e0.newton_hist]
 
 
+@pytest.mark.parametrize("mode,stress", [("binary", 1.1), ("relaxed_exact", 1.3)])
+def test_chained_newton_iteration_on_fake_kernels(mode, stress):
+    """Binding steady state: after a solve of exactly one Newton iteration on the small model,
+    step() enqueues evaluation, model, step, evaluation and the sweep before reading anything
+    (_chain_launch).  Kept or redone, the trajectory is the unchained driver's, bit for bit."""
+    from fake_kernels import FakeKernels
+    from helpers import f32
+    from revs_admm_amd.engine import AdmmEngine, OperatorOptions
+    from revs_admm_amd.synthetic import make_workload
+    w = make_workload(150, 12, n_nodes=20, seed=2, stress=stress, binary_feasible=(mode == "binary"))
+    w.load, w.cost = f32(w.load), f32(w.cost)
+    runs = []
+    for chain in (True, False):
+        e = AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, kappa=w.kappa, vset=w.vset,
+                       vlow=w.vlow, vhigh=w.vhigh, mode=mode, device="cpu",
+                       _kernels=FakeKernels(), op=OperatorOptions(chain=chain))
+        runs.append((e.run(30), e.result(), e))
+    (d1, r1, e1), (d0, r0, e0) = runs
+    assert min(e1.chain_hist) > 0 and e0.chain_hist == [0, 0], (e1.chain_hist, e1.newton_hist)
+    np.testing.assert_array_equal(d1, d0)
+    for a, b in zip(r1, r0):
+        np.testing.assert_array_equal(a, b)
+    assert [h[0] for h in e1.newton_hist] == [h[0] for h in e0.newton_hist]
+
+
 @pytest.mark.parametrize("stress,paths", [(0.9, {"node"}), (2.0, {"node", "home"})])
 def test_operator_paths_on_fake_kernels(stress, paths):
     """Driver logic of the two ADMM operator paths (OperatorOptions.solver = "admm"): the node-space fast path is kept while no
