@@ -476,10 +476,12 @@ int revs_op_dual_step(int32_t T, const int64_t *cand_idx, const int32_t *cand_cn
  * model was built on: alpha_t = 1 if stats_prev[8 t] / scale > eps (rows of slot t not yet
  * within tolerance), else 0 -- what a driver that had read those stats would pass.  Lets a
  * driver enqueue evaluation, model, step and the next evaluation without reading anything in
- * between (engine.py: the binding steady state). */
+ * between (engine.py: the binding steady state).  y (double[m][T]) != NULL: y_trial = y is
+ * copied by the same launch before the candidates are written (else the caller has done so). */
 int revs_op_dual_step_pending(int32_t T, const int64_t *cand_idx, const int32_t *cand_cnt,
                               const double *cand_val, const double *yhat,
                               const double *stats_prev, double scale, double eps,
+                              const double *y, int32_t m,
                               double *y_trial, double *lin_out, void *stream);
 /* Host only (no GPU work): the acceptance test of such a chained iteration on the two stats
  * blocks (double[T][8], as revs_op_dual_select writes them; s1[8 t + 4] = the step kernel's

@@ -600,9 +600,13 @@ __global__ __launch_bounds__(64) void op_dual_step_kernel(
         const double *__restrict__ cval, const double *__restrict__ yhat,
         const double *__restrict__ alpha, double *__restrict__ ytrial,
         double *__restrict__ lin_out, const double *__restrict__ stats_prev, double scale,
-        double eps) {
+        double eps, const double *__restrict__ ycopy, int m) {
     const int t = blockIdx.x;
     const int a = ccnt[t];
+    if (ycopy) {                            // y_trial[., t] = y[., t] first (this slot's column only)
+        for (int r = threadIdx.x; r < m; r += 64) ytrial[(int64_t)r * T + t] = ycopy[(int64_t)r * T + t];
+        __syncthreads();
+    }
     // (stats_prev: full step for the slots whose rows are not yet within tolerance, decided
     // here exactly as the host would: the caller has not read those stats yet)
     const double al = stats_prev ? (stats_prev[t * 8] / scale > eps ? 1.0 : 0.0) : alpha[t];
@@ -755,7 +759,7 @@ extern "C" int revs_op_dual_step(int32_t T, const int64_t *cand_idx, const int32
     REVS_REQUIRE(T > 0 && cand_idx && cand_cnt && cand_val && yhat && alpha && y_trial && lin_out,
                  "revs_op_dual_step: bad argument");
     hipLaunchKernelGGL(op_dual_step_kernel, dim3(T), dim3(64), 0, S_(stream), T, cand_idx,
-                       cand_cnt, cand_val, yhat, alpha, y_trial, lin_out, nullptr, 1.0, 0.0);
+                       cand_cnt, cand_val, yhat, alpha, y_trial, lin_out, nullptr, 1.0, 0.0, nullptr, 0);
     REVS_CHECK_LAUNCH("revs_op_dual_step");
     return REVS_OK;
 }
@@ -763,11 +767,14 @@ extern "C" int revs_op_dual_step(int32_t T, const int64_t *cand_idx, const int32
 extern "C" int revs_op_dual_step_pending(int32_t T, const int64_t *cand_idx, const int32_t *cand_cnt,
                                          const double *cand_val, const double *yhat,
                                          const double *stats_prev, double scale, double eps,
-                                         double *y_trial, double *lin_out, void *stream) {
+                                         const double *y, int32_t m, double *y_trial,
+                                         double *lin_out, void *stream) {
     REVS_REQUIRE(T > 0 && cand_idx && cand_cnt && cand_val && yhat && stats_prev && y_trial &&
-                 lin_out && scale > 0.0, "revs_op_dual_step_pending: bad argument");
+                 lin_out && scale > 0.0 && (!y || m > 0) && y != y_trial,
+                 "revs_op_dual_step_pending: bad argument");
     hipLaunchKernelGGL(op_dual_step_kernel, dim3(T), dim3(64), 0, S_(stream), T, cand_idx,
-                       cand_cnt, cand_val, yhat, nullptr, y_trial, lin_out, stats_prev, scale, eps);
+                       cand_cnt, cand_val, yhat, nullptr, y_trial, lin_out, stats_prev, scale, eps,
+                       y, m);
     REVS_CHECK_LAUNCH("revs_op_dual_step_pending");
     return REVS_OK;
 }

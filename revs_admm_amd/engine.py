@@ -240,6 +240,7 @@ class AdmmEngine:
         self.yhat = torch.zeros(T, A, **f64)
         self._y_support = False
         self._chain_ok, self._chain_few, self._pre_kept = False, False, False
+        self._chain_seq = 0.0                          # tags of the chain's evaluations: -1, -2, ...
         self.chain_hist = [0, 0]                       # chained Newton iterations kept / redone
         self._spec_ok = False
         self._spec_wait, self._spec_back = 0, 1
@@ -732,7 +733,7 @@ class AdmmEngine:
             ptr(self.R64), ptr(self.c_idx[sup]), ptr(self.c_cnt[sup]), ptr(y), self.kappa,
             ptr(self.pnq), ptr(self.P_est_new), self.stream), "revs_op_dual_eval_rows")
 
-    def _dual_launch(self, y, use_y: bool, k: int, full: bool = True, sup=None):
+    def _dual_launch(self, y, use_y: bool, k: int, full: bool = True, sup=None, record=True):
         """Enqueue one evaluation: p, N, D and the voltage rows for the multipliers y;
         candidate lists and stats into buffer set k, stats on their way to pinned host
         memory.  Also writes P_est_new = max(g0 - R^T y / kappa, 0).  Does not wait.
@@ -752,7 +753,7 @@ class AdmmEngine:
             self._dual_phase(1, y, use_y, k)
             self._allreduce(self.pnq if full else self.pnq[0])   # the only exchange
             self._dual_phase(2, y, use_y, k)
-        if self.stats_ev[k] is not None:
+        if record and self.stats_ev[k] is not None:
             self.stats_ev[k].record()
 
     def _dual_complete(self, y, use_y: bool, k: int):
@@ -899,26 +900,48 @@ class AdmmEngine:
         self.op_converged = True
         return True
 
-    def _chain_launch(self):
+    def _chain_launch(self, write_sc, rec):
         """The binding steady state without the host in the loop: evaluation of the current
         multipliers (set 0), small model, full step for the slots that evaluation leaves
-        pending (decided on the device, revs_op_dual_step_pending) and the evaluation of the
-        trial (set 1), all enqueued; nothing is read."""
+        pending (decided on the device, revs_op_dual_step_pending), the evaluation of the
+        trial (set 1) and the home sweep on its answer -- the trial's candidate selection
+        rides in the sweep's launch --, all enqueued; nothing is read."""
         o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
         scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
         ycur, ytrial = self.yd
-        self._dual_launch(ycur, self._y_support, 0, sup=self._sup)
+        # (no event records in the chain: each costs the stream ~6 us; the host polls the
+        # sequence tag the last selection writes)
+        self._dual_launch(ycur, self._y_support, 0, sup=self._sup, record=False)
         check(lib.revs_op_dual_model_small(M, T, ptr(self.R64), ptr(self.pnq[1]), ptr(self.c_idx[0]),
                                            ptr(self.c_cnt[0]), ptr(self.c_val[0]), self.kappa,
                                            o.newton_delta, o.newton_pivots, ptr(self.k_full),
                                            ptr(self.yhat), self.info_dev, st),
               "revs_op_dual_model_small")
-        ytrial.copy_(ycur)
         check(lib.revs_op_dual_step_pending(T, ptr(self.c_idx[0]), ptr(self.c_cnt[0]),
                                             ptr(self.c_val[0]), ptr(self.yhat), self.stats_dev[0],
-                                            scale, o.eps, ptr(ytrial), self.stats_dev[1] + 32, st),
+                                            scale, o.eps, ptr(ycur), M, ptr(ytrial),
+                                            self.stats_dev[1] + 32, st),
               "revs_op_dual_step_pending")
-        self._dual_launch(ytrial, True, 1, sup=0 if self._chain_few else None)
+        if self._chain_few:                       # d = R^T y / kappa from the rows of set 0
+            self._dual_home_pass_rows(ytrial, 0)
+        else:
+            self._dual_phase(1, ytrial, True, 1)
+        if self.group is not None:
+            self._allreduce(self.pnq)
+        self._dual_phase(2 | 4, ytrial, True, 1)  # product and rows; selection: in the sweep
+        rec(1)
+        self._chain_seq -= 1.0
+        nb = (M + 31) // 32
+        check(lib.revs_agent_step_select(
+            self.n, T, ptr(self.cost), ptr(self.homes), ptr(self.load), ptr(self.P_est),
+            ptr(self.P_est_new), ptr(self.P_sch), ptr(self.G), ptr(self.P_sch_alt), ptr(self.G_alt),
+            ptr(self.S) if write_sc else None, ptr(self.Csoc) if write_sc else None,
+            ptr(self.diff), ptr(self.dsq), ptr(self.status), ptr(self.pdhg_dual), self.kappa,
+            self.mode, C.byref(self.pdhg), M, ptr(self.d_part), ptr(ytrial), self.vlo, self.vhi,
+            o.newton_kadd, ptr(self.vfull), ptr(self.violw), ptr(self.c_idx[1]), ptr(self.c_cnt[1]),
+            ptr(self.c_val[1]), self.stats_dev[1], self._chain_seq, None, None, None,
+            nb if (T <= 32 and nb <= 256) else 0, st), "revs_agent_step_select")
+        rec(2)
 
     def _chain_accept(self):
         """Wait for the chain's two evaluations and, if they are the usual outcome -- one
@@ -926,9 +949,20 @@ class AdmmEngine:
         bookkeeping _operator_solve_newton would do for it (revs_newton_chain_accept makes
         the same checks in one native call).  False: nothing was changed."""
         o = self.op
-        for ev in self.stats_ev:
-            if ev is not None:
-                ev.synchronize()
+        if self.stats_ev[0] is not None:
+            # the trial's verdict is written early in the sweep's launch: poll its sequence tag
+            # (pinned memory) rather than wait for the sweep; stream order puts everything the
+            # chain wrote before it
+            tags = self.stats_host[1].numpy()[:, 5]
+            spins, t0 = 0, None
+            while not (tags == self._chain_seq).all():
+                spins += 1
+                if spins & 0xFFF == 0:
+                    import time
+                    t0 = t0 or time.monotonic()
+                    if time.monotonic() - t0 > 20.0:
+                        raise _lib.RevsError("chained Newton iteration: timed out waiting for "
+                                             "the evaluation's sequence tag")
         nsum, nmax = C.c_int32(), C.c_int32()
         scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
         if not self.lib.revs_newton_chain_accept(
@@ -1140,14 +1174,11 @@ class AdmmEngine:
             # binding steady state: the last solve was one Newton iteration on the small model;
             # enqueue the same again, and the sweep behind it, before reading anything
             self._fused_ready = False
-            self._chain_launch()
-            rec(1)
-            self.agent_step(write_sc, to_alt=True)
-            rec(2)
+            self._chain_launch(write_sc, rec)
             if self._chain_accept():             # the usual outcome, judged natively
                 ok = True
-            else:
-                stt0, stn = self._dual_wait(0), self._dual_wait(1)
+            else:                                # (the tag was seen: both blocks are complete)
+                stt0, stn = (self.stats_host[0].numpy().copy(), self.stats_host[1].numpy().copy())
                 ok = self._operator_solve_newton(first=stt0, pre=stn)
             if ok and self._pre_kept:
                 self.P_sch, self.P_sch_alt = self.P_sch_alt, self.P_sch

@@ -58,6 +58,19 @@ class FakeKernels:
         view(dsq, (n,), np.float32)[:] = (dg ** 2).sum(axis=1)
         return 0
 
+    def revs_agent_step_select(self, n, T, cost, homes, load, pe_old, pe_new, ps, gm, ps_out, gm_out,
+                               s_out, c_out, diff, dsq, status, pdhg_dual, kappa, mode, pdhg, m,
+                               sel_partial, y, vlo, vhi, kadd, vfull, viol, cidx, ccnt, cval, stats,
+                               seq, node_of, p_next, pe_next, sel_nblk, stream):
+        """The sweep; the selection itself was done by revs_op_dual_evaluate here (this double
+        ignores phase bit 4), so only its sequence tag is left to write."""
+        assert not p_next and not pe_next, "fused home pass: GPU only"
+        rc = self.revs_agent_step_out(n, T, cost, homes, load, pe_old, pe_new, ps, gm, ps_out, gm_out,
+                                      s_out, c_out, diff, dsq, status, pdhg_dual, kappa, mode, pdhg,
+                                      stream)
+        view(stats, (T, 8), np.float64)[:, 5] = seq
+        return rc
+
     def revs_residual_finalize(self, diff, dsq, n, T, kappa, eps, scratch, out, stream):
         d = view(diff, (n,), np.float32).astype(float)
         q = view(dsq, (n,), np.float32).astype(float)
@@ -446,8 +459,10 @@ class FakeKernels:
             C.c_double.from_address(int(lin_out) + 8 * 8 * t).value = lin
         return 0
 
-    def revs_op_dual_step_pending(self, T, cidx, ccnt, cval, yhat, stats_prev, scale, eps, ytrial,
-                                  lin_out, stream):
+    def revs_op_dual_step_pending(self, T, cidx, ccnt, cval, yhat, stats_prev, scale, eps, y, m,
+                                  ytrial, lin_out, stream):
+        if y:
+            view(ytrial, (m, T), np.float64)[:] = view(y, (m, T), np.float64)
         st = view(stats_prev, (T, 8), np.float64)
         al = (st[:, 0] / scale > eps).astype(np.float64)
         return self.revs_op_dual_step(T, cidx, ccnt, cval, yhat, al.ctypes.data, ytrial, lin_out, stream)
