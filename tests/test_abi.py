@@ -83,3 +83,48 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_chain_accept_host_logic_matches_the_numpy_double(lib):
+    """revs_newton_chain_accept is host code (no GPU): every branch against the restatement
+    in tests/fake_kernels.py on random stats blocks built around the accepted pattern."""
+    import ctypes as C
+    import numpy as np
+    from fake_kernels import FakeKernels
+    fake = FakeKernels()
+    rng = np.random.default_rng(0)
+    T, scale, eps, A, kadd = 24, 0.04, 1e-8, 128, 6
+    seen = set()
+    for trial in range(400):
+        s0, s1 = np.zeros((T, 8)), np.zeros((T, 8))
+        s0[:, 0] = rng.choice([0.0, 1e-12, 1e-5], T) * scale          # rows: within eps or not
+        s0[:, 1] = rng.normal(0, 10, T)
+        s0[:, 2] = rng.integers(0, 4, T)
+        s0[:, 3] = rng.integers(0, 5, T)
+        s1[:, 0] = rng.choice([0.0, 1e-12], T) * scale
+        s1[:, 4] = np.abs(rng.normal(0, 1e-3, T))
+        s1[:, 1] = s0[:, 1] + 2e-4 * s1[:, 4]                          # Armijo passed ...
+        s1[:, 2] = rng.integers(0, 6, T)
+        kind = trial % 8
+        if kind == 1:
+            s1[rng.integers(T), 1] -= 1.0                              # ... or not
+        elif kind == 2:
+            s1[rng.integers(T), 0] = 1e-3 * scale                      # not converged after
+        elif kind == 3:
+            s0[rng.integers(T), 2] = 7                                 # more than 8 candidates
+        elif kind == 4:
+            s0[:, 0] = 0.0                                             # converged before
+        elif kind == 5:
+            s0[rng.integers(T), 2] = A + 1
+        elif kind == 6:
+            s0[rng.integers(T), 2] = 45                                # dense home pass expected
+        few = int(rng.integers(0, 2)) if kind == 7 else 1
+        outs = []
+        for impl in (lib, fake):
+            a, b = C.c_int32(-1), C.c_int32(-1)
+            rc = impl.revs_newton_chain_accept(T, s0.ctypes.data, s1.ctypes.data, scale, eps, A, kadd,
+                                               few, C.addressof(a), C.addressof(b))
+            outs.append((rc, a.value, b.value) if rc else (0,))
+        assert outs[0] == outs[1], (trial, outs)
+        seen.add(outs[0][0])
+    assert seen == {0, 1}
