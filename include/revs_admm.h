@@ -483,6 +483,20 @@ int revs_op_dual_step_pending(int32_t T, const int64_t *cand_idx, const int32_t 
                               const double *stats_prev, double scale, double eps,
                               const double *y, int32_t m,
                               double *y_trial, double *lin_out, void *stream);
+/* The selection of revs_op_dual_select (after revs_op_dual_rows / _product_rows; arguments as
+ * revs_agent_step_select's), revs_op_dual_model_small on the lists it builds and
+ * revs_op_dual_step_pending (y_trial = y, then the full step in the slots whose rows this
+ * selection finds beyond eps; lin_out as there) in ONE launch, one workgroup per slot.  A
+ * slot with more than 8 candidates gets info = -999 (and an unchanged y_trial column), as
+ * from revs_op_dual_model_small: the caller then runs the general model. */
+int revs_op_dual_select_model_step(int32_t m, int32_t T, const double *sel_partial, int32_t sel_nblk,
+                                   const double *y, double vlo, double vhi, int32_t kadd,
+                                   const double *vfull, const double *viol, int64_t *cand_idx,
+                                   int32_t *cand_cnt, double *cand_val, double *stats, double seq,
+                                   const double *R, const double *n_free, double kappa, double delta,
+                                   int32_t max_pivots, double *k_full, double *yhat, int32_t *info,
+                                   double scale, double eps, double *y_trial, double *lin_out,
+                                   void *stream);
 /* Host only (no GPU work): the acceptance test of such a chained iteration on the two stats
  * blocks (double[T][8], as revs_op_dual_select writes them; s1[8 t + 4] = the step kernel's
  * linear term) -- returns 1 iff the driver's own checks (engine.py:

@@ -118,6 +118,9 @@ SIGNATURES = {
     "revs_op_dual_model_small": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p, _f64, _f64, _i32, _p, _p,
                                            _p, _p]),
     "revs_op_dual_step": (C.c_int, [_i32, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "revs_op_dual_select_model_step": (C.c_int, [_i32, _i32, _p, _i32, _p, _f64, _f64, _i32, _p, _p, _p,
+                                                _p, _p, _p, _f64, _p, _p, _f64, _f64, _i32, _p, _p, _p,
+                                                _f64, _f64, _p, _p, _p]),
     "revs_newton_chain_accept": (C.c_int, [_i32, _p, _p, _f64, _f64, _i32, _i32, _i32, _p, _p]),
     "revs_op_dual_step_pending": (C.c_int, [_i32, _p, _p, _p, _p, _p, _f64, _f64, _p, _i32, _p, _p, _p]),
 }

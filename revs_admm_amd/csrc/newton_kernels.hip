@@ -525,12 +525,12 @@ __device__ __forceinline__ void small_bpp(const double (&Ks)[8][8], const double
 // columns (coalesced row reads), one thread then runs the same block principal pivoting
 // (same regularisation, tolerances and backup rule) on the 8 x 8 problem in LDS.
 constexpr int kSmall = 8;
-__global__ __launch_bounds__(256) void op_dual_model_small_kernel(
-        int m, int T, const double *__restrict__ R, const double *__restrict__ Nn,
+__device__ __forceinline__ void small_model_body(
+        const int t, int m, int T, const double *__restrict__ R, const double *__restrict__ Nn,
         const int64_t *__restrict__ cidx, const int32_t *__restrict__ ccnt,
         const double *__restrict__ cval, double inv_kappa, double delta, int max_pivots,
         double *__restrict__ Kall, double *__restrict__ yhat, int32_t *__restrict__ info) {
-    const int t = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const int a = ccnt[t];
     int64_t f[kSmall];                      // (entries beyond the count hold row 0: loadable)
 #pragma unroll
@@ -594,22 +594,29 @@ __global__ __launch_bounds__(256) void op_dual_model_small_kernel(
     }
 }
 
+__global__ __launch_bounds__(256) void op_dual_model_small_kernel(
+        int m, int T, const double *__restrict__ R, const double *__restrict__ Nn,
+        const int64_t *__restrict__ cidx, const int32_t *__restrict__ ccnt,
+        const double *__restrict__ cval, double inv_kappa, double delta, int max_pivots,
+        double *__restrict__ Kall, double *__restrict__ yhat, int32_t *__restrict__ info) {
+    small_model_body(blockIdx.x, m, T, R, Nn, cidx, ccnt, cval, inv_kappa, delta, max_pivots, Kall,
+                     yhat, info);
+}
+
 // y_trial[cand] = y + alpha_t (yhat - y); lin_out[8 t] = grad . (y_trial - y)
-__global__ __launch_bounds__(64) void op_dual_step_kernel(
-        int T, const int64_t *__restrict__ cidx, const int32_t *__restrict__ ccnt,
-        const double *__restrict__ cval, const double *__restrict__ yhat,
-        const double *__restrict__ alpha, double *__restrict__ ytrial,
-        double *__restrict__ lin_out, const double *__restrict__ stats_prev, double scale,
-        double eps, const double *__restrict__ ycopy, int m) {
-    const int t = blockIdx.x;
+// (first wavefront of the workgroup only past the copy; NT = the workgroup's threads)
+template <int NT>
+__device__ __forceinline__ void dual_step_body(
+        const int t, int T, const int64_t *__restrict__ cidx, const int32_t *__restrict__ ccnt,
+        const double *__restrict__ cval, const double *__restrict__ yhat, const double al,
+        double *__restrict__ ytrial, double *__restrict__ lin_out,
+        const double *__restrict__ ycopy, int m) {
     const int a = ccnt[t];
     if (ycopy) {                            // y_trial[., t] = y[., t] first (this slot's column only)
-        for (int r = threadIdx.x; r < m; r += 64) ytrial[(int64_t)r * T + t] = ycopy[(int64_t)r * T + t];
+        for (int r = threadIdx.x; r < m; r += NT) ytrial[(int64_t)r * T + t] = ycopy[(int64_t)r * T + t];
         __syncthreads();
     }
-    // (stats_prev: full step for the slots whose rows are not yet within tolerance, decided
-    // here exactly as the host would: the caller has not read those stats yet)
-    const double al = stats_prev ? (stats_prev[t * 8] / scale > eps ? 1.0 : 0.0) : alpha[t];
+    if (threadIdx.x >= 64) return;
     const double *cs = cval + (int64_t)t * 3 * kAmax, *cg = cs + kAmax, *cy = cg + kAmax;
     double lin = 0.0;
     for (int i = threadIdx.x; i < a; i += 64) {
@@ -621,6 +628,42 @@ __global__ __launch_bounds__(64) void op_dual_step_kernel(
     }
     lin = wave_sum_d(lin);
     if (threadIdx.x == 0) lin_out[t * 8] = lin;
+}
+
+__global__ __launch_bounds__(64) void op_dual_step_kernel(
+        int T, const int64_t *__restrict__ cidx, const int32_t *__restrict__ ccnt,
+        const double *__restrict__ cval, const double *__restrict__ yhat,
+        const double *__restrict__ alpha, double *__restrict__ ytrial,
+        double *__restrict__ lin_out, const double *__restrict__ stats_prev, double scale,
+        double eps, const double *__restrict__ ycopy, int m) {
+    const int t = blockIdx.x;
+    // (stats_prev: full step for the slots whose rows are not yet within tolerance, decided
+    // here exactly as the host would: the caller has not read those stats yet)
+    const double al = stats_prev ? (stats_prev[t * 8] / scale > eps ? 1.0 : 0.0) : alpha[t];
+    dual_step_body<64>(t, T, cidx, ccnt, cval, yhat, al, ytrial, lin_out, ycopy, m);
+}
+
+// Selection, small model and full/zero step of one slot in ONE workgroup (the chained Newton
+// iteration of the binding steady state: three launches and two reloads of the candidate
+// lists less).  A slot with more than 8 candidates gets info = -999 from the model part, as
+// from op_dual_model_small_kernel, and the caller falls back.
+struct FusedArgs {
+    const double *R, *Nn, *ycopy;
+    double inv_kappa, delta, scale, eps;
+    int max_pivots;
+    double *Kall, *yhat, *ytrial, *lin_out;
+    int32_t *info;
+};
+__global__ __launch_bounds__(256) void op_dual_select_model_step_kernel(const SelectArgs sa,
+                                                                        const FusedArgs fa) {
+    const int t = blockIdx.x;
+    const double rmax = dual_select_body<true>(sa, t);
+    __syncthreads();                        // this workgroup's lists, written to global memory
+    small_model_body(t, sa.m, sa.T, fa.R, fa.Nn, sa.cidx, sa.ccnt, sa.cval, fa.inv_kappa, fa.delta,
+                     fa.max_pivots, fa.Kall, fa.yhat, fa.info);
+    __syncthreads();                        // yhat (thread 0)
+    dual_step_body<256>(t, sa.T, sa.cidx, sa.ccnt, sa.cval, fa.yhat,
+                        rmax / fa.scale > fa.eps ? 1.0 : 0.0, fa.ytrial, fa.lin_out, fa.ycopy, sa.m);
 }
 
 }  // namespace revs
@@ -750,6 +793,27 @@ extern "C" int revs_op_dual_model_small(int32_t m, int32_t T, const double *R, c
     hipLaunchKernelGGL(op_dual_model_small_kernel, dim3(T), dim3(256), 0, S_(stream), m, T, R, n_free,
                        cand_idx, cand_cnt, cand_val, 1.0 / kappa, delta, max_pivots, k_full, yhat, info);
     REVS_CHECK_LAUNCH("revs_op_dual_model_small");
+    return REVS_OK;
+}
+
+extern "C" int revs_op_dual_select_model_step(
+        int32_t m, int32_t T, const double *sel_partial, int32_t sel_nblk, const double *y, double vlo,
+        double vhi, int32_t kadd, const double *vfull, const double *viol, int64_t *cand_idx,
+        int32_t *cand_cnt, double *cand_val, double *stats, double seq, const double *R,
+        const double *n_free, double kappa, double delta, int32_t max_pivots, double *k_full,
+        double *yhat, int32_t *info, double scale, double eps, double *y_trial, double *lin_out,
+        void *stream) {
+    REVS_REQUIRE(m > 0 && m <= 16384 && T > 0 && sel_partial && y && vfull && viol && cand_idx &&
+                 cand_cnt && cand_val && stats && vlo <= vhi && kadd >= 0 && sel_nblk >= 0 &&
+                 sel_nblk <= 256 && R && n_free && k_full && yhat && info && kappa > 0 && delta >= 0 &&
+                 max_pivots > 0 && scale > 0.0 && y_trial && y_trial != y && lin_out,
+                 "revs_op_dual_select_model_step: bad argument");
+    const SelectArgs sa{m, T, sel_nblk ? sel_nblk : revs_op_dual_blocks(m), kadd, sel_partial, y, vfull,
+                        viol, vlo, vhi, seq, cand_idx, cand_cnt, cand_val, stats};
+    const FusedArgs fa{R, n_free, y, 1.0 / kappa, delta, scale, eps, max_pivots, k_full, yhat, y_trial,
+                       lin_out, info};
+    hipLaunchKernelGGL(op_dual_select_model_step_kernel, dim3(T), dim3(256), 0, S_(stream), sa, fa);
+    REVS_CHECK_LAUNCH("revs_op_dual_select_model_step");
     return REVS_OK;
 }
 

@@ -41,7 +41,7 @@ struct SelectArgs {
 // violations -- is issued at the top.  Not inside the sweep's launch: the registers would set
 // the sweep's occupancy, and a slot with nothing to do (its usual case there) needs none.
 template <bool EAGER = false>
-__device__ __forceinline__ void dual_select_body(const SelectArgs &sa, const int t) {
+__device__ __forceinline__ double dual_select_body(const SelectArgs &sa, const int t) {
     const int m = sa.m, T = sa.T, nblk = sa.nblk, kadd = sa.kadd;
     const double *__restrict__ partial = sa.partial, *__restrict__ y = sa.y;
     const double *__restrict__ vfull = sa.vfull, *__restrict__ viol = sa.viol;
@@ -87,8 +87,9 @@ __device__ __forceinline__ void dual_select_body(const SelectArgs &sa, const int
     __syncthreads();
     const int ns = (int)(((red_s[2][0] + red_s[2][1]) + red_s[2][2]) + red_s[2][3]);
     const int nv = (int)(((red_s[3][0] + red_s[3][1]) + red_s[3][2]) + red_s[3][3]);
+    const double rmax_t = fmax(fmax(red_s[0][0], red_s[0][1]), fmax(red_s[0][2], red_s[0][3]));
     if (tid == 0) {
-        stats[t * 8 + 0] = fmax(fmax(red_s[0][0], red_s[0][1]), fmax(red_s[0][2], red_s[0][3]));
+        stats[t * 8 + 0] = rmax_t;
         stats[t * 8 + 1] = ((red_s[1][0] + red_s[1][1]) + red_s[1][2]) + red_s[1][3];
         stats[t * 8 + 2] = (double)ns;
         stats[t * 8 + 3] = (double)nv;
@@ -102,7 +103,7 @@ __device__ __forceinline__ void dual_select_body(const SelectArgs &sa, const int
     if (ns > kAmax || (ns == 0 && nv == 0)) {   // uniform: too many multipliers / nothing to do
         if (tid == 0) ccnt[t] = ns > kAmax ? -1 : 0;
         if (tid < kAmax) { ci[tid] = 0; cs[tid] = 1.0; cg[tid] = 0.0; cy[tid] = 0.0; }
-        return;
+        return rmax_t;
     }
     int nsup = 0;
     if (eager) {
@@ -219,6 +220,7 @@ __device__ __forceinline__ void dual_select_body(const SelectArgs &sa, const int
     const int cnt = ns + added;
     if (tid == 0) ccnt[t] = cnt;
     if (tid >= cnt && tid < kAmax) { ci[tid] = 0; cs[tid] = 1.0; cg[tid] = 0.0; cy[tid] = 0.0; }
+    return rmax_t;
 }
 
 }  // namespace revs

@@ -911,17 +911,23 @@ class AdmmEngine:
         ycur, ytrial = self.yd
         # (no event records in the chain: each costs the stream ~6 us; the host polls the
         # sequence tag the last selection writes)
-        self._dual_launch(ycur, self._y_support, 0, sup=self._sup, record=False)
-        check(lib.revs_op_dual_model_small(M, T, ptr(self.R64), ptr(self.pnq[1]), ptr(self.c_idx[0]),
-                                           ptr(self.c_cnt[0]), ptr(self.c_val[0]), self.kappa,
-                                           o.newton_delta, o.newton_pivots, ptr(self.k_full),
-                                           ptr(self.yhat), self.info_dev, st),
-              "revs_op_dual_model_small")
-        check(lib.revs_op_dual_step_pending(T, ptr(self.c_idx[0]), ptr(self.c_cnt[0]),
-                                            ptr(self.c_val[0]), ptr(self.yhat), self.stats_dev[0],
-                                            scale, o.eps, ptr(ycur), M, ptr(ytrial),
-                                            self.stats_dev[1] + 32, st),
-              "revs_op_dual_step_pending")
+        nb = (M + 31) // 32
+        nb = nb if (T <= 32 and nb <= 256) else 0
+        use_y = self._y_support
+        if use_y and self._sup is not None:       # as _dual_launch, the selection left out
+            self._dual_home_pass_rows(ycur, self._sup)
+        else:
+            self._dual_phase(1, ycur, use_y, 0)
+        if self.group is not None:
+            self._allreduce(self.pnq)
+        self._dual_phase(2 | 4, ycur, use_y, 0)
+        # selection, small model and step of every slot in one launch
+        check(lib.revs_op_dual_select_model_step(
+            M, T, ptr(self.d_part), nb, ptr(ycur), self.vlo, self.vhi, o.newton_kadd,
+            ptr(self.vfull), ptr(self.violw), ptr(self.c_idx[0]), ptr(self.c_cnt[0]),
+            ptr(self.c_val[0]), self.stats_dev[0], 0.0, ptr(self.R64), ptr(self.pnq[1]), self.kappa,
+            o.newton_delta, o.newton_pivots, ptr(self.k_full), ptr(self.yhat), self.info_dev, scale,
+            o.eps, ptr(ytrial), self.stats_dev[1] + 32, st), "revs_op_dual_select_model_step")
         if self._chain_few:                       # d = R^T y / kappa from the rows of set 0
             self._dual_home_pass_rows(ytrial, 0)
         else:
@@ -931,7 +937,6 @@ class AdmmEngine:
         self._dual_phase(2 | 4, ytrial, True, 1)  # product and rows; selection: in the sweep
         rec(1)
         self._chain_seq -= 1.0
-        nb = (M + 31) // 32
         check(lib.revs_agent_step_select(
             self.n, T, ptr(self.cost), ptr(self.homes), ptr(self.load), ptr(self.P_est),
             ptr(self.P_est_new), ptr(self.P_sch), ptr(self.G), ptr(self.P_sch_alt), ptr(self.G_alt),
@@ -939,8 +944,8 @@ class AdmmEngine:
             ptr(self.diff), ptr(self.dsq), ptr(self.status), ptr(self.pdhg_dual), self.kappa,
             self.mode, C.byref(self.pdhg), M, ptr(self.d_part), ptr(ytrial), self.vlo, self.vhi,
             o.newton_kadd, ptr(self.vfull), ptr(self.violw), ptr(self.c_idx[1]), ptr(self.c_cnt[1]),
-            ptr(self.c_val[1]), self.stats_dev[1], self._chain_seq, None, None, None,
-            nb if (T <= 32 and nb <= 256) else 0, st), "revs_agent_step_select")
+            ptr(self.c_val[1]), self.stats_dev[1], self._chain_seq, None, None, None, nb, st),
+            "revs_agent_step_select")
         rec(2)
 
     def _chain_accept(self):

@@ -467,6 +467,17 @@ class FakeKernels:
         al = (st[:, 0] / scale > eps).astype(np.float64)
         return self.revs_op_dual_step(T, cidx, ccnt, cval, yhat, al.ctypes.data, ytrial, lin_out, stream)
 
+    def revs_op_dual_select_model_step(self, m, T, sel_partial, sel_nblk, y, vlo, vhi, kadd, vfull, viol,
+                                       cidx, ccnt, cval, stats, seq, R, n_free, kappa, delta,
+                                       max_pivots, k_full, yhat, info, scale, eps, ytrial, lin_out,
+                                       stream):
+        """(the selection was done by revs_op_dual_evaluate here: this double ignores phase bit 4)"""
+        view(stats, (T, 8), np.float64)[:, 5] = seq
+        self.revs_op_dual_model_small(m, T, R, n_free, cidx, ccnt, cval, kappa, delta, max_pivots,
+                                      k_full, yhat, info, stream)
+        return self.revs_op_dual_step_pending(T, cidx, ccnt, cval, yhat, stats, scale, eps, y, m,
+                                              ytrial, lin_out, stream)
+
     def revs_newton_chain_accept(self, T, s0, s1, scale, eps, amax, kadd, chain_few, nsup_sum, nsup_max):
         a, b = view(s0, (T, 8), np.float64), view(s1, (T, 8), np.float64)
         r0, r1 = a[:, 0] / scale, b[:, 0] / scale

@@ -315,6 +315,57 @@ def test_sweep_with_selection_and_next_home_pass(gpu_lib, mode):
     np.testing.assert_allclose(p_next.cpu().numpy(), pnq2[0].cpu().numpy(), rtol=1e-13, atol=1e-12)
 
 
+@pytest.mark.parametrize("n_mult,kadd", [(3, 4), (1, 6), (6, 6)])
+def test_selection_model_and_step_in_one_launch(gpu_lib, n_mult, kadd):
+    """revs_op_dual_select_model_step against revs_op_dual_select + revs_op_dual_model_small +
+    revs_op_dual_step_pending on the same rows: lists, stats, model answer, trial multipliers
+    and linear terms bit for bit; slots with more than 8 candidates (n_mult + kadd > 8) get
+    info = -999 and an unchanged column from both."""
+    import torch
+    from fake_kernels import FakeKernels
+    from revs_admm_amd._lib import check, ptr
+    n, M, T, ks = 2500, 260, 24, 3
+    node_of, ptr_, R, pe, ps, gm, y = _case(11 + n_mult, n, M, T, n_mult)
+    kappa, vlo, vhi = 5.0, -0.05, 0.06
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    gi, gb = _run_evaluate(gpu_lib, FakeKernels(), up, ptr, M, T, ptr_, pe, ps, gm, R, y, kappa, vlo, vhi,
+                           kadd, ks)                    # (rows + the reference selection, seq 7)
+    f64 = dict(dtype=torch.float64, device="cuda:0")
+    nfree = gb["pnq"][1].contiguous()
+    scale, eps = 0.06, 1e-8
+
+    def outs():
+        return dict(kfull=torch.zeros(T, A, A, **f64), yhat=torch.full((T, A), -3.0, **f64),
+                    info=torch.full((T,), 77, dtype=torch.int32, device="cuda:0"),
+                    ytr=torch.full((M, T), 9.0, **f64), lin=torch.zeros(T, 8, **f64))
+    a, b = outs(), outs()
+    check(gpu_lib.revs_op_dual_model_small(M, T, ptr(gi["R"]), ptr(nfree), ptr(gb["cidx"]), ptr(gb["ccnt"]),
+                                           ptr(gb["cval"]), kappa, 1e-10, 300, ptr(a["kfull"]),
+                                           ptr(a["yhat"]), ptr(a["info"]), None))
+    check(gpu_lib.revs_op_dual_step_pending(T, ptr(gb["cidx"]), ptr(gb["ccnt"]), ptr(gb["cval"]),
+                                            ptr(a["yhat"]), ptr(gb["stats"]), scale, eps, ptr(gi["y"]), M,
+                                            ptr(a["ytr"]), ptr(a["lin"]), None))
+    nblk = int(gpu_lib.revs_op_dual_blocks(M))
+    cidx = torch.full((T, A), -5, dtype=torch.int64, device="cuda:0")
+    ccnt = torch.full((T,), -5, dtype=torch.int32, device="cuda:0")
+    cval, st = torch.full((T, 3, A), -5.0, **f64), torch.zeros(T, 8, **f64)
+    check(gpu_lib.revs_op_dual_select_model_step(
+        M, T, ptr(gb["part"]), nblk, ptr(gi["y"]), vlo, vhi, kadd, ptr(gb["vfull"]), ptr(gb["viol"]),
+        ptr(cidx), ptr(ccnt), ptr(cval), ptr(st), 7.0, ptr(gi["R"]), ptr(nfree), kappa, 1e-10, 300,
+        ptr(b["kfull"]), ptr(b["yhat"]), ptr(b["info"]), scale, eps, ptr(b["ytr"]), ptr(b["lin"]), None))
+    torch.cuda.synchronize()
+    assert torch.equal(cidx, gb["cidx"]) and torch.equal(ccnt, gb["ccnt"]) and torch.equal(cval, gb["cval"])
+    assert torch.equal(st[:, [0, 1, 2, 3, 5]], gb["stats"][:, [0, 1, 2, 3, 5]])
+    for k in ("yhat", "info", "ytr", "lin"):
+        assert torch.equal(a[k], b[k]), k
+    big = (ccnt > 8).cpu().numpy()
+    assert big.any() == (n_mult + kadd > 8)
+    assert (b["info"].cpu().numpy()[big] == -999).all() and (b["info"].cpu().numpy()[~big] != -999).all()
+    yt, y0 = b["ytr"].cpu().numpy(), gi["y"].cpu().numpy()
+    np.testing.assert_array_equal(yt[:, big], y0[:, big])
+    assert big.all() or (yt[:, ~big] != y0[:, ~big]).any()
+
+
 @pytest.mark.parametrize("a", [1, 2, 5, 8, 31, 63, 64, 65, 100, 127, 128])
 def test_model_problem_sizes(gpu_lib, a):
     """revs_op_dual_model at every interesting candidate count (one row, the 64/65 boundary of
