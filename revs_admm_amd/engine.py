@@ -902,10 +902,11 @@ class AdmmEngine:
 
     def _chain_launch(self, write_sc, rec):
         """The binding steady state without the host in the loop: evaluation of the current
-        multipliers (set 0), small model, full step for the slots that evaluation leaves
-        pending (decided on the device, revs_op_dual_step_pending), the evaluation of the
-        trial (set 1) and the home sweep on its answer -- the trial's candidate selection
-        rides in the sweep's launch --, all enqueued; nothing is read."""
+        multipliers (set 0) with its selection, the small model and the step in one launch
+        (full step for the slots that evaluation leaves pending, decided on the device:
+        revs_op_dual_select_model_step), the evaluation of the trial (set 1) and the home
+        sweep on its answer -- the trial's candidate selection rides in the sweep's launch --,
+        all enqueued; nothing is read."""
         o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
         scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
         ycur, ytrial = self.yd
