@@ -62,7 +62,7 @@ def _prep(n, T, seed, **kw):
     return w, oracle_homes(w)
 
 
-@pytest.mark.parametrize("T", [24, 96, 7, 33, 130])
+@pytest.mark.parametrize("T", [24, 96, 7, 33, 130, 192, 2])
 @pytest.mark.parametrize("zero_state", [True, False])
 def test_binary_matches_oracle(gpu_lib, T, zero_state):
     """Binary charger = the reference MIQP.  Bit-exact schedule wherever the oracle's
@@ -77,7 +77,7 @@ def test_binary_matches_oracle(gpu_lib, T, zero_state):
     r = _run_agent(gpu_lib, w, pe_old, pe_new, ps, gm, "binary")
     p, s, g, st = ro.home_solve_binary(w.cost, oh, pe_old, ps, gm, w.kappa)
     assert ((r["status"] & 0xFF) == st).all()          # same homes flagged infeasible
-    assert (st == 0).mean() > 0.9
+    assert (st == 0).mean() > (0.9 if T > 4 else 0.3)     # (T = 2: few windows can reach 90 %)
     # the schedule is a set of slots: compare objective (ties / near-ties may pick
     # another slot of equal cost) and exact equality where the choice is unique
     obj_gpu = ro.home_objective(w.cost, oh, r["S"], pe_old, ps, gm, w.kappa)
@@ -100,7 +100,7 @@ def test_binary_matches_oracle(gpu_lib, T, zero_state):
                                rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("T", [24, 96, 50])
+@pytest.mark.parametrize("T", [24, 96, 50, 192])
 @pytest.mark.parametrize("mode", ["relaxed_exact", "pdhg"])
 def test_relaxed_matches_oracle(gpu_lib, T, mode):
     """Continuous box+SOC QP (north star).  float32 tolerance: 2e-4 kW absolute on
