@@ -533,6 +533,16 @@ typedef struct {
     int32_t mode;
     revs_pdhg_t pdhg;
     const int32_t *node_of;      /* node of every residence, or NULL (no fused home pass) */
+    /* revs_plan_chain_step only (may be zero otherwise): the second set of candidate lists
+     * and stats, the model's scratch, and the Newton parameters */
+    int64_t *cand_idx1;
+    int32_t *cand_cnt1;
+    double *cand_val1, *stats1;
+    const double *stats1_host;
+    double *yhat, *k_full;
+    int32_t *info;
+    double delta, eps;
+    int32_t max_pivots;
 } revs_plan_desc_t;
 typedef struct revs_plan revs_plan_t;
 revs_plan_t *revs_plan_create(const revs_plan_desc_t *desc_host);
@@ -556,6 +566,22 @@ int revs_plan_spec_step(revs_plan_t *plan, int32_t phase, const double *y, int32
                         float *s_out, float *c_out, int32_t fused_in, const double *p_in,
                         double *p_out, float *p_est_next, double *rmax_out_host,
                         void *ev_mid, void *ev_end, void *stream);
+
+/* The binding steady state as ONE host call (engine.py: AdmmEngine._chain_launch /
+ * _chain_accept; one GPU): evaluation of the multipliers y into candidate set 0 (home pass
+ * row-wise from the lists of set `sup0` when use_y and sup0 >= 0, else dense),
+ * revs_op_dual_select_model_step into y_trial, evaluation of y_trial into set 1 (home pass
+ * row-wise from set 0 when chain_few), the home sweep on its answer p_est_new with the
+ * trial's selection in its launch (revs_agent_step_select, P_sch / G into the _out
+ * buffers); then the sequence tag of set 1 is polled and both stats blocks are judged by
+ * revs_newton_chain_accept: *accepted = its verdict, nsup_sum / nsup_max as there.  The
+ * stats blocks stay in stats_host / stats1_host for a caller that has to go on. */
+int revs_plan_chain_step(revs_plan_t *plan, const double *y, double *y_trial, int32_t use_y,
+                         int32_t sup0, int32_t chain_few, const float *p_est, float *p_est_new,
+                         const float *p_sch, const float *gamma, float *p_sch_out,
+                         float *gamma_out, float *s_out, float *c_out, int32_t *accepted,
+                         int32_t *nsup_sum, int32_t *nsup_max, void *ev_mid, void *ev_end,
+                         void *stream);
 
 #ifdef __cplusplus
 }

@@ -42,7 +42,11 @@ class PlanDesc(C.Structure):
                 ("cost", C.c_void_p), ("homes", C.c_void_p), ("load", C.c_void_p),
                 ("diff", C.c_void_p), ("dsq", C.c_void_p), ("status", C.c_void_p),
                 ("pdhg_dual", C.c_void_p), ("mode", C.c_int32), ("pdhg", PDHG),
-                ("node_of", C.c_void_p)]
+                ("node_of", C.c_void_p),
+                ("cand_idx1", C.c_void_p), ("cand_cnt1", C.c_void_p), ("cand_val1", C.c_void_p),
+                ("stats1", C.c_void_p), ("stats1_host", C.c_void_p),
+                ("yhat", C.c_void_p), ("k_full", C.c_void_p), ("info", C.c_void_p),
+                ("delta", C.c_double), ("eps", C.c_double), ("max_pivots", C.c_int32)]
 
 
 class RevsError(RuntimeError):
@@ -59,6 +63,8 @@ SIGNATURES = {
     "revs_host_device_ptr": (C.c_int, [_p, C.POINTER(C.c_void_p)]),
     "revs_plan_create": (C.c_void_p, [C.POINTER(PlanDesc)]),
     "revs_plan_destroy": (None, [_p]),
+    "revs_plan_chain_step": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                      _p, _p, _p, _p]),
     "revs_plan_spec_step": (C.c_int, [_p, _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p,
                                       _p, _p, C.POINTER(C.c_double), _p, _p, _p]),
     "revs_op_dual_rows": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _f64, _f64, _p, _p, _p, _p, _p]),

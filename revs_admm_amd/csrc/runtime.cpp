@@ -1,7 +1,9 @@
 // Error reporting and version string of librevs_admm.so.
 #include "common.h"
 #include <stdarg.h>
+#include <algorithm>
 #include <atomic>
+#include <cmath>
 #include <chrono>
 
 namespace revs {
@@ -178,5 +180,87 @@ extern "C" int revs_plan_spec_step(revs_plan_t *plan, int32_t phase, const doubl
     double mx = 0.0;
     for (int t = 0; t < d.T; ++t) mx = st[8 * t] > mx ? st[8 * t] : mx;
     *rmax_out = mx;
+    return REVS_OK;
+}
+
+extern "C" int revs_plan_chain_step(revs_plan_t *plan, const double *y, double *y_trial,
+                                    int32_t use_y, int32_t sup0, int32_t chain_few,
+                                    const float *p_est, float *p_est_new, const float *p_sch,
+                                    const float *gamma, float *p_sch_out, float *gamma_out,
+                                    float *s_out, float *c_out, int32_t *accepted,
+                                    int32_t *nsup_sum, int32_t *nsup_max, void *ev_mid,
+                                    void *ev_end, void *stream) {
+    REVS_REQUIRE(plan && y && y_trial && y != y_trial && p_est && p_est_new && p_sch && gamma &&
+                 p_sch_out && gamma_out && accepted && nsup_sum && nsup_max && sup0 >= -1 && sup0 <= 1,
+                 "revs_plan_chain_step: bad argument");
+    const revs_plan_desc_t &d = plan->d;
+    REVS_REQUIRE(d.cand_idx1 && d.cand_cnt1 && d.cand_val1 && d.stats1 && d.stats1_host && d.yhat &&
+                 d.k_full && d.info && d.max_pivots > 0 && d.eps > 0,
+                 "revs_plan_chain_step: the plan was created without the chain's buffers");
+    hipStream_t s = (hipStream_t)stream;
+    int64_t *const ci[2] = {d.cand_idx, d.cand_idx1};
+    int32_t *const cc[2] = {d.cand_cnt, d.cand_cnt1};
+    double *const cv[2] = {d.cand_val, d.cand_val1};
+    double *const st[2] = {d.stats, d.stats1};
+    const double scale = std::max(std::max(std::fabs(d.vlo), std::fabs(d.vhi)), 1e-300);
+    const int nb32 = (d.m + 31) / 32;
+    const int sel_nblk = (d.T <= 32 && nb32 <= 256) ? nb32 : 0;
+    // home pass of an evaluation of multipliers yy: row-wise from the lists of set `sup`, or dense
+    auto home_pass = [&](const double *yy, int uy, int sup) -> int {
+        if (uy && sup >= 0)
+            return revs_op_dual_eval_rows(d.m, d.T, d.node_ptr, p_est, p_sch, gamma, d.R, ci[sup],
+                                          cc[sup], yy, d.kappa, d.pnq, p_est_new, stream);
+        return revs_op_dual_evaluate(1, d.m, d.T, d.node_ptr, p_est, p_sch, gamma, d.R, d.Rt, yy, uy,
+                                     d.kappa, d.vlo, d.vhi, d.kadd, d.ksplit, d.d_slabs, d.v_slabs,
+                                     d.pnq, p_est_new, d.vfull, d.viol, d.partial, ci[0], cc[0], cv[0],
+                                     st[0], 0.0, nullptr, stream);
+    };
+    // product R p and the row bookkeeping; the selection is left to the next launch
+    auto rows = [&](const double *yy, int uy, int k) -> int {
+        return revs_op_dual_evaluate(2 | 4, d.m, d.T, d.node_ptr, p_est, p_sch, gamma, d.R, d.Rt, yy, uy,
+                                     d.kappa, d.vlo, d.vhi, d.kadd, d.ksplit, d.d_slabs, d.v_slabs,
+                                     d.pnq, p_est_new, d.vfull, d.viol, d.partial, ci[k], cc[k], cv[k],
+                                     st[k], 0.0, plan->counters, stream);
+    };
+    int rc;
+    if ((rc = home_pass(y, use_y, sup0)) != REVS_OK) return rc;
+    if ((rc = rows(y, use_y, 0)) != REVS_OK) return rc;
+    rc = revs_op_dual_select_model_step(d.m, d.T, d.partial, sel_nblk, y, d.vlo, d.vhi, d.kadd, d.vfull,
+                                        d.viol, ci[0], cc[0], cv[0], st[0], 0.0, d.R,
+                                        d.pnq + (int64_t)d.m * d.T, d.kappa, d.delta, d.max_pivots,
+                                        d.k_full, d.yhat, d.info, scale, d.eps, y_trial, st[1] + 4,
+                                        stream);
+    if (rc != REVS_OK) return rc;
+    if ((rc = home_pass(y_trial, 1, chain_few ? 0 : -1)) != REVS_OK) return rc;
+    if ((rc = rows(y_trial, 1, 1)) != REVS_OK) return rc;
+    if (ev_mid) (void)hipEventRecord((hipEvent_t)ev_mid, s);
+    const double seq = -(plan->seq += 1.0);          // (negative: not a spec-step tag)
+    rc = revs_agent_step_select(d.n_homes, d.T, d.cost, d.homes, d.load, p_est, p_est_new, p_sch,
+                                gamma, p_sch_out, gamma_out, s_out, c_out, d.diff, d.dsq, d.status,
+                                d.pdhg_dual, (float)d.kappa, d.mode, &d.pdhg, d.m, d.partial, y_trial,
+                                d.vlo, d.vhi, d.kadd, d.vfull, d.viol, ci[1], cc[1], cv[1], st[1], seq,
+                                nullptr, nullptr, nullptr, sel_nblk, stream);
+    if (rc != REVS_OK) return rc;
+    if (ev_end) (void)hipEventRecord((hipEvent_t)ev_end, s);
+    const volatile double *tg = d.stats1_host;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int t = 0; t < d.T; ++t) {
+        unsigned spins = 0;
+        while (tg[8 * t + 5] != seq) {
+            if ((++spins & 0xFFFF) == 0) {
+                if (hipStreamQuery(s) == hipSuccess && tg[8 * t + 5] != seq) {
+                    revs::set_error("revs_plan_chain_step: stream idle but stats tag missing");
+                    return REVS_ELAUNCH;
+                }
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+                    revs::set_error("revs_plan_chain_step: timed out waiting for the evaluation");
+                    return REVS_ELAUNCH;
+                }
+            }
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    *accepted = revs_newton_chain_accept(d.T, d.stats_host, d.stats1_host, scale, d.eps,
+                                         REVS_DUAL_AMAX, d.kadd, chain_few, nsup_sum, nsup_max);
     return REVS_OK;
 }

@@ -317,6 +317,11 @@ class AdmmEngine:
             self.P_est_alt = torch.zeros(n, T, **f32)
             self.p_alt = nz()                         # second buffer of the fused node sums
             d.node_of = ptr(self.node_of_dev)
+            d.cand_idx1, d.cand_cnt1, d.cand_val1 = (ptr(self.c_idx[1]), ptr(self.c_cnt[1]),
+                                                     ptr(self.c_val[1]))
+            d.stats1, d.stats1_host = self.stats_dev[1], self.stats_host[1].data_ptr()
+            d.yhat, d.k_full, d.info = ptr(self.yhat), ptr(self.k_full), self.info_dev
+            d.delta, d.eps, d.max_pivots = self.op.newton_delta, self.op.eps, self.op.newton_pivots
             self._plan_desc = d
             self._plan = self.lib.revs_plan_create(C.byref(d))
             if not self._plan:
@@ -976,16 +981,20 @@ class AdmmEngine:
                 _lib.DUAL_AMAX, o.newton_kadd, int(self._chain_few), C.addressof(nsum),
                 C.addressof(nmax)):
             return False
+        self._chain_book(nsum.value, nmax.value)
+        return True
+
+    def _chain_book(self, nsum, nmax):
+        o = self.op
         self.yd = [self.yd[1], self.yd[0]]
         self.model_calls[0] += 1
         self.newton_hist.append((1, 2, int(np.abs(self.info_h.numpy()).sum())))
         self._pre_kept, self._chain_ok, self._spec_ok = True, True, False
-        self._y_support = nsum.value > 0
-        self._sup = 1 if (self._y_support and nmax.value + o.newton_kadd <= 48) else None
+        self._y_support = nsum > 0
+        self._sup = 1 if (self._y_support and nmax + o.newton_kadd <= 48) else None
         self.op_iters_hist.append(2)
         self.op_path_hist.append("dual")
         self.op_converged = True
-        return True
 
     def operator_solve(self, admm_only=False):
         """Utility(graph, P_est[k], P_sch[k], G[k]).solve() -> P_est[k+1]
@@ -1180,8 +1189,30 @@ class AdmmEngine:
             # binding steady state: the last solve was one Newton iteration on the small model;
             # enqueue the same again, and the sweep behind it, before reading anything
             self._fused_ready = False
-            self._chain_launch(write_sc, rec)
-            if self._chain_accept():             # the usual outcome, judged natively
+            if self._plan is not None and self.group is None:
+                # one native call: the six launches, the wait and the verdict
+                acc, nsum, nmax = C.c_int32(), C.c_int32(), C.c_int32()
+                evh = [None, None]
+                if events:
+                    for i in (1, 2):
+                        if not events[i].cuda_event:
+                            events[i].record()
+                        evh[i - 1] = events[i].cuda_event
+                sup0 = self._sup if (self._y_support and self._sup is not None) else -1
+                check(self.lib.revs_plan_chain_step(
+                    self._plan, ptr(self.yd[0]), ptr(self.yd[1]), int(self._y_support), sup0,
+                    int(self._chain_few), ptr(self.P_est), ptr(self.P_est_new), ptr(self.P_sch),
+                    ptr(self.G), ptr(self.P_sch_alt), ptr(self.G_alt),
+                    ptr(self.S) if write_sc else None, ptr(self.Csoc) if write_sc else None,
+                    C.addressof(acc), C.addressof(nsum), C.addressof(nmax), evh[0], evh[1],
+                    self.stream), "revs_plan_chain_step")
+                accepted = bool(acc.value)
+                if accepted:
+                    self._chain_book(nsum.value, nmax.value)
+            else:
+                self._chain_launch(write_sc, rec)
+                accepted = self._chain_accept()  # the usual outcome, judged natively
+            if accepted:
                 ok = True
             else:                                # (the tag was seen: both blocks are complete)
                 stt0, stn = (self.stats_host[0].numpy().copy(), self.stats_host[1].numpy().copy())
