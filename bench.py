@@ -188,6 +188,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    barrier()       # ranks leave the set-up together (a step waits for every rank's all-reduce)
+
     # Spin-up: the first ADMM iterations are a transient of their own -- every charger
     # jumps to the cheapest slots, voltage rows bind hard and some residences are clamped,
     # so the operator QP needs hundreds to thousands of inner iterations.  They are run

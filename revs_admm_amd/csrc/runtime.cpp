@@ -169,7 +169,7 @@ extern "C" int revs_plan_spec_step(revs_plan_t *plan, int32_t phase, const doubl
                     revs::set_error("revs_plan_spec_step: stream idle but stats tag missing");
                     return REVS_ELAUNCH;
                 }
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
                     revs::set_error("revs_plan_spec_step: timed out waiting for the evaluation");
                     return REVS_ELAUNCH;
                 }
@@ -252,7 +252,7 @@ extern "C" int revs_plan_chain_step(revs_plan_t *plan, const double *y, double *
                     revs::set_error("revs_plan_chain_step: stream idle but stats tag missing");
                     return REVS_ELAUNCH;
                 }
-                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
                     revs::set_error("revs_plan_chain_step: timed out waiting for the evaluation");
                     return REVS_ELAUNCH;
                 }

@@ -971,7 +971,7 @@ class AdmmEngine:
                 if spins & 0xFFF == 0:
                     import time
                     t0 = t0 or time.monotonic()
-                    if time.monotonic() - t0 > 20.0:
+                    if time.monotonic() - t0 > 120.0:
                         raise _lib.RevsError("chained Newton iteration: timed out waiting for "
                                              "the evaluation's sequence tag")
         nsum, nmax = C.c_int32(), C.c_int32()
