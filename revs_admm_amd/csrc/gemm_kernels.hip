@@ -287,14 +287,17 @@ __global__ __launch_bounds__(kGemmWaves * 64) void gemm_tn_kernel(
             buf[0][rr][t] = res; buf[1][rr][t] = dterm; buf[2][rr][t] = sup; buf[3][rr][t] = vio;
         }
         __syncthreads();
-        if ((int)threadIdx.x < n) {
-            const int t = threadIdx.x;
-            double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
-            for (int rr = 0; rr < kRows; ++rr) {              // fixed order
-                a = fmax(a, buf[0][rr][t]); b += buf[1][rr][t]; c += buf[2][rr][t]; d += buf[3][rr][t];
+        if ((int)threadIdx.x < 4 * 32) {                      // one thread per (quantity, slot)
+            const int q = threadIdx.x >> 5, t = threadIdx.x & 31;
+            double acc = 0.0;
+            if (q == 0) {
+#pragma unroll 8
+                for (int rr = 0; rr < kRows; ++rr) acc = fmax(acc, buf[0][rr][t]);
+            } else {
+#pragma unroll 8
+                for (int rr = 0; rr < kRows; ++rr) acc += buf[q][rr][t];    // fixed order
             }
-            double *o = rw.partial + ((int64_t)blockIdx.x * n + t) * 4;
-            o[0] = a; o[1] = b; o[2] = c; o[3] = d;
+            if (t < n) rw.partial[((int64_t)blockIdx.x * n + t) * 4 + q] = acc;
         }
     }
 }
