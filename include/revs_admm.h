@@ -567,6 +567,27 @@ int revs_plan_spec_step(revs_plan_t *plan, int32_t phase, const double *y, int32
                         double *p_out, float *p_est_next, double *rmax_out_host,
                         void *ev_mid, void *ev_end, void *stream);
 
+/* Up to max_steps consecutive steady-state iterations in one host call (one GPU, multipliers
+ * all zero, the next evaluation's home pass folded into every sweep, no S / C output): each
+ * is revs_plan_spec_step(phase 3, use_y = 0, p_out != NULL) on the buffer roles in `st`,
+ * judged by rmax / scale <= eps, and -- if kept -- followed by the role rotation of
+ * AdmmEngine.step (P_sch / G with their spares; P_est <- P_est_new <- P_est_alt <- P_est;
+ * node sums alternating between p0 and p_alt).  The call returns after max_steps kept
+ * iterations or after the first one whose sweep must be discarded: that iteration's launches
+ * have been made, `st` still holds ITS roles, *last_fused_in tells whether its evaluation
+ * took the node sums from the previous sweep, *rmax_out its row residual; *kept_steps counts
+ * the kept ones before it. */
+typedef struct {
+    float *p_est, *p_est_new, *p_est_alt;
+    float *p_sch, *p_sch_alt, *gamma, *gamma_alt;
+    double *p0, *p_alt;          /* the two node-sum arrays (p0 = pnq[0] of the plan) */
+    double *fused_p;             /* where the last kept sweep left the next node sums */
+    int32_t fused_ready;         /* ... if it did */
+} revs_spec_state_t;
+int revs_plan_spec_run(revs_plan_t *plan, int32_t max_steps, const double *y,
+                       revs_spec_state_t *st, double scale, double eps, int32_t *kept_steps,
+                       int32_t *last_fused_in, double *rmax_out, void *stream);
+
 /* The binding steady state as ONE host call (engine.py: AdmmEngine._chain_launch /
  * _chain_accept; one GPU): evaluation of the multipliers y into candidate set 0 (home pass
  * row-wise from the lists of set `sup0` when use_y and sup0 >= 0, else dense),

@@ -49,6 +49,14 @@ class PlanDesc(C.Structure):
                 ("delta", C.c_double), ("eps", C.c_double), ("max_pivots", C.c_int32)]
 
 
+class SpecState(C.Structure):
+    """revs_spec_state_t"""
+    _fields_ = [("p_est", C.c_void_p), ("p_est_new", C.c_void_p), ("p_est_alt", C.c_void_p),
+                ("p_sch", C.c_void_p), ("p_sch_alt", C.c_void_p), ("gamma", C.c_void_p),
+                ("gamma_alt", C.c_void_p), ("p0", C.c_void_p), ("p_alt", C.c_void_p),
+                ("fused_p", C.c_void_p), ("fused_ready", C.c_int32)]
+
+
 class RevsError(RuntimeError):
     pass
 
@@ -65,6 +73,7 @@ SIGNATURES = {
     "revs_plan_destroy": (None, [_p]),
     "revs_plan_chain_step": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                       _p, _p, _p, _p]),
+    "revs_plan_spec_run": (C.c_int, [_p, _i32, _p, C.POINTER(SpecState), _f64, _f64, _p, _p, _p, _p]),
     "revs_plan_spec_step": (C.c_int, [_p, _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p,
                                       _p, _p, C.POINTER(C.c_double), _p, _p, _p]),
     "revs_op_dual_rows": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _f64, _f64, _p, _p, _p, _p, _p]),

@@ -264,3 +264,41 @@ extern "C" int revs_plan_chain_step(revs_plan_t *plan, const double *y, double *
                                          REVS_DUAL_AMAX, d.kadd, chain_few, nsup_sum, nsup_max);
     return REVS_OK;
 }
+
+extern "C" int revs_plan_spec_run(revs_plan_t *plan, int32_t max_steps, const double *y,
+                                  revs_spec_state_t *st, double scale, double eps,
+                                  int32_t *kept_steps, int32_t *last_fused_in, double *rmax_out,
+                                  void *stream) {
+    REVS_REQUIRE(plan && max_steps >= 0 && y && st && kept_steps && last_fused_in && rmax_out &&
+                 scale > 0.0 && st->p_est && st->p_est_new && st->p_est_alt && st->p_sch &&
+                 st->p_sch_alt && st->gamma && st->gamma_alt && st->p0 && st->p_alt &&
+                 st->p0 != st->p_alt && st->p0 == plan->d.pnq &&
+                 (!st->fused_ready || st->fused_p == st->p0 || st->fused_p == st->p_alt),
+                 "revs_plan_spec_run: bad argument");
+    *kept_steps = 0;
+    *last_fused_in = 0;
+    *rmax_out = 0.0;
+    for (int32_t k = 0; k < max_steps; ++k) {
+        const int32_t fused_in = st->fused_ready;
+        const double *p_in = fused_in ? st->fused_p : st->p0;
+        double *p_out = p_in == st->p0 ? st->p_alt : st->p0;
+        double rm = 0.0;
+        const int rc = revs_plan_spec_step(plan, 3, y, 0, st->p_est, st->p_est_new, st->p_sch, st->gamma,
+                                           st->p_sch_alt, st->gamma_alt, nullptr, nullptr, fused_in, p_in,
+                                           p_out, st->p_est_alt, &rm, nullptr, nullptr, stream);
+        if (rc != REVS_OK) return rc;
+        *rmax_out = rm;
+        if (!(rm / scale <= eps)) {          // discard: the caller finishes this iteration
+            *last_fused_in = fused_in;
+            return REVS_OK;
+        }
+        std::swap(st->p_sch, st->p_sch_alt);
+        std::swap(st->gamma, st->gamma_alt);
+        st->fused_ready = 1;
+        st->fused_p = p_out;
+        std::swap(st->p_est, st->p_est_new);
+        std::swap(st->p_est_new, st->p_est_alt);
+        ++*kept_steps;
+    }
+    return REVS_OK;
+}

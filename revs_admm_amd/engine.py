@@ -1175,16 +1175,7 @@ class AdmmEngine:
                 self.spec_hist[0] += 1
                 self._spec_back = 1
             else:                          # rows need work: finish the solve, redo the sweep
-                self.spec_hist[1] += 1
-                self._spec_back = min(2 * self._spec_back, 64)
-                self._spec_wait = self._spec_back
-                if stt is not None:
-                    stt = self._dual_complete(self.yd[0], self._y_support, 0)
-                if not self._operator_solve_newton(first=stt):
-                    self._fast_cold = True
-                    self.op_cold = True
-                    self.operator_solve(admm_only=True)
-                self.agent_step(write_sc)
+                self._spec_discard(stt, write_sc)
         elif o.solver == "newton" and o.chain and self._chain_ok:
             # binding steady state: the last solve was one Newton iteration on the small model;
             # enqueue the same again, and the sweep behind it, before reading anything
@@ -1259,6 +1250,74 @@ class AdmmEngine:
             ptr(self.node_of_dev) if fused else None, ptr(p_scratch) if fused else None,
             ptr(pe_scratch) if fused else None, nb if (T <= 32 and nb <= 256) else 0,
             self.stream), "revs_agent_step_select")
+
+    def _spec_discard(self, stt, write_sc):
+        """A speculative sweep whose evaluation found rows beyond tolerance: finish the Newton
+        solve (from the evaluation's stats `stt` when they carry a dual value), run the sweep
+        on its answer; speculation backs off."""
+        self.spec_hist[1] += 1
+        self._spec_back = min(2 * self._spec_back, 64)
+        self._spec_wait = self._spec_back
+        if stt is not None:
+            stt = self._dual_complete(self.yd[0], self._y_support, 0)
+        if not self._operator_solve_newton(first=stt):
+            self._fast_cold = True
+            self.op_cold = True
+            self.operator_solve(admm_only=True)
+        self.agent_step(write_sc)
+
+    def run_steps(self, count):
+        """`count` iterations of step(write_sc=False).  Consecutive steady-state iterations
+        (one GPU, no multipliers, speculation on) run inside ONE native call,
+        revs_plan_spec_run -- the buffer rotation included, no Python between the launches --
+        which returns at the first sweep that has to be discarded; that iteration is finished
+        here as step() would, and the loop goes on.  Same trajectory as calling step()."""
+        o, done = self.op, 0
+        scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
+        while done < count:
+            if not (self._plan is not None and self.group is None and o.solver == "newton"
+                    and o.speculate and self._spec_ok and o.fuse_home_pass
+                    and not self._y_support):
+                self.step(write_sc=False)
+                done += 1
+                continue
+            p0 = self.pnq[0]
+            bufs = (self.P_est, self.P_est_new, self.P_est_alt, self.P_sch, self.P_sch_alt, self.G,
+                    self.G_alt)
+            st = _lib.SpecState(*[ptr(t) for t in bufs], ptr(p0), ptr(self.p_alt),
+                                ptr(self._fused_p) if self._fused_ready else None,
+                                int(self._fused_ready))
+            kept, fin, rm = C.c_int32(), C.c_int32(), C.c_double()
+            check(self.lib.revs_plan_spec_run(self._plan, count - done, ptr(self.yd[0]), C.byref(st),
+                                              scale, o.eps, C.addressof(kept), C.addressof(fin),
+                                              C.addressof(rm), self.stream), "revs_plan_spec_run")
+            n = kept.value
+            by = {t.data_ptr(): t for t in bufs}
+            self.P_est, self.P_est_new, self.P_est_alt = (by[st.p_est], by[st.p_est_new],
+                                                          by[st.p_est_alt])
+            self.P_sch, self.P_sch_alt = by[st.p_sch], by[st.p_sch_alt]
+            self.G, self.G_alt = by[st.gamma], by[st.gamma_alt]
+            self._fused_ready = bool(st.fused_ready)
+            if self._fused_ready:
+                self._fused_p = p0 if st.fused_p == p0.data_ptr() else self.p_alt
+            if n:
+                self.op_iters_hist.extend([1] * n)
+                self.op_path_hist.extend(["dual"] * n)
+                self.newton_hist.extend([(0, 1, 0)] * n)
+                self.op_converged = True
+                self.spec_hist[0] += n
+                self._spec_back = 1
+                self.iteration += n
+                done += n
+            if done < count and n < count - (done - n):
+                # the call stopped at a sweep to discard: finish that iteration as step() does
+                fused_in = bool(fin.value)
+                self._fused_ready = False
+                stt = None if fused_in else self.stats_host[0].numpy().copy()
+                self._spec_discard(stt, False)
+                self.P_est, self.P_est_new = self.P_est_new, self.P_est
+                self.iteration += 1
+                done += 1
 
     def __del__(self):
         try:

@@ -525,6 +525,38 @@ def test_chained_newton_iteration_changes_nothing(gpu_lib, mode, stress):
     np.testing.assert_array_equal(y1, y0)
 
 
+@pytest.mark.parametrize("mode,stress", [("relaxed_exact", 1.0), ("pdhg", 1.02), ("binary", 0.5)])
+def test_run_steps_equals_repeated_step(gpu_lib, mode, stress):
+    """run_steps (consecutive steady-state iterations inside one native call, buffer rotation
+    included: revs_plan_spec_run; discarded sweeps and everything else through step()) leaves
+    the state that the same number of step() calls leaves, bit for bit -- through the
+    transient, kept and discarded speculative sweeps, and in chunks of any size."""
+    from helpers import f32
+    from revs_admm_amd.synthetic import make_workload
+    w = make_workload(8000, 24, n_nodes=200, seed=3, binary_feasible=(mode == "binary"), stress=stress)
+    w.load, w.cost = f32(w.load), f32(w.cost)
+    a, b = _engine(w, mode), _engine(w, mode)
+    for _ in range(90):
+        a.step(write_sc=False)
+    for chunk in (1, 7, 30, 2, 50):
+        b.run_steps(chunk)
+    assert a.iteration == b.iteration == 90
+    assert a.spec_hist == b.spec_hist and a.spec_hist[0] > 20, (a.spec_hist, b.spec_hist)
+    assert a.op_iters_hist == b.op_iters_hist and a.newton_hist == b.newton_hist
+    if mode != "binary":
+        assert a.spec_hist[1] > 0                  # discards went through the hand-back too
+    for name in ("P_est", "P_sch", "G", "diff"):
+        assert torch_equal(getattr(a, name), getattr(b, name)), name
+    a.step(write_sc=True); b.step(write_sc=True)   # and the run goes on identically
+    for x, y in zip(a.result(), b.result()):
+        np.testing.assert_array_equal(x, y)
+
+
+def torch_equal(x, y):
+    import torch
+    return torch.equal(x, y)
+
+
 @pytest.mark.parametrize("n,M,T", [(1, 1, 24), (5, 2, 24), (9, 9, 7), (40, 3, 33)])
 def test_tiny_runs_match_oracle(gpu_lib, n, M, T):
     """Degenerate sizes through the whole engine (one residence, fewer residences than a

@@ -229,6 +229,27 @@ def test_chained_newton_iteration_on_fake_kernels(mode, stress):
     assert [h[0] for h in e1.newton_hist] == [h[0] for h in e0.newton_hist]
 
 
+def test_run_steps_without_a_plan_is_a_loop_of_steps():
+    """Without the native plan (no GPU here) run_steps(k) is k calls of step()."""
+    from fake_kernels import FakeKernels
+    from helpers import f32
+    from revs_admm_amd.engine import AdmmEngine
+    from revs_admm_amd.synthetic import make_workload
+    w = make_workload(120, 12, n_nodes=15, seed=4, stress=1.02, binary_feasible=False)
+    w.load, w.cost = f32(w.load), f32(w.cost)
+    mk = lambda: AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, kappa=w.kappa, vset=w.vset,
+                            vlow=w.vlow, vhigh=w.vhigh, mode="relaxed_exact", device="cpu",
+                            _kernels=FakeKernels())
+    a, b = mk(), mk()
+    for _ in range(9):
+        a.step(write_sc=False)
+    b.run_steps(4)
+    b.run_steps(5)
+    assert a.iteration == b.iteration == 9 and a.op_iters_hist == b.op_iters_hist
+    np.testing.assert_array_equal(a.P_sch.numpy(), b.P_sch.numpy())
+    np.testing.assert_array_equal(a.G.numpy(), b.G.numpy())
+
+
 @pytest.mark.parametrize("stress,paths", [(0.9, {"node"}), (2.0, {"node", "home"})])
 def test_operator_paths_on_fake_kernels(stress, paths):
     """Driver logic of the two ADMM operator paths (OperatorOptions.solver = "admm"): the node-space fast path is kept while no
