@@ -604,6 +604,23 @@ int revs_plan_chain_step(revs_plan_t *plan, const double *y, double *y_trial, in
                          int32_t *nsup_sum, int32_t *nsup_max, void *ev_mid, void *ev_end,
                          void *stream);
 
+/* Up to max_steps consecutive iterations of the binding steady state in one host call:
+ * revs_plan_chain_step on the roles in `st`; an accepted iteration is followed by the role
+ * rotation of AdmmEngine.step / _chain_book (y <-> y_trial; use_y = any multiplier left;
+ * sup0 = 1 if the row-wise home pass applies to them -- at most 48 - kadd per slot -- else
+ * -1; P_sch / G with their spares; P_est <-> P_est_new).  Returns after max_steps accepted
+ * iterations or after the first one that is not (its launches made, `st` holding ITS roles,
+ * the stats blocks in place for the caller's general loop); *kept_steps counts the accepted
+ * ones. */
+typedef struct {
+    double *y, *y_trial;
+    int32_t use_y, sup0;
+    float *p_est, *p_est_new;
+    float *p_sch, *p_sch_alt, *gamma, *gamma_alt;
+} revs_chain_state_t;
+int revs_plan_chain_run(revs_plan_t *plan, int32_t max_steps, revs_chain_state_t *st,
+                        int32_t chain_few, int32_t *kept_steps, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,13 @@ class SpecState(C.Structure):
                 ("fused_p", C.c_void_p), ("fused_ready", C.c_int32)]
 
 
+class ChainState(C.Structure):
+    """revs_chain_state_t"""
+    _fields_ = [("y", C.c_void_p), ("y_trial", C.c_void_p), ("use_y", C.c_int32), ("sup0", C.c_int32),
+                ("p_est", C.c_void_p), ("p_est_new", C.c_void_p), ("p_sch", C.c_void_p),
+                ("p_sch_alt", C.c_void_p), ("gamma", C.c_void_p), ("gamma_alt", C.c_void_p)]
+
+
 class RevsError(RuntimeError):
     pass
 
@@ -73,6 +80,7 @@ SIGNATURES = {
     "revs_plan_destroy": (None, [_p]),
     "revs_plan_chain_step": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                       _p, _p, _p, _p]),
+    "revs_plan_chain_run": (C.c_int, [_p, _i32, C.POINTER(ChainState), _i32, _p, _p]),
     "revs_plan_spec_run": (C.c_int, [_p, _i32, _p, C.POINTER(SpecState), _f64, _f64, _p, _p, _p, _p]),
     "revs_plan_spec_step": (C.c_int, [_p, _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p,
                                       _p, _p, C.POINTER(C.c_double), _p, _p, _p]),

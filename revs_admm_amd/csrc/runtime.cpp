@@ -302,3 +302,28 @@ extern "C" int revs_plan_spec_run(revs_plan_t *plan, int32_t max_steps, const do
     }
     return REVS_OK;
 }
+
+extern "C" int revs_plan_chain_run(revs_plan_t *plan, int32_t max_steps, revs_chain_state_t *st,
+                                   int32_t chain_few, int32_t *kept_steps, void *stream) {
+    REVS_REQUIRE(plan && max_steps >= 0 && st && kept_steps && st->y && st->y_trial && st->p_est &&
+                 st->p_est_new && st->p_sch && st->p_sch_alt && st->gamma && st->gamma_alt,
+                 "revs_plan_chain_run: bad argument");
+    *kept_steps = 0;
+    for (int32_t k = 0; k < max_steps; ++k) {
+        int32_t acc = 0, nsum = 0, nmax = 0;
+        const int rc = revs_plan_chain_step(plan, st->y, st->y_trial, st->use_y, st->sup0, chain_few,
+                                            st->p_est, st->p_est_new, st->p_sch, st->gamma,
+                                            st->p_sch_alt, st->gamma_alt, nullptr, nullptr, &acc, &nsum,
+                                            &nmax, nullptr, nullptr, stream);
+        if (rc != REVS_OK) return rc;
+        if (!acc) return REVS_OK;              // the caller's general loop takes this iteration
+        std::swap(st->y, st->y_trial);
+        st->use_y = nsum > 0;
+        st->sup0 = (nsum > 0 && nmax + plan->d.kadd <= 48) ? 1 : -1;
+        std::swap(st->p_sch, st->p_sch_alt);
+        std::swap(st->gamma, st->gamma_alt);
+        std::swap(st->p_est, st->p_est_new);
+        ++*kept_steps;
+    }
+    return REVS_OK;
+}

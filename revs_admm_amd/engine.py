@@ -1197,28 +1197,16 @@ class AdmmEngine:
                     ptr(self.S) if write_sc else None, ptr(self.Csoc) if write_sc else None,
                     C.addressof(acc), C.addressof(nsum), C.addressof(nmax), evh[0], evh[1],
                     self.stream), "revs_plan_chain_step")
-                accepted = bool(acc.value)
-                if accepted:
-                    self._chain_book(nsum.value, nmax.value)
+                self._chain_finish(bool(acc.value), nsum.value, nmax.value, write_sc)
             else:
                 self._chain_launch(write_sc, rec)
-                accepted = self._chain_accept()  # the usual outcome, judged natively
-            if accepted:
-                ok = True
-            else:                                # (the tag was seen: both blocks are complete)
-                stt0, stn = (self.stats_host[0].numpy().copy(), self.stats_host[1].numpy().copy())
-                ok = self._operator_solve_newton(first=stt0, pre=stn)
-            if ok and self._pre_kept:
-                self.P_sch, self.P_sch_alt = self.P_sch_alt, self.P_sch
-                self.G, self.G_alt = self.G_alt, self.G
-                self.chain_hist[0] += 1
-            else:
-                self.chain_hist[1] += 1
-                if not ok:
-                    self._fast_cold = True
-                    self.op_cold = True
-                    self.operator_solve(admm_only=True)
-                self.agent_step(write_sc)
+                # (_chain_accept books the usual outcome itself)
+                if self._chain_accept():
+                    self.P_sch, self.P_sch_alt = self.P_sch_alt, self.P_sch
+                    self.G, self.G_alt = self.G_alt, self.G
+                    self.chain_hist[0] += 1
+                else:
+                    self._chain_finish(False, 0, 0, write_sc)
         else:
             self._fused_ready = False
             self.operator_solve()
@@ -1266,6 +1254,66 @@ class AdmmEngine:
             self.operator_solve(admm_only=True)
         self.agent_step(write_sc)
 
+    def _chain_run(self, count):
+        """Up to `count` iterations of the binding steady state inside one native call
+        (revs_plan_chain_run); the first one that is not the usual outcome is finished here as
+        step() would.  Returns the number of iterations done (at least one)."""
+        self._fused_ready = False
+        ys = (self.yd[0], self.yd[1])
+        bufs = (self.P_est, self.P_est_new, self.P_sch, self.P_sch_alt, self.G, self.G_alt)
+        sup0 = self._sup if (self._y_support and self._sup is not None) else -1
+        st = _lib.ChainState(ptr(ys[0]), ptr(ys[1]), int(self._y_support), sup0,
+                             *[ptr(t) for t in bufs])
+        kept = C.c_int32()
+        check(self.lib.revs_plan_chain_run(self._plan, count, C.byref(st), int(self._chain_few),
+                                           C.addressof(kept), self.stream), "revs_plan_chain_run")
+        n = kept.value
+        by = {t.data_ptr(): t for t in bufs}
+        self.P_est, self.P_est_new = by[st.p_est], by[st.p_est_new]
+        self.P_sch, self.P_sch_alt = by[st.p_sch], by[st.p_sch_alt]
+        self.G, self.G_alt = by[st.gamma], by[st.gamma_alt]
+        self.yd = [ys[0], ys[1]] if st.y == ys[0].data_ptr() else [ys[1], ys[0]]
+        if n:
+            self.model_calls[0] += n
+            self.newton_hist.extend([(1, 2, -1)] * n)      # (pivot counts not read)
+            self._pre_kept, self._chain_ok, self._spec_ok = True, True, False
+            self._y_support = bool(st.use_y)
+            self._sup = 1 if st.sup0 == 1 else None
+            self.op_iters_hist.extend([2] * n)
+            self.op_path_hist.extend(["dual"] * n)
+            self.op_converged = True
+            self.chain_hist[0] += n
+            self.iteration += n
+        if n == count:
+            return n
+        # the call stopped at an iteration for the general loop (its launches are made)
+        self._chain_finish(False, 0, 0, False)
+        self.P_est, self.P_est_new = self.P_est_new, self.P_est
+        self.iteration += 1
+        return n + 1
+
+    def _chain_finish(self, accepted, nsum, nmax, write_sc):
+        """After the chain's launches: book the usual outcome, or hand both evaluations to the
+        general loop (which reuses the trial where it is exactly its own first step); keep the
+        speculative sweep or run it again."""
+        if accepted:
+            self._chain_book(nsum, nmax)
+            ok = True
+        else:                                # (the tag was seen: both blocks are complete)
+            stt0, stn = (self.stats_host[0].numpy().copy(), self.stats_host[1].numpy().copy())
+            ok = self._operator_solve_newton(first=stt0, pre=stn)
+        if ok and self._pre_kept:
+            self.P_sch, self.P_sch_alt = self.P_sch_alt, self.P_sch
+            self.G, self.G_alt = self.G_alt, self.G
+            self.chain_hist[0] += 1
+        else:
+            self.chain_hist[1] += 1
+            if not ok:
+                self._fast_cold = True
+                self.op_cold = True
+                self.operator_solve(admm_only=True)
+            self.agent_step(write_sc)
+
     def run_steps(self, count):
         """`count` iterations of step(write_sc=False).  Consecutive steady-state iterations
         (one GPU, no multipliers, speculation on) run inside ONE native call,
@@ -1275,8 +1323,11 @@ class AdmmEngine:
         o, done = self.op, 0
         scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
         while done < count:
-            if not (self._plan is not None and self.group is None and o.solver == "newton"
-                    and o.speculate and self._spec_ok and o.fuse_home_pass
+            native = self._plan is not None and self.group is None and o.solver == "newton"
+            if native and o.chain and self._chain_ok and not (o.speculate and self._spec_ok):
+                done += self._chain_run(count - done)
+                continue
+            if not (native and o.speculate and self._spec_ok and o.fuse_home_pass
                     and not self._y_support):
                 self.step(write_sc=False)
                 done += 1

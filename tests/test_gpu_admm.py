@@ -525,10 +525,12 @@ def test_chained_newton_iteration_changes_nothing(gpu_lib, mode, stress):
     np.testing.assert_array_equal(y1, y0)
 
 
-@pytest.mark.parametrize("mode,stress", [("relaxed_exact", 1.0), ("pdhg", 1.02), ("binary", 0.5)])
+@pytest.mark.parametrize("mode,stress", [("relaxed_exact", 1.0), ("pdhg", 1.02), ("binary", 0.5), ("binary", 1.0),
+                                         ("relaxed_exact", 1.3)])
 def test_run_steps_equals_repeated_step(gpu_lib, mode, stress):
     """run_steps (consecutive steady-state iterations inside one native call, buffer rotation
-    included: revs_plan_spec_run; discarded sweeps and everything else through step()) leaves
+    included: revs_plan_spec_run, and revs_plan_chain_run where rows keep binding; discarded
+    sweeps and everything else through step()) leaves
     the state that the same number of step() calls leaves, bit for bit -- through the
     transient, kept and discarded speculative sweeps, and in chunks of any size."""
     from helpers import f32
@@ -541,10 +543,12 @@ def test_run_steps_equals_repeated_step(gpu_lib, mode, stress):
     for chunk in (1, 7, 30, 2, 50):
         b.run_steps(chunk)
     assert a.iteration == b.iteration == 90
-    assert a.spec_hist == b.spec_hist and a.spec_hist[0] > 20, (a.spec_hist, b.spec_hist)
-    assert a.op_iters_hist == b.op_iters_hist and a.newton_hist == b.newton_hist
+    assert a.spec_hist == b.spec_hist and a.chain_hist == b.chain_hist, (a.spec_hist, b.spec_hist)
+    assert a.spec_hist[0] > 20 or a.chain_hist[0] > 20, (a.spec_hist, a.chain_hist)
+    assert a.op_iters_hist == b.op_iters_hist
+    assert [h[:2] for h in a.newton_hist] == [h[:2] for h in b.newton_hist]
     if mode != "binary":
-        assert a.spec_hist[1] > 0                  # discards went through the hand-back too
+        assert a.spec_hist[1] + a.chain_hist[1] > 0   # discards went through the hand-back too
     for name in ("P_est", "P_sch", "G", "diff"):
         assert torch_equal(getattr(a, name), getattr(b, name)), name
     a.step(write_sc=True); b.step(write_sc=True)   # and the run goes on identically
