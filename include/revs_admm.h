@@ -559,7 +559,13 @@ void revs_plan_destroy(revs_plan_t *plan);
  *           accumulates the NEXT evaluation's node sums while writing p_est_next; it is
  *           cleared on the way
  * ev_mid / ev_end: optional hipEvent_t handles recorded between evaluation and sweep / after
- * the sweep. */
+ * the sweep.
+ * phase bit 3 (value 8, with bit 1; used by revs_plan_spec_run): after the sweep and BEFORE
+ * waiting for the verdict, the product + rows of the NEXT iteration are enqueued too (node sums
+ * p_out, clearing p_in's array): they depend on this sweep only, and the queue does not run
+ * dry while the host turns around.  phase bit 2 (value 4): this call's product was enqueued
+ * that way by the previous call -- skip it.  If the sweep is discarded the work run ahead is
+ * never read: the caller's next evaluation rewrites every array it touched. */
 int revs_plan_spec_step(revs_plan_t *plan, int32_t phase, const double *y, int32_t use_y,
                         const float *p_est, float *p_est_new, const float *p_sch,
                         const float *gamma, float *p_sch_out, float *gamma_out,

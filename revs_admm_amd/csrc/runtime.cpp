@@ -110,8 +110,10 @@ extern "C" int revs_plan_spec_step(revs_plan_t *plan, int32_t phase, const doubl
                                    float *gamma_out, float *s_out, float *c_out, int32_t fused_in,
                                    const double *p_in, double *p_out, float *p_est_next,
                                    double *rmax_out, void *ev_mid, void *ev_end, void *stream) {
-    REVS_REQUIRE(plan && phase >= 1 && phase <= 3 && y && p_est && p_est_new && p_sch && gamma &&
-                 p_sch_out && gamma_out && rmax_out && p_in, "revs_plan_spec_step: bad argument");
+    REVS_REQUIRE(plan && phase >= 1 && phase <= 15 && (!(phase & 12) || (phase & 2)) && y && p_est &&
+                 p_est_new && p_sch && gamma && p_sch_out && gamma_out && rmax_out && p_in,
+                 "revs_plan_spec_step: bad argument");
+    REVS_REQUIRE(!(phase & 8) || p_out, "revs_plan_spec_step: running ahead needs p_out");
     const revs_plan_desc_t &d = plan->d;
     const bool fuse_out = p_out != nullptr;
     REVS_REQUIRE(!(fuse_out || fused_in) || (!use_y && d.node_of && (!fuse_out || p_est_next)),
@@ -133,18 +135,20 @@ extern "C" int revs_plan_spec_step(revs_plan_t *plan, int32_t phase, const doubl
     // sweep; all-reduced by a sharded caller between the phases); p_out: where this sweep
     // accumulates the next ones -- never the same array, so that clearing the latter cannot
     // race with the product reading the former
-    int sel_nblk = 0;
-    if (d.T <= 32 && (d.m + 31) / 32 <= 256) {      // R p and the row bookkeeping in one launch
-        rc = revs_op_dual_product_rows(d.m, d.T, d.Rt, p_in, d.pnq, y, d.vlo, d.vhi, d.ksplit,
-                                       d.v_slabs, d.vfull, d.viol, d.partial, p_out, plan->counters,
-                                       stream);
-        if (rc != REVS_OK) return rc;
-        sel_nblk = (d.m + 31) / 32;
-    } else {
-        rc = revs_gemm_tn_f64_split(d.m, d.T, d.m, d.Rt, p_in, d.v_slabs, d.ksplit, stream);
-        if (rc != REVS_OK) return rc;
-        rc = revs_op_dual_rows(d.m, d.T, d.ksplit, d.v_slabs, d.pnq, y, d.vlo, d.vhi, d.vfull,
-                               d.viol, d.partial, p_out, stream);
+    const bool one_launch = d.T <= 32 && (d.m + 31) / 32 <= 256;
+    const int sel_nblk = one_launch ? (d.m + 31) / 32 : 0;
+    auto product = [&](const double *pin, double *pout) -> int {
+        if (one_launch)                              // R p and the row bookkeeping in one launch
+            return revs_op_dual_product_rows(d.m, d.T, d.Rt, pin, d.pnq, y, d.vlo, d.vhi, d.ksplit,
+                                             d.v_slabs, d.vfull, d.viol, d.partial, pout,
+                                             plan->counters, stream);
+        const int r = revs_gemm_tn_f64_split(d.m, d.T, d.m, d.Rt, pin, d.v_slabs, d.ksplit, stream);
+        if (r != REVS_OK) return r;
+        return revs_op_dual_rows(d.m, d.T, d.ksplit, d.v_slabs, d.pnq, y, d.vlo, d.vhi, d.vfull,
+                                 d.viol, d.partial, pout, stream);
+    };
+    if (!(phase & 4)) {                              // (else: the previous call ran it ahead)
+        rc = product(p_in, p_out);
         if (rc != REVS_OK) return rc;
     }
     if (ev_mid) (void)hipEventRecord((hipEvent_t)ev_mid, s);
@@ -157,6 +161,15 @@ extern "C" int revs_plan_spec_step(revs_plan_t *plan, int32_t phase, const doubl
                                 p_out, fuse_out ? p_est_next : nullptr, sel_nblk, stream);
     if (rc != REVS_OK) return rc;
     if (ev_end) (void)hipEventRecord((hipEvent_t)ev_end, s);
+    if (phase & 8) {
+        // The NEXT iteration's product, before this one's verdict is known: it needs only the
+        // node sums this sweep leaves in p_out, and it keeps the queue from running dry while
+        // the host turns around (a restart costs the stream ~6 us).  It clears the array that
+        // held this evaluation's sums.  If this sweep is discarded it has computed nothing
+        // anyone reads: the caller's next evaluation rewrites every array it touches.
+        rc = product(p_out, const_cast<double *>(p_in));
+        if (rc != REVS_OK) return rc;
+    }
     // Wait for the evaluation, not the sweep: poll the sequence tag the select kernel writes
     // into the pinned stats block of every slot (lower latency than an event wait).
     const volatile double *st = d.stats_host;
@@ -278,12 +291,15 @@ extern "C" int revs_plan_spec_run(revs_plan_t *plan, int32_t max_steps, const do
     *kept_steps = 0;
     *last_fused_in = 0;
     *rmax_out = 0.0;
+    bool ahead = false;                    // this iteration's product is already in the queue
     for (int32_t k = 0; k < max_steps; ++k) {
         const int32_t fused_in = st->fused_ready;
         const double *p_in = fused_in ? st->fused_p : st->p0;
         double *p_out = p_in == st->p0 ? st->p_alt : st->p0;
         double rm = 0.0;
-        const int rc = revs_plan_spec_step(plan, 3, y, 0, st->p_est, st->p_est_new, st->p_sch, st->gamma,
+        const int32_t phase = 3 | (ahead ? 4 : 0) | (k + 1 < max_steps ? 8 : 0);
+        ahead = (phase & 8) != 0;
+        const int rc = revs_plan_spec_step(plan, phase, y, 0, st->p_est, st->p_est_new, st->p_sch, st->gamma,
                                            st->p_sch_alt, st->gamma_alt, nullptr, nullptr, fused_in, p_in,
                                            p_out, st->p_est_alt, &rm, nullptr, nullptr, stream);
         if (rc != REVS_OK) return rc;
