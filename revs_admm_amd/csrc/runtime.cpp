@@ -110,9 +110,9 @@ extern "C" int revs_plan_spec_step(revs_plan_t *plan, int32_t phase, const doubl
                                    float *gamma_out, float *s_out, float *c_out, int32_t fused_in,
                                    const double *p_in, double *p_out, float *p_est_next,
                                    double *rmax_out, void *ev_mid, void *ev_end, void *stream) {
-    REVS_REQUIRE(plan && phase >= 1 && phase <= 15 && (!(phase & 12) || (phase & 2)) && y && p_est &&
-                 p_est_new && p_sch && gamma && p_sch_out && gamma_out && rmax_out && p_in,
-                 "revs_plan_spec_step: bad argument");
+    REVS_REQUIRE(plan && phase >= 1 && phase <= 63 && (!(phase & 28) || (phase & 2)) &&
+                 (!(phase & 32) || phase == 32) && y && p_est && p_est_new && p_sch && gamma &&
+                 p_sch_out && gamma_out && rmax_out && p_in, "revs_plan_spec_step: bad argument");
     REVS_REQUIRE(!(phase & 8) || p_out, "revs_plan_spec_step: running ahead needs p_out");
     const revs_plan_desc_t &d = plan->d;
     const bool fuse_out = p_out != nullptr;
@@ -129,8 +129,9 @@ extern "C" int revs_plan_spec_step(revs_plan_t *plan, int32_t phase, const doubl
                                    d.cand_cnt, d.cand_val, d.stats, 0.0, nullptr, stream);
         if (rc != REVS_OK) return rc;
     }
-    if (!(phase & 2)) return REVS_OK;
-    const double seq = (plan->seq += 1.0);
+    if (!(phase & (2 | 32))) return REVS_OK;
+    const double seq = (phase & 32) ? plan->seq : (plan->seq += 1.0);
+    if (!(phase & 32)) {
     // node sums p_in: this evaluation's (from the home pass above, or from the last fused
     // sweep; all-reduced by a sharded caller between the phases); p_out: where this sweep
     // accumulates the next ones -- never the same array, so that clearing the latter cannot
@@ -169,6 +170,8 @@ extern "C" int revs_plan_spec_step(revs_plan_t *plan, int32_t phase, const doubl
         // anyone reads: the caller's next evaluation rewrites every array it touches.
         rc = product(p_out, const_cast<double *>(p_in));
         if (rc != REVS_OK) return rc;
+    }
+    if (phase & 16) return REVS_OK;          // the caller waits with a phase-32 call
     }
     // Wait for the evaluation, not the sweep: poll the sequence tag the select kernel writes
     // into the pinned stats block of every slot (lower latency than an event wait).

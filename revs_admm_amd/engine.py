@@ -298,6 +298,7 @@ class AdmmEngine:
         self._plan = None
         self._fused_ready = False        # the last kept sweep did the next evaluation's home pass
         self._fused_p = None             # ... and where it left the node sums
+        self._ar_ahead = False           # ... already exchanged between the ranks
         if (cuda and self.op.solver == "newton" and _kernels is None
                 and not os.environ.get("REVS_NO_PLAN")):
             d = _lib.PlanDesc()
@@ -1144,13 +1145,28 @@ class AdmmEngine:
                         ptr(self.Csoc) if write_sc else None, int(fused_in), ptr(p_in), ptr(p_out),
                         ptr(self.P_est_alt), C.byref(rm), evh[0], evh[1],
                         self.stream), "revs_plan_spec_step")
+                ar_ahead = False
                 if self.group is None:
                     call(3)
                 else:                                # home pass, exchange of p, the rest
                     if not fused_in:
                         call(1)
-                    self._allreduce(p_in)            # the only exchange of the iteration
-                    call(2)
+                    if not (fused_in and self._ar_ahead):
+                        self._allreduce(p_in)        # the only exchange of the iteration
+                    self._ar_ahead = False
+                    if p_out is None:
+                        call(2)
+                    else:
+                        # enqueue product and sweep, then -- before waiting for the verdict --
+                        # the exchange of the node sums this sweep leaves for the NEXT
+                        # evaluation: it is stream-ordered behind the sweep, and its host-side
+                        # cost overlaps the sweep instead of standing between two iterations
+                        # (a discarded sweep makes it a wasted, harmless exchange; every rank
+                        # takes the same decisions, so the collectives stay in step)
+                        call(2 | 16)
+                        self._allreduce(p_out)
+                        ar_ahead = True
+                        call(32)
                 fuse_out = p_out is not None
                 kept = rm.value / scale <= o.eps
                 # after a fused home pass the stats carry no dual value: a discarded sweep is
@@ -1158,6 +1174,7 @@ class AdmmEngine:
                 stt = None if (kept or fused_in) else self.stats_host[0].numpy().copy()
                 if kept and fuse_out:
                     self._fused_ready, self._fused_p = True, p_out
+                    self._ar_ahead = ar_ahead
             else:
                 self._dual_launch(self.yd[0], self._y_support, 0, full=False)
                 rec(1)
