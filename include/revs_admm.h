@@ -565,7 +565,11 @@ void revs_plan_destroy(revs_plan_t *plan);
  * p_out, clearing p_in's array): they depend on this sweep only, and the queue does not run
  * dry while the host turns around.  phase bit 2 (value 4): this call's product was enqueued
  * that way by the previous call -- skip it.  If the sweep is discarded the work run ahead is
- * never read: the caller's next evaluation rewrites every array it touched. */
+ * never read: the caller's next evaluation rewrites every array it touched.
+ * For a driver that has to act between the stages (the sharded one exchanges node sums):
+ * phase bit 4 (value 16, with bit 1) returns after the launches without waiting; phase = 32
+ * only waits for the verdict of the launches made last; phase = 64 only enqueues a product
+ * R p_in + rows (clearing p_out) -- the one a later call skips with bit 2. */
 int revs_plan_spec_step(revs_plan_t *plan, int32_t phase, const double *y, int32_t use_y,
                         const float *p_est, float *p_est_new, const float *p_sch,
                         const float *gamma, float *p_sch_out, float *gamma_out,

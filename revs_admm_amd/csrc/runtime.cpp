@@ -104,12 +104,30 @@ extern "C" void revs_plan_destroy(revs_plan_t *plan) {
     delete plan;
 }
 
+// v = R p_in with the row bookkeeping (one launch when the tile form applies); clears p_out.
+static int plan_product(revs_plan_t *plan, const double *y, const double *pin, double *pout,
+                        void *stream) {
+    const revs_plan_desc_t &d = plan->d;
+    if (d.T <= 32 && (d.m + 31) / 32 <= 256)
+        return revs_op_dual_product_rows(d.m, d.T, d.Rt, pin, d.pnq, y, d.vlo, d.vhi, d.ksplit,
+                                         d.v_slabs, d.vfull, d.viol, d.partial, pout, plan->counters,
+                                         stream);
+    const int r = revs_gemm_tn_f64_split(d.m, d.T, d.m, d.Rt, pin, d.v_slabs, d.ksplit, stream);
+    if (r != REVS_OK) return r;
+    return revs_op_dual_rows(d.m, d.T, d.ksplit, d.v_slabs, d.pnq, y, d.vlo, d.vhi, d.vfull, d.viol,
+                             d.partial, pout, stream);
+}
+
 extern "C" int revs_plan_spec_step(revs_plan_t *plan, int32_t phase, const double *y,
                                    int32_t use_y, const float *p_est, float *p_est_new,
                                    const float *p_sch, const float *gamma, float *p_sch_out,
                                    float *gamma_out, float *s_out, float *c_out, int32_t fused_in,
                                    const double *p_in, double *p_out, float *p_est_next,
                                    double *rmax_out, void *ev_mid, void *ev_end, void *stream) {
+    if (phase == 64) {                       // a product run ahead, nothing else
+        REVS_REQUIRE(plan && y && p_in && p_out && p_in != p_out, "revs_plan_spec_step: bad argument");
+        return plan_product(plan, y, p_in, p_out, stream);
+    }
     REVS_REQUIRE(plan && phase >= 1 && phase <= 63 && (!(phase & 28) || (phase & 2)) &&
                  (!(phase & 32) || phase == 32) && y && p_est && p_est_new && p_sch && gamma &&
                  p_sch_out && gamma_out && rmax_out && p_in, "revs_plan_spec_step: bad argument");
@@ -139,14 +157,7 @@ extern "C" int revs_plan_spec_step(revs_plan_t *plan, int32_t phase, const doubl
     const bool one_launch = d.T <= 32 && (d.m + 31) / 32 <= 256;
     const int sel_nblk = one_launch ? (d.m + 31) / 32 : 0;
     auto product = [&](const double *pin, double *pout) -> int {
-        if (one_launch)                              // R p and the row bookkeeping in one launch
-            return revs_op_dual_product_rows(d.m, d.T, d.Rt, pin, d.pnq, y, d.vlo, d.vhi, d.ksplit,
-                                             d.v_slabs, d.vfull, d.viol, d.partial, pout,
-                                             plan->counters, stream);
-        const int r = revs_gemm_tn_f64_split(d.m, d.T, d.m, d.Rt, pin, d.v_slabs, d.ksplit, stream);
-        if (r != REVS_OK) return r;
-        return revs_op_dual_rows(d.m, d.T, d.ksplit, d.v_slabs, d.pnq, y, d.vlo, d.vhi, d.vfull,
-                                 d.viol, d.partial, pout, stream);
+        return plan_product(plan, y, pin, pout, stream);
     };
     if (!(phase & 4)) {                              // (else: the previous call ran it ahead)
         rc = product(p_in, p_out);

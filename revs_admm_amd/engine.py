@@ -299,6 +299,7 @@ class AdmmEngine:
         self._fused_ready = False        # the last kept sweep did the next evaluation's home pass
         self._fused_p = None             # ... and where it left the node sums
         self._ar_ahead = False           # ... already exchanged between the ranks
+        self._prod_ahead = False         # ... and the product on them already enqueued
         if (cuda and self.op.solver == "newton" and _kernels is None
                 and not os.environ.get("REVS_NO_PLAN")):
             d = _lib.PlanDesc()
@@ -1145,7 +1146,8 @@ class AdmmEngine:
                         ptr(self.Csoc) if write_sc else None, int(fused_in), ptr(p_in), ptr(p_out),
                         ptr(self.P_est_alt), C.byref(rm), evh[0], evh[1],
                         self.stream), "revs_plan_spec_step")
-                ar_ahead = False
+                ar_ahead = prod_ahead = False
+                skip_product = fused_in and self._ar_ahead and self._prod_ahead
                 if self.group is None:
                     call(3)
                 else:                                # home pass, exchange of p, the rest
@@ -1153,9 +1155,9 @@ class AdmmEngine:
                         call(1)
                     if not (fused_in and self._ar_ahead):
                         self._allreduce(p_in)        # the only exchange of the iteration
-                    self._ar_ahead = False
+                    self._ar_ahead = self._prod_ahead = False
                     if p_out is None:
-                        call(2)
+                        call(2 | (4 if skip_product else 0))
                     else:
                         # enqueue product and sweep, then -- before waiting for the verdict --
                         # the exchange of the node sums this sweep leaves for the NEXT
@@ -1163,9 +1165,17 @@ class AdmmEngine:
                         # cost overlaps the sweep instead of standing between two iterations
                         # (a discarded sweep makes it a wasted, harmless exchange; every rank
                         # takes the same decisions, so the collectives stay in step)
-                        call(2 | 16)
+                        call(2 | 16 | (4 if skip_product else 0))
                         self._allreduce(p_out)
                         ar_ahead = True
+                        if fused_in:
+                            # ... and the next product behind it (not after an evaluation whose
+                            # stats a discard would continue from: its node sums must survive)
+                            check(self.lib.revs_plan_spec_step(
+                                self._plan, 64, ptr(self.yd[0]), 0, None, None, None, None, None, None,
+                                None, None, 0, ptr(p_out), ptr(p_in), None, None, None, None,
+                                self.stream), "revs_plan_spec_step")
+                            prod_ahead = True
                         call(32)
                 fuse_out = p_out is not None
                 kept = rm.value / scale <= o.eps
@@ -1174,7 +1184,7 @@ class AdmmEngine:
                 stt = None if (kept or fused_in) else self.stats_host[0].numpy().copy()
                 if kept and fuse_out:
                     self._fused_ready, self._fused_p = True, p_out
-                    self._ar_ahead = ar_ahead
+                    self._ar_ahead, self._prod_ahead = ar_ahead, prod_ahead
             else:
                 self._dual_launch(self.yd[0], self._y_support, 0, full=False)
                 rec(1)
