@@ -37,6 +37,7 @@ struct revs_plan {
     hipEvent_t ev;
     double seq;
     uint32_t *counters;     // device, one per 32-row tile: K-split workgroups of R p done
+    double t_launch = 0.0, t_wait = 0.0;   // host time in launches / waiting (REVS_PLAN_TRACE)
 };
 
 // Host-side acceptance test of a chained Newton iteration (engine.py: _chain_launch): the
@@ -139,6 +140,7 @@ extern "C" int revs_plan_spec_step(revs_plan_t *plan, int32_t phase, const doubl
     REVS_REQUIRE(p_out != p_in && (fused_in || p_in == d.pnq),
                  "revs_plan_spec_step: p_in / p_out inconsistent");
     hipStream_t s = (hipStream_t)stream;
+    const auto t_enter = std::chrono::steady_clock::now();
     int rc;
     if ((phase & 1) && !fused_in) {  // home pass of this evaluation (else: the last sweep did it)
         rc = revs_op_dual_evaluate(1, d.m, d.T, d.node_ptr, p_est, p_sch, gamma, d.R, d.Rt, y, use_y,
@@ -188,6 +190,7 @@ extern "C" int revs_plan_spec_step(revs_plan_t *plan, int32_t phase, const doubl
     // into the pinned stats block of every slot (lower latency than an event wait).
     const volatile double *st = d.stats_host;
     const auto t0 = std::chrono::steady_clock::now();
+    plan->t_launch += std::chrono::duration<double, std::micro>(t0 - t_enter).count();
     for (int t = 0; t < d.T; ++t) {
         unsigned spins = 0;
         while (st[8 * t + 5] != seq) {
@@ -204,6 +207,7 @@ extern "C" int revs_plan_spec_step(revs_plan_t *plan, int32_t phase, const doubl
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);
+    plan->t_wait += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     double mx = 0.0;
     for (int t = 0; t < d.T; ++t) mx = st[8 * t] > mx ? st[8 * t] : mx;
     *rmax_out = mx;
@@ -306,6 +310,8 @@ extern "C" int revs_plan_spec_run(revs_plan_t *plan, int32_t max_steps, const do
     *last_fused_in = 0;
     *rmax_out = 0.0;
     bool ahead = false;                    // this iteration's product is already in the queue
+    static const bool trace = getenv("REVS_PLAN_TRACE") != nullptr;
+    const auto tr0 = std::chrono::steady_clock::now();
     for (int32_t k = 0; k < max_steps; ++k) {
         const int32_t fused_in = st->fused_ready;
         const double *p_in = fused_in ? st->fused_p : st->p0;
@@ -329,6 +335,13 @@ extern "C" int revs_plan_spec_run(revs_plan_t *plan, int32_t max_steps, const do
         std::swap(st->p_est, st->p_est_new);
         std::swap(st->p_est_new, st->p_est_alt);
         ++*kept_steps;
+    }
+    if (trace && *kept_steps > 0) {
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr0).count();
+        fprintf(stderr, "[revs_plan_spec_run] %d steps, %.2f us per step on the host; launches %.2f us, "
+                "waiting %.2f us per step\n", *kept_steps, us / *kept_steps, plan->t_launch / *kept_steps,
+                plan->t_wait / *kept_steps);
+        plan->t_launch = plan->t_wait = 0.0;
     }
     return REVS_OK;
 }
