@@ -50,6 +50,9 @@ __device__ __forceinline__ double dual_select_body(const SelectArgs &sa, const i
     int32_t *__restrict__ ccnt = sa.ccnt;
     double *__restrict__ cval = sa.cval, *__restrict__ stats = sa.stats;
     const int tid = threadIdx.x;
+    // inside the sweep's launch these few wavefronts share their SIMDs with the sweep's, which
+    // keep the vector pipe busy, and the host is waiting for their verdict: raised priority
+    if (!EAGER) __builtin_amdgcn_s_setprio(3);
     __shared__ int cnt_s[4];
     __shared__ double red_s[4][4];
     __shared__ double best_v[4];
