@@ -35,7 +35,7 @@ def _worker(rank, world, port, mode, solver, stress, iters, out):
     rp, rd, dmax, conv = e.residuals(1e-4)
     v = e.voltage().numpy().copy()
     np.savez(out.format(rank=rank), d=d, S=S, P=P, lo=lo, hi=hi, res=[rp, rd, dmax], v=v,
-             iters=e.op_iters_hist, spec=e.spec_hist)
+             iters=e.op_iters_hist, spec=e.spec_hist, chain=e.chain_hist)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -45,7 +45,9 @@ def _worker(rank, world, port, mode, solver, stress, iters, out):
     ("relaxed_exact", "admm", 1.3, 3), ("binary", "admm", 1.3, 3),
     # long enough for the steady state: speculative home sweeps kept AND discarded, with only
     # p exchanged in the speculative evaluation
-    ("relaxed_exact", "newton", 1.02, 12)])
+    ("relaxed_exact", "newton", 1.02, 12),
+    # ... and for the binding steady state: Newton iterations enqueued whole, kept and redone
+    ("relaxed_exact", "newton", 1.3, 30)])
 def test_two_ranks_equal_one_rank(tmp_path, mode, solver, stress, iters):
     import torch.multiprocessing as mp
     sys.path.insert(0, HERE)
@@ -72,8 +74,11 @@ def test_two_ranks_equal_one_rank(tmp_path, mode, solver, stress, iters):
     assert np.abs(d2 - d1).max() < 1e-5 and np.abs(S2 - S1).max() < 1e-4
     assert list(r[0]["iters"]) == list(r[1]["iters"])          # ranks stop together
     assert list(r[0]["spec"]) == list(r[1]["spec"]) == list(e.spec_hist)
-    if iters > 3:
+    assert list(r[0]["chain"]) == list(r[1]["chain"]) == list(e.chain_hist)
+    if iters == 12:
         assert e.spec_hist[0] > 0 and e.spec_hist[1] > 0
+    if iters == 30:
+        assert min(e.chain_hist) > 0
     np.testing.assert_allclose(r[0]["res"], [rp, rd, dmax], rtol=1e-4)
     np.testing.assert_allclose(r[0]["res"], r[1]["res"], rtol=0, atol=0)
     # voltage profile R.(aggregate load): identical on both ranks after the all-reduce
