@@ -607,21 +607,21 @@ __global__ __launch_bounds__(kBlock) void residence_kernel(
 // ---- dispatch ---------------------------------------------------------------
 struct Shape { int lpa, spl; };
 static Shape pick_shape(int T) {
-    // REVS_AGENT_SHAPE=LPAxSPL overrides the mapping for T <= 24 (tuning hook)
-    if (T <= 24) {
-        if (const char *e = getenv("REVS_AGENT_SHAPE")) {
+    // REVS_AGENT_SHAPE=LPAxSPL overrides the mapping for T <= 24 and 64 < T <= 96 (tuning
+    // hook; read once: this runs twice per launch on the host's critical path)
+    static const Shape env = [] {
+        Shape e{0, 0};
+        if (const char *v = getenv("REVS_AGENT_SHAPE")) {
             int l = 0, p = 0;
-            if (sscanf(e, "%dx%d", &l, &p) == 2 && l * p >= T &&
-                ((l == 8 && p == 3) || (l == 4 && p == 6) || (l == 2 && p == 12)))
-                return {l, p};
+            if (sscanf(v, "%dx%d", &l, &p) == 2) e = Shape{l, p};
         }
-    } else if (T > 64 && T <= 96) {
-        if (const char *e = getenv("REVS_AGENT_SHAPE")) {
-            int l = 0, p = 0;
-            if (sscanf(e, "%dx%d", &l, &p) == 2 && l * p >= T &&
-                ((l == 32 && p == 3) || (l == 16 && p == 6) || (l == 8 && p == 12)))
-                return {l, p};
-        }
+        return e;
+    }();
+    if (env.lpa > 0 && env.lpa * env.spl >= T) {
+        const int l = env.lpa, p = env.spl;
+        if (T <= 24 && ((l == 8 && p == 3) || (l == 4 && p == 6) || (l == 2 && p == 12))) return env;
+        if (T > 64 && T <= 96 && ((l == 32 && p == 3) || (l == 16 && p == 6) || (l == 8 && p == 12)))
+            return env;
     }
     if (T <= 8) return {8, 1};
     if (T <= 16) return {8, 2};
