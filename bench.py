@@ -48,7 +48,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s ach
 F64_MFMA_PEAK_TFLOPS = 78.6    # MI355X datasheet, dense f64 matrix
 
 
-def agent_bytes_per_home(T, write_sc, pdhg_dual, fused=False):
+def agent_bytes_per_home(T, write_sc, pdhg_dual, fused=False, recompute=False):
     """Algorithmic HBM bytes of revs_agent_step per residence:
     reads LOAD, P_est[k], P_est[k+1], P_sch[k], G[k] (5 profiles) + the 32-byte home
     record; writes P_sch[k+1], G[k+1] (2 profiles) + diff + dsq + status (12 bytes);
@@ -65,6 +65,8 @@ def agent_bytes_per_home(T, write_sc, pdhg_dual, fused=False):
         b += 4 * T + 4 * (T + 1)
     if fused:       # the sweep also does the next operator home pass: node index in, P_est out
         b += 4 + 4 * T
+    if recompute:   # ... and recomputes P_est[k+1] instead of reading it
+        b -= 4 * T
     return b
 
 
@@ -313,7 +315,8 @@ def main():
     if rank == 0:
         warm = (None if eng.pdhg_dual is None else
                 ("full" if eng.pdhg_dual.dim() == 2 else "scalar"))
-        bph = agent_bytes_per_home(args.T, False, warm, fused=bool(getattr(eng, "_fused_ready", False)))
+        bph = agent_bytes_per_home(args.T, False, warm, fused=bool(getattr(eng, "_fused_ready", False)),
+                                   recompute=bool(getattr(eng, "recompute_pe_new", False)))
         bytes_per_launch = bph * n_local
         launch_ms = agent_b2b_ms if agent_b2b_ms is not None else agent_ms
         ach = bytes_per_launch / (launch_ms * 1e-3) / 1e9

@@ -142,6 +142,10 @@ int revs_agent_step_out(int64_t n_homes, int32_t T,
  * p_est_next float[n][T] = max(g0', 0), g0' = (P_est[k+1] + P_sch[k+1])/2 - G[k+1]/kappa, and
  * p_next double[m][T] += node sums of it (ZERO on entry: revs_op_dual_rows can clear it);
  * node_of int32[n] = node of every residence (residences sorted by node).
+ * p_est_new may be NULL when the operator's multipliers are all zero: its answer is then
+ * max(g0, 0), g0 = (P_est[k] + P_sch[k])/2 - G[k]/kappa, a function of three profiles the
+ * sweep reads anyway, and is recomputed (same arithmetic, same bits) instead of loaded --
+ * one input stream less where the sweep is bandwidth-bound.
  * sel_nblk: number of partial blocks the selection folds (0 = revs_op_dual_blocks(m), the
  * count revs_op_dual_select / _rows write; (m + 31) / 32 after revs_op_dual_product_rows). */
 int revs_agent_step_select(int64_t n_homes, int32_t T,
@@ -533,6 +537,8 @@ typedef struct {
     int32_t mode;
     revs_pdhg_t pdhg;
     const int32_t *node_of;      /* node of every residence, or NULL (no fused home pass) */
+    int32_t recompute_pe_new;    /* revs_plan_spec_step with use_y = 0: the sweep does not read
+                                  * p_est_new (see revs_agent_step_select) */
     /* revs_plan_chain_step only (may be zero otherwise): the second set of candidate lists
      * and stats, the model's scratch, and the Newton parameters */
     int64_t *cand_idx1;

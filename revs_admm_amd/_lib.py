@@ -42,7 +42,7 @@ class PlanDesc(C.Structure):
                 ("cost", C.c_void_p), ("homes", C.c_void_p), ("load", C.c_void_p),
                 ("diff", C.c_void_p), ("dsq", C.c_void_p), ("status", C.c_void_p),
                 ("pdhg_dual", C.c_void_p), ("mode", C.c_int32), ("pdhg", PDHG),
-                ("node_of", C.c_void_p),
+                ("node_of", C.c_void_p), ("recompute_pe_new", C.c_int32),
                 ("cand_idx1", C.c_void_p), ("cand_cnt1", C.c_void_p), ("cand_val1", C.c_void_p),
                 ("stats1", C.c_void_p), ("stats1_host", C.c_void_p),
                 ("yhat", C.c_void_p), ("k_full", C.c_void_p), ("info", C.c_void_p),

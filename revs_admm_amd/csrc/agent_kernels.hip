@@ -129,10 +129,14 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
     bool valid[SPL], win[SPL];
     // a lane whose SPL slots all exist moves them as one dwordxSPL per profile
     const bool full = live && (t0 + SPL <= T);
+    // pe_new == NULL (multipliers all zero): the operator's answer max(g0, 0) is recomputed
+    // below from the three profiles it is a function of, instead of being read
+    const bool rec_pen = a.pe_new == nullptr;
+    const float *pen_src = rec_pen ? a.pe_old : a.pe_new;   // (a mapped address for the else branch)
     if (full) {
         ld_pack<SPL>(a.load + row + t0, L);
         ld_pack<SPL>(a.pe_old + row + t0, pe);
-        ld_pack<SPL>(a.pe_new + row + t0, pen);
+        if (!rec_pen) ld_pack<SPL>(a.pe_new + row + t0, pen);
         ld_pack<SPL>(a.ps + row + t0, pso);
         ld_pack<SPL>(a.gam + row + t0, gm);
         ld_pack<SPL>(a.cost + t0, cst);
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
             // out-of-range lanes read element 0 (always mapped) and discard it: straight-line
             // loads instead of one exec-masked branch per element
             const int64_t o = valid[j] ? row + t : 0;
-            const float vL = a.load[o], vpe = a.pe_old[o], vpn = a.pe_new[o], vps = a.ps[o],
+            const float vL = a.load[o], vpe = a.pe_old[o], vpn = pen_src[o], vps = a.ps[o],
                         vg = a.gam[o], vc = a.cost[(t < T) ? t : 0];
             L[j]   = valid[j] ? vL : 0.f;
             pe[j]  = valid[j] ? vpe : 0.f;
@@ -154,6 +158,14 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
             pso[j] = valid[j] ? vps : 0.f;
             gm[j]  = valid[j] ? vg : 0.f;
             cst[j] = (t < T) ? vc : 0.f;
+        }
+    }
+    if (rec_pen) {      // same arithmetic as the folded home pass that would have stored it
+        const double inv_kd = 1.0 / (double)kappa;
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+            const double g0 = 0.5 * ((double)pe[j] + (double)pso[j]) - (double)gm[j] * inv_kd;
+            pen[j] = (valid[j] && g0 > 0.0) ? (float)g0 : 0.f;
         }
     }
     // Every global load of the kernel is issued before the first use of any of them (one
@@ -706,7 +718,7 @@ static int agent_step_impl(int64_t n_homes, int32_t T, const float *cost,
                            float *pe2_out, void *stream) {
     REVS_REQUIRE(n_homes > 0, "revs_agent_step: n_homes=%lld", (long long)n_homes);
     REVS_REQUIRE(T > 0 && T <= REVS_MAX_T, "revs_agent_step: T=%d outside 1..%d", T, REVS_MAX_T);
-    REVS_REQUIRE(cost && homes && load && p_est_old && p_est_new && p_sch && gamma && p_sch_out &&
+    REVS_REQUIRE(cost && homes && load && p_est_old && p_sch && gamma && p_sch_out &&
                  gamma_out && diff && dsq, "revs_agent_step: null pointer argument");
     REVS_REQUIRE(mode >= 0 && mode <= 2, "revs_agent_step: mode=%d", mode);
     REVS_REQUIRE(kappa > 0.f, "revs_agent_step: kappa=%g must be positive", (double)kappa);

@@ -167,7 +167,8 @@ extern "C" int revs_plan_spec_step(revs_plan_t *plan, int32_t phase, const doubl
     }
     if (ev_mid) (void)hipEventRecord((hipEvent_t)ev_mid, s);
     // the candidate selection rides in the sweep's launch (its first T workgroups)
-    rc = revs_agent_step_select(d.n_homes, d.T, d.cost, d.homes, d.load, p_est, p_est_new, p_sch,
+    rc = revs_agent_step_select(d.n_homes, d.T, d.cost, d.homes, d.load, p_est,
+                                (d.recompute_pe_new && !use_y) ? nullptr : p_est_new, p_sch,
                                 gamma, p_sch_out, gamma_out, s_out, c_out, d.diff, d.dsq,
                                 d.status, d.pdhg_dual, (float)d.kappa, d.mode, &d.pdhg, d.m,
                                 d.partial, y, d.vlo, d.vhi, d.kadd, d.vfull, d.viol, d.cand_idx,

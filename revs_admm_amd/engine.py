@@ -298,6 +298,7 @@ class AdmmEngine:
         self._plan = None
         self._fused_ready = False        # the last kept sweep did the next evaluation's home pass
         self._fused_p = None             # ... and where it left the node sums
+        self.recompute_pe_new = False
         self._ar_ahead = False           # ... already exchanged between the ranks
         self._prod_ahead = False         # ... and the product on them already enqueued
         if (cuda and self.op.solver == "newton" and _kernels is None
@@ -319,6 +320,11 @@ class AdmmEngine:
             self.P_est_alt = torch.zeros(n, T, **f32)
             self.p_alt = nz()                         # second buffer of the fused node sums
             d.node_of = ptr(self.node_of_dev)
+            # where the sweep is bandwidth-bound it recomputes the operator's steady-state answer
+            # instead of reading it (same bits; REVS_RECOMPUTE=0/1 overrides the size rule)
+            rec = os.environ.get("REVS_RECOMPUTE")
+            d.recompute_pe_new = int(rec) if rec is not None else int(n * T >= 6_000_000)
+            self.recompute_pe_new = bool(d.recompute_pe_new)
             d.cand_idx1, d.cand_cnt1, d.cand_val1 = (ptr(self.c_idx[1]), ptr(self.c_cnt[1]),
                                                      ptr(self.c_val[1]))
             d.stats1, d.stats1_host = self.stats_dev[1], self.stats_host[1].data_ptr()
@@ -1256,7 +1262,8 @@ class AdmmEngine:
         nb = (M + 31) // 32
         check(self.lib.revs_agent_step_select(
             self.n, T, ptr(self.cost), ptr(self.homes), ptr(self.load), ptr(self.P_est),
-            ptr(self.P_est_new), ptr(self.P_sch), ptr(self.G), ptr(self.P_sch_alt), ptr(self.G_alt),
+            None if self.recompute_pe_new else ptr(self.P_est_new), ptr(self.P_sch), ptr(self.G),
+            ptr(self.P_sch_alt), ptr(self.G_alt),
             None, None, ptr(self.diff), ptr(self.dsq), ptr(self.status),
             ptr(self.pdhg_dual if dual is None else dual),
             self.kappa, self.mode, C.byref(self.pdhg), M, ptr(self.d_part), ptr(self.yd[0]),

@@ -468,7 +468,8 @@ def test_native_step_and_fused_home_pass_change_nothing(gpu_lib, mode, T, monkey
     the next evaluation's home pass folded into the sweep, against the Python-issued
     iteration: same speculation history, same schedules and residuals bit for bit (the
     fused node sums are accumulated with atomics, but with y = 0 nothing depends on their
-    last bits), over a run with kept AND discarded speculative sweeps."""
+    last bits), over a run with kept AND discarded speculative sweeps; also with the sweep
+    recomputing P_est[k+1] from the state instead of loading it."""
     from revs_admm_amd.engine import OperatorOptions
     from revs_admm_amd.synthetic import make_workload
     # (binary schedules at stress 1 keep the rows moving: no steady state; at 0.5 the rows stay slack)
@@ -477,13 +478,16 @@ def test_native_step_and_fused_home_pass_change_nothing(gpu_lib, mode, T, monkey
     w = make_workload(3000 if T <= 24 else 1500, T, n_nodes=100, seed=5,
                       binary_feasible=(mode == "binary"), stress=0.5 if mode == "binary" else 1.02)
     runs = []
-    for plan, fuse in ((True, True), (True, False), (False, False)):
+    # (rec: the sweep recomputes the operator's steady-state answer instead of reading it --
+    # the rule for large problems, forced here)
+    for plan, fuse, rec in ((True, True, "1"), (True, True, "0"), (True, False, "0"), (False, False, "0")):
+        monkeypatch.setenv("REVS_RECOMPUTE", rec)
         if plan:
             monkeypatch.delenv("REVS_NO_PLAN", raising=False)
         else:
             monkeypatch.setenv("REVS_NO_PLAN", "1")
         e = _engine(w, mode, op=OperatorOptions(fuse_home_pass=fuse))
-        assert (e._plan is not None) == plan
+        assert (e._plan is not None) == plan and e.recompute_pe_new == (rec == "1")
         d = e.run(25)
         runs.append((d, e.result(), e.P_est.cpu().numpy(), list(e.spec_hist),
                      [h[0] for h in e.newton_hist]))
