@@ -496,6 +496,80 @@ def utility_kkt(Rn, node_of, g, g0, kappa, vlo, vhi, yv, yb):
     return prim, stat, comp / kappa
 
 
+def utility_solve_dual(Rn, node_of, g0, kappa, vlo, vhi, y0=None, max_iter=80, tol=1e-10, kadd=8,
+                       nonneg=True):
+    """The same operator step (lpsolver.py:163-238) through its dual, slot by slot --
+    about a second where `utility_solve`'s home-space ADMM takes tens of seconds on the
+    121144 feeder, so that golden-feeder trajectories and runs of hundreds of ADMM
+    iterations stay affordable in tests.  The QP is strictly convex, so ANY point carrying
+    a KKT certificate is THE solution: every answer of this routine is certified against the
+    literal problem by `utility_kkt` before it is returned (RuntimeError otherwise -- the
+    caller then falls back to `utility_solve`), and tests/test_oracle.py compares the two
+    solvers directly.
+
+    Per slot, with B = Rn A (rows: constraint nodes, columns: residences) and y the
+    multipliers of the voltage rows (y > 0: at vhi, y < 0: at vlo):
+        g(y) = max(g0 - B^T y / kappa, 0)        (stationarity with the g >= 0 rows)
+    Iteration: working set W = rows with y != 0 plus the `kadd` most violated rows; with
+    the free residences F = {g0 - B^T y / kappa > 0} frozen, the dual restricted to W is
+        max_u>=0  -1/2 u^T K u + c^T u,   K = S B_WF B_WF^T S / kappa,  c = S (B_WF g0_F - b_W)
+    (S = row side +-1, b = vhi / vlo), solved exactly as a non-negative least-squares
+    problem on K's Cholesky factor (duplicated rows make K singular; the sign constraint
+    is what keeps the multipliers of near-identical rows from cancelling).  Repeat until no
+    row is violated and every row with a multiplier sits on its bound.
+    Returns g (N,T), yv (M,T), yb (N,T) -- multipliers in `utility_kkt`'s convention.
+    `nonneg=False` drops the g >= 0 rows: NOT the reference's model, used only as a negative
+    control by the tests (Gurobi's default lb = 0, lpsolver.py:179-180, is easy to miss)."""
+    from scipy.linalg import cholesky, solve_triangular
+    from scipy.optimize import nnls
+    N, T = g0.shape
+    M = Rn.shape[0]
+    B = Rn[:, node_of]                                        # (M,N)
+    Y = np.zeros((M, T)) if y0 is None else np.array(y0, float)
+    G = np.zeros((N, T))
+    scale = max(abs(vlo), abs(vhi), 1e-300)
+    for t in range(T):
+        y, g0t = Y[:, t].copy(), g0[:, t]
+        ok = False
+        for _ in range(max_iter):
+            d = B.T @ y / kappa
+            free = (g0t - d > 0) if nonneg else np.ones(N, bool)
+            g = np.where(free, g0t - d, 0.0)
+            v = B @ g
+            viol = np.where(y == 0, np.maximum(np.maximum(v - vhi, vlo - v), 0.0), 0.0)
+            act = np.where(y > 0, np.abs(v - vhi), np.where(y < 0, np.abs(v - vlo), 0.0))
+            if viol.max() <= tol * scale and act.max() <= tol * scale:
+                ok = True
+                break
+            cand = np.argsort(-viol, kind="stable")[:kadd]
+            W = np.union1d(np.where(y != 0)[0], cand[viol[cand] > tol * scale])
+            up = np.where(y[W] != 0, y[W] > 0, v[W] > vhi)
+            sgn, b = np.where(up, 1.0, -1.0), np.where(up, vhi, vlo)
+            BW = B[np.ix_(W, np.where(free)[0])]
+            K = sgn[:, None] * (BW @ BW.T / kappa) * sgn[None, :]
+            c = sgn * (BW @ g0t[free] - b)
+            K[np.diag_indices_from(K)] += 1e-12 * np.trace(K) / len(W)
+            L = cholesky(K, lower=True)
+            u, _ = nnls(L.T, solve_triangular(L, c, lower=True), maxiter=50 * len(W))
+            y = np.zeros(M)
+            y[W] = sgn * u
+        if not ok:
+            raise RuntimeError(f"utility_solve_dual: slot {t} did not settle")
+        Y[:, t] = y
+        G[:, t] = g
+    if not nonneg:          # (negative control of the tests: no certificate for a wrong model)
+        return G, Y, None
+    yb = -(kappa * (G - g0) + B.T @ Y)                        # multipliers of the g >= 0 rows
+    yb[G > 0] = 0.0
+    prim, stat, comp = utility_kkt(Rn, node_of, G, g0, kappa, vlo, vhi, Y, yb)
+    gs = max(1.0, np.abs(g0).max())
+    # (complementarity is |y| x distance-to-bound: relative to the largest multiplier)
+    if not (prim <= 1e-8 * scale and stat <= 1e-9 * gs
+            and comp <= 1e-8 * max(gs, np.abs(Y).max() / kappa)):
+        raise RuntimeError(f"utility_solve_dual: KKT certificate failed {prim:.2e} {stat:.2e} {comp:.2e}")
+    return G, Y, yb
+
+
 # --------------------------------------------------------------------------
 # ADMM loop
 # --------------------------------------------------------------------------
@@ -511,7 +585,7 @@ class ADMMTrace:
 
 def solve_ADMM(h: Homes, Rn, node_of, cost, kappa=5.0, iter_max=15, vset=1.0,
                vlow=0.95, vhigh=1.05, mode="binary", keep=False, util_eps=1e-11,
-               home_solver=None):
+               home_solver=None, util_method="admm", variant=None):
     """lpsolver.py:242-290.  State starts at zero (lines 244-246).  Each iteration:
       1. operator step from (P_est[k], P_sch[k], G[k])            (lines 256-259)
       2. every home from (P_est[k], P_sch[k], G[k]) -- NOTE the OLD estimate
@@ -530,12 +604,30 @@ def solve_ADMM(h: Homes, Rn, node_of, cost, kappa=5.0, iter_max=15, vset=1.0,
     tr = ADMMTrace(diffs)
     warm = None
     S = C = None
+    y_warm = None
     for k in range(iter_max):
         g0 = utility_g0(P_est, P_sch, G, kappa)
-        P_est_new, info = utility_solve(Rn, node_of, g0, kappa, vlo, vhi, eps=util_eps,
-                                        warm=warm, return_info=True)
-        warm = info["state"]
-        S, C, P_sch_new, status = solver(cost, h, P_est, P_sch, G, kappa)
+        info = None
+        if variant == "no_lb":
+            # NEGATIVE CONTROL (tests only): the operator QP without Gurobi's default lb = 0
+            # (lpsolver.py:179-180) -- a plausible misreading of the reference
+            P_est_new, y_warm, _ = utility_solve_dual(Rn, node_of, g0, kappa, vlo, vhi, y0=y_warm,
+                                                      nonneg=False)
+        elif util_method == "dual":
+            try:
+                P_est_new, y_warm, _ = utility_solve_dual(Rn, node_of, g0, kappa, vlo, vhi, y0=y_warm)
+                info = dict(iters=0)
+            except RuntimeError:
+                y_warm = None
+        if info is None and variant != "no_lb":
+            P_est_new, info = utility_solve(Rn, node_of, g0, kappa, vlo, vhi, eps=util_eps,
+                                            warm=warm, return_info=True)
+            warm = info["state"]
+        info = info or dict(iters=0)
+        # NEGATIVE CONTROL (tests only): homes solved from the NEW estimate P_est[k+1]
+        # instead of P_est[k] (contradicts lpsolver.py:273)
+        pe_for_homes = P_est_new if variant == "new_estimate" else P_est
+        S, C, P_sch_new, status = solver(cost, h, pe_for_homes, P_sch, G, kappa)
         if status is not None and np.ndim(status) and status.dtype == np.int32 and status.any():
             raise RuntimeError("No solution found (lpsolver.py:153-155)")
         check = P_est_new - P_sch_new
@@ -549,6 +641,68 @@ def solve_ADMM(h: Homes, Rn, node_of, cost, kappa=5.0, iter_max=15, vset=1.0,
     if keep:
         return diffs, P_sch, S, C, tr
     return diffs, P_sch, S, C
+
+
+# --------------------------------------------------------------------------
+# centralized problem the distributed scheme decomposes
+# --------------------------------------------------------------------------
+def solve_central_lp(tariff, h: Homes, Rn, node_of, vset, vlow, vhigh, binary=False,
+                     time_limit=120.0):
+    """The network-wide problem whose consensus form the reference's ADMM iterates on:
+        min  sum_h tariff . g_h
+        s.t. every residence's rows of Home (lpsolver.py:83-109: charger window and rating,
+             SOC recursion, init <= s_t <= 1, s_T >= 0.9)   -- the residences' side
+             g >= 0, vlo <= Rn (A g)[:, t] <= vhi per slot (lpsolver.py:179-193) -- the
+             operator's side                                 (consensus: the same g).
+    At a fixed point of lpsolver.py:254-287 the residence minimises (c - G).g over its rows
+    and the operator G.g over the network rows with the same g: the KKT system of this LP.
+    It is the yard-stick of the reference's test-centralopt.py, which compares a stored
+    distributed schedule with `Central(homes, dist, COST, ...)` per residence,
+    dev = 100 (C2 - C1) / C1 (test-centralopt.py:114-116; the `Central` class lives in the
+    reference's un-vendored libs/pySchedEVChargelib).  NOTE lpsolver.solve_central
+    (lpsolver.py:463-502) is a different model (no s_T >= 0.9 row, sign-flipped voltage
+    rows): its optimum is "no charging" and it is not what the ADMM converges to.
+
+    binary=False: chargers relaxed to 0 <= p <= rating (an LP, HiGHS through scipy);
+    binary=True: p = e * rating, e binary (a MILP; small cases only).
+    Returns p (N,T), g (N,T), per-residence cost (N,), total cost."""
+    from scipy import sparse
+    from scipy.optimize import Bounds, LinearConstraint, milp
+    N, T = h.LOAD.shape
+    M = Rn.shape[0]
+    vlo, vhi = voltage_limits(vset, vlow, vhigh)
+    c = np.asarray(tariff, float)
+    win = h.window()
+    Elo, Ehi = energy_bounds(h)
+    # variables x[i,t] = p[i,t] / rating_i in [0, win]
+    rate = np.where(h.ev, h.rating, 0.0)
+    cost = (rate[:, None] * c[None, :]).ravel()
+    ub = win.astype(float).ravel()
+    cons = []
+    # SOC: with p >= 0 the SOC is nondecreasing, so init <= s_t <= 1 and s_T >= 0.9 reduce to
+    # Elo <= sum_t p_t <= Ehi (slot_count_bounds / energy_bounds)
+    rows = np.repeat(np.arange(N), T)
+    Asoc = sparse.csr_matrix((np.repeat(rate, T), (rows, np.arange(N * T))), shape=(N, N * T))
+    cons.append(LinearConstraint(Asoc, Elo, Ehi))
+    # voltage rows per slot: Rn[:, node_of] (LOAD + p)[:, t] in [vlo, vhi]
+    Bm = Rn[:, node_of]                                       # (M,N)
+    base = Bm @ h.LOAD                                        # (M,T)
+    Bs = sparse.csr_matrix(Bm * rate[None, :])
+    sel = [sparse.csr_matrix((np.ones(N), (np.arange(N), np.arange(N) * T + t)), shape=(N, N * T))
+           for t in range(T)]
+    Av = sparse.vstack([Bs @ sel[t] for t in range(T)]).tocsr()
+    cons.append(LinearConstraint(Av, (vlo - base).T.ravel(), (vhi - base).T.ravel()))
+    integrality = (np.ones(N * T) if binary else np.zeros(N * T))
+    r = milp(cost, constraints=cons, bounds=Bounds(0.0, ub), integrality=integrality,
+             options=dict(time_limit=time_limit, presolve=True))
+    if r.x is None:
+        raise RuntimeError(f"solve_central_lp: {r.message}")
+    p = r.x.reshape(N, T) * rate[:, None]
+    g = p + h.LOAD
+    if g.min() < -1e-9:
+        raise RuntimeError("solve_central_lp: g >= 0 violated by the base load")
+    per_home = g @ c
+    return p, g, per_home, float(per_home.sum())
 
 
 # --------------------------------------------------------------------------

@@ -81,8 +81,10 @@ struct GemmBatch {
 // the gridDim.z K-split workgroups of a row tile to finish sums the slabs of its 32 rows and
 // does the row bookkeeping of op_dual_rows_kernel for them on the spot -- v, residual /
 // violation, per-(tile, slot) partials -- so that no separate rows kernel is launched.  The
-// slabs are handed over inside the launch through the agent-wide coherence point (sc1 stores
-// and loads; the workgroup's barrier completes them before it is counted): no fence.
+// slabs are handed over inside the launch through the agent-wide coherence point: sc1
+// (write-through) stores, an explicit s_waitcnt vmcnt(0) in every storing wave, the
+// workgroup barrier, ONE agent-scope counter add per workgroup; the workgroup whose add
+// returns gridDim.z - 1 reads the slabs with sc1 loads behind a barrier.  No L2 write-back.
 struct GemmRows {
     const double *qpart, *y;      // pnq + 2 m T; multipliers
     double vlo, vhi;
@@ -243,10 +245,17 @@ __global__ __launch_bounds__(kGemmWaves * 64) void gemm_tn_kernel(
                 }
             }
         }
+        // ROWS: the slab stores above are handed to another workgroup below.  A barrier does
+        // not drain VMEM (the ISA of this kernel showed `global_store ... sc1; s_barrier;
+        // global_atomic_add` with no wait in between), so every storing wave waits for its own
+        // write-through stores to complete before it joins the barrier that precedes the
+        // counter increment (MI355X_MICROARCH.md, inter-workgroup visibility: sc1 stores +
+        // vmcnt(0) in every storing wave + barrier + one agent-scope add; consumer: sc1 loads
+        // behind the returned add and a barrier).
+        if constexpr (ROWS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
     if constexpr (ROWS && std::is_same_v<T, double>) {
-        // (the loop's last barrier waited for this workgroup's stores: vmcnt(0))
         __shared__ int last_s;
         if (threadIdx.x == 0) {
             const unsigned int old = __hip_atomic_fetch_add(rw.counters + blockIdx.x, 1u, __ATOMIC_RELAXED,

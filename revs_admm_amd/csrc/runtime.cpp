@@ -88,10 +88,14 @@ extern "C" revs_plan_t *revs_plan_create(const revs_plan_desc_t *desc) {
     }
     revs_plan *p = new revs_plan{*desc, nullptr, 0.0, nullptr};
     const size_t nb = sizeof(uint32_t) * ((desc->m + 31) / 32);
-    if (hipEventCreateWithFlags(&p->ev, hipEventDisableTiming) != hipSuccess ||
-        hipMalloc((void **)&p->counters, nb) != hipSuccess ||
-        hipMemset(p->counters, 0, nb) != hipSuccess) {
-        revs::set_error("revs_plan_create: hipEventCreate / hipMalloc failed");
+    hipError_t e = hipEventCreateWithFlags(&p->ev, hipEventDisableTiming);
+    const char *what = "hipEventCreateWithFlags";
+    if (e == hipSuccess) { e = hipMalloc((void **)&p->counters, nb); what = "hipMalloc"; }
+    if (e == hipSuccess) { e = hipMemset(p->counters, 0, nb); what = "hipMemset"; }
+    if (e != hipSuccess) {
+        revs::set_error("revs_plan_create: %s: %s", what, hipGetErrorString(e));
+        if (p->ev) (void)hipEventDestroy(p->ev);
+        if (p->counters) (void)hipFree(p->counters);
         delete p;
         return nullptr;
     }
@@ -201,6 +205,7 @@ extern "C" int revs_plan_spec_step(revs_plan_t *plan, int32_t phase, const doubl
                     return REVS_ELAUNCH;
                 }
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+                    (void)hipStreamSynchronize(s);   // nothing of ours may still be writing
                     revs::set_error("revs_plan_spec_step: timed out waiting for the evaluation");
                     return REVS_ELAUNCH;
                 }
@@ -285,6 +290,7 @@ extern "C" int revs_plan_chain_step(revs_plan_t *plan, const double *y, double *
                     return REVS_ELAUNCH;
                 }
                 if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+                    (void)hipStreamSynchronize(s);
                     revs::set_error("revs_plan_chain_step: timed out waiting for the evaluation");
                     return REVS_ELAUNCH;
                 }

@@ -322,8 +322,8 @@ class AdmmEngine:
             d.node_of = ptr(self.node_of_dev)
             # where the sweep is bandwidth-bound it recomputes the operator's steady-state answer
             # instead of reading it (same bits; REVS_RECOMPUTE=0/1 overrides the size rule)
-            rec = os.environ.get("REVS_RECOMPUTE")
-            d.recompute_pe_new = int(rec) if rec is not None else int(n * T >= 6_000_000)
+            rec = os.environ.get("REVS_RECOMPUTE", "").strip()
+            d.recompute_pe_new = int(rec not in ("0", "false", "no")) if rec else int(n * T >= 6_000_000)
             self.recompute_pe_new = bool(d.recompute_pe_new)
             d.cand_idx1, d.cand_cnt1, d.cand_val1 = (ptr(self.c_idx[1]), ptr(self.c_cnt[1]),
                                                      ptr(self.c_val[1]))
@@ -1262,7 +1262,8 @@ class AdmmEngine:
         nb = (M + 31) // 32
         check(self.lib.revs_agent_step_select(
             self.n, T, ptr(self.cost), ptr(self.homes), ptr(self.load), ptr(self.P_est),
-            None if self.recompute_pe_new else ptr(self.P_est_new), ptr(self.P_sch), ptr(self.G),
+            None if (self.recompute_pe_new and not self._y_support) else ptr(self.P_est_new),
+            ptr(self.P_sch), ptr(self.G),
             ptr(self.P_sch_alt), ptr(self.G_alt),
             None, None, ptr(self.diff), ptr(self.dsq), ptr(self.status),
             ptr(self.pdhg_dual if dual is None else dual),

@@ -146,3 +146,97 @@ def test_golden_distributed_final_is_feasible(golden):
     soc = 0.2 + np.cumsum(P, 1) / 20.0
     np.testing.assert_allclose(z["dis_a90_r4800_SOC"][:, 1:], soc, atol=1e-9)
     np.testing.assert_allclose(z["dis_a90_r4800_P_res"][evi], P + oh.LOAD[evi], atol=1e-9)
+
+
+def test_dual_operator_solver_equals_admm_solver():
+    """utility_solve_dual (working-set dual, certified by utility_kkt) == utility_solve (home-space
+    ADMM on the literal QP) on a state where rows bind and residences are clamped."""
+    w, oh = _wl(200, 6, seed=9, stress=1.6)
+    pe, ps, gm = _state(w, 4)
+    g0 = ro.utility_g0(pe, ps, gm, w.kappa) - 1.0            # some g0 < 0: the lb = 0 rows matter
+    vlo, vhi = ro.voltage_limits(w.vset, w.vlow, w.vhigh)
+    g_admm = ro.utility_solve(w.Rn, w.node_of, g0, w.kappa, vlo, vhi, eps=1e-12, max_iter=200000)
+    g_dual, yv, yb = ro.utility_solve_dual(w.Rn, w.node_of, g0, w.kappa, vlo, vhi)
+    assert (yv != 0).sum() > 0 and ((g_dual == 0) & (g0 < 0)).sum() > 0
+    assert np.abs(g_admm - g_dual).max() < 1e-7
+    # the negative-control variant (no lb) is a different model: it must differ here
+    g_nolb, *_ = ro.utility_solve_dual(w.Rn, w.node_of, g0, w.kappa, vlo, vhi, nonneg=False)
+    assert np.abs(g_nolb - g_dual).max() > 1e-3
+
+
+def test_golden_distributed_trajectory_statistics(golden, feeder_R):
+    """15 iterations on the 121144 feeder against the stored trajectory (267 EV residences x
+    15 iterations, final schedules) on tie-robust statistics -- and two negative controls, each a
+    plausible misreading of lpsolver.py, which MUST fail the same bounds:
+      * homes solved from the new estimate P_est[k+1] instead of P_est[k] (lpsolver.py:273);
+      * the operator QP without Gurobi's default variable lower bound 0 (lpsolver.py:179-180)."""
+    from conftest import golden_homes
+    from helpers import GOLDEN_BOUNDS, golden_trajectory_stats
+    z, fd = golden
+    oh, evi = golden_homes(z, "dis_a90_r4800", 4.8)
+    n = oh.N
+
+    def run(variant):
+        d, P, S, C = ro.solve_ADMM(oh, feeder_R, np.arange(n), z["tariff_shift6"], 5.0, 15, 1.03,
+                                   0.95, 1.05, mode="binary", util_method="dual", variant=variant)
+        return golden_trajectory_stats(d[:, evi], S[evi], z)
+
+    good = run(None)
+    for k, bound in GOLDEN_BOUNDS.items():
+        assert good[k] <= bound, (k, good[k], bound)
+    for variant in ("new_estimate", "no_lb"):
+        bad = run(variant)
+        failed = [k for k, bound in GOLDEN_BOUNDS.items() if bad[k] > bound]
+        assert len(failed) >= 3, (variant, bad)               # not a marginal miss: most of them
+        assert bad["mean"] > 2 * good["mean"] and bad["w1"] > 1.5 * good["w1"]
+
+
+def test_central_lp(golden):
+    """solve_central_lp: (i) with slack voltage rows it is every residence's own cheapest-slot
+    optimum; (ii) with binding rows its answer is feasible and costs more; (iii) it is what the
+    distributed iteration converges to (total cost within 1 % after 600 oracle iterations, from
+    above); (iv) the MILP form (binary chargers) is bounded below by the LP."""
+    w, oh = _wl(120, 12, seed=3, binary_feasible=False, stress=0.3)
+    p, g, per_home, tot = ro.solve_central_lp(w.cost, oh, w.Rn, w.node_of, w.vset, w.vlow, w.vhigh)
+    Elo, _ = ro.energy_bounds(oh)
+    # own optimum: fill the cheapest window slots up to E_lo
+    own = np.zeros(oh.N)
+    for i in np.where(oh.ev)[0]:
+        need, c = Elo[i], 0.0
+        for t in np.argsort(np.where(oh.window()[i], w.cost, np.inf), kind="stable"):
+            take = min(need, oh.rating[i])
+            c += take * w.cost[t]
+            need -= take
+            if need <= 0:
+                break
+        own[i] = c
+    np.testing.assert_allclose(per_home, own + oh.LOAD @ w.cost, rtol=1e-9)
+    w2, oh2 = _wl(120, 12, seed=3, binary_feasible=False, stress=1.2)
+    p2, g2, per2, tot2 = ro.solve_central_lp(w2.cost, oh2, w2.Rn, w2.node_of, w2.vset, w2.vlow, w2.vhigh)
+    vlo, vhi = ro.voltage_limits(w2.vset, w2.vlow, w2.vhigh)
+    A = np.zeros((w2.Rn.shape[0], oh2.N)); A[w2.node_of, np.arange(oh2.N)] = 1
+    v = w2.Rn @ A @ g2
+    assert v.max() <= vhi * (1 + 1e-7) and v.max() >= vhi * (1 - 1e-6)       # rows bind
+    assert (p2.sum(1) >= Elo - 1e-7).all() and (p2 >= -1e-9).all() and (p2[~oh2.window()] == 0).all()
+    assert tot2 > tot * (1 + 1e-4)
+    d, P, S, C = ro.solve_ADMM(oh2, w2.Rn, w2.node_of, w2.cost, w2.kappa, 600, w2.vset, w2.vlow,
+                               w2.vhigh, mode="relaxed", util_method="dual")
+    dev_total = ((P @ w2.cost).sum() - tot2) / tot2
+    assert -1e-3 < dev_total < 0.01, dev_total
+
+
+def test_central_milp_small():
+    """Binary chargers (the reference's home model) in the centralized problem: a MILP through
+    HiGHS; bounded below by its LP relaxation, schedules on/off at full rating, rows respected."""
+    w3, oh3 = _wl(16, 24, seed=5, stress=1.05)
+    pb, gb, perb, totb = ro.solve_central_lp(w3.cost, oh3, w3.Rn, w3.node_of, w3.vset, w3.vlow,
+                                             w3.vhigh, binary=True, time_limit=60)
+    pl, gl, perl, totl = ro.solve_central_lp(w3.cost, oh3, w3.Rn, w3.node_of, w3.vset, w3.vlow, w3.vhigh)
+    assert totb >= totl - 1e-9
+    assert np.isin(np.round(pb / np.where(oh3.ev, oh3.rating, 1.0)[:, None], 6), [0.0, 1.0]).all()
+    nmin, nmax = ro.slot_count_bounds(oh3)
+    non = (pb > 1e-9).sum(1)
+    assert (non >= nmin).all() and (non <= nmax).all()
+    vlo, vhi = ro.voltage_limits(w3.vset, w3.vlow, w3.vhigh)
+    A = np.zeros((w3.Rn.shape[0], oh3.N)); A[w3.node_of, np.arange(oh3.N)] = 1
+    assert (w3.Rn @ A @ gb).max() <= vhi * (1 + 1e-7)
