@@ -637,6 +637,87 @@ typedef struct {
 int revs_plan_chain_run(revs_plan_t *plan, int32_t max_steps, revs_chain_state_t *st,
                         int32_t chain_few, int32_t *kept_steps, void *stream);
 
+/* ---- the feeder as a tree: R p in O(nodes) ------------------------------------------
+ * The reference forms the LinDistFlow sensitivity matrix R = 2 F D F^T densely
+ * (lpsolver.py:17-26) and checks R_res g[:,t] against the limits (lpsolver.py:188-193).  On
+ * a radial feeder R[i][j] = 2 * (sum of r over the edges shared by the root->i and root->j
+ * paths), so v = R p is two tree passes: P_sub(e) = load below edge e, then
+ * v_i = sum over the edges e on the root->i path of 2 r_e P_sub(e).  With the tree nodes in
+ * DFS preorder (a subtree = a contiguous range [j, end_j)) both passes are prefix sums:
+ *     C      = exclusive prefix of the injections                  P_sub(j) = C[end_j] - C[j]
+ *     w'_j   = w_j P_sub(j),  w_j = 2 r(edge to the parent)
+ *     v_j    = sum_{a <= j} w'_a - sum_{a : end_a <= j} w'_a      (= over the ancestors a of j)
+ * the second sum taken from a prefix over the nodes sorted by `end`.  All arrays below live
+ * on the device and are indexed by preorder position, n <= REVS_TREE_MAX:
+ *   src[j]  constraint row (0..m-1) whose node sum p[src][t] is injected at -- and whose
+ *           voltage row is checked at -- position j; -1: a node without residences
+ *   end[j]  one past the last position of j's subtree
+ *   eo[k]   the positions sorted by end (stable)
+ *   cle[j]  number of positions a with end[a] <= j
+ *   w[j]    2 r of the edge from j to its parent
+ * revs_tree_voltage: one workgroup per slot; v_out double[m][T] (rows with src; may be NULL),
+ * rmax_out double[T] = largest violation max(v - vhi, vlo - v, 0) over the checked rows. */
+#define REVS_TREE_MAX 2048
+typedef struct {
+    int32_t n;
+    const int32_t *src, *end, *eo, *cle;
+    const double *w;
+} revs_tree_t;
+int revs_tree_voltage(int32_t m, int32_t T, const revs_tree_t *tree_host, const double *p,
+                      double vlo, double vhi, double *v_out, double *rmax_out, void *stream);
+
+/* ---- RCCL communicator owned by the library ---------------------------------------------
+ * Residences shard over ranks; the only data-path collective is the all-reduce (sum, f64) of
+ * the M x T node sums, enqueued by the library itself on the compute stream between two
+ * sweeps (no host in between, no second stream).  librccl.so.1 is opened at run time
+ * (the copy already mapped into the process, i.e. PyTorch's, when there is one): a
+ * single-GPU process never needs it.  The 128-byte unique id is made on rank 0 and carried
+ * to the other ranks by the caller (any host channel). */
+typedef struct revs_comm revs_comm_t;
+int revs_comm_unique_id(void *id128_out);
+revs_comm_t *revs_comm_create(const void *id128, int32_t rank, int32_t nranks);
+void revs_comm_destroy(revs_comm_t *comm);
+int revs_comm_allreduce_f64(revs_comm_t *comm, double *buf, int64_t count, int32_t op /* 0 sum, 2 max, 3 min */,
+                            void *stream);
+
+/* ---- streaming steady state: one launch per ADMM iteration, no host in the loop ---------
+ * While the operator's multipliers are zero an iteration of lpsolver.py:254-287 is ONE
+ * launch: its first T workgroups judge the voltage rows of the estimate P_est[k+1] the
+ * previous sweep prepared (tree form above, node sums p[0]), every other workgroup solves
+ * its residences from that estimate, updates G, writes the next estimate P_est[k+2] and
+ * accumulates its node sums into p[1]; p[2] is cleared on the way for the launch after.
+ * A launch whose rows are NOT within eps * scale records its sequence number in the plan's
+ * control block, and every later launch returns at once (all workgroups read that word
+ * first) -- so the host can keep the queue full without waiting for any verdict, and
+ * nothing written after a failed verdict has to be undone beyond that one sweep's spare
+ * buffers.  With a communicator set (revs_plan_set_comm) the node sums are all-reduced on
+ * the same stream after every sweep; launches are made in chunks of `chunk` steps and the
+ * decision to go on is taken only on completed chunks, so every rank issues the same
+ * collectives.
+ *   st    roles at entry and, rotated by the kept steps, at return:
+ *         p_est[0] = P_est[k], p_est[1] = P_est[k+1] (prepared by the previous sweep),
+ *         p_est[2] spare;  p_sch[0], gamma[0] current, [1] spare;  p[0] = node sums of
+ *         p_est[1] (already all-reduced), p[1] = ZERO, p[2] = any
+ * Returns after max_steps kept iterations, or after the first whose verdict failed
+ * (*kept_steps < max_steps; the stream has drained; roles are those of the failed
+ * iteration, whose sweep wrote only to the spares). */
+typedef struct {
+    float *p_est[3];
+    float *p_sch[2];
+    float *gamma[2];
+    double *p[3];
+} revs_stream_state_t;
+int revs_plan_set_tree(revs_plan_t *plan, const revs_tree_t *tree_host);
+int revs_plan_set_comm(revs_plan_t *plan, revs_comm_t *comm);
+int revs_plan_stream_run(revs_plan_t *plan, int32_t max_steps, revs_stream_state_t *st,
+                         double scale, double eps, int32_t chunk, int32_t *kept_steps,
+                         double *rmax_last, void *stream);
+/* Bits OR-ed by the sweeps launched through the plan since the last clear: 1 = a residence's
+ * window cannot reach 90 % SOC (the reference prints "No solution found", lpsolver.py:153-155),
+ * 2 = a PDHG residence hit max_iter before its tolerance.  Meaningful after the stream has
+ * been synchronised. */
+int32_t revs_plan_status_flags(revs_plan_t *plan, int32_t clear);
+
 #ifdef __cplusplus
 }
 #endif

@@ -200,7 +200,7 @@ def home_objective(cost, h: Homes, p, p_est, p_sch, gamma, kappa):
     return ((np.asarray(cost)[None, :] - a) * g + 0.5 * kappa * g * g).sum(axis=1)
 
 
-def home_solve_binary(cost, h: Homes, p_est, p_sch, gamma, kappa=5.0):
+def home_solve_binary(cost, h: Homes, p_est, p_sch, gamma, kappa=5.0, tie=None):
     """Exact optimum of the reference's per-residence MIQP (lpsolver.py:44-129).
 
     p_t = e_t * rating with e_t binary and zero outside [start,end); the SOC rows
@@ -219,7 +219,14 @@ def home_solve_binary(cost, h: Homes, p_est, p_sch, gamma, kappa=5.0):
     win = h.window()
     nmin, nmax = slot_count_bounds(h)
     d = np.where(win, delta, np.inf)
-    order = np.argsort(d, axis=1, kind="stable")          # ties -> earlier slot
+    if tie is None:
+        order = np.argsort(d, axis=1, kind="stable")      # ties -> earlier slot
+    else:
+        # another rule among EXACTLY tied slots (Gurobi's is unknown): a numpy Generator
+        # draws the order, "last" prefers the later slot.  Used by the tests to measure how
+        # much of a trajectory statistic is decided by the tie rule alone.
+        sec = -np.arange(h.T)[None, :].repeat(h.N, 0) if tie == "last" else tie.random(d.shape)
+        order = np.lexsort((sec, d), axis=1)
     rank = np.empty_like(order)
     np.put_along_axis(rank, order, np.arange(h.T)[None, :].repeat(h.N, 0), axis=1)
     take = win & ((rank < nmin[:, None]) | ((rank < nmax[:, None]) & (delta < 0)))

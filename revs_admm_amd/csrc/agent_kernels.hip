@@ -22,6 +22,8 @@
 // diff over all homes (the reference's only convergence measure).
 #include "common.h"
 #include "select_body.h"
+#include "tree_body.h"
+#include "internal.h"
 #include <math.h>
 #include <stdlib.h>
 #include <type_traits>
@@ -61,6 +63,21 @@ struct AgentArgs {
     const int32_t *node_of;
     double *p_next;
     float *pe2_out;
+    // Streaming steady state (revs_plan_stream_run).  ctl != NULL: every workgroup first reads
+    // ctl->bad_seq and returns at once when an EARLIER launch's verdict failed (nothing this
+    // launch would write may then be written).  tree.n > 0: the first nsel = T workgroups judge
+    // the voltage rows of slot blockIdx.x from the node sums p_in by the tree form of R p
+    // (tree_body.h) instead of running the candidate selection, clear their share of p_zero,
+    // and the last of them to finish leaves the launch's record {rmax, failed, seq} in `rec`.
+    StreamCtl *ctl;
+    unsigned int seq;
+    TreeArgs tree;
+    const double *p_in;
+    double *p_zero;
+    double vtol;           // eps * scale: the verdict fails when a row is further out
+    double *rec;           // this launch's record slot, double[4] (pinned host memory)
+    unsigned int *flags;   // OR of status bits over all residences (pinned host memory), or NULL
+    int32_t m;
 };
 
 // SPL consecutive floats of one lane as ONE global_load/store_dwordxSPL: the 64 lanes of a
@@ -107,11 +124,48 @@ __device__ __forceinline__ void group_rank(const float (&key)[SPL], int t0, int 
     }
 }
 
+// One slot's verdict inside the streaming sweep's launch (workgroup t < T).
+__device__ __forceinline__ void stream_verdict_body(const AgentArgs &a, const int t) {
+    extern __shared__ double tree_lds[];
+    __builtin_amdgcn_s_setprio(3);       // few wavefronts among the sweep's, and on the critical path
+    const int tid = threadIdx.x;
+    // clear this workgroup's share of the node-sum array the launch AFTER this one accumulates into
+    if (a.p_zero) {
+        const int64_t tot = (int64_t)a.m * a.T, per = (tot + a.nsel - 1) / a.nsel;
+        const int64_t i0 = (int64_t)t * per, i1 = i0 + per < tot ? i0 + per : tot;
+        for (int64_t i = i0 + tid; i < i1; i += kBlock) a.p_zero[i] = 0.0;
+    }
+    const double rmax = tree_rmax(a.tree, a.p_in, a.T, t, a.sel.vlo, a.sel.vhi, tree_lds, nullptr);
+    if (tid != 0) return;
+    if (!(rmax <= a.vtol))
+        __hip_atomic_fetch_min(&a.ctl->bad_seq, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_fetch_max(&a.ctl->rmax_bits, (unsigned long long)__double_as_longlong(rmax),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // both performed before this slot is counted
+    const unsigned int old = __hip_atomic_fetch_add(&a.ctl->arrive, 1u, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT);
+    if (old != (unsigned int)a.nsel - 1) return;
+    // last slot of this launch: the record the host polls, then reset for the next launch
+    const unsigned long long bits = __hip_atomic_load(&a.ctl->rmax_bits, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned int bad = __hip_atomic_load(&a.ctl->bad_seq, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&a.ctl->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&a.ctl->rmax_bits, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    volatile double *rec = a.rec;
+    rec[0] = __longlong_as_double((long long)bits);
+    rec[1] = bad <= a.seq ? 1.0 : 0.0;
+    __threadfence_system();
+    rec[2] = (double)a.seq;
+}
+
 template <int LPA, int SPL, int MODE, bool FULL_ROWS = false>
 __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
     constexpr int kHomesPerBlock = kBlock / LPA;
+    if (a.ctl && a.ctl->bad_seq < a.seq) return;           // an earlier verdict failed: no-op
     if (a.nsel > 0 && (int)blockIdx.x < a.nsel) {          // uniform per workgroup
-        dual_select_body(a.sel, (int)blockIdx.x);
+        if (a.tree.n > 0) stream_verdict_body(a, (int)blockIdx.x);
+        else dual_select_body(a.sel, (int)blockIdx.x);
         return;
     }
     const int bid = (int)blockIdx.x - a.nsel;
@@ -369,7 +423,9 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
         }
 #pragma unroll
         for (int j = 0; j < SPL; ++j) p[j] = (ev && !infeasible) ? x[j] * h.rating : 0.f;
-        status = (iters << 8) | (infeasible ? 1 : 0);
+        // bit 1: the iteration cap was reached before the tolerance (the schedule is then only
+        // as good as max_iter passes make it: surfaced, not silently accepted)
+        status = (iters << 8) | ((ev && !infeasible && !done) ? 2 : 0) | (infeasible ? 1 : 0);
     } else {
         // closed form: p_t = clip(u_t + nu, 0, ub_t), u = -q/kappa; nu is the
         // multiplier of the terminal SOC rows (the only ones that can bind when
@@ -488,6 +544,9 @@ __global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
         a.diff[agent] = dfh;
         a.dsq[agent] = ddg;
         if (a.status) a.status[agent] = status;
+        if (a.flags && (status & 3))         // rare: straight into the host's word
+            __hip_atomic_fetch_or(a.flags, (unsigned int)(status & 3), __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // node sums of the next home pass: residences are sorted by node, so a workgroup's homes
     // sit on a few consecutive nodes -- accumulate in LDS, flush one global add per (node, slot)
@@ -648,18 +707,20 @@ static Shape pick_shape(int T) {
 
 template <int LPA, int SPL>
 static void launch_agent(const AgentArgs &a, int mode, dim3 grid, hipStream_t s) {
+    // dynamic LDS: only a launch whose first workgroups run the tree form of R p needs any
+    const size_t lds = a.tree.n > 0 ? tree_lds_bytes(a.tree.n) : 0;
     switch (mode) {
         case REVS_MODE_BINARY:
-            hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_BINARY>), grid, dim3(kBlock), 0, s, a);
+            hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_BINARY>), grid, dim3(kBlock), lds, s, a);
             break;
         case REVS_MODE_RELAXED_PDHG:
             if (a.pd.full_rows)
-                hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_RELAXED_PDHG, true>), grid, dim3(kBlock), 0, s, a);
+                hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_RELAXED_PDHG, true>), grid, dim3(kBlock), lds, s, a);
             else
-                hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_RELAXED_PDHG, false>), grid, dim3(kBlock), 0, s, a);
+                hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_RELAXED_PDHG, false>), grid, dim3(kBlock), lds, s, a);
             break;
         default:
-            hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_RELAXED_EXACT>), grid, dim3(kBlock), 0, s, a);
+            hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_RELAXED_EXACT>), grid, dim3(kBlock), lds, s, a);
             break;
     }
 }
@@ -715,7 +776,8 @@ static int agent_step_impl(int64_t n_homes, int32_t T, const float *cost,
                            float *dsq, int32_t *status, float *pdhg_dual,
                            float kappa, int32_t mode, const revs_pdhg_t *pdhg_host,
                            const SelectArgs *sel, const int32_t *node_of, double *p_next,
-                           float *pe2_out, void *stream) {
+                           float *pe2_out, void *stream, const StreamExtra *sx = nullptr,
+                           unsigned int *flags = nullptr) {
     REVS_REQUIRE(n_homes > 0, "revs_agent_step: n_homes=%lld", (long long)n_homes);
     REVS_REQUIRE(T > 0 && T <= REVS_MAX_T, "revs_agent_step: T=%d outside 1..%d", T, REVS_MAX_T);
     REVS_REQUIRE(cost && homes && load && p_est_old && p_sch && gamma && p_sch_out &&
@@ -734,6 +796,18 @@ static int agent_step_impl(int64_t n_homes, int32_t T, const float *cost,
     if (sel) { a.nsel = sel->T; a.sel = *sel; }
     a.node_of = node_of; a.p_next = p_next; a.pe2_out = pe2_out;
     REVS_REQUIRE(!p_next || (node_of && pe2_out), "revs_agent_step: node_of / pe2_out missing");
+    a.ctl = nullptr; a.seq = 0; a.tree = TreeArgs{}; a.p_in = nullptr; a.p_zero = nullptr;
+    a.vtol = 0.0; a.rec = nullptr; a.flags = flags; a.m = 0;
+    if (sx) {
+        REVS_REQUIRE(sx->ctl && sx->rec && sx->p_in && sx->tree.n > 0 && sx->tree.n <= REVS_TREE_MAX &&
+                     sx->tree.src && sx->tree.end && sx->tree.eo && sx->tree.cle && sx->tree.w &&
+                     sx->m > 0 && sx->vlo <= sx->vhi && sx->vtol >= 0.0 && !sel,
+                     "revs_agent_step: bad streaming argument");
+        a.ctl = sx->ctl; a.seq = sx->seq; a.tree = sx->tree; a.p_in = sx->p_in; a.p_zero = sx->p_zero;
+        a.vtol = sx->vtol; a.rec = sx->rec; a.flags = sx->flags; a.m = sx->m;
+        a.nsel = T;
+        a.sel.vlo = sx->vlo; a.sel.vhi = sx->vhi;
+    }
     if (pdhg_host) a.pd = *pdhg_host; else revs_pdhg_defaults(&a.pd);
     REVS_REQUIRE(a.pd.max_iter > 0 && a.pd.check > 0 && a.pd.tau_scale >= 0 && a.pd.sigma_scale >= 0,
                  "revs_agent_step: bad PDHG parameters");
@@ -746,6 +820,40 @@ static int agent_step_impl(int64_t n_homes, int32_t T, const float *cost,
     REVS_FOR_SHAPE(sh, CALL);
 #undef CALL
     REVS_CHECK_LAUNCH("revs_agent_step");
+    return REVS_OK;
+}
+
+namespace revs {
+int agent_step_stream(int64_t n_homes, int32_t T, const float *cost, const revs_home_t *homes,
+                      const float *load, const float *p_est_old, const float *p_est_new,
+                      const float *p_sch, const float *gamma, float *p_sch_out, float *gamma_out,
+                      float *diff, float *dsq, int32_t *status, float *pdhg_dual, float kappa,
+                      int32_t mode, const revs_pdhg_t *pdhg_host, const int32_t *node_of,
+                      double *p_next, float *p_est_next, const StreamExtra &sx, void *stream) {
+    return agent_step_impl(n_homes, T, cost, homes, load, p_est_old, p_est_new, p_sch, gamma,
+                           p_sch_out, gamma_out, nullptr, nullptr, diff, dsq, status, pdhg_dual,
+                           kappa, mode, pdhg_host, nullptr, node_of, p_next, p_est_next, stream, &sx);
+}
+
+__global__ __launch_bounds__(256) void tree_voltage_kernel(TreeArgs tr, const double *p, int T,
+                                                           double vlo, double vhi, double *v_out,
+                                                           double *rmax_out) {
+    extern __shared__ double tree_lds[];
+    const double r = tree_rmax(tr, p, T, (int)blockIdx.x, vlo, vhi, tree_lds, v_out);
+    if (threadIdx.x == 0 && rmax_out) rmax_out[blockIdx.x] = r;
+}
+}  // namespace revs
+
+extern "C" int revs_tree_voltage(int32_t m, int32_t T, const revs_tree_t *tree, const double *p,
+                                 double vlo, double vhi, double *v_out, double *rmax_out,
+                                 void *stream) {
+    REVS_REQUIRE(m > 0 && T > 0 && tree && p && tree->n > 0 && tree->n <= REVS_TREE_MAX && tree->src &&
+                 tree->end && tree->eo && tree->cle && tree->w && vlo <= vhi,
+                 "revs_tree_voltage: bad argument (tree nodes <= %d)", REVS_TREE_MAX);
+    const TreeArgs tr{tree->n, tree->src, tree->end, tree->eo, tree->cle, tree->w};
+    hipLaunchKernelGGL(tree_voltage_kernel, dim3(T), dim3(256), tree_lds_bytes(tree->n),
+                       (hipStream_t)stream, tr, p, T, vlo, vhi, v_out, rmax_out);
+    REVS_CHECK_LAUNCH("revs_tree_voltage");
     return REVS_OK;
 }
 

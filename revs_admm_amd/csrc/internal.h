@@ -1,0 +1,29 @@
+// Calls between the translation units of librevs_admm.so that are not part of the C ABI.
+#pragma once
+#include "common.h"
+#include "tree_body.h"
+
+namespace revs {
+
+// What the streaming steady state adds to a sweep's launch (AgentArgs in agent_kernels.hip).
+struct StreamExtra {
+    StreamCtl *ctl;          // control block (device); NULL: an ordinary launch
+    unsigned int seq;
+    TreeArgs tree;           // tree.n > 0: the first T workgroups judge the voltage rows
+    const double *p_in;      // node sums they judge
+    double *p_zero;          // array they clear for the launch after this one (or NULL)
+    double vlo, vhi, vtol;
+    double *rec;             // record slot of this launch (device address of pinned memory)
+    unsigned int *flags;     // status bits (device address of pinned memory) or NULL
+    int32_t m;
+};
+
+// revs_agent_step_select's sweep with the next home pass folded in, plus `sx` (see above).
+int agent_step_stream(int64_t n_homes, int32_t T, const float *cost, const revs_home_t *homes,
+                      const float *load, const float *p_est_old, const float *p_est_new,
+                      const float *p_sch, const float *gamma, float *p_sch_out, float *gamma_out,
+                      float *diff, float *dsq, int32_t *status, float *pdhg_dual, float kappa,
+                      int32_t mode, const revs_pdhg_t *pdhg_host, const int32_t *node_of,
+                      double *p_next, float *p_est_next, const StreamExtra &sx, void *stream);
+
+}  // namespace revs

@@ -1424,6 +1424,27 @@ class AdmmEngine:
             diffs[k] = self.diff.cpu().numpy()[self.inv_perm]
         return diffs
 
+    # ------------------------------------------------------- state in / out
+    def set_state(self, P_est, P_sch, G, iteration=None):
+        """Load (P_est[k], P_sch[k], G[k]) -- the whole state of lpsolver.py:254-287 -- in the
+        caller's home order: resume a run, or continue from somebody else's iterate.  Whatever
+        the engine had prepared ahead for its own state (the next evaluation's home pass and
+        its node sums, an exchanged or multiplied copy of them) is dropped; the operator's
+        multipliers stay as a warm start."""
+        for t, a in ((self.P_est, P_est), (self.P_sch, P_sch), (self.G, G)):
+            a = np.ascontiguousarray(np.asarray(a, np.float32)[self.perm])
+            assert a.shape == (self.n, self.T)
+            t.copy_(torch.from_numpy(a))
+        self._fused_ready = self._ar_ahead = self._prod_ahead = False
+        self._fused_p = None
+        self._chain_ok = False
+        if iteration is not None:
+            self.iteration = int(iteration)
+
+    def get_state(self):
+        """(P_est[k], P_sch[k], G[k]) in the caller's home order."""
+        return self._unsort(self.P_est), self._unsort(self.P_sch), self._unsort(self.G)
+
     # ----------------------------------------------------------- inspection
     def _unsort(self, t):
         return t.cpu().numpy()[self.inv_perm]

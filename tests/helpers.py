@@ -17,15 +17,21 @@ def f32(a):
 # The stored trajectory (out/121144-com2/distributed/adopt90-rating4800-seed1234.txt) cannot be
 # matched per residence beyond iteration 1 (exactly tied MIQP optima), so
 # it is matched on statistics that do not depend on which of several equal-cost slots a
-# residence picked.  Bounds: what the faithful restatement achieves, with a margin, and well
-# below what two plausible misreadings of lpsolver.py produce (tests/test_oracle.py runs both
-# as negative controls):            faithful   homes from P_est[k+1]   operator without lb = 0
-#   mean diff[k], worst k            5.2 %          15.6 %                  22.6 %
-#   sorted-diff distance, worst k    7.7 %          16.4 %                  22.7 %
-#   lower quartile of diff[k]       12.2 %          29.8 %                  27.4 %
-#   EV slots per tariff block        <= 5           <= 12                   <= 12
-#   total EV energy cost             0.08 %         0.48 %                  1.03 %
-GOLDEN_BOUNDS = dict(mean=0.07, w1=0.10, q25=0.17, blocks=8, ev_cost=0.0025)
+# residence picked.  What decides the bounds (tests/test_oracle.py runs all of it on the CPU):
+#   * the faithful restatement under the two CONSISTENT tie rules (earlier / later slot; f64
+#     oracle) and the GPU run (earlier slot, f32) -- three samples of "the reference's model,
+#     some tie rule";
+#   * two plausible misreadings of lpsolver.py as negative controls, under both tie rules.
+#                                  faithful (first | last | GPU)     homes from P_est[k+1]   operator without lb = 0
+#   mean diff[k], worst k           5.2 % | 10.7 % |  8.6 %            15.6 - 15.7 %           22.6 - 25.6 %
+#   sorted-diff distance, worst k   7.7 % | 12.6 % |  9.1 %            16.3 - 16.4 %           22.7 - 25.8 %
+#   lower quartile of diff[k]      12.2 % |  8.1 % | 10.9 %            24.5 - 29.8 %           27.4 - 43.4 %
+#   EV slots per tariff block         5   |    4   |    2                 9 - 12                  7 - 12
+#   total EV energy cost           0.08 % | 0.10 % | 0.23 %            0.41 - 0.48 %           0.72 - 1.03 %
+# (A tie rule that changes from iteration to iteration -- random order among tied slots -- is
+# NOT in the faithful band: mean diff[k] is then off by 200 %.  Whatever Gurobi does with ties,
+# it does the same thing every iteration.)
+GOLDEN_BOUNDS = dict(mean=0.13, w1=0.145, q25=0.18, blocks=6, ev_cost=0.0032)
 
 
 def golden_trajectory_stats(diff_ev, S_ev, z, tag="dis_a90_r4800"):

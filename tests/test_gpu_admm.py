@@ -98,8 +98,12 @@ def test_golden_feeder_admm_statistics(gpu_lib, golden, feeder_R):
     mine = diffs[:, evi].T
     np.testing.assert_allclose(mine[:, 0], ref[:, 0], rtol=2e-6)
     m_ref, m_me = ref.mean(0), mine.mean(0)
-    assert np.abs(m_me - m_ref).max() < 0.1 * m_ref.max()
-    assert np.abs(m_me[1:] / m_ref[1:] - 1).max() < 0.15
+    # (13 %: the faithful model reaches 5.2 - 10.7 % depending on the tie rule, two misreadings
+    # of lpsolver.py 15.6 % and more: helpers.GOLDEN_BOUNDS, tests/test_oracle.py::
+    # test_golden_distributed_trajectory_statistics; the full set of statistics on the GPU run:
+    # tests/test_gpu_config4.py::test_golden_feeder_gpu_trajectory)
+    from helpers import GOLDEN_BOUNDS
+    assert np.abs(m_me / m_ref - 1).max() < GOLDEN_BOUNDS["mean"]
     P_sch, S, C = e.result()
     assert ((S[evi] > 0).sum(1) == 3).all() and (S[~oh.ev] == 0).all()
     np.testing.assert_allclose(C[evi][:, -1], 0.92, atol=1e-5)
