@@ -64,6 +64,21 @@ class ChainState(C.Structure):
                 ("p_sch_alt", C.c_void_p), ("gamma", C.c_void_p), ("gamma_alt", C.c_void_p)]
 
 
+class Tree(C.Structure):
+    """revs_tree_t"""
+    _fields_ = [("n", C.c_int32), ("src", C.c_void_p), ("end", C.c_void_p), ("eo", C.c_void_p),
+                ("cle", C.c_void_p), ("w", C.c_void_p)]
+
+
+class StreamState(C.Structure):
+    """revs_stream_state_t"""
+    _fields_ = [("p_est", C.c_void_p * 3), ("p_sch", C.c_void_p * 2), ("gamma", C.c_void_p * 2),
+                ("p", C.c_void_p * 3)]
+
+
+TREE_MAX = 2048          # REVS_TREE_MAX
+
+
 class RevsError(RuntimeError):
     pass
 
@@ -145,6 +160,15 @@ SIGNATURES = {
                                                 _p, _p, _p, _f64, _p, _p, _f64, _f64, _i32, _p, _p, _p,
                                                 _f64, _f64, _p, _p, _p]),
     "revs_newton_chain_accept": (C.c_int, [_i32, _p, _p, _f64, _f64, _i32, _i32, _i32, _p, _p]),
+    "revs_tree_voltage": (C.c_int, [_i32, _i32, C.POINTER(Tree), _p, _f64, _f64, _p, _p, _p]),
+    "revs_comm_unique_id": (C.c_int, [_p]),
+    "revs_comm_create": (C.c_void_p, [_p, _i32, _i32]),
+    "revs_comm_destroy": (None, [_p]),
+    "revs_comm_allreduce_f64": (C.c_int, [_p, _p, _i64, _i32, _p]),
+    "revs_plan_set_tree": (C.c_int, [_p, C.POINTER(Tree)]),
+    "revs_plan_set_comm": (C.c_int, [_p, _p]),
+    "revs_plan_stream_run": (C.c_int, [_p, _i32, C.POINTER(StreamState), _f64, _f64, _i32, _p, _p, _p]),
+    "revs_plan_status_flags": (_i32, [_p, _i32]),
     "revs_op_dual_step_pending": (C.c_int, [_i32, _p, _p, _p, _p, _p, _f64, _f64, _p, _i32, _p, _p, _p]),
 }
 DUAL_AMAX = 128          # REVS_DUAL_AMAX

@@ -159,8 +159,11 @@ __device__ __forceinline__ void stream_verdict_body(const AgentArgs &a, const in
     rec[2] = (double)a.seq;
 }
 
+// 64 VGPRs = 8 wavefronts per SIMD: the sweep's own path needs 56; the verdict workgroups that
+// share its launch are written to fit the same budget (tree_body.h) and must not lower it.
 template <int LPA, int SPL, int MODE, bool FULL_ROWS = false>
-__global__ __launch_bounds__(kBlock) void agent_step_kernel(const AgentArgs a) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SPL <= 4 && !FULL_ROWS ? 8 : 4)))
+void agent_step_kernel(const AgentArgs a) {
     constexpr int kHomesPerBlock = kBlock / LPA;
     if (a.ctl && a.ctl->bad_seq < a.seq) return;           // an earlier verdict failed: no-op
     if (a.nsel > 0 && (int)blockIdx.x < a.nsel) {          // uniform per workgroup

@@ -1,10 +1,13 @@
 // Error reporting and version string of librevs_admm.so.
 #include "common.h"
+#include "internal.h"
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <chrono>
+#include <cstring>
 
 namespace revs {
 static thread_local char g_err[512] = "";
@@ -32,12 +35,22 @@ extern "C" int revs_host_device_ptr(void *host_ptr, void **dev_ptr) {
 }
 
 // ---- steady-state ADMM iteration as one host call (see revs_admm.h) -------------------
+struct revs_comm;
 struct revs_plan {
     revs_plan_desc_t d;
     hipEvent_t ev;
     double seq;
     uint32_t *counters;     // device, one per 32-row tile: K-split workgroups of R p done
     double t_launch = 0.0, t_wait = 0.0;   // host time in launches / waiting (REVS_PLAN_TRACE)
+    // streaming steady state (revs_plan_stream_run)
+    revs::StreamCtl *ctl = nullptr;        // device
+    double *rec_host = nullptr;            // pinned: double[kRecRing][4] = {rmax, failed, seq, -}
+    double *rec_dev = nullptr;             // its device-side address
+    unsigned int *flags_host = nullptr;    // pinned: OR of the residences' status bits
+    unsigned int *flags_dev = nullptr;
+    unsigned int stream_seq = 0;           // sequence number of the last streaming launch
+    revs::TreeArgs tree{};                 // tree.n == 0: no tree form
+    revs_comm *comm = nullptr;
 };
 
 // Host-side acceptance test of a chained Newton iteration (engine.py: _chain_launch): the
@@ -99,13 +112,41 @@ extern "C" revs_plan_t *revs_plan_create(const revs_plan_desc_t *desc) {
         delete p;
         return nullptr;
     }
+    // control block, record ring and status word of the streaming steady state
+    const revs::StreamCtl ctl0{~0u, 0u, 0ull};
+    void *host = nullptr;
+    what = "hipMalloc";
+    e = hipMalloc((void **)&p->ctl, sizeof(revs::StreamCtl));
+    if (e == hipSuccess) { e = hipMemcpy(p->ctl, &ctl0, sizeof(ctl0), hipMemcpyHostToDevice); what = "hipMemcpy"; }
+    if (e == hipSuccess) {
+        e = hipHostMalloc(&host, sizeof(double) * 4 * revs::kRecRing + 64, hipHostMallocMapped);
+        what = "hipHostMalloc";
+    }
+    if (e == hipSuccess) {
+        p->rec_host = (double *)host;
+        p->flags_host = (unsigned int *)(p->rec_host + 4 * revs::kRecRing);
+        for (int i = 0; i < 4 * revs::kRecRing; ++i) p->rec_host[i] = -1.0;
+        *p->flags_host = 0u;
+        void *dp = nullptr;
+        e = hipHostGetDevicePointer(&dp, host, 0);
+        what = "hipHostGetDevicePointer";
+        p->rec_dev = (double *)dp;
+        p->flags_dev = (unsigned int *)(p->rec_dev + 4 * revs::kRecRing);
+    }
+    if (e != hipSuccess) {
+        revs::set_error("revs_plan_create: %s: %s", what, hipGetErrorString(e));
+        revs_plan_destroy(p);
+        return nullptr;
+    }
     return p;
 }
 
 extern "C" void revs_plan_destroy(revs_plan_t *plan) {
     if (!plan) return;
-    (void)hipEventDestroy(plan->ev);
-    (void)hipFree(plan->counters);
+    if (plan->ev) (void)hipEventDestroy(plan->ev);
+    if (plan->counters) (void)hipFree(plan->counters);
+    if (plan->ctl) (void)hipFree(plan->ctl);
+    if (plan->rec_host) (void)hipHostFree(plan->rec_host);
     delete plan;
 }
 
@@ -376,4 +417,232 @@ extern "C" int revs_plan_chain_run(revs_plan_t *plan, int32_t max_steps, revs_ch
         ++*kept_steps;
     }
     return REVS_OK;
+}
+
+
+// ---- RCCL communicator owned by the library (see revs_admm.h) ---------------------------
+// librccl.so.1 is opened at run time: the copy already mapped into the process when there is
+// one (PyTorch's), else the system's.  Only the handful of entry points used here is bound.
+struct Id128 { char b[128]; };          // ncclUniqueId: 128 bytes, passed by value
+namespace {
+struct Rccl {
+    void *h = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, Id128, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+}  // namespace
+static Rccl g_rccl;
+
+static bool rccl_load() {
+    if (g_rccl.h) return true;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW);
+    if (!h) {
+        revs::set_error("revs_comm: cannot open librccl.so.1: %s", dlerror());
+        return false;
+    }
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce) {
+        revs::set_error("revs_comm: librccl.so.1 lacks an expected entry point");
+        return false;
+    }
+    g_rccl.h = h;
+    return true;
+}
+
+struct revs_comm {
+    void *nccl;
+    int rank, nranks;
+};
+
+extern "C" int revs_comm_unique_id(void *id128_out) {
+    REVS_REQUIRE(id128_out, "revs_comm_unique_id: null argument");
+    if (!rccl_load()) return REVS_ELAUNCH;
+    const int rc = g_rccl.GetUniqueId(id128_out);
+    if (rc != 0) {
+        revs::set_error("ncclGetUniqueId: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+        return REVS_ELAUNCH;
+    }
+    return REVS_OK;
+}
+
+extern "C" revs_comm_t *revs_comm_create(const void *id128, int32_t rank, int32_t nranks) {
+    if (!id128 || nranks < 1 || rank < 0 || rank >= nranks) {
+        revs::set_error("revs_comm_create: bad argument");
+        return nullptr;
+    }
+    if (!rccl_load()) return nullptr;
+    Id128 id;
+    memcpy(id.b, id128, sizeof(id.b));
+    void *c = nullptr;
+    const int rc = g_rccl.CommInitRank(&c, nranks, id, rank);
+    if (rc != 0 || !c) {
+        revs::set_error("ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+        return nullptr;
+    }
+    return new revs_comm{c, rank, nranks};
+}
+
+extern "C" void revs_comm_destroy(revs_comm_t *comm) {
+    if (!comm) return;
+    if (g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm->nccl);
+    delete comm;
+}
+
+extern "C" int revs_comm_allreduce_f64(revs_comm_t *comm, double *buf, int64_t count, int32_t op,
+                                       void *stream) {
+    REVS_REQUIRE(comm && buf && count > 0 && (op == 0 || op == 2 || op == 3),
+                 "revs_comm_allreduce_f64: bad argument");
+    // ncclFloat64 = 8; ncclSum / ncclMax / ncclMin = 0 / 2 / 3 (rccl.h)
+    const int rc = g_rccl.AllReduce(buf, buf, (size_t)count, 8, op, comm->nccl, (hipStream_t)stream);
+    if (rc != 0) {
+        revs::set_error("ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+        return REVS_ELAUNCH;
+    }
+    return REVS_OK;
+}
+
+// ---- streaming steady state (see revs_admm.h) ------------------------------------------
+extern "C" int revs_plan_set_tree(revs_plan_t *plan, const revs_tree_t *t) {
+    REVS_REQUIRE(plan, "revs_plan_set_tree: null plan");
+    if (!t || t->n == 0) { plan->tree = revs::TreeArgs{}; return REVS_OK; }
+    REVS_REQUIRE(t->n > 0 && t->n <= REVS_TREE_MAX && t->src && t->end && t->eo && t->cle && t->w,
+                 "revs_plan_set_tree: bad tree (at most %d nodes)", REVS_TREE_MAX);
+    plan->tree = revs::TreeArgs{t->n, t->src, t->end, t->eo, t->cle, t->w};
+    return REVS_OK;
+}
+
+extern "C" int revs_plan_set_comm(revs_plan_t *plan, revs_comm_t *comm) {
+    REVS_REQUIRE(plan, "revs_plan_set_comm: null plan");
+    plan->comm = comm;
+    return REVS_OK;
+}
+
+extern "C" int32_t revs_plan_status_flags(revs_plan_t *plan, int32_t clear) {
+    if (!plan || !plan->flags_host) return 0;
+    const unsigned int f = *(volatile unsigned int *)plan->flags_host;
+    if (clear) *(volatile unsigned int *)plan->flags_host = 0u;
+    return (int32_t)f;
+}
+
+// Wait for the record of launch `seq`; 0 = kept, 1 = its verdict failed, < 0 = error.
+static int stream_wait(revs_plan_t *plan, unsigned int seq, hipStream_t s, double *rmax) {
+    const volatile double *r = plan->rec_host + 4 * (seq % revs::kRecRing);
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (r[2] != (double)seq) {
+        if ((++spins & 0xFFFF) == 0) {
+            if (hipStreamQuery(s) == hipSuccess && r[2] != (double)seq) {
+                revs::set_error("revs_plan_stream_run: stream idle but record %u missing", seq);
+                return REVS_ELAUNCH;
+            }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+                (void)hipStreamSynchronize(s);
+                revs::set_error("revs_plan_stream_run: timed out waiting for record %u", seq);
+                return REVS_ELAUNCH;
+            }
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    *rmax = r[0];
+    return r[1] != 0.0 ? 1 : 0;
+}
+
+extern "C" int revs_plan_stream_run(revs_plan_t *plan, int32_t max_steps, revs_stream_state_t *st,
+                                    double scale, double eps, int32_t chunk, int32_t *kept_steps,
+                                    double *rmax_last, void *stream) {
+    REVS_REQUIRE(plan && st && kept_steps && rmax_last && max_steps >= 0 && scale > 0.0 && eps > 0.0 &&
+                 chunk >= 1 && 2 * chunk < revs::kRecRing, "revs_plan_stream_run: bad argument");
+    const revs_plan_desc_t &d = plan->d;
+    REVS_REQUIRE(plan->tree.n > 0 && d.node_of, "revs_plan_stream_run: the plan has no tree / node_of");
+    for (int i = 0; i < 3; ++i)
+        REVS_REQUIRE(st->p_est[i] && st->p[i] && (i == 2 || (st->p_sch[i] && st->gamma[i])),
+                     "revs_plan_stream_run: null buffer");
+    REVS_REQUIRE(st->p[0] != st->p[1] && st->p[1] != st->p[2] && st->p[0] != st->p[2] &&
+                 st->p_est[0] != st->p_est[1] && st->p_est[1] != st->p_est[2] && st->p_est[0] != st->p_est[2] &&
+                 st->p_sch[0] != st->p_sch[1] && st->gamma[0] != st->gamma[1],
+                 "revs_plan_stream_run: buffers must be distinct");
+    hipStream_t s = (hipStream_t)stream;
+    *kept_steps = 0;
+    *rmax_last = 0.0;
+    if (max_steps == 0) return REVS_OK;
+    // a failed verdict of an earlier call must not silence this one: re-arm the control block
+    // (the previous call drained the stream before it returned, so nothing is in flight)
+    const revs::StreamCtl ctl0{~0u, 0u, 0ull};
+    if (hipMemcpyAsync(plan->ctl, &ctl0, sizeof(ctl0), hipMemcpyHostToDevice, s) != hipSuccess) {
+        revs::set_error("revs_plan_stream_run: hipMemcpyAsync failed");
+        return REVS_ELAUNCH;
+    }
+    const unsigned int seq0 = plan->stream_seq + 1;
+    const int64_t mt = (int64_t)d.m * d.T;
+    auto launch = [&](int k) -> int {               // step k of this call (roles by rotation)
+        revs::StreamExtra sx;
+        sx.ctl = plan->ctl;
+        sx.seq = seq0 + (unsigned int)k;
+        sx.tree = plan->tree;
+        sx.p_in = st->p[k % 3];
+        sx.p_zero = st->p[(k + 2) % 3];
+        sx.vlo = d.vlo; sx.vhi = d.vhi; sx.vtol = eps * scale;
+        sx.rec = plan->rec_dev + 4 * (sx.seq % revs::kRecRing);
+        sx.flags = plan->flags_dev;
+        sx.m = d.m;
+        double *p_next = st->p[(k + 1) % 3];
+        int rc = revs::agent_step_stream(
+            d.n_homes, d.T, d.cost, d.homes, d.load, st->p_est[k % 3],
+            d.recompute_pe_new ? nullptr : st->p_est[(k + 1) % 3], st->p_sch[k % 2], st->gamma[k % 2],
+            st->p_sch[(k + 1) % 2], st->gamma[(k + 1) % 2], d.diff, d.dsq, d.status, d.pdhg_dual,
+            (float)d.kappa, d.mode, &d.pdhg, d.node_of, p_next, st->p_est[(k + 2) % 3], sx, stream);
+        if (rc != REVS_OK) return rc;
+        if (plan->comm) rc = revs_comm_allreduce_f64(plan->comm, p_next, mt, 0, stream);
+        return rc;
+    };
+    // Launch in chunks; go on to chunk c only when every record of chunk c - 2 is in and none
+    // failed.  The decision depends on verdicts alone, never on timing: every rank of a
+    // sharded run makes the same launches and the same collectives.
+    int launched = 0, checked = 0, failed_at = -1, rc = REVS_OK;
+    double rm = 0.0;
+    const int nchunks = (max_steps + chunk - 1) / chunk;
+    for (int c = 0; c < nchunks && failed_at < 0; ++c) {
+        if (c >= 2) {
+            const int upto = (c - 1) * chunk;            // records of chunks <= c - 2
+            for (; checked < upto && failed_at < 0; ++checked) {
+                const int v = stream_wait(plan, seq0 + (unsigned int)checked, s, &rm);
+                if (v < 0) { rc = v; goto out; }
+                if (v == 1) failed_at = checked;
+            }
+            if (failed_at >= 0) break;
+        }
+        const int end = std::min(max_steps, (c + 1) * chunk);
+        for (; launched < end; ++launched)
+            if ((rc = launch(launched)) != REVS_OK) goto out;
+    }
+    for (; checked < launched && failed_at < 0; ++checked) {
+        const int v = stream_wait(plan, seq0 + (unsigned int)checked, s, &rm);
+        if (v < 0) { rc = v; goto out; }
+        if (v == 1) failed_at = checked;
+    }
+out:
+    plan->stream_seq = seq0 + (unsigned int)std::max(launched, 1) - 1;
+    *rmax_last = rm;
+    const int kept = rc != REVS_OK ? 0 : (failed_at >= 0 ? failed_at : launched);
+    if (failed_at >= 0 || rc != REVS_OK)
+        (void)hipStreamSynchronize(s);                   // the launches behind the failed one are no-ops
+    *kept_steps = kept;
+    // rotate the roles by the kept steps
+    if (kept > 0) {
+        revs_stream_state_t r = *st;
+        for (int i = 0; i < 3; ++i) { r.p_est[i] = st->p_est[(kept + i) % 3]; r.p[i] = st->p[(kept + i) % 3]; }
+        for (int i = 0; i < 2; ++i) { r.p_sch[i] = st->p_sch[(kept + i) % 2]; r.gamma[i] = st->gamma[(kept + i) % 2]; }
+        *st = r;
+    }
+    return rc;
 }

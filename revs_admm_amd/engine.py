@@ -100,6 +100,12 @@ class OperatorOptions:
     # One GPU, multipliers all zero: the speculative sweep also does the home pass of the NEXT
     # operator evaluation (one pass over the homes per ADMM iteration instead of two).
     fuse_home_pass: bool = True
+    # How the steady state judges the voltage rows of an estimate: "dense" = the f64 matrix-core
+    # product R p (always possible); "tree" = two tree passes over the radial feeder, O(nodes)
+    # instead of O(nodes^2), inside the sweep's own launch (needs the feeder: `feeder=` of
+    # AdmmEngine); "auto" = tree when a feeder of at most REVS_TREE_MAX nodes was given.
+    voltage: str = "auto"
+    stream_chunk: int = 4        # streaming steady state: launches per chunk (see revs_plan_stream_run)
 
 
 def _dev_check(device):
@@ -107,6 +113,62 @@ def _dev_check(device):
         raise _lib.RevsError("revs_admm_amd needs a ROCm GPU (torch.cuda.is_available() is "
                              "False); there is no CPU fallback")
     return torch.device(device)
+
+
+def feeder_tree(parent, edge_r, cons_of, checked):
+    """Host-side preparation of revs_tree_t: the feeder's nodes in DFS preorder.
+
+    parent[i]   parent of tree node i, -1 when i hangs off the substation (a forest is fine)
+    edge_r[i]   resistance of the edge from i to its parent
+    cons_of[i]  constraint row (0..M-1) of node i, or -1
+    checked[r]  whether row r is constrained (it carries residences, lpsolver.py:188-189)
+    Returns dict(n, src, end, eo, cle, w) of numpy arrays (see include/revs_admm.h)."""
+    parent = np.asarray(parent, np.int64)
+    n = len(parent)
+    kids = [[] for _ in range(n)]
+    roots = []
+    for i in range(n):
+        (roots if parent[i] < 0 else kids[parent[i]]).append(i)
+    order, size = [], np.ones(n, np.int64)
+    stack = [(r, False) for r in reversed(roots)]
+    while stack:
+        u, done = stack.pop()
+        if done:
+            for c in kids[u]:
+                size[u] += size[c]
+            continue
+        order.append(u)
+        stack.append((u, True))
+        stack.extend((c, False) for c in reversed(kids[u]))
+    if len(order) != n:
+        raise ValueError("feeder: parent[] does not describe a forest")
+    order = np.asarray(order, np.int64)
+    pos = np.empty(n, np.int64)
+    pos[order] = np.arange(n)
+    end = (pos + size)[order]                                  # by preorder position
+    cons = np.asarray(cons_of, np.int64)[order]
+    chk = np.asarray(checked, bool)
+    src = np.where((cons >= 0) & chk[np.maximum(cons, 0)], cons, -1)
+    eo = np.argsort(end, kind="stable")
+    cle = np.searchsorted(end[eo], np.arange(n), side="right")
+    w = 2.0 * np.asarray(edge_r, np.float64)[order]
+    return dict(n=n, src=src.astype(np.int32), end=end.astype(np.int32), eo=eo.astype(np.int32),
+                cle=cle.astype(np.int32), w=w)
+
+
+def tree_voltage_host(tree, p):
+    """numpy restatement of the three prefix sums (tests, and the constructor's check that the
+    feeder reproduces Rn): v at the checked rows, indexed like p."""
+    n, src = tree["n"], tree["src"]
+    inj = np.where(src >= 0, 1.0, 0.0)[:, None] * p[np.maximum(src, 0)]
+    C = np.concatenate([np.zeros((1, p.shape[1])), np.cumsum(inj, 0)])
+    wp = tree["w"][:, None] * (C[tree["end"]] - C[:-1])
+    pre = np.cumsum(wp, 0)
+    F = np.concatenate([np.zeros((1, p.shape[1])), np.cumsum(wp[tree["eo"]], 0)])
+    v = pre - F[tree["cle"]]
+    out = np.zeros_like(p)
+    out[src[src >= 0]] = v[src >= 0]
+    return out
 
 
 class AdmmEngine:
@@ -120,12 +182,17 @@ class AdmmEngine:
     node_of   (n,)   constraint-node index of each residence (0..M-1)
     Rn        (M,M)  LinDistFlow matrix restricted to the constraint nodes
     group            torch.distributed process group when residences are sharded
+    feeder           optional (parent, edge_r, cons_of): the radial feeder behind Rn as a tree --
+                     parent[i] (-1: hangs off the substation), resistance of the edge to the
+                     parent, constraint row of tree node i (or -1).  With it the steady state
+                     evaluates R p in O(nodes) (OperatorOptions.voltage); the constructor checks
+                     that the tree reproduces Rn.
     """
 
     def __init__(self, cost, homes, load, node_of, Rn, kappa=5.0, vset=1.0, vlow=0.95,
                  vhigh=1.05, mode="binary", device="cuda:0", pdhg=None,
                  op: OperatorOptions | None = None, group=None, node_counts=None,
-                 pdhg_warm=True, _kernels=None):
+                 pdhg_warm=True, feeder=None, _kernels=None):
         if _kernels is None:
             self.lib = _lib.load()               # raises when the HIP library is missing
             self.dev = _dev_check(device)        # raises without a GPU
@@ -335,6 +402,44 @@ class AdmmEngine:
             if not self._plan:
                 raise _lib.RevsError("revs_plan_create failed: "
                                      + self.lib.revs_last_error().decode())
+        # third node-sum buffer and the feeder as a tree: streaming steady state
+        self.p_alt2 = nz()
+        self._tree = None
+        self._comm = None
+        if feeder is not None and self.op.voltage in ("auto", "tree"):
+            par, er, cons = feeder
+            if len(par) <= _lib.TREE_MAX:
+                tr = feeder_tree(par, er, cons, counts > 0)
+                probe = np.random.default_rng(0).uniform(0.5, 1.5, (M, 2)) * (counts > 0)[:, None]
+                ref = (Rn @ probe) * (counts > 0)[:, None]
+                got = tree_voltage_host(tr, probe)
+                if np.abs(got - ref).max() > 1e-9 * max(np.abs(ref).max(), 1e-300):
+                    raise ValueError("feeder: the tree does not reproduce Rn (R[i][j] = 2 x the "
+                                     "resistance shared by the substation->i and ->j paths)")
+                self._tree_host = tr
+                self._tree_dev = {k: up(v) for k, v in tr.items() if k != "n"}
+                self._tree = _lib.Tree(tr["n"], *[ptr(self._tree_dev[k]) for k in ("src", "end", "eo", "cle", "w")])
+                if self._plan is not None:
+                    check(self.lib.revs_plan_set_tree(self._plan, C.byref(self._tree)),
+                          "revs_plan_set_tree")
+            elif self.op.voltage == "tree":
+                raise ValueError(f"feeder has {len(par)} nodes; the tree form holds {_lib.TREE_MAX}")
+        elif self.op.voltage == "tree":
+            raise ValueError('OperatorOptions(voltage="tree") needs feeder=')
+        if group is not None and cuda and _kernels is None and not os.environ.get("REVS_NO_COMM"):
+            # the library's own RCCL communicator: unique id from rank 0 over the caller's group
+            ws, rk = torch.distributed.get_world_size(group), torch.distributed.get_rank(group)
+            idb = (C.c_char * 128)()
+            if rk == 0:
+                check(self.lib.revs_comm_unique_id(idb), "revs_comm_unique_id")
+            idt = torch.frombuffer(bytearray(idb.raw), dtype=torch.uint8).to(self.dev)
+            torch.distributed.broadcast(idt, src=torch.distributed.get_global_rank(group, 0), group=group)
+            raw = bytes(idt.cpu().numpy().tobytes())
+            self._comm = self.lib.revs_comm_create(raw, rk, ws)
+            if not self._comm:
+                raise _lib.RevsError("revs_comm_create failed: " + self.lib.revs_last_error().decode())
+            if self._plan is not None:
+                check(self.lib.revs_plan_set_comm(self._plan, self._comm), "revs_plan_set_comm")
         # R (float) for the voltage check
         self.R32 = up(Rn.astype(np.float32))
         self.node_load = torch.zeros(M, T, **f32)
@@ -424,9 +529,18 @@ class AdmmEngine:
             check(rc, "revs_gemm_tn_f64_x2")
 
     def _allreduce(self, t, op=None):
-        if self.group is not None:
-            torch.distributed.all_reduce(
-                t, op=op or torch.distributed.ReduceOp.SUM, group=self.group)
+        if self.group is None:
+            return
+        RO = torch.distributed.ReduceOp
+        if (getattr(self, "_comm", None) and t.dtype == torch.float64 and t.is_contiguous()
+                and op in (None, RO.SUM, RO.MAX, RO.MIN)):
+            # the library's own RCCL communicator, on the compute stream: no second stream, no
+            # event hand-over (torch.distributed keeps only the bootstrap of the unique id)
+            code = 0 if op in (None, RO.SUM) else (2 if op == RO.MAX else 3)
+            check(self.lib.revs_comm_allreduce_f64(self._comm, ptr(t), t.numel(), code, self.stream),
+                  "revs_comm_allreduce_f64")
+            return
+        torch.distributed.all_reduce(t, op=op or RO.SUM, group=self.group)
 
     # -------------------------------------------------------------- operator
     def _home_pass(self, with_update: bool, check: bool = False, reduce: bool = True):
@@ -1110,6 +1224,7 @@ class AdmmEngine:
                                               ptr(self.resid), self.stream),
               "revs_residual_finalize")
         r = self.resid.cpu().numpy().astype(np.float64)
+        self.check_status()
         if self.group is not None:
             t = torch.tensor([r[0] ** 2, r[1] ** 2], dtype=torch.float64, device=self.dev)
             self._allreduce(t)
@@ -1125,6 +1240,9 @@ class AdmmEngine:
         (bench.py's per-kernel timing; [0] is the caller's: the previous step's [2])."""
         rec = (lambda i: events[i].record()) if events else (lambda i: None)
         o = self.op
+        if not write_sc and not events and self._fused_ready and self._stream_ok():
+            self._stream_run(1)              # steady state: one launch, verdict inside it
+            return
         if o.solver == "newton" and o.speculate and self._spec_ok:
             # steady state: the multipliers of the last iteration are expected to stand
             scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
@@ -1358,6 +1476,13 @@ class AdmmEngine:
         o, done = self.op, 0
         scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
         while done < count:
+            if self._stream_ok():
+                if not self._fused_ready:            # entry: one step of the general driver
+                    self.step(write_sc=False)
+                    done += 1
+                else:
+                    done += self._stream_run(count - done)
+                continue
             native = self._plan is not None and self.group is None and o.solver == "newton"
             if native and o.chain and self._chain_ok and not (o.speculate and self._spec_ok):
                 done += self._chain_run(count - done)
@@ -1405,11 +1530,94 @@ class AdmmEngine:
                 self.iteration += 1
                 done += 1
 
+    def _stream_ok(self):
+        """The steady state as one launch per iteration (revs_plan_stream_run) applies: a plan
+        with the feeder's tree, no multipliers, speculation allowed, and -- sharded -- the
+        library's own communicator."""
+        o = self.op
+        return (self._plan is not None and self._tree is not None and o.solver == "newton"
+                and o.speculate and self._spec_ok and o.fuse_home_pass and not self._y_support
+                and (self.group is None or self._comm is not None))
+
+    def _stream_run(self, count):
+        """Up to `count` steady-state iterations, one launch each, the queue kept full by the
+        native loop; the first iteration whose rows are not within tolerance ends the call and
+        is finished here as step() finishes a discarded speculative sweep.  Returns the number
+        of iterations done (at least one)."""
+        o = self.op
+        scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
+        p0 = self._fused_p
+        rest = [b for b in (self.pnq[0], self.p_alt, self.p_alt2) if b.data_ptr() != p0.data_ptr()]
+        rest[0].zero_()
+        if self.group is not None and not self._ar_ahead:
+            self._allreduce(p0)
+        pes = (self.P_est, self.P_est_new, self.P_est_alt)
+        pss, gs, ps = (self.P_sch, self.P_sch_alt), (self.G, self.G_alt), (p0, rest[0], rest[1])
+        st = _lib.StreamState()
+        for i in range(3):
+            st.p_est[i], st.p[i] = ptr(pes[i]), ptr(ps[i])
+        for i in range(2):
+            st.p_sch[i], st.gamma[i] = ptr(pss[i]), ptr(gs[i])
+        kept, rm = C.c_int32(), C.c_double()
+        check(self.lib.revs_plan_stream_run(self._plan, count, C.byref(st), scale, o.eps,
+                                            o.stream_chunk, C.addressof(kept), C.addressof(rm),
+                                            self.stream), "revs_plan_stream_run")
+        n = kept.value
+        by = {t.data_ptr(): t for t in pes + pss + gs + ps}
+        self.P_est, self.P_est_new, self.P_est_alt = (by[st.p_est[i]] for i in range(3))
+        self.P_sch, self.P_sch_alt = by[st.p_sch[0]], by[st.p_sch[1]]
+        self.G, self.G_alt = by[st.gamma[0]], by[st.gamma[1]]
+        self._fused_p = by[st.p[0]]
+        self._prod_ahead = False
+        self._ar_ahead = self.group is not None
+        if n:
+            self.op_iters_hist.extend([1] * n)
+            self.op_path_hist.extend(["dual"] * n)
+            self.newton_hist.extend([(0, 1, 0)] * n)
+            self.op_converged = True
+            self.spec_hist[0] += n
+            self._spec_back = 1
+            self.iteration += n
+        if n == count:
+            return n
+        # iteration n's verdict failed (its sweep wrote to the spares only; every launch behind
+        # it was a no-op): finish it as step() does for a discarded speculative sweep
+        self._fused_ready = False
+        self._spec_discard(None, False)
+        self.P_est, self.P_est_new = self.P_est_new, self.P_est
+        self.iteration += 1
+        return n + 1
+
+    def check_status(self):
+        """Raise if a residence reported 'no solution' (lpsolver.py:153-155) or a PDHG residence
+        stopped at its iteration cap, in any sweep since the last check -- a collective decision
+        when residences are sharded (every rank raises, or none).  Call at a point where the
+        stream has been synchronised (run(), result() and residuals() do)."""
+        if self._plan is not None:
+            f = int(self.lib.revs_plan_status_flags(self._plan, 1))
+        else:
+            f = 0
+        f |= int((self.status & 3).max().item()) if self.n else 0
+        if self.group is not None:
+            t = torch.tensor([float(f & 1), float((f >> 1) & 1)], dtype=torch.float64, device=self.dev)
+            self._allreduce(t, torch.distributed.ReduceOp.MAX)
+            a, b = t.cpu().tolist()
+            f = int(a) | (int(b) << 1)
+        if f & 1:
+            raise _lib.RevsError("No solution found (lpsolver.py:153-155): a residence's "
+                                 "charging window cannot reach 90% state of charge")
+        if f & 2:
+            raise _lib.RevsError("REVS_ENOTCONV: a residence's PDHG iteration reached max_iter "
+                                 f"({self.pdhg.max_iter}) before its tolerance ({self.pdhg.tol:g})")
+
     def __del__(self):
         try:
             if getattr(self, "_plan", None):
                 self.lib.revs_plan_destroy(self._plan)
                 self._plan = None
+            if getattr(self, "_comm", None):
+                self.lib.revs_comm_destroy(self._comm)
+                self._comm = None
         except Exception:
             pass
 
@@ -1418,10 +1626,8 @@ class AdmmEngine:
         diffs = np.zeros((iter_max, self.n), np.float32)
         for k in range(iter_max):
             self.step(write_sc=(k == iter_max - 1))
-            if (self.status & 0xFF).any().item():
-                raise _lib.RevsError("No solution found (lpsolver.py:153-155): a residence's "
-                                     "charging window cannot reach 90% state of charge")
-            diffs[k] = self.diff.cpu().numpy()[self.inv_perm]
+            diffs[k] = self.diff.cpu().numpy()[self.inv_perm]      # (synchronises)
+            self.check_status()
         return diffs
 
     # ------------------------------------------------------- state in / out
@@ -1451,7 +1657,9 @@ class AdmmEngine:
 
     def result(self):
         """(P_sch, S, C) of the last iteration in the caller's home order."""
-        return self._unsort(self.P_sch), self._unsort(self.S), self._unsort(self.Csoc)
+        out = self._unsort(self.P_sch), self._unsort(self.S), self._unsort(self.Csoc)
+        self.check_status()
+        return out
 
     def voltage(self, profile=None):
         """R . (node aggregate of a home profile) on the f32 matrix cores: the

@@ -21,7 +21,7 @@ from . import _lib
 from .engine import AdmmEngine, OperatorOptions, pack_homes, residence_solve
 
 __all__ = ["compute_Rmat", "solve_ADMM", "solve_residence", "solve_residences",
-           "solve_central", "homes_to_arrays"]
+           "solve_central", "homes_to_arrays", "feeder_arrays"]
 
 
 def compute_Rmat(graph) -> np.ndarray:
@@ -62,6 +62,31 @@ def compute_Rmat(graph) -> np.ndarray:
     return R
 
 
+def feeder_arrays(graph, res):
+    """The radial feeder as (parent, edge_r, cons_of) over its non-substation nodes, for
+    AdmmEngine(feeder=...): parent index (-1: fed by the substation), resistance of the edge to
+    the parent, and the position in `res` of a residence node (-1 for every other node)."""
+    nonsub = [n for n in graph.nodes if graph.nodes[n]["label"] != "S"]
+    roots = [n for n in graph.nodes if graph.nodes[n]["label"] == "S"]
+    if len(roots) != 1 or graph.number_of_edges() != graph.number_of_nodes() - 1:
+        raise ValueError("feeder_arrays expects a radial feeder with one substation node")
+    pos = {n: i for i, n in enumerate(nonsub)}
+    parent = np.full(len(nonsub), -1, np.int64)
+    edge_r = np.zeros(len(nonsub))
+    seen, stack = {roots[0]}, [roots[0]]
+    while stack:
+        u = stack.pop()
+        for v in graph.neighbors(u):
+            if v not in seen:
+                seen.add(v)
+                parent[pos[v]] = pos.get(u, -1)
+                edge_r[pos[v]] = graph.edges[u, v]["r"]
+                stack.append(v)
+    ridx = {h: i for i, h in enumerate(res)}
+    cons_of = np.array([ridx.get(n, -1) for n in nonsub], np.int64)
+    return parent, edge_r, cons_of
+
+
 def homes_to_arrays(homes, res):
     """Reference `homes` dict -> (LOAD (n,T), revs_home_t records) in `res` order."""
     load = np.array([homes[h]["LOAD"] for h in res], dtype=np.float64)
@@ -97,7 +122,8 @@ def solve_ADMM(homes, graph, cost, grbpath=None, kappa=5.0, iter_max=15, vset=1.
     resind = [pos[n] for n in res]                                      # lpsolver.py:188-189
     R_res = R[np.ix_(resind, resind)]
     eng = AdmmEngine(np.asarray(cost, float), rec, load, np.arange(len(res)), R_res, kappa=kappa,
-                     vset=vset, vlow=vlow, vhigh=vhigh, mode=mode, device=device, op=operator)
+                     vset=vset, vlow=vlow, vhigh=vhigh, mode=mode, device=device, op=operator,
+                     feeder=feeder_arrays(graph, res))
     d = eng.run(iter_max)
     P_sch, S, C = eng.result()
     diff = {k + 1: {h: float(d[k, i]) for i, h in enumerate(res)} for k in range(iter_max)}

@@ -43,6 +43,11 @@ class Workload:
     def M(self):
         return self.Rn.shape[0]
 
+    @property
+    def feeder(self):
+        """(parent, edge_r, cons_of) for AdmmEngine(feeder=...): every tree node is a constraint node."""
+        return self.parent, self.edge_r, np.arange(self.M)
+
     def shard(self, rank, world):
         """Contiguous block of residences for one rank (nodes stay replicated)."""
         lo, hi = (self.N * rank) // world, (self.N * (rank + 1)) // world

@@ -6,7 +6,11 @@ pytestmark = pytest.mark.gpu
 
 
 def _engine(w, mode, **kw):
+    """The synthetic feeder is handed over as a tree too (OperatorOptions.voltage = "auto"): the
+    steady state then runs as one launch per iteration with the rows judged by the tree form of
+    R p; voltage="dense" keeps the matrix-core product."""
     from revs_admm_amd.engine import AdmmEngine
+    kw.setdefault("feeder", w.feeder)
     return AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, kappa=w.kappa, vset=w.vset,
                       vlow=w.vlow, vhigh=w.vhigh, mode=mode, **kw)
 
@@ -205,6 +209,19 @@ def test_process_group_path_on_one_gpu(gpu_lib):
         assert b._plan is not None and b.spec_hist == a.spec_hist and a.spec_hist[0] > 0 < a.spec_hist[1]
         np.testing.assert_array_equal(db, da)
         np.testing.assert_array_equal(b.result()[0], a.result()[0])
+        # the streaming steady state with the library's OWN communicator in the loop: sweep ->
+        # ncclAllReduce of the node sums on the compute stream -> sweep, launches made in chunks,
+        # no host read in between (revs_plan_stream_run) == the one-GPU run, bit for bit
+        a = _engine(w2, "pdhg")
+        b = _engine(w2, "pdhg", group=dist.group.WORLD)
+        assert b._comm is not None and b._tree is not None
+        for chunk in (3, 40, 37):
+            a.run_steps(chunk)
+            b.run_steps(chunk)
+        assert a.spec_hist == b.spec_hist and a.spec_hist[0] > 40 and a.spec_hist[1] > 0
+        for name in ("P_est", "P_sch", "G", "diff"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), name
+        assert b.residuals(1e-4)[:3] == pytest.approx(a.residuals(1e-4)[:3], rel=1e-6)
     finally:
         dist.destroy_process_group()
 
@@ -587,3 +604,61 @@ def test_tiny_runs_match_oracle(gpu_lib, n, M, T):
     assert e.spec_hist[0] > 0                                     # the native step did run
     assert np.abs(d - d_ref).max() < 1e-3 * max(1.0, d_ref.max())
     assert np.abs(S - S_ref).max() < 2e-3 and np.abs(P - P_ref).max() < 2e-3
+
+
+@pytest.mark.parametrize("mode,stress,T", [("pdhg", 1.02, 24), ("relaxed_exact", 1.0, 24), ("binary", 0.5, 24),
+                                           ("pdhg", 1.02, 96)])
+def test_streaming_steady_state_equals_dense_product_path(gpu_lib, mode, stress, T):
+    """The steady state as ONE launch per iteration -- rows judged inside the sweep's launch by
+    the tree form of R p, later launches silenced on the device after a failed verdict, the
+    host only keeping the queue full (revs_plan_stream_run) -- against the path that multiplies
+    by the dense R on the matrix cores and reads every verdict on the host: same decisions
+    (kept / discarded sweeps at the same iterations), same state bit for bit, in ragged
+    chunks, through discards."""
+    from helpers import f32
+    from revs_admm_amd.engine import OperatorOptions
+    from revs_admm_amd.synthetic import make_workload
+    w = make_workload(8000 if T == 24 else 3000, T, n_nodes=200, seed=3, binary_feasible=(mode == "binary"),
+                      stress=stress)
+    w.load, w.cost = f32(w.load), f32(w.cost)
+    a = _engine(w, mode, op=OperatorOptions(voltage="dense"))
+    b = _engine(w, mode, op=OperatorOptions(voltage="tree", stream_chunk=3))
+    assert a._tree is None and b._tree is not None
+    for chunk in (1, 7, 30, 2, 50):
+        a.run_steps(chunk)
+        b.run_steps(chunk)
+        assert a.iteration == b.iteration
+    assert a.spec_hist == b.spec_hist and a.spec_hist[0] > 40, (a.spec_hist, b.spec_hist)
+    if mode != "binary":
+        assert a.spec_hist[1] > 0                       # discards were crossed
+    assert a.op_iters_hist == b.op_iters_hist
+    for name in ("P_est", "P_sch", "G", "diff"):
+        assert torch_equal(getattr(a, name), getattr(b, name)), name
+    a.step(write_sc=True); b.step(write_sc=True)
+    for x, y in zip(a.result(), b.result()):
+        np.testing.assert_array_equal(x, y)
+
+
+def test_status_flags_surface_through_run_steps(gpu_lib):
+    """A PDHG residence that stops at its iteration cap, or a residence whose window cannot
+    reach 90 % SOC, is reported by the sweeps themselves (status bits OR-ed into a word the
+    host reads) and raised at the next synchronisation point -- also when the iterations ran
+    inside run_steps."""
+    from revs_admm_amd import _lib
+    from revs_admm_amd.synthetic import make_workload
+    w = make_workload(3000, 24, n_nodes=100, seed=5, binary_feasible=False, stress=0.9)
+    e = _engine(w, "pdhg", pdhg={"max_iter": 8})
+    e.run_steps(12)
+    with pytest.raises(_lib.RevsError, match="REVS_ENOTCONV"):
+        e.result()
+    e = _engine(w, "pdhg")
+    e.run_steps(12)
+    e.result()                                          # the default cap is never reached here
+    st = e.status.cpu().numpy()
+    assert ((st & 3) == 0).all() and (st >> 8).max() < 4000
+    w.homes["end"][7:9] = w.homes["start"][7:9] + 1     # one slot cannot deliver the energy
+    w.homes["ev"][7:9] = 1
+    e = _engine(w, "pdhg")
+    e.run_steps(3)
+    with pytest.raises(_lib.RevsError, match="No solution found"):
+        e.residuals()

@@ -8,7 +8,11 @@ pytestmark = pytest.mark.gpu
 
 
 def _engine(w, mode, **kw):
+    """The synthetic feeder is handed over as a tree too (OperatorOptions.voltage = "auto"): the
+    steady state then runs as one launch per iteration with the rows judged by the tree form of
+    R p; voltage="dense" keeps the matrix-core product."""
     from revs_admm_amd.engine import AdmmEngine
+    kw.setdefault("feeder", w.feeder)
     return AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, kappa=w.kappa, vset=w.vset,
                       vlow=w.vlow, vhigh=w.vhigh, mode=mode, **kw)
 

@@ -445,3 +445,57 @@ def test_model_problem_sizes(gpu_lib, a):
         # (the repeated row with unrelated gradients leaves the delta shift in charge of a huge
         # component: objective values agree to its conditioning, not to rounding)
         assert obj(u) <= obj(s * ref[t, :a]) + 1e-5 * (abs(obj(s * ref[t, :a])) + 1e-300)
+
+
+@pytest.mark.parametrize("case", ["synthetic2048", "golden1691", "tiny", "gaps"])
+def test_tree_voltage_matches_dense_product(gpu_lib, case, golden, feeder_R):
+    """revs_tree_voltage (R p as three prefix sums over the feeder in DFS preorder) == the dense
+    float64 product Rn @ p at every checked row, to 1e-12 relative; rmax per slot == the largest
+    violation; nodes without residences are neither injected nor checked."""
+    import ctypes as C
+    import torch
+    from revs_admm_amd import _lib
+    from revs_admm_amd.engine import feeder_tree, tree_voltage_host
+    from revs_admm_amd.synthetic import make_workload
+    rng = np.random.default_rng(7)
+    if case == "golden1691":
+        import networkx as nx
+        from revs_admm_amd.lpsolver import feeder_arrays
+        z, fd = golden
+        g = nx.Graph()
+        for nid, lab in zip(z["node_id"], fd.label):
+            g.add_node(int(nid), label=lab.decode())
+        for u, v, r in zip(fd.edge_u, fd.edge_v, fd.edge_r):
+            g.add_edge(int(z["node_id"][u]), int(z["node_id"][v]), r=float(r))
+        res = [n for n in g if g.nodes[n]["label"] == "H"]
+        par, er, cons = feeder_arrays(g, res)
+        Rn, T = feeder_R, 96
+        checked = np.ones(len(res), bool)
+    else:
+        M, T = {"synthetic2048": (2048, 24), "tiny": (1, 7), "gaps": (300, 33)}[case]
+        w = make_workload(max(M * 3, 10), 24, n_nodes=M, seed=4)
+        par, er, cons = w.feeder
+        Rn = w.Rn
+        checked = np.ones(M, bool) if case != "gaps" else rng.random(M) < 0.6
+    M = Rn.shape[0]
+    tr = feeder_tree(par, er, cons, checked)
+    p = rng.uniform(0.0, 4.0, (M, T)) * checked[:, None]
+    ref = (Rn @ p) * checked[:, None]
+    np.testing.assert_allclose(tree_voltage_host(tr, p), ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+    dev = "cuda:0"
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d = {k: up(v) for k, v in tr.items() if k != "n"}
+    tree = _lib.Tree(tr["n"], *[d[k].data_ptr() for k in ("src", "end", "eo", "cle", "w")])
+    dp, dv = up(p), torch.full((M, T), np.nan, dtype=torch.float64, device=dev)
+    drm = torch.zeros(T, dtype=torch.float64, device=dev)
+    vhi = float(np.quantile(ref[checked], 0.98))
+    vlo = float(np.quantile(ref[checked], 0.01))
+    _lib.check(gpu_lib.revs_tree_voltage(M, T, C.byref(tree), dp.data_ptr(), vlo, vhi, dv.data_ptr(),
+                                         drm.data_ptr(), None), "revs_tree_voltage")
+    torch.cuda.synchronize()
+    v = dv.cpu().numpy()
+    assert np.isnan(v[~checked]).all()                      # unchecked rows are not written
+    np.testing.assert_allclose(v[checked], ref[checked], rtol=0, atol=1e-12 * np.abs(ref).max())
+    want = np.maximum(np.maximum(ref - vhi, vlo - ref), 0.0)[checked].max(axis=0)
+    np.testing.assert_allclose(drm.cpu().numpy(), want, rtol=0, atol=1e-12 * np.abs(ref).max())
+    assert (want > 0).any()
