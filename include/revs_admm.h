@@ -648,7 +648,8 @@ int revs_plan_chain_run(revs_plan_t *plan, int32_t max_steps, revs_chain_state_t
  *     w'_j   = w_j P_sub(j),  w_j = 2 r(edge to the parent)
  *     v_j    = sum_{a <= j} w'_a - sum_{a : end_a <= j} w'_a      (= over the ancestors a of j)
  * the second sum taken from a prefix over the nodes sorted by `end`.  All arrays below live
- * on the device and are indexed by preorder position, n <= REVS_TREE_MAX:
+ * on the device and are indexed by preorder position; n <= REVS_TREE_MAX and n % 8 == 0 (pad with
+ * weightless nodes hanging off the substation: src = -1, w = 0, end = j + 1):
  *   src[j]  constraint row (0..m-1) whose node sum p[src][t] is injected at -- and whose
  *           voltage row is checked at -- position j; -1: a node without residences
  *   end[j]  one past the last position of j's subtree
@@ -691,9 +692,10 @@ int revs_comm_allreduce_f64(revs_comm_t *comm, double *buf, int64_t count, int32
  * first) -- so the host can keep the queue full without waiting for any verdict, and
  * nothing written after a failed verdict has to be undone beyond that one sweep's spare
  * buffers.  With a communicator set (revs_plan_set_comm) the node sums are all-reduced on
- * the same stream after every sweep; launches are made in chunks of `chunk` steps and the
- * decision to go on is taken only on completed chunks, so every rank issues the same
- * collectives.
+ * the same stream after every sweep.  All max_steps launches (at most REVS_STREAM_MAX) are
+ * enqueued in one burst and no decision is taken in between, so every rank of a sharded run
+ * issues the same collectives; the caller bounds max_steps by the silenced launches it accepts
+ * to waste behind a failed verdict.
  *   st    roles at entry and, rotated by the kept steps, at return:
  *         p_est[0] = P_est[k], p_est[1] = P_est[k+1] (prepared by the previous sweep),
  *         p_est[2] spare;  p_sch[0], gamma[0] current, [1] spare;  p[0] = node sums of
@@ -709,9 +711,10 @@ typedef struct {
 } revs_stream_state_t;
 int revs_plan_set_tree(revs_plan_t *plan, const revs_tree_t *tree_host);
 int revs_plan_set_comm(revs_plan_t *plan, revs_comm_t *comm);
+#define REVS_STREAM_MAX 1023
 int revs_plan_stream_run(revs_plan_t *plan, int32_t max_steps, revs_stream_state_t *st,
-                         double scale, double eps, int32_t chunk, int32_t *kept_steps,
-                         double *rmax_last, void *stream);
+                         double scale, double eps, int32_t *kept_steps, double *rmax_last,
+                         void *stream);
 /* Bits OR-ed by the sweeps launched through the plan since the last clear: 1 = a residence's
  * window cannot reach 90 % SOC (the reference prints "No solution found", lpsolver.py:153-155),
  * 2 = a PDHG residence hit max_iter before its tolerance.  Meaningful after the stream has

@@ -515,8 +515,8 @@ extern "C" int revs_comm_allreduce_f64(revs_comm_t *comm, double *buf, int64_t c
 extern "C" int revs_plan_set_tree(revs_plan_t *plan, const revs_tree_t *t) {
     REVS_REQUIRE(plan, "revs_plan_set_tree: null plan");
     if (!t || t->n == 0) { plan->tree = revs::TreeArgs{}; return REVS_OK; }
-    REVS_REQUIRE(t->n > 0 && t->n <= REVS_TREE_MAX && t->src && t->end && t->eo && t->cle && t->w,
-                 "revs_plan_set_tree: bad tree (at most %d nodes)", REVS_TREE_MAX);
+    REVS_REQUIRE(t->n > 0 && t->n <= REVS_TREE_MAX && t->n % 8 == 0 && t->src && t->end && t->eo && t->cle && t->w,
+                 "revs_plan_set_tree: bad tree (at most %d nodes, a multiple of 8)", REVS_TREE_MAX);
     plan->tree = revs::TreeArgs{t->n, t->src, t->end, t->eo, t->cle, t->w};
     return REVS_OK;
 }
@@ -540,12 +540,16 @@ static int stream_wait(revs_plan_t *plan, unsigned int seq, hipStream_t s, doubl
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
     while (r[2] != (double)seq) {
-        if ((++spins & 0xFFFF) == 0) {
-            if (hipStreamQuery(s) == hipSuccess && r[2] != (double)seq) {
+        // (no HIP call in this loop: a hipStreamQuery here was measured to stop the host for
+        // milliseconds now and then -- the runtime retires its finished commands inside it --
+        // while the queue behind the awaited launch ran dry)
+        if ((++spins & 0xFFFFF) == 0) {
+            const auto waited = std::chrono::steady_clock::now() - t0;
+            if (waited > std::chrono::seconds(2) && hipStreamQuery(s) == hipSuccess && r[2] != (double)seq) {
                 revs::set_error("revs_plan_stream_run: stream idle but record %u missing", seq);
                 return REVS_ELAUNCH;
             }
-            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+            if (waited > std::chrono::seconds(120)) {
                 (void)hipStreamSynchronize(s);
                 revs::set_error("revs_plan_stream_run: timed out waiting for record %u", seq);
                 return REVS_ELAUNCH;
@@ -558,10 +562,11 @@ static int stream_wait(revs_plan_t *plan, unsigned int seq, hipStream_t s, doubl
 }
 
 extern "C" int revs_plan_stream_run(revs_plan_t *plan, int32_t max_steps, revs_stream_state_t *st,
-                                    double scale, double eps, int32_t chunk, int32_t *kept_steps,
+                                    double scale, double eps, int32_t *kept_steps,
                                     double *rmax_last, void *stream) {
-    REVS_REQUIRE(plan && st && kept_steps && rmax_last && max_steps >= 0 && scale > 0.0 && eps > 0.0 &&
-                 chunk >= 1 && 2 * chunk < revs::kRecRing, "revs_plan_stream_run: bad argument");
+    REVS_REQUIRE(plan && st && kept_steps && rmax_last && max_steps >= 0 && max_steps < revs::kRecRing &&
+                 scale > 0.0 && eps > 0.0, "revs_plan_stream_run: bad argument (at most %d steps per call)",
+                 revs::kRecRing - 1);
     const revs_plan_desc_t &d = plan->d;
     REVS_REQUIRE(plan->tree.n > 0 && d.node_of, "revs_plan_stream_run: the plan has no tree / node_of");
     for (int i = 0; i < 3; ++i)
@@ -605,26 +610,17 @@ extern "C" int revs_plan_stream_run(revs_plan_t *plan, int32_t max_steps, revs_s
         if (plan->comm) rc = revs_comm_allreduce_f64(plan->comm, p_next, mt, 0, stream);
         return rc;
     };
-    // Launch in chunks; go on to chunk c only when every record of chunk c - 2 is in and none
-    // failed.  The decision depends on verdicts alone, never on timing: every rank of a
-    // sharded run makes the same launches and the same collectives.
+    // All max_steps launches (and, sharded, their collectives) are enqueued in ONE burst, then
+    // the records are read in order.  No decision is taken between launches -- a failed verdict
+    // silences the launches behind it on the device -- so every rank of a sharded run issues the
+    // same collectives whatever its timing, and the host never pauses between submissions (a
+    // launch submitted after a pause was measured to start late: ~6 us always, milliseconds now
+    // and then, whatever the queue holds).  The caller bounds max_steps by how many silenced
+    // launches it is willing to waste behind a failure (AdmmEngine._stream_run).
     int launched = 0, checked = 0, failed_at = -1, rc = REVS_OK;
     double rm = 0.0;
-    const int nchunks = (max_steps + chunk - 1) / chunk;
-    for (int c = 0; c < nchunks && failed_at < 0; ++c) {
-        if (c >= 2) {
-            const int upto = (c - 1) * chunk;            // records of chunks <= c - 2
-            for (; checked < upto && failed_at < 0; ++checked) {
-                const int v = stream_wait(plan, seq0 + (unsigned int)checked, s, &rm);
-                if (v < 0) { rc = v; goto out; }
-                if (v == 1) failed_at = checked;
-            }
-            if (failed_at >= 0) break;
-        }
-        const int end = std::min(max_steps, (c + 1) * chunk);
-        for (; launched < end; ++launched)
-            if ((rc = launch(launched)) != REVS_OK) goto out;
-    }
+    for (; launched < max_steps; ++launched)
+        if ((rc = launch(launched)) != REVS_OK) goto out;
     for (; checked < launched && failed_at < 0; ++checked) {
         const int v = stream_wait(plan, seq0 + (unsigned int)checked, s, &rm);
         if (v < 0) { rc = v; goto out; }

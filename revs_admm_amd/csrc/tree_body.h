@@ -7,130 +7,156 @@
 
 namespace revs {
 
-constexpr int kTreeIpt = REVS_TREE_MAX / 256;        // positions per thread (strided: j = tid + 256 i)
-static_assert(kTreeIpt * 256 == REVS_TREE_MAX, "REVS_TREE_MAX must be a multiple of 256");
+constexpr int kTreeIpt = REVS_TREE_MAX / 256;        // consecutive positions per thread: j = 8 tid + i
+static_assert(kTreeIpt == 8, "thread-local vectors below are written for 8 positions");
 
-// dynamic LDS of a launch that carries the tree workgroups: one leading zero, the scan /
-// gather buffer (n doubles), and two sets of wave totals
-__host__ __device__ inline size_t tree_lds_bytes(int n) {
-    return sizeof(double) * ((size_t)n + 1 + 8);
+// dynamic LDS of a launch that carries the tree workgroups: two leading zeros (the second is
+// element -1 of the 16-byte-aligned scan / gather buffer), the buffer, two sets of wave totals
+__host__ __device__ inline size_t tree_lds_bytes(int) {
+    return sizeof(double) * (2 + REVS_TREE_MAX + 8);
 }
 
-__device__ __forceinline__ double wave_incl_scan_d(double v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const double o = __shfl_up(v, d, 64);
-        if (lane >= d) v += o;
-    }
+// Inclusive prefix sum over the 64 lanes of a wavefront, doubles, on the DPP network: four
+// row_shr steps inside each row of 16 lanes, then row_bcast:15 / row_bcast:31 carry the row
+// totals across (gfx9 DPP controls) -- six steps of two 32-bit moves and one add, no LDS
+// permute (a __shfl_up of a double is two ds_bpermute round trips per step).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xf, ROW_MASK == 0xf);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, ROW_MASK == 0xf);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_incl_scan_d(double v) {
+    v += dpp_d<0x111, 0xf>(v);        // row_shr:1 (lanes without a source read 0)
+    v += dpp_d<0x112, 0xf>(v);        // row_shr:2
+    v += dpp_d<0x114, 0xf>(v);        // row_shr:4
+    v += dpp_d<0x118, 0xf>(v);        // row_shr:8
+    v += dpp_d<0x142, 0xa>(v);        // row_bcast:15 into rows 1 and 3 (others add 0)
+    v += dpp_d<0x143, 0xc>(v);        // row_bcast:31 into rows 2 and 3
     return v;
 }
 
-// In-place inclusive prefix sum of base[0..n) in LDS by the whole workgroup (256 threads),
-// 256 positions per round with a running carry; fixed order: bitwise reproducible.  One
-// barrier per round (the wave totals ping-pong between two sets) and one at the end.
-// Deliberately NOT unrolled: this runs inside the residence sweep's kernel and must stay far
-// below its register budget (see tree_rmax).
-__device__ __forceinline__ void lds_scan_inplace(double *base, int n, double *tot) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double carry = 0.0;
-    int pp = 0;
-#pragma unroll 1
-    for (int c0 = 0; c0 < n; c0 += 256, pp ^= 4) {
-        const int j = c0 + tid;
-        double x = j < n ? base[j] : 0.0;
-        x = wave_incl_scan_d(x, lane);
-        if (lane == 63) tot[pp + wave] = x;
-        __syncthreads();
-        const double t0 = tot[pp], t1 = tot[pp + 1], t2 = tot[pp + 2], t3 = tot[pp + 3];
-        x += carry + (wave > 0 ? t0 : 0.0) + (wave > 1 ? t1 : 0.0) + (wave > 2 ? t2 : 0.0);
-        carry += ((t0 + t1) + t2) + t3;
-        if (j < n) base[j] = x;
-    }
+// Sum of `tot` over all threads before this one in the workgroup (256 threads, fixed order:
+// bitwise reproducible).  One barrier; `red` (4 doubles) must not be rewritten before the
+// caller's next barrier.
+__device__ __forceinline__ double block_excl_offset(double tot, double *red) {
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const double incl = wave_incl_scan_d(tot);
+    if ((tid & 63) == 63) red[wave] = incl;
     __syncthreads();
+    double off = incl - tot;
+    if (wave > 0) off += red[0];
+    if (wave > 1) off += red[1];
+    if (wave > 2) off += red[2];
+    return off;
 }
 
 struct TreeArgs {
-    int32_t n;
+    int32_t n;                              // a multiple of 8 (the host pads with weightless roots)
     const int32_t *src, *end, *eo, *cle;
     const double *w;
 };
 
+struct alignas(16) TreeI4 { int v[4]; };
+struct alignas(16) TreeD2 { double v[2]; };
+__device__ __forceinline__ void tree_ld8(const int32_t *p, int (&o)[8]) {
+    const TreeI4 a = reinterpret_cast<const TreeI4 *>(p)[0], b = reinterpret_cast<const TreeI4 *>(p)[1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[i] = a.v[i]; o[4 + i] = b.v[i]; }
+}
+
 // Largest violation max(v - vhi, vlo - v, 0) over the checked rows of slot t (every thread
-// gets it); v_out[src][t] = v when v_out != NULL.  `lds`: tree_lds_bytes(n) bytes.
+// gets it); v_out[src][t] = v when v_out != NULL.  `lds`: tree_lds_bytes() bytes, 16-byte aligned.
 // Register budget: this body runs inside the residence sweep's kernel, whose occupancy (8
-// wavefronts per SIMD, 64 VGPRs) it must not lower.  So the prefix sums run in place in LDS
-// (base[-1] = 0 makes an exclusive prefix a read at j - 1), and only two 8-double arrays ever
-// live in registers across a barrier: the values being re-ordered, and Pre.
+// wavefronts per SIMD, 64 VGPRs) it must not lower: two 8-double vectors per thread (thread tid
+// owns positions 8 tid .. 8 tid + 7), index vectors loaded where they are used.
 __device__ __forceinline__ double tree_rmax(const TreeArgs &tr, const double *p, int T, int t,
                                             double vlo, double vhi, double *lds, double *v_out) {
-    const int tid = threadIdx.x, n = tr.n;
-    double *base = lds + 1, *tot = lds + 1 + n;
-    if (tid == 0) lds[0] = 0.0;
-    // C: prefix of the injections in preorder
+    const int tid = threadIdx.x, n = tr.n, j0 = 8 * tid;
+    const bool act = j0 < n;
+    double *base = lds + 2, *red0 = lds + 2 + REVS_TREE_MAX, *red1 = red0 + 4;
+    if (tid == 0) lds[1] = 0.0;                                 // base[-1]
+    double a[8], b[8];
+    int ix[8];
+    // C: inclusive prefix of the injections in preorder
 #pragma unroll
-    for (int i = 0; i < kTreeIpt; ++i) {
-        const int j = tid + 256 * i;
-        if (j < n) {
-            const int s = tr.src[j];
-            base[j] = s >= 0 ? p[(int64_t)s * T + t] : 0.0;
+    for (int i = 0; i < 8; ++i) a[i] = 0.0;
+    if (act) {
+        tree_ld8(tr.src + j0, ix);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = ix[i] >= 0 ? p[(int64_t)ix[i] * T + t] : 0.0;
+    }
+#pragma unroll
+    for (int i = 1; i < 8; ++i) a[i] += a[i - 1];
+    const double cex = block_excl_offset(a[7], red0);           // C_excl at j0
+    if (act) {
+#pragma unroll
+        for (int i = 0; i < 8; i += 2)
+            *reinterpret_cast<TreeD2 *>(base + j0 + i) = TreeD2{{a[i] + cex, a[i + 1] + cex}};
+    }
+    __syncthreads();
+    // w'_j = w_j (C[end_j] - C[j]),  C[j] = base[j - 1] (own positions: registers)
+    if (act) {
+        tree_ld8(tr.end + j0, ix);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) b[i] = base[ix[i] - 1];
+#pragma unroll
+        for (int i = 7; i >= 1; --i) a[i] = b[i] - (a[i - 1] + cex);
+        a[0] = b[0] - cex;
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            const TreeD2 wv = *reinterpret_cast<const TreeD2 *>(tr.w + j0 + i);
+            a[i] *= wv.v[0];
+            a[i + 1] *= wv.v[1];
         }
     }
-    __syncthreads();
-    lds_scan_inplace(base, n, tot);
-    // w'_j = w_j (C[end_j] - C[j]),  C[j] = base[j - 1]
-    double a[kTreeIpt];
-#pragma unroll
-    for (int i = 0; i < kTreeIpt; ++i) {
-        const int j = tid + 256 * i;
-        a[i] = j < n ? tr.w[j] * (base[tr.end[j] - 1] - base[j - 1]) : 0.0;
-    }
     __syncthreads();                                            // every read of C is done
+    if (act) {
 #pragma unroll
-    for (int i = 0; i < kTreeIpt; ++i) {
-        const int j = tid + 256 * i;
-        if (j < n) base[j] = a[i];
+        for (int i = 0; i < 8; i += 2)
+            *reinterpret_cast<TreeD2 *>(base + j0 + i) = TreeD2{{a[i], a[i + 1]}};
     }
     __syncthreads();
-    // the same values in end-order (held in registers), then Pre = prefix of w' in preorder
+    // the same values in end-order, then both prefixes: Pre over preorder (a), F over end-order (b)
 #pragma unroll
-    for (int i = 0; i < kTreeIpt; ++i) {
-        const int k = tid + 256 * i;
-        a[i] = k < n ? base[tr.eo[k]] : 0.0;
+    for (int i = 0; i < 8; ++i) b[i] = 0.0;
+    if (act) {
+        tree_ld8(tr.eo + j0, ix);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) b[i] = base[ix[i]];
     }
-    __syncthreads();                                            // every read of w' is done
-    lds_scan_inplace(base, n, tot);
-    double pre[kTreeIpt];
 #pragma unroll
-    for (int i = 0; i < kTreeIpt; ++i) {
-        const int j = tid + 256 * i;
-        pre[i] = j < n ? base[j] : 0.0;
-    }
-    __syncthreads();
-    // F: prefix of w' in end-order
+    for (int i = 1; i < 8; ++i) { a[i] += a[i - 1]; b[i] += b[i - 1]; }
+    const double pex = block_excl_offset(a[7], red1);           // (its barrier: every read of w' is done)
+    const double fex = block_excl_offset(b[7], red0);
+    if (act) {
 #pragma unroll
-    for (int i = 0; i < kTreeIpt; ++i) {
-        const int k = tid + 256 * i;
-        if (k < n) base[k] = a[i];
+        for (int i = 0; i < 8; i += 2)
+            *reinterpret_cast<TreeD2 *>(base + j0 + i) = TreeD2{{b[i] + fex, b[i + 1] + fex}};
     }
     __syncthreads();
-    lds_scan_inplace(base, n, tot);
-    // v_j = Pre[j] - F_excl[cle[j]] on the checked rows
+    // v_j = Pre[j] - F_excl[cle[j]] on the checked rows,  F_excl[c] = base[c - 1]
     double rmax = 0.0;
+    if (act) {
+        tree_ld8(tr.cle + j0, ix);
 #pragma unroll
-    for (int i = 0; i < kTreeIpt; ++i) {
-        const int j = tid + 256 * i;
-        const int s = j < n ? tr.src[j] : -1;
-        if (s >= 0) {
-            const double v = pre[i] - base[tr.cle[j] - 1];
-            rmax = fmax(rmax, fmax(fmax(v - vhi, vlo - v), 0.0));
-            if (v_out) v_out[(int64_t)s * T + t] = v;
+        for (int i = 0; i < 8; ++i) b[i] = base[ix[i] - 1];
+        tree_ld8(tr.src + j0, ix);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (ix[i] >= 0) {
+                const double v = (a[i] + pex) - b[i];
+                rmax = fmax(rmax, fmax(fmax(v - vhi, vlo - v), 0.0));
+                if (v_out) v_out[(int64_t)ix[i] * T + t] = v;
+            }
         }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, d, 64));
-    if ((tid & 63) == 0) tot[tid >> 6] = rmax;
+    if ((tid & 63) == 0) red1[tid >> 6] = rmax;
     __syncthreads();
-    return fmax(fmax(tot[0], tot[1]), fmax(tot[2], tot[3]));
+    return fmax(fmax(red1[0], red1[1]), fmax(red1[2], red1[3]));
 }
 
 // Control block of the streaming steady state (device memory, owned by the plan).
@@ -139,6 +165,6 @@ struct StreamCtl {
     unsigned int arrive;                  // tree workgroups of the current launch that are done
     unsigned long long rmax_bits;         // max over their slots (bit pattern of a double >= 0)
 };
-constexpr int kRecRing = 64;              // records double[kRecRing][4] in pinned host memory
+constexpr int kRecRing = 1024;             // records double[kRecRing][4] in pinned host memory
 
 }  // namespace revs

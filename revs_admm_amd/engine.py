@@ -105,7 +105,12 @@ class OperatorOptions:
     # instead of O(nodes^2), inside the sweep's own launch (needs the feeder: `feeder=` of
     # AdmmEngine); "auto" = tree when a feeder of at most REVS_TREE_MAX nodes was given.
     voltage: str = "auto"
-    stream_chunk: int = 4        # streaming steady state: launches per chunk (see revs_plan_stream_run)
+    # streaming steady state: launches enqueued per native call.  Starts at stream_burst, x4 after
+    # every call whose launches were all kept (up to stream_burst_max), back to stream_burst after
+    # a failed verdict: the launches behind a failure are silenced on the device but still cost
+    # ~3 us each, so a regime that fails often keeps its bursts short
+    stream_burst: int = 8
+    stream_burst_max: int = 512
 
 
 def _dev_check(device):
@@ -124,6 +129,11 @@ def feeder_tree(parent, edge_r, cons_of, checked):
     checked[r]  whether row r is constrained (it carries residences, lpsolver.py:188-189)
     Returns dict(n, src, end, eo, cle, w) of numpy arrays (see include/revs_admm.h)."""
     parent = np.asarray(parent, np.int64)
+    pad = (-len(parent)) % 8                 # the kernel's threads own 8 consecutive positions:
+    if pad:                                  # pad with weightless nodes hanging off the substation
+        parent = np.concatenate([parent, np.full(pad, -1, np.int64)])
+        edge_r = np.concatenate([np.asarray(edge_r, np.float64), np.zeros(pad)])
+        cons_of = np.concatenate([np.asarray(cons_of, np.int64), np.full(pad, -1, np.int64)])
     n = len(parent)
     kids = [[] for _ in range(n)]
     roots = []
@@ -404,11 +414,12 @@ class AdmmEngine:
                                      + self.lib.revs_last_error().decode())
         # third node-sum buffer and the feeder as a tree: streaming steady state
         self.p_alt2 = nz()
+        self._burst = max(1, int(self.op.stream_burst))
         self._tree = None
         self._comm = None
         if feeder is not None and self.op.voltage in ("auto", "tree"):
             par, er, cons = feeder
-            if len(par) <= _lib.TREE_MAX:
+            if len(par) <= _lib.TREE_MAX:          # (padded to a multiple of 8 below)
                 tr = feeder_tree(par, er, cons, counts > 0)
                 probe = np.random.default_rng(0).uniform(0.5, 1.5, (M, 2)) * (counts > 0)[:, None]
                 ref = (Rn @ probe) * (counts > 0)[:, None]
@@ -1118,6 +1129,16 @@ class AdmmEngine:
         self.op_path_hist.append("dual")
         self.op_converged = True
 
+    def _require_converged(self, ok):
+        """An operator answer that did not reach its tolerance is not handed to the residences:
+        REVS_ENOTCONV (every rank holds the same node-space state and takes the same decision)."""
+        if not ok:
+            raise _lib.RevsError(
+                "REVS_ENOTCONV: the operator QP (lpsolver.py:163-238) did not converge -- the dual "
+                f"Newton path gave up (more than {_lib.DUAL_AMAX} binding rows in a slot, no ascent, or "
+                f"{self.op.newton_max} iterations) and the ADMM form stopped at max_iter = "
+                f"{self.op.max_iter} above eps = {self.op.eps:g}")
+
     def operator_solve(self, admm_only=False):
         """Utility(graph, P_est[k], P_sch[k], G[k]).solve() -> P_est[k+1]
         (lpsolver.py:256-259), written to self.P_est_new.  `admm_only`: skip the dual
@@ -1360,7 +1381,7 @@ class AdmmEngine:
                     self._chain_finish(False, 0, 0, write_sc)
         else:
             self._fused_ready = False
-            self.operator_solve()
+            self._require_converged(self.operator_solve())
             rec(1)
             self.agent_step(write_sc)
             rec(2)
@@ -1404,7 +1425,7 @@ class AdmmEngine:
         if not self._operator_solve_newton(first=stt):
             self._fast_cold = True
             self.op_cold = True
-            self.operator_solve(admm_only=True)
+            self._require_converged(self.operator_solve(admm_only=True))
         self.agent_step(write_sc)
 
     def _chain_run(self, count):
@@ -1464,7 +1485,7 @@ class AdmmEngine:
             if not ok:
                 self._fast_cold = True
                 self.op_cold = True
-                self.operator_solve(admm_only=True)
+                self._require_converged(self.operator_solve(admm_only=True))
             self.agent_step(write_sc)
 
     def run_steps(self, count):
@@ -1540,10 +1561,10 @@ class AdmmEngine:
                 and (self.group is None or self._comm is not None))
 
     def _stream_run(self, count):
-        """Up to `count` steady-state iterations, one launch each, the queue kept full by the
-        native loop; the first iteration whose rows are not within tolerance ends the call and
-        is finished here as step() finishes a discarded speculative sweep.  Returns the number
-        of iterations done (at least one)."""
+        """Up to `count` steady-state iterations (at most the current burst), one launch each,
+        enqueued in one go by the native loop; the first iteration whose rows are not within
+        tolerance silences the launches behind it and is finished here as step() finishes a
+        discarded speculative sweep.  Returns the number of iterations done (at least one)."""
         o = self.op
         scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
         p0 = self._fused_p
@@ -1559,10 +1580,12 @@ class AdmmEngine:
         for i in range(2):
             st.p_sch[i], st.gamma[i] = ptr(pss[i]), ptr(gs[i])
         kept, rm = C.c_int32(), C.c_double()
+        count = min(count, self._burst)
         check(self.lib.revs_plan_stream_run(self._plan, count, C.byref(st), scale, o.eps,
-                                            o.stream_chunk, C.addressof(kept), C.addressof(rm),
-                                            self.stream), "revs_plan_stream_run")
+                                            C.addressof(kept), C.addressof(rm), self.stream),
+              "revs_plan_stream_run")
         n = kept.value
+        self._burst = min(4 * self._burst, o.stream_burst_max) if n == count else o.stream_burst
         by = {t.data_ptr(): t for t in pes + pss + gs + ps}
         self.P_est, self.P_est_new, self.P_est_alt = (by[st.p_est[i]] for i in range(3))
         self.P_sch, self.P_sch_alt = by[st.p_sch[0]], by[st.p_sch[1]]

@@ -622,7 +622,7 @@ def test_streaming_steady_state_equals_dense_product_path(gpu_lib, mode, stress,
                       stress=stress)
     w.load, w.cost = f32(w.load), f32(w.cost)
     a = _engine(w, mode, op=OperatorOptions(voltage="dense"))
-    b = _engine(w, mode, op=OperatorOptions(voltage="tree", stream_chunk=3))
+    b = _engine(w, mode, op=OperatorOptions(voltage="tree", stream_burst=3, stream_burst_max=24))
     assert a._tree is None and b._tree is not None
     for chunk in (1, 7, 30, 2, 50):
         a.run_steps(chunk)

@@ -272,3 +272,22 @@ def test_operator_paths_on_fake_kernels(stress, paths):
         k = e.op_path_hist.index("home")
         assert set(e.op_path_hist[k:]) == {"home"} and e.P_est.min().item() == 0.0
     assert np.abs(e.result()[1] - S_ref).max() < 1e-5 and np.abs(d - d_ref).max() < 1e-6
+
+
+def test_operator_not_converged_is_an_error_not_an_answer():
+    """An operator QP that stops at max_iter above its tolerance raises REVS_ENOTCONV from
+    step() / run() instead of handing a half-projected estimate to the residences."""
+    from fake_kernels import FakeKernels
+    from helpers import f32
+    from revs_admm_amd import _lib
+    from revs_admm_amd.engine import AdmmEngine, OperatorOptions
+    from revs_admm_amd.synthetic import make_workload
+    w = make_workload(150, 12, n_nodes=20, seed=2, stress=1.6, binary_feasible=False)
+    w.load, w.cost = f32(w.load), f32(w.cost)
+    e = AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, kappa=w.kappa, vset=w.vset,
+                   vlow=w.vlow, vhigh=w.vhigh, mode="relaxed_exact", device="cpu",
+                   _kernels=FakeKernels(),
+                   op=OperatorOptions(solver="admm", max_iter=25, eps=1e-13, calibrate=False))
+    with pytest.raises(_lib.RevsError, match="REVS_ENOTCONV"):
+        e.run(6)
+    assert 1 <= e.iteration < 6                     # (the first iterations need no projection)
