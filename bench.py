@@ -300,13 +300,18 @@ def main():
             spin_s = time.perf_counter() - t1
             clock_warm(e2)
             s0, c0 = list(e2.spec_hist), list(e2.chain_hist)
-            d2, _ = timed_steps(e2, steps)
+            # three blocks of `steps`; the median block is the regime's figure (these regimes have
+            # the host in every iteration: a descheduled host thread costs a block ~10 ms once in
+            # a while on a shared box -- all three blocks are listed)
+            blocks = [timed_steps(e2, steps)[0] / steps * 1e3 for _ in range(3)]
+            d2 = float(np.median(blocks)) * 1e-3 * steps
             out = {"value": homes * steps / d2, "unit": "solves/s", "ms_per_step": d2 / steps * 1e3,
+                   "blocks_ms_per_step": blocks,
                    "homes": homes, "T": T, "home_solver": mode, "stress": stress,
                    "first_iterations": spin, "first_iterations_ms": spin_s * 1e3,
                    "steady_state_steps_kept": e2.spec_hist[0] - s0[0],
                    "chained_newton_steps": e2.chain_hist[0] - c0[0],
-                   "operator_evaluations_per_step": float(np.mean(e2.op_iters_hist[-steps:]))}
+                   "operator_evaluations_per_step": float(np.mean(e2.op_iters_hist[-3 * steps:]))}
             del e2, w2
             torch.cuda.empty_cache()
             return out
@@ -382,6 +387,7 @@ def main():
                 # two HIP events around the K timed launches on their stream / K: the launch
                 # duration INCLUDING the inter-kernel boundary (rocprofv3's kernel time is shorter)
                 "avg_launch_ms": launch_ms,
+                "frac_of_achievable_copy_rate": (ach / 6290.0) if ach else None,   # 6.29 TB/s: float4 copy
                 "pdhg_iters_mean": pdhg_it,
             },
             "roofline_matvec": {

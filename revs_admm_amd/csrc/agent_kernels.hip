@@ -160,18 +160,13 @@ __device__ __forceinline__ void stream_verdict_body(const AgentArgs &a, const in
     rec[2] = (double)a.seq;
 }
 
-// A wavefront works through G consecutive groups of residences; the loads of group g + 1 are
-// issued before the arithmetic of group g (two input sets in registers), so that memory stays
-// busy while a group is being solved and the whole grid is resident at once at the benchmark
-// size (100 000 homes x T = 24, G = 3: 4 167 wavefronts on 1 024 SIMDs) instead of needing a
-// second, half-empty residency round.  Occupancy: G = 1 fits 64 VGPRs (8 wavefronts per SIMD) and
-// so do the verdict workgroups that share the launch (tree_body.h); G > 1 trades occupancy
-// (5 per SIMD) for the prefetched set.
-// G > 1 is instantiated only for T == LPA * SPL (every lane's slots exist: no ragged path, no
-// per-slot validity masks -- the scalar registers they cost are what the second input set needs).
-template <int LPA, int SPL, int MODE, bool FULL_ROWS = false, int G = 1>
-__global__ __launch_bounds__(kBlock)
-__attribute__((amdgpu_waves_per_eu(G > 1 ? (SPL <= 4 ? 5 : 4) : (SPL <= 4 && !FULL_ROWS ? 8 : 4))))
+// 64 VGPRs = 8 wavefronts per SIMD: the sweep's own path needs 56; the verdict workgroups that
+// share its launch are written to fit the same budget (tree_body.h) and must not lower it.
+// (Measured and rejected, round 2: a wavefront working through 2-4 groups of residences with the
+// next group's loads in flight -- the second input set costs 118-128 VGPRs, occupancy 4, and the
+// launch takes 24-25 us against 20; without the prefetch the loop spills at the 64-register cap.)
+template <int LPA, int SPL, int MODE, bool FULL_ROWS = false>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SPL <= 4 && !FULL_ROWS ? 8 : 4)))
 void agent_step_kernel(const AgentArgs a) {
     constexpr int kHomesPerBlock = kBlock / LPA;
     if (a.ctl && a.ctl->bad_seq < a.seq) return;           // an earlier verdict failed: no-op
@@ -186,8 +181,7 @@ void agent_step_kernel(const AgentArgs a) {
     const int T = a.T;
     const int t0 = lig * SPL;
     const float kappa = a.kappa;
-    constexpr bool EXACT = G > 1;            // the launcher guarantees T == LPA * SPL
-    const bool tfull = EXACT || t0 + SPL <= T;   // this lane's SPL slots all exist: one dwordxSPL per profile
+    const bool tfull = t0 + SPL <= T;        // this lane's SPL slots all exist: one dwordxSPL per profile
     // pe_new == NULL (multipliers all zero): the operator's answer max(g0, 0) is recomputed
     // below from the three profiles it is a function of, instead of being read
     const bool rec_pen = a.pe_new == nullptr;
@@ -196,75 +190,59 @@ void agent_step_kernel(const AgentArgs a) {
     bool tval[SPL];
 #pragma unroll
     for (int j = 0; j < SPL; ++j) {
-        tval[j] = EXACT || t0 + j < T;
+        tval[j] = t0 + j < T;
         cst[j] = tval[j] ? a.cost[t0 + j] : 0.f;
     }
     // node sums of the next home pass: residences are sorted by node, so a workgroup's homes
     // sit on a few consecutive nodes -- accumulate in LDS, flush one global add per (node, slot)
     constexpr int kNodeLoc = 4, kSlots = LPA * SPL;
     __shared__ double nacc[kNodeLoc][kSlots];
-    const int64_t first = (int64_t)bid * kHomesPerBlock * G;
+    const int64_t first = (int64_t)bid * kHomesPerBlock;
+    // Every global load of the kernel is issued before the first use of any of them (one exposed
+    // memory latency per wavefront, not three): profiles, then the home record and the carried
+    // PDHG multiplier.
+    const int64_t agent = first + tid / LPA;
+    const bool live = agent < a.n;
+    const int64_t row = agent * (int64_t)T;
+    float L[SPL], pe[SPL], pso[SPL], gm[SPL], pen[SPL];
+    if (live && tfull) {
+        ld_pack<SPL>(a.load + row + t0, L);
+        ld_pack<SPL>(a.pe_old + row + t0, pe);
+        if (!rec_pen) ld_pack<SPL>(a.pe_new + row + t0, pen);
+        ld_pack<SPL>(a.ps + row + t0, pso);
+        ld_pack<SPL>(a.gam + row + t0, gm);
+    } else {
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+            // out-of-range lanes read element 0 (always mapped) and discard it: straight-line
+            // loads instead of one exec-masked branch per element
+            const bool v = live && tval[j];
+            const int64_t o = v ? row + t0 + j : 0;
+            const float vL = a.load[o], vpe = a.pe_old[o], vpn = pen_src[o], vps = a.ps[o], vg = a.gam[o];
+            L[j] = v ? vL : 0.f;
+            pe[j] = v ? vpe : 0.f;
+            pen[j] = v ? vpn : 0.f;
+            pso[j] = v ? vps : 0.f;
+            gm[j] = v ? vg : 0.f;
+        }
+    }
+    revs_home_t h;
+    float yy_in = 0.f;
+    if (live) {
+        h = a.homes[agent];
+        if constexpr (MODE == REVS_MODE_RELAXED_PDHG && !FULL_ROWS)
+            if (a.y_state) yy_in = a.y_state[agent];
+    } else {
+        h.ev = 0; h.start = 0; h.end = 0; h.nmin = 0; h.nmax = 0;
+        h.rating = 0.f; h.capacity = 1.f; h.initial = 0.f;
+    }
     int base = 0;
-    if (a.p_next) {
+    if (a.p_next) {      // (behind the loads: the barrier does not wait for them)
         for (int i = tid; i < kNodeLoc * kSlots; i += kBlock) (&nacc[0][0])[i] = 0.0;
         base = a.node_of[first < a.n ? first : a.n - 1];
         __syncthreads();
     }
-    // Every global load of a group is issued before the first use of any of them (one exposed
-    // memory latency, not three): profiles, then the home record and the carried multiplier.
-    auto load_group = [&](int g, float (&iL)[SPL], float (&ipe)[SPL], float (&ipso)[SPL],
-                          float (&igm)[SPL], float (&ipen)[SPL], revs_home_t &ih, float &iyy,
-                          int64_t &iagent, bool &ilive) {
-        iagent = first + (int64_t)g * kHomesPerBlock + tid / LPA;
-        ilive = iagent < a.n;
-        const int64_t row = iagent * (int64_t)T;
-        if (ilive && tfull) {
-            ld_pack<SPL>(a.load + row + t0, iL);
-            ld_pack<SPL>(a.pe_old + row + t0, ipe);
-            if (!rec_pen) ld_pack<SPL>(a.pe_new + row + t0, ipen);
-            ld_pack<SPL>(a.ps + row + t0, ipso);
-            ld_pack<SPL>(a.gam + row + t0, igm);
-        } else if constexpr (EXACT) {
-#pragma unroll
-            for (int j = 0; j < SPL; ++j) { iL[j] = 0.f; ipe[j] = 0.f; ipen[j] = 0.f; ipso[j] = 0.f; igm[j] = 0.f; }
-        } else {
-#pragma unroll
-            for (int j = 0; j < SPL; ++j) {
-                // out-of-range lanes read element 0 (always mapped) and discard it: straight-line
-                // loads instead of one exec-masked branch per element
-                const bool v = ilive && tval[j];
-                const int64_t o = v ? row + t0 + j : 0;
-                const float vL = a.load[o], vpe = a.pe_old[o], vpn = pen_src[o], vps = a.ps[o], vg = a.gam[o];
-                iL[j] = v ? vL : 0.f;
-                ipe[j] = v ? vpe : 0.f;
-                ipen[j] = v ? vpn : 0.f;
-                ipso[j] = v ? vps : 0.f;
-                igm[j] = v ? vg : 0.f;
-            }
-        }
-        iyy = 0.f;
-        if (ilive) {
-            ih = a.homes[iagent];
-            if constexpr (MODE == REVS_MODE_RELAXED_PDHG && !FULL_ROWS)
-                if (a.y_state) iyy = a.y_state[iagent];
-        } else {
-            ih.ev = 0; ih.start = 0; ih.end = 0; ih.nmin = 0; ih.nmax = 0;
-            ih.rating = 0.f; ih.capacity = 1.f; ih.initial = 0.f;
-        }
-    };
-    // the group being solved, and the one whose loads are in flight
-    float L[SPL], pe[SPL], pso[SPL], gm[SPL], pen[SPL];
-    float nL[SPL], npe[SPL], npso[SPL], ngm[SPL], npen[SPL];
-    revs_home_t h, nh;
-    float yy_in, nyy;
-    int64_t agent, nagent;
-    bool live, nlive;
-    load_group(0, L, pe, pso, gm, pen, h, yy_in, agent, live);
-#pragma unroll 1
-    for (int grp = 0; grp < G; ++grp) {
-    if (G > 1 && grp + 1 < G) load_group(grp + 1, nL, npe, npso, ngm, npen, nh, nyy, nagent, nlive);
     const bool full = live && tfull;
-    const int64_t row = agent * (int64_t)T;
     float q[SPL], p[SPL];
     bool valid[SPL], win[SPL];
 #pragma unroll
@@ -601,12 +579,6 @@ void agent_step_kernel(const AgentArgs a) {
             }
         }
     }
-    if (G > 1 && grp + 1 < G) {
-#pragma unroll
-        for (int j = 0; j < SPL; ++j) { L[j] = nL[j]; pe[j] = npe[j]; pso[j] = npso[j]; gm[j] = ngm[j]; pen[j] = npen[j]; }
-        h = nh; yy_in = nyy; agent = nagent; live = nlive;
-    }
-    }   // groups of this wavefront
     if (a.p_next) {
         __syncthreads();
         for (int i = tid; i < kNodeLoc * T; i += kBlock) {
@@ -745,59 +717,24 @@ static Shape pick_shape(int T) {
     return {64, 3};
 }
 
-template <int LPA, int SPL, int G>
-static void launch_agent_g(const AgentArgs &a, int mode, dim3 grid, hipStream_t s) {
+template <int LPA, int SPL>
+static void launch_agent(const AgentArgs &a, int mode, dim3 grid, hipStream_t s) {
     // dynamic LDS: only a launch whose first workgroups run the tree form of R p needs any
-    // (REVS_AGENT_LDS_KB pads it: an occupancy experiment, read once)
-    static const size_t pad = [] { const char *v = getenv("REVS_AGENT_LDS_KB"); return v ? (size_t)atoi(v) * 1024 : 0; }();
-    const size_t lds = std::max(a.tree.n > 0 ? tree_lds_bytes(a.tree.n) : 0, pad);
+    const size_t lds = a.tree.n > 0 ? tree_lds_bytes(a.tree.n) : 0;
     switch (mode) {
         case REVS_MODE_BINARY:
-            hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_BINARY, false, G>), grid, dim3(kBlock), lds, s, a);
+            hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_BINARY>), grid, dim3(kBlock), lds, s, a);
             break;
         case REVS_MODE_RELAXED_PDHG:
-            if constexpr (G == 1) {
-                if (a.pd.full_rows) {
-                    hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_RELAXED_PDHG, true, 1>), grid, dim3(kBlock), lds, s, a);
-                    break;
-                }
-            }
-            hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_RELAXED_PDHG, false, G>), grid, dim3(kBlock), lds, s, a);
+            if (a.pd.full_rows)
+                hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_RELAXED_PDHG, true>), grid, dim3(kBlock), lds, s, a);
+            else
+                hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_RELAXED_PDHG, false>), grid, dim3(kBlock), lds, s, a);
             break;
         default:
-            hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_RELAXED_EXACT, false, G>), grid, dim3(kBlock), lds, s, a);
+            hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_RELAXED_EXACT>), grid, dim3(kBlock), lds, s, a);
             break;
     }
-}
-
-// Groups of residences per wavefront (template parameter G of agent_step_kernel).  More than
-// one only for the two shapes the benchmarks run (T <= 24: 8 x 3, 64 < T <= 96: 16 x 6), and only
-// when the launch still has at least two wavefronts per SIMD: a small problem wants parallelism,
-// not pipelining.  REVS_AGENT_GROUPS = 1..4 overrides (tuning hook, read once).
-static int pick_groups(const Shape &sh, int T, int64_t n_homes, bool full_rows) {
-    static const int env = [] {
-        const char *v = getenv("REVS_AGENT_GROUPS");
-        const int g = v ? atoi(v) : 0;
-        return (g >= 1 && g <= 4) ? g : 0;
-    }();
-    const bool multi = ((sh.lpa == 8 && sh.spl == 3) || (sh.lpa == 16 && sh.spl == 6)) && !full_rows &&
-                       T == sh.lpa * sh.spl;
-    if (!multi) return 1;
-    (void)n_homes;
-    return env ? env : 1;
-}
-
-template <int LPA, int SPL>
-static void launch_agent(const AgentArgs &a, int mode, dim3 grid, hipStream_t s, int groups) {
-    if constexpr ((LPA == 8 && SPL == 3) || (LPA == 16 && SPL == 6)) {
-        switch (groups) {
-            case 2: return launch_agent_g<LPA, SPL, 2>(a, mode, grid, s);
-            case 3: return launch_agent_g<LPA, SPL, 3>(a, mode, grid, s);
-            case 4: return launch_agent_g<LPA, SPL, 4>(a, mode, grid, s);
-            default: break;
-        }
-    }
-    launch_agent_g<LPA, SPL, 1>(a, mode, grid, s);
 }
 
 #define REVS_FOR_SHAPE(sh, CALL)                                   \
@@ -830,10 +767,10 @@ extern "C" void revs_pdhg_defaults(revs_pdhg_t *o) {
     o->full_rows = 0;
 }
 
-static int64_t agent_num_blocks(int64_t n_homes, int32_t T, int groups) {
+static int64_t agent_num_blocks(int64_t n_homes, int32_t T) {
     if (n_homes <= 0 || T <= 0 || T > REVS_MAX_T) return 0;
     const Shape sh = pick_shape(T);
-    const int64_t per = (int64_t)(kBlock / sh.lpa) * groups;
+    const int64_t per = kBlock / sh.lpa;
     return (n_homes + per - 1) / per;
 }
 
@@ -887,12 +824,11 @@ static int agent_step_impl(int64_t n_homes, int32_t T, const float *cost,
     REVS_REQUIRE(a.pd.max_iter > 0 && a.pd.check > 0 && a.pd.tau_scale >= 0 && a.pd.sigma_scale >= 0,
                  "revs_agent_step: bad PDHG parameters");
     const Shape sh = pick_shape(T);
-    const int groups = pick_groups(sh, T, n_homes, a.pd.full_rows != 0);
-    const int64_t nblk = agent_num_blocks(n_homes, T, groups);
+    const int64_t nblk = agent_num_blocks(n_homes, T);
     REVS_REQUIRE(nblk < (1ll << 31), "revs_agent_step: too many homes for one launch");
     const dim3 grid((unsigned)(nblk + a.nsel));
     hipStream_t s = (hipStream_t)stream;
-#define CALL(LPA, SPL) launch_agent<LPA, SPL>(a, mode, grid, s, groups)
+#define CALL(LPA, SPL) launch_agent<LPA, SPL>(a, mode, grid, s)
     REVS_FOR_SHAPE(sh, CALL);
 #undef CALL
     REVS_CHECK_LAUNCH("revs_agent_step");

@@ -397,10 +397,11 @@ class AdmmEngine:
             self.P_est_alt = torch.zeros(n, T, **f32)
             self.p_alt = nz()                         # second buffer of the fused node sums
             d.node_of = ptr(self.node_of_dev)
-            # where the sweep is bandwidth-bound it recomputes the operator's steady-state answer
-            # instead of reading it (same bits; REVS_RECOMPUTE=0/1 overrides the size rule)
+            # with no multipliers the sweep recomputes the operator's answer instead of reading it
+            # (same bits, one input stream less: 20.0 -> 19.0 us per launch at 100k homes x 24,
+            # round 2; REVS_RECOMPUTE=0 restores the read)
             rec = os.environ.get("REVS_RECOMPUTE", "").strip()
-            d.recompute_pe_new = int(rec not in ("0", "false", "no")) if rec else int(n * T >= 6_000_000)
+            d.recompute_pe_new = int(rec not in ("0", "false", "no")) if rec else 1
             self.recompute_pe_new = bool(d.recompute_pe_new)
             d.cand_idx1, d.cand_cnt1, d.cand_val1 = (ptr(self.c_idx[1]), ptr(self.c_cnt[1]),
                                                      ptr(self.c_val[1]))
