@@ -1391,29 +1391,6 @@ class AdmmEngine:
             self.P_est_new, self.P_est_alt = self.P_est_alt, self.P_est_new
         self.iteration += 1
 
-    def replay_sweep(self, p_scratch, pe_scratch, fused=True, dual=None):
-        """Measurement aid (bench.py): enqueue once more the steady-state launch of
-        revs_plan_spec_step's second phase -- home sweep with the candidate selection in its
-        first T workgroups and, with `fused`, the next evaluation's home pass -- on the
-        current state, writing to the spare buffers and to the caller's scratch arrays
-        (p_scratch double[M][T], pe_scratch float[n][T]; `dual`: a copy of pdhg_dual to use and
-        overwrite instead of the run's); the run is not advanced."""
-        M, T = self.M, self.T
-        nb = (M + 31) // 32
-        check(self.lib.revs_agent_step_select(
-            self.n, T, ptr(self.cost), ptr(self.homes), ptr(self.load), ptr(self.P_est),
-            None if (self.recompute_pe_new and not self._y_support) else ptr(self.P_est_new),
-            ptr(self.P_sch), ptr(self.G),
-            ptr(self.P_sch_alt), ptr(self.G_alt),
-            None, None, ptr(self.diff), ptr(self.dsq), ptr(self.status),
-            ptr(self.pdhg_dual if dual is None else dual),
-            self.kappa, self.mode, C.byref(self.pdhg), M, ptr(self.d_part), ptr(self.yd[0]),
-            self.vlo, self.vhi, self.op.newton_kadd, ptr(self.vfull), ptr(self.violw),
-            ptr(self.c_idx[1]), ptr(self.c_cnt[1]), ptr(self.c_val[1]), self.stats_dev[1], -1.0,
-            ptr(self.node_of_dev) if fused else None, ptr(p_scratch) if fused else None,
-            ptr(pe_scratch) if fused else None, nb if (T <= 32 and nb <= 256) else 0,
-            self.stream), "revs_agent_step_select")
-
     def _spec_discard(self, stt, write_sc):
         """A speculative sweep whose evaluation found rows beyond tolerance: finish the Newton
         solve (from the evaluation's stats `stt` when they carry a dual value), run the sweep

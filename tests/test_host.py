@@ -291,3 +291,53 @@ def test_operator_not_converged_is_an_error_not_an_answer():
     with pytest.raises(_lib.RevsError, match="REVS_ENOTCONV"):
         e.run(6)
     assert 1 <= e.iteration < 6                     # (the first iterations need no projection)
+
+
+def test_feeder_as_a_tree_reproduces_R(golden, feeder_R):
+    """feeder_tree / tree_voltage_host (the host side of revs_tree_t, and the numpy restatement of
+    the kernel's three prefix sums): R p from the tree == the dense product, on the 121144 feeder
+    (1691 tree nodes, 1126 constraint rows, extracted from a networkx graph as solve_ADMM does),
+    on a synthetic forest with nodes that carry no residence, and through the padding to a
+    multiple of 8 positions; a tree that does not match Rn is refused by the engine."""
+    import networkx as nx
+    from revs_admm_amd.engine import feeder_tree, tree_voltage_host
+    from revs_admm_amd.lpsolver import feeder_arrays
+    from revs_admm_amd.synthetic import make_workload
+    z, fd = golden
+    g = nx.Graph()
+    for nid, lab in zip(z["node_id"], fd.label):
+        g.add_node(int(nid), label=lab.decode())
+    for u, v, r in zip(fd.edge_u, fd.edge_v, fd.edge_r):
+        g.add_edge(int(z["node_id"][u]), int(z["node_id"][v]), r=float(r))
+    res = [n for n in g if g.nodes[n]["label"] == "H"]
+    par, er, cons = feeder_arrays(g, res)
+    assert len(par) == 1691 and (cons >= 0).sum() == 1126 and (par < 0).sum() >= 1
+    tr = feeder_tree(par, er, cons, np.ones(len(res), bool))
+    assert tr["n"] == 1696 and tr["n"] % 8 == 0                    # padded
+    rng = np.random.default_rng(0)
+    p = rng.uniform(0, 3, (len(res), 5))
+    ref = feeder_R @ p
+    assert np.abs(tree_voltage_host(tr, p) - ref).max() < 1e-12 * np.abs(ref).max()
+    # subtree ranges are nested or disjoint, ends sorted, cle consistent
+    j = np.arange(tr["n"])
+    assert (tr["end"] > j).all() and (np.diff(tr["end"][tr["eo"]]) >= 0).all()
+    assert (tr["cle"] == np.searchsorted(np.sort(tr["end"]), j, side="right")).all()
+    w = make_workload(900, 24, n_nodes=300, seed=4)
+    chk = rng.random(300) < 0.6
+    tr = feeder_tree(*w.feeder, chk)
+    p = rng.uniform(0, 3, (300, 3)) * chk[:, None]
+    ref = (w.Rn @ p) * chk[:, None]
+    got = tree_voltage_host(tr, p)
+    assert np.abs(got - ref).max() < 1e-12 * np.abs(ref).max() and (got[~chk] == 0).all()
+    assert (tr["src"] >= 0).sum() == chk.sum() and (w.parent < 0).sum() > 1     # a forest
+    with pytest.raises(ValueError, match="forest"):
+        feeder_tree(np.array([1, 0]), np.ones(2), np.arange(2), np.ones(2, bool))   # a cycle
+    # the engine checks a feeder against Rn before it trusts it
+    from fake_kernels import FakeKernels
+    from revs_admm_amd.engine import AdmmEngine
+    kw = dict(kappa=w.kappa, vset=w.vset, vlow=w.vlow, vhigh=w.vhigh, mode="relaxed_exact",
+              device="cpu", _kernels=FakeKernels())
+    e = AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, feeder=w.feeder, **kw)
+    assert e._tree is not None and e._plan is None
+    with pytest.raises(ValueError, match="does not reproduce Rn"):
+        AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, feeder=(w.parent, w.edge_r * 1.01, np.arange(300)), **kw)
