@@ -71,7 +71,7 @@ struct AgentArgs {
     // (tree_body.h) instead of running the candidate selection, clear their share of p_zero,
     // and the last of them to finish leaves the launch's record {rmax, failed, seq} in `rec`.
     StreamCtl *ctl;
-    unsigned int seq;
+    unsigned int seq, base_seq;   // this launch's number; the first number of the current call
     TreeArgs tree;
     const double *p_in;
     double *p_zero;
@@ -138,8 +138,10 @@ __device__ __forceinline__ void stream_verdict_body(const AgentArgs &a, const in
     }
     const double rmax = tree_rmax(a.tree, a.p_in, a.T, t, a.sel.vlo, a.sel.vhi, tree_lds, nullptr);
     if (tid != 0) return;
+    // (every later launch of the call is silenced, so a call writes at most this one value; a
+    // number left by an earlier call is below base_seq and ignored: no re-arming between calls)
     if (!(rmax <= a.vtol))
-        __hip_atomic_fetch_min(&a.ctl->bad_seq, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&a.ctl->bad_seq, a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_fetch_max(&a.ctl->rmax_bits, (unsigned long long)__double_as_longlong(rmax),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // both performed before this slot is counted
@@ -155,7 +157,7 @@ __device__ __forceinline__ void stream_verdict_body(const AgentArgs &a, const in
     __hip_atomic_store(&a.ctl->rmax_bits, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     volatile double *rec = a.rec;
     rec[0] = __longlong_as_double((long long)bits);
-    rec[1] = bad <= a.seq ? 1.0 : 0.0;
+    rec[1] = (bad >= a.base_seq && bad <= a.seq) ? 1.0 : 0.0;
     __threadfence_system();
     rec[2] = (double)a.seq;
 }
@@ -169,7 +171,10 @@ template <int LPA, int SPL, int MODE, bool FULL_ROWS = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SPL <= 4 && !FULL_ROWS ? 8 : 4)))
 void agent_step_kernel(const AgentArgs a) {
     constexpr int kHomesPerBlock = kBlock / LPA;
-    if (a.ctl && a.ctl->bad_seq < a.seq) return;           // an earlier verdict failed: no-op
+    if (a.ctl) {       // an earlier launch of this call failed its verdict: no-op
+        const unsigned int bad = a.ctl->bad_seq;
+        if (bad >= a.base_seq && bad < a.seq) return;
+    }
     if (a.nsel > 0 && (int)blockIdx.x < a.nsel) {          // uniform per workgroup
         if (a.tree.n > 0) stream_verdict_body(a, (int)blockIdx.x);
         else dual_select_body(a.sel, (int)blockIdx.x);
@@ -808,14 +813,14 @@ static int agent_step_impl(int64_t n_homes, int32_t T, const float *cost,
     if (sel) { a.nsel = sel->T; a.sel = *sel; }
     a.node_of = node_of; a.p_next = p_next; a.pe2_out = pe2_out;
     REVS_REQUIRE(!p_next || (node_of && pe2_out), "revs_agent_step: node_of / pe2_out missing");
-    a.ctl = nullptr; a.seq = 0; a.tree = TreeArgs{}; a.p_in = nullptr; a.p_zero = nullptr;
+    a.ctl = nullptr; a.seq = 0; a.base_seq = 0; a.tree = TreeArgs{}; a.p_in = nullptr; a.p_zero = nullptr;
     a.vtol = 0.0; a.rec = nullptr; a.flags = flags; a.m = 0;
     if (sx) {
         REVS_REQUIRE(sx->ctl && sx->rec && sx->p_in && sx->tree.n > 0 && sx->tree.n <= REVS_TREE_MAX && sx->tree.n % 8 == 0 &&
                      sx->tree.src && sx->tree.end && sx->tree.eo && sx->tree.cle && sx->tree.w &&
                      sx->m > 0 && sx->vlo <= sx->vhi && sx->vtol >= 0.0 && !sel,
                      "revs_agent_step: bad streaming argument");
-        a.ctl = sx->ctl; a.seq = sx->seq; a.tree = sx->tree; a.p_in = sx->p_in; a.p_zero = sx->p_zero;
+        a.ctl = sx->ctl; a.seq = sx->seq; a.base_seq = sx->base_seq; a.tree = sx->tree; a.p_in = sx->p_in; a.p_zero = sx->p_zero;
         a.vtol = sx->vtol; a.rec = sx->rec; a.flags = sx->flags; a.m = sx->m;
         a.nsel = T;
         a.sel.vlo = sx->vlo; a.sel.vhi = sx->vhi;

@@ -8,7 +8,7 @@ namespace revs {
 // What the streaming steady state adds to a sweep's launch (AgentArgs in agent_kernels.hip).
 struct StreamExtra {
     StreamCtl *ctl;          // control block (device); NULL: an ordinary launch
-    unsigned int seq;
+    unsigned int seq, base_seq;   // this launch; the first launch of the call it belongs to
     TreeArgs tree;           // tree.n > 0: the first T workgroups judge the voltage rows
     const double *p_in;      // node sums they judge
     double *p_zero;          // array they clear for the launch after this one (or NULL)

@@ -113,7 +113,7 @@ extern "C" revs_plan_t *revs_plan_create(const revs_plan_desc_t *desc) {
         return nullptr;
     }
     // control block, record ring and status word of the streaming steady state
-    const revs::StreamCtl ctl0{~0u, 0u, 0ull};
+    const revs::StreamCtl ctl0{0u, 0u, 0ull};
     void *host = nullptr;
     what = "hipMalloc";
     e = hipMalloc((void **)&p->ctl, sizeof(revs::StreamCtl));
@@ -580,12 +580,16 @@ extern "C" int revs_plan_stream_run(revs_plan_t *plan, int32_t max_steps, revs_s
     *kept_steps = 0;
     *rmax_last = 0.0;
     if (max_steps == 0) return REVS_OK;
-    // a failed verdict of an earlier call must not silence this one: re-arm the control block
-    // (the previous call drained the stream before it returned, so nothing is in flight)
-    const revs::StreamCtl ctl0{~0u, 0u, 0ull};
-    if (hipMemcpyAsync(plan->ctl, &ctl0, sizeof(ctl0), hipMemcpyHostToDevice, s) != hipSuccess) {
-        revs::set_error("revs_plan_stream_run: hipMemcpyAsync failed");
-        return REVS_ELAUNCH;
+    // (sequence numbers only grow: what an earlier call left in the control word is below this
+    // call's first number and ignored by the kernels -- nothing to re-arm, no copy on the stream)
+    if (plan->stream_seq > 0xFFFF0000u) {                // wrap, once in 4e9 launches: start over
+        const revs::StreamCtl ctl0{0u, 0u, 0ull};
+        if (hipStreamSynchronize(s) != hipSuccess ||
+            hipMemcpy(plan->ctl, &ctl0, sizeof(ctl0), hipMemcpyHostToDevice) != hipSuccess) {
+            revs::set_error("revs_plan_stream_run: resetting the control block failed");
+            return REVS_ELAUNCH;
+        }
+        plan->stream_seq = 0;
     }
     const unsigned int seq0 = plan->stream_seq + 1;
     const int64_t mt = (int64_t)d.m * d.T;
@@ -593,6 +597,7 @@ extern "C" int revs_plan_stream_run(revs_plan_t *plan, int32_t max_steps, revs_s
         revs::StreamExtra sx;
         sx.ctl = plan->ctl;
         sx.seq = seq0 + (unsigned int)k;
+        sx.base_seq = seq0;
         sx.tree = plan->tree;
         sx.p_in = st->p[k % 3];
         sx.p_zero = st->p[(k + 2) % 3];

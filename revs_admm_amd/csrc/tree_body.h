@@ -161,7 +161,7 @@ __device__ __forceinline__ double tree_rmax(const TreeArgs &tr, const double *p,
 
 // Control block of the streaming steady state (device memory, owned by the plan).
 struct StreamCtl {
-    unsigned int bad_seq;                 // smallest sequence number whose verdict failed; ~0u: none
+    unsigned int bad_seq;                 // sequence number of the last launch whose verdict failed (0: none yet)
     unsigned int arrive;                  // tree workgroups of the current launch that are done
     unsigned long long rmax_bits;         // max over their slots (bit pattern of a double >= 0)
 };

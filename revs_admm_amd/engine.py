@@ -416,6 +416,7 @@ class AdmmEngine:
         # third node-sum buffer and the feeder as a tree: streaming steady state
         self.p_alt2 = nz()
         self._burst = max(1, int(self.op.stream_burst))
+        self._p_clear = None             # the node-sum array the last streaming launch cleared
         self._tree = None
         self._comm = None
         if feeder is not None and self.op.voltage in ("auto", "tree"):
@@ -1141,6 +1142,7 @@ class AdmmEngine:
                 f"{self.op.max_iter} above eps = {self.op.eps:g}")
 
     def operator_solve(self, admm_only=False):
+        self._p_clear = None
         """Utility(graph, P_est[k], P_sch[k], G[k]).solve() -> P_est[k+1]
         (lpsolver.py:256-259), written to self.P_est_new.  `admm_only`: skip the dual
         Newton attempt (the caller has just seen it fail for this state)."""
@@ -1265,6 +1267,7 @@ class AdmmEngine:
         if not write_sc and not events and self._fused_ready and self._stream_ok():
             self._stream_run(1)              # steady state: one launch, verdict inside it
             return
+        self._p_clear = None                 # (every other path rewrites the node-sum arrays)
         if o.solver == "newton" and o.speculate and self._spec_ok:
             # steady state: the multipliers of the last iteration are expected to stand
             scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
@@ -1411,6 +1414,7 @@ class AdmmEngine:
         (revs_plan_chain_run); the first one that is not the usual outcome is finished here as
         step() would.  Returns the number of iterations done (at least one)."""
         self._fused_ready = False
+        self._p_clear = None
         ys = (self.yd[0], self.yd[1])
         bufs = (self.P_est, self.P_est_new, self.P_sch, self.P_sch_alt, self.G, self.G_alt)
         sup0 = self._sup if (self._y_support and self._sup is not None) else -1
@@ -1492,6 +1496,10 @@ class AdmmEngine:
                 done += 1
                 continue
             p0 = self.pnq[0]
+            self._p_clear = None
+            if self._fused_ready and self._fused_p is self.p_alt2:     # (revs_plan_spec_run knows two arrays)
+                p0.copy_(self.p_alt2)
+                self._fused_p = p0
             bufs = (self.P_est, self.P_est_new, self.P_est_alt, self.P_sch, self.P_sch_alt, self.G,
                     self.G_alt)
             st = _lib.SpecState(*[ptr(t) for t in bufs], ptr(p0), ptr(self.p_alt),
@@ -1547,7 +1555,13 @@ class AdmmEngine:
         scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
         p0 = self._fused_p
         rest = [b for b in (self.pnq[0], self.p_alt, self.p_alt2) if b.data_ptr() != p0.data_ptr()]
-        rest[0].zero_()
+        # p[1] must be zero on entry.  The last launch of a fully kept call has just cleared the
+        # array that is p[1] now (roles rotate): no fill launch then
+        if self._p_clear is not None and self._p_clear.data_ptr() != p0.data_ptr():
+            rest = [self._p_clear] + [b for b in rest if b.data_ptr() != self._p_clear.data_ptr()]
+        else:
+            rest[0].zero_()
+        self._p_clear = None
         if self.group is not None and not self._ar_ahead:
             self._allreduce(p0)
         pes = (self.P_est, self.P_est_new, self.P_est_alt)
@@ -1569,6 +1583,7 @@ class AdmmEngine:
         self.P_sch, self.P_sch_alt = by[st.p_sch[0]], by[st.p_sch[1]]
         self.G, self.G_alt = by[st.gamma[0]], by[st.gamma[1]]
         self._fused_p = by[st.p[0]]
+        self._p_clear = by[st.p[1]] if n == count else None
         self._prod_ahead = False
         self._ar_ahead = self.group is not None
         if n:
@@ -1644,6 +1659,7 @@ class AdmmEngine:
             t.copy_(torch.from_numpy(a))
         self._fused_ready = self._ar_ahead = self._prod_ahead = False
         self._fused_p = None
+        self._p_clear = None
         self._chain_ok = False
         if iteration is not None:
             self.iteration = int(iteration)
