@@ -238,6 +238,55 @@ def test_product_rows_in_one_launch_equals_two_kernels(gpu_lib):
     assert pb[:, :, 2].sum() == (y != 0).sum() and pb[:, :, 3].sum() > 0
 
 
+def test_product_rows_slab_handoff_under_load(gpu_lib):
+    """The K-split slabs of revs_op_dual_product_rows are handed between workgroups inside the
+    launch (sc1 stores, s_waitcnt vmcnt(0) in every storing wave, barrier, one agent-scope counter
+    add; the last workgroup of a tile reads them with sc1 loads).  Stress it the way such
+    hand-offs fail: 400 launches back to back at the benchmark shape (2048 nodes, 4 K-splits,
+    every tile summed by a workgroup that did not store 3 of its 4 slabs), the slabs POISONED
+    with NaN between launches so that a stale read cannot pass, a bandwidth-heavy kernel queued
+    between them (uneven load), a different p every launch -- against the two-kernel path
+    (product, then rows: a kernel boundary in between) on the same inputs, every word."""
+    import torch
+    from revs_admm_amd._lib import check, ptr
+    M, T, ks, reps = 2048, 24, 4, 400
+    rng = np.random.default_rng(5)
+    f64 = dict(dtype=torch.float64, device="cuda:0")
+    A = rng.uniform(0, 1, (M, 6))
+    R = A @ A.T + np.eye(M)
+    Rt = torch.from_numpy(R.T.copy()).to("cuda:0")
+    y = torch.zeros(M, T, **f64)
+    ps = [torch.from_numpy(np.stack([rng.uniform(0, 30, (M, T)), np.ones((M, T)), -np.ones((M, T))])).to("cuda:0")
+          for _ in range(8)]
+    vlo, vhi = -1e9, 1e9
+    nblk = (M + 31) // 32
+    vs = torch.zeros(ks, M, T, **f64)
+    cnt = torch.zeros(nblk, dtype=torch.int32, device="cuda:0")
+    vf = [torch.zeros(M, T, **f64) for _ in range(reps)]
+    vi, part = torch.zeros(M, T, **f64), torch.zeros(nblk, T, 4, **f64)
+    hog = torch.zeros(64 << 20, dtype=torch.float32, device="cuda:0")
+    for r in range(reps):
+        vs.fill_(float("nan"))                       # poison: a stale slab read shows up as NaN
+        if r % 3 == 0:
+            hog.add_(1.0)                            # uneven load on the memory system
+        check(gpu_lib.revs_op_dual_product_rows(M, T, ptr(Rt), ptr(ps[r % 8][0]), ptr(ps[r % 8]), ptr(y), vlo,
+                                                vhi, ks, ptr(vs), ptr(vf[r]), ptr(vi), ptr(part), None,
+                                                ptr(cnt), None))
+    torch.cuda.synchronize()
+    assert (cnt == 0).all()
+    ref = []
+    vs2, vf2 = torch.zeros(ks, M, T, **f64), torch.zeros(M, T, **f64)
+    part2 = torch.zeros(int(gpu_lib.revs_op_dual_blocks(M)), T, 4, **f64)
+    for k in range(8):
+        check(gpu_lib.revs_gemm_tn_f64_split(M, T, M, ptr(Rt), ptr(ps[k][0]), ptr(vs2), ks, None))
+        check(gpu_lib.revs_op_dual_rows(M, T, ks, ptr(vs2), ptr(ps[k]), ptr(y), vlo, vhi, ptr(vf2),
+                                        ptr(vi), ptr(part2), None, None))
+        ref.append(vf2.clone())
+    torch.cuda.synchronize()
+    bad = [r for r in range(reps) if not torch.equal(vf[r], ref[r % 8])]
+    assert not bad, f"stale or torn slab reads in launches {bad[:10]} (of {len(bad)})"
+
+
 @pytest.mark.parametrize("mode", [1, 0])
 def test_sweep_with_selection_and_next_home_pass(gpu_lib, mode):
     """revs_agent_step_select against its parts: the sweep's own outputs equal
