@@ -259,7 +259,7 @@ def main():
     # the same regime with the rows judged by the dense f64 product on the matrix cores (its own
     # launch before every sweep, verdict read by the host): what the tree form replaces
     dense = None
-    if eng._tree is not None and eng._plan is not None:
+    if eng._tree is not None and eng._plan is not None and world == 1:
         tree, eng._tree = eng._tree, None
         eng.run_steps(args.warmup)
         d_dt, _ = timed_steps(eng, args.steps)
