@@ -480,7 +480,7 @@ int revs_op_dual_step(int32_t T, const int64_t *cand_idx, const int32_t *cand_cn
  * model was built on: alpha_t = 1 if stats_prev[8 t] / scale > eps (rows of slot t not yet
  * within tolerance), else 0 -- what a driver that had read those stats would pass.  Lets a
  * driver enqueue evaluation, model, step and the next evaluation without reading anything in
- * between (engine.py: the binding steady state).  y (double[m][T]) != NULL: y_trial = y is
+ * between (operator_newton.py: the binding steady state).  y (double[m][T]) != NULL: y_trial = y is
  * copied by the same launch before the candidates are written (else the caller has done so). */
 int revs_op_dual_step_pending(int32_t T, const int64_t *cand_idx, const int32_t *cand_cnt,
                               const double *cand_val, const double *yhat,
@@ -503,7 +503,7 @@ int revs_op_dual_select_model_step(int32_t m, int32_t T, const double *sel_parti
                                    void *stream);
 /* Host only (no GPU work): the acceptance test of such a chained iteration on the two stats
  * blocks (double[T][8], as revs_op_dual_select writes them; s1[8 t + 4] = the step kernel's
- * linear term) -- returns 1 iff the driver's own checks (engine.py:
+ * linear term) -- returns 1 iff the driver's own checks (operator_newton.py:
  * AdmmEngine._operator_solve_newton) would find: evaluation 0 not yet within eps, at most 8
  * candidates per slot (the small model), the row-wise/dense choice `chain_few` right, the
  * Armijo test passed by the full step in every pending slot, and evaluation 1 within eps.
@@ -604,7 +604,7 @@ int revs_plan_spec_run(revs_plan_t *plan, int32_t max_steps, const double *y,
                        revs_spec_state_t *st, double scale, double eps, int32_t *kept_steps,
                        int32_t *last_fused_in, double *rmax_out, void *stream);
 
-/* The binding steady state as ONE host call (engine.py: AdmmEngine._chain_launch /
+/* The binding steady state as ONE host call (operator_newton.py: AdmmEngine._chain_launch /
  * _chain_accept; one GPU): evaluation of the multipliers y into candidate set 0 (home pass
  * row-wise from the lists of set `sup0` when use_y and sup0 >= 0, else dense),
  * revs_op_dual_select_model_step into y_trial, evaluation of y_trial into set 1 (home pass

@@ -53,7 +53,7 @@ struct revs_plan {
     revs_comm *comm = nullptr;
 };
 
-// Host-side acceptance test of a chained Newton iteration (engine.py: _chain_launch): the
+// Host-side acceptance test of a chained Newton iteration (operator_newton.py: _chain_launch): the
 // checks AdmmEngine._operator_solve_newton would make on the two evaluations' stats, for the
 // one outcome that needs no further launch.  See include/revs_admm.h.
 extern "C" int revs_newton_chain_accept(int32_t T, const double *s0, const double *s1, double scale,

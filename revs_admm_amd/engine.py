@@ -23,6 +23,10 @@ import torch
 
 from . import _lib
 from ._lib import HOME_DTYPE, MODES, PDHG, check, ptr
+from .feeder import feeder_tree, tree_voltage_host  # noqa: F401  (re-exported)
+from .operator_admm import AdmmFormsMixin
+from .operator_newton import DualNewtonMixin
+from .steady_state import SteadyStateMixin
 
 SOC_TARGET, SOC_MAX, _SOC_TOL = 0.9, 1.0, 1e-9
 
@@ -120,68 +124,7 @@ def _dev_check(device):
     return torch.device(device)
 
 
-def feeder_tree(parent, edge_r, cons_of, checked):
-    """Host-side preparation of revs_tree_t: the feeder's nodes in DFS preorder.
-
-    parent[i]   parent of tree node i, -1 when i hangs off the substation (a forest is fine)
-    edge_r[i]   resistance of the edge from i to its parent
-    cons_of[i]  constraint row (0..M-1) of node i, or -1
-    checked[r]  whether row r is constrained (it carries residences, lpsolver.py:188-189)
-    Returns dict(n, src, end, eo, cle, w) of numpy arrays (see include/revs_admm.h)."""
-    parent = np.asarray(parent, np.int64)
-    pad = (-len(parent)) % 8                 # the kernel's threads own 8 consecutive positions:
-    if pad:                                  # pad with weightless nodes hanging off the substation
-        parent = np.concatenate([parent, np.full(pad, -1, np.int64)])
-        edge_r = np.concatenate([np.asarray(edge_r, np.float64), np.zeros(pad)])
-        cons_of = np.concatenate([np.asarray(cons_of, np.int64), np.full(pad, -1, np.int64)])
-    n = len(parent)
-    kids = [[] for _ in range(n)]
-    roots = []
-    for i in range(n):
-        (roots if parent[i] < 0 else kids[parent[i]]).append(i)
-    order, size = [], np.ones(n, np.int64)
-    stack = [(r, False) for r in reversed(roots)]
-    while stack:
-        u, done = stack.pop()
-        if done:
-            for c in kids[u]:
-                size[u] += size[c]
-            continue
-        order.append(u)
-        stack.append((u, True))
-        stack.extend((c, False) for c in reversed(kids[u]))
-    if len(order) != n:
-        raise ValueError("feeder: parent[] does not describe a forest")
-    order = np.asarray(order, np.int64)
-    pos = np.empty(n, np.int64)
-    pos[order] = np.arange(n)
-    end = (pos + size)[order]                                  # by preorder position
-    cons = np.asarray(cons_of, np.int64)[order]
-    chk = np.asarray(checked, bool)
-    src = np.where((cons >= 0) & chk[np.maximum(cons, 0)], cons, -1)
-    eo = np.argsort(end, kind="stable")
-    cle = np.searchsorted(end[eo], np.arange(n), side="right")
-    w = 2.0 * np.asarray(edge_r, np.float64)[order]
-    return dict(n=n, src=src.astype(np.int32), end=end.astype(np.int32), eo=eo.astype(np.int32),
-                cle=cle.astype(np.int32), w=w)
-
-
-def tree_voltage_host(tree, p):
-    """numpy restatement of the three prefix sums (tests, and the constructor's check that the
-    feeder reproduces Rn): v at the checked rows, indexed like p."""
-    n, src = tree["n"], tree["src"]
-    inj = np.where(src >= 0, 1.0, 0.0)[:, None] * p[np.maximum(src, 0)]
-    C = np.concatenate([np.zeros((1, p.shape[1])), np.cumsum(inj, 0)])
-    wp = tree["w"][:, None] * (C[tree["end"]] - C[:-1])
-    pre = np.cumsum(wp, 0)
-    F = np.concatenate([np.zeros((1, p.shape[1])), np.cumsum(wp[tree["eo"]], 0)])
-    v = pre - F[tree["cle"]]
-    out = np.zeros_like(p)
-    out[src[src >= 0]] = v[src >= 0]
-    return out
-
-
-class AdmmEngine:
+class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
     """State of one ADMM run on one GPU.
 
     Parameters
@@ -458,88 +401,12 @@ class AdmmEngine:
         self.node_load = torch.zeros(M, T, **f32)
         self.volt = torch.zeros(M, T, **f32)
 
-    def _ensure_admm(self):
-        """State of the ADMM forms (eigendecomposition of the scaled R on the host, per-home
-        double arrays): built on first use -- the default dual Newton path never needs it."""
-        if self._admm_ready:
-            return
-        self._admm_ready = True
-        Rn, counts = self._Rn_host, self._counts_host
-        n, T, M = self.n, self.T, self.M
-        f64 = dict(dtype=torch.float64, device=self.dev)
-        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(self.dev)
-        # Voltage row m is scaled by sqrt(n_m) (bounds too), so the operator matrix
-        # D^1/2 R D^1/2 is symmetric PSD = Q L Q^T: one factor serves C_v and C_v^T.
-        # Nodes without residences get a zero row: voltage is constrained where
-        # residences are, as in the reference (R_res, lpsolver.py:188-189).
-        sq = np.sqrt(counts.astype(np.float64))
-        lam, Q = np.linalg.eigh(sq[:, None] * Rn * sq[None, :])
-        lam = np.maximum(lam, 0.0)
-        self.smax = float(lam.max())
-        self.Q, self.QT = up(Q), up(Q.T)
-        # the scaled sensitivity matrix itself, for the one-product voltage check Rs.p0
-        self.Rs = up((Q * lam[None, :]) @ Q.T)
-        self.s = up(lam)
-        self.sqrt_n = up(sq)
-        self.inv_sqrt_n = up(np.where(counts > 0, 1.0 / np.maximum(sq, 1e-300), 0.0))
-        self.g0 = torch.zeros(n, T, **f64)
-        self.sb = torch.zeros(n, T, **f64)             # z_b + y_b of the g >= 0 rows
-        nz = lambda: torch.zeros(M, T, **f64)
-        (self.zv, self.yv, self.cx, self.w, self.rhat, self.xc, self.a, self.sa,
-         self.cty) = (nz() for _ in range(9))
-        # GEMM outputs come as K-split partial slabs (summed by the node kernels): enough
-        # workgroups to fill 256 CUs even when M/32 row tiles x 2 products is below that
-        self.cat = 2 * T <= 192                        # [rhat | w] in one product
-        ncol = 2 * T if self.cat else T
-        tiles = ((M + 31) // 32 if ncol <= 48 else (M + 15) // 16) * (1 if self.cat else 2)
-        self.ksplit = int(min(8, max(1, -(-256 // tiles))))
-        nzs = lambda: torch.zeros(self.ksplit, M, T, **f64)
-        self.ta, self.tb, self.va, self.usa = nzs(), nzs(), nzs(), nzs()
-        # node-space fast path
-        nz1 = lambda: torch.zeros(self.ksplit1, M, T, **f64)
-        self.f_wh, self.f_zt = nz1(), nz1()
-        (self.p0, self.gmin, self.ph0, self.xh, self.sx, self.dnode, self.slack) = (nz() for _ in range(7))
-        self.f_stats = torch.zeros(2, **f64)
-        self.rho_f = torch.full((T,), self.op.rho_v_scale * self.kappa / self.smax ** 2, **f64)
-        self._dnode_zero = False
-        # exact presolve of the fast path (see revs_op_node_prep): needs R >= 0 and vlo <= 0
-        self.preclamp = int(bool(Rn.min() >= 0.0 and self.vlo <= 0.0))
-        self._fast_wait = 0
-        self._fast_backoff = 1
-        self._fast_cal = False
-        self._fgraph = None
-        self._fgraph_warm = False
-        self.rho_v = torch.full((T,), self.op.rho_v_scale * self.kappa / self.smax ** 2, **f64)
-        self.rho_b = torch.full((T,), self.op.rho_b_scale * self.kappa, **f64)
-        self.res_out = torch.zeros(8, T, **f64)
-        self._calibrated = False
-        self._graph = None
-        self._graph_warm = False
-
     # ------------------------------------------------------------------ util
     @property
     def stream(self):
         if self.dev.type != "cuda":
             return None
         return torch.cuda.current_stream(self.dev).cuda_stream
-
-    def _gemm(self, At, B, Cout, accumulate=0):
-        k, m = At.shape
-        n = B.shape[1]
-        check(self.lib.revs_gemm_tn_f64(m, n, k, ptr(At), m, ptr(B), n, ptr(Cout), n,
-                                        accumulate, self.stream), "revs_gemm_tn_f64")
-
-    def _gemm_cat(self, At, B0, B1, C0, C1):
-        """[C0 | C1] = At^T [B0 | B1] as K-split slabs; one launch when 2T <= 192."""
-        M, T, st = self.M, self.T, self.stream
-        if self.cat:
-            rc = self.lib.revs_gemm_tn_f64_cat(M, T, M, ptr(At), ptr(B0), ptr(B1), ptr(C0),
-                                               ptr(C1), self.ksplit, st)
-            check(rc, "revs_gemm_tn_f64_cat")
-        else:
-            rc = self.lib.revs_gemm_tn_f64_x2(M, T, M, ptr(At), ptr(B0), ptr(C0), ptr(At),
-                                              ptr(B1), ptr(C1), self.ksplit, st)
-            check(rc, "revs_gemm_tn_f64_x2")
 
     def _allreduce(self, t, op=None):
         if self.group is None:
@@ -555,582 +422,14 @@ class AdmmEngine:
             return
         torch.distributed.all_reduce(t, op=op or RO.SUM, group=self.group)
 
-    # -------------------------------------------------------------- operator
-    def _home_pass(self, with_update: bool, check: bool = False, reduce: bool = True):
-        o = self.op
-        rc = self.lib.revs_op_home_pass(
-            self.M, self.T, ptr(self.node_ptr), ptr(self.inv_sqrt_n), ptr(self.sb), ptr(self.g0),
-            ptr(self.xc) if with_update else None, ptr(self.rho_b), self.kappa, o.alpha,
-            ptr(self.rhat), ptr(self.cty) if check else None,
-            ptr(self.res_out) if check else None, self.stream)
-        _lib.check(rc, "revs_op_home_pass")
-        if reduce:
-            self._allreduce(self.rhat)
-
-    def _home_pass_fused(self, reduce: bool = True):
-        o = self.op
-        rc = self.lib.revs_op_home_pass_fused(
-            self.M, self.T, ptr(self.node_ptr), ptr(self.inv_sqrt_n), ptr(self.sb), ptr(self.g0),
-            ptr(self.rho_b), self.kappa, o.alpha, ptr(self.rhat), self.ksplit, ptr(self.va),
-            ptr(self.usa), ptr(self.rho_v), ptr(self.sqrt_n), self.vlo, self.vhi, ptr(self.xc),
-            ptr(self.zv), ptr(self.yv), ptr(self.w), self.stream)
-        _lib.check(rc, "revs_op_home_pass_fused")
-        if reduce:
-            self._allreduce(self.rhat)
-
-    def _node_half(self, check: bool = False, fuse: bool = False):
-        """rhat -> xc, and the z_v / y_v update (GEMMs on the f64 matrix cores).  On a
-        checking iteration also the node-side residual maxima and cty = C_v^T y_v.  With
-        `fuse` the node update is left to the following fused home pass."""
-        o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
-        ks = self.ksplit
-        self._gemm_cat(self.Q, self.rhat, self.w, self.ta, self.tb)        # Q^T [rhat | w]
-        _lib.check(lib.revs_op_node_scale(M, T, ks, ptr(self.ta), ptr(self.tb), ptr(self.s),
-                                          ptr(self.rho_v), ptr(self.rho_b), self.kappa,
-                                          ptr(self.a), ptr(self.sa), st), "revs_op_node_scale")
-        self._gemm_cat(self.QT, self.a, self.sa, self.va, self.usa)        # Q [a | l a]
-        if fuse:
-            return
-        _lib.check(lib.revs_op_node_update(M, T, ks, ptr(self.va), ptr(self.rhat), ptr(self.usa),
-                                           ptr(self.rho_v), ptr(self.rho_b), ptr(self.sqrt_n),
-                                           self.kappa, o.alpha, self.vlo, self.vhi, ptr(self.xc),
-                                           ptr(self.zv), ptr(self.yv), ptr(self.w),
-                                           ptr(self.res_out) if check else None, st),
-                   "revs_op_node_update")
-        if check:
-            self._gemm(self.Q, self.yv, self.tb[0])                 # Q^T y_v
-            _lib.check(lib.revs_op_row_scale(M, T, ptr(self.s), ptr(self.tb[0]),
-                                             ptr(self.ta[0]), st), "revs_op_row_scale")
-            self._gemm(self.QT, self.ta[0], self.cty)               # Q L Q^T y_v = C_v^T y_v
-
-    def _inner_block(self):
-        """`check_every` inner iterations, the last one also accumulating the residual
-        maxima.  hipGraphs (through torch.cuda.CUDAGraph: the ctypes launches go to torch's
-        current stream, which is the capture stream) cut the host work:
-          * one GPU: the whole block is one graph -- one host call per 25 iterations;
-          * sharded: one iteration's kernels (2 products, node scale, fused home pass) are
-            a graph and only the RCCL all-reduce of rhat between iterations stays eager:
-            2 host calls per iteration, and no collective is ever captured."""
-        n_it = self.op.check_every
-
-        def body():
-            self.res_out.zero_()
-            for k in range(n_it):
-                if k == n_it - 1:              # checking iteration: separate passes + residuals
-                    self._node_half(check=True)
-                    self._home_pass(with_update=True, check=True)
-                else:                          # node update fused into the home pass
-                    self._node_half(fuse=True)
-                    self._home_pass_fused()
-
-        if not self.op.use_graph or self.dev.type != "cuda":
-            return body()
-        if not self._graph_warm:               # first block eager: warms up, loads code objects
-            self._graph_warm = True
-            return body()
-        if self.group is None:
-            if self._graph is None:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    body()
-                self._graph = g
-            return self._graph.replay()
-        if self._graph is None:
-            gs = []
-            for chk in (False, True):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._node_half(check=chk, fuse=not chk)
-                    if chk:
-                        self._home_pass(with_update=True, check=True, reduce=False)
-                    else:
-                        self._home_pass_fused(reduce=False)
-                gs.append(g)
-            self._graph = gs
-        self.res_out.zero_()
-        for k in range(n_it):
-            self._graph[1 if k == n_it - 1 else 0].replay()
-            self._allreduce(self.rhat)
-
-    def _residuals(self):
-        self._allreduce(self.res_out, torch.distributed.ReduceOp.MAX if self.group else None)
-        return self.res_out.cpu().numpy()
-
-    def _rel_residuals(self, r):
-        vscale = max(abs(self.vlo), abs(self.vhi), 1e-300)
-        n_pv = np.maximum(np.maximum(r[3], r[4]), vscale)
-        n_pb = np.maximum(r[5], 1e-12)
-        n_d = np.maximum(np.maximum(self.kappa * r[5], r[6]), np.maximum(r[7], 1e-12))
-        return np.maximum(r[0] / n_pv, r[1] / n_pb), r[2] / n_d
-
-    def _set_rho(self, rv_scale, rb_scale):
-        self.rho_v.fill_(rv_scale * self.kappa / self.smax ** 2)
-        self.rho_b.fill_(rb_scale * self.kappa)
-        _lib.check(self.lib.revs_op_node_w(self.M, self.T, ptr(self.zv), ptr(self.yv),
-                                           ptr(self.rho_v), ptr(self.w), self.stream),
-                   "revs_op_node_w")
-        self._home_pass(with_update=False)
-
-    def _calibrate_rho(self):
-        """Try each candidate (rho_v, rho_b) for two blocks from the current state, keep the
-        best.  Returns the number of inner iterations spent."""
-        o = self.op
-        snap = [t.clone() for t in (self.sb, self.zv, self.yv)]
-        best, spent = None, 0
-        for rv in o.cal_rho_v:
-            for rb in o.cal_rho_b:
-                for t, c in zip((self.sb, self.zv, self.yv), snap):
-                    t.copy_(c)
-                self._set_rho(rv, rb)
-                nblk = max(1, -(-o.cal_iters // o.check_every))
-                for _ in range(nblk):
-                    self._inner_block()
-                spent += nblk * o.check_every
-                rel_p, rel_d = self._rel_residuals(self._residuals())
-                score = float(max(rel_p.max(), rel_d.max()))
-                if np.isfinite(score) and (best is None or score < best[0]):
-                    best = (score, rv, rb)
-        for t, c in zip((self.sb, self.zv, self.yv), snap):
-            t.copy_(c)
-        self.rho_scales = best[1:]
-        self.cal_score = best[0]
-        self._set_rho(*self.rho_scales)
-        self._calibrated = True
-        return spent
-
-    # ------------------------------------------------- operator, node-space fast path
     def _gemm1(self, At, B, Cslabs):
         check(self.lib.revs_gemm_tn_f64_split(self.M, self.T, self.M, ptr(At), ptr(B),
                                               ptr(Cslabs), self.ksplit1, self.stream),
               "revs_gemm_tn_f64_split")
 
-    def _fast_iteration(self, chk: bool):
-        o, lib, M, T, st, ks = self.op, self.lib, self.M, self.T, self.stream, self.ksplit1
-        self._gemm1(self.Q, self.w, self.f_wh)                             # wh = Q^T w
-        check(lib.revs_op_nodefast_scale(M, T, ks, ptr(self.f_wh), ptr(self.ph0), ptr(self.s),
-                                         ptr(self.rho_f), self.kappa, ptr(self.xh), ptr(self.sx),
-                                         st), "revs_op_nodefast_scale")
-        self._gemm1(self.QT, self.sx, self.f_zt)                           # zt = Q (l xh)
-        check(lib.revs_op_nodefast_update(M, T, ks, ptr(self.f_zt), ptr(self.rho_f),
-                                          ptr(self.sqrt_n), o.alpha, self.vlo, self.vhi,
-                                          ptr(self.zv), ptr(self.yv), ptr(self.w),
-                                          ptr(self.res_out) if chk else None, st),
-              "revs_op_nodefast_update")
-        if chk:
-            self._gemm1(self.Q, self.yv, self.f_wh)                        # yh = Q^T y_v
-            check(lib.revs_op_nodefast_dualres(M, T, ks, ptr(self.xh), ptr(self.ph0),
-                                               ptr(self.s), ptr(self.f_wh), self.kappa,
-                                               ptr(self.res_out), st), "revs_op_nodefast_dualres")
-
-    def _fast_block(self):
-        n_it = self.op.check_every
-
-        def body():
-            self.res_out.zero_()
-            for k in range(n_it):
-                self._fast_iteration(k == n_it - 1)
-
-        if not self.op.use_graph or self.dev.type != "cuda":
-            return body()
-        if not self._fgraph_warm:
-            self._fgraph_warm = True
-            return body()
-        if self._fgraph is None:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                body()
-            self._fgraph = g
-        self._fgraph.replay()
-
-    def _fast_set_rho(self, scale):
-        self.rho_f.fill_(scale * self.kappa / self.smax ** 2)
-        check(self.lib.revs_op_node_w(self.M, self.T, ptr(self.zv), ptr(self.yv), ptr(self.rho_f),
-                                      ptr(self.w), self.stream), "revs_op_node_w")
-
-    def _fast_residuals(self):
-        r = self.res_out.cpu().numpy()          # identical on every rank: no reduction needed
-        vscale = max(abs(self.vlo), abs(self.vhi), 1e-300)
-        rel_p = r[0] / np.maximum(np.maximum(r[3], r[4]), vscale)
-        rel_d = r[2] / np.maximum(np.maximum(self.kappa * r[5], r[6]), np.maximum(r[7], 1e-12))
-        return rel_p, rel_d
-
-    def _operator_solve_node(self, precheck=False):
-        """Fast path.  Returns True when its answer (in P_est_new) is the operator's exact
-        answer; "pre" when the pre-check found a residence with g0 < 0 (nothing solved yet),
-        "post" when the node solve finished but some residence would have to be clamped."""
-        o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
-        check(lib.revs_op_node_prep(M, T, ptr(self.node_ptr), ptr(self.inv_sqrt_n), ptr(self.P_est),
-                                    ptr(self.P_sch), ptr(self.G), self.kappa, self.preclamp,
-                                    ptr(self.p0), ptr(self.gmin), None, st), "revs_op_node_prep")
-        if self.group is not None:               # the only exchange of this outer iteration
-            self._allreduce(self.p0)
-            if not self.preclamp:                # with the pre-clamp gmin >= 0 is known, and its
-                self._allreduce(self.gmin, torch.distributed.ReduceOp.MIN)   # exact value is
-                                                 # only needed if rows bind (below)
-        # The voltage check proper: v0 = Rs.p0, one product on the f64 matrix cores.  If it
-        # already respects every row, the projection is g0 itself (d = 0): no iteration.
-        self._gemm1(self.Rs, self.p0, self.f_zt)                           # Rs symmetric: At = Rs
-        self.f_stats.zero_()
-        check(lib.revs_op_nodefast_feas(M, T, self.ksplit1, ptr(self.f_zt), ptr(self.sqrt_n),
-                                        ptr(self.gmin), self.vlo, self.vhi, ptr(self.cx),
-                                        ptr(self.f_stats), st), "revs_op_nodefast_feas")
-        viol0, neg0 = self.f_stats.cpu().tolist()        # the one host sync of the easy case
-        if neg0 > 0.0 and (precheck or viol0 == 0.0):
-            return "pre"                     # a residence with g0 < 0 has to be clamped anyway
-        if viol0 == 0.0:
-            if not self._dnode_zero:
-                self.dnode.zero_()
-                self._dnode_zero = True
-            check(lib.revs_op_node_apply(M, T, ptr(self.node_ptr), ptr(self.inv_sqrt_n),
-                                         ptr(self.P_est), ptr(self.P_sch), ptr(self.G), self.kappa,
-                                         self.preclamp, ptr(self.dnode), ptr(self.P_est_new), st),
-                  "revs_op_node_apply")
-            self._fast_cold = True           # z = Rs p0, y = 0 is re-made when rows bind again
-            self.op_iters_hist.append(0)
-            self.op_path_hist.append("node")
-            self.op_converged = True
-            return True
-        if self.group is not None and self.preclamp:
-            self._allreduce(self.gmin, torch.distributed.ReduceOp.MIN)   # for the slack test
-        self._dnode_zero = False
-        self._gemm(self.Q, self.p0, self.ph0)                              # ph0 = Q^T p0
-        if self._fast_cold:
-            check(lib.revs_op_init_node(M, T, ptr(self.cx), ptr(self.rho_f), ptr(self.sqrt_n),
-                                        self.vlo, self.vhi, ptr(self.zv), ptr(self.yv),
-                                        ptr(self.w), st), "revs_op_init_node")   # z = clip(Rs p0), y = 0
-            self._fast_cold = False
-        it, converged = 0, False
-        while it < o.max_iter:
-            self._fast_block()
-            it += o.check_every
-            rel_p, rel_d = self._fast_residuals()
-            if max(rel_p.max(), rel_d.max()) <= o.eps:
-                converged = True
-                break
-            if o.calibrate and not self._fast_cal:
-                snap = [t.clone() for t in (self.zv, self.yv)]
-                best = None
-                nblk = max(1, -(-o.cal_iters // o.check_every))
-                for rv in o.cal_rho_v:
-                    for t, c in zip((self.zv, self.yv), snap):
-                        t.copy_(c)
-                    self._fast_set_rho(rv)
-                    for _ in range(nblk):
-                        self._fast_block()
-                    it += nblk * o.check_every
-                    rp, rd = self._fast_residuals()
-                    score = float(max(rp.max(), rd.max()))
-                    if np.isfinite(score) and (best is None or score < best[0]):
-                        best = (score, rv)
-                for t, c in zip((self.zv, self.yv), snap):
-                    t.copy_(c)
-                self._fast_set_rho(best[1])
-                self.rho_f_scale = best[1]
-                self._fast_cal = True
-                continue
-            if o.adapt_every and it % o.adapt_every == 0:
-                sc = np.sqrt(np.maximum(rel_p, 1e-14) / np.maximum(rel_d, 1e-14))
-                sc = np.clip(sc, 0.2, 5.0)
-                sc = np.where((sc > 2.0) | (sc < 0.5), sc, 1.0)
-                if (sc != 1.0).any():
-                    self.rho_f.mul_(torch.from_numpy(sc).to(self.dev))
-                    check(lib.revs_op_node_w(M, T, ptr(self.zv), ptr(self.yv), ptr(self.rho_f),
-                                             ptr(self.w), st), "revs_op_node_w")
-        self._gemm1(self.QT, self.xh, self.f_zt)                           # x = Q xh
-        self.f_stats.zero_()
-        check(lib.revs_op_nodefast_finish(M, T, self.ksplit1, ptr(self.f_zt), ptr(self.p0),
-                                          ptr(self.gmin), ptr(self.inv_sqrt_n), ptr(self.dnode),
-                                          ptr(self.slack), ptr(self.f_stats), st),
-              "revs_op_nodefast_finish")
-        # nodes without residences have gmin = +inf; a clamp is active iff some slack < 0
-        viol, pmax = self.f_stats.cpu().tolist()
-        if viol > 1e-9 * max(1.0, pmax):
-            return "post"
-        check(lib.revs_op_node_apply(M, T, ptr(self.node_ptr), ptr(self.inv_sqrt_n), ptr(self.P_est),
-                                     ptr(self.P_sch), ptr(self.G), self.kappa, self.preclamp,
-                                     ptr(self.dnode), ptr(self.P_est_new), st), "revs_op_node_apply")
-        self.op_iters_hist.append(it)
-        self.op_path_hist.append("node")
-        self.op_converged = converged
-        return True
-
-    # ------------------------------------------------- operator, dual Newton path
-    def _dual_phase(self, phase: int, y, use_y: bool, k: int):
-        lib, M, T = self.lib, self.M, self.T
-        check(lib.revs_op_dual_evaluate(
-            phase, M, T, ptr(self.node_ptr), ptr(self.P_est), ptr(self.P_sch), ptr(self.G),
-            ptr(self.R64), ptr(self.R64T), ptr(y), int(use_y), self.kappa, self.vlo, self.vhi,
-            self.op.newton_kadd, self.ksplit1, ptr(self.d_sl), ptr(self.v_sl), ptr(self.pnq),
-            ptr(self.P_est_new), ptr(self.vfull), ptr(self.violw), ptr(self.d_part),
-            ptr(self.c_idx[k]), ptr(self.c_cnt[k]), ptr(self.c_val[k]), self.stats_dev[k],
-            0.0, ptr(self.tile_cnt), self.stream), "revs_op_dual_evaluate")
-
-    def _dual_home_pass_rows(self, y, sup: int):
-        """Phase 1 of an evaluation with d = R^T y / kappa taken from the few rows listed in
-        candidate set `sup` (they include every row with y != 0) instead of a dense product."""
-        check(self.lib.revs_op_dual_eval_rows(
-            self.M, self.T, ptr(self.node_ptr), ptr(self.P_est), ptr(self.P_sch), ptr(self.G),
-            ptr(self.R64), ptr(self.c_idx[sup]), ptr(self.c_cnt[sup]), ptr(y), self.kappa,
-            ptr(self.pnq), ptr(self.P_est_new), self.stream), "revs_op_dual_eval_rows")
-
-    def _dual_launch(self, y, use_y: bool, k: int, full: bool = True, sup=None, record=True):
-        """Enqueue one evaluation: p, N, D and the voltage rows for the multipliers y;
-        candidate lists and stats into buffer set k, stats on their way to pinned host
-        memory.  Also writes P_est_new = max(g0 - R^T y / kappa, 0).  Does not wait.
-        One host call; two around the all-reduce of pnq when residences are sharded.  With
-        full=False only p is exchanged (enough to judge the voltage rows: the steady-state
-        case); N and the dual value follow through _dual_complete if the solve goes on.
-        (Replaying the launches as a hipGraph was measured and is slower than issuing
-        them: 44 vs 37 us per evaluation.)"""
-        if use_y and sup is not None:            # few multipliers: no dense product for d
-            self._dual_home_pass_rows(y, sup)
-            if self.group is not None:
-                self._allreduce(self.pnq if full else self.pnq[0])
-            self._dual_phase(2, y, use_y, k)
-        elif self.group is None:
-            self._dual_phase(3, y, use_y, k)
-        else:
-            self._dual_phase(1, y, use_y, k)
-            self._allreduce(self.pnq if full else self.pnq[0])   # the only exchange
-            self._dual_phase(2, y, use_y, k)
-        if record and self.stats_ev[k] is not None:
-            self.stats_ev[k].record()
-
-    def _dual_complete(self, y, use_y: bool, k: int):
-        """After a full=False evaluation that did not settle the solve: exchange N and the
-        dual value too and redo the row bookkeeping (the stats' D_t needs the global sum)."""
-        if self.group is None:
-            return self._dual_wait(k)
-        self._allreduce(self.pnq[1:])
-        self._dual_phase(2, y, use_y, k)
-        if self.stats_ev[k] is not None:
-            self.stats_ev[k].record()
-        return self._dual_wait(k)
-
-    def _dual_wait(self, k: int):
-        if self.stats_ev[k] is not None:
-            self.stats_ev[k].synchronize()
-        return self.stats_host[k].numpy().copy()
-
-    def _dual_evaluate(self, y, use_y: bool, k: int, sup=None):
-        self._dual_launch(y, use_y, k, sup=sup)
-        return self._dual_wait(k)
-
-    def _operator_solve_newton(self, first=None, pre=None):
-        """Utility.solve through the dual (see csrc/newton_kernels.hip).  True when
-        P_est_new holds the answer to tolerance; False hands the iteration to ADMM.
-        `first`: stats of an evaluation of the current multipliers already made (buffer 0).
-        `pre`: stats of the evaluation (buffer 1) that `_chain_launch` enqueued behind `first`
-        without reading it -- small model on candidate set 0, a full step for the slots not
-        yet within tolerance -- i.e. the first line-search trial of the first Newton iteration
-        if that iteration turns out to be the one this loop would have run.  Sets
-        `_pre_kept`: the accepted state is exactly the one `pre` (or `first`) left behind."""
-        o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
-        A = _lib.DUAL_AMAX
-        scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
-        ycur, ytrial = self.yd
-        cur = 0
-        # (`_sup`: a candidate set that lists every row of the current multipliers, while there
-        # are few enough of them for the row-wise home pass)
-        stt = (self._dual_evaluate(ycur, self._y_support, cur, sup=self._sup)
-               if first is None else first)
-        evals, newton, pivots, ok_all = 1, 0, 0, False
-        best, stall = np.inf, 0
-        last_small = False
-        from_pre = pre is not None       # P_est_new is what `pre` (== `first` if nothing moved) wrote
-        while True:
-            if (stt[:, 2] > A).any():
-                break                                    # more multipliers than a model holds
-            rmax = stt[:, 0] / scale
-            if rmax.max() <= o.eps:
-                ok_all = True
-                break
-            if newton >= o.newton_max:
-                break
-            # a slot whose model is full of multipliers while rows are still violated cannot
-            # take them in; and a solve that stopped improving is not worth more iterations
-            if ((stt[:, 2] >= A) & (stt[:, 3] > 0) & (rmax > o.eps)).any():
-                break
-            if rmax.max() < 0.5 * best:
-                best, stall = rmax.max(), 0
-            else:
-                stall += 1
-                if stall >= 10:
-                    break
-            newton += 1
-            # model of every slot: K_t = R_F N_t R_F^T / kappa over its candidates, maximised
-            # over the sign constraints (block principal pivoting, one workgroup per slot)
-            # (candidates of a slot = its rows with a multiplier + the violated rows admitted)
-            ncand = stt[:, 2] + np.minimum(stt[:, 3], np.minimum(o.newton_kadd, A - stt[:, 2]))
-            self.model_calls[0 if ncand.max() <= 8 else 1] += 1
-            last_small = bool(ncand.max() <= 8)
-            few = stt[:, 2].max() + o.newton_kadd <= 48
-            # (the chain guessed how its trial's home pass gets d = R^T y / kappa -- row-wise or
-            # dense; another choice here would differ in the last bits: then redo the trial)
-            use_pre = (pre is not None and newton == 1 and last_small
-                       and bool(few) == self._chain_few)
-            if use_pre:
-                pass                             # (the chain ran this model on this set)
-            elif ncand.max() <= 8:               # the binding steady state: one small kernel
-                check(lib.revs_op_dual_model_small(M, T, ptr(self.R64), ptr(self.pnq[1]),
-                                                   ptr(self.c_idx[cur]), ptr(self.c_cnt[cur]),
-                                                   ptr(self.c_val[cur]), self.kappa, o.newton_delta,
-                                                   o.newton_pivots, ptr(self.k_full), ptr(self.yhat),
-                                                   self.info_dev, st), "revs_op_dual_model_small")
-            else:
-                check(lib.revs_op_dual_model(M, T, ptr(self.R64), ptr(self.pnq[1]),
-                                             ptr(self.c_idx[cur]), ptr(self.c_cnt[cur]),
-                                             ptr(self.c_val[cur]), self.kappa, o.newton_delta,
-                                             o.newton_pivots, self.nks, ptr(self.k_slabs),
-                                             ptr(self.k_full), ptr(self.yhat), self.info_dev, st),
-                      "revs_op_dual_model")
-            D = stt[:, 1]
-            pending = rmax > o.eps
-            alpha = pending.astype(np.float64)
-            nxt = 1 - cur
-            for ls in range(o.newton_ls):
-                if use_pre and ls == 0:
-                    stn = pre                    # that trial and its evaluation: already there
-                else:
-                    from_pre = False
-                    self.alpha_h.numpy()[:] = alpha  # read by the step kernel through its mapping
-                    ytrial.copy_(ycur)
-                    check(lib.revs_op_dual_step(T, ptr(self.c_idx[cur]), ptr(self.c_cnt[cur]),
-                                                ptr(self.c_val[cur]), ptr(self.yhat),
-                                                self.alpha_dev, ptr(ytrial),
-                                                self.stats_dev[nxt] + 32, st),
-                          "revs_op_dual_step")
-                    stn = self._dual_evaluate(ytrial, True, nxt, sup=cur if few else None)
-                evals += 1
-                okk = stn[:, 1] >= D + 1e-4 * stn[:, 4] - 1e-13 * np.abs(D)
-                pending &= ~okk
-                if not pending.any():
-                    break
-                alpha[pending] *= 0.5
-            pivots += int(np.abs(self.info_h.numpy()).sum())     # (the evaluation was waited for)
-            if pending.any():
-                break                                    # no ascent found: leave it to ADMM
-            ycur, ytrial = ytrial, ycur
-            cur, stt = nxt, stn
-        self.yd = [ycur, ytrial]
-        self.newton_hist.append((newton, evals, pivots))
-        self._pre_kept = bool(ok_all and from_pre and newton <= 1)
-        # a solve of exactly one Newton iteration on the small model tends to repeat: the next
-        # one is enqueued whole (_chain_launch)
-        self._chain_ok = bool(ok_all and newton == 1 and last_small and evals == 2)
-        self._chain_few = bool(few) if newton >= 1 else False
-        # speculate on the next iteration after a solve that needed no Newton iteration -- but
-        # after a discarded sweep only once 2, 4, ... 64 such solves have gone by (rows that
-        # keep moving in and out of their limits would otherwise cost a wasted sweep each time)
-        if ok_all and newton == 0:
-            self._spec_wait = max(self._spec_wait - 1, 0)
-            self._spec_ok = self._spec_wait == 0
-        else:
-            self._spec_ok = False
-        if not ok_all:
-            ycur.zero_()
-            self._y_support = False
-            self._sup = None
-            return False
-        self._y_support = bool(stt[:, 2].sum() > 0)
-        # the accepted evaluation's candidate set `cur` lists the rows with y != 0 first
-        self._sup = cur if (self._y_support and stt[:, 2].max() + o.newton_kadd <= 48) else None
-        self.op_iters_hist.append(evals)
-        self.op_path_hist.append("dual")
-        self.op_converged = True
-        return True
-
-    def _chain_launch(self, write_sc, rec):
-        """The binding steady state without the host in the loop: evaluation of the current
-        multipliers (set 0) with its selection, the small model and the step in one launch
-        (full step for the slots that evaluation leaves pending, decided on the device:
-        revs_op_dual_select_model_step), the evaluation of the trial (set 1) and the home
-        sweep on its answer -- the trial's candidate selection rides in the sweep's launch --,
-        all enqueued; nothing is read."""
-        o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
-        scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
-        ycur, ytrial = self.yd
-        # (no event records in the chain: each costs the stream ~6 us; the host polls the
-        # sequence tag the last selection writes)
-        nb = (M + 31) // 32
-        nb = nb if (T <= 32 and nb <= 256) else 0
-        use_y = self._y_support
-        if use_y and self._sup is not None:       # as _dual_launch, the selection left out
-            self._dual_home_pass_rows(ycur, self._sup)
-        else:
-            self._dual_phase(1, ycur, use_y, 0)
-        if self.group is not None:
-            self._allreduce(self.pnq)
-        self._dual_phase(2 | 4, ycur, use_y, 0)
-        # selection, small model and step of every slot in one launch
-        check(lib.revs_op_dual_select_model_step(
-            M, T, ptr(self.d_part), nb, ptr(ycur), self.vlo, self.vhi, o.newton_kadd,
-            ptr(self.vfull), ptr(self.violw), ptr(self.c_idx[0]), ptr(self.c_cnt[0]),
-            ptr(self.c_val[0]), self.stats_dev[0], 0.0, ptr(self.R64), ptr(self.pnq[1]), self.kappa,
-            o.newton_delta, o.newton_pivots, ptr(self.k_full), ptr(self.yhat), self.info_dev, scale,
-            o.eps, ptr(ytrial), self.stats_dev[1] + 32, st), "revs_op_dual_select_model_step")
-        if self._chain_few:                       # d = R^T y / kappa from the rows of set 0
-            self._dual_home_pass_rows(ytrial, 0)
-        else:
-            self._dual_phase(1, ytrial, True, 1)
-        if self.group is not None:
-            self._allreduce(self.pnq)
-        self._dual_phase(2 | 4, ytrial, True, 1)  # product and rows; selection: in the sweep
-        rec(1)
-        self._chain_seq -= 1.0
-        check(lib.revs_agent_step_select(
-            self.n, T, ptr(self.cost), ptr(self.homes), ptr(self.load), ptr(self.P_est),
-            ptr(self.P_est_new), ptr(self.P_sch), ptr(self.G), ptr(self.P_sch_alt), ptr(self.G_alt),
-            ptr(self.S) if write_sc else None, ptr(self.Csoc) if write_sc else None,
-            ptr(self.diff), ptr(self.dsq), ptr(self.status), ptr(self.pdhg_dual), self.kappa,
-            self.mode, C.byref(self.pdhg), M, ptr(self.d_part), ptr(ytrial), self.vlo, self.vhi,
-            o.newton_kadd, ptr(self.vfull), ptr(self.violw), ptr(self.c_idx[1]), ptr(self.c_cnt[1]),
-            ptr(self.c_val[1]), self.stats_dev[1], self._chain_seq, None, None, None, nb, st),
-            "revs_agent_step_select")
-        rec(2)
-
-    def _chain_accept(self):
-        """Wait for the chain's two evaluations and, if they are the usual outcome -- one
-        Newton iteration on the small model, full step accepted, converged -- do the
-        bookkeeping _operator_solve_newton would do for it (revs_newton_chain_accept makes
-        the same checks in one native call).  False: nothing was changed."""
-        o = self.op
-        if self.stats_ev[0] is not None:
-            # the trial's verdict is written early in the sweep's launch: poll its sequence tag
-            # (pinned memory) rather than wait for the sweep; stream order puts everything the
-            # chain wrote before it
-            tags = self.stats_host[1].numpy()[:, 5]
-            spins, t0 = 0, None
-            while not (tags == self._chain_seq).all():
-                spins += 1
-                if spins & 0xFFF == 0:
-                    import time
-                    t0 = t0 or time.monotonic()
-                    if time.monotonic() - t0 > 120.0:
-                        raise _lib.RevsError("chained Newton iteration: timed out waiting for "
-                                             "the evaluation's sequence tag")
-        nsum, nmax = C.c_int32(), C.c_int32()
-        scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
-        if not self.lib.revs_newton_chain_accept(
-                self.T, self.stats_host[0].data_ptr(), self.stats_host[1].data_ptr(), scale, o.eps,
-                _lib.DUAL_AMAX, o.newton_kadd, int(self._chain_few), C.addressof(nsum),
-                C.addressof(nmax)):
-            return False
-        self._chain_book(nsum.value, nmax.value)
-        return True
-
-    def _chain_book(self, nsum, nmax):
-        o = self.op
-        self.yd = [self.yd[1], self.yd[0]]
-        self.model_calls[0] += 1
-        self.newton_hist.append((1, 2, int(np.abs(self.info_h.numpy()).sum())))
-        self._pre_kept, self._chain_ok, self._spec_ok = True, True, False
-        self._y_support = nsum > 0
-        self._sup = 1 if (self._y_support and nmax + o.newton_kadd <= 48) else None
-        self.op_iters_hist.append(2)
-        self.op_path_hist.append("dual")
-        self.op_converged = True
-
+    # -------------------------------------------------------------- operator
+    # (dual Newton path: operator_newton.py; ADMM forms: operator_admm.py; steady state:
+    # steady_state.py -- mixed into this class)
     def _require_converged(self, ok):
         """An operator answer that did not reach its tolerance is not handed to the residences:
         REVS_ENOTCONV (every rank holds the same node-space state and takes the same decision)."""
@@ -1394,82 +693,6 @@ class AdmmEngine:
             self.P_est_new, self.P_est_alt = self.P_est_alt, self.P_est_new
         self.iteration += 1
 
-    def _spec_discard(self, stt, write_sc):
-        """A speculative sweep whose evaluation found rows beyond tolerance: finish the Newton
-        solve (from the evaluation's stats `stt` when they carry a dual value), run the sweep
-        on its answer; speculation backs off."""
-        self.spec_hist[1] += 1
-        self._spec_back = min(2 * self._spec_back, 64)
-        self._spec_wait = self._spec_back
-        if stt is not None:
-            stt = self._dual_complete(self.yd[0], self._y_support, 0)
-        if not self._operator_solve_newton(first=stt):
-            self._fast_cold = True
-            self.op_cold = True
-            self._require_converged(self.operator_solve(admm_only=True))
-        self.agent_step(write_sc)
-
-    def _chain_run(self, count):
-        """Up to `count` iterations of the binding steady state inside one native call
-        (revs_plan_chain_run); the first one that is not the usual outcome is finished here as
-        step() would.  Returns the number of iterations done (at least one)."""
-        self._fused_ready = False
-        self._p_clear = None
-        ys = (self.yd[0], self.yd[1])
-        bufs = (self.P_est, self.P_est_new, self.P_sch, self.P_sch_alt, self.G, self.G_alt)
-        sup0 = self._sup if (self._y_support and self._sup is not None) else -1
-        st = _lib.ChainState(ptr(ys[0]), ptr(ys[1]), int(self._y_support), sup0,
-                             *[ptr(t) for t in bufs])
-        kept = C.c_int32()
-        check(self.lib.revs_plan_chain_run(self._plan, count, C.byref(st), int(self._chain_few),
-                                           C.addressof(kept), self.stream), "revs_plan_chain_run")
-        n = kept.value
-        by = {t.data_ptr(): t for t in bufs}
-        self.P_est, self.P_est_new = by[st.p_est], by[st.p_est_new]
-        self.P_sch, self.P_sch_alt = by[st.p_sch], by[st.p_sch_alt]
-        self.G, self.G_alt = by[st.gamma], by[st.gamma_alt]
-        self.yd = [ys[0], ys[1]] if st.y == ys[0].data_ptr() else [ys[1], ys[0]]
-        if n:
-            self.model_calls[0] += n
-            self.newton_hist.extend([(1, 2, -1)] * n)      # (pivot counts not read)
-            self._pre_kept, self._chain_ok, self._spec_ok = True, True, False
-            self._y_support = bool(st.use_y)
-            self._sup = 1 if st.sup0 == 1 else None
-            self.op_iters_hist.extend([2] * n)
-            self.op_path_hist.extend(["dual"] * n)
-            self.op_converged = True
-            self.chain_hist[0] += n
-            self.iteration += n
-        if n == count:
-            return n
-        # the call stopped at an iteration for the general loop (its launches are made)
-        self._chain_finish(False, 0, 0, False)
-        self.P_est, self.P_est_new = self.P_est_new, self.P_est
-        self.iteration += 1
-        return n + 1
-
-    def _chain_finish(self, accepted, nsum, nmax, write_sc):
-        """After the chain's launches: book the usual outcome, or hand both evaluations to the
-        general loop (which reuses the trial where it is exactly its own first step); keep the
-        speculative sweep or run it again."""
-        if accepted:
-            self._chain_book(nsum, nmax)
-            ok = True
-        else:                                # (the tag was seen: both blocks are complete)
-            stt0, stn = (self.stats_host[0].numpy().copy(), self.stats_host[1].numpy().copy())
-            ok = self._operator_solve_newton(first=stt0, pre=stn)
-        if ok and self._pre_kept:
-            self.P_sch, self.P_sch_alt = self.P_sch_alt, self.P_sch
-            self.G, self.G_alt = self.G_alt, self.G
-            self.chain_hist[0] += 1
-        else:
-            self.chain_hist[1] += 1
-            if not ok:
-                self._fast_cold = True
-                self.op_cold = True
-                self._require_converged(self.operator_solve(admm_only=True))
-            self.agent_step(write_sc)
-
     def run_steps(self, count):
         """`count` iterations of step(write_sc=False).  Consecutive steady-state iterations
         (one GPU, no multipliers, speculation on) run inside ONE native call,
@@ -1536,73 +759,6 @@ class AdmmEngine:
                 self.P_est, self.P_est_new = self.P_est_new, self.P_est
                 self.iteration += 1
                 done += 1
-
-    def _stream_ok(self):
-        """The steady state as one launch per iteration (revs_plan_stream_run) applies: a plan
-        with the feeder's tree, no multipliers, speculation allowed, and -- sharded -- the
-        library's own communicator."""
-        o = self.op
-        return (self._plan is not None and self._tree is not None and o.solver == "newton"
-                and o.speculate and self._spec_ok and o.fuse_home_pass and not self._y_support
-                and (self.group is None or self._comm is not None))
-
-    def _stream_run(self, count):
-        """Up to `count` steady-state iterations (at most the current burst), one launch each,
-        enqueued in one go by the native loop; the first iteration whose rows are not within
-        tolerance silences the launches behind it and is finished here as step() finishes a
-        discarded speculative sweep.  Returns the number of iterations done (at least one)."""
-        o = self.op
-        scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
-        p0 = self._fused_p
-        rest = [b for b in (self.pnq[0], self.p_alt, self.p_alt2) if b.data_ptr() != p0.data_ptr()]
-        # p[1] must be zero on entry.  The last launch of a fully kept call has just cleared the
-        # array that is p[1] now (roles rotate): no fill launch then
-        if self._p_clear is not None and self._p_clear.data_ptr() != p0.data_ptr():
-            rest = [self._p_clear] + [b for b in rest if b.data_ptr() != self._p_clear.data_ptr()]
-        else:
-            rest[0].zero_()
-        self._p_clear = None
-        if self.group is not None and not self._ar_ahead:
-            self._allreduce(p0)
-        pes = (self.P_est, self.P_est_new, self.P_est_alt)
-        pss, gs, ps = (self.P_sch, self.P_sch_alt), (self.G, self.G_alt), (p0, rest[0], rest[1])
-        st = _lib.StreamState()
-        for i in range(3):
-            st.p_est[i], st.p[i] = ptr(pes[i]), ptr(ps[i])
-        for i in range(2):
-            st.p_sch[i], st.gamma[i] = ptr(pss[i]), ptr(gs[i])
-        kept, rm = C.c_int32(), C.c_double()
-        count = min(count, self._burst)
-        check(self.lib.revs_plan_stream_run(self._plan, count, C.byref(st), scale, o.eps,
-                                            C.addressof(kept), C.addressof(rm), self.stream),
-              "revs_plan_stream_run")
-        n = kept.value
-        self._burst = min(4 * self._burst, o.stream_burst_max) if n == count else o.stream_burst
-        by = {t.data_ptr(): t for t in pes + pss + gs + ps}
-        self.P_est, self.P_est_new, self.P_est_alt = (by[st.p_est[i]] for i in range(3))
-        self.P_sch, self.P_sch_alt = by[st.p_sch[0]], by[st.p_sch[1]]
-        self.G, self.G_alt = by[st.gamma[0]], by[st.gamma[1]]
-        self._fused_p = by[st.p[0]]
-        self._p_clear = by[st.p[1]] if n == count else None
-        self._prod_ahead = False
-        self._ar_ahead = self.group is not None
-        if n:
-            self.op_iters_hist.extend([1] * n)
-            self.op_path_hist.extend(["dual"] * n)
-            self.newton_hist.extend([(0, 1, 0)] * n)
-            self.op_converged = True
-            self.spec_hist[0] += n
-            self._spec_back = 1
-            self.iteration += n
-        if n == count:
-            return n
-        # iteration n's verdict failed (its sweep wrote to the spares only; every launch behind
-        # it was a no-op): finish it as step() does for a discarded speculative sweep
-        self._fused_ready = False
-        self._spec_discard(None, False)
-        self.P_est, self.P_est_new = self.P_est_new, self.P_est
-        self.iteration += 1
-        return n + 1
 
     def check_status(self):
         """Raise if a residence reported 'no solution' (lpsolver.py:153-155) or a PDHG residence

@@ -1,0 +1,352 @@
+"""The operator QP (reference lpsolver.py:163-238) through its dual: semismooth Newton on the
+voltage-row multipliers -- evaluations, candidate models, Armijo steps on
+the host, and the binding steady state enqueued whole (one Newton iteration per ADMM iteration).
+Methods of AdmmEngine (mixed in by engine.py); kernels: csrc/newton_kernels.hip, gemm_kernels.hip."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr
+
+
+class DualNewtonMixin:
+    def _dual_phase(self, phase: int, y, use_y: bool, k: int):
+        lib, M, T = self.lib, self.M, self.T
+        check(lib.revs_op_dual_evaluate(
+            phase, M, T, ptr(self.node_ptr), ptr(self.P_est), ptr(self.P_sch), ptr(self.G),
+            ptr(self.R64), ptr(self.R64T), ptr(y), int(use_y), self.kappa, self.vlo, self.vhi,
+            self.op.newton_kadd, self.ksplit1, ptr(self.d_sl), ptr(self.v_sl), ptr(self.pnq),
+            ptr(self.P_est_new), ptr(self.vfull), ptr(self.violw), ptr(self.d_part),
+            ptr(self.c_idx[k]), ptr(self.c_cnt[k]), ptr(self.c_val[k]), self.stats_dev[k],
+            0.0, ptr(self.tile_cnt), self.stream), "revs_op_dual_evaluate")
+
+    def _dual_home_pass_rows(self, y, sup: int):
+        """Phase 1 of an evaluation with d = R^T y / kappa taken from the few rows listed in
+        candidate set `sup` (they include every row with y != 0) instead of a dense product."""
+        check(self.lib.revs_op_dual_eval_rows(
+            self.M, self.T, ptr(self.node_ptr), ptr(self.P_est), ptr(self.P_sch), ptr(self.G),
+            ptr(self.R64), ptr(self.c_idx[sup]), ptr(self.c_cnt[sup]), ptr(y), self.kappa,
+            ptr(self.pnq), ptr(self.P_est_new), self.stream), "revs_op_dual_eval_rows")
+
+    def _dual_launch(self, y, use_y: bool, k: int, full: bool = True, sup=None, record=True):
+        """Enqueue one evaluation: p, N, D and the voltage rows for the multipliers y;
+        candidate lists and stats into buffer set k, stats on their way to pinned host
+        memory.  Also writes P_est_new = max(g0 - R^T y / kappa, 0).  Does not wait.
+        One host call; two around the all-reduce of pnq when residences are sharded.  With
+        full=False only p is exchanged (enough to judge the voltage rows: the steady-state
+        case); N and the dual value follow through _dual_complete if the solve goes on.
+        (Replaying the launches as a hipGraph was measured and is slower than issuing
+        them: 44 vs 37 us per evaluation.)"""
+        if use_y and sup is not None:            # few multipliers: no dense product for d
+            self._dual_home_pass_rows(y, sup)
+            if self.group is not None:
+                self._allreduce(self.pnq if full else self.pnq[0])
+            self._dual_phase(2, y, use_y, k)
+        elif self.group is None:
+            self._dual_phase(3, y, use_y, k)
+        else:
+            self._dual_phase(1, y, use_y, k)
+            self._allreduce(self.pnq if full else self.pnq[0])   # the only exchange
+            self._dual_phase(2, y, use_y, k)
+        if record and self.stats_ev[k] is not None:
+            self.stats_ev[k].record()
+
+    def _dual_complete(self, y, use_y: bool, k: int):
+        """After a full=False evaluation that did not settle the solve: exchange N and the
+        dual value too and redo the row bookkeeping (the stats' D_t needs the global sum)."""
+        if self.group is None:
+            return self._dual_wait(k)
+        self._allreduce(self.pnq[1:])
+        self._dual_phase(2, y, use_y, k)
+        if self.stats_ev[k] is not None:
+            self.stats_ev[k].record()
+        return self._dual_wait(k)
+
+    def _dual_wait(self, k: int):
+        if self.stats_ev[k] is not None:
+            self.stats_ev[k].synchronize()
+        return self.stats_host[k].numpy().copy()
+
+    def _dual_evaluate(self, y, use_y: bool, k: int, sup=None):
+        self._dual_launch(y, use_y, k, sup=sup)
+        return self._dual_wait(k)
+
+    def _operator_solve_newton(self, first=None, pre=None):
+        """Utility.solve through the dual (see csrc/newton_kernels.hip).  True when
+        P_est_new holds the answer to tolerance; False hands the iteration to ADMM.
+        `first`: stats of an evaluation of the current multipliers already made (buffer 0).
+        `pre`: stats of the evaluation (buffer 1) that `_chain_launch` enqueued behind `first`
+        without reading it -- small model on candidate set 0, a full step for the slots not
+        yet within tolerance -- i.e. the first line-search trial of the first Newton iteration
+        if that iteration turns out to be the one this loop would have run.  Sets
+        `_pre_kept`: the accepted state is exactly the one `pre` (or `first`) left behind."""
+        o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
+        A = _lib.DUAL_AMAX
+        scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
+        ycur, ytrial = self.yd
+        cur = 0
+        # (`_sup`: a candidate set that lists every row of the current multipliers, while there
+        # are few enough of them for the row-wise home pass)
+        stt = (self._dual_evaluate(ycur, self._y_support, cur, sup=self._sup)
+               if first is None else first)
+        evals, newton, pivots, ok_all = 1, 0, 0, False
+        best, stall = np.inf, 0
+        last_small = False
+        from_pre = pre is not None       # P_est_new is what `pre` (== `first` if nothing moved) wrote
+        while True:
+            if (stt[:, 2] > A).any():
+                break                                    # more multipliers than a model holds
+            rmax = stt[:, 0] / scale
+            if rmax.max() <= o.eps:
+                ok_all = True
+                break
+            if newton >= o.newton_max:
+                break
+            # a slot whose model is full of multipliers while rows are still violated cannot
+            # take them in; and a solve that stopped improving is not worth more iterations
+            if ((stt[:, 2] >= A) & (stt[:, 3] > 0) & (rmax > o.eps)).any():
+                break
+            if rmax.max() < 0.5 * best:
+                best, stall = rmax.max(), 0
+            else:
+                stall += 1
+                if stall >= 10:
+                    break
+            newton += 1
+            # model of every slot: K_t = R_F N_t R_F^T / kappa over its candidates, maximised
+            # over the sign constraints (block principal pivoting, one workgroup per slot)
+            # (candidates of a slot = its rows with a multiplier + the violated rows admitted)
+            ncand = stt[:, 2] + np.minimum(stt[:, 3], np.minimum(o.newton_kadd, A - stt[:, 2]))
+            self.model_calls[0 if ncand.max() <= 8 else 1] += 1
+            last_small = bool(ncand.max() <= 8)
+            few = stt[:, 2].max() + o.newton_kadd <= 48
+            # (the chain guessed how its trial's home pass gets d = R^T y / kappa -- row-wise or
+            # dense; another choice here would differ in the last bits: then redo the trial)
+            use_pre = (pre is not None and newton == 1 and last_small
+                       and bool(few) == self._chain_few)
+            if use_pre:
+                pass                             # (the chain ran this model on this set)
+            elif ncand.max() <= 8:               # the binding steady state: one small kernel
+                check(lib.revs_op_dual_model_small(M, T, ptr(self.R64), ptr(self.pnq[1]),
+                                                   ptr(self.c_idx[cur]), ptr(self.c_cnt[cur]),
+                                                   ptr(self.c_val[cur]), self.kappa, o.newton_delta,
+                                                   o.newton_pivots, ptr(self.k_full), ptr(self.yhat),
+                                                   self.info_dev, st), "revs_op_dual_model_small")
+            else:
+                check(lib.revs_op_dual_model(M, T, ptr(self.R64), ptr(self.pnq[1]),
+                                             ptr(self.c_idx[cur]), ptr(self.c_cnt[cur]),
+                                             ptr(self.c_val[cur]), self.kappa, o.newton_delta,
+                                             o.newton_pivots, self.nks, ptr(self.k_slabs),
+                                             ptr(self.k_full), ptr(self.yhat), self.info_dev, st),
+                      "revs_op_dual_model")
+            D = stt[:, 1]
+            pending = rmax > o.eps
+            alpha = pending.astype(np.float64)
+            nxt = 1 - cur
+            for ls in range(o.newton_ls):
+                if use_pre and ls == 0:
+                    stn = pre                    # that trial and its evaluation: already there
+                else:
+                    from_pre = False
+                    self.alpha_h.numpy()[:] = alpha  # read by the step kernel through its mapping
+                    ytrial.copy_(ycur)
+                    check(lib.revs_op_dual_step(T, ptr(self.c_idx[cur]), ptr(self.c_cnt[cur]),
+                                                ptr(self.c_val[cur]), ptr(self.yhat),
+                                                self.alpha_dev, ptr(ytrial),
+                                                self.stats_dev[nxt] + 32, st),
+                          "revs_op_dual_step")
+                    stn = self._dual_evaluate(ytrial, True, nxt, sup=cur if few else None)
+                evals += 1
+                okk = stn[:, 1] >= D + 1e-4 * stn[:, 4] - 1e-13 * np.abs(D)
+                pending &= ~okk
+                if not pending.any():
+                    break
+                alpha[pending] *= 0.5
+            pivots += int(np.abs(self.info_h.numpy()).sum())     # (the evaluation was waited for)
+            if pending.any():
+                break                                    # no ascent found: leave it to ADMM
+            ycur, ytrial = ytrial, ycur
+            cur, stt = nxt, stn
+        self.yd = [ycur, ytrial]
+        self.newton_hist.append((newton, evals, pivots))
+        self._pre_kept = bool(ok_all and from_pre and newton <= 1)
+        # a solve of exactly one Newton iteration on the small model tends to repeat: the next
+        # one is enqueued whole (_chain_launch)
+        self._chain_ok = bool(ok_all and newton == 1 and last_small and evals == 2)
+        self._chain_few = bool(few) if newton >= 1 else False
+        # speculate on the next iteration after a solve that needed no Newton iteration -- but
+        # after a discarded sweep only once 2, 4, ... 64 such solves have gone by (rows that
+        # keep moving in and out of their limits would otherwise cost a wasted sweep each time)
+        if ok_all and newton == 0:
+            self._spec_wait = max(self._spec_wait - 1, 0)
+            self._spec_ok = self._spec_wait == 0
+        else:
+            self._spec_ok = False
+        if not ok_all:
+            ycur.zero_()
+            self._y_support = False
+            self._sup = None
+            return False
+        self._y_support = bool(stt[:, 2].sum() > 0)
+        # the accepted evaluation's candidate set `cur` lists the rows with y != 0 first
+        self._sup = cur if (self._y_support and stt[:, 2].max() + o.newton_kadd <= 48) else None
+        self.op_iters_hist.append(evals)
+        self.op_path_hist.append("dual")
+        self.op_converged = True
+        return True
+
+    def _chain_launch(self, write_sc, rec):
+        """The binding steady state without the host in the loop: evaluation of the current
+        multipliers (set 0) with its selection, the small model and the step in one launch
+        (full step for the slots that evaluation leaves pending, decided on the device:
+        revs_op_dual_select_model_step), the evaluation of the trial (set 1) and the home
+        sweep on its answer -- the trial's candidate selection rides in the sweep's launch --,
+        all enqueued; nothing is read."""
+        o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
+        scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
+        ycur, ytrial = self.yd
+        # (no event records in the chain: each costs the stream ~6 us; the host polls the
+        # sequence tag the last selection writes)
+        nb = (M + 31) // 32
+        nb = nb if (T <= 32 and nb <= 256) else 0
+        use_y = self._y_support
+        if use_y and self._sup is not None:       # as _dual_launch, the selection left out
+            self._dual_home_pass_rows(ycur, self._sup)
+        else:
+            self._dual_phase(1, ycur, use_y, 0)
+        if self.group is not None:
+            self._allreduce(self.pnq)
+        self._dual_phase(2 | 4, ycur, use_y, 0)
+        # selection, small model and step of every slot in one launch
+        check(lib.revs_op_dual_select_model_step(
+            M, T, ptr(self.d_part), nb, ptr(ycur), self.vlo, self.vhi, o.newton_kadd,
+            ptr(self.vfull), ptr(self.violw), ptr(self.c_idx[0]), ptr(self.c_cnt[0]),
+            ptr(self.c_val[0]), self.stats_dev[0], 0.0, ptr(self.R64), ptr(self.pnq[1]), self.kappa,
+            o.newton_delta, o.newton_pivots, ptr(self.k_full), ptr(self.yhat), self.info_dev, scale,
+            o.eps, ptr(ytrial), self.stats_dev[1] + 32, st), "revs_op_dual_select_model_step")
+        if self._chain_few:                       # d = R^T y / kappa from the rows of set 0
+            self._dual_home_pass_rows(ytrial, 0)
+        else:
+            self._dual_phase(1, ytrial, True, 1)
+        if self.group is not None:
+            self._allreduce(self.pnq)
+        self._dual_phase(2 | 4, ytrial, True, 1)  # product and rows; selection: in the sweep
+        rec(1)
+        self._chain_seq -= 1.0
+        check(lib.revs_agent_step_select(
+            self.n, T, ptr(self.cost), ptr(self.homes), ptr(self.load), ptr(self.P_est),
+            ptr(self.P_est_new), ptr(self.P_sch), ptr(self.G), ptr(self.P_sch_alt), ptr(self.G_alt),
+            ptr(self.S) if write_sc else None, ptr(self.Csoc) if write_sc else None,
+            ptr(self.diff), ptr(self.dsq), ptr(self.status), ptr(self.pdhg_dual), self.kappa,
+            self.mode, C.byref(self.pdhg), M, ptr(self.d_part), ptr(ytrial), self.vlo, self.vhi,
+            o.newton_kadd, ptr(self.vfull), ptr(self.violw), ptr(self.c_idx[1]), ptr(self.c_cnt[1]),
+            ptr(self.c_val[1]), self.stats_dev[1], self._chain_seq, None, None, None, nb, st),
+            "revs_agent_step_select")
+        rec(2)
+
+    def _chain_accept(self):
+        """Wait for the chain's two evaluations and, if they are the usual outcome -- one
+        Newton iteration on the small model, full step accepted, converged -- do the
+        bookkeeping _operator_solve_newton would do for it (revs_newton_chain_accept makes
+        the same checks in one native call).  False: nothing was changed."""
+        o = self.op
+        if self.stats_ev[0] is not None:
+            # the trial's verdict is written early in the sweep's launch: poll its sequence tag
+            # (pinned memory) rather than wait for the sweep; stream order puts everything the
+            # chain wrote before it
+            tags = self.stats_host[1].numpy()[:, 5]
+            spins, t0 = 0, None
+            while not (tags == self._chain_seq).all():
+                spins += 1
+                if spins & 0xFFF == 0:
+                    import time
+                    t0 = t0 or time.monotonic()
+                    if time.monotonic() - t0 > 120.0:
+                        raise _lib.RevsError("chained Newton iteration: timed out waiting for "
+                                             "the evaluation's sequence tag")
+        nsum, nmax = C.c_int32(), C.c_int32()
+        scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
+        if not self.lib.revs_newton_chain_accept(
+                self.T, self.stats_host[0].data_ptr(), self.stats_host[1].data_ptr(), scale, o.eps,
+                _lib.DUAL_AMAX, o.newton_kadd, int(self._chain_few), C.addressof(nsum),
+                C.addressof(nmax)):
+            return False
+        self._chain_book(nsum.value, nmax.value)
+        return True
+
+    def _chain_book(self, nsum, nmax):
+        o = self.op
+        self.yd = [self.yd[1], self.yd[0]]
+        self.model_calls[0] += 1
+        self.newton_hist.append((1, 2, int(np.abs(self.info_h.numpy()).sum())))
+        self._pre_kept, self._chain_ok, self._spec_ok = True, True, False
+        self._y_support = nsum > 0
+        self._sup = 1 if (self._y_support and nmax + o.newton_kadd <= 48) else None
+        self.op_iters_hist.append(2)
+        self.op_path_hist.append("dual")
+        self.op_converged = True
+
+    def _chain_run(self, count):
+        """Up to `count` iterations of the binding steady state inside one native call
+        (revs_plan_chain_run); the first one that is not the usual outcome is finished here as
+        step() would.  Returns the number of iterations done (at least one)."""
+        self._fused_ready = False
+        self._p_clear = None
+        ys = (self.yd[0], self.yd[1])
+        bufs = (self.P_est, self.P_est_new, self.P_sch, self.P_sch_alt, self.G, self.G_alt)
+        sup0 = self._sup if (self._y_support and self._sup is not None) else -1
+        st = _lib.ChainState(ptr(ys[0]), ptr(ys[1]), int(self._y_support), sup0,
+                             *[ptr(t) for t in bufs])
+        kept = C.c_int32()
+        check(self.lib.revs_plan_chain_run(self._plan, count, C.byref(st), int(self._chain_few),
+                                           C.addressof(kept), self.stream), "revs_plan_chain_run")
+        n = kept.value
+        by = {t.data_ptr(): t for t in bufs}
+        self.P_est, self.P_est_new = by[st.p_est], by[st.p_est_new]
+        self.P_sch, self.P_sch_alt = by[st.p_sch], by[st.p_sch_alt]
+        self.G, self.G_alt = by[st.gamma], by[st.gamma_alt]
+        self.yd = [ys[0], ys[1]] if st.y == ys[0].data_ptr() else [ys[1], ys[0]]
+        if n:
+            self.model_calls[0] += n
+            self.newton_hist.extend([(1, 2, -1)] * n)      # (pivot counts not read)
+            self._pre_kept, self._chain_ok, self._spec_ok = True, True, False
+            self._y_support = bool(st.use_y)
+            self._sup = 1 if st.sup0 == 1 else None
+            self.op_iters_hist.extend([2] * n)
+            self.op_path_hist.extend(["dual"] * n)
+            self.op_converged = True
+            self.chain_hist[0] += n
+            self.iteration += n
+        if n == count:
+            return n
+        # the call stopped at an iteration for the general loop (its launches are made)
+        self._chain_finish(False, 0, 0, False)
+        self.P_est, self.P_est_new = self.P_est_new, self.P_est
+        self.iteration += 1
+        return n + 1
+
+    def _chain_finish(self, accepted, nsum, nmax, write_sc):
+        """After the chain's launches: book the usual outcome, or hand both evaluations to the
+        general loop (which reuses the trial where it is exactly its own first step); keep the
+        speculative sweep or run it again."""
+        if accepted:
+            self._chain_book(nsum, nmax)
+            ok = True
+        else:                                # (the tag was seen: both blocks are complete)
+            stt0, stn = (self.stats_host[0].numpy().copy(), self.stats_host[1].numpy().copy())
+            ok = self._operator_solve_newton(first=stt0, pre=stn)
+        if ok and self._pre_kept:
+            self.P_sch, self.P_sch_alt = self.P_sch_alt, self.P_sch
+            self.G, self.G_alt = self.G_alt, self.G
+            self.chain_hist[0] += 1
+        else:
+            self.chain_hist[1] += 1
+            if not ok:
+                self._fast_cold = True
+                self.op_cold = True
+                self._require_converged(self.operator_solve(admm_only=True))
+            self.agent_step(write_sc)
