@@ -166,7 +166,9 @@ __device__ __forceinline__ void stream_verdict_body(const AgentArgs &a, const in
 // share its launch are written to fit the same budget (tree_body.h) and must not lower it.
 // (Measured and rejected, round 2: a wavefront working through 2-4 groups of residences with the
 // next group's loads in flight -- the second input set costs 118-128 VGPRs, occupancy 4, and the
-// launch takes 24-25 us against 20; without the prefetch the loop spills at the 64-register cap.)
+// launch takes 24-25 us against 20; without the prefetch the loop spills at the 64-register cap;
+// 16 homes per wavefront (4 lanes x 6 slots) squeezed to 72 VGPRs so that all 6 250 wavefronts are
+// resident at once: 22.7 us against 18.5.)
 template <int LPA, int SPL, int MODE, bool FULL_ROWS = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SPL <= 4 && !FULL_ROWS ? 8 : 4)))
 void agent_step_kernel(const AgentArgs a) {
