@@ -254,12 +254,12 @@ void agent_step_kernel(const AgentArgs a) {
     bool valid[SPL], win[SPL];
 #pragma unroll
     for (int j = 0; j < SPL; ++j) valid[j] = live && tval[j];
+    const float inv_kf = 1.0f / kappa;
     if (rec_pen) {      // same arithmetic as the folded home pass that would have stored it
-        const double inv_kd = 1.0 / (double)kappa;
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
-            const double g0 = 0.5 * ((double)pe[j] + (double)pso[j]) - (double)gm[j] * inv_kd;
-            pen[j] = (valid[j] && g0 > 0.0) ? (float)g0 : 0.f;
+            const float g0 = revs_g0f(pe[j], pso[j], gm[j], inv_kf);
+            pen[j] = (valid[j] && g0 > 0.f) ? g0 : 0.f;
         }
     }
     const bool ev = h.ev != 0;
@@ -282,7 +282,10 @@ void agent_step_kernel(const AgentArgs a) {
     int status = 0;
     const ScanMasks<LPA> mk(lig);
 
-    if constexpr (MODE == REVS_MODE_BINARY) {
+    // A wavefront whose residences have no EV at all (the engine sorts like with like: 43 % of
+    // the wavefronts of the bench workload) has nothing to solve: p = 0, status = 0 stand.
+    if (!__any(ev)) {
+    } else if constexpr (MODE == REVS_MODE_BINARY) {
         // p_t = e_t * rating, e_t binary (lpsolver.py:92-98).  Switching slot t on
         // costs delta_t = rating ((kappa/2) rating + q_t); take the nmin cheapest,
         // then more while delta < 0, up to nmax.
@@ -509,11 +512,7 @@ void agent_step_kernel(const AgentArgs a) {
     }
 
     // ---- epilogue: g, SOC, dual update, residuals (lpsolver.py:275-284) ----
-    float ss = 0.f, dd = 0.f, pacc = 0.f, pfx[SPL];
-#pragma unroll
-    for (int j = 0; j < SPL; ++j) { pacc += p[j]; pfx[j] = pacc; }
-    const float poff = group_excl_prefix<LPA>(pacc, lig, mk);
-    const float invcap = ev ? __builtin_amdgcn_rcpf(h.capacity) : 0.f;    // (1 ulp; SOC only)
+    float ss = 0.f, dd = 0.f;
     const int64_t crow = agent * (int64_t)(T + 1);
     float gn[SPL], gmn[SPL], socv[SPL];
 #pragma unroll
@@ -522,21 +521,26 @@ void agent_step_kernel(const AgentArgs a) {
         const float chk = pen[j] - g;                       // lpsolver.py:280
         gn[j] = g;
         gmn[j] = gm[j] + 0.5f * kappa * chk;                // lpsolver.py:282
-        socv[j] = ev ? h.initial + (pfx[j] + poff) * invcap : 0.f;
         const float dg = g - pso[j];
         ss += valid[j] ? chk * chk : 0.f;
         dd += valid[j] ? dg * dg : 0.f;
     }
+    if (a.c_out) {      // the SOC trajectory (a prefix sum over the slots) only where it is returned
+        float pacc = 0.f, pfx[SPL];
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) { pacc += p[j]; pfx[j] = pacc; }
+        const float poff = group_excl_prefix<LPA>(pacc, lig, mk);
+        const float invcap = ev ? __builtin_amdgcn_rcpf(h.capacity) : 0.f;    // (1 ulp; SOC only)
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) socv[j] = ev ? h.initial + (pfx[j] + poff) * invcap : 0.f;
+    }
     // next evaluation's home pass (same arithmetic as op_dual_eval_kernel with d = 0)
     float pe2[SPL];
-    double gnext[SPL];
     if (a.p_next) {
-        const double inv_k = 1.0 / (double)kappa;
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
-            const double g0 = 0.5 * ((double)pen[j] + (double)gn[j]) - (double)gmn[j] * inv_k;
-            gnext[j] = (valid[j] && g0 > 0.0) ? g0 : 0.0;
-            pe2[j] = (float)gnext[j];
+            const float g0 = revs_g0f(pen[j], gn[j], gmn[j], inv_kf);
+            pe2[j] = (valid[j] && g0 > 0.f) ? g0 : 0.f;
         }
     }
     if (full) {
@@ -580,9 +584,9 @@ void agent_step_kernel(const AgentArgs a) {
         const int loc = node - base;
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
-            if (gnext[j] > 0.0) {
-                if (loc < kNodeLoc) unsafeAtomicAdd(&nacc[loc][t0 + j], gnext[j]);
-                else unsafeAtomicAdd(&a.p_next[(int64_t)node * T + t0 + j], gnext[j]);
+            if (pe2[j] > 0.f) {      // (floats widened to double: the node sums are exact, whatever the order)
+                if (loc < kNodeLoc) unsafeAtomicAdd(&nacc[loc][t0 + j], (double)pe2[j]);
+                else unsafeAtomicAdd(&a.p_next[(int64_t)node * T + t0 + j], (double)pe2[j]);
             }
         }
     }

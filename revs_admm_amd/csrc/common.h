@@ -122,6 +122,17 @@ __device__ __forceinline__ float group_excl_suffix(float v, int lig, const ScanM
     return s;
 }
 
+// g0 = (P_est + P_sch)/2 - G/kappa, the unconstrained minimiser of the operator's objective
+// (lpsolver.py:196-207: g0 = -a/kappa), in FLOAT: the sum rounded once, then one fused multiply-add
+// (inv_kf = 1.0f / (float)kappa in every caller).  The operator's state and its answer are float
+// arrays; every kernel that forms g0 -- the dual evaluations, the ADMM forms, the home pass folded
+// into the residence sweep -- goes through this function, so the answer max(g0 - d, 0) is the same
+// float whichever kernel computes it.  (Round 1 formed g0 in double in each of them: 71 f64
+// instructions per wavefront of the sweep, which is VALU-issue bound: -3 us per launch.)
+__device__ __forceinline__ float revs_g0f(float pe, float ps, float gm, float inv_kf) {
+    return __builtin_fmaf(-gm, inv_kf, 0.5f * (pe + ps));
+}
+
 // clip(v, lo, hi) as one v_med3_f32 (lo <= hi)
 __device__ __forceinline__ float clip3(float v, float lo, float hi) {
     return __builtin_amdgcn_fmed3f(v, lo, hi);

@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256) void op_dual_eval_kernel(
     const int64_t total = (int64_t)m * T;
     const int idx = node * T + (tok ? t : 0);
     const double inv_k = 1.0 / kappa;
+    const float inv_kf = 1.0f / (float)kappa;
     double d = 0.0;
     if (dsl) {
         for (int q = 0; q < nslab; ++q) d += dsl[idx + q * total];
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void op_dual_eval_kernel(
     if (tok) {
         for (int64_t i = i0 + hs; i < i1; i += HS) {
             const int64_t o = i * T + t;
-            const double g0 = 0.5 * ((double)pe[o] + (double)ps[o]) - (double)gm[o] * inv_k;
+            const double g0 = (double)revs_g0f(pe[o], ps[o], gm[o], inv_kf);
             const bool fr = g0 > d;
             const double g = fr ? g0 - d : 0.0;
             ap += g;

@@ -43,7 +43,7 @@ __device__ __forceinline__ void atomic_max_nonneg(double *addr, double v) {
 __global__ void op_g0_kernel(int64_t total, const float *pe, const float *ps, const float *gm,
                              double kappa, double *g0) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < total) g0[i] = 0.5 * ((double)pe[i] + (double)ps[i]) - (double)gm[i] / kappa;
+    if (i < total) g0[i] = (double)revs_g0f(pe[i], ps[i], gm[i], 1.0f / (float)kappa);
 }
 
 // cold start: s_b = max(g0, 0)  (z_b = that, y_b = 0)
@@ -306,11 +306,11 @@ __global__ __launch_bounds__(256) void op_node_prep_kernel(
     const bool tok = t < T;
     double acc = 0.0, mn = INFINITY;
     const int64_t i0 = node_ptr[node], i1 = node_ptr[node + 1];
-    const double inv_k = 1.0 / kappa;
+    const float inv_kf = 1.0f / (float)kappa;
     if (tok) {
         for (int64_t i = i0 + hs; i < i1; i += HS) {
             const int64_t o = i * T + t;
-            double g = 0.5 * ((double)pe[o] + (double)ps[o]) - (double)gm[o] * inv_k;
+            double g = (double)revs_g0f(pe[o], ps[o], gm[o], inv_kf);
             if (g0_out) g0_out[o] = g;
             // R >= 0 entrywise and vlo <= 0: only upper rows can bind, the node shift is
             // <= 0, so max(g0 - theta, 0) = max(max(g0,0) - theta, 0): residences with
@@ -498,11 +498,11 @@ __global__ __launch_bounds__(256) void op_node_apply_kernel(
     const int t = threadIdx.x % TL, hs = threadIdx.x / TL;
     if (t >= T) return;
     const double corr = inv_sqrt_n[node] * d[node * T + t];
-    const double inv_k = 1.0 / kappa;
+    const float inv_kf = 1.0f / (float)kappa;
     const int64_t i0 = node_ptr[node], i1 = node_ptr[node + 1];
     for (int64_t i = i0 + hs; i < i1; i += HS) {
         const int64_t o = i * T + t;
-        double g = 0.5 * ((double)pe[o] + (double)ps[o]) - (double)gm[o] * inv_k;
+        double g = (double)revs_g0f(pe[o], ps[o], gm[o], inv_kf);
         if (preclamp) g = fmax(g, 0.0);
         pe_new[o] = (float)fmax(g + corr, 0.0);
     }

@@ -20,6 +20,15 @@ def view(p, shape, dt):
     return np.ctypeslib.as_array((_F[dt] * n).from_address(int(p))).reshape(shape)
 
 
+def g0f(pe, ps, gm, kappa):
+    """revs_g0f of csrc/common.h: g0 = (P_est + P_sch)/2 - G/kappa in float -- the sum rounded
+    once, then one fused multiply-add (emulated in extended precision, rounded to float once)."""
+    inv = np.float32(1.0) / np.float32(kappa)
+    s = np.float32(0.5) * (np.asarray(pe, np.float32) + np.asarray(ps, np.float32))
+    r = s.astype(np.longdouble) - np.asarray(gm, np.float32).astype(np.longdouble) * np.longdouble(inv)
+    return r.astype(np.float32).astype(np.float64)
+
+
 class FakeKernels:
     def revs_pdhg_defaults(self, ref):
         o = ref._obj
@@ -82,8 +91,8 @@ class FakeKernels:
         return 0
 
     def revs_op_g0(self, n, T, pe, ps, gm, kappa, g0, stream):
-        f = lambda p: view(p, (n, T), np.float32).astype(float)
-        view(g0, (n, T), np.float64)[:] = 0.5 * (f(pe) + f(ps)) - f(gm) / kappa
+        f = lambda p: view(p, (n, T), np.float32)
+        view(g0, (n, T), np.float64)[:] = g0f(f(pe), f(ps), f(gm), kappa)
         return 0
 
     def revs_op_init_home(self, n, T, g0, sb, stream):
@@ -226,8 +235,8 @@ class FakeKernels:
     def revs_op_node_prep(self, m, T, node_ptr, isn, pe, ps, gm, kappa, preclamp, p0, gmin, g0_out,
                           stream):
         node, n = self._seg(m, node_ptr)
-        f = lambda p: view(p, (n, T), np.float32).astype(float)
-        g = 0.5 * (f(pe) + f(ps)) - f(gm) / kappa
+        f = lambda p: view(p, (n, T), np.float32)
+        g = g0f(f(pe), f(ps), f(gm), kappa)
         if g0_out:
             view(g0_out, (n, T), np.float64)[:] = g
         if preclamp:
@@ -296,8 +305,8 @@ class FakeKernels:
     def revs_op_node_apply(self, m, T, node_ptr, isn, pe, ps, gm, kappa, preclamp, dd, pe_new,
                            stream):
         node, n = self._seg(m, node_ptr)
-        f = lambda p: view(p, (n, T), np.float32).astype(float)
-        g = 0.5 * (f(pe) + f(ps)) - f(gm) / kappa
+        f = lambda p: view(p, (n, T), np.float32)
+        g = g0f(f(pe), f(ps), f(gm), kappa)
         if preclamp:
             g = np.maximum(g, 0)
         corr = (view(isn, (m,), np.float64)[:, None] * view(dd, (m, T), np.float64))[node]
@@ -307,8 +316,8 @@ class FakeKernels:
     # ---- dual Newton path ----
     def revs_op_dual_eval(self, m, T, node_ptr, pe, ps, gm, nslab, dsl, kappa, pnq, pe_new, stream):
         node, n = self._seg(m, node_ptr)
-        f = lambda p: view(p, (n, T), np.float32).astype(float)
-        g0 = 0.5 * (f(pe) + f(ps)) - f(gm) / kappa
+        f = lambda p: view(p, (n, T), np.float32)
+        g0 = g0f(f(pe), f(ps), f(gm), kappa)
         d = view(dsl, (nslab, m, T), np.float64).sum(axis=0) / kappa if dsl else np.zeros((m, T))
         dh = d[node]
         free = g0 > dh
