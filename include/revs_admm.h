@@ -655,13 +655,15 @@ int revs_plan_chain_run(revs_plan_t *plan, int32_t max_steps, revs_chain_state_t
  *   end[j]  one past the last position of j's subtree
  *   eo[k]   the positions sorted by end (stable)
  *   cle[j]  number of positions a with end[a] <= j
- *   w[j]    2 r of the edge from j to its parent
+ * packed 16 bits each into pack[j] = (src[j] + 1) | end[j] << 16 | eo[j] << 32 | cle[j] << 48 (one
+ * 64-bit load per position: the evaluation is latency-bound), and
+ *   w[j]    2 r of the edge from j to its parent (double)
  * revs_tree_voltage: one workgroup per slot; v_out double[m][T] (rows with src; may be NULL),
  * rmax_out double[T] = largest violation max(v - vhi, vlo - v, 0) over the checked rows. */
 #define REVS_TREE_MAX 2048
 typedef struct {
     int32_t n;
-    const int32_t *src, *end, *eo, *cle;
+    const uint64_t *pack;
     const double *w;
 } revs_tree_t;
 int revs_tree_voltage(int32_t m, int32_t T, const revs_tree_t *tree_host, const double *p,

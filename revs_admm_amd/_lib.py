@@ -66,8 +66,7 @@ class ChainState(C.Structure):
 
 class Tree(C.Structure):
     """revs_tree_t"""
-    _fields_ = [("n", C.c_int32), ("src", C.c_void_p), ("end", C.c_void_p), ("eo", C.c_void_p),
-                ("cle", C.c_void_p), ("w", C.c_void_p)]
+    _fields_ = [("n", C.c_int32), ("pack", C.c_void_p), ("w", C.c_void_p)]
 
 
 class StreamState(C.Structure):

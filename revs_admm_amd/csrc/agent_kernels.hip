@@ -823,7 +823,7 @@ static int agent_step_impl(int64_t n_homes, int32_t T, const float *cost,
     a.vtol = 0.0; a.rec = nullptr; a.flags = flags; a.m = 0;
     if (sx) {
         REVS_REQUIRE(sx->ctl && sx->rec && sx->p_in && sx->tree.n > 0 && sx->tree.n <= REVS_TREE_MAX && sx->tree.n % 8 == 0 &&
-                     sx->tree.src && sx->tree.end && sx->tree.eo && sx->tree.cle && sx->tree.w &&
+                     sx->tree.pack && sx->tree.w &&
                      sx->m > 0 && sx->vlo <= sx->vhi && sx->vtol >= 0.0 && !sel,
                      "revs_agent_step: bad streaming argument");
         a.ctl = sx->ctl; a.seq = sx->seq; a.base_seq = sx->base_seq; a.tree = sx->tree; a.p_in = sx->p_in; a.p_zero = sx->p_zero;
@@ -870,10 +870,9 @@ __global__ __launch_bounds__(256) void tree_voltage_kernel(TreeArgs tr, const do
 extern "C" int revs_tree_voltage(int32_t m, int32_t T, const revs_tree_t *tree, const double *p,
                                  double vlo, double vhi, double *v_out, double *rmax_out,
                                  void *stream) {
-    REVS_REQUIRE(m > 0 && T > 0 && tree && p && tree->n > 0 && tree->n <= REVS_TREE_MAX && tree->n % 8 == 0 && tree->src &&
-                 tree->end && tree->eo && tree->cle && tree->w && vlo <= vhi,
+    REVS_REQUIRE(m > 0 && T > 0 && tree && p && tree->n > 0 && tree->n <= REVS_TREE_MAX && tree->n % 8 == 0 && tree->pack && tree->w && vlo <= vhi,
                  "revs_tree_voltage: bad argument (tree nodes <= %d)", REVS_TREE_MAX);
-    const TreeArgs tr{tree->n, tree->src, tree->end, tree->eo, tree->cle, tree->w};
+    const TreeArgs tr{tree->n, (const unsigned long long *)tree->pack, tree->w};
     hipLaunchKernelGGL(tree_voltage_kernel, dim3(T), dim3(256), tree_lds_bytes(tree->n),
                        (hipStream_t)stream, tr, p, T, vlo, vhi, v_out, rmax_out);
     REVS_CHECK_LAUNCH("revs_tree_voltage");

@@ -515,9 +515,9 @@ extern "C" int revs_comm_allreduce_f64(revs_comm_t *comm, double *buf, int64_t c
 extern "C" int revs_plan_set_tree(revs_plan_t *plan, const revs_tree_t *t) {
     REVS_REQUIRE(plan, "revs_plan_set_tree: null plan");
     if (!t || t->n == 0) { plan->tree = revs::TreeArgs{}; return REVS_OK; }
-    REVS_REQUIRE(t->n > 0 && t->n <= REVS_TREE_MAX && t->n % 8 == 0 && t->src && t->end && t->eo && t->cle && t->w,
+    REVS_REQUIRE(t->n > 0 && t->n <= REVS_TREE_MAX && t->n % 8 == 0 && t->pack && t->w,
                  "revs_plan_set_tree: bad tree (at most %d nodes, a multiple of 8)", REVS_TREE_MAX);
-    plan->tree = revs::TreeArgs{t->n, t->src, t->end, t->eo, t->cle, t->w};
+    plan->tree = revs::TreeArgs{t->n, (const unsigned long long *)t->pack, t->w};
     return REVS_OK;
 }
 

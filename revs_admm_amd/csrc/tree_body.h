@@ -54,38 +54,46 @@ __device__ __forceinline__ double block_excl_offset(double tot, double *red) {
 
 struct TreeArgs {
     int32_t n;                              // a multiple of 8 (the host pads with weightless roots)
-    const int32_t *src, *end, *eo, *cle;
+    const unsigned long long *pack;         // per position: src + 1 | end << 16 | eo << 32 | cle << 48
     const double *w;
 };
 
-struct alignas(16) TreeI4 { int v[4]; };
+struct alignas(16) TreeU2 { unsigned long long v[2]; };
 struct alignas(16) TreeD2 { double v[2]; };
-__device__ __forceinline__ void tree_ld8(const int32_t *p, int (&o)[8]) {
-    const TreeI4 a = reinterpret_cast<const TreeI4 *>(p)[0], b = reinterpret_cast<const TreeI4 *>(p)[1];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { o[i] = a.v[i]; o[4 + i] = b.v[i]; }
-}
 
 // Largest violation max(v - vhi, vlo - v, 0) over the checked rows of slot t (every thread
 // gets it); v_out[src][t] = v when v_out != NULL.  `lds`: tree_lds_bytes() bytes, 16-byte aligned.
-// Register budget: this body runs inside the residence sweep's kernel, whose occupancy (8
-// wavefronts per SIMD, 64 VGPRs) it must not lower: two 8-double vectors per thread (thread tid
-// owns positions 8 tid .. 8 tid + 7), index vectors loaded where they are used.
+// Two things shape this body.  Registers: it runs inside the residence sweep's kernel, whose
+// occupancy (8 wavefronts per SIMD, 64 VGPRs) it must not lower -- two 8-double vectors per
+// thread (thread tid owns positions 8 tid .. 8 tid + 7) beside the static data.  Latency: its 24
+// or 96 workgroups are the launch's critical path when memory is saturated by the sweep (every
+// dependent global load costs 2-3 us there), so ALL the static data of a thread -- four 16-bit
+// indices per position packed in one 64-bit word, and the weights -- are requested at the very
+// top, and the only dependent global access is the gather of the node sums behind them.
 __device__ __forceinline__ double tree_rmax(const TreeArgs &tr, const double *p, int T, int t,
                                             double vlo, double vhi, double *lds, double *v_out) {
     const int tid = threadIdx.x, n = tr.n, j0 = 8 * tid;
     const bool act = j0 < n;
     double *base = lds + 2, *red0 = lds + 2 + REVS_TREE_MAX, *red1 = red0 + 4;
     if (tid == 0) lds[1] = 0.0;                                 // base[-1]
+    unsigned long long pk[8];
     double a[8], b[8];
-    int ix[8];
-    // C: inclusive prefix of the injections in preorder
 #pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] = 0.0;
+    for (int i = 0; i < 8; ++i) { pk[i] = 0ull; a[i] = 0.0; b[i] = 0.0; }
     if (act) {
-        tree_ld8(tr.src + j0, ix);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a[i] = ix[i] >= 0 ? p[(int64_t)ix[i] * T + t] : 0.0;
+        for (int i = 0; i < 8; i += 2) {
+            const TreeU2 u = *reinterpret_cast<const TreeU2 *>(tr.pack + j0 + i);
+            const TreeD2 wv = *reinterpret_cast<const TreeD2 *>(tr.w + j0 + i);
+            pk[i] = u.v[0]; pk[i + 1] = u.v[1];
+            b[i] = wv.v[0]; b[i + 1] = wv.v[1];                 // (b holds the weights until phase 2)
+        }
+        // C: inclusive prefix of the injections in preorder
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int s = (int)(pk[i] & 0xFFFFu) - 1;
+            a[i] = s >= 0 ? p[(int64_t)s * T + t] : 0.0;
+        }
     }
 #pragma unroll
     for (int i = 1; i < 8; ++i) a[i] += a[i - 1];
@@ -98,18 +106,10 @@ __device__ __forceinline__ double tree_rmax(const TreeArgs &tr, const double *p,
     __syncthreads();
     // w'_j = w_j (C[end_j] - C[j]),  C[j] = base[j - 1] (own positions: registers)
     if (act) {
-        tree_ld8(tr.end + j0, ix);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) b[i] = base[ix[i] - 1];
-#pragma unroll
-        for (int i = 7; i >= 1; --i) a[i] = b[i] - (a[i - 1] + cex);
-        a[0] = b[0] - cex;
-#pragma unroll
-        for (int i = 0; i < 8; i += 2) {
-            const TreeD2 wv = *reinterpret_cast<const TreeD2 *>(tr.w + j0 + i);
-            a[i] *= wv.v[0];
-            a[i + 1] *= wv.v[1];
-        }
+        for (int i = 7; i >= 1; --i)
+            a[i] = b[i] * (base[(int)((pk[i] >> 16) & 0xFFFFu) - 1] - (a[i - 1] + cex));
+        a[0] = b[0] * (base[(int)((pk[0] >> 16) & 0xFFFFu) - 1] - cex);
     }
     __syncthreads();                                            // every read of C is done
     if (act) {
@@ -120,12 +120,7 @@ __device__ __forceinline__ double tree_rmax(const TreeArgs &tr, const double *p,
     __syncthreads();
     // the same values in end-order, then both prefixes: Pre over preorder (a), F over end-order (b)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) b[i] = 0.0;
-    if (act) {
-        tree_ld8(tr.eo + j0, ix);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) b[i] = base[ix[i]];
-    }
+    for (int i = 0; i < 8; ++i) b[i] = act ? base[(int)((pk[i] >> 32) & 0xFFFFu)] : 0.0;
 #pragma unroll
     for (int i = 1; i < 8; ++i) { a[i] += a[i - 1]; b[i] += b[i - 1]; }
     const double pex = block_excl_offset(a[7], red1);           // (its barrier: every read of w' is done)
@@ -139,16 +134,13 @@ __device__ __forceinline__ double tree_rmax(const TreeArgs &tr, const double *p,
     // v_j = Pre[j] - F_excl[cle[j]] on the checked rows,  F_excl[c] = base[c - 1]
     double rmax = 0.0;
     if (act) {
-        tree_ld8(tr.cle + j0, ix);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) b[i] = base[ix[i] - 1];
-        tree_ld8(tr.src + j0, ix);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            if (ix[i] >= 0) {
-                const double v = (a[i] + pex) - b[i];
+            const int s = (int)(pk[i] & 0xFFFFu) - 1;
+            if (s >= 0) {
+                const double v = (a[i] + pex) - base[(int)(pk[i] >> 48) - 1];
                 rmax = fmax(rmax, fmax(fmax(v - vhi, vlo - v), 0.0));
-                if (v_out) v_out[(int64_t)ix[i] * T + t] = v;
+                if (v_out) v_out[(int64_t)s * T + t] = v;
             }
         }
     }

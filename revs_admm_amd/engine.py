@@ -373,8 +373,8 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
                     raise ValueError("feeder: the tree does not reproduce Rn (R[i][j] = 2 x the "
                                      "resistance shared by the substation->i and ->j paths)")
                 self._tree_host = tr
-                self._tree_dev = {k: up(v) for k, v in tr.items() if k != "n"}
-                self._tree = _lib.Tree(tr["n"], *[ptr(self._tree_dev[k]) for k in ("src", "end", "eo", "cle", "w")])
+                self._tree_dev = {k: up(tr[k].view(np.int64) if k == "pack" else tr[k]) for k in ("pack", "w")}
+                self._tree = _lib.Tree(tr["n"], ptr(self._tree_dev["pack"]), ptr(self._tree_dev["w"]))
                 if self._plan is not None:
                     check(self.lib.revs_plan_set_tree(self._plan, C.byref(self._tree)),
                           "revs_plan_set_tree")

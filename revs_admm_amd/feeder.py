@@ -12,7 +12,8 @@ def feeder_tree(parent, edge_r, cons_of, checked):
     edge_r[i]   resistance of the edge from i to its parent
     cons_of[i]  constraint row (0..M-1) of node i, or -1
     checked[r]  whether row r is constrained (it carries residences, lpsolver.py:188-189)
-    Returns dict(n, src, end, eo, cle, w) of numpy arrays (see include/revs_admm.h)."""
+    Returns dict(n, src, end, eo, cle, w, pack) of numpy arrays (see include/revs_admm.h; the device
+    gets `pack` and `w`, the separate index arrays serve tree_voltage_host)."""
     parent = np.asarray(parent, np.int64)
     pad = (-len(parent)) % 8                 # the kernel's threads own 8 consecutive positions:
     if pad:                                  # pad with weightless nodes hanging off the substation
@@ -47,8 +48,10 @@ def feeder_tree(parent, edge_r, cons_of, checked):
     eo = np.argsort(end, kind="stable")
     cle = np.searchsorted(end[eo], np.arange(n), side="right")
     w = 2.0 * np.asarray(edge_r, np.float64)[order]
+    pack = ((src + 1).astype(np.uint64) | (end.astype(np.uint64) << np.uint64(16))
+            | (eo.astype(np.uint64) << np.uint64(32)) | (cle.astype(np.uint64) << np.uint64(48)))
     return dict(n=n, src=src.astype(np.int32), end=end.astype(np.int32), eo=eo.astype(np.int32),
-                cle=cle.astype(np.int32), w=w)
+                cle=cle.astype(np.int32), w=w, pack=pack)
 
 
 def tree_voltage_host(tree, p):

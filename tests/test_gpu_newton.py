@@ -533,8 +533,8 @@ def test_tree_voltage_matches_dense_product(gpu_lib, case, golden, feeder_R):
     np.testing.assert_allclose(tree_voltage_host(tr, p), ref, rtol=0, atol=1e-12 * np.abs(ref).max())
     dev = "cuda:0"
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    d = {k: up(v) for k, v in tr.items() if k != "n"}
-    tree = _lib.Tree(tr["n"], *[d[k].data_ptr() for k in ("src", "end", "eo", "cle", "w")])
+    d = {"pack": up(tr["pack"].view(np.int64)), "w": up(tr["w"])}
+    tree = _lib.Tree(tr["n"], d["pack"].data_ptr(), d["w"].data_ptr())
     dp, dv = up(p), torch.full((M, T), np.nan, dtype=torch.float64, device=dev)
     drm = torch.zeros(T, dtype=torch.float64, device=dev)
     vhi = float(np.quantile(ref[checked], 0.98))
