@@ -37,7 +37,17 @@ import os
 import sys
 import time
 
-import numpy as np
+# Host-side thread pools (OpenBLAS under numpy, OpenMP/MKL under torch) keep spinning for a while
+# after every parallel region.  On a box whose CPU share is a cgroup quota (16 CPUs per GPU here,
+# 256 visible) two pools of 32-64 spinning threads use the quota up, and the kernel then freezes
+# EVERY thread of the process -- the one that feeds the GPU too -- for the rest of the 100 ms
+# period: measured as 20-50 ms holes in 5-10 % of the bursts (tools/comm_probe.py).
+# So the pools are capped before numpy / torch load (torch.distributed.run sets OMP_NUM_THREADS=1
+# itself for N > 1).  Nothing on the hot path runs on these threads.
+for _k in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_k, "4")
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -85,7 +95,7 @@ def cpu_baseline(w, state, budget_s=20.0):
     the GPU run has reached: (i) every residence's QP (`home_solve_relaxed`: the exact optimum
     the PDHG kernel iterates towards), residences split over one process per core; (ii) the
     operator's side of a steady-state iteration -- g0, its node sums and the dense voltage
-    product Rn p (numpy BLAS, all cores).  value = residences / (t_homes + t_operator)."""
+    product Rn p (numpy BLAS, the parent's capped pool).  value = residences / (t_homes + t_operator)."""
     import multiprocessing as mp
     from oracle import revs_oracle as ro
     pe, ps, gm = (np.asarray(a, np.float64) for a in state)

@@ -717,6 +717,22 @@ int revs_plan_set_comm(revs_plan_t *plan, revs_comm_t *comm);
 int revs_plan_stream_run(revs_plan_t *plan, int32_t max_steps, revs_stream_state_t *st,
                          double scale, double eps, int32_t *kept_steps, double *rmax_last,
                          void *stream);
+/* Verdicts by blocks -- the sharded form of the loop above.  The node sums of an iteration are
+ * only known after the all-reduce, and one collective per sweep would make the collective's
+ * latency the step.  With block = B > 1, revs_plan_stream_run lets B sweeps run without a
+ * verdict, each accumulating its node sums into its own slice of a ring owned by the plan;
+ * ONE all-reduce sums the B slices over the ranks and one launch of B x T workgroups judges
+ * them (tree form, as above).  Every launch of the burst is still a no-op once an iteration at
+ * or before its own has failed; the sweeps of the block that ran behind a failed iteration
+ * are undone: each block first saves the state it overwrites (four profiles and the PDHG
+ * residences' carried multipliers, in arrays owned by the plan), and the call puts it back and runs
+ * the good sweeps of that block again, then the failed iteration's own sweep (to the spares),
+ * before it returns -- memory is then bit for bit what the single-GPU form leaves.
+ * The contract of revs_plan_stream_run is unchanged (st->p[1], p[2] are not used; st->p[0] holds
+ * the all-reduced sums of the next iteration at return).  block <= 1: every launch judges itself
+ * (the single-GPU form).  Memory: B M T doubles + 5 n T floats.  Set it on every rank alike. */
+#define REVS_STREAM_BLOCK_MAX 256
+int revs_plan_set_stream_block(revs_plan_t *plan, int32_t block);
 /* Bits OR-ed by the sweeps launched through the plan since the last clear: 1 = a residence's
  * window cannot reach 90 % SOC (the reference prints "No solution found", lpsolver.py:153-155),
  * 2 = a PDHG residence hit max_iter before its tolerance.  Meaningful after the stream has

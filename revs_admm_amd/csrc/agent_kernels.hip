@@ -825,7 +825,10 @@ static int agent_step_impl(int64_t n_homes, int32_t T, const float *cost,
     REVS_REQUIRE(!p_next || (node_of && pe2_out), "revs_agent_step: node_of / pe2_out missing");
     a.ctl = nullptr; a.seq = 0; a.base_seq = 0; a.tree = TreeArgs{}; a.p_in = nullptr; a.p_zero = nullptr;
     a.vtol = 0.0; a.rec = nullptr; a.flags = flags; a.m = 0;
-    if (sx) {
+    if (sx && !sx->verdict) {         // judged by blocks (stream_block_verdict): silencing only
+        REVS_REQUIRE(sx->ctl && !sel, "revs_agent_step: bad streaming argument");
+        a.ctl = sx->ctl; a.seq = sx->seq; a.base_seq = sx->base_seq; a.flags = sx->flags;
+    } else if (sx) {
         REVS_REQUIRE(sx->ctl && sx->rec && sx->p_in && sx->tree.n > 0 && sx->tree.n <= REVS_TREE_MAX && sx->tree.n % 8 == 0 &&
                      sx->tree.pack && sx->tree.w &&
                      sx->m > 0 && sx->vlo <= sx->vhi && sx->vtol >= 0.0 && !sel,
@@ -860,6 +863,132 @@ int agent_step_stream(int64_t n_homes, int32_t T, const float *cost, const revs_
     return agent_step_impl(n_homes, T, cost, homes, load, p_est_old, p_est_new, p_sch, gamma,
                            p_sch_out, gamma_out, nullptr, nullptr, diff, dsq, status, pdhg_dual,
                            kappa, mode, pdhg_host, nullptr, node_of, p_next, p_est_next, stream, &sx);
+}
+
+// ---- verdicts by blocks (sharded streaming steady state, runtime.cpp) --------------------
+// With residences sharded the node sums of an iteration are only known after an all-reduce, and
+// one collective per 18 us sweep would be the whole step.  So a block of B sweeps runs without
+// verdicts, each accumulating its sums into its own slice of a ring; ONE all-reduce then sums
+// the B slices over the ranks, and one launch of B x T workgroups judges them all.  A failed
+// verdict silences everything behind the block; the sweeps of the block behind the failed
+// iteration have run on an estimate that is not the operator's answer, so the block starts
+// by saving the state they overwrite (stream_block_begin) and the host rolls back to it.
+struct BlockBegin {
+    const StreamCtl *ctl;
+    unsigned int base_seq, gate_seq;      // no-op when a launch numbered base_seq..gate_seq failed
+    const float *src[5];
+    float *dst[5];
+    long long count[5];                   // floats
+    int32_t narr;
+    double *ring;                         // cleared: ring_count doubles
+    long long ring_count;
+};
+__global__ __launch_bounds__(256) void stream_block_begin_kernel(const BlockBegin b) {
+    const unsigned int bad = b.ctl->bad_seq;
+    if (bad >= b.base_seq && bad <= b.gate_seq) return;
+    const long long gtid = (long long)blockIdx.x * 256 + threadIdx.x, nth = (long long)gridDim.x * 256;
+    for (int q = 0; q < b.narr; ++q) {    // (bases come from the allocator: 16-byte aligned)
+        const long long n4 = b.count[q] >> 2;
+        const float4 *s4 = reinterpret_cast<const float4 *>(b.src[q]);
+        float4 *d4 = reinterpret_cast<float4 *>(b.dst[q]);
+        for (long long i = gtid; i < n4; i += nth) d4[i] = s4[i];
+        for (long long i = 4 * n4 + gtid; i < b.count[q]; i += nth) b.dst[q][i] = b.src[q][i];
+    }
+    for (long long i = gtid; i < b.ring_count; i += nth) b.ring[i] = 0.0;
+}
+
+struct BlockVerdict {
+    StreamCtl *ctl;
+    unsigned int base_seq, gate_seq;      // as above
+    unsigned int first_seq;               // slice g holds the sums judged for launch first_seq + g
+    int32_t nb, T;
+    TreeArgs tree;
+    const double *ring;
+    long long mt;                         // doubles per slice
+    double vlo, vhi, vtol;
+    unsigned long long *grp_bits;         // [nb] device words, zero on entry and on exit
+    double *rec;                          // the record ring (device address of pinned memory)
+};
+// Workgroup (g, t): slot t of slice g.  The last workgroup to finish writes the nb records
+// {rmax, failed, seq} and the lowest failed number into the control word.
+__global__ __launch_bounds__(256) void stream_block_verdict_kernel(const BlockVerdict b) {
+    extern __shared__ double tree_lds[];
+    {
+        const unsigned int bad = b.ctl->bad_seq;
+        if (bad >= b.base_seq && bad <= b.gate_seq) return;
+    }
+    const int tid = threadIdx.x;
+    const int g = (int)blockIdx.x / b.T, t = (int)blockIdx.x - g * b.T;
+    const double rmax = tree_rmax(b.tree, b.ring + (long long)g * b.mt, b.T, t, b.vlo, b.vhi, tree_lds, nullptr);
+    __shared__ int last_s;
+    __shared__ unsigned int bad_s;
+    if (tid == 0) {
+        __hip_atomic_fetch_max(&b.grp_bits[g], (unsigned long long)__double_as_longlong(rmax),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // performed before this workgroup is counted
+        const unsigned int old = __hip_atomic_fetch_add(&b.ctl->arrive, 1u, __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT);
+        last_s = old == (unsigned int)(b.nb * b.T) - 1u;
+        bad_s = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    if (!last_s) return;
+    for (int q = tid; q < b.nb; q += 256) {
+        const unsigned long long bits = __hip_atomic_load(&b.grp_bits[q], __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&b.grp_bits[q], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double r = __longlong_as_double((long long)bits);
+        const unsigned int seq = b.first_seq + (unsigned int)q;
+        const bool failed = !(r <= b.vtol);
+        if (failed) atomicMin(&bad_s, seq);
+        volatile double *rec = b.rec + 4 * (seq % kRecRing);
+        rec[0] = r;
+        rec[1] = failed ? 1.0 : 0.0;
+        __threadfence_system();
+        rec[2] = (double)seq;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (bad_s != 0xFFFFFFFFu)
+            __hip_atomic_store(&b.ctl->bad_seq, bad_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&b.ctl->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+int stream_block_begin(const StreamCtl *ctl, unsigned int base_seq, unsigned int gate_seq,
+                       const float *const *src, float *const *dst, const int64_t *count,
+                       int32_t narr, double *ring, int64_t ring_count, void *stream) {
+    REVS_REQUIRE(ctl && narr >= 0 && narr <= 5 && ring && ring_count >= 0,
+                 "stream_block_begin: bad argument");
+    BlockBegin b{ctl, base_seq, gate_seq, {}, {}, {}, narr, ring, (long long)ring_count};
+    long long work = (long long)ring_count;
+    for (int q = 0; q < narr; ++q) {
+        REVS_REQUIRE(src[q] && dst[q] && count[q] >= 0 && ((uintptr_t)src[q] & 15) == 0 &&
+                     ((uintptr_t)dst[q] & 15) == 0, "stream_block_begin: arrays must be 16-byte aligned");
+        b.src[q] = src[q];
+        b.dst[q] = dst[q];
+        b.count[q] = (long long)count[q];
+        work = std::max<long long>(work, (long long)count[q] / 4);
+    }
+    const int grid = (int)std::min<long long>(2048, std::max<long long>(1, (work + 255) / 256));
+    hipLaunchKernelGGL(stream_block_begin_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, b);
+    REVS_CHECK_LAUNCH("stream_block_begin");
+    return REVS_OK;
+}
+
+int stream_block_verdict(StreamCtl *ctl, unsigned int base_seq, unsigned int gate_seq,
+                         unsigned int first_seq, int32_t nb, int32_t T, const TreeArgs &tree,
+                         const double *ring, int64_t mt, double vlo, double vhi, double vtol,
+                         unsigned long long *grp_bits, double *rec, void *stream) {
+    REVS_REQUIRE(ctl && nb > 0 && nb < kRecRing && T > 0 && tree.n > 0 && tree.n <= REVS_TREE_MAX &&
+                 tree.n % 8 == 0 && tree.pack && tree.w && ring && mt > 0 && vlo <= vhi && vtol >= 0.0 &&
+                 grp_bits && rec, "stream_block_verdict: bad argument");
+    const BlockVerdict b{ctl, base_seq, gate_seq, first_seq, nb, T, tree, ring, (long long)mt,
+                         vlo, vhi, vtol, grp_bits, rec};
+    hipLaunchKernelGGL(stream_block_verdict_kernel, dim3((unsigned)(nb * T)), dim3(256),
+                       tree_lds_bytes(tree.n), (hipStream_t)stream, b);
+    REVS_CHECK_LAUNCH("stream_block_verdict");
+    return REVS_OK;
 }
 
 __global__ __launch_bounds__(256) void tree_voltage_kernel(TreeArgs tr, const double *p, int T,

@@ -9,6 +9,7 @@ namespace revs {
 struct StreamExtra {
     StreamCtl *ctl;          // control block (device); NULL: an ordinary launch
     unsigned int seq, base_seq;   // this launch; the first launch of the call it belongs to
+    bool verdict;            // false: silencing only (seq, base_seq, flags) -- verdicts by blocks
     TreeArgs tree;           // tree.n > 0: the first T workgroups judge the voltage rows
     const double *p_in;      // node sums they judge
     double *p_zero;          // array they clear for the launch after this one (or NULL)
@@ -25,5 +26,18 @@ int agent_step_stream(int64_t n_homes, int32_t T, const float *cost, const revs_
                       float *diff, float *dsq, int32_t *status, float *pdhg_dual, float kappa,
                       int32_t mode, const revs_pdhg_t *pdhg_host, const int32_t *node_of,
                       double *p_next, float *p_est_next, const StreamExtra &sx, void *stream);
+
+// Verdicts by blocks (agent_kernels.hip).  Both launches are no-ops when a launch numbered
+// base_seq..gate_seq has failed its verdict.  stream_block_begin copies `narr` arrays of
+// `count[q]` floats (the state a block of sweeps overwrites) and clears the ring;
+// stream_block_verdict judges `nb` slices of node sums (slice g: the sums launch first_seq + g
+// consumes), writes their records and the lowest failed number into the control word.
+int stream_block_begin(const StreamCtl *ctl, unsigned int base_seq, unsigned int gate_seq,
+                       const float *const *src, float *const *dst, const int64_t *count,
+                       int32_t narr, double *ring, int64_t ring_count, void *stream);
+int stream_block_verdict(StreamCtl *ctl, unsigned int base_seq, unsigned int gate_seq,
+                         unsigned int first_seq, int32_t nb, int32_t T, const TreeArgs &tree,
+                         const double *ring, int64_t mt, double vlo, double vhi, double vtol,
+                         unsigned long long *grp_bits, double *rec, void *stream);
 
 }  // namespace revs

@@ -51,6 +51,11 @@ struct revs_plan {
     unsigned int stream_seq = 0;           // sequence number of the last streaming launch
     revs::TreeArgs tree{};                 // tree.n == 0: no tree form
     revs_comm *comm = nullptr;
+    // verdicts by blocks (revs_plan_set_stream_block)
+    int32_t block = 0;                     // iterations judged together; <= 1: every launch judges itself
+    double *ring = nullptr;                // device: node sums of a block, double[block][m T]
+    float *ck[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // device: the state a block overwrites
+    unsigned long long *grp_bits = nullptr;                // device: per-slice maxima, zero between launches
 };
 
 // Host-side acceptance test of a chained Newton iteration (operator_newton.py: _chain_launch): the
@@ -147,6 +152,9 @@ extern "C" void revs_plan_destroy(revs_plan_t *plan) {
     if (plan->counters) (void)hipFree(plan->counters);
     if (plan->ctl) (void)hipFree(plan->ctl);
     if (plan->rec_host) (void)hipHostFree(plan->rec_host);
+    if (plan->ring) (void)hipFree(plan->ring);
+    if (plan->grp_bits) (void)hipFree(plan->grp_bits);
+    for (float *c : plan->ck) if (c) (void)hipFree(c);
     delete plan;
 }
 
@@ -527,6 +535,32 @@ extern "C" int revs_plan_set_comm(revs_plan_t *plan, revs_comm_t *comm) {
     return REVS_OK;
 }
 
+extern "C" int revs_plan_set_stream_block(revs_plan_t *plan, int32_t block) {
+    REVS_REQUIRE(plan && block >= 0 && block <= REVS_STREAM_BLOCK_MAX,
+                 "revs_plan_set_stream_block: block=%d outside 0..%d", block, REVS_STREAM_BLOCK_MAX);
+    if (block <= 1) { plan->block = 0; return REVS_OK; }
+    const revs_plan_desc_t &d = plan->d;
+    REVS_REQUIRE(d.n_homes > 0 && d.node_of, "revs_plan_set_stream_block: the plan has no residences / node_of");
+    if (block > plan->block || !plan->ring) {            // (grow only; the arrays are reused)
+        if (plan->ring) (void)hipFree(plan->ring);
+        if (plan->grp_bits) (void)hipFree(plan->grp_bits);
+        plan->ring = nullptr; plan->grp_bits = nullptr;
+        const size_t rb = sizeof(double) * (size_t)block * d.m * d.T, gb = sizeof(unsigned long long) * block;
+        hipError_t e = hipMalloc((void **)&plan->ring, rb);
+        if (e == hipSuccess) e = hipMalloc((void **)&plan->grp_bits, gb);
+        if (e == hipSuccess) e = hipMemset(plan->grp_bits, 0, gb);
+        for (int q = 0; q < 5 && e == hipSuccess; ++q)     // ([4]: the PDHG residences' carried multipliers)
+            if (!plan->ck[q]) e = hipMalloc((void **)&plan->ck[q], sizeof(float) * (size_t)d.n_homes * d.T);
+        if (e != hipSuccess) {
+            revs::set_error("revs_plan_set_stream_block: %s", hipGetErrorString(e));
+            plan->block = 0;
+            return REVS_ELAUNCH;
+        }
+    }
+    plan->block = block;
+    return REVS_OK;
+}
+
 extern "C" int32_t revs_plan_status_flags(revs_plan_t *plan, int32_t clear) {
     if (!plan || !plan->flags_host) return 0;
     const unsigned int f = *(volatile unsigned int *)plan->flags_host;
@@ -539,7 +573,14 @@ static int stream_wait(revs_plan_t *plan, unsigned int seq, hipStream_t s, doubl
     const volatile double *r = plan->rec_host + 4 * (seq % revs::kRecRing);
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
+    static const bool trace = getenv("REVS_PLAN_TRACE") != nullptr;
+    auto prev = t0;
     while (r[2] != (double)seq) {
+        if (trace) {        // the longest the host itself was away from this loop
+            const auto now = std::chrono::steady_clock::now();
+            plan->t_wait = std::max(plan->t_wait, std::chrono::duration<double, std::micro>(now - prev).count());
+            prev = now;
+        }
         // (no HIP call in this loop: a hipStreamQuery here was measured to stop the host for
         // milliseconds now and then -- the runtime retires its finished commands inside it --
         // while the queue behind the awaited launch ran dry)
@@ -559,6 +600,136 @@ static int stream_wait(revs_plan_t *plan, unsigned int seq, hipStream_t s, doubl
     std::atomic_thread_fence(std::memory_order_acquire);
     *rmax = r[0];
     return r[1] != 0.0 ? 1 : 0;
+}
+
+static void stream_rotate(revs_stream_state_t *st, int kept) {
+    if (kept <= 0) return;
+    revs_stream_state_t r = *st;
+    for (int i = 0; i < 3; ++i) { r.p_est[i] = st->p_est[(kept + i) % 3]; r.p[i] = st->p[(kept + i) % 3]; }
+    for (int i = 0; i < 2; ++i) { r.p_sch[i] = st->p_sch[(kept + i) % 2]; r.gamma[i] = st->gamma[(kept + i) % 2]; }
+    *st = r;
+}
+
+// revs_plan_stream_run with the verdicts taken by blocks (plan->block = B > 1; see the comment in
+// agent_kernels.hip).  Launch k of the call has number seq0 + k and consumes the node sums
+// "of iteration k".  Enqueued in one burst:
+//   verdict of iteration 0 (the caller's st->p[0]);
+//   per block [k0, k0 + nb):  save the state iteration k0 starts from and clear the ring |
+//       nb sweeps, sweep k accumulating the sums of iteration k + 1 into ring slice k - k0 |
+//       ONE all-reduce of the nb slices (sharded) | verdicts of iterations k0+1 .. k0+nb
+//       (the last block: .. max_steps - 1, its last slice is the next call's st->p[0]);
+// every launch is a no-op once an iteration at or before its own has failed.  Then the records are
+// read in order.  A failed iteration j inside a block means sweeps j .. k0+nb-1 ran on an estimate
+// that was not the operator's answer: the saved state is put back and sweeps k0 .. j-1 (all judged
+// good) are run again, then sweep j itself (to the spares): bit for bit the memory that the loop
+// judging every launch leaves behind a failed verdict (the PDHG residences' carried multipliers
+// are part of the saved state).
+static int stream_run_blocks(revs_plan_t *plan, int32_t max_steps, revs_stream_state_t *st, double scale,
+                             double eps, int32_t *kept_steps, double *rmax_last, unsigned int seq0,
+                             hipStream_t s) {
+    const revs_plan_desc_t &d = plan->d;
+    const int64_t mt = (int64_t)d.m * d.T, nt = d.n_homes * (int64_t)d.T;
+    const int B = plan->block;
+    const double vtol = eps * scale;
+    auto sweep = [&](int k, int k0, bool replay) -> int {
+        revs::StreamExtra sx{};
+        sx.ctl = plan->ctl;
+        sx.seq = seq0 + (unsigned int)k + 1u;            // (the kernel skips when bad < seq: at or before k)
+        sx.base_seq = replay ? sx.seq : seq0;            // (a replayed sweep is never skipped)
+        sx.verdict = false;
+        sx.flags = plan->flags_dev;
+        return revs::agent_step_stream(
+            d.n_homes, d.T, d.cost, d.homes, d.load, st->p_est[k % 3],
+            d.recompute_pe_new ? nullptr : st->p_est[(k + 1) % 3], st->p_sch[k % 2], st->gamma[k % 2],
+            st->p_sch[(k + 1) % 2], st->gamma[(k + 1) % 2], d.diff, d.dsq, d.status, d.pdhg_dual,
+            (float)d.kappa, d.mode, &d.pdhg, d.node_of, plan->ring + (int64_t)(k - k0) * mt,
+            st->p_est[(k + 2) % 3], sx, s);
+    };
+    // the state iteration k0 starts from: P_est[k0], P_est[k0+1] (read by sweep k0+1, written
+    // before the block), P_sch[k0], Gamma[k0], and the PDHG residences' carried multipliers
+    const bool warm = d.mode == REVS_MODE_RELAXED_PDHG && d.pdhg_dual != nullptr;
+    const int narr = warm ? 5 : 4;
+    const int64_t cnt[5] = {nt, nt, nt, nt, d.pdhg.full_rows ? nt : d.n_homes};
+    auto state_of = [&](int k0, float **a) {
+        a[0] = st->p_est[k0 % 3]; a[1] = st->p_est[(k0 + 1) % 3];
+        a[2] = st->p_sch[k0 % 2]; a[3] = st->gamma[k0 % 2];
+        a[4] = d.pdhg_dual;
+    };
+    int rc = REVS_OK, launched = 0, checked = 0, failed_at = -1, last_nb = 0;
+    double rm = 0.0;
+    static const bool trace = getenv("REVS_PLAN_TRACE") != nullptr;
+    const auto tr0 = std::chrono::steady_clock::now();
+    rc = revs::stream_block_verdict(plan->ctl, seq0, seq0 - 1u, seq0, 1, d.T, plan->tree, st->p[0], mt,
+                                    d.vlo, d.vhi, vtol, plan->grp_bits, plan->rec_dev, s);
+    for (int k0 = 0; k0 < max_steps && rc == REVS_OK; k0 += B) {
+        const int nb = std::min(B, max_steps - k0);
+        float *cur[5];
+        state_of(k0, cur);
+        rc = revs::stream_block_begin(plan->ctl, seq0, seq0 + (unsigned int)k0, cur, plan->ck, cnt, narr,
+                                      plan->ring, (int64_t)nb * mt, s);
+        for (int k = k0; k < k0 + nb && rc == REVS_OK; ++k, ++launched) rc = sweep(k, k0, false);
+        if (rc == REVS_OK && plan->comm)
+            rc = revs_comm_allreduce_f64(plan->comm, plan->ring, (int64_t)nb * mt, 0, s);
+        const int judged = k0 + nb < max_steps ? nb : nb - 1;
+        if (rc == REVS_OK && judged > 0)
+            rc = revs::stream_block_verdict(plan->ctl, seq0, seq0 + (unsigned int)k0,
+                                            seq0 + (unsigned int)k0 + 1u, judged, d.T, plan->tree,
+                                            plan->ring, mt, d.vlo, d.vhi, vtol, plan->grp_bits,
+                                            plan->rec_dev, s);
+        last_nb = nb;
+    }
+    // the sums of iteration max_steps (summed over the ranks, not judged yet) are the caller's
+    // st->p[0] after the rotation below
+    if (rc == REVS_OK && launched == max_steps &&
+        hipMemcpyAsync(st->p[max_steps % 3], plan->ring + (int64_t)(last_nb - 1) * mt,
+                       sizeof(double) * mt, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        revs::set_error("revs_plan_stream_run: copying the last node sums failed");
+        rc = REVS_ELAUNCH;
+    }
+    const auto tr1 = std::chrono::steady_clock::now();
+    for (; rc == REVS_OK && checked < launched && failed_at < 0; ++checked) {
+        const int v = stream_wait(plan, seq0 + (unsigned int)checked, s, &rm);
+        if (v < 0) rc = v;
+        else if (v == 1) failed_at = checked;
+    }
+    if (trace) {
+        fprintf(stderr, "[revs_plan_stream_run] blocks of %d: %d launches in %.1f us, records read %.1f us "
+                "later (host away from the wait loop for at most %.1f us), failed at %d\n", B, launched,
+                std::chrono::duration<double, std::micro>(tr1 - tr0).count(),
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr1).count(),
+                plan->t_wait, failed_at);
+        plan->t_wait = 0.0;
+    }
+    plan->stream_seq = seq0 + (unsigned int)std::max(launched, 1);
+    *rmax_last = rm;
+    if (failed_at >= 0 || rc != REVS_OK) (void)hipStreamSynchronize(s);
+    int kept = rc != REVS_OK ? 0 : (failed_at >= 0 ? failed_at : launched);
+    if (rc == REVS_OK && failed_at >= 0) {
+        int from = failed_at, k0 = failed_at;
+        if (failed_at > 0 && failed_at < std::min(((failed_at - 1) / B) * B + B, max_steps)) {
+            // inside the block whose verdicts covered it: sweeps failed_at .. ran -- roll back
+            from = k0 = ((failed_at - 1) / B) * B;
+            float *cur[5];
+            state_of(k0, cur);
+            for (int q = 0; q < narr && rc == REVS_OK; ++q)
+                if (hipMemcpyAsync(cur[q], plan->ck[q], sizeof(float) * cnt[q], hipMemcpyDeviceToDevice, s) != hipSuccess) {
+                    revs::set_error("revs_plan_stream_run: restoring the saved state failed");
+                    rc = REVS_ELAUNCH;
+                }
+        }
+        // the good sweeps of the block again, and the failed iteration's own sweep, which writes
+        // to the spares only (at a block boundary it was silenced: only that one): the memory is
+        // then what a loop that judges every launch leaves behind a failed verdict
+        for (int k = from; k <= failed_at && rc == REVS_OK; ++k) rc = sweep(k, k0, true);
+        if (rc != REVS_OK || hipStreamSynchronize(s) != hipSuccess) {
+            if (rc == REVS_OK) revs::set_error("revs_plan_stream_run: replaying the block failed");
+            rc = REVS_ELAUNCH;
+            kept = 0;
+        }
+    }
+    *kept_steps = kept;
+    stream_rotate(st, kept);
+    return rc;
 }
 
 extern "C" int revs_plan_stream_run(revs_plan_t *plan, int32_t max_steps, revs_stream_state_t *st,
@@ -593,11 +764,14 @@ extern "C" int revs_plan_stream_run(revs_plan_t *plan, int32_t max_steps, revs_s
     }
     const unsigned int seq0 = plan->stream_seq + 1;
     const int64_t mt = (int64_t)d.m * d.T;
+    if (plan->block > 1)
+        return stream_run_blocks(plan, max_steps, st, scale, eps, kept_steps, rmax_last, seq0, s);
     auto launch = [&](int k) -> int {               // step k of this call (roles by rotation)
         revs::StreamExtra sx;
         sx.ctl = plan->ctl;
         sx.seq = seq0 + (unsigned int)k;
         sx.base_seq = seq0;
+        sx.verdict = true;
         sx.tree = plan->tree;
         sx.p_in = st->p[k % 3];
         sx.p_zero = st->p[(k + 2) % 3];
@@ -624,12 +798,31 @@ extern "C" int revs_plan_stream_run(revs_plan_t *plan, int32_t max_steps, revs_s
     // launches it is willing to waste behind a failure (AdmmEngine._stream_run).
     int launched = 0, checked = 0, failed_at = -1, rc = REVS_OK;
     double rm = 0.0;
-    for (; launched < max_steps; ++launched)
+    static const bool trace = getenv("REVS_PLAN_TRACE") != nullptr;
+    const auto tr0 = std::chrono::steady_clock::now();
+    auto tr1 = tr0;
+    double slowest = 0.0;
+    for (; launched < max_steps; ++launched) {
+        const auto a = trace ? std::chrono::steady_clock::now() : tr0;
         if ((rc = launch(launched)) != REVS_OK) goto out;
+        if (trace)
+            slowest = std::max(slowest, std::chrono::duration<double, std::micro>(
+                                            std::chrono::steady_clock::now() - a).count());
+    }
+    tr1 = std::chrono::steady_clock::now();
     for (; checked < launched && failed_at < 0; ++checked) {
         const int v = stream_wait(plan, seq0 + (unsigned int)checked, s, &rm);
         if (v < 0) { rc = v; goto out; }
         if (v == 1) failed_at = checked;
+    }
+    if (trace) {
+        const auto tr2 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[revs_plan_stream_run] %d launches in %.1f us (slowest %.1f us), records read "
+                "%.1f us later (host away from the wait loop for at most %.1f us), %d kept\n", launched,
+                std::chrono::duration<double, std::micro>(tr1 - tr0).count(), slowest,
+                std::chrono::duration<double, std::micro>(tr2 - tr1).count(), plan->t_wait,
+                failed_at >= 0 ? failed_at : launched);
+        plan->t_wait = 0.0;
     }
 out:
     plan->stream_seq = seq0 + (unsigned int)std::max(launched, 1) - 1;
@@ -638,12 +831,6 @@ out:
     if (failed_at >= 0 || rc != REVS_OK)
         (void)hipStreamSynchronize(s);                   // the launches behind the failed one are no-ops
     *kept_steps = kept;
-    // rotate the roles by the kept steps
-    if (kept > 0) {
-        revs_stream_state_t r = *st;
-        for (int i = 0; i < 3; ++i) { r.p_est[i] = st->p_est[(kept + i) % 3]; r.p[i] = st->p[(kept + i) % 3]; }
-        for (int i = 0; i < 2; ++i) { r.p_sch[i] = st->p_sch[(kept + i) % 2]; r.gamma[i] = st->gamma[(kept + i) % 2]; }
-        *st = r;
-    }
+    stream_rotate(st, kept);              // the roles, by the kept steps
     return rc;
 }

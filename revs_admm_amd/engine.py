@@ -115,6 +115,12 @@ class OperatorOptions:
     # ~3 us each, so a regime that fails often keeps its bursts short
     stream_burst: int = 8
     stream_burst_max: int = 512
+    # Residences sharded: the verdicts of this many consecutive iterations are taken together,
+    # after ONE all-reduce of their node sums (revs_plan_set_stream_block) -- a collective per
+    # sweep would make the collective's latency the step.  1: every iteration, as on one GPU.
+    # stream_block_single: use blocks on one GPU too (how the tests drive the roll-back).
+    stream_block: int = 32
+    stream_block_single: bool = False
 
 
 def _dev_check(device):
@@ -396,6 +402,13 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
                 raise _lib.RevsError("revs_comm_create failed: " + self.lib.revs_last_error().decode())
             if self._plan is not None:
                 check(self.lib.revs_plan_set_comm(self._plan, self._comm), "revs_plan_set_comm")
+        self._block = 0
+        self.stream_calls = []          # (launches enqueued, iterations kept) of every native burst
+        if (self._plan is not None and self._tree is not None and self.op.stream_block > 1
+                and (self._comm is not None or self.op.stream_block_single)):
+            self._block = min(int(self.op.stream_block), _lib.STREAM_BLOCK_MAX)
+            check(self.lib.revs_plan_set_stream_block(self._plan, self._block),
+                  "revs_plan_set_stream_block")
         # R (float) for the voltage check
         self.R32 = up(Rn.astype(np.float32))
         self.node_load = torch.zeros(M, T, **f32)

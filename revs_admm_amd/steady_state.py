@@ -49,7 +49,10 @@ class SteadyStateMixin:
         rest = [b for b in (self.pnq[0], self.p_alt, self.p_alt2) if b.data_ptr() != p0.data_ptr()]
         # p[1] must be zero on entry.  The last launch of a fully kept call has just cleared the
         # array that is p[1] now (roles rotate): no fill launch then
-        if self._p_clear is not None and self._p_clear.data_ptr() != p0.data_ptr():
+        # (verdicts by blocks: the sweeps accumulate into the plan's ring, p[1] and p[2] are not used)
+        if self._block:
+            pass
+        elif self._p_clear is not None and self._p_clear.data_ptr() != p0.data_ptr():
             rest = [self._p_clear] + [b for b in rest if b.data_ptr() != self._p_clear.data_ptr()]
         else:
             rest[0].zero_()
@@ -69,13 +72,14 @@ class SteadyStateMixin:
                                             C.addressof(kept), C.addressof(rm), self.stream),
               "revs_plan_stream_run")
         n = kept.value
+        self.stream_calls.append((count, n))
         self._burst = min(4 * self._burst, o.stream_burst_max) if n == count else o.stream_burst
         by = {t.data_ptr(): t for t in pes + pss + gs + ps}
         self.P_est, self.P_est_new, self.P_est_alt = (by[st.p_est[i]] for i in range(3))
         self.P_sch, self.P_sch_alt = by[st.p_sch[0]], by[st.p_sch[1]]
         self.G, self.G_alt = by[st.gamma[0]], by[st.gamma[1]]
         self._fused_p = by[st.p[0]]
-        self._p_clear = by[st.p[1]] if n == count else None
+        self._p_clear = by[st.p[1]] if (n == count and not self._block) else None
         self._prod_ahead = False
         self._ar_ahead = self.group is not None
         if n:

@@ -222,6 +222,14 @@ def test_process_group_path_on_one_gpu(gpu_lib):
         for name in ("P_est", "P_sch", "G", "diff"):
             assert torch.equal(getattr(a, name), getattr(b, name)), name
         assert b.residuals(1e-4)[:3] == pytest.approx(a.residuals(1e-4)[:3], rel=1e-6)
+        # (sharded, the verdicts are taken by blocks: one all-reduce per block of sweeps)
+        assert b._block == 32 and a._block == 0 and a.stream_calls == b.stream_calls
+        c = _engine(w2, "pdhg", group=dist.group.WORLD, op=OperatorOptions(stream_block=1))
+        for chunk in (3, 40, 37):
+            c.run_steps(chunk)
+        assert c._block == 0 and c.stream_calls == a.stream_calls    # one all-reduce per sweep
+        for name in ("P_est", "P_sch", "G", "diff"):
+            assert torch.equal(getattr(a, name), getattr(c, name)), name
     finally:
         dist.destroy_process_group()
 
@@ -634,6 +642,56 @@ def test_streaming_steady_state_equals_dense_product_path(gpu_lib, mode, stress,
     assert a.op_iters_hist == b.op_iters_hist
     for name in ("P_est", "P_sch", "G", "diff"):
         assert torch_equal(getattr(a, name), getattr(b, name)), name
+    a.step(write_sc=True); b.step(write_sc=True)
+    for x, y in zip(a.result(), b.result()):
+        np.testing.assert_array_equal(x, y)
+
+
+_RAGGED = (1, 7, 30, 2, 50, 64, 11)
+
+
+@pytest.mark.parametrize("mode,n,nodes,seed,stress,T,block,chunks", [
+    ("pdhg", 20000, 512, 0, 1.0, 24, 32, (40, 400, 400)),          # rows start to bind ~190 sweeps into a burst
+    ("pdhg", 20000, 512, 0, 1.0, 24, 7, (40, 400, 400)),
+    ("relaxed_exact", 20000, 512, 0, 1.01, 24, 5, (40, 400, 400)),
+    ("pdhg", 8000, 200, 0, 1.1, 24, 16, (40, 400, 400)),
+    ("pdhg", 8000, 200, 3, 1.02, 24, 5, _RAGGED),                   # a failed verdict at the head of a call
+    ("binary", 8000, 200, 3, 0.5, 24, 7, _RAGGED),
+    ("pdhg", 3000, 200, 3, 1.02, 96, 4, _RAGGED)])
+def test_block_verdicts_equal_per_launch_verdicts(gpu_lib, mode, n, nodes, seed, stress, T, block, chunks):
+    """The sharded form of the streaming loop -- `block` sweeps run unjudged, their node sums go to
+    a ring, one launch judges the whole block, and a failed iteration inside a block is undone
+    from the state the block saved (revs_plan_set_stream_block) -- against the loop where every
+    launch judges itself: same kept / discarded iterations, same memory bit for bit (profiles,
+    carried PDHG multipliers, node sums handed to the next call), through failures at the head
+    of a call and deep inside a burst (sweeps behind the failed one had run and are undone)."""
+    from helpers import f32
+    from revs_admm_amd.engine import OperatorOptions
+    from revs_admm_amd.synthetic import make_workload
+    w = make_workload(n, T, n_nodes=nodes, seed=seed, binary_feasible=(mode == "binary"), stress=stress)
+    small = chunks is _RAGGED
+    if small:
+        w.load, w.cost = f32(w.load), f32(w.cost)
+    kw = dict(stream_burst=16, stream_burst_max=64) if small else {}
+    a = _engine(w, mode, op=OperatorOptions(**kw))
+    b = _engine(w, mode, op=OperatorOptions(stream_block=block, stream_block_single=True, **kw))
+    assert a._block == 0 and b._block == block
+    for chunk in chunks:
+        a.run_steps(chunk)
+        b.run_steps(chunk)
+        assert a.iteration == b.iteration
+        assert a.stream_calls == b.stream_calls
+        for name in ("P_est", "P_sch", "G", "diff") + (("pdhg_dual",) if mode == "pdhg" else ()):
+            assert torch_equal(getattr(a, name), getattr(b, name)), (name, a.iteration)
+        if a._fused_ready:
+            assert b._fused_ready and torch_equal(a._fused_p, b._fused_p)
+    assert a.spec_hist == b.spec_hist and a.chain_hist == b.chain_hist and a.spec_hist[0] > 60
+    assert a.op_iters_hist == b.op_iters_hist and a.newton_hist == b.newton_hist
+    failed = [(c, k) for c, k in b.stream_calls if k < c]
+    if mode != "binary":
+        assert failed, b.stream_calls
+    if not small:       # ... inside a block: the sweeps behind the failed one had run
+        assert any(k > block and k % block != 0 for c, k in failed), failed
     a.step(write_sc=True); b.step(write_sc=True)
     for x, y in zip(a.result(), b.result()):
         np.testing.assert_array_equal(x, y)

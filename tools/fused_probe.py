@@ -47,9 +47,9 @@ def sel():
                                   ptr(part), ptr(cidx), ptr(ccnt), ptr(cval), ptr(st), 1.0, None))
 
 
-def model():
+def model(max_pivots=300):
     check(lib.revs_op_dual_model_small(M, T, ptr(R), ptr(nfree), ptr(cidx), ptr(ccnt), ptr(cval), 5.0,
-                                       1e-10, 300, ptr(kfull), ptr(yhat), ptr(info), None))
+                                       1e-10, max_pivots, ptr(kfull), ptr(yhat), ptr(info), None))
 
 
 def step():
@@ -81,6 +81,7 @@ torch.cuda.synchronize()
 print("candidates per slot", ccnt.cpu().numpy().tolist())
 timed("rows + selection (two kernels)", sel)
 timed("small model", model)
+timed("small model, one pivoting round", lambda: model(1))
 timed("step (with the copy)", step)
 timed("selection + model + step, one launch", fused)
 print("pivots", info.cpu().numpy().tolist())
