@@ -11,7 +11,8 @@ residences: the operator's answer and its voltage rows, every home QP (batched P
 the dual update and the per-home residual terms.  Weak scaling: every GPU owns `--homes`
 residences (default 100 000 x T = 24, the size BASELINE.json's metric is quoted on); the
 feeder's 2048 constraint nodes are replicated and the only collective is the all-reduce of
-the M x T node sums, once per iteration.
+the M x T node sums -- in the steady state the sums of 32 iterations in one collective on a second
+stream, beside the next 32 sweeps (verdicts by blocks).
 
 The timed steps start `--spinup` (30) iterations into the run: the first ~10 iterations are a
 transient in which voltage rows bind hard and residences are clamped (operator QP: a few
@@ -376,7 +377,10 @@ def main():
                 "homes_per_gpu": args.homes, "homes_total": n_total, "T": args.T,
                 "nodes": args.nodes, "home_solver": args.mode, "kappa": w.kappa,
                 "operator_dtype": "f64", "parallelism": f"homes sharded x{world}, nodes replicated, "
-                                                        "one all-reduce of the node sums per iteration",
+                                                        "node sums all-reduced"
+                + (f", {eng._block} iterations per collective"
+                   + (" on a second stream" if eng.op.stream_overlap else "") if eng._block else
+                   ", one collective per iteration"),
                 "voltage_rows": ("tree form of R p inside the sweep's launch" if streamed else
                                  "dense f64 product R p on the matrix cores"),
                 "launches_per_step": 1 if streamed else 2,

@@ -730,9 +730,16 @@ int revs_plan_stream_run(revs_plan_t *plan, int32_t max_steps, revs_stream_state
  * before it returns -- memory is then bit for bit what the single-GPU form leaves.
  * The contract of revs_plan_stream_run is unchanged (st->p[1], p[2] are not used; st->p[0] holds
  * the all-reduced sums of the next iteration at return).  block <= 1: every launch judges itself
- * (the single-GPU form).  Memory: B M T doubles + 5 n T floats.  Set it on every rank alike. */
+ * (the single-GPU form).
+ * overlap != 0: the all-reduce and the verdicts of block b run on a second stream owned by the
+ * plan while the caller's stream already runs the sweeps of block b + 1 (two ring halves, two
+ * generations of saved state; block b + 2 waits for block b's verdicts) -- the collective then
+ * costs the step nothing as long as it is shorter than a block of sweeps.  A failure rolls back to
+ * the start of the block that judged it.  The caller's stream waits for the second stream before
+ * the call returns, so synchronising the caller's stream is still enough.
+ * Memory: 2 B M T doubles + 10 n T floats.  Set both on every rank alike. */
 #define REVS_STREAM_BLOCK_MAX 256
-int revs_plan_set_stream_block(revs_plan_t *plan, int32_t block);
+int revs_plan_set_stream_block(revs_plan_t *plan, int32_t block, int32_t overlap);
 /* Bits OR-ed by the sweeps launched through the plan since the last clear: 1 = a residence's
  * window cannot reach 90 % SOC (the reference prints "No solution found", lpsolver.py:153-155),
  * 2 = a PDHG residence hit max_iter before its tolerance.  Meaningful after the stream has

@@ -7,6 +7,7 @@
 #include <atomic>
 #include <cmath>
 #include <chrono>
+#include <vector>
 #include <cstring>
 
 namespace revs {
@@ -53,9 +54,12 @@ struct revs_plan {
     revs_comm *comm = nullptr;
     // verdicts by blocks (revs_plan_set_stream_block)
     int32_t block = 0;                     // iterations judged together; <= 1: every launch judges itself
-    double *ring = nullptr;                // device: node sums of a block, double[block][m T]
-    float *ck[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};   // device: the state a block overwrites
+    int32_t overlap = 0;                   // all-reduce + verdicts of a block on `side`, beside the next block's sweeps
+    double *ring = nullptr;                // device: node sums of two blocks, double[2][block][m T]
+    float *ck[2][5] = {};                  // device: the state a block overwrites (two generations)
     unsigned long long *grp_bits = nullptr;                // device: per-slice maxima, zero between launches
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> events;        // pool: sweeps-done / verdicts-done per block, end of call
 };
 
 // Host-side acceptance test of a chained Newton iteration (operator_newton.py: _chain_launch): the
@@ -154,7 +158,9 @@ extern "C" void revs_plan_destroy(revs_plan_t *plan) {
     if (plan->rec_host) (void)hipHostFree(plan->rec_host);
     if (plan->ring) (void)hipFree(plan->ring);
     if (plan->grp_bits) (void)hipFree(plan->grp_bits);
-    for (float *c : plan->ck) if (c) (void)hipFree(c);
+    for (auto &gen : plan->ck) for (float *c : gen) if (c) (void)hipFree(c);
+    for (hipEvent_t e : plan->events) (void)hipEventDestroy(e);
+    if (plan->side) (void)hipStreamDestroy(plan->side);
     delete plan;
 }
 
@@ -535,7 +541,7 @@ extern "C" int revs_plan_set_comm(revs_plan_t *plan, revs_comm_t *comm) {
     return REVS_OK;
 }
 
-extern "C" int revs_plan_set_stream_block(revs_plan_t *plan, int32_t block) {
+extern "C" int revs_plan_set_stream_block(revs_plan_t *plan, int32_t block, int32_t overlap) {
     REVS_REQUIRE(plan && block >= 0 && block <= REVS_STREAM_BLOCK_MAX,
                  "revs_plan_set_stream_block: block=%d outside 0..%d", block, REVS_STREAM_BLOCK_MAX);
     if (block <= 1) { plan->block = 0; return REVS_OK; }
@@ -545,12 +551,15 @@ extern "C" int revs_plan_set_stream_block(revs_plan_t *plan, int32_t block) {
         if (plan->ring) (void)hipFree(plan->ring);
         if (plan->grp_bits) (void)hipFree(plan->grp_bits);
         plan->ring = nullptr; plan->grp_bits = nullptr;
-        const size_t rb = sizeof(double) * (size_t)block * d.m * d.T, gb = sizeof(unsigned long long) * block;
+        const size_t rb = sizeof(double) * 2 * (size_t)block * d.m * d.T, gb = sizeof(unsigned long long) * block;
         hipError_t e = hipMalloc((void **)&plan->ring, rb);
         if (e == hipSuccess) e = hipMalloc((void **)&plan->grp_bits, gb);
         if (e == hipSuccess) e = hipMemset(plan->grp_bits, 0, gb);
-        for (int q = 0; q < 5 && e == hipSuccess; ++q)     // ([4]: the PDHG residences' carried multipliers)
-            if (!plan->ck[q]) e = hipMalloc((void **)&plan->ck[q], sizeof(float) * (size_t)d.n_homes * d.T);
+        for (int g = 0; g < 2 && e == hipSuccess; ++g)
+            for (int q = 0; q < 5 && e == hipSuccess; ++q)   // ([4]: the PDHG residences' carried multipliers)
+                if (!plan->ck[g][q])
+                    e = hipMalloc((void **)&plan->ck[g][q], sizeof(float) * (size_t)d.n_homes * d.T);
+        if (e == hipSuccess && !plan->side) e = hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking);
         if (e != hipSuccess) {
             revs::set_error("revs_plan_set_stream_block: %s", hipGetErrorString(e));
             plan->block = 0;
@@ -558,6 +567,7 @@ extern "C" int revs_plan_set_stream_block(revs_plan_t *plan, int32_t block) {
         }
     }
     plan->block = block;
+    plan->overlap = overlap != 0;
     return REVS_OK;
 }
 
@@ -630,8 +640,10 @@ static int stream_run_blocks(revs_plan_t *plan, int32_t max_steps, revs_stream_s
     const revs_plan_desc_t &d = plan->d;
     const int64_t mt = (int64_t)d.m * d.T, nt = d.n_homes * (int64_t)d.T;
     const int B = plan->block;
+    const bool ov = plan->overlap != 0;
     const double vtol = eps * scale;
-    auto sweep = [&](int k, int k0, bool replay) -> int {
+    auto ring_of = [&](int b) { return plan->ring + (ov ? (int64_t)(b & 1) * B * mt : 0); };
+    auto sweep = [&](int k, int k0, double *ring, bool replay) -> int {
         revs::StreamExtra sx{};
         sx.ctl = plan->ctl;
         sx.seq = seq0 + (unsigned int)k + 1u;            // (the kernel skips when bad < seq: at or before k)
@@ -642,7 +654,7 @@ static int stream_run_blocks(revs_plan_t *plan, int32_t max_steps, revs_stream_s
             d.n_homes, d.T, d.cost, d.homes, d.load, st->p_est[k % 3],
             d.recompute_pe_new ? nullptr : st->p_est[(k + 1) % 3], st->p_sch[k % 2], st->gamma[k % 2],
             st->p_sch[(k + 1) % 2], st->gamma[(k + 1) % 2], d.diff, d.dsq, d.status, d.pdhg_dual,
-            (float)d.kappa, d.mode, &d.pdhg, d.node_of, plan->ring + (int64_t)(k - k0) * mt,
+            (float)d.kappa, d.mode, &d.pdhg, d.node_of, ring + (int64_t)(k - k0) * mt,
             st->p_est[(k + 2) % 3], sx, s);
     };
     // the state iteration k0 starts from: P_est[k0], P_est[k0+1] (read by sweep k0+1, written
@@ -655,36 +667,63 @@ static int stream_run_blocks(revs_plan_t *plan, int32_t max_steps, revs_stream_s
         a[2] = st->p_sch[k0 % 2]; a[3] = st->gamma[k0 % 2];
         a[4] = d.pdhg_dual;
     };
+    const int nblocks = (max_steps + B - 1) / B;
+    // events of the overlapped form: [2 b] = block b's sweeps are done, [2 b + 1] = its verdicts are
+    // in, [2 nblocks] = the side stream has finished this call
+    if (ov)
+        while ((int)plan->events.size() < 2 * nblocks + 1) {
+            hipEvent_t e;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+                revs::set_error("revs_plan_stream_run: hipEventCreate failed");
+                return REVS_ELAUNCH;
+            }
+            plan->events.push_back(e);
+        }
+    auto hip_ok = [&](hipError_t e, const char *what) -> int {
+        if (e == hipSuccess) return REVS_OK;
+        revs::set_error("revs_plan_stream_run: %s: %s", what, hipGetErrorString(e));
+        return REVS_ELAUNCH;
+    };
     int rc = REVS_OK, launched = 0, checked = 0, failed_at = -1, last_nb = 0;
     double rm = 0.0;
     static const bool trace = getenv("REVS_PLAN_TRACE") != nullptr;
     const auto tr0 = std::chrono::steady_clock::now();
     rc = revs::stream_block_verdict(plan->ctl, seq0, seq0 - 1u, seq0, 1, d.T, plan->tree, st->p[0], mt,
                                     d.vlo, d.vhi, vtol, plan->grp_bits, plan->rec_dev, s);
-    for (int k0 = 0; k0 < max_steps && rc == REVS_OK; k0 += B) {
+    hipStream_t q = ov ? plan->side : s;                 // where the collective and the verdicts go
+    for (int b = 0, k0 = 0; k0 < max_steps && rc == REVS_OK; ++b, k0 += B) {
         const int nb = std::min(B, max_steps - k0);
+        double *ring = ring_of(b);
+        // (overlapped: this block reuses the ring half and the saved-state generation of block
+        // b - 2, whose verdicts must be in -- they also decide whether this block is a no-op)
+        if (ov && b >= 2) rc = hip_ok(hipStreamWaitEvent(s, plan->events[2 * (b - 2) + 1], 0), "hipStreamWaitEvent");
         float *cur[5];
         state_of(k0, cur);
-        rc = revs::stream_block_begin(plan->ctl, seq0, seq0 + (unsigned int)k0, cur, plan->ck, cnt, narr,
-                                      plan->ring, (int64_t)nb * mt, s);
-        for (int k = k0; k < k0 + nb && rc == REVS_OK; ++k, ++launched) rc = sweep(k, k0, false);
+        if (rc == REVS_OK)
+            rc = revs::stream_block_begin(plan->ctl, seq0, seq0 + (unsigned int)k0, cur, plan->ck[ov ? b & 1 : 0],
+                                          cnt, narr, ring, (int64_t)nb * mt, s);
+        for (int k = k0; k < k0 + nb && rc == REVS_OK; ++k, ++launched) rc = sweep(k, k0, ring, false);
+        if (ov && rc == REVS_OK) rc = hip_ok(hipEventRecord(plan->events[2 * b], s), "hipEventRecord");
+        if (ov && rc == REVS_OK) rc = hip_ok(hipStreamWaitEvent(q, plan->events[2 * b], 0), "hipStreamWaitEvent");
         if (rc == REVS_OK && plan->comm)
-            rc = revs_comm_allreduce_f64(plan->comm, plan->ring, (int64_t)nb * mt, 0, s);
+            rc = revs_comm_allreduce_f64(plan->comm, ring, (int64_t)nb * mt, 0, q);
         const int judged = k0 + nb < max_steps ? nb : nb - 1;
         if (rc == REVS_OK && judged > 0)
             rc = revs::stream_block_verdict(plan->ctl, seq0, seq0 + (unsigned int)k0,
                                             seq0 + (unsigned int)k0 + 1u, judged, d.T, plan->tree,
-                                            plan->ring, mt, d.vlo, d.vhi, vtol, plan->grp_bits,
-                                            plan->rec_dev, s);
+                                            ring, mt, d.vlo, d.vhi, vtol, plan->grp_bits, plan->rec_dev, q);
+        if (ov && rc == REVS_OK) rc = hip_ok(hipEventRecord(plan->events[2 * b + 1], q), "hipEventRecord");
         last_nb = nb;
     }
     // the sums of iteration max_steps (summed over the ranks, not judged yet) are the caller's
     // st->p[0] after the rotation below
-    if (rc == REVS_OK && launched == max_steps &&
-        hipMemcpyAsync(st->p[max_steps % 3], plan->ring + (int64_t)(last_nb - 1) * mt,
-                       sizeof(double) * mt, hipMemcpyDeviceToDevice, s) != hipSuccess) {
-        revs::set_error("revs_plan_stream_run: copying the last node sums failed");
-        rc = REVS_ELAUNCH;
+    if (rc == REVS_OK && launched == max_steps)
+        rc = hip_ok(hipMemcpyAsync(st->p[max_steps % 3], ring_of(nblocks - 1) + (int64_t)(last_nb - 1) * mt,
+                                   sizeof(double) * mt, hipMemcpyDeviceToDevice, q), "hipMemcpyAsync");
+    if (ov) {        // the caller's stream is done when the side stream is (also after an error above)
+        int r2 = hip_ok(hipEventRecord(plan->events[2 * nblocks], q), "hipEventRecord");
+        if (r2 == REVS_OK) r2 = hip_ok(hipStreamWaitEvent(s, plan->events[2 * nblocks], 0), "hipStreamWaitEvent");
+        if (rc == REVS_OK) rc = r2;
     }
     const auto tr1 = std::chrono::steady_clock::now();
     for (; rc == REVS_OK && checked < launched && failed_at < 0; ++checked) {
@@ -693,8 +732,9 @@ static int stream_run_blocks(revs_plan_t *plan, int32_t max_steps, revs_stream_s
         else if (v == 1) failed_at = checked;
     }
     if (trace) {
-        fprintf(stderr, "[revs_plan_stream_run] blocks of %d: %d launches in %.1f us, records read %.1f us "
-                "later (host away from the wait loop for at most %.1f us), failed at %d\n", B, launched,
+        fprintf(stderr, "[revs_plan_stream_run] blocks of %d%s: %d launches in %.1f us, records read %.1f us "
+                "later (host away from the wait loop for at most %.1f us), failed at %d\n", B,
+                ov ? ", overlapped" : "", launched,
                 std::chrono::duration<double, std::micro>(tr1 - tr0).count(),
                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr1).count(),
                 plan->t_wait, failed_at);
@@ -702,25 +742,31 @@ static int stream_run_blocks(revs_plan_t *plan, int32_t max_steps, revs_stream_s
     }
     plan->stream_seq = seq0 + (unsigned int)std::max(launched, 1);
     *rmax_last = rm;
-    if (failed_at >= 0 || rc != REVS_OK) (void)hipStreamSynchronize(s);
+    if (failed_at >= 0 || rc != REVS_OK) {
+        if (ov) (void)hipStreamSynchronize(plan->side);
+        (void)hipStreamSynchronize(s);
+    }
     int kept = rc != REVS_OK ? 0 : (failed_at >= 0 ? failed_at : launched);
     if (rc == REVS_OK && failed_at >= 0) {
         int from = failed_at, k0 = failed_at;
-        if (failed_at > 0 && failed_at < std::min(((failed_at - 1) / B) * B + B, max_steps)) {
-            // inside the block whose verdicts covered it: sweeps failed_at .. ran -- roll back
+        // Block bf = (failed_at - 1) / B judged it.  Inside that block the sweeps failed_at .. ran:
+        // roll back to what the block saved.  At its end (failed_at = first iteration of the next
+        // block) nothing behind it ran -- unless the blocks overlap: then the next block was
+        // under way while the verdicts came in (some of its workgroups silenced, some not, its
+        // own saved state possibly half written), and block bf's saved state is the one to trust.
+        if (failed_at > 0 && (ov || failed_at < std::min(((failed_at - 1) / B) * B + B, max_steps))) {
             from = k0 = ((failed_at - 1) / B) * B;
             float *cur[5];
             state_of(k0, cur);
-            for (int q = 0; q < narr && rc == REVS_OK; ++q)
-                if (hipMemcpyAsync(cur[q], plan->ck[q], sizeof(float) * cnt[q], hipMemcpyDeviceToDevice, s) != hipSuccess) {
-                    revs::set_error("revs_plan_stream_run: restoring the saved state failed");
-                    rc = REVS_ELAUNCH;
-                }
+            float **saved = plan->ck[ov ? (k0 / B) & 1 : 0];
+            for (int q2 = 0; q2 < narr && rc == REVS_OK; ++q2)
+                rc = hip_ok(hipMemcpyAsync(cur[q2], saved[q2], sizeof(float) * cnt[q2], hipMemcpyDeviceToDevice, s),
+                            "restoring the saved state");
         }
         // the good sweeps of the block again, and the failed iteration's own sweep, which writes
         // to the spares only (at a block boundary it was silenced: only that one): the memory is
         // then what a loop that judges every launch leaves behind a failed verdict
-        for (int k = from; k <= failed_at && rc == REVS_OK; ++k) rc = sweep(k, k0, true);
+        for (int k = from; k <= failed_at && rc == REVS_OK; ++k) rc = sweep(k, k0, plan->ring, true);
         if (rc != REVS_OK || hipStreamSynchronize(s) != hipSuccess) {
             if (rc == REVS_OK) revs::set_error("revs_plan_stream_run: replaying the block failed");
             rc = REVS_ELAUNCH;

@@ -121,6 +121,9 @@ class OperatorOptions:
     # stream_block_single: use blocks on one GPU too (how the tests drive the roll-back).
     stream_block: int = 32
     stream_block_single: bool = False
+    # ... with the all-reduce and the verdicts of a block on a second stream, beside the sweeps of
+    # the next block (the collective is hidden as long as it is shorter than a block of sweeps)
+    stream_overlap: bool = True
 
 
 def _dev_check(device):
@@ -407,7 +410,7 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
         if (self._plan is not None and self._tree is not None and self.op.stream_block > 1
                 and (self._comm is not None or self.op.stream_block_single)):
             self._block = min(int(self.op.stream_block), _lib.STREAM_BLOCK_MAX)
-            check(self.lib.revs_plan_set_stream_block(self._plan, self._block),
+            check(self.lib.revs_plan_set_stream_block(self._plan, self._block, int(self.op.stream_overlap)),
                   "revs_plan_set_stream_block")
         # R (float) for the voltage check
         self.R32 = up(Rn.astype(np.float32))

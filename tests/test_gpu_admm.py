@@ -224,12 +224,14 @@ def test_process_group_path_on_one_gpu(gpu_lib):
         assert b.residuals(1e-4)[:3] == pytest.approx(a.residuals(1e-4)[:3], rel=1e-6)
         # (sharded, the verdicts are taken by blocks: one all-reduce per block of sweeps)
         assert b._block == 32 and a._block == 0 and a.stream_calls == b.stream_calls
-        c = _engine(w2, "pdhg", group=dist.group.WORLD, op=OperatorOptions(stream_block=1))
-        for chunk in (3, 40, 37):
-            c.run_steps(chunk)
-        assert c._block == 0 and c.stream_calls == a.stream_calls    # one all-reduce per sweep
-        for name in ("P_est", "P_sch", "G", "diff"):
-            assert torch.equal(getattr(a, name), getattr(c, name)), name
+        for opt in (OperatorOptions(stream_block=1), OperatorOptions(stream_overlap=False)):
+            c = _engine(w2, "pdhg", group=dist.group.WORLD, op=opt)
+            for chunk in (3, 40, 37):
+                c.run_steps(chunk)
+            assert c._block == (0 if opt.stream_block == 1 else 32)  # (0: one all-reduce per sweep)
+            assert c.stream_calls == a.stream_calls
+            for name in ("P_est", "P_sch", "G", "diff"):
+                assert torch.equal(getattr(a, name), getattr(c, name)), name
     finally:
         dist.destroy_process_group()
 
@@ -658,13 +660,15 @@ _RAGGED = (1, 7, 30, 2, 50, 64, 11)
     ("pdhg", 8000, 200, 3, 1.02, 24, 5, _RAGGED),                   # a failed verdict at the head of a call
     ("binary", 8000, 200, 3, 0.5, 24, 7, _RAGGED),
     ("pdhg", 3000, 200, 3, 1.02, 96, 4, _RAGGED)])
-def test_block_verdicts_equal_per_launch_verdicts(gpu_lib, mode, n, nodes, seed, stress, T, block, chunks):
+@pytest.mark.parametrize("overlap", [False, True])
+def test_block_verdicts_equal_per_launch_verdicts(gpu_lib, mode, n, nodes, seed, stress, T, block, chunks, overlap):
     """The sharded form of the streaming loop -- `block` sweeps run unjudged, their node sums go to
     a ring, one launch judges the whole block, and a failed iteration inside a block is undone
     from the state the block saved (revs_plan_set_stream_block) -- against the loop where every
     launch judges itself: same kept / discarded iterations, same memory bit for bit (profiles,
     carried PDHG multipliers, node sums handed to the next call), through failures at the head
-    of a call and deep inside a burst (sweeps behind the failed one had run and are undone)."""
+    of a call and deep inside a burst (sweeps behind the failed one had run and are undone).
+    `overlap`: the verdicts of a block on a second stream beside the sweeps of the next block."""
     from helpers import f32
     from revs_admm_amd.engine import OperatorOptions
     from revs_admm_amd.synthetic import make_workload
@@ -674,7 +678,8 @@ def test_block_verdicts_equal_per_launch_verdicts(gpu_lib, mode, n, nodes, seed,
         w.load, w.cost = f32(w.load), f32(w.cost)
     kw = dict(stream_burst=16, stream_burst_max=64) if small else {}
     a = _engine(w, mode, op=OperatorOptions(**kw))
-    b = _engine(w, mode, op=OperatorOptions(stream_block=block, stream_block_single=True, **kw))
+    b = _engine(w, mode, op=OperatorOptions(stream_block=block, stream_block_single=True,
+                                            stream_overlap=overlap, **kw))
     assert a._block == 0 and b._block == block
     for chunk in chunks:
         a.run_steps(chunk)

@@ -22,10 +22,10 @@ dist.init_process_group("nccl", device_id=torch.device("cuda:0"))
 w = make_workload(n, 24, n_nodes=2048, seed=0, binary_feasible=False, stress=1.0)
 
 
-def run(group, unset=False, block=32, single=False):
+def run(group, unset=False, block=32, single=False, overlap=True):
     e = AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, kappa=w.kappa, vset=w.vset,
                    vlow=w.vlow, vhigh=w.vhigh, mode="pdhg", feeder=w.feeder, group=group,
-                   op=OperatorOptions(stream_block=block, stream_block_single=single))
+                   op=OperatorOptions(stream_block=block, stream_block_single=single, stream_overlap=overlap))
     e.run_steps(40)
     if unset:                       # the engine's group code paths without the call in the loop
         check(e.lib.revs_plan_set_comm(e._plan, None), "set_comm")
@@ -46,15 +46,17 @@ def run(group, unset=False, block=32, single=False):
         out.append((time.perf_counter() - t0) / 250 * 1e6)
     print("   native calls (iterations, us per iteration):", calls)
     print((("group, no call in the loop" if unset else "group") if group is not None else "alone")
-          + f", verdicts by blocks of {e._block}" * (e._block > 0), "us per iteration, blocks of 250:",
+          + f", verdicts by blocks of {e._block}{', second stream' * overlap}" * (e._block > 0), "us per iteration, blocks of 250:",
           " ".join(f"{x:.2f}" for x in out), "kept/discarded", e.spec_hist, flush=True)
     return e
 
 
 run(None)
+run(None, single=True, overlap=False)
 run(None, single=True)
 run(None, block=8, single=True)
 run(dist.group.WORLD, block=1)
+run(dist.group.WORLD, overlap=False)
 run(dist.group.WORLD, block=8)
 e = run(dist.group.WORLD)
 buf = torch.zeros(2048 * 24, dtype=torch.float64, device="cuda:0")
