@@ -198,7 +198,7 @@ def main():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     def build(homes, T, mode, stress, voltage):
         n_total = homes * world
@@ -217,20 +217,35 @@ def main():
 
     def timed_steps(eng, k):
         """K steps, nothing else on the stream; wall clock between two barriers (MAX over ranks)
-        and two HIP events on the kernels' stream around the same K steps."""
+        and two HIP events on the kernels' stream around the same K steps -- recorded by the
+        library itself right before the first and right after the last launch of the streaming
+        loop (revs_plan_stream_timing), by torch around run_steps on the other paths."""
+        import ctypes as C
+        native = eng._plan is not None and eng._tree is not None
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if native:
+            eng.lib.revs_plan_stream_timing(eng._plan, 1)
         barrier()
         t0 = time.perf_counter()
-        e0.record()
+        if not native:
+            e0.record()
         eng.run_steps(k)
-        e1.record()
+        if not native:
+            e1.record()
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = t.item()
-        return dt, e0.elapsed_time(e1) * 1e-3
+        ms = C.c_double()
+        if native and eng.lib.revs_plan_stream_elapsed_ms(eng._plan, C.addressof(ms)) == 0:
+            dt_ev = ms.value * 1e-3
+        else:                       # (no streaming burst in the region: nothing to price)
+            dt_ev = e0.elapsed_time(e1) * 1e-3 if not native else float("nan")
+        if native:
+            eng.lib.revs_plan_stream_timing(eng._plan, 0)
+        return dt, dt_ev
 
     def clock_warm(eng):
         for _ in range(args.clock_warm):

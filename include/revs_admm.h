@@ -740,6 +740,13 @@ int revs_plan_stream_run(revs_plan_t *plan, int32_t max_steps, revs_stream_state
  * Memory: 2 B M T doubles + 10 n T floats.  Set both on every rank alike. */
 #define REVS_STREAM_BLOCK_MAX 256
 int revs_plan_set_stream_block(revs_plan_t *plan, int32_t block, int32_t overlap);
+/* Two HIP events around the bursts of revs_plan_stream_run, recorded by the library on the
+ * bursts' own stream: revs_plan_stream_timing(plan, 1) arms them (the next burst records the
+ * first one, every burst re-records the second after its last launch);
+ * revs_plan_stream_elapsed_ms returns the time between them once the stream has been
+ * synchronised, and re-arms.  What bench.py prices the sweep kernel's launch duration with. */
+int revs_plan_stream_timing(revs_plan_t *plan, int32_t enable);
+int revs_plan_stream_elapsed_ms(revs_plan_t *plan, double *ms);
 /* Bits OR-ed by the sweeps launched through the plan since the last clear: 1 = a residence's
  * window cannot reach 90 % SOC (the reference prints "No solution found", lpsolver.py:153-155),
  * 2 = a PDHG residence hit max_iter before its tolerance.  Meaningful after the stream has

@@ -60,6 +60,9 @@ struct revs_plan {
     unsigned long long *grp_bits = nullptr;                // device: per-slice maxima, zero between launches
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> events;        // pool: sweeps-done / verdicts-done per block, end of call
+    // optional timing of the bursts on their own stream (revs_plan_stream_timing)
+    hipEvent_t tev[2] = {nullptr, nullptr};
+    int32_t timing = 0;                    // 0 off, 1 armed (next burst records tev[0]), 2 open
 };
 
 // Host-side acceptance test of a chained Newton iteration (operator_newton.py: _chain_launch): the
@@ -160,6 +163,7 @@ extern "C" void revs_plan_destroy(revs_plan_t *plan) {
     if (plan->grp_bits) (void)hipFree(plan->grp_bits);
     for (auto &gen : plan->ck) for (float *c : gen) if (c) (void)hipFree(c);
     for (hipEvent_t e : plan->events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : plan->tev) if (e) (void)hipEventDestroy(e);
     if (plan->side) (void)hipStreamDestroy(plan->side);
     delete plan;
 }
@@ -571,6 +575,39 @@ extern "C" int revs_plan_set_stream_block(revs_plan_t *plan, int32_t block, int3
     return REVS_OK;
 }
 
+extern "C" int revs_plan_stream_timing(revs_plan_t *plan, int32_t enable) {
+    REVS_REQUIRE(plan, "revs_plan_stream_timing: null plan");
+    for (hipEvent_t &e : plan->tev)
+        if (enable && !e && hipEventCreate(&e) != hipSuccess) {
+            revs::set_error("revs_plan_stream_timing: hipEventCreate failed");
+            return REVS_ELAUNCH;
+        }
+    plan->timing = enable ? 1 : 0;
+    return REVS_OK;
+}
+
+extern "C" int revs_plan_stream_elapsed_ms(revs_plan_t *plan, double *ms) {
+    REVS_REQUIRE(plan && ms, "revs_plan_stream_elapsed_ms: null argument");
+    REVS_REQUIRE(plan->timing == 2, "revs_plan_stream_elapsed_ms: no burst since revs_plan_stream_timing");
+    float f = 0.f;
+    const hipError_t e = hipEventElapsedTime(&f, plan->tev[0], plan->tev[1]);
+    if (e != hipSuccess) {
+        revs::set_error("revs_plan_stream_elapsed_ms: %s (synchronise the stream first)", hipGetErrorString(e));
+        return REVS_ELAUNCH;
+    }
+    *ms = (double)f;
+    plan->timing = 1;
+    return REVS_OK;
+}
+
+// two HIP events around the bursts since revs_plan_stream_timing, on the bursts' own stream
+static void timing_begin(revs_plan_t *plan, hipStream_t s) {
+    if (plan->timing == 1 && hipEventRecord(plan->tev[0], s) == hipSuccess) plan->timing = 2;
+}
+static void timing_end(revs_plan_t *plan, hipStream_t s) {
+    if (plan->timing == 2) (void)hipEventRecord(plan->tev[1], s);
+}
+
 extern "C" int32_t revs_plan_status_flags(revs_plan_t *plan, int32_t clear) {
     if (!plan || !plan->flags_host) return 0;
     const unsigned int f = *(volatile unsigned int *)plan->flags_host;
@@ -688,6 +725,7 @@ static int stream_run_blocks(revs_plan_t *plan, int32_t max_steps, revs_stream_s
     double rm = 0.0;
     static const bool trace = getenv("REVS_PLAN_TRACE") != nullptr;
     const auto tr0 = std::chrono::steady_clock::now();
+    timing_begin(plan, s);
     rc = revs::stream_block_verdict(plan->ctl, seq0, seq0 - 1u, seq0, 1, d.T, plan->tree, st->p[0], mt,
                                     d.vlo, d.vhi, vtol, plan->grp_bits, plan->rec_dev, s);
     hipStream_t q = ov ? plan->side : s;                 // where the collective and the verdicts go
@@ -725,6 +763,7 @@ static int stream_run_blocks(revs_plan_t *plan, int32_t max_steps, revs_stream_s
         if (r2 == REVS_OK) r2 = hip_ok(hipStreamWaitEvent(s, plan->events[2 * nblocks], 0), "hipStreamWaitEvent");
         if (rc == REVS_OK) rc = r2;
     }
+    timing_end(plan, s);
     const auto tr1 = std::chrono::steady_clock::now();
     for (; rc == REVS_OK && checked < launched && failed_at < 0; ++checked) {
         const int v = stream_wait(plan, seq0 + (unsigned int)checked, s, &rm);
@@ -848,6 +887,7 @@ extern "C" int revs_plan_stream_run(revs_plan_t *plan, int32_t max_steps, revs_s
     const auto tr0 = std::chrono::steady_clock::now();
     auto tr1 = tr0;
     double slowest = 0.0;
+    timing_begin(plan, s);
     for (; launched < max_steps; ++launched) {
         const auto a = trace ? std::chrono::steady_clock::now() : tr0;
         if ((rc = launch(launched)) != REVS_OK) goto out;
@@ -855,6 +895,7 @@ extern "C" int revs_plan_stream_run(revs_plan_t *plan, int32_t max_steps, revs_s
             slowest = std::max(slowest, std::chrono::duration<double, std::micro>(
                                             std::chrono::steady_clock::now() - a).count());
     }
+    timing_end(plan, s);
     tr1 = std::chrono::steady_clock::now();
     for (; checked < launched && failed_at < 0; ++checked) {
         const int v = stream_wait(plan, seq0 + (unsigned int)checked, s, &rm);

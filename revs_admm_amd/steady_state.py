@@ -13,6 +13,19 @@ from . import _lib
 from ._lib import check, ptr
 
 
+def _dp(t) -> int:
+    """data_ptr() of a long-lived buffer, remembered on the tensor object itself (the bursts of
+    the streaming loop are short: a dozen data_ptr() calls are microseconds of an idle GPU)."""
+    d = getattr(t, "_revs_dp", None)
+    if d is None:
+        d = t.data_ptr()
+        try:
+            t._revs_dp = d
+        except AttributeError:
+            pass
+    return d
+
+
 class SteadyStateMixin:
     def _spec_discard(self, stt, write_sc):
         """A speculative sweep whose evaluation found rows beyond tolerance: finish the Newton
@@ -44,16 +57,19 @@ class SteadyStateMixin:
         tolerance silences the launches behind it and is finished here as step() finishes a
         discarded speculative sweep.  Returns the number of iterations done (at least one)."""
         o = self.op
-        scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
         p0 = self._fused_p
-        rest = [b for b in (self.pnq[0], self.p_alt, self.p_alt2) if b.data_ptr() != p0.data_ptr()]
+        d0 = _dp(p0)
+        if self._pn0 is None:
+            self._pn0 = self.pnq[0]
+        rest = [b for b in (self._pn0, self.p_alt, self.p_alt2) if _dp(b) != d0]
         # p[1] must be zero on entry.  The last launch of a fully kept call has just cleared the
         # array that is p[1] now (roles rotate): no fill launch then
         # (verdicts by blocks: the sweeps accumulate into the plan's ring, p[1] and p[2] are not used)
         if self._block:
             pass
-        elif self._p_clear is not None and self._p_clear.data_ptr() != p0.data_ptr():
-            rest = [self._p_clear] + [b for b in rest if b.data_ptr() != self._p_clear.data_ptr()]
+        elif self._p_clear is not None and _dp(self._p_clear) != d0:
+            dc = _dp(self._p_clear)
+            rest = [self._p_clear] + [b for b in rest if _dp(b) != dc]
         else:
             rest[0].zero_()
         self._p_clear = None
@@ -61,20 +77,24 @@ class SteadyStateMixin:
             self._allreduce(p0)
         pes = (self.P_est, self.P_est_new, self.P_est_alt)
         pss, gs, ps = (self.P_sch, self.P_sch_alt), (self.G, self.G_alt), (p0, rest[0], rest[1])
-        st = _lib.StreamState()
+        st = self._stream_st
+        by = {}
         for i in range(3):
-            st.p_est[i], st.p[i] = ptr(pes[i]), ptr(ps[i])
+            a, b = _dp(pes[i]), _dp(ps[i])
+            st.p_est[i], st.p[i] = a, b
+            by[a], by[b] = pes[i], ps[i]
         for i in range(2):
-            st.p_sch[i], st.gamma[i] = ptr(pss[i]), ptr(gs[i])
-        kept, rm = C.c_int32(), C.c_double()
+            a, b = _dp(pss[i]), _dp(gs[i])
+            st.p_sch[i], st.gamma[i] = a, b
+            by[a], by[b] = pss[i], gs[i]
+        kept, rm = self._stream_out
         count = min(count, self._burst)
-        check(self.lib.revs_plan_stream_run(self._plan, count, C.byref(st), scale, o.eps,
-                                            C.addressof(kept), C.addressof(rm), self.stream),
+        check(self.lib.revs_plan_stream_run(self._plan, count, self._stream_st_ref, self._scale, o.eps,
+                                            self._stream_out_ref[0], self._stream_out_ref[1], self.stream),
               "revs_plan_stream_run")
         n = kept.value
         self.stream_calls.append((count, n))
         self._burst = min(4 * self._burst, o.stream_burst_max) if n == count else o.stream_burst
-        by = {t.data_ptr(): t for t in pes + pss + gs + ps}
         self.P_est, self.P_est_new, self.P_est_alt = (by[st.p_est[i]] for i in range(3))
         self.P_sch, self.P_sch_alt = by[st.p_sch[0]], by[st.p_sch[1]]
         self.G, self.G_alt = by[st.gamma[0]], by[st.gamma[1]]
