@@ -166,6 +166,10 @@ def main():
     ap.add_argument("--pdhg-check", type=int, default=None, help="PDHG: convergence test period")
     ap.add_argument("--op-kadd", type=int, default=None,
                     help="operator: violated rows admitted to a slot's model per Newton iteration")
+    ap.add_argument("--stream-block", type=int, default=None,
+                    help="sharded steady state: iterations per all-reduce / verdict launch (default 32)")
+    ap.add_argument("--no-stream-overlap", action="store_true",
+                    help="sharded steady state: collective and verdicts on the compute stream")
     ap.add_argument("--no-converge", action="store_true",
                     help="skip the untimed run to the eps-residual (profiling runs)")
     args = ap.parse_args()
@@ -209,6 +213,9 @@ def main():
         opts = OperatorOptions(voltage=voltage)
         if args.op_kadd is not None:
             opts.newton_kadd = args.op_kadd
+        if args.stream_block is not None:
+            opts.stream_block = args.stream_block
+        opts.stream_overlap = not args.no_stream_overlap
         eng = AdmmEngine(w.cost, w.homes[lo:hi], w.load[lo:hi], w.node_of[lo:hi], w.Rn, kappa=w.kappa,
                          vset=w.vset, vlow=w.vlow, vhigh=w.vhigh, mode=mode, device=dev, group=group,
                          node_counts=counts, op=opts, feeder=w.feeder,

@@ -723,20 +723,21 @@ int revs_plan_stream_run(revs_plan_t *plan, int32_t max_steps, revs_stream_state
  * verdict, each accumulating its node sums into its own slice of a ring owned by the plan;
  * ONE all-reduce sums the B slices over the ranks and one launch of B x T workgroups judges
  * them (tree form, as above).  Every launch of the burst is still a no-op once an iteration at
- * or before its own has failed; the sweeps of the block that ran behind a failed iteration
- * are undone: each block first saves the state it overwrites (four profiles and the PDHG
- * residences' carried multipliers, in arrays owned by the plan), and the call puts it back and runs
- * the good sweeps of that block again, then the failed iteration's own sweep (to the spares),
- * before it returns -- memory is then bit for bit what the single-GPU form leaves.
+ * or before its own has failed; the sweeps that ran behind a failed iteration are undone: every
+ * fourth block first saves the state it overwrites (four profiles and the PDHG residences'
+ * carried multipliers, in arrays owned by the plan), and the call puts the last saved state back
+ * and runs the good sweeps from there again, then the failed iteration's own sweep (to the
+ * spares), before it returns -- memory is then bit for bit what the single-GPU form leaves.
  * The contract of revs_plan_stream_run is unchanged (st->p[1], p[2] are not used; st->p[0] holds
  * the all-reduced sums of the next iteration at return).  block <= 1: every launch judges itself
  * (the single-GPU form).
- * overlap != 0: the all-reduce and the verdicts of block b run on a second stream owned by the
- * plan while the caller's stream already runs the sweeps of block b + 1 (two ring halves, two
- * generations of saved state; block b + 2 waits for block b's verdicts) -- the collective then
- * costs the step nothing as long as it is shorter than a block of sweeps.  A failure rolls back to
- * the start of the block that judged it.  The caller's stream waits for the second stream before
- * the call returns, so synchronising the caller's stream is still enough.
+ * overlap != 0 (and more than `block` launches in the call): the all-reduce and the verdicts of
+ * block b run on a second stream owned by the plan while the caller's stream already runs the
+ * sweeps of block b + 1 (two ring halves, two generations of saved state; block b + 2 waits for
+ * block b's verdicts) -- the collective then costs the step nothing as long as it is shorter
+ * than a block of sweeps; the last `block` launches are split 3 : 1 so that the last collective
+ * is a short one.  The caller's stream waits for the second stream before the call returns, so
+ * synchronising the caller's stream is still enough.
  * Memory: 2 B M T doubles + 10 n T floats.  Set both on every rank alike. */
 #define REVS_STREAM_BLOCK_MAX 256
 int revs_plan_set_stream_block(revs_plan_t *plan, int32_t block, int32_t overlap);

@@ -870,9 +870,9 @@ int agent_step_stream(int64_t n_homes, int32_t T, const float *cost, const revs_
 // one collective per 18 us sweep would be the whole step.  So a block of B sweeps runs without
 // verdicts, each accumulating its sums into its own slice of a ring; ONE all-reduce then sums
 // the B slices over the ranks, and one launch of B x T workgroups judges them all.  A failed
-// verdict silences everything behind the block; the sweeps of the block behind the failed
-// iteration have run on an estimate that is not the operator's answer, so the block starts
-// by saving the state they overwrite (stream_block_begin) and the host rolls back to it.
+// verdict silences everything behind the block; the sweeps behind the failed iteration that
+// did run worked from an estimate that is not the operator's answer, so the state the sweeps
+// overwrite is saved now and then (stream_block_begin) and the host rolls back to it.
 struct BlockBegin {
     const StreamCtl *ctl;
     unsigned int base_seq, gate_seq;      // no-op when a launch numbered base_seq..gate_seq failed

@@ -661,24 +661,46 @@ static void stream_rotate(revs_stream_state_t *st, int kept) {
 // agent_kernels.hip).  Launch k of the call has number seq0 + k and consumes the node sums
 // "of iteration k".  Enqueued in one burst:
 //   verdict of iteration 0 (the caller's st->p[0]);
-//   per block [k0, k0 + nb):  save the state iteration k0 starts from and clear the ring |
+//   per block [k0, k0 + nb):  every kSaveEvery-th block (and the first) saves the state iteration
+//       k0 starts from; the first also clears the ring |
 //       nb sweeps, sweep k accumulating the sums of iteration k + 1 into ring slice k - k0 |
-//       ONE all-reduce of the nb slices (sharded) | verdicts of iterations k0+1 .. k0+nb
-//       (the last block: .. max_steps - 1, its last slice is the next call's st->p[0]);
-// every launch is a no-op once an iteration at or before its own has failed.  Then the records are
-// read in order.  A failed iteration j inside a block means sweeps j .. k0+nb-1 ran on an estimate
-// that was not the operator's answer: the saved state is put back and sweeps k0 .. j-1 (all judged
-// good) are run again, then sweep j itself (to the spares): bit for bit the memory that the loop
-// judging every launch leaves behind a failed verdict (the PDHG residences' carried multipliers
-// are part of the saved state).
+//       ONE all-reduce of the nb slices (sharded) | verdicts of iterations k0+1 .. k0+nb (the last
+//       block: .. max_steps - 1, its last slice is the next call's st->p[0]) | the slices cleared;
+// every launch is a no-op once an iteration at or before its own has failed.  With plan->overlap
+// the all-reduce and the verdicts of block b go to the plan's second stream while the caller's
+// stream runs block b + 1 (two ring halves; block b + 2 waits for block b's verdicts).  The
+// blocks are B long, the last B iterations of a call split 3 : 1 so that the all-reduce nobody
+// can hide -- the last one -- is a short one.  Then the records are read in order.  A failed
+// iteration j means that sweeps behind j ran on an estimate that was not the operator's answer:
+// the last state saved at or before the block that judged j is put back and the sweeps from
+// there to j - 1 (all judged good) are run again, then sweep j itself (to the spares): bit for
+// bit the memory that the loop judging every launch leaves behind a failed verdict (the PDHG
+// residences' carried multipliers are part of the saved state).
+constexpr int kSaveEvery = 4;
 static int stream_run_blocks(revs_plan_t *plan, int32_t max_steps, revs_stream_state_t *st, double scale,
                              double eps, int32_t *kept_steps, double *rmax_last, unsigned int seq0,
                              hipStream_t s) {
     const revs_plan_desc_t &d = plan->d;
     const int64_t mt = (int64_t)d.m * d.T, nt = d.n_homes * (int64_t)d.T;
     const int B = plan->block;
-    const bool ov = plan->overlap != 0;
+    // (the second stream costs a burst ~0.15 ms of host time in event and cross-stream calls: a
+    // burst of one block has nothing to hide behind and stays on the caller's stream)
+    const bool ov = plan->overlap != 0 && max_steps > B;
     const double vtol = eps * scale;
+    // block starts: k0[b], b = 0 .. nblocks (k0[nblocks] = max_steps)
+    std::vector<int> k0s;
+    for (int k = 0; k < max_steps;) {
+        k0s.push_back(k);
+        const int rem = max_steps - k;
+        k += rem > B ? B : (ov && rem >= 8 ? rem - (rem + 3) / 4 : rem);
+    }
+    const int nblocks = (int)k0s.size();
+    k0s.push_back(max_steps);
+    auto block_of = [&](int j) {       // the block whose verdicts cover iteration j >= 1: k0 < j <= k0 + nb
+        int b = 0;
+        while (k0s[b + 1] < j) ++b;
+        return b;
+    };
     auto ring_of = [&](int b) { return plan->ring + (ov ? (int64_t)(b & 1) * B * mt : 0); };
     auto sweep = [&](int k, int k0, double *ring, bool replay) -> int {
         revs::StreamExtra sx{};
@@ -704,7 +726,6 @@ static int stream_run_blocks(revs_plan_t *plan, int32_t max_steps, revs_stream_s
         a[2] = st->p_sch[k0 % 2]; a[3] = st->gamma[k0 % 2];
         a[4] = d.pdhg_dual;
     };
-    const int nblocks = (max_steps + B - 1) / B;
     // events of the overlapped form: [2 b] = block b's sweeps are done, [2 b + 1] = its verdicts are
     // in, [2 nblocks] = the side stream has finished this call
     if (ov)
@@ -721,7 +742,7 @@ static int stream_run_blocks(revs_plan_t *plan, int32_t max_steps, revs_stream_s
         revs::set_error("revs_plan_stream_run: %s: %s", what, hipGetErrorString(e));
         return REVS_ELAUNCH;
     };
-    int rc = REVS_OK, launched = 0, checked = 0, failed_at = -1, last_nb = 0;
+    int rc = REVS_OK, launched = 0, checked = 0, failed_at = -1;
     double rm = 0.0;
     static const bool trace = getenv("REVS_PLAN_TRACE") != nullptr;
     const auto tr0 = std::chrono::steady_clock::now();
@@ -729,34 +750,41 @@ static int stream_run_blocks(revs_plan_t *plan, int32_t max_steps, revs_stream_s
     rc = revs::stream_block_verdict(plan->ctl, seq0, seq0 - 1u, seq0, 1, d.T, plan->tree, st->p[0], mt,
                                     d.vlo, d.vhi, vtol, plan->grp_bits, plan->rec_dev, s);
     hipStream_t q = ov ? plan->side : s;                 // where the collective and the verdicts go
-    for (int b = 0, k0 = 0; k0 < max_steps && rc == REVS_OK; ++b, k0 += B) {
-        const int nb = std::min(B, max_steps - k0);
+    for (int b = 0; b < nblocks && rc == REVS_OK; ++b) {
+        const int k0 = k0s[b], nb = k0s[b + 1] - k0;
         double *ring = ring_of(b);
-        // (overlapped: this block reuses the ring half and the saved-state generation of block
-        // b - 2, whose verdicts must be in -- they also decide whether this block is a no-op)
+        // (overlapped: this block reuses the ring half of block b - 2, whose verdicts must be in
+        // and the half cleared -- they also decide whether this block is a no-op)
         if (ov && b >= 2) rc = hip_ok(hipStreamWaitEvent(s, plan->events[2 * (b - 2) + 1], 0), "hipStreamWaitEvent");
-        float *cur[5];
-        state_of(k0, cur);
-        if (rc == REVS_OK)
-            rc = revs::stream_block_begin(plan->ctl, seq0, seq0 + (unsigned int)k0, cur, plan->ck[ov ? b & 1 : 0],
-                                          cnt, narr, ring, (int64_t)nb * mt, s);
+        if (rc == REVS_OK && b % kSaveEvery == 0) {
+            // generation (b / kSaveEvery) & 1: the other one may still be needed by a verdict that is not in yet
+            float *cur[5];
+            state_of(k0, cur);
+            rc = revs::stream_block_begin(plan->ctl, seq0, seq0 + (unsigned int)k0, cur,
+                                          plan->ck[(b / kSaveEvery) & 1], cnt, narr, plan->ring,
+                                          b == 0 ? (int64_t)(ov && nblocks > 1 ? 2 * B : std::min(B, max_steps)) * mt : 0, s);
+        }
         for (int k = k0; k < k0 + nb && rc == REVS_OK; ++k, ++launched) rc = sweep(k, k0, ring, false);
         if (ov && rc == REVS_OK) rc = hip_ok(hipEventRecord(plan->events[2 * b], s), "hipEventRecord");
         if (ov && rc == REVS_OK) rc = hip_ok(hipStreamWaitEvent(q, plan->events[2 * b], 0), "hipStreamWaitEvent");
         if (rc == REVS_OK && plan->comm)
             rc = revs_comm_allreduce_f64(plan->comm, ring, (int64_t)nb * mt, 0, q);
-        const int judged = k0 + nb < max_steps ? nb : nb - 1;
+        const int judged = b + 1 < nblocks ? nb : nb - 1;
         if (rc == REVS_OK && judged > 0)
             rc = revs::stream_block_verdict(plan->ctl, seq0, seq0 + (unsigned int)k0,
                                             seq0 + (unsigned int)k0 + 1u, judged, d.T, plan->tree,
                                             ring, mt, d.vlo, d.vhi, vtol, plan->grp_bits, plan->rec_dev, q);
+        // (the slices are accumulated into again two blocks on -- one block on without the second
+        // stream; the last block's are cleared by the next call)
+        if (rc == REVS_OK && b + 1 < nblocks)
+            rc = hip_ok(hipMemsetAsync(ring, 0, sizeof(double) * (size_t)nb * mt, q), "hipMemsetAsync");
         if (ov && rc == REVS_OK) rc = hip_ok(hipEventRecord(plan->events[2 * b + 1], q), "hipEventRecord");
-        last_nb = nb;
     }
     // the sums of iteration max_steps (summed over the ranks, not judged yet) are the caller's
     // st->p[0] after the rotation below
     if (rc == REVS_OK && launched == max_steps)
-        rc = hip_ok(hipMemcpyAsync(st->p[max_steps % 3], ring_of(nblocks - 1) + (int64_t)(last_nb - 1) * mt,
+        rc = hip_ok(hipMemcpyAsync(st->p[max_steps % 3],
+                                   ring_of(nblocks - 1) + (int64_t)(max_steps - k0s[nblocks - 1] - 1) * mt,
                                    sizeof(double) * mt, hipMemcpyDeviceToDevice, q), "hipMemcpyAsync");
     if (ov) {        // the caller's stream is done when the side stream is (also after an error above)
         int r2 = hip_ok(hipEventRecord(plan->events[2 * nblocks], q), "hipEventRecord");
@@ -771,9 +799,9 @@ static int stream_run_blocks(revs_plan_t *plan, int32_t max_steps, revs_stream_s
         else if (v == 1) failed_at = checked;
     }
     if (trace) {
-        fprintf(stderr, "[revs_plan_stream_run] blocks of %d%s: %d launches in %.1f us, records read %.1f us "
-                "later (host away from the wait loop for at most %.1f us), failed at %d\n", B,
-                ov ? ", overlapped" : "", launched,
+        fprintf(stderr, "[revs_plan_stream_run] %d blocks of at most %d%s: %d launches in %.1f us, records "
+                "read %.1f us later (host away from the wait loop for at most %.1f us), failed at %d\n",
+                nblocks, B, ov ? ", overlapped" : "", launched,
                 std::chrono::duration<double, std::micro>(tr1 - tr0).count(),
                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr1).count(),
                 plan->t_wait, failed_at);
@@ -788,24 +816,26 @@ static int stream_run_blocks(revs_plan_t *plan, int32_t max_steps, revs_stream_s
     int kept = rc != REVS_OK ? 0 : (failed_at >= 0 ? failed_at : launched);
     if (rc == REVS_OK && failed_at >= 0) {
         int from = failed_at, k0 = failed_at;
-        // Block bf = (failed_at - 1) / B judged it.  Inside that block the sweeps failed_at .. ran:
-        // roll back to what the block saved.  At its end (failed_at = first iteration of the next
-        // block) nothing behind it ran -- unless the blocks overlap: then the next block was
-        // under way while the verdicts came in (some of its workgroups silenced, some not, its
-        // own saved state possibly half written), and block bf's saved state is the one to trust.
-        if (failed_at > 0 && (ov || failed_at < std::min(((failed_at - 1) / B) * B + B, max_steps))) {
-            from = k0 = ((failed_at - 1) / B) * B;
+        // Block bf judged it.  At the very end of bf (failed_at = first iteration of block bf + 1)
+        // with everything on one stream nothing behind it ran, and if bf + 1 saved the state, that
+        // is the state wanted.  Otherwise sweeps from failed_at on did run (overlapped: the next
+        // block was under way while the verdicts came in -- some of its workgroups silenced, some
+        // not, a state it saved possibly half written): back to the last state saved at or before bf.
+        const int bf = failed_at > 0 ? block_of(failed_at) : -1;
+        if (bf >= 0 && (ov || failed_at < k0s[bf + 1])) {
+            const int bs = (bf / kSaveEvery) * kSaveEvery;
+            from = k0 = k0s[bs];
             float *cur[5];
             state_of(k0, cur);
-            float **saved = plan->ck[ov ? (k0 / B) & 1 : 0];
+            float **saved = plan->ck[(bs / kSaveEvery) & 1];
             for (int q2 = 0; q2 < narr && rc == REVS_OK; ++q2)
                 rc = hip_ok(hipMemcpyAsync(cur[q2], saved[q2], sizeof(float) * cnt[q2], hipMemcpyDeviceToDevice, s),
                             "restoring the saved state");
         }
-        // the good sweeps of the block again, and the failed iteration's own sweep, which writes
-        // to the spares only (at a block boundary it was silenced: only that one): the memory is
-        // then what a loop that judges every launch leaves behind a failed verdict
-        for (int k = from; k <= failed_at && rc == REVS_OK; ++k) rc = sweep(k, k0, plan->ring, true);
+        // the good sweeps again, and the failed iteration's own sweep, which writes to the spares
+        // only: the memory is then what a loop that judges every launch leaves behind a failed
+        // verdict.  (Their node sums go to one scratch slice: nobody reads them.)
+        for (int k = from; k <= failed_at && rc == REVS_OK; ++k) rc = sweep(k, k, plan->ring, true);
         if (rc != REVS_OK || hipStreamSynchronize(s) != hipSuccess) {
             if (rc == REVS_OK) revs::set_error("revs_plan_stream_run: replaying the block failed");
             rc = REVS_ELAUNCH;
