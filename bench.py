@@ -334,8 +334,9 @@ def main():
             clock_warm(e2)
             s0, c0 = list(e2.spec_hist), list(e2.chain_hist)
             # three blocks of `steps`; the median block is the regime's figure (these regimes have
-            # the host in every iteration: a descheduled host thread costs a block ~10 ms once in
-            # a while on a shared box -- all three blocks are listed)
+            # the host in every iteration: a host thread frozen by the box's CPU quota cost a block
+            # ~10 ms once in a while before the thread pools were capped, see the top of this
+            # file -- all three blocks are still listed)
             blocks = [timed_steps(e2, steps)[0] / steps * 1e3 for _ in range(3)]
             d2 = float(np.median(blocks)) * 1e-3 * steps
             out = {"value": homes * steps / d2, "unit": "solves/s", "ms_per_step": d2 / steps * 1e3,
