@@ -270,6 +270,8 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
         self._y_support = False
         self._chain_ok, self._chain_few, self._pre_kept = False, False, False
         self._chain_seq = 0.0                          # tags of the chain's evaluations: -1, -2, ...
+        self._eval_seq = 0.0                           # tags of the other evaluations: 1, 2, ...
+        self._pending_tag = [None, None]
         self.chain_hist = [0, 0]                       # chained Newton iterations kept / redone
         self._spec_ok = False
         self._spec_wait, self._spec_back = 0, 1

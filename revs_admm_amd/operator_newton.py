@@ -16,13 +16,22 @@ from ._lib import check, ptr
 class DualNewtonMixin:
     def _dual_phase(self, phase: int, y, use_y: bool, k: int):
         lib, M, T = self.lib, self.M, self.T
+        # an evaluation that ends with its own selection tags the stats block (pinned host
+        # memory, written by the selection's workgroups behind a system-scope fence) with a
+        # fresh number: _dual_wait polls for it -- no event record on the stream, no
+        # synchronize on the host
+        # (n + 0.5: the native loops tag the same blocks with whole numbers, +/-)
+        tag = 0.0
+        if (phase & 2) and not (phase & 4):
+            self._eval_seq += 1.0
+            tag = self._pending_tag[k] = self._eval_seq + 0.5
         check(lib.revs_op_dual_evaluate(
             phase, M, T, ptr(self.node_ptr), ptr(self.P_est), ptr(self.P_sch), ptr(self.G),
             ptr(self.R64), ptr(self.R64T), ptr(y), int(use_y), self.kappa, self.vlo, self.vhi,
             self.op.newton_kadd, self.ksplit1, ptr(self.d_sl), ptr(self.v_sl), ptr(self.pnq),
             ptr(self.P_est_new), ptr(self.vfull), ptr(self.violw), ptr(self.d_part),
             ptr(self.c_idx[k]), ptr(self.c_cnt[k]), ptr(self.c_val[k]), self.stats_dev[k],
-            0.0, ptr(self.tile_cnt), self.stream), "revs_op_dual_evaluate")
+            tag, ptr(self.tile_cnt), self.stream), "revs_op_dual_evaluate")
 
     def _dual_home_pass_rows(self, y, sup: int):
         """Phase 1 of an evaluation with d = R^T y / kappa taken from the few rows listed in
@@ -52,8 +61,6 @@ class DualNewtonMixin:
             self._dual_phase(1, y, use_y, k)
             self._allreduce(self.pnq if full else self.pnq[0])   # the only exchange
             self._dual_phase(2, y, use_y, k)
-        if record and self.stats_ev[k] is not None:
-            self.stats_ev[k].record()
 
     def _dual_complete(self, y, use_y: bool, k: int):
         """After a full=False evaluation that did not settle the solve: exchange N and the
@@ -62,13 +69,23 @@ class DualNewtonMixin:
             return self._dual_wait(k)
         self._allreduce(self.pnq[1:])
         self._dual_phase(2, y, use_y, k)
-        if self.stats_ev[k] is not None:
-            self.stats_ev[k].record()
         return self._dual_wait(k)
 
     def _dual_wait(self, k: int):
-        if self.stats_ev[k] is not None:
-            self.stats_ev[k].synchronize()
+        tag = self._pending_tag[k]
+        if self.stats_ev[k] is not None and tag is not None:
+            tags = self.stats_host[k].numpy()[:, 5]
+            spins, t0 = 0, None
+            while not (tags == tag).all():
+                spins += 1
+                if spins & 0xFFF == 0:
+                    import time
+                    t0 = t0 or time.monotonic()
+                    if time.monotonic() - t0 > 120.0:
+                        raise _lib.RevsError("operator evaluation: timed out waiting for its stats")
+            # (consumed: a later wait on this block without a new evaluation of ours -- the
+            # block may since have been written by a native loop, which waits itself -- just reads)
+            self._pending_tag[k] = None
         return self.stats_host[k].numpy().copy()
 
     def _dual_evaluate(self, y, use_y: bool, k: int, sup=None):
