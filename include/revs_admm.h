@@ -710,6 +710,10 @@ typedef struct {
     float *p_sch[2];
     float *gamma[2];
     double *p[3];
+    float *diff_hist;       /* NULL, or float[max_steps][n_homes]: launch k writes the residences' diff
+                             * (lpsolver.py:284) to row k instead of the plan's diff array; advanced
+                             * by the kept steps at return -- the per-iteration diff of solve_ADMM
+                             * without a host round trip per iteration */
 } revs_stream_state_t;
 int revs_plan_set_tree(revs_plan_t *plan, const revs_tree_t *tree_host);
 int revs_plan_set_comm(revs_plan_t *plan, revs_comm_t *comm);

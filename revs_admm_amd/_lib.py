@@ -72,7 +72,7 @@ class Tree(C.Structure):
 class StreamState(C.Structure):
     """revs_stream_state_t"""
     _fields_ = [("p_est", C.c_void_p * 3), ("p_sch", C.c_void_p * 2), ("gamma", C.c_void_p * 2),
-                ("p", C.c_void_p * 3)]
+                ("p", C.c_void_p * 3), ("diff_hist", C.c_void_p)]
 
 
 TREE_MAX = 2048          # REVS_TREE_MAX

@@ -649,11 +649,12 @@ static int stream_wait(revs_plan_t *plan, unsigned int seq, hipStream_t s, doubl
     return r[1] != 0.0 ? 1 : 0;
 }
 
-static void stream_rotate(revs_stream_state_t *st, int kept) {
+static void stream_rotate(revs_stream_state_t *st, int kept, int64_t n_homes) {
     if (kept <= 0) return;
     revs_stream_state_t r = *st;
     for (int i = 0; i < 3; ++i) { r.p_est[i] = st->p_est[(kept + i) % 3]; r.p[i] = st->p[(kept + i) % 3]; }
     for (int i = 0; i < 2; ++i) { r.p_sch[i] = st->p_sch[(kept + i) % 2]; r.gamma[i] = st->gamma[(kept + i) % 2]; }
+    if (st->diff_hist) r.diff_hist = st->diff_hist + (int64_t)kept * n_homes;
     *st = r;
 }
 
@@ -712,7 +713,8 @@ static int stream_run_blocks(revs_plan_t *plan, int32_t max_steps, revs_stream_s
         return revs::agent_step_stream(
             d.n_homes, d.T, d.cost, d.homes, d.load, st->p_est[k % 3],
             d.recompute_pe_new ? nullptr : st->p_est[(k + 1) % 3], st->p_sch[k % 2], st->gamma[k % 2],
-            st->p_sch[(k + 1) % 2], st->gamma[(k + 1) % 2], d.diff, d.dsq, d.status, d.pdhg_dual,
+            st->p_sch[(k + 1) % 2], st->gamma[(k + 1) % 2],
+            st->diff_hist ? st->diff_hist + (int64_t)k * d.n_homes : d.diff, d.dsq, d.status, d.pdhg_dual,
             (float)d.kappa, d.mode, &d.pdhg, d.node_of, ring + (int64_t)(k - k0) * mt,
             st->p_est[(k + 2) % 3], sx, s);
     };
@@ -843,7 +845,7 @@ static int stream_run_blocks(revs_plan_t *plan, int32_t max_steps, revs_stream_s
         }
     }
     *kept_steps = kept;
-    stream_rotate(st, kept);
+    stream_rotate(st, kept, d.n_homes);
     return rc;
 }
 
@@ -898,7 +900,8 @@ extern "C" int revs_plan_stream_run(revs_plan_t *plan, int32_t max_steps, revs_s
         int rc = revs::agent_step_stream(
             d.n_homes, d.T, d.cost, d.homes, d.load, st->p_est[k % 3],
             d.recompute_pe_new ? nullptr : st->p_est[(k + 1) % 3], st->p_sch[k % 2], st->gamma[k % 2],
-            st->p_sch[(k + 1) % 2], st->gamma[(k + 1) % 2], d.diff, d.dsq, d.status, d.pdhg_dual,
+            st->p_sch[(k + 1) % 2], st->gamma[(k + 1) % 2],
+            st->diff_hist ? st->diff_hist + (int64_t)k * d.n_homes : d.diff, d.dsq, d.status, d.pdhg_dual,
             (float)d.kappa, d.mode, &d.pdhg, d.node_of, p_next, st->p_est[(k + 2) % 3], sx, stream);
         if (rc != REVS_OK) return rc;
         if (plan->comm) rc = revs_comm_allreduce_f64(plan->comm, p_next, mt, 0, stream);
@@ -948,6 +951,6 @@ out:
     if (failed_at >= 0 || rc != REVS_OK)
         (void)hipStreamSynchronize(s);                   // the launches behind the failed one are no-ops
     *kept_steps = kept;
-    stream_rotate(st, kept);              // the roles, by the kept steps
+    stream_rotate(st, kept, d.n_homes);   // the roles, by the kept steps
     return rc;
 }

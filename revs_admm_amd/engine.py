@@ -820,13 +820,34 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
             pass
 
     def run(self, iter_max=15):
-        """Full solve_ADMM loop; returns diff (iter_max, n) in the caller's home order."""
-        diffs = np.zeros((iter_max, self.n), np.float32)
-        for k in range(iter_max):
-            self.step(write_sc=(k == iter_max - 1))
-            diffs[k] = self.diff.cpu().numpy()[self.inv_perm]      # (synchronises)
-            self.check_status()
-        return diffs
+        """Full solve_ADMM loop; returns diff (iter_max, n) in the caller's home order.
+        The per-iteration diff of every residence (lpsolver.py:284) is collected on the device --
+        the steady-state launches write their row themselves -- and fetched in pieces of at most
+        2 GB: the host is not in the loop of the iterations, only a residence that cannot reach
+        90 % SOC is reported right after the first iteration, as the reference does."""
+        diffs = torch.empty((iter_max, self.n), dtype=torch.float32)
+        rows = max(1, min(iter_max, int(2e9) // (4 * max(self.n, 1))))
+        hist = torch.empty((rows, self.n), dtype=torch.float32, device=self.dev)
+        inv = torch.from_numpy(np.ascontiguousarray(self.inv_perm, dtype=np.int64)).to(self.dev)
+        k = 0
+        while k < iter_max:
+            base, r = k, 0
+            while r < rows and k < iter_max:
+                last = k == iter_max - 1
+                if (not last and self._stream_ok() and self._fused_ready):
+                    done = self._stream_run(min(rows - r, iter_max - 1 - k), hist[r:])
+                else:
+                    self.step(write_sc=last)
+                    hist[r].copy_(self.diff)
+                    done = 1
+                    if k == 0:
+                        self.check_status()          # (synchronises once)
+                k += done
+                r += done
+            # (back to the caller's home order on the device: one gather, one copy)
+            diffs[base:k].copy_(hist[:r].index_select(1, inv))
+        self.check_status()
+        return diffs.numpy()
 
     # ------------------------------------------------------- state in / out
     def set_state(self, P_est, P_sch, G, iteration=None):

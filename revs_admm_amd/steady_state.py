@@ -51,11 +51,14 @@ class SteadyStateMixin:
                 and o.speculate and self._spec_ok and o.fuse_home_pass and not self._y_support
                 and (self.group is None or self._comm is not None))
 
-    def _stream_run(self, count):
+    def _stream_run(self, count, hist=None):
         """Up to `count` steady-state iterations (at most the current burst), one launch each,
         enqueued in one go by the native loop; the first iteration whose rows are not within
         tolerance silences the launches behind it and is finished here as step() finishes a
-        discarded speculative sweep.  Returns the number of iterations done (at least one)."""
+        discarded speculative sweep.  Returns the number of iterations done (at least one).
+        `hist`: float[>= count][n] on the device -- row i receives the residences' diff of the
+        i-th iteration done here (run(): solve_ADMM's per-iteration diff without a host round
+        trip per iteration)."""
         o = self.op
         p0 = self._fused_p
         d0 = _dp(p0)
@@ -89,6 +92,7 @@ class SteadyStateMixin:
             by[a], by[b] = pss[i], gs[i]
         kept, rm = self._stream_out
         count = min(count, self._burst)
+        st.diff_hist = None if hist is None else hist.data_ptr()
         check(self.lib.revs_plan_stream_run(self._plan, count, self._stream_st_ref, self._scale, o.eps,
                                             self._stream_out_ref[0], self._stream_out_ref[1], self.stream),
               "revs_plan_stream_run")
@@ -111,6 +115,8 @@ class SteadyStateMixin:
             self._spec_back = 1
             self.iteration += n
         if n == count:
+            if hist is not None:
+                self.diff.copy_(hist[n - 1])         # (self.diff: always the last iteration's)
             return n
         # iteration n's verdict failed (its sweep wrote to the spares only; every launch behind
         # it was a no-op): finish it as step() does for a discarded speculative sweep
@@ -118,4 +124,6 @@ class SteadyStateMixin:
         self._spec_discard(None, False)
         self.P_est, self.P_est_new = self.P_est_new, self.P_est
         self.iteration += 1
+        if hist is not None:
+            hist[n].copy_(self.diff)
         return n + 1

@@ -702,6 +702,37 @@ def test_block_verdicts_equal_per_launch_verdicts(gpu_lib, mode, n, nodes, seed,
         np.testing.assert_array_equal(x, y)
 
 
+@pytest.mark.parametrize("mode,block", [("pdhg", 0), ("relaxed_exact", 0), ("binary", 0), ("pdhg", 5)])
+def test_run_collects_every_iterations_diff_on_the_device(gpu_lib, mode, block):
+    """AdmmEngine.run (what lpsolver.solve_ADMM calls) lets the steady-state launches write each
+    iteration's diff into a history on the device and fetches it in one piece; the rows must be
+    what a loop of step() reads back iteration by iteration -- through the transient, kept and
+    discarded sweeps, and the last iteration's S and C."""
+    from helpers import f32
+    from revs_admm_amd.engine import OperatorOptions
+    from revs_admm_amd.synthetic import make_workload
+    w = make_workload(8000, 24, n_nodes=200, seed=3, binary_feasible=(mode == "binary"),
+                      stress=0.5 if mode == "binary" else 1.02)
+    w.load, w.cost = f32(w.load), f32(w.cost)
+    K = 70
+    a = _engine(w, mode)
+    ref = np.zeros((K, a.n), np.float32)
+    for k in range(K):
+        a.step(write_sc=(k == K - 1))
+        ref[k] = a.diff.cpu().numpy()[a.inv_perm]
+    b = _engine(w, mode, op=OperatorOptions(stream_block=max(block, 1), stream_block_single=block > 0))
+    d = b.run(K)
+    assert b.spec_hist == a.spec_hist and b.spec_hist[0] > 30      # the streaming loop did the work
+    assert len(b.stream_calls) < 15                                # ... in bursts, not iteration by iteration
+    if mode == "pdhg":
+        # (a discarded PDHG sweep leaves other warm-start multipliers when it ran inside a burst)
+        np.testing.assert_allclose(d, ref, rtol=0, atol=2e-6)
+    else:
+        np.testing.assert_array_equal(d, ref)
+    for x, y in zip(a.result(), b.result()):
+        np.testing.assert_allclose(x, y, rtol=0, atol=0 if mode != "pdhg" else 2e-5)
+
+
 def test_status_flags_surface_through_run_steps(gpu_lib):
     """A PDHG residence that stops at its iteration cap, or a residence whose window cannot
     reach 90 % SOC, is reported by the sweeps themselves (status bits OR-ed into a word the
