@@ -173,11 +173,14 @@ template <int LPA, int SPL, int MODE, bool FULL_ROWS = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SPL <= 4 && !FULL_ROWS ? 8 : 4)))
 void agent_step_kernel(const AgentArgs a) {
     constexpr int kHomesPerBlock = kBlock / LPA;
-    if (a.ctl) {       // an earlier launch of this call failed its verdict: no-op
-        const unsigned int bad = a.ctl->bad_seq;
-        if (bad >= a.base_seq && bad < a.seq) return;
-    }
+    // An earlier launch of this call failed its verdict: this launch must write nothing.  The
+    // control word is requested here and tested where the residences' own loads have been issued
+    // (reading is harmless): one loaded memory round trip per workgroup less in front of them.
+    unsigned int bad = 0u;
+    if (a.ctl) bad = a.ctl->bad_seq;
+    const bool silenced = a.ctl && bad >= a.base_seq && bad < a.seq;
     if (a.nsel > 0 && (int)blockIdx.x < a.nsel) {          // uniform per workgroup
+        if (silenced) return;
         if (a.tree.n > 0) stream_verdict_body(a, (int)blockIdx.x);
         else dual_select_body(a.sel, (int)blockIdx.x);
         return;
@@ -247,6 +250,7 @@ void agent_step_kernel(const AgentArgs a) {
         h.ev = 0; h.start = 0; h.end = 0; h.nmin = 0; h.nmax = 0;
         h.rating = 0.f; h.capacity = 1.f; h.initial = 0.f;
     }
+    if (silenced) return;
     int base = 0;
     if (a.p_next) {      // (behind the loads: the barrier does not wait for them)
         for (int i = tid; i < kNodeLoc * kSlots; i += kBlock) (&nacc[0][0])[i] = 0.0;
