@@ -712,6 +712,43 @@ def solve_central_lp(tariff, h: Homes, Rn, node_of, vset, vlow, vhigh, binary=Fa
     return p, g, per_home, float(per_home.sum())
 
 
+def solve_central_ref(tariff, h: Homes, R_res, vset, vmin, vmax, time_limit=120.0):
+    """lpsolver.solve_central itself (lpsolver.py:463-502) as a MILP through HiGHS:
+        min  sum_h tariff . g_h,   g_h = p_h + LOAD_h           (add_home_load, objective_centralized)
+        p_h = e_h rating_h, e binary, e = 0 outside [start, end); init <= s_t <= 1 with
+        s_t = init + sum_{tau < t} p_tau / capacity -- NO s_T >= 0.9 row   (add_home_EV, 338-379)
+        vmin^2 - vset^2 <= -R_res g[:, t] <= vmax^2 - vset^2             (network_constraints, 386-405)
+    one residence per row of R_res (the reference's `res` order).  Returns p (N,T), g (N,T),
+    total cost; raises RuntimeError where the reference prints 'No solution found'."""
+    from scipy import sparse
+    from scipy.optimize import Bounds, LinearConstraint, milp
+    N, T = h.LOAD.shape
+    c = np.asarray(tariff, float)
+    vlo, vhi = vmin * vmin - vset * vset, vmax * vmax - vset * vset
+    win = h.window()
+    rate = np.where(h.ev, h.rating, 0.0)
+    cost = (rate[:, None] * c[None, :]).ravel()              # in e; the LOAD term is a constant
+    cons = []
+    # p >= 0: the SOC is nondecreasing, so init <= s_t <= 1 is sum_t p_t / capacity <= 1 - init
+    rows = np.repeat(np.arange(N), T)
+    Asoc = sparse.csr_matrix((np.repeat(rate / np.where(h.ev, h.capacity, 1.0), T), (rows, np.arange(N * T))),
+                             shape=(N, N * T))
+    cons.append(LinearConstraint(Asoc, -np.inf, np.where(h.ev, 1.0 - h.initial, 0.0) + 1e-12))
+    base = -(R_res @ h.LOAD)                                  # (N,T): -R_res LOAD
+    Bs = sparse.csr_matrix(-R_res * rate[None, :])
+    sel = [sparse.csr_matrix((np.ones(N), (np.arange(N), np.arange(N) * T + t)), shape=(N, N * T))
+           for t in range(T)]
+    Av = sparse.vstack([Bs @ sel[t] for t in range(T)]).tocsr()
+    cons.append(LinearConstraint(Av, (vlo - base).T.ravel(), (vhi - base).T.ravel()))
+    r = milp(cost, constraints=cons, bounds=Bounds(0.0, win.astype(float).ravel()),
+             integrality=np.ones(N * T), options=dict(time_limit=time_limit, presolve=True))
+    if r.x is None:
+        raise RuntimeError(f"solve_central_ref: {r.message}")
+    p = np.round(r.x).reshape(N, T) * rate[:, None]
+    g = p + h.LOAD
+    return p, g, float((g @ c).sum())
+
+
 # --------------------------------------------------------------------------
 # individual mode
 # --------------------------------------------------------------------------

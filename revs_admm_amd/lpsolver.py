@@ -154,40 +154,55 @@ def solve_central(tariff, homes, dist, path, vset, vmin, vmax, device="cuda:0"):
     add_home_EV, lines 338-379) and vmin^2 - vset^2 <= -R_res g[:,t] <= vmax^2 - vset^2
     (network_constraints, lines 386-405).
 
-    Every tariff is positive and nothing rewards charging, so the optimum of that model is
-    p = 0 whenever it is feasible, and it is feasible iff the base load alone respects the
-    voltage rows (p >= 0 can only push -R g further down).  So this is the operator's
-    voltage check R.LOAD on the GPU (revs_voltage_f32) plus the trivial schedule -- which is
-    exactly what the reference stored for the 121144 feeder (all chargers off, SOC 0.2).
+    Nothing in that model asks for charge, so a charger is switched on only where the price
+    is negative: per residence the most negative slots of its window, at most as many as the
+    SOC box allows (n_max; ties to the earlier slot) -- with every price >= 0 that is "no
+    charging", which is exactly what the reference stored for the 121144 feeder (all chargers
+    off, SOC 0.2).  The residences decouple as long as that schedule respects the voltage rows,
+    which is checked on the GPU (revs_voltage_f32: -R_res g); then it IS the model's optimum.
     Returns (p_opt, s_opt, g_opt) dicts; raises RevsError where the reference prints
-    'No solution found' (infeasible base load)."""
+    'No solution found' (the base load alone violates the rows), and NotImplementedError when
+    negative prices pull so much charging in that voltage rows bind (a coupled MILP: not done)."""
     import torch
     from ._lib import check, load, ptr
     from .engine import _dev_check, voltage_limits
-    if min(tariff) <= 0:
-        raise NotImplementedError("solve_central with a non-positive tariff is not the trivial "
-                                  "model (DESIGN.md section 7)")
     lib, dev = load(), _dev_check(device)
     res = [n for n in dist if dist.nodes[n]["label"] == "H"]
     nonsub = [n for n in dist.nodes if dist.nodes[n]["label"] != "S"]
     load_, rec = homes_to_arrays(homes, res)
     T, m = len(tariff), len(res)
+    c = np.asarray(tariff, float)
+    p = np.zeros((m, T))
+    neg = np.flatnonzero(c < 0)
+    if len(neg):
+        order = neg[np.argsort(c[neg], kind="stable")]           # most negative first, earlier slot on ties
+        for i in np.flatnonzero(rec["ev"]):
+            slots = order[(order >= rec["start"][i]) & (order < rec["end"][i])][:max(int(rec["nmax"][i]), 0)]
+            p[i, slots] = rec["rating"][i]
     R = compute_Rmat(dist)
     pos = {n: i for i, n in enumerate(nonsub)}
     resind = [pos[n] for n in res]
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
-    dR, dP = up(R[np.ix_(resind, resind)]), up(load_)
-    dV = torch.zeros(m, T, dtype=torch.float32, device=dev)
-    check(lib.revs_voltage_f32(m, T, ptr(dR), ptr(dP), ptr(dV),
-                               torch.cuda.current_stream(dev).cuda_stream), "revs_voltage_f32")
-    v = -dV.cpu().numpy().astype(np.float64)
     vlo, vhi = voltage_limits(vset, vmin, vmax)
     tol = 1e-6 * max(abs(vlo), abs(vhi))
-    if v.min() < vlo - tol or v.max() > vhi + tol:
+    dR = up(R[np.ix_(resind, resind)])
+
+    def rows_ok(g):
+        dP, dV = up(g), torch.zeros(m, T, dtype=torch.float32, device=dev)
+        check(lib.revs_voltage_f32(m, T, ptr(dR), ptr(dP), ptr(dV),
+                                   torch.cuda.current_stream(dev).cuda_stream), "revs_voltage_f32")
+        v = -dV.cpu().numpy().astype(np.float64)
+        return v.min() >= vlo - tol and v.max() <= vhi + tol
+
+    if not rows_ok(load_ + p):
+        if p.any() and rows_ok(load_):
+            raise NotImplementedError("solve_central: with these negative prices the voltage rows bind "
+                                      "and the residences no longer decouple (DESIGN.md section 7)")
         raise _lib.RevsError("No solution found (lpsolver.py:495-497): the base load alone "
                              "violates the voltage limits")
-    p_opt = {h: np.zeros(T) for h in res}
-    s_opt = {h: (np.full(T + 1, float(rec["initial"][i])) if rec["ev"][i] else np.zeros(T + 1))
-             for i, h in enumerate(res)}
-    g_opt = {h: load_[i].copy() for i, h in enumerate(res)}
+    cap = np.where(rec["ev"], rec["capacity"], 1.0)
+    soc = rec["initial"][:, None] + np.concatenate([np.zeros((m, 1)), np.cumsum(p, 1)], 1) / cap[:, None]
+    p_opt = {h: p[i].copy() for i, h in enumerate(res)}
+    s_opt = {h: (soc[i] if rec["ev"][i] else np.zeros(T + 1)) for i, h in enumerate(res)}
+    g_opt = {h: load_[i] + p[i] for i, h in enumerate(res)}
     return p_opt, s_opt, g_opt

@@ -256,6 +256,43 @@ def test_centralized_mode_golden(gpu_lib, golden):
         solve_central(z["tariff_shift6"].tolist(), homes, g, None, 1.03, 0.99, 1.05)
 
 
+def test_centralized_mode_negative_prices(gpu_lib, golden):
+    """solve_central where some prices are negative: the chargers go on in the most negative slots of
+    their windows, as many as the SOC box allows, as long as the voltage rows stay respected
+    (checked on the GPU) -- the optimum of the reference's model (lpsolver.py:463-502), which the
+    oracle solves as a MILP.  When the rows would bind, it says so instead of returning something."""
+    from oracle import revs_oracle as ro
+    from revs_admm_amd.extract import get_homes_ev_param
+    from revs_admm_amd.lpsolver import compute_Rmat, homes_to_arrays, solve_central
+    z, fd = golden
+    g = _nx_graph(fd, z)
+    res = z["res_id"].tolist()
+    ev = z["cen_a90_r4800_ev_homes"]
+    homes = get_homes_ev_param({h: z["LOAD"][i].tolist() for i, h in enumerate(res)}, g, ev,
+                               4.8, 20, 0.2, 11, 23)
+    tariff = np.array(z["tariff_shift6"], float)
+    tariff[[12, 13, 20]] = [-0.02, -0.05, -0.02]          # a tie between slots 12 and 20
+    tariff[3] = -1.0                                      # outside every window: never used
+    p, s, gg = solve_central(tariff.tolist(), homes, g, None, 1.03, 0.90, 1.05)
+    P = np.array([p[h] for h in res])
+    assert (P[:, 3] == 0).all() and P[:, 13].max() == pytest.approx(4.8) and P.sum() > 0
+    nonsub = [n for n in g.nodes if g.nodes[n]["label"] != "S"]
+    ri = [nonsub.index(n) for n in res]
+    R_res = compute_Rmat(g)[np.ix_(ri, ri)]
+    load_, rec = homes_to_arrays(homes, res)
+    p_ref, g_ref, tot_ref = ro.solve_central_ref(tariff, ro.homes_from_records(load_, rec), R_res, 1.03, 0.90, 1.05)
+    tot = sum(float(np.dot(tariff, gg[h])) for h in res)
+    assert tot == pytest.approx(tot_ref, rel=1e-12, abs=1e-9)
+    assert P.sum(1) == pytest.approx(p_ref.sum(1))            # same number of slots per residence
+    S = np.array([s[h] for h in res])
+    assert S.max() <= 1.0 + 1e-9 and (np.diff(S, axis=1) >= -1e-12).all()
+    # a floor the extra charging cannot respect: the rows bind, the residences do not decouple
+    v = -(R_res @ (load_ + P))
+    vmin_tight = float(np.sqrt(1.03 ** 2 + 0.5 * (v.min() + (-(R_res @ load_)).min())))
+    with pytest.raises(NotImplementedError, match="voltage rows bind"):
+        solve_central(tariff.tolist(), homes, g, None, 1.03, vmin_tight, 1.05)
+
+
 def _operator_kkt_f64(e):
     """KKT certificate of the operator's last answer on the node-space fast path, recomputed
     in float64 on the host from the engine's state: stationarity kappa d + Rs y = 0, rows

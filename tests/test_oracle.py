@@ -236,6 +236,22 @@ def test_central_lp(golden):
     assert -1e-3 < dev_total < 0.01, dev_total
 
 
+def test_central_ref_model_on_the_golden_feeder(golden, feeder_R):
+    """solve_central_ref -- lpsolver.solve_central's own model (no s_T >= 0.9 row, -R g between the
+    limits) -- returns what the reference stored for the 121144 feeder: every charger off,
+    P_res = LOAD; and with a negative price it switches on exactly the slots that pay."""
+    from conftest import golden_homes
+    z, fd = golden
+    h, _ = golden_homes(z, "cen_a90_r4800", 4.8)
+    p, g, tot = ro.solve_central_ref(z["tariff_shift6"], h, feeder_R, 1.03, 0.90, 1.05)
+    assert (p == 0).all()
+    np.testing.assert_allclose(g, z["cen_a90_r4800_P_res"], atol=1e-9)
+    t2 = np.array(z["tariff_shift6"], float)
+    t2[13] = -0.05
+    p2, g2, tot2 = ro.solve_central_ref(t2, h, feeder_R, 1.03, 0.90, 1.05)
+    assert (p2[h.ev, 13] == h.rating[h.ev]).all() and p2.sum() == pytest.approx(h.rating[h.ev].sum())
+
+
 def test_central_milp_small():
     """Binary chargers (the reference's home model) in the centralized problem: a MILP through
     HiGHS; bounded below by its LP relaxation, schedules on/off at full rating, rows respected."""
