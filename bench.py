@@ -3,9 +3,16 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--homes H] [--T 24] [--mode pdhg]
 
-N > 1 is launched by the driver as
+N > 1: one rank per GPU, the library's own RCCL communicator (bootstrapped over torch.distributed).
+Either the driver starts the ranks,
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-(one rank per GPU; the library's own RCCL communicator, bootstrapped over torch.distributed).
+or `python bench.py --gpus N` starts them itself: with no WORLD_SIZE in the environment the parent
+-- which makes no GPU call -- spawns N fresh child processes (RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* set, 127.0.0.1), relays rank 0's JSON line and exits non-zero if any child does.
+`--scaling weak` (default): every GPU owns `--homes` residences; `--scaling strong`: `--homes` is
+the total, split over the GPUs (BASELINE config 2: 100 000 homes over 8 GPUs = 12 500 each).
+`--share-gpu`: all ranks on cuda:0 with the node sums through the library's hook communicator over
+gloo -- the rehearsal of the N > 1 path on a one-GPU box (RCCL refuses two ranks on one device).
 A "step" is ONE ADMM iteration of lpsolver.solve_ADMM (reference lpsolver.py:254-287) over all
 residences: the operator's answer and its voltage rows, every home QP (batched PDHG kernel),
 the dual update and the per-home residual terms.  Weak scaling: every GPU owns `--homes`
@@ -138,15 +145,59 @@ def cpu_baseline(w, state, budget_s=20.0):
                       f"sums and the dense {w.M}x{w.M}x{w.T} voltage product ({t_op * 1e3:.0f} ms, numpy BLAS)"}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks of this script (this
+    process has made no GPU call and makes none), relay rank 0's stdout, exit with the first
+    failing rank's code.  Children are separate processes started with Popen -- never exec."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1",
+                   OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", REVS_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=120 if rc == 0 else 5)
+        except subprocess.TimeoutExpired:
+            p.kill()                      # (exactly the process started above)
+            p.wait()
+        rc = rc or p.returncode
+    for line in (out0 or "").splitlines():       # the JSON line to stdout, library chatter to stderr
+        print(line, file=sys.stdout if line.lstrip().startswith("{") else sys.stderr)
+    sys.stdout.flush()
+    if rc:
+        raise SystemExit(rc if rc > 0 else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --homes residences per GPU; strong: --homes in total, split over the GPUs")
+    ap.add_argument("--spawn", action="store_true",
+                    help="start the ranks as child processes even for --gpus 1 (rehearsal of the launcher)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rendezvous only (gloo, no GPU): rank 0 prints the launch topology -- the CPU "
+                         "test of the launcher")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="all ranks on cuda:0, node sums through the hook communicator over gloo "
+                         "(rehearsal of N > 1 on a one-GPU box)")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--spinup", type=int, default=30,
                     help="ADMM iterations run (untimed, but reported) before the warm-up so that "
                          "the timed steps start from a mid-run state")
-    ap.add_argument("--homes", type=int, default=100_000, help="residences per GPU")
+    ap.add_argument("--homes", type=int, default=100_000,
+                    help="residences per GPU (--scaling weak) or in total (--scaling strong)")
     ap.add_argument("--T", type=int, default=24)
     ap.add_argument("--nodes", type=int, default=2048)
     ap.add_argument("--mode", default="pdhg", choices=["pdhg", "relaxed_exact", "binary"])
@@ -174,25 +225,47 @@ def main():
                     help="skip the untimed run to the eps-residual (profiling runs)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.spawn):
+        return spawn_ranks(args.gpus)        # before anything touches the GPU
+
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE = {world}")
+    if args.dry_run:
+        dist.init_process_group("gloo")
+        t = torch.tensor([float(rank), float(local), 1.0], dtype=torch.float64)
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "sum_ranks": t[0].item(),
+                              "sum_local_ranks": t[1].item(), "ranks_seen": t[2].item(),
+                              "scaling": args.scaling,
+                              "launcher": "self" if os.environ.get("REVS_BENCH_CHILD") else "external"}),
+                  flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU")
+    if args.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = f"cuda:{local}"
     group = None
-    if world > 1 or os.environ.get("REVS_FORCE_GROUP"):      # (1-rank group: rehearsal of N > 1)
+    if world > 1 or os.environ.get("REVS_FORCE_GROUP") or os.environ.get("REVS_BENCH_CHILD"):
+        # (a 1-rank group rehearses the N > 1 code on one GPU)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if "RANK" not in os.environ:
             os.environ.update(RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if args.share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))
         group = dist.group.WORLD
 
     from revs_admm_amd.engine import AdmmEngine, OperatorOptions
@@ -205,7 +278,7 @@ def main():
             torch.cuda.synchronize()
 
     def build(homes, T, mode, stress, voltage):
-        n_total = homes * world
+        n_total = homes * world if args.scaling == "weak" else homes
         w = make_workload(n_total, T, n_nodes=args.nodes, seed=args.seed,
                           binary_feasible=(mode == "binary"), stress=stress)
         lo, hi = w.shard(rank, world)
@@ -242,7 +315,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.share_gpu else dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = t.item()
         ms = C.c_double()
@@ -259,7 +332,7 @@ def main():
             eng._gemm1(eng.R64T, eng.pnq[2], eng.v_sl)
 
     w, eng, (lo, hi) = build(args.homes, args.T, args.mode, args.stress, args.voltage)
-    n_total, n_local = args.homes * world, hi - lo
+    n_total, n_local = w.N, hi - lo
     barrier()       # ranks leave the set-up together (a step waits for every rank's all-reduce)
 
     # Spin-up: the transient -- every charger jumps to the cheapest slots, voltage rows bind and
@@ -385,19 +458,22 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"synthetic {args.homes} homes/GPU x T={args.T} box+SOC home QP, "
+                "workload": f"synthetic {n_local} homes/GPU x T={args.T} ("
+                            + (f"weak scaling: {args.homes} per GPU" if args.scaling == "weak" else
+                               f"strong scaling: {n_total} in total over {world} GPU(s), BASELINE config 2's shape")
+                            + ") box+SOC home QP, "
                             f"{args.nodes}-node radial feeder, one ADMM iteration per step (voltage "
                             "rows of the operator's estimate + all home QPs + dual update + "
                             f"residual terms), timed from a state {args.spinup + args.warmup} ADMM "
                             "iterations into the run; the transient before it is in "
                             "breakdown.transient, the binding / binary / 125k x 96 regimes in "
                             "value_binding / value_binary / value_125k_T96",
-                "homes_per_gpu": args.homes, "homes_total": n_total, "T": args.T,
+                "homes_per_gpu": n_local, "homes_total": n_total, "T": args.T,
                 "nodes": args.nodes, "home_solver": args.mode, "kappa": w.kappa,
                 "operator_dtype": "f64", "parallelism": f"homes sharded x{world}, nodes replicated, "
                                                         "node sums all-reduced"
@@ -409,7 +485,10 @@ def main():
                 "launches_per_step": 1 if streamed else 2,
                 "recompute_pe_new": rec,
                 "collective": (None if world == 1 and group is None else
-                               ("library-owned RCCL communicator" if eng._comm else "torch.distributed")),
+                               ("hook communicator over gloo, all ranks on cuda:0 (rehearsal)" if args.share_gpu
+                                else "library-owned RCCL communicator" if eng._comm else "torch.distributed")),
+                "launcher": ("bench.py spawned the ranks itself" if os.environ.get("REVS_BENCH_CHILD")
+                             else "external (torch.distributed.run)" if world > 1 else "single process"),
                 "clock_warmup_products": args.clock_warm,
             },
             "roofline": {

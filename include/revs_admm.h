@@ -31,6 +31,12 @@ extern "C" {
 
 /* Largest T the agent kernels are instantiated for. */
 #define REVS_MAX_T 192
+/* consecutive ADMM iterations one launch of the residence sweep can carry in registers
+ * (streaming steady state, multipliers zero; revs_plan_set_stream_inner) */
+#define REVS_AGENT_MAX_INNER 4
+/* the sweep leaves the largest diff of an iteration (the convergence measure, lpsolver.py:284) as
+ * REVS_DMAX_SLOTS partial maxima, workgroup b into slot b % REVS_DMAX_SLOTS */
+#define REVS_DMAX_SLOTS 64
 
 /* ---- per-residence data -------------------------------------------------
  * One record per home; replaces homes[h]["EV"] of the reference
@@ -513,6 +519,32 @@ int revs_newton_chain_accept(int32_t T, const double *s0, const double *s1, doub
                              int32_t amax, int32_t kadd, int32_t chain_few, int32_t *nsup_sum,
                              int32_t *nsup_max);
 
+/* `kin` (1..REVS_AGENT_MAX_INNER) consecutive ADMM iterations of every residence in ONE launch,
+ * for the regime in which the operator's multipliers are zero: its answer of iteration g + 1,
+ * P_est[g+1] = max((P_est[g] + P_sch[g])/2 - G[g]/kappa, 0) (lpsolver.py:196-207 with slack rows),
+ * is a function of the residence's own state, so the recurrence of lpsolver.py:254-287 touches no
+ * other residence -- only the voltage verdict does, and it is taken afterwards from the node sums
+ * this launch leaves (the streaming loop judges them by blocks and rolls back, see
+ * revs_plan_set_stream_block).  The state (P_est[g], P_sch[g], G[g], carried PDHG multipliers) is
+ * read once, kept in registers for kin iterations and written once: HBM bytes per iteration / kin.
+ * Bit for bit what kin launches of revs_agent_step_select's folded form compute.
+ *   p_est / p_sch / gamma      state at g (float[n][T]);  *_out: state at g + kin (other arrays)
+ *   p_est_next                 NULL, or P_est[g + kin + 1] (the estimate the next iteration consumes)
+ *   diff                       row i (stride diff_stride floats; 0: one row) = diff of iteration g + i
+ *   pdhg_dual / pdhg_dual_out  carried multipliers in / out (may be the same array; PDHG only)
+ *   p_next                     double, slice i at p_next + i * slice_stride: += node sums of
+ *                              P_est[g + i + 2] (zero on entry); node_of: node of every residence
+ *   dmax_out                   NULL, or (same stride) REVS_DMAX_SLOTS doubles per iteration: atomic max
+ *                              (on the bit pattern of a non-negative double) of the residences' diff
+ *                              of iteration g + i; the maximum over the slots is max_h diff[h] */
+int revs_agent_step_multi(int64_t n_homes, int32_t T, const float *cost, const revs_home_t *homes,
+                          const float *load, const float *p_est, const float *p_sch, const float *gamma,
+                          float *p_est_out, float *p_sch_out, float *gamma_out, float *p_est_next,
+                          float *diff, int64_t diff_stride, float *dsq, int32_t *status,
+                          float *pdhg_dual, float *pdhg_dual_out, float kappa, int32_t mode,
+                          const revs_pdhg_t *pdhg_host, const int32_t *node_of, double *p_next,
+                          int64_t slice_stride, double *dmax_out, int32_t kin, void *stream);
+
 /* ---- steady-state ADMM iteration as one host call ---------------------------------
  * The driver's loop of lpsolver.py:254-287 for the case "the operator's multipliers are
  * expected to stand" (revs_admm_amd/engine.py: AdmmEngine.step): enqueue one evaluation of
@@ -682,6 +714,15 @@ revs_comm_t *revs_comm_create(const void *id128, int32_t rank, int32_t nranks);
 void revs_comm_destroy(revs_comm_t *comm);
 int revs_comm_allreduce_f64(revs_comm_t *comm, double *buf, int64_t count, int32_t op /* 0 sum, 2 max, 3 min */,
                             void *stream);
+/* The same communicator over the CALLER's transport: `fn(ctx, host_buf, count, op)` must leave in
+ * host_buf (pinned host memory owned by the library, `count` doubles) the element-wise reduction
+ * over all ranks and return 0.  revs_comm_allreduce_f64 then waits for the stream, stages the
+ * buffer to the host, calls fn, and stages the result back before it returns -- synchronous,
+ * for ranks that have no RCCL path between them (RCCL refuses two ranks on one device; MPI or
+ * gloo over the host; the two-process tests of the sharded loop, tests/test_gpu_sharded.py).
+ * Every rank must make the same sequence of calls, as with RCCL. */
+typedef int (*revs_host_allreduce_fn)(void *ctx, double *host_buf, int64_t count, int32_t op);
+revs_comm_t *revs_comm_create_hook(revs_host_allreduce_fn fn, void *ctx, int32_t rank, int32_t nranks);
 
 /* ---- streaming steady state: one launch per ADMM iteration, no host in the loop ---------
  * While the operator's multipliers are zero an iteration of lpsolver.py:254-287 is ONE

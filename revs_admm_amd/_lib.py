@@ -75,6 +75,9 @@ class StreamState(C.Structure):
                 ("p", C.c_void_p * 3), ("diff_hist", C.c_void_p)]
 
 
+# revs_host_allreduce_fn
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int32)
+
 TREE_MAX = 2048          # REVS_TREE_MAX
 STREAM_BLOCK_MAX = 256   # REVS_STREAM_BLOCK_MAX
 
@@ -110,6 +113,8 @@ SIGNATURES = {
                                          _p, _p, _p, _f32, _i32, C.POINTER(PDHG), _i32, _p, _p,
                                          _f64, _f64, _i32, _p, _p, _p, _p, _p, _p, _f64, _p, _p, _p,
                                          _i32, _p]),
+    "revs_agent_step_multi": (C.c_int, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p,
+                                        _p, _p, _f32, _i32, C.POINTER(PDHG), _p, _p, _i64, _p, _i32, _p]),
     "revs_op_dual_product_rows": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _f64, _f64, _i32, _p, _p, _p,
                                             _p, _p, _p, _p]),
     "revs_residual_finalize": (C.c_int, [_p, _p, _i64, _i32, _f32, _f32, _p, _p, _p]),
@@ -163,6 +168,7 @@ SIGNATURES = {
     "revs_tree_voltage": (C.c_int, [_i32, _i32, C.POINTER(Tree), _p, _f64, _f64, _p, _p, _p]),
     "revs_comm_unique_id": (C.c_int, [_p]),
     "revs_comm_create": (C.c_void_p, [_p, _i32, _i32]),
+    "revs_comm_create_hook": (C.c_void_p, [_p, _p, _i32, _i32]),
     "revs_comm_destroy": (None, [_p]),
     "revs_comm_allreduce_f64": (C.c_int, [_p, _p, _i64, _i32, _p]),
     "revs_plan_set_tree": (C.c_int, [_p, C.POINTER(Tree)]),

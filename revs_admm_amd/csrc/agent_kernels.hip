@@ -79,7 +79,25 @@ struct AgentArgs {
     double *rec;           // this launch's record slot, double[4] (pinned host memory)
     unsigned int *flags;   // OR of status bits over all residences (pinned host memory), or NULL
     int32_t m;
+    // kin > 1: this launch does kin consecutive ADMM iterations of every residence, the state kept in
+    // registers (multipliers zero: the operator's answer of iteration g + 1 is a function of the
+    // residence's own state after iteration g) -- profiles read and written once per kin iterations.
+    // Inner iteration i accumulates its node sums into p_next + i * slice_stride, writes its diff to
+    // diff + i * diff_stride and the largest diff of this launch's residences into the REVS_DMAX_SLOTS
+    // doubles at dmax_out + i * slice_stride (atomic max on the bit pattern of a non-negative double,
+    // workgroup b into slot b % REVS_DMAX_SLOTS; NULL: not recorded).
+    // pe_out: P_est[g + kin] (the estimate the last inner iteration consumed); y_out: the carried
+    // PDHG multiplier after the last inner iteration (== y_state: in place).
+    int32_t kin;
+    float *pe_out;
+    float *y_out;
+    long long slice_stride, diff_stride;
+    double *dmax_out;
 };
+constexpr int kMaxInner = REVS_AGENT_MAX_INNER;
+#ifndef REVS_AGENT_MULTI_WAVES
+#define REVS_AGENT_MULTI_WAVES 5     // wavefronts per SIMD of the multi-iteration sweep (tuning: build with -D)
+#endif
 
 // SPL consecutive floats of one lane as ONE global_load/store_dwordxSPL: the 64 lanes of a
 // wavefront then cover one contiguous 64*SPL*4-byte span per instruction instead of SPL
@@ -169,8 +187,15 @@ __device__ __forceinline__ void stream_verdict_body(const AgentArgs &a, const in
 // launch takes 24-25 us against 20; without the prefetch the loop spills at the 64-register cap;
 // 16 homes per wavefront (4 lanes x 6 slots) squeezed to 72 VGPRs so that all 6 250 wavefronts are
 // resident at once: 22.7 us against 18.5.)
-template <int LPA, int SPL, int MODE, bool FULL_ROWS = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(SPL <= 4 && !FULL_ROWS ? 8 : 4)))
+// MULTI: the loop over AgentArgs::kin inner iterations exists (its loop-carried state -- five
+// profiles, the PDHG constants of the residence -- does not fit 64 VGPRs: the multi-iteration
+// form trades occupancy for registers, it is bound by instruction issue, not by memory latency);
+// without it the body runs once and compiles to the one-iteration kernel.
+constexpr int agent_waves(int spl, bool full_rows, bool multi) {
+    return (spl <= 4 && !full_rows) ? (multi ? REVS_AGENT_MULTI_WAVES : 8) : 4;
+}
+template <int LPA, int SPL, int MODE, bool FULL_ROWS = false, bool MULTI = false>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(agent_waves(SPL, FULL_ROWS, MULTI))))
 void agent_step_kernel(const AgentArgs a) {
     constexpr int kHomesPerBlock = kBlock / LPA;
     // An earlier launch of this call failed its verdict: this launch must write nothing.  The
@@ -191,6 +216,7 @@ void agent_step_kernel(const AgentArgs a) {
     const int T = a.T;
     const int t0 = lig * SPL;
     const float kappa = a.kappa;
+    const int kin = MULTI ? a.kin : 1;
     const bool tfull = t0 + SPL <= T;        // this lane's SPL slots all exist: one dwordxSPL per profile
     // pe_new == NULL (multipliers all zero): the operator's answer max(g0, 0) is recomputed
     // below from the three profiles it is a function of, instead of being read
@@ -204,13 +230,15 @@ void agent_step_kernel(const AgentArgs a) {
         cst[j] = tval[j] ? a.cost[t0 + j] : 0.f;
     }
     // node sums of the next home pass: residences are sorted by node, so a workgroup's homes
-    // sit on a few consecutive nodes -- accumulate in LDS, flush one global add per (node, slot).
+    // sit on a few consecutive nodes -- accumulate in LDS (one set per inner iteration), flush one
+    // global add per (iteration, node, slot) at the end of the launch.
     // (Measured and rejected, round 2: per-wavefront xor-shuffle reduction and one global add per
     // slot, no LDS and no workgroup barrier -- 19.5 us against 18.4 at T = 24, and 149 us against
     // 74 at 125 000 x 96, where a wavefront holds 4 residences and the memory-side f64 atomics
     // quadruple.)
     constexpr int kNodeLoc = 4, kSlots = LPA * SPL;
-    __shared__ double nacc[kNodeLoc][kSlots];
+    __shared__ double nacc[kMaxInner][kNodeLoc][kSlots];
+    __shared__ unsigned int dmx[kMaxInner];
     const int64_t first = (int64_t)bid * kHomesPerBlock;
     // Every global load of the kernel is issued before the first use of any of them (one exposed
     // memory latency per wavefront, not three): profiles, then the home record and the carried
@@ -253,12 +281,12 @@ void agent_step_kernel(const AgentArgs a) {
     if (silenced) return;
     int base = 0;
     if (a.p_next) {      // (behind the loads: the barrier does not wait for them)
-        for (int i = tid; i < kNodeLoc * kSlots; i += kBlock) (&nacc[0][0])[i] = 0.0;
+        for (int i = tid; i < kin * kNodeLoc * kSlots; i += kBlock) (&nacc[0][0][0])[i] = 0.0;
+        if (tid < kMaxInner) dmx[tid] = 0u;
         base = a.node_of[first < a.n ? first : a.n - 1];
         __syncthreads();
     }
     const bool full = live && tfull;
-    float q[SPL], p[SPL];
     bool valid[SPL], win[SPL];
 #pragma unroll
     for (int j = 0; j < SPL; ++j) valid[j] = live && tval[j];
@@ -271,24 +299,85 @@ void agent_step_kernel(const AgentArgs a) {
         }
     }
     const bool ev = h.ev != 0;
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+        const int t = t0 + j;
+        win[j] = ev && valid[j] && (t >= h.start) && (t < h.end);
+    }
+    const ScanMasks<LPA> mk(lig);
+    const int node = (a.p_next && live) ? a.node_of[agent] : 0;
 
+    // ---- what a residence's PDHG passes need and no ADMM iteration changes (hoisted out of the
+    // loop over the inner iterations) ----
+    // Per-home scalars are computed redundantly by the LPA lanes of the group: use the 1-ulp
+    // hardware reciprocal / square root instead of IEEE division (10 instructions each) -- step
+    // sizes need no exactness, and b, x0 only to the PDHG tolerance.
+    float inv_rate = 0.f, delta = 0.f, hi = 0.f, lo_last = 0.f, inv_kr = 0.f, wsum = 0.f;
+    float tau = 0.f, sig = 0.f, inv1pt = 0.f, sd = 0.f;              // FULL_ROWS
+    float tau1 = 0.f, inv1 = 0.f, sd1 = 0.f, ts = 0.f;               // presolved
+    float w[SPL];
+    bool pd_infeasible = false;
+    if constexpr (MODE == REVS_MODE_RELAXED_PDHG) {
+        const float rate = ev ? h.rating : 1.f;
+        inv_rate = __builtin_amdgcn_rcpf(rate);
+        delta = ev ? h.rating * __builtin_amdgcn_rcpf(h.capacity) : 1.f;
+        const int ws = max(h.start, 0), we = min(h.end, T);
+        const float Tw = (float)max(we - ws, 1);
+        hi = kSocMax - h.initial;
+        lo_last = fmaxf(kSocTarget, h.initial) - h.initial;
+        inv_kr = __builtin_amdgcn_rcpf(kappa * rate);
+        if constexpr (FULL_ROWS) {
+            const float inv_nK = __builtin_amdgcn_rcpf(delta * 0.63661977236758134f * (Tw + 1.0f));
+            tau = (a.pd.tau_scale > 0.f ? a.pd.tau_scale : 0.25f) * inv_nK;
+            sig = (a.pd.sigma_scale > 0.f ? a.pd.sigma_scale : 4.0f) * inv_nK;
+            inv1pt = __builtin_amdgcn_rcpf(1.0f + tau);
+            sd = sig * delta;
+        } else {
+            // Presolved form: with p >= 0 the SOC is nondecreasing, so of the rows
+            // init <= s_t <= 1, s_T >= 0.9 only the terminal one can bind.  K is then the
+            // single row delta * 1^T (||K|| = delta sqrt(T_w)), its dual one scalar per home,
+            // and K x a group sum -- no scans.
+            const float inv_nK1 = __builtin_amdgcn_rcpf(delta * __builtin_amdgcn_sqrtf(Tw));
+            tau1 = (a.pd.tau_scale > 0.f ? a.pd.tau_scale : 0.5f) * inv_nK1;
+            const float sig1 = (a.pd.sigma_scale > 0.f ? a.pd.sigma_scale : 2.0f) * inv_nK1;
+            inv1 = __builtin_amdgcn_rcpf(1.0f + tau1);
+            sd1 = sig1 * delta;
+            ts = tau1 * inv1 * sd1;
+        }
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) { w[j] = win[j] ? 1.f : 0.f; wsum += w[j]; }
+        // the window cannot deliver the energy to 90 % SOC: "No solution found"
+        wsum = group_sum<LPA>(wsum);
+        pd_infeasible = ev && (lo_last > delta * wsum * (1.f + 1e-6f));
+    }
+    float yrow[SPL];      // FULL_ROWS: the carried multipliers of the SOC rows
+    if constexpr (MODE == REVS_MODE_RELAXED_PDHG && FULL_ROWS) {
+#pragma unroll
+        for (int j = 0; j < SPL; ++j)
+            yrow[j] = (a.y_state && valid[j] && ev) ? a.y_state[row + t0 + j] : 0.f;
+    }
+    float yy = ev ? yy_in : 0.f;      // presolved PDHG: the carried multiplier of the terminal row
+
+    float p[SPL], gn[SPL], gmn[SPL], pe2[SPL];
+    int status = 0, sticky = 0;
+    float ddg = 0.f, dfh = 0.f;
+    const bool need_pe2 = a.p_next != nullptr;
+#pragma unroll 1
+    for (int it = 0;; ++it) {
+    float q[SPL];
     // No FMA contraction in the linear term and the keys: every slot must go through the
     // same rounding steps, so that equal inputs give equal keys ("ties to the earlier slot"
     // is the reference-visible rule) whatever the unrolled code looks like.
 #pragma unroll
     for (int j = 0; j < SPL; ++j) {
 #pragma clang fp contract(off)
-        const int t = t0 + j;
         // lpsolver.py:118-119  a_t = gamma_t + (kappa/2)(p_util_t + p_res_t)
         const float at = gm[j] + 0.5f * kappa * (pe[j] + pso[j]);
         // objective in p:  (kappa/2) p^2 + q p,  q = kappa*LOAD + c - a
         q[j] = kappa * L[j] + cst[j] - at;
-        win[j] = ev && valid[j] && (t >= h.start) && (t < h.end);
         p[j] = 0.f;
     }
-
-    int status = 0;
-    const ScanMasks<LPA> mk(lig);
+    status = 0;
 
     // A wavefront whose residences have no EV at all (the engine sorts like with like: 43 % of
     // the wavefronts of the bench workload) has nothing to solve: p = 0, status = 0 stand.
@@ -319,59 +408,25 @@ void agent_step_kernel(const AgentArgs a) {
     } else if constexpr (MODE == REVS_MODE_RELAXED_PDHG) {
         // PDHG on  min x^2/2 + b x,  0 <= x <= w,  lo <= K x <= hi,  x = p/rating,
         // K = delta * inclusive prefix sum (rows j: s_{j+1} - initial).
-        // Per-home scalars are computed redundantly by the LPA lanes of the group: use the
-        // 1-ulp hardware reciprocal / square root instead of IEEE division (10 instructions
-        // each) -- step sizes need no exactness, and b, x0 only to the PDHG tolerance.
-        const float rate = ev ? h.rating : 1.f;
-        const float inv_rate = __builtin_amdgcn_rcpf(rate);
-        const float delta = ev ? h.rating * __builtin_amdgcn_rcpf(h.capacity) : 1.f;
-        const int ws = max(h.start, 0), we = min(h.end, T);
-        const float Tw = (float)max(we - ws, 1);
-        const float inv_nK = __builtin_amdgcn_rcpf(delta * 0.63661977236758134f * (Tw + 1.0f));
-        const float tau = (a.pd.tau_scale > 0.f ? a.pd.tau_scale : 0.25f) * inv_nK;
-        const float sig = (a.pd.sigma_scale > 0.f ? a.pd.sigma_scale : 4.0f) * inv_nK;
-        const float inv1pt = __builtin_amdgcn_rcpf(1.0f + tau);
-        const float sd = sig * delta;
-        const float hi = kSocMax - h.initial;
-        const float lo_last = fmaxf(kSocTarget, h.initial) - h.initial;
-        const float inv_kr = __builtin_amdgcn_rcpf(kappa * rate);
-        float b[SPL], w[SPL], x[SPL], y[SPL], lo[SPL];
+        float b[SPL], x[SPL], lo[SPL];
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
             b[j] = q[j] * inv_kr;
-            w[j] = win[j] ? 1.f : 0.f;
             lo[j] = (t0 + j == T - 1) ? lo_last : 0.f;
             // warm start: primal from the previous schedule (P_sch[k] - LOAD), dual from
             // the previous iteration's multipliers when the caller keeps them
             x[j] = a.y_state ? fminf(fmaxf((pso[j] - L[j]) * inv_rate, 0.f), w[j]) : 0.f;
-            y[j] = (FULL_ROWS && a.y_state && valid[j] && ev) ? a.y_state[row + t0 + j] : 0.f;
         }
-        // the window cannot deliver the energy to 90 % SOC: "No solution found"
-        float wsum = 0.f;
-#pragma unroll
-        for (int j = 0; j < SPL; ++j) wsum += w[j];
-        wsum = group_sum<LPA>(wsum);
-        const bool infeasible = ev && (lo_last > delta * wsum * (1.f + 1e-6f));
+        const bool infeasible = pd_infeasible;
         bool done = !ev || infeasible;
         int iters = 0;
         const int check = max(a.pd.check, 1);
         if constexpr (!FULL_ROWS) {
-            // Presolved form: with p >= 0 the SOC is nondecreasing, so of the rows
-            // init <= s_t <= 1, s_T >= 0.9 only the terminal one can bind.  K is then the
-            // single row delta * 1^T (||K|| = delta sqrt(T_w)), its dual one scalar per home,
-            // and K x a group sum -- no scans.
-            const float inv_nK1 = __builtin_amdgcn_rcpf(delta * __builtin_amdgcn_sqrtf(Tw));
-            const float tau1 = (a.pd.tau_scale > 0.f ? a.pd.tau_scale : 0.5f) * inv_nK1;
-            const float sig1 = (a.pd.sigma_scale > 0.f ? a.pd.sigma_scale : 2.0f) * inv_nK1;
-            const float inv1 = __builtin_amdgcn_rcpf(1.0f + tau1);
-            const float sd1 = sig1 * delta;
-            float yy = ev ? yy_in : 0.f;
             // The sweep is VALU-issue bound and half of its instructions are this loop, so the
             // iteration is arranged for the fewest operations:
             //   x+ = clip((x - tau (sd y + b)) / (1 + tau), 0, w) = clip(a x - cb - s, 0, w),
             //        a = 1/(1+tau), cb = tau a b (per slot, once), s = tau a sd y (one multiply)
             //   K (2 x+ - x) = delta (2 sum x+ - sum x), with sum x carried from the last pass
-            const float ts = tau1 * inv1 * sd1;
             float cb[SPL], sx = 0.f;
 #pragma unroll
             for (int j = 0; j < SPL; ++j) { cb[j] = tau1 * inv1 * b[j]; sx += x[j]; }
@@ -394,7 +449,7 @@ void agent_step_kernel(const AgentArgs a) {
                 yy = yn;
                 return dmax;
             };
-            for (int it = 0; it < a.pd.max_iter; it += check) {
+            for (int k = 0; k < a.pd.max_iter; k += check) {
                 if (__all(done)) break;      // wave-uniform exit every wave reaches
                 for (int c = 1; c < check; ++c) iterate1(std::false_type{});
                 float res = iterate1(std::true_type{});
@@ -402,7 +457,7 @@ void agent_step_kernel(const AgentArgs a) {
                 res = group_max<LPA>(res);
                 done = done || (res <= a.pd.tol);
             }
-            if (a.y_state && live && lig == 0) a.y_state[agent] = ev ? yy : 0.f;
+            yy = ev ? yy : 0.f;
         } else {
         // y of padded slots must stay 0: give them lo = hi = 0 ... no: v - clip(v,0,0) = v.
         // Instead padded slots get lo = -inf, hi = +inf, so y = v - v = 0.
@@ -418,7 +473,7 @@ void agent_step_kernel(const AgentArgs a) {
             // K^T y : inclusive suffix sum of y
             float sfx[SPL], acc = 0.f;
 #pragma unroll
-            for (int j = SPL - 1; j >= 0; --j) { acc += y[j]; sfx[j] = acc; }
+            for (int j = SPL - 1; j >= 0; --j) { acc += yrow[j]; sfx[j] = acc; }
             const float so = group_excl_suffix<LPA>(acc, lig, mk);
             float xb[SPL], dmax = 0.f;
 #pragma unroll
@@ -437,17 +492,17 @@ void agent_step_kernel(const AgentArgs a) {
             const float po = group_excl_prefix<LPA>(acc, lig, mk);
 #pragma unroll
             for (int j = 0; j < SPL; ++j) {
-                const float v = y[j] + delta * (pfx[j] + po);
+                const float v = yrow[j] + delta * (pfx[j] + po);
                 const float yn = v - clip3(v, lo[j], hiv[j]);
-                if constexpr (RES) dmax = fmaxf(dmax, fabsf(yn - y[j]));
-                y[j] = yn;
+                if constexpr (RES) dmax = fmaxf(dmax, fabsf(yn - yrow[j]));
+                yrow[j] = yn;
             }
             return dmax;
         };
         // Homes of one wavefront iterate together until all of them have converged (a
         // converged home keeps iterating: it only moves closer to its optimum); `iters`
         // records when each home first met the tolerance.
-        for (int it = 0; it < a.pd.max_iter; it += check) {
+        for (int k = 0; k < a.pd.max_iter; k += check) {
             if (__all(done)) break;          // wave-uniform exit every wave reaches
             for (int c = 1; c < check; ++c) iterate(std::false_type{});
             float res = iterate(std::true_type{});
@@ -456,8 +511,7 @@ void agent_step_kernel(const AgentArgs a) {
             done = done || (res <= a.pd.tol);
         }
 #pragma unroll
-        for (int j = 0; j < SPL; ++j)
-            if (a.y_state && valid[j]) a.y_state[row + t0 + j] = ev ? y[j] : 0.f;
+        for (int j = 0; j < SPL; ++j) yrow[j] = ev ? yrow[j] : 0.f;
         }
 #pragma unroll
         for (int j = 0; j < SPL; ++j) p[j] = (ev && !infeasible) ? x[j] * h.rating : 0.f;
@@ -519,10 +573,8 @@ void agent_step_kernel(const AgentArgs a) {
             p[j] = (ev && !infeasible) ? fminf(fmaxf(u[j] + nu, 0.f), ub[j]) : 0.f;
     }
 
-    // ---- epilogue: g, SOC, dual update, residuals (lpsolver.py:275-284) ----
+    // ---- g, dual update, residual terms of this iteration (lpsolver.py:275-284) ----
     float ss = 0.f, dd = 0.f;
-    const int64_t crow = agent * (int64_t)(T + 1);
-    float gn[SPL], gmn[SPL], socv[SPL];
 #pragma unroll
     for (int j = 0; j < SPL; ++j) {
         const float g = p[j] + L[j];                        // lpsolver.py:64-65
@@ -533,6 +585,47 @@ void agent_step_kernel(const AgentArgs a) {
         ss += valid[j] ? chk * chk : 0.f;
         dd += valid[j] ? dg * dg : 0.f;
     }
+    // next evaluation's home pass (same arithmetic as op_dual_eval_kernel with d = 0)
+    if (need_pe2) {
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+            const float g0 = revs_g0f(pen[j], gn[j], gmn[j], inv_kf);
+            pe2[j] = (valid[j] && g0 > 0.f) ? g0 : 0.f;
+        }
+    }
+    // per-home residual terms; the norms over all homes are folded by revs_residual_finalize
+    // only when somebody asks for them (no workgroup reduction in the sweep, which is VALU
+    // issue bound)
+    const float ssg = group_sum<LPA>(ss);
+    ddg = group_sum<LPA>(dd);
+    // lpsolver.py:284; hardware sqrt and reciprocal (1 ulp each) instead of the IEEE sequences
+    dfh = live ? __builtin_amdgcn_sqrtf(ssg) * __builtin_amdgcn_rcpf((float)T) : 0.f;
+    sticky |= status & 3;
+    if (live && lig == 0) {
+        a.diff[(long long)it * a.diff_stride + agent] = dfh;
+        if (a.dmax_out) atomicMax(&dmx[it], __float_as_uint(dfh));     // (dfh >= 0: the bit patterns order)
+    }
+    if (a.p_next && live) {
+        const int loc = node - base;
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+            if (pe2[j] > 0.f) {      // (floats widened to double: the node sums are exact, whatever the order)
+                if (loc < kNodeLoc) unsafeAtomicAdd(&nacc[it][loc][t0 + j], (double)pe2[j]);
+                else unsafeAtomicAdd(&a.p_next[(long long)it * a.slice_stride + (int64_t)node * T + t0 + j],
+                                     (double)pe2[j]);
+            }
+        }
+    }
+    if (!MULTI || it + 1 >= kin) break;
+    // the next iteration of the same residences: P_est[g+1] = this iteration's estimate, P_est[g+2]
+    // the one just prepared -- exactly the floats a launch per iteration would write and read back
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) { pe[j] = pen[j]; pen[j] = pe2[j]; pso[j] = gn[j]; gm[j] = gmn[j]; }
+    }
+
+    // ---- stores: the state after the last inner iteration ----
+    const int64_t crow = agent * (int64_t)(T + 1);
+    float socv[SPL];
     if (a.c_out) {      // the SOC trajectory (a prefix sum over the slots) only where it is returned
         float pacc = 0.f, pfx[SPL];
 #pragma unroll
@@ -542,21 +635,13 @@ void agent_step_kernel(const AgentArgs a) {
 #pragma unroll
         for (int j = 0; j < SPL; ++j) socv[j] = ev ? h.initial + (pfx[j] + poff) * invcap : 0.f;
     }
-    // next evaluation's home pass (same arithmetic as op_dual_eval_kernel with d = 0)
-    float pe2[SPL];
-    if (a.p_next) {
-#pragma unroll
-        for (int j = 0; j < SPL; ++j) {
-            const float g0 = revs_g0f(pen[j], gn[j], gmn[j], inv_kf);
-            pe2[j] = (valid[j] && g0 > 0.f) ? g0 : 0.f;
-        }
-    }
     if (full) {
         st_pack<SPL>(a.ps_out + row + t0, gn);
         st_pack<SPL>(a.gam_out + row + t0, gmn);
+        if (a.pe_out) st_pack<SPL>(a.pe_out + row + t0, pen);
         if (a.s_out) st_pack<SPL>(a.s_out + row + t0, p);
         if (a.c_out) st_pack<SPL>(a.c_out + crow + t0 + 1, socv);
-        if (a.p_next) st_pack<SPL>(a.pe2_out + row + t0, pe2);
+        if (a.pe2_out) st_pack<SPL>(a.pe2_out + row + t0, pe2);
     } else {
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
@@ -565,46 +650,45 @@ void agent_step_kernel(const AgentArgs a) {
                 const int64_t o = row + t;
                 a.ps_out[o] = gn[j];
                 a.gam_out[o] = gmn[j];
+                if (a.pe_out) a.pe_out[o] = pen[j];
                 if (a.s_out) a.s_out[o] = p[j];
                 if (a.c_out) a.c_out[crow + t + 1] = socv[j];
-                if (a.p_next) a.pe2_out[o] = pe2[j];
+                if (a.pe2_out) a.pe2_out[o] = pe2[j];
             }
         }
     }
-    if (live && lig == 0 && a.c_out) a.c_out[crow] = ev ? h.initial : 0.f;
-    // per-home residual terms; the norms over all homes are folded by revs_residual_finalize
-    // only when somebody asks for them (no workgroup reduction in the sweep, which is VALU
-    // issue bound)
-    const float ssg = group_sum<LPA>(ss);
-    const float ddg = group_sum<LPA>(dd);
-    // lpsolver.py:284; hardware sqrt and reciprocal (1 ulp each) instead of the IEEE sequences
-    const float dfh = live ? __builtin_amdgcn_sqrtf(ssg) * __builtin_amdgcn_rcpf((float)T) : 0.f;
-    if (live && lig == 0) {
-        a.diff[agent] = dfh;
-        a.dsq[agent] = ddg;
-        if (a.status) a.status[agent] = status;
-        if (a.flags && (status & 3))         // rare: straight into the host's word
-            __hip_atomic_fetch_or(a.flags, (unsigned int)(status & 3), __ATOMIC_RELAXED,
-                                  __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    if (a.p_next && live) {
-        const int node = a.node_of[agent];
-        const int loc = node - base;
+    if constexpr (MODE == REVS_MODE_RELAXED_PDHG && FULL_ROWS) {
 #pragma unroll
-        for (int j = 0; j < SPL; ++j) {
-            if (pe2[j] > 0.f) {      // (floats widened to double: the node sums are exact, whatever the order)
-                if (loc < kNodeLoc) unsafeAtomicAdd(&nacc[loc][t0 + j], (double)pe2[j]);
-                else unsafeAtomicAdd(&a.p_next[(int64_t)node * T + t0 + j], (double)pe2[j]);
-            }
-        }
+        for (int j = 0; j < SPL; ++j)
+            if (a.y_out && valid[j]) a.y_out[row + t0 + j] = yrow[j];
+    }
+    if (live && lig == 0) {
+        if constexpr (MODE == REVS_MODE_RELAXED_PDHG && !FULL_ROWS)
+            if (a.y_out) a.y_out[agent] = yy;
+        if (a.c_out) a.c_out[crow] = ev ? h.initial : 0.f;
+        a.dsq[agent] = ddg;
+        const int st = status | sticky;
+        if (a.status) a.status[agent] = st;
+        if (a.flags && (st & 3))         // rare: straight into the host's word
+            __hip_atomic_fetch_or(a.flags, (unsigned int)(st & 3), __ATOMIC_RELAXED,
+                                  __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (a.p_next) {
         __syncthreads();
-        for (int i = tid; i < kNodeLoc * T; i += kBlock) {
-            const int l = i / T, t = i - l * T;
-            const double v = nacc[l][t];
-            if (v != 0.0) unsafeAtomicAdd(&a.p_next[(int64_t)(base + l) * T + t], v);
+        for (int i = tid; i < kin * kNodeLoc * T; i += kBlock) {
+            const int itq = i / (kNodeLoc * T), r = i - itq * (kNodeLoc * T);
+            const int l = r / T, t = r - l * T;
+            const double v = nacc[itq][l][t];
+            if (v != 0.0)
+                unsafeAtomicAdd(&a.p_next[(long long)itq * a.slice_stride + (int64_t)(base + l) * T + t], v);
         }
+        if (a.dmax_out && tid < kin && dmx[tid] != 0u)
+            // (REVS_DMAX_SLOTS addresses per iteration: thousands of workgroups on ONE address serialise
+            // in the L2 -- measured 27 us per launch at 3 125 workgroups)
+            __hip_atomic_fetch_max((unsigned long long *)(a.dmax_out + (long long)tid * a.slice_stride +
+                                                          (bid & (REVS_DMAX_SLOTS - 1))),
+                                   (unsigned long long)__double_as_longlong((double)__uint_as_float(dmx[tid])),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -740,6 +824,23 @@ template <int LPA, int SPL>
 static void launch_agent(const AgentArgs &a, int mode, dim3 grid, hipStream_t s) {
     // dynamic LDS: only a launch whose first workgroups run the tree form of R p needs any
     const size_t lds = a.tree.n > 0 ? tree_lds_bytes(a.tree.n) : 0;
+    if (a.kin > 1) {     // several iterations per launch (no verdict workgroups in these launches)
+        switch (mode) {
+            case REVS_MODE_BINARY:
+                hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_BINARY, false, true>), grid, dim3(kBlock), 0, s, a);
+                break;
+            case REVS_MODE_RELAXED_PDHG:
+                if (a.pd.full_rows)
+                    hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_RELAXED_PDHG, true, true>), grid, dim3(kBlock), 0, s, a);
+                else
+                    hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_RELAXED_PDHG, false, true>), grid, dim3(kBlock), 0, s, a);
+                break;
+            default:
+                hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_RELAXED_EXACT, false, true>), grid, dim3(kBlock), 0, s, a);
+                break;
+        }
+        return;
+    }
     switch (mode) {
         case REVS_MODE_BINARY:
             hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_BINARY>), grid, dim3(kBlock), lds, s, a);
@@ -829,9 +930,19 @@ static int agent_step_impl(int64_t n_homes, int32_t T, const float *cost,
     REVS_REQUIRE(!p_next || (node_of && pe2_out), "revs_agent_step: node_of / pe2_out missing");
     a.ctl = nullptr; a.seq = 0; a.base_seq = 0; a.tree = TreeArgs{}; a.p_in = nullptr; a.p_zero = nullptr;
     a.vtol = 0.0; a.rec = nullptr; a.flags = flags; a.m = 0;
+    a.kin = 1; a.pe_out = nullptr; a.y_out = pdhg_dual; a.slice_stride = 0; a.diff_stride = 0; a.dmax_out = nullptr;
     if (sx && !sx->verdict) {         // judged by blocks (stream_block_verdict): silencing only
-        REVS_REQUIRE(sx->ctl && !sel, "revs_agent_step: bad streaming argument");
+        REVS_REQUIRE(!sel, "revs_agent_step: bad streaming argument");      // (ctl == NULL: never silenced)
         a.ctl = sx->ctl; a.seq = sx->seq; a.base_seq = sx->base_seq; a.flags = sx->flags;
+        REVS_REQUIRE(sx->kin >= 1 && sx->kin <= REVS_AGENT_MAX_INNER && sx->slice_stride >= 0 && sx->diff_stride >= 0,
+                     "revs_agent_step: kin=%d outside 1..%d", sx->kin, REVS_AGENT_MAX_INNER);
+        REVS_REQUIRE(sx->kin == 1 || (!p_est_new && p_next && sx->pe_out && !s_out && !c_out &&
+                                      sx->slice_stride >= (int64_t)0),
+                     "revs_agent_step: several iterations per launch need the recomputed estimate, node sums "
+                     "and pe_out, and write no S / C");
+        a.kin = sx->kin; a.pe_out = sx->pe_out; a.slice_stride = sx->slice_stride; a.diff_stride = sx->diff_stride;
+        a.dmax_out = sx->dmax_out;
+        if (sx->y_out) a.y_out = sx->y_out;
     } else if (sx) {
         REVS_REQUIRE(sx->ctl && sx->rec && sx->p_in && sx->tree.n > 0 && sx->tree.n <= REVS_TREE_MAX && sx->tree.n % 8 == 0 &&
                      sx->tree.pack && sx->tree.w &&
@@ -1027,6 +1138,31 @@ extern "C" int revs_agent_step_out(int64_t n_homes, int32_t T, const float *cost
     return agent_step_impl(n_homes, T, cost, homes, load, p_est_old, p_est_new, p_sch, gamma,
                            p_sch_out, gamma_out, s_out, c_out, diff, dsq, status, pdhg_dual,
                            kappa, mode, pdhg_host, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int revs_agent_step_multi(int64_t n_homes, int32_t T, const float *cost, const revs_home_t *homes,
+                                     const float *load, const float *p_est, const float *p_sch,
+                                     const float *gamma, float *p_est_out, float *p_sch_out,
+                                     float *gamma_out, float *p_est_next, float *diff, int64_t diff_stride,
+                                     float *dsq, int32_t *status, float *pdhg_dual, float *pdhg_dual_out,
+                                     float kappa, int32_t mode, const revs_pdhg_t *pdhg_host,
+                                     const int32_t *node_of, double *p_next, int64_t slice_stride,
+                                     double *dmax_out, int32_t kin, void *stream) {
+    REVS_REQUIRE(p_est_out && node_of && p_next && kin >= 1 && kin <= REVS_AGENT_MAX_INNER,
+                 "revs_agent_step_multi: bad argument (kin = %d, at most %d)", kin, REVS_AGENT_MAX_INNER);
+    REVS_REQUIRE(p_est_out != p_est && p_sch_out != p_sch && gamma_out != gamma,
+                 "revs_agent_step_multi: the state is not updated in place");
+    StreamExtra sx{};
+    sx.verdict = false;
+    sx.kin = kin;
+    sx.pe_out = p_est_out;
+    sx.y_out = pdhg_dual_out;
+    sx.slice_stride = slice_stride;
+    sx.diff_stride = diff_stride;
+    sx.dmax_out = dmax_out;
+    return agent_step_impl(n_homes, T, cost, homes, load, p_est, nullptr, p_sch, gamma, p_sch_out, gamma_out,
+                           nullptr, nullptr, diff, dsq, status, pdhg_dual, kappa, mode, pdhg_host, nullptr,
+                           node_of, p_next, p_est_next, stream, &sx);
 }
 
 extern "C" int revs_agent_step_select(int64_t n_homes, int32_t T, const float *cost,

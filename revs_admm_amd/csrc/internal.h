@@ -17,6 +17,13 @@ struct StreamExtra {
     double *rec;             // record slot of this launch (device address of pinned memory)
     unsigned int *flags;     // status bits (device address of pinned memory) or NULL
     int32_t m;
+    // several ADMM iterations per launch (AgentArgs::kin in agent_kernels.hip; verdict == false only)
+    int32_t kin = 1;         // inner iterations, 1..REVS_AGENT_MAX_INNER
+    float *pe_out = nullptr; // P_est after the last inner iteration (kin > 1: required)
+    float *y_out = nullptr;  // carried PDHG multipliers out (NULL: in place)
+    int64_t slice_stride = 0;   // doubles between the node-sum slices of consecutive inner iterations
+    int64_t diff_stride = 0;    // floats between their diff rows (0: one row, the last iteration's)
+    double *dmax_out = nullptr; // per inner iteration (stride slice_stride): max diff, bits of a double
 };
 
 // revs_agent_step_select's sweep with the next home pass folded in, plus `sx` (see above).

@@ -478,8 +478,12 @@ static bool rccl_load() {
 }
 
 struct revs_comm {
-    void *nccl;
+    void *nccl;                             // RCCL communicator, or NULL: the caller's own transport
     int rank, nranks;
+    revs_host_allreduce_fn fn = nullptr;    // host-staged all-reduce supplied by the caller
+    void *ctx = nullptr;
+    double *stage = nullptr;                // pinned staging buffer of the hook form
+    size_t stage_count = 0;
 };
 
 extern "C" int revs_comm_unique_id(void *id128_out) {
@@ -510,16 +514,67 @@ extern "C" revs_comm_t *revs_comm_create(const void *id128, int32_t rank, int32_
     return new revs_comm{c, rank, nranks};
 }
 
+extern "C" revs_comm_t *revs_comm_create_hook(revs_host_allreduce_fn fn, void *ctx, int32_t rank,
+                                              int32_t nranks) {
+    if (!fn || nranks < 1 || rank < 0 || rank >= nranks) {
+        revs::set_error("revs_comm_create_hook: bad argument");
+        return nullptr;
+    }
+    revs_comm *c = new revs_comm{nullptr, rank, nranks};
+    c->fn = fn;
+    c->ctx = ctx;
+    return c;
+}
+
 extern "C" void revs_comm_destroy(revs_comm_t *comm) {
     if (!comm) return;
-    if (g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm->nccl);
+    if (comm->nccl && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(comm->nccl);
+    if (comm->stage) (void)hipHostFree(comm->stage);
     delete comm;
+}
+
+// The hook form: everything enqueued on `stream` so far is waited for, the buffer goes through
+// pinned host memory to the caller's function and back.  Synchronous by construction -- it is
+// the transport of a caller that has no RCCL path between its ranks (two ranks sharing one
+// device, MPI over the host, a test harness), not a fast path.
+static int comm_allreduce_hook(revs_comm_t *comm, double *buf, int64_t count, int32_t op, hipStream_t s) {
+    if (comm->stage_count < (size_t)count) {
+        if (comm->stage) (void)hipHostFree(comm->stage);
+        comm->stage = nullptr;
+        comm->stage_count = 0;
+        void *h = nullptr;
+        if (hipHostMalloc(&h, sizeof(double) * (size_t)count, hipHostMallocDefault) != hipSuccess) {
+            revs::set_error("revs_comm_allreduce_f64: hipHostMalloc of the staging buffer failed");
+            return REVS_ELAUNCH;
+        }
+        comm->stage = (double *)h;
+        comm->stage_count = (size_t)count;
+    }
+    hipError_t e = hipMemcpyAsync(comm->stage, buf, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        revs::set_error("revs_comm_allreduce_f64: staging to the host: %s", hipGetErrorString(e));
+        return REVS_ELAUNCH;
+    }
+    const int rc = comm->fn(comm->ctx, comm->stage, count, op);
+    if (rc != 0) {
+        revs::set_error("revs_comm_allreduce_f64: the caller's all-reduce returned %d", rc);
+        return REVS_ELAUNCH;
+    }
+    e = hipMemcpyAsync(buf, comm->stage, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);          // (the staging buffer is reused)
+    if (e != hipSuccess) {
+        revs::set_error("revs_comm_allreduce_f64: staging back to the device: %s", hipGetErrorString(e));
+        return REVS_ELAUNCH;
+    }
+    return REVS_OK;
 }
 
 extern "C" int revs_comm_allreduce_f64(revs_comm_t *comm, double *buf, int64_t count, int32_t op,
                                        void *stream) {
     REVS_REQUIRE(comm && buf && count > 0 && (op == 0 || op == 2 || op == 3),
                  "revs_comm_allreduce_f64: bad argument");
+    if (comm->fn) return comm_allreduce_hook(comm, buf, count, op, (hipStream_t)stream);
     // ncclFloat64 = 8; ncclSum / ncclMax / ncclMin = 0 / 2 / 3 (rccl.h)
     const int rc = g_rccl.AllReduce(buf, buf, (size_t)count, 8, op, comm->nccl, (hipStream_t)stream);
     if (rc != 0) {

@@ -144,6 +144,11 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
     node_of   (n,)   constraint-node index of each residence (0..M-1)
     Rn        (M,M)  LinDistFlow matrix restricted to the constraint nodes
     group            torch.distributed process group when residences are sharded
+    comm_hook        optional `fn(host_array, op)`: the all-reduce of the node sums over the caller's
+                     own transport instead of RCCL (revs_comm_create_hook; op 0 sum, 2 max, 3 min,
+                     in place on a float64 numpy view).  Default with a `group` whose backend is
+                     not nccl (gloo: ranks sharing one device, CPU-side transports): all_reduce
+                     over that group.
     feeder           optional (parent, edge_r, cons_of): the radial feeder behind Rn as a tree --
                      parent[i] (-1: hangs off the substation), resistance of the edge to the
                      parent, constraint row of tree node i (or -1).  With it the steady state
@@ -154,7 +159,7 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
     def __init__(self, cost, homes, load, node_of, Rn, kappa=5.0, vset=1.0, vlow=0.95,
                  vhigh=1.05, mode="binary", device="cuda:0", pdhg=None,
                  op: OperatorOptions | None = None, group=None, node_counts=None,
-                 pdhg_warm=True, feeder=None, _kernels=None):
+                 pdhg_warm=True, feeder=None, comm_hook=None, _kernels=None):
         if _kernels is None:
             self.lib = _lib.load()               # raises when the HIP library is missing
             self.dev = _dev_check(device)        # raises without a GPU
@@ -195,8 +200,10 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
         local_counts = np.bincount(node_of, minlength=M).astype(np.int64)
         node_ptr = np.concatenate([[0], np.cumsum(local_counts)]).astype(np.int64)
         counts = local_counts.copy()
+        self._host_group = (group is not None and _kernels is None
+                            and torch.distributed.get_backend(group) != "nccl")
         if group is not None:
-            ct = torch.from_numpy(counts).to(self.dev)
+            ct = torch.from_numpy(counts) if self._host_group else torch.from_numpy(counts).to(self.dev)
             torch.distributed.all_reduce(ct, group=group)
             counts = ct.cpu().numpy()
         if node_counts is not None:
@@ -375,8 +382,14 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
         self._comm = None
         if feeder is not None and self.op.voltage in ("auto", "tree"):
             par, er, cons = feeder
+            tr = None
             if len(par) <= _lib.TREE_MAX:          # (padded to a multiple of 8 below)
-                tr = feeder_tree(par, er, cons, counts > 0)
+                try:
+                    tr = feeder_tree(par, er, cons, counts > 0)
+                except ValueError:                 # (row indices beyond the packed fields)
+                    if self.op.voltage == "tree":
+                        raise
+            if tr is not None:
                 probe = np.random.default_rng(0).uniform(0.5, 1.5, (M, 2)) * (counts > 0)[:, None]
                 ref = (Rn @ probe) * (counts > 0)[:, None]
                 got = tree_voltage_host(tr, probe)
@@ -393,7 +406,18 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
                 raise ValueError(f"feeder has {len(par)} nodes; the tree form holds {_lib.TREE_MAX}")
         elif self.op.voltage == "tree":
             raise ValueError('OperatorOptions(voltage="tree") needs feeder=')
-        if group is not None and cuda and _kernels is None and not os.environ.get("REVS_NO_COMM"):
+        self._hook_ref = None
+        if group is not None and cuda and _kernels is None and (comm_hook is not None or self._host_group):
+            # the caller's transport behind the library's communicator (revs_comm_create_hook)
+            ws, rk = torch.distributed.get_world_size(group), torch.distributed.get_rank(group)
+            from .comm import group_allreduce_hook, host_hook
+            self._hook_ref = host_hook(comm_hook if comm_hook is not None else group_allreduce_hook(group))
+            self._comm = self.lib.revs_comm_create_hook(self._hook_ref, None, rk, ws)
+            if not self._comm:
+                raise _lib.RevsError("revs_comm_create_hook failed: " + self.lib.revs_last_error().decode())
+            if self._plan is not None:
+                check(self.lib.revs_plan_set_comm(self._plan, self._comm), "revs_plan_set_comm")
+        elif group is not None and cuda and _kernels is None and not os.environ.get("REVS_NO_COMM"):
             # the library's own RCCL communicator: unique id from rank 0 over the caller's group
             ws, rk = torch.distributed.get_world_size(group), torch.distributed.get_rank(group)
             idb = (C.c_char * 128)()
@@ -446,6 +470,11 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
             check(self.lib.revs_comm_allreduce_f64(self._comm, ptr(t), t.numel(), code, self.stream),
                   "revs_comm_allreduce_f64")
             return
+        if getattr(self, "_host_group", False) and t.is_cuda:     # a CPU-side group: through the host
+            h = t.cpu()
+            torch.distributed.all_reduce(h, op=op or RO.SUM, group=self.group)
+            t.copy_(h)
+            return
         torch.distributed.all_reduce(t, op=op or RO.SUM, group=self.group)
 
     def _gemm1(self, At, B, Cslabs):
@@ -467,10 +496,10 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
                 f"{self.op.max_iter} above eps = {self.op.eps:g}")
 
     def operator_solve(self, admm_only=False):
-        self._p_clear = None
         """Utility(graph, P_est[k], P_sch[k], G[k]).solve() -> P_est[k+1]
         (lpsolver.py:256-259), written to self.P_est_new.  `admm_only`: skip the dual
         Newton attempt (the caller has just seen it fail for this state)."""
+        self._p_clear = None
         o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
         self._fused_ready = False
         if o.solver == "newton" and not admm_only:

@@ -48,6 +48,9 @@ def feeder_tree(parent, edge_r, cons_of, checked):
     eo = np.argsort(end, kind="stable")
     cle = np.searchsorted(end[eo], np.arange(n), side="right")
     w = 2.0 * np.asarray(edge_r, np.float64)[order]
+    if max(int((src + 1).max(initial=0)), int(end.max(initial=0)), int(cle.max(initial=0)), n) > 0xFFFF:
+        raise ValueError("feeder: a constraint row or tree position does not fit the 16-bit fields of "
+                         "revs_tree_t.pack (rows and tree nodes must be below 65535)")
     pack = ((src + 1).astype(np.uint64) | (end.astype(np.uint64) << np.uint64(16))
             | (eo.astype(np.uint64) << np.uint64(32)) | (cle.astype(np.uint64) << np.uint64(48)))
     return dict(n=n, src=src.astype(np.int32), end=end.astype(np.int32), eo=eo.astype(np.int32),

@@ -161,8 +161,10 @@ def solve_central(tariff, homes, dist, path, vset, vmin, vmax, device="cuda:0"):
     off, SOC 0.2).  The residences decouple as long as that schedule respects the voltage rows,
     which is checked on the GPU (revs_voltage_f32: -R_res g); then it IS the model's optimum.
     Returns (p_opt, s_opt, g_opt) dicts; raises RevsError where the reference prints
-    'No solution found' (the base load alone violates the rows), and NotImplementedError when
-    negative prices pull so much charging in that voltage rows bind (a coupled MILP: not done)."""
+    'No solution found' (the base load alone violates a lower row -- charging only lowers
+    v = -R g -- or an EV starts above 100 % SOC), and NotImplementedError where voltage rows
+    couple the residences (negative prices pulling rows to their limit; an upper row violated
+    by a net-exporting base load, which charging could repair): a network-wide MILP, not done."""
     import torch
     from ._lib import check, load, ptr
     from .engine import _dev_check, voltage_limits
@@ -187,19 +189,31 @@ def solve_central(tariff, homes, dist, path, vset, vmin, vmax, device="cuda:0"):
     tol = 1e-6 * max(abs(vlo), abs(vhi))
     dR = up(R[np.ix_(resind, resind)])
 
-    def rows_ok(g):
+    def rows(g):
+        """(lower rows respected, upper rows respected) for v = -R_res g"""
         dP, dV = up(g), torch.zeros(m, T, dtype=torch.float32, device=dev)
         check(lib.revs_voltage_f32(m, T, ptr(dR), ptr(dP), ptr(dV),
                                    torch.cuda.current_stream(dev).cuda_stream), "revs_voltage_f32")
         v = -dV.cpu().numpy().astype(np.float64)
-        return v.min() >= vlo - tol and v.max() <= vhi + tol
+        return v.min() >= vlo - tol, v.max() <= vhi + tol
 
-    if not rows_ok(load_ + p):
-        if p.any() and rows_ok(load_):
-            raise NotImplementedError("solve_central: with these negative prices the voltage rows bind "
-                                      "and the residences no longer decouple (DESIGN.md section 7)")
-        raise _lib.RevsError("No solution found (lpsolver.py:495-497): the base load alone "
-                             "violates the voltage limits")
+    if (rec["ev"] & (rec["nmax"] < 0)).any():
+        # SOC box init <= s <= 1 with init > 1 (add_home_EV, lpsolver.py:338-379): empty
+        raise _lib.RevsError("No solution found (lpsolver.py:495-497): an EV's initial state of "
+                             "charge is above 1")
+    lo_ok, hi_ok = rows(load_ + p)
+    if not (lo_ok and hi_ok):
+        base_lo, base_hi = rows(load_) if p.any() else (lo_ok, hi_ok)
+        # Charging (p >= 0, R >= 0) only lowers v = -R g: a lower row the base load already
+        # violates cannot be repaired -- the reference's 'No solution found'.  Everything else
+        # (negative prices pulling rows to their limit; an upper row violated by a net-exporting
+        # base load, which charging could repair) is a coupled network-wide MILP.
+        if not base_lo:
+            raise _lib.RevsError("No solution found (lpsolver.py:495-497): the base load alone "
+                                 "violates the lower voltage limit")
+        raise NotImplementedError("solve_central: the voltage rows bind (negative prices, or a base load "
+                                  "above the upper limit that charging could repair) and the residences "
+                                  "no longer decouple (DESIGN.md section 7)")
     cap = np.where(rec["ev"], rec["capacity"], 1.0)
     soc = rec["initial"][:, None] + np.concatenate([np.zeros((m, 1)), np.cumsum(p, 1)], 1) / cap[:, None]
     p_opt = {h: p[i].copy() for i, h in enumerate(res)}

@@ -1,0 +1,135 @@
+"""The sharded native loop with REAL partial sums (lpsolver.py:254-287: the loop whose iterates all
+ranks must share).  Two processes, both on cuda:0, each with a node-aligned half of the residences,
+run the real kernels and the real revs_plan_stream_run / stream_run_blocks; the node sums travel
+through the library's hook communicator (revs_comm_create_hook) over gloo.  State after every chunk
+must equal the one-process run bit for bit -- and must NOT when the collective is dropped or
+applied to the wrong extent (negative controls)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_RAGGED = (1, 7, 30, 2, 50, 64, 11)
+_SMALL_BURST = dict(stream_burst=16, stream_burst_max=64)
+
+CASES = [
+    # rows start to bind ~190 sweeps into a burst: sweeps behind the failed one have run
+    dict(name="deep", mode="pdhg", n=20000, nodes=512, seed=0, stress=1.0, T=24, chunks=(40, 400, 400),
+         configs=[dict(tag="b32ov", block=32, overlap=True, hook="gloo"),
+                  dict(tag="b32", block=32, overlap=False, hook="gloo"),
+                  dict(tag="b4ov", block=4, overlap=True, hook="gloo"),
+                  dict(tag="b1", block=1, overlap=False, hook="gloo"),
+                  dict(tag="noop", block=32, overlap=True, hook="noop"),
+                  dict(tag="slice", block=32, overlap=False, hook="first_slice")]),
+    # a failed verdict at the head of a call, ragged chunks
+    dict(name="head", mode="pdhg", n=8000, nodes=200, seed=3, stress=1.02, T=24, chunks=_RAGGED, f32=True,
+         burst=_SMALL_BURST,
+         configs=[dict(tag="b4", block=4, overlap=False, hook="gloo"),
+                  dict(tag="b32ov", block=32, overlap=True, hook="gloo"),
+                  dict(tag="b1", block=1, overlap=False, hook="gloo")]),
+    dict(name="binary", mode="binary", n=8000, nodes=200, seed=3, stress=0.5, T=24, chunks=_RAGGED, f32=True,
+         burst=_SMALL_BURST,
+         configs=[dict(tag="b4ov", block=4, overlap=True, hook="gloo"),
+                  dict(tag="b32", block=32, overlap=False, hook="gloo")]),
+    dict(name="t96", mode="pdhg", n=3000, nodes=200, seed=3, stress=1.02, T=96, chunks=_RAGGED, f32=True,
+         burst=_SMALL_BURST,
+         configs=[dict(tag="b4ov", block=4, overlap=True, hook="gloo"),
+                  dict(tag="b1", block=1, overlap=False, hook="gloo")]),
+]
+
+
+@pytest.fixture(scope="module")
+def two_rank_runs(gpu_lib, tmp_path_factory):
+    """Both ranks run every case and configuration once (one pair of processes for the module)."""
+    out = tmp_path_factory.mktemp("sharded")
+    port = 29700 + os.getpid() % 2000
+    procs = []
+    for rank in range(2):
+        spec = dict(rank=rank, world=2, port=port, outdir=str(out), cases=CASES)
+        path = out / f"spec{rank}.json"
+        path.write_text(json.dumps(spec))
+        env = dict(os.environ, OMP_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2", MKL_NUM_THREADS="2")
+        log = open(out / f"rank{rank}.log", "w")
+        procs.append((subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_worker.py"), str(path)],
+                                       stdout=log, stderr=subprocess.STDOUT, env=env), log))
+    rcs = []
+    for p, log in procs:
+        try:
+            rcs.append(p.wait(timeout=900))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rcs.append(-9)
+        log.close()
+    logs = "\n".join((out / f"rank{r}.log").read_text()[-3000:] for r in range(2))
+    assert rcs == [0, 0], logs
+    return out
+
+
+def _reference(case):
+    """The one-process run, every launch judging itself (no blocks, no communicator)."""
+    sys.path.insert(0, HERE)
+    from sharded_worker import make_case, run_chunks
+    from revs_admm_amd.engine import AdmmEngine, OperatorOptions
+    w = make_case(case)
+    e = AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, kappa=w.kappa, vset=w.vset, vlow=w.vlow,
+                   vhigh=w.vhigh, mode=case["mode"], feeder=w.feeder,
+                   op=OperatorOptions(**(case.get("burst") or {})))
+    assert e._block == 0 and e._comm is None
+    return w, run_chunks(e, case["chunks"], case["mode"])
+
+
+def _mismatch(case, ref, shards):
+    """Names of the quantities in which the two shards differ from the one-process run."""
+    bad = []
+    names = ("P_est", "P_sch", "G", "diff") + (("pdhg_dual",) if case["mode"] == "pdhg" else ())
+    for r in shards:
+        lo, hi = int(r["lo"]), int(r["hi"])
+        if "error" in r.files:
+            bad.append("P_sch: " + str(r["error"]))
+            continue
+        for i in range(len(case["chunks"])):
+            if int(r[f"iter_{i}"]) != int(ref[f"iter_{i}"]):
+                bad.append(f"iter_{i}")
+            for name in names:
+                if not np.array_equal(r[f"{name}_{i}"], ref[f"{name}_{i}"][lo:hi]):
+                    bad.append(f"{name}_{i}")
+        for k in ("stream_calls", "spec_hist", "chain_hist", "op_iters"):
+            if not np.array_equal(r[k], ref[k]):
+                bad.append(k)
+    return bad
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_two_ranks_with_real_partial_sums_equal_one_rank(two_rank_runs, case):
+    w, ref = _reference(case)
+    failed = [(int(c), int(k)) for c, k in ref["stream_calls"] if k < c]
+    if case["mode"] != "binary":
+        assert failed, ref["stream_calls"]                 # failed verdicts were crossed
+    assert ref["spec_hist"][0] > 60
+    mt = w.M * w.T
+    for cfg in case["configs"]:
+        shards = [np.load(two_rank_runs / f"{case['name']}_{cfg['tag']}_r{r}.npz") for r in range(2)]
+        assert int(shards[0]["lo"]) == 0 and int(shards[0]["hi"]) == int(shards[1]["lo"]) > 0
+        assert int(shards[1]["hi"]) == case["n"] > int(shards[1]["lo"])
+        bad = _mismatch(case, ref, shards)
+        if cfg["hook"] == "gloo":
+            assert not bad, (cfg, bad[:8])
+            # both ranks issued the same collectives; with blocks, whole blocks in one call
+            assert np.array_equal(shards[0]["hook_calls"], shards[1]["hook_calls"])
+            sizes = shards[0]["hook_calls"]
+            if cfg["block"] > 1:
+                assert sizes.max() == min(cfg["block"], max(case["chunks"])) * mt or case["chunks"] is _RAGGED
+                assert (sizes[sizes >= mt] % mt == 0).all() and (sizes > mt).any()
+            else:
+                assert (sizes[sizes >= mt] == mt).sum() > 60
+        else:
+            # negative controls: without the sums of the other rank (or with only one slice of
+            # them) the verdicts are taken on wrong voltages -- the run must come out different
+            assert bad, cfg
+            assert any(b.startswith(("P_sch", "G_", "stream_calls", "spec_hist")) for b in bad), bad[:8]

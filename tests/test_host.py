@@ -1,6 +1,7 @@
 """Host-side mirror of the reference interface: records, R matrix, readers/writers,
 and the engine's driver logic on the test double (tests/fake_kernels.py).  CPU only."""
 import numpy as np
+import os
 import pytest
 
 from oracle import revs_oracle as ro
@@ -341,3 +342,46 @@ def test_feeder_as_a_tree_reproduces_R(golden, feeder_R):
     assert e._tree is not None and e._plan is None
     with pytest.raises(ValueError, match="does not reproduce Rn"):
         AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, feeder=(w.parent, w.edge_r * 1.01, np.arange(300)), **kw)
+
+
+def test_feeder_pack_rejects_rows_beyond_16_bits():
+    """revs_tree_t.pack holds four 16-bit fields per position: a constraint row beyond them must be
+    refused on the host (it would silently corrupt the neighbouring field on the device)."""
+    from revs_admm_amd.feeder import feeder_tree
+    par = np.array([-1, 0, 1, 2], np.int64)
+    cons = np.array([0, 70000, -1, 3])
+    with pytest.raises(ValueError, match="16-bit"):
+        feeder_tree(par, np.ones(4), cons, np.ones(70001, bool))
+    assert feeder_tree(par, np.ones(4), np.array([0, 65000, -1, 3]), np.ones(65001, bool))["n"] == 8
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` with no launcher: the parent spawns N fresh ranks (RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* on 127.0.0.1), relays rank 0's one JSON line on stdout and
+    exits non-zero when a rank fails.  --dry-run stops after the rendezvous (no GPU here)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run",
+                        "--scaling", "strong"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out == {"dry_run": True, "n_gpus": 2, "sum_ranks": 1.0, "sum_local_ranks": 1.0,
+                   "ranks_seen": 2.0, "scaling": "strong", "launcher": "self"}
+    import torch
+    if not torch.cuda.is_available():      # without a GPU every rank refuses: the parent must fail too
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"],
+                           capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode != 0 and "needs a ROCm GPU" in r.stderr and not r.stdout.strip()
+
+
+def test_plot_result_warns_and_returns():
+    """test-optimizer.py:55-58 ends in fx.plot_result(...): out of scope, but it must not kill the caller."""
+    from revs_admm_amd.revs_fixture import REVS
+    fx = REVS.__new__(REVS)
+    with pytest.warns(RuntimeWarning, match="outside"):
+        assert fx.plot_result(None, None, anything=1) is None
