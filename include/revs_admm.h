@@ -33,7 +33,7 @@ extern "C" {
 #define REVS_MAX_T 192
 /* consecutive ADMM iterations one launch of the residence sweep can carry in registers
  * (streaming steady state, multipliers zero; revs_plan_set_stream_inner) */
-#define REVS_AGENT_MAX_INNER 4
+#define REVS_AGENT_MAX_INNER 8
 /* the sweep leaves the largest diff of an iteration (the convergence measure, lpsolver.py:284) as
  * REVS_DMAX_SLOTS partial maxima, workgroup b into slot b % REVS_DMAX_SLOTS */
 #define REVS_DMAX_SLOTS 64
@@ -735,7 +735,8 @@ revs_comm_t *revs_comm_create_hook(revs_host_allreduce_fn fn, void *ctx, int32_t
  * first) -- so the host can keep the queue full without waiting for any verdict, and
  * nothing written after a failed verdict has to be undone beyond that one sweep's spare
  * buffers.  With a communicator set (revs_plan_set_comm) the node sums are all-reduced on
- * the same stream after every sweep.  All max_steps launches (at most REVS_STREAM_MAX) are
+ * the same stream after every sweep (block <= 1 only: see revs_plan_stream_run_blocks below for
+ * the form with one collective per block).  All max_steps launches (at most REVS_STREAM_MAX) are
  * enqueued in one burst and no decision is taken in between, so every rank of a sharded run
  * issues the same collectives; the caller bounds max_steps by the silenced launches it accepts
  * to waste behind a failed verdict.
@@ -762,30 +763,60 @@ int revs_plan_set_comm(revs_plan_t *plan, revs_comm_t *comm);
 int revs_plan_stream_run(revs_plan_t *plan, int32_t max_steps, revs_stream_state_t *st,
                          double scale, double eps, int32_t *kept_steps, double *rmax_last,
                          void *stream);
-/* Verdicts by blocks -- the sharded form of the loop above.  The node sums of an iteration are
- * only known after the all-reduce, and one collective per sweep would make the collective's
- * latency the step.  With block = B > 1, revs_plan_stream_run lets B sweeps run without a
- * verdict, each accumulating its node sums into its own slice of a ring owned by the plan;
- * ONE all-reduce sums the B slices over the ranks and one launch of B x T workgroups judges
- * them (tree form, as above).  Every launch of the burst is still a no-op once an iteration at
- * or before its own has failed; the sweeps that ran behind a failed iteration are undone: every
- * fourth block first saves the state it overwrites (four profiles and the PDHG residences'
- * carried multipliers, in arrays owned by the plan), and the call puts the last saved state back
- * and runs the good sweeps from there again, then the failed iteration's own sweep (to the
- * spares), before it returns -- memory is then bit for bit what the single-GPU form leaves.
- * The contract of revs_plan_stream_run is unchanged (st->p[1], p[2] are not used; st->p[0] holds
- * the all-reduced sums of the next iteration at return).  block <= 1: every launch judges itself
- * (the single-GPU form).
- * overlap != 0 (and more than `block` launches in the call): the all-reduce and the verdicts of
+/* Verdicts by blocks -- the form of the loop above that the engine uses by default, and the only one
+ * that makes sense with residences sharded: the node sums of an iteration are only known after the
+ * all-reduce, and one collective per sweep would make the collective's latency the step.  With
+ * block = B > 1 (revs_plan_set_stream_block), revs_plan_stream_run_blocks lets B iterations run
+ * without a verdict, each accumulating its node sums into its own slice of a ring owned by the
+ * plan; ONE all-reduce sums the B slices over the ranks and one launch of B x T workgroups judges
+ * them (tree form, as above).  Because no verdict is needed between them, `inner` consecutive
+ * iterations (revs_plan_set_stream_inner, <= REVS_AGENT_MAX_INNER) are ONE launch that keeps every
+ * residence's state in registers (revs_agent_step_multi): profiles read and written once per
+ * `inner` iterations.  Every launch of the burst is still a no-op once an iteration at or before
+ * its own has failed; the sweeps that ran behind a failed iteration are undone WITHOUT copies: the
+ * caller hands over FOUR sets of state buffers, a block's launches alternate between the two sets
+ * that are neither its own entry set nor the entry set of the block before, so the state a block
+ * started from is intact until its verdicts are in; after a failure the call runs the good
+ * iterations of that block again from its entry set, then the failed iteration's own sweep (outputs
+ * to a spare set, carried multipliers in place) -- memory is then bit for bit what the loop that
+ * judges every launch leaves.
+ *   st    sets [0..3] of {P_est, P_sch, G, carried PDHG multipliers (PDHG with warm start only)};
+ *         at entry set 0 is the state (P_est[k], P_sch[k], G[k]; its pdhg_dual must be the plan's),
+ *         the others are scratch; at return set 0 is the state after the kept iterations (the roles
+ *         are permuted, the plan's pdhg_dual follows -- see revs_plan_set_pdhg_dual).
+ *         p0: node sums of the estimate P_est[k+1] (all-reduced) in, those of P_est[k+kept+1] out
+ *         when every iteration was kept; p_est_next (a buffer outside the sets): P_est[k+kept+1]
+ *         itself then; diff_hist as in revs_stream_state_t.
+ *   dmax_out  NULL, or double[max_steps]: [i] = max_h diff[h] of the i-th iteration of this call
+ *         (lpsolver.py:284 -- the convergence measure), for the kept iterations: folded on the
+ *         device by the sweeps (REVS_DMAX_SLOTS partial maxima per rank in the tail of every ring
+ *         slice, so that the all-reduce of the sums also gathers them) and the verdict launches.
+ * overlap != 0 (and more than `block` iterations in the call): the all-reduce and the verdicts of
  * block b run on a second stream owned by the plan while the caller's stream already runs the
- * sweeps of block b + 1 (two ring halves, two generations of saved state; block b + 2 waits for
- * block b's verdicts) -- the collective then costs the step nothing as long as it is shorter
- * than a block of sweeps; the last `block` launches are split 3 : 1 so that the last collective
- * is a short one.  The caller's stream waits for the second stream before the call returns, so
- * synchronising the caller's stream is still enough.
- * Memory: 2 B M T doubles + 10 n T floats.  Set both on every rank alike. */
+ * sweeps of block b + 1 (two ring halves; block b + 2 waits for block b's verdicts) -- the
+ * collective then costs the step nothing as long as it is shorter than a block of sweeps; the last
+ * `block` iterations are split 3 : 1 so that the last collective is a short one.  The caller's
+ * stream waits for the second stream before the call returns, so synchronising the caller's
+ * stream is still enough.
+ * Memory: 2 B (M T + REVS_DMAX_SLOTS ranks) doubles.  Set block, inner and overlap on every rank alike. */
 #define REVS_STREAM_BLOCK_MAX 256
+typedef struct {
+    float *p_est[4];
+    float *p_sch[4];
+    float *gamma[4];
+    float *pdhg_dual[4];
+    double *p0;
+    float *p_est_next;
+    float *diff_hist;
+} revs_stream_sets_t;
 int revs_plan_set_stream_block(revs_plan_t *plan, int32_t block, int32_t overlap);
+int revs_plan_set_stream_inner(revs_plan_t *plan, int32_t inner);
+int revs_plan_stream_run_blocks(revs_plan_t *plan, int32_t max_steps, revs_stream_sets_t *st,
+                                double scale, double eps, int32_t *kept_steps, double *rmax_last,
+                                double *dmax_out, void *stream);
+/* The array of carried PDHG multipliers the plan's other entry points (revs_plan_spec_step, ...)
+ * use -- revs_plan_stream_run_blocks rotates it with the sets and leaves the plan pointing at set 0's. */
+int revs_plan_set_pdhg_dual(revs_plan_t *plan, float *pdhg_dual);
 /* Two HIP events around the bursts of revs_plan_stream_run, recorded by the library on the
  * bursts' own stream: revs_plan_stream_timing(plan, 1) arms them (the next burst records the
  * first one, every burst re-records the second after its last launch);

@@ -75,11 +75,19 @@ class StreamState(C.Structure):
                 ("p", C.c_void_p * 3), ("diff_hist", C.c_void_p)]
 
 
+class StreamSets(C.Structure):
+    """revs_stream_sets_t"""
+    _fields_ = [("p_est", C.c_void_p * 4), ("p_sch", C.c_void_p * 4), ("gamma", C.c_void_p * 4),
+                ("pdhg_dual", C.c_void_p * 4), ("p0", C.c_void_p), ("p_est_next", C.c_void_p),
+                ("diff_hist", C.c_void_p)]
+
+
 # revs_host_allreduce_fn
 HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int32)
 
 TREE_MAX = 2048          # REVS_TREE_MAX
 STREAM_BLOCK_MAX = 256   # REVS_STREAM_BLOCK_MAX
+AGENT_MAX_INNER = 8      # REVS_AGENT_MAX_INNER
 
 
 class RevsError(RuntimeError):
@@ -174,6 +182,9 @@ SIGNATURES = {
     "revs_plan_set_tree": (C.c_int, [_p, C.POINTER(Tree)]),
     "revs_plan_set_comm": (C.c_int, [_p, _p]),
     "revs_plan_set_stream_block": (C.c_int, [_p, C.c_int32, C.c_int32]),
+    "revs_plan_set_stream_inner": (C.c_int, [_p, C.c_int32]),
+    "revs_plan_set_pdhg_dual": (C.c_int, [_p, _p]),
+    "revs_plan_stream_run_blocks": (C.c_int, [_p, _i32, C.POINTER(StreamSets), _f64, _f64, _p, _p, _p, _p]),
     "revs_plan_stream_timing": (C.c_int, [_p, C.c_int32]),
     "revs_plan_stream_elapsed_ms": (C.c_int, [_p, _p]),
     "revs_plan_stream_run": (C.c_int, [_p, _i32, C.POINTER(StreamState), _f64, _f64, _p, _p, _p]),

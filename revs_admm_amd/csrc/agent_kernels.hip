@@ -237,8 +237,9 @@ void agent_step_kernel(const AgentArgs a) {
     // 74 at 125 000 x 96, where a wavefront holds 4 residences and the memory-side f64 atomics
     // quadruple.)
     constexpr int kNodeLoc = 4, kSlots = LPA * SPL;
-    __shared__ double nacc[kMaxInner][kNodeLoc][kSlots];
-    __shared__ unsigned int dmx[kMaxInner];
+    constexpr int kAcc = MULTI ? kMaxInner : 1;
+    __shared__ double nacc[kAcc][kNodeLoc][kSlots];
+    __shared__ unsigned int dmx[kAcc];
     const int64_t first = (int64_t)bid * kHomesPerBlock;
     // Every global load of the kernel is issued before the first use of any of them (one exposed
     // memory latency per wavefront, not three): profiles, then the home record and the carried
@@ -282,7 +283,7 @@ void agent_step_kernel(const AgentArgs a) {
     int base = 0;
     if (a.p_next) {      // (behind the loads: the barrier does not wait for them)
         for (int i = tid; i < kin * kNodeLoc * kSlots; i += kBlock) (&nacc[0][0][0])[i] = 0.0;
-        if (tid < kMaxInner) dmx[tid] = 0u;
+        if (tid < kAcc) dmx[tid] = 0u;
         base = a.node_of[first < a.n ? first : a.n - 1];
         __syncthreads();
     }
@@ -927,7 +928,7 @@ static int agent_step_impl(int64_t n_homes, int32_t T, const float *cost,
     a.sel = SelectArgs{};
     if (sel) { a.nsel = sel->T; a.sel = *sel; }
     a.node_of = node_of; a.p_next = p_next; a.pe2_out = pe2_out;
-    REVS_REQUIRE(!p_next || (node_of && pe2_out), "revs_agent_step: node_of / pe2_out missing");
+    REVS_REQUIRE(!p_next || (node_of && (pe2_out || (sx && !sx->verdict))), "revs_agent_step: node_of / pe2_out missing");
     a.ctl = nullptr; a.seq = 0; a.base_seq = 0; a.tree = TreeArgs{}; a.p_in = nullptr; a.p_zero = nullptr;
     a.vtol = 0.0; a.rec = nullptr; a.flags = flags; a.m = 0;
     a.kin = 1; a.pe_out = nullptr; a.y_out = pdhg_dual; a.slice_stride = 0; a.diff_stride = 0; a.dmax_out = nullptr;
@@ -986,46 +987,31 @@ int agent_step_stream(int64_t n_homes, int32_t T, const float *cost, const revs_
 // verdicts, each accumulating its sums into its own slice of a ring; ONE all-reduce then sums
 // the B slices over the ranks, and one launch of B x T workgroups judges them all.  A failed
 // verdict silences everything behind the block; the sweeps behind the failed iteration that
-// did run worked from an estimate that is not the operator's answer, so the state the sweeps
-// overwrite is saved now and then (stream_block_begin) and the host rolls back to it.
-struct BlockBegin {
-    const StreamCtl *ctl;
-    unsigned int base_seq, gate_seq;      // no-op when a launch numbered base_seq..gate_seq failed
-    const float *src[5];
-    float *dst[5];
-    long long count[5];                   // floats
-    int32_t narr;
-    double *ring;                         // cleared: ring_count doubles
-    long long ring_count;
-};
-__global__ __launch_bounds__(256) void stream_block_begin_kernel(const BlockBegin b) {
-    const unsigned int bad = b.ctl->bad_seq;
-    if (bad >= b.base_seq && bad <= b.gate_seq) return;
-    const long long gtid = (long long)blockIdx.x * 256 + threadIdx.x, nth = (long long)gridDim.x * 256;
-    for (int q = 0; q < b.narr; ++q) {    // (bases come from the allocator: 16-byte aligned)
-        const long long n4 = b.count[q] >> 2;
-        const float4 *s4 = reinterpret_cast<const float4 *>(b.src[q]);
-        float4 *d4 = reinterpret_cast<float4 *>(b.dst[q]);
-        for (long long i = gtid; i < n4; i += nth) d4[i] = s4[i];
-        for (long long i = 4 * n4 + gtid; i < b.count[q]; i += nth) b.dst[q][i] = b.src[q][i];
-    }
-    for (long long i = gtid; i < b.ring_count; i += nth) b.ring[i] = 0.0;
-}
-
+// did run worked from an estimate that is not the operator's answer: the state a block starts
+// from is never overwritten while its verdicts are pending (the sweeps of a block rotate through
+// the other sets of buffers, runtime.cpp), and the host goes back to it.
 struct BlockVerdict {
     StreamCtl *ctl;
-    unsigned int base_seq, gate_seq;      // as above
-    unsigned int first_seq;               // slice g holds the sums judged for launch first_seq + g
-    int32_t nb, T;
+    unsigned int base_seq, gate_seq;      // no-op when a launch numbered base_seq..gate_seq failed
+    unsigned int first_seq;               // slice g holds the sums judged for iteration first_seq + g
+    int32_t nb, T;                        // slices judged
+    int32_t ndmax;                        // slices whose tail is folded: nb, or nb + 1 (the call's last slice)
     TreeArgs tree;
     const double *ring;
-    long long mt;                         // doubles per slice
+    long long stride;                     // doubles from one slice to the next
+    const double *tail;                   // slice g's partial maxima of diff at tail + g * stride, or NULL
+    int32_t ntail;
     double vlo, vhi, vtol;
     unsigned long long *grp_bits;         // [nb] device words, zero on entry and on exit
+    double *grp_dmax;                     // [ndmax] device words
     double *rec;                          // the record ring (device address of pinned memory)
 };
-// Workgroup (g, t): slot t of slice g.  The last workgroup to finish writes the nb records
-// {rmax, failed, seq} and the lowest failed number into the control word.
+// Workgroup (g, t): slot t of slice g; workgroup t == 0 of a slice also folds the slice's tail --
+// the partial maxima of diff that the sweep which produced the slice left (every rank in its own
+// REVS_DMAX_SLOTS words: the all-reduce's sum IS the gather) -- into max_h diff[h] of that sweep's
+// iteration; one extra workgroup does the same for the call's last slice, whose rows the next call
+// judges.  The last workgroup to finish writes the records {rmax, failed, seq, max diff of the
+// iteration before} and the lowest failed number into the control word.
 __global__ __launch_bounds__(256) void stream_block_verdict_kernel(const BlockVerdict b) {
     extern __shared__ double tree_lds[];
     {
@@ -1033,32 +1019,50 @@ __global__ __launch_bounds__(256) void stream_block_verdict_kernel(const BlockVe
         if (bad >= b.base_seq && bad <= b.gate_seq) return;
     }
     const int tid = threadIdx.x;
-    const int g = (int)blockIdx.x / b.T, t = (int)blockIdx.x - g * b.T;
-    const double rmax = tree_rmax(b.tree, b.ring + (long long)g * b.mt, b.T, t, b.vlo, b.vhi, tree_lds, nullptr);
+    const int njudge = b.nb * b.T;
+    const bool extra = (int)blockIdx.x >= njudge;
+    const int g = extra ? b.nb : (int)blockIdx.x / b.T, t = extra ? 0 : (int)blockIdx.x - g * b.T;
+    __shared__ double dm_s[4];
+    if (t == 0 && b.tail && g < b.ndmax) {
+        double v = 0.0;
+        for (int i = tid; i < b.ntail; i += 256) v = fmax(v, b.tail[(long long)g * b.stride + i]);
+        v = wave_max_d(v);
+        if ((tid & 63) == 0) dm_s[tid >> 6] = v;
+        __syncthreads();
+        if (tid == 0) b.grp_dmax[g] = fmax(fmax(dm_s[0], dm_s[1]), fmax(dm_s[2], dm_s[3]));
+    }
+    double rmax = 0.0;
+    if (!extra) rmax = tree_rmax(b.tree, b.ring + (long long)g * b.stride, b.T, t, b.vlo, b.vhi, tree_lds, nullptr);
     __shared__ int last_s;
     __shared__ unsigned int bad_s;
     if (tid == 0) {
-        __hip_atomic_fetch_max(&b.grp_bits[g], (unsigned long long)__double_as_longlong(rmax),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!extra)
+            __hip_atomic_fetch_max(&b.grp_bits[g], (unsigned long long)__double_as_longlong(rmax),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // performed before this workgroup is counted
         const unsigned int old = __hip_atomic_fetch_add(&b.ctl->arrive, 1u, __ATOMIC_RELAXED,
                                                         __HIP_MEMORY_SCOPE_AGENT);
-        last_s = old == (unsigned int)(b.nb * b.T) - 1u;
+        last_s = old == gridDim.x - 1u;
         bad_s = 0xFFFFFFFFu;
     }
     __syncthreads();
     if (!last_s) return;
-    for (int q = tid; q < b.nb; q += 256) {
-        const unsigned long long bits = __hip_atomic_load(&b.grp_bits[q], __ATOMIC_RELAXED,
-                                                          __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&b.grp_bits[q], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double r = __longlong_as_double((long long)bits);
+    for (int q = tid; q < b.ndmax; q += 256) {
+        const bool judged = q < b.nb;
+        double r = 0.0;
+        if (judged) {
+            const unsigned long long bits = __hip_atomic_load(&b.grp_bits[q], __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&b.grp_bits[q], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            r = __longlong_as_double((long long)bits);
+        }
         const unsigned int seq = b.first_seq + (unsigned int)q;
-        const bool failed = !(r <= b.vtol);
+        const bool failed = judged && !(r <= b.vtol);
         if (failed) atomicMin(&bad_s, seq);
         volatile double *rec = b.rec + 4 * (seq % kRecRing);
         rec[0] = r;
         rec[1] = failed ? 1.0 : 0.0;
+        rec[3] = b.tail ? __hip_atomic_load(&b.grp_dmax[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1.0;
         __threadfence_system();
         rec[2] = (double)seq;
     }
@@ -1070,37 +1074,18 @@ __global__ __launch_bounds__(256) void stream_block_verdict_kernel(const BlockVe
     }
 }
 
-int stream_block_begin(const StreamCtl *ctl, unsigned int base_seq, unsigned int gate_seq,
-                       const float *const *src, float *const *dst, const int64_t *count,
-                       int32_t narr, double *ring, int64_t ring_count, void *stream) {
-    REVS_REQUIRE(ctl && narr >= 0 && narr <= 5 && ring && ring_count >= 0,
-                 "stream_block_begin: bad argument");
-    BlockBegin b{ctl, base_seq, gate_seq, {}, {}, {}, narr, ring, (long long)ring_count};
-    long long work = (long long)ring_count;
-    for (int q = 0; q < narr; ++q) {
-        REVS_REQUIRE(src[q] && dst[q] && count[q] >= 0 && ((uintptr_t)src[q] & 15) == 0 &&
-                     ((uintptr_t)dst[q] & 15) == 0, "stream_block_begin: arrays must be 16-byte aligned");
-        b.src[q] = src[q];
-        b.dst[q] = dst[q];
-        b.count[q] = (long long)count[q];
-        work = std::max<long long>(work, (long long)count[q] / 4);
-    }
-    const int grid = (int)std::min<long long>(2048, std::max<long long>(1, (work + 255) / 256));
-    hipLaunchKernelGGL(stream_block_begin_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, b);
-    REVS_CHECK_LAUNCH("stream_block_begin");
-    return REVS_OK;
-}
-
 int stream_block_verdict(StreamCtl *ctl, unsigned int base_seq, unsigned int gate_seq,
                          unsigned int first_seq, int32_t nb, int32_t T, const TreeArgs &tree,
-                         const double *ring, int64_t mt, double vlo, double vhi, double vtol,
-                         unsigned long long *grp_bits, double *rec, void *stream) {
-    REVS_REQUIRE(ctl && nb > 0 && nb < kRecRing && T > 0 && tree.n > 0 && tree.n <= REVS_TREE_MAX &&
-                 tree.n % 8 == 0 && tree.pack && tree.w && ring && mt > 0 && vlo <= vhi && vtol >= 0.0 &&
-                 grp_bits && rec, "stream_block_verdict: bad argument");
-    const BlockVerdict b{ctl, base_seq, gate_seq, first_seq, nb, T, tree, ring, (long long)mt,
-                         vlo, vhi, vtol, grp_bits, rec};
-    hipLaunchKernelGGL(stream_block_verdict_kernel, dim3((unsigned)(nb * T)), dim3(256),
+                         const double *ring, int64_t stride, const double *tail, int32_t ntail,
+                         bool tail_extra, double vlo, double vhi, double vtol,
+                         unsigned long long *grp_bits, double *grp_dmax, double *rec, void *stream) {
+    REVS_REQUIRE(ctl && nb >= 0 && nb < kRecRing && (nb > 0 || tail_extra) && T > 0 && tree.n > 0 &&
+                 tree.n <= REVS_TREE_MAX && tree.n % 8 == 0 && tree.pack && tree.w && ring && stride > 0 &&
+                 vlo <= vhi && vtol >= 0.0 && grp_bits && grp_dmax && rec && (!tail_extra || tail) &&
+                 (!tail || ntail > 0), "stream_block_verdict: bad argument");
+    const BlockVerdict b{ctl, base_seq, gate_seq, first_seq, nb, T, nb + (tail_extra ? 1 : 0), tree, ring,
+                         (long long)stride, tail, ntail, vlo, vhi, vtol, grp_bits, grp_dmax, rec};
+    hipLaunchKernelGGL(stream_block_verdict_kernel, dim3((unsigned)(nb * T + (tail_extra ? 1 : 0))), dim3(256),
                        tree_lds_bytes(tree.n), (hipStream_t)stream, b);
     REVS_CHECK_LAUNCH("stream_block_verdict");
     return REVS_OK;

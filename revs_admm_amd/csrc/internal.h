@@ -34,17 +34,17 @@ int agent_step_stream(int64_t n_homes, int32_t T, const float *cost, const revs_
                       int32_t mode, const revs_pdhg_t *pdhg_host, const int32_t *node_of,
                       double *p_next, float *p_est_next, const StreamExtra &sx, void *stream);
 
-// Verdicts by blocks (agent_kernels.hip).  Both launches are no-ops when a launch numbered
-// base_seq..gate_seq has failed its verdict.  stream_block_begin copies `narr` arrays of
-// `count[q]` floats (the state a block of sweeps overwrites) and clears the ring;
-// stream_block_verdict judges `nb` slices of node sums (slice g: the sums launch first_seq + g
-// consumes), writes their records and the lowest failed number into the control word.
-int stream_block_begin(const StreamCtl *ctl, unsigned int base_seq, unsigned int gate_seq,
-                       const float *const *src, float *const *dst, const int64_t *count,
-                       int32_t narr, double *ring, int64_t ring_count, void *stream);
+// Verdicts by blocks (agent_kernels.hip).  A no-op when a launch numbered base_seq..gate_seq has
+// failed its verdict.  Judges `nb` slices of node sums (slice g at ring + g * stride: the sums
+// iteration first_seq + g consumes), folds every slice's tail (ntail partial maxima of diff at
+// tail + g * stride, left by the sweep that produced the slice; tail == NULL: none) and, with
+// tail_extra, the tail of slice nb as well; writes the records {rmax, failed, seq, max diff of the
+// iteration before} of first_seq .. first_seq + nb (+ 1) and the lowest failed number into the
+// control word.
 int stream_block_verdict(StreamCtl *ctl, unsigned int base_seq, unsigned int gate_seq,
                          unsigned int first_seq, int32_t nb, int32_t T, const TreeArgs &tree,
-                         const double *ring, int64_t mt, double vlo, double vhi, double vtol,
-                         unsigned long long *grp_bits, double *rec, void *stream);
+                         const double *ring, int64_t stride, const double *tail, int32_t ntail,
+                         bool tail_extra, double vlo, double vhi, double vtol,
+                         unsigned long long *grp_bits, double *grp_dmax, double *rec, void *stream);
 
 }  // namespace revs

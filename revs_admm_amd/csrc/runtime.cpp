@@ -55,9 +55,11 @@ struct revs_plan {
     // verdicts by blocks (revs_plan_set_stream_block)
     int32_t block = 0;                     // iterations judged together; <= 1: every launch judges itself
     int32_t overlap = 0;                   // all-reduce + verdicts of a block on `side`, beside the next block's sweeps
-    double *ring = nullptr;                // device: node sums of two blocks, double[2][block][m T]
-    float *ck[2][5] = {};                  // device: the state a block overwrites (two generations)
+    int32_t inner = 1;                     // ADMM iterations per sweep launch (revs_plan_set_stream_inner)
+    double *ring = nullptr;                // device: node sums (+ diff tails) of two blocks, double[2][block][stride]
+    size_t ring_cap = 0;                   // ... doubles allocated
     unsigned long long *grp_bits = nullptr;                // device: per-slice maxima, zero between launches
+    double *grp_dmax = nullptr;            // device: per-slice max diff
     hipStream_t side = nullptr;
     std::vector<hipEvent_t> events;        // pool: sweeps-done / verdicts-done per block, end of call
     // optional timing of the bursts on their own stream (revs_plan_stream_timing)
@@ -161,7 +163,7 @@ extern "C" void revs_plan_destroy(revs_plan_t *plan) {
     if (plan->rec_host) (void)hipHostFree(plan->rec_host);
     if (plan->ring) (void)hipFree(plan->ring);
     if (plan->grp_bits) (void)hipFree(plan->grp_bits);
-    for (auto &gen : plan->ck) for (float *c : gen) if (c) (void)hipFree(c);
+    if (plan->grp_dmax) (void)hipFree(plan->grp_dmax);
     for (hipEvent_t e : plan->events) (void)hipEventDestroy(e);
     for (hipEvent_t e : plan->tev) if (e) (void)hipEventDestroy(e);
     if (plan->side) (void)hipStreamDestroy(plan->side);
@@ -606,18 +608,13 @@ extern "C" int revs_plan_set_stream_block(revs_plan_t *plan, int32_t block, int3
     if (block <= 1) { plan->block = 0; return REVS_OK; }
     const revs_plan_desc_t &d = plan->d;
     REVS_REQUIRE(d.n_homes > 0 && d.node_of, "revs_plan_set_stream_block: the plan has no residences / node_of");
-    if (block > plan->block || !plan->ring) {            // (grow only; the arrays are reused)
-        if (plan->ring) (void)hipFree(plan->ring);
-        if (plan->grp_bits) (void)hipFree(plan->grp_bits);
-        plan->ring = nullptr; plan->grp_bits = nullptr;
-        const size_t rb = sizeof(double) * 2 * (size_t)block * d.m * d.T, gb = sizeof(unsigned long long) * block;
-        hipError_t e = hipMalloc((void **)&plan->ring, rb);
-        if (e == hipSuccess) e = hipMalloc((void **)&plan->grp_bits, gb);
+    REVS_REQUIRE(d.recompute_pe_new, "revs_plan_set_stream_block: verdicts by blocks need recompute_pe_new");
+    if (!plan->grp_bits) {
+        const size_t gb = sizeof(unsigned long long) * (REVS_STREAM_BLOCK_MAX + 1);
+        hipError_t e = hipMalloc((void **)&plan->grp_bits, gb);
         if (e == hipSuccess) e = hipMemset(plan->grp_bits, 0, gb);
-        for (int g = 0; g < 2 && e == hipSuccess; ++g)
-            for (int q = 0; q < 5 && e == hipSuccess; ++q)   // ([4]: the PDHG residences' carried multipliers)
-                if (!plan->ck[g][q])
-                    e = hipMalloc((void **)&plan->ck[g][q], sizeof(float) * (size_t)d.n_homes * d.T);
+        if (e == hipSuccess) e = hipMalloc((void **)&plan->grp_dmax, gb);
+        if (e == hipSuccess) e = hipMemset(plan->grp_dmax, 0, gb);
         if (e == hipSuccess && !plan->side) e = hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking);
         if (e != hipSuccess) {
             revs::set_error("revs_plan_set_stream_block: %s", hipGetErrorString(e));
@@ -627,6 +624,21 @@ extern "C" int revs_plan_set_stream_block(revs_plan_t *plan, int32_t block, int3
     }
     plan->block = block;
     plan->overlap = overlap != 0;
+    return REVS_OK;
+}
+
+extern "C" int revs_plan_set_stream_inner(revs_plan_t *plan, int32_t inner) {
+    REVS_REQUIRE(plan && inner >= 1 && inner <= REVS_AGENT_MAX_INNER,
+                 "revs_plan_set_stream_inner: inner=%d outside 1..%d", inner, REVS_AGENT_MAX_INNER);
+    plan->inner = inner;
+    return REVS_OK;
+}
+
+extern "C" int revs_plan_set_pdhg_dual(revs_plan_t *plan, float *pdhg_dual) {
+    REVS_REQUIRE(plan && (pdhg_dual != nullptr) == (plan->d.pdhg_dual != nullptr),
+                 "revs_plan_set_pdhg_dual: the plan was created %s carried multipliers",
+                 plan && plan->d.pdhg_dual ? "with" : "without");
+    plan->d.pdhg_dual = pdhg_dual;
     return REVS_OK;
 }
 
@@ -713,36 +725,88 @@ static void stream_rotate(revs_stream_state_t *st, int kept, int64_t n_homes) {
     *st = r;
 }
 
-// revs_plan_stream_run with the verdicts taken by blocks (plan->block = B > 1; see the comment in
-// agent_kernels.hip).  Launch k of the call has number seq0 + k and consumes the node sums
-// "of iteration k".  Enqueued in one burst:
-//   verdict of iteration 0 (the caller's st->p[0]);
-//   per block [k0, k0 + nb):  every kSaveEvery-th block (and the first) saves the state iteration
-//       k0 starts from; the first also clears the ring |
-//       nb sweeps, sweep k accumulating the sums of iteration k + 1 into ring slice k - k0 |
-//       ONE all-reduce of the nb slices (sharded) | verdicts of iterations k0+1 .. k0+nb (the last
-//       block: .. max_steps - 1, its last slice is the next call's st->p[0]) | the slices cleared;
+// The streaming loop with the verdicts taken by blocks (see include/revs_admm.h).  Iteration k of
+// the call has number seq0 + k and consumes the node sums "of iteration k".  Enqueued in one burst:
+//   verdict of iteration 0 (the caller's st->p0);
+//   per block [k0, k0 + nb):  sweep launches of up to `inner` iterations each, iteration k
+//       accumulating the sums of iteration k + 1 (and the partial maxima of its own diff) into
+//       ring slice k - k0 | ONE all-reduce of the nb slices (sharded) | verdicts of iterations
+//       k0+1 .. k0+nb (the last block: .. max_steps - 1, its last slice is the next call's st->p0;
+//       its diff tail is folded into the extra record seq0 + max_steps) | the slices cleared;
 // every launch is a no-op once an iteration at or before its own has failed.  With plan->overlap
 // the all-reduce and the verdicts of block b go to the plan's second stream while the caller's
 // stream runs block b + 1 (two ring halves; block b + 2 waits for block b's verdicts).  The
 // blocks are B long, the last B iterations of a call split 3 : 1 so that the all-reduce nobody
-// can hide -- the last one -- is a short one.  Then the records are read in order.  A failed
-// iteration j means that sweeps behind j ran on an estimate that was not the operator's answer:
-// the last state saved at or before the block that judged j is put back and the sweeps from
-// there to j - 1 (all judged good) are run again, then sweep j itself (to the spares): bit for
-// bit the memory that the loop judging every launch leaves behind a failed verdict (the PDHG
-// residences' carried multipliers are part of the saved state).
-constexpr int kSaveEvery = 4;
-static int stream_run_blocks(revs_plan_t *plan, int32_t max_steps, revs_stream_state_t *st, double scale,
-                             double eps, int32_t *kept_steps, double *rmax_last, unsigned int seq0,
-                             hipStream_t s) {
+// can hide -- the last one -- is a short one.  Then the records are read in order.
+// Roll-back without copies: the residences' state lives in FOUR sets of buffers.  A block reads
+// its entry set E_b and its launches alternate between the two sets that are neither E_b nor
+// E_{b-1}, so the state a block started from survives until the block AFTER it has been enqueued
+// -- and that one cannot start before this block's verdicts are in.  A failed iteration j means
+// that sweeps behind j ran on an estimate that was not the operator's answer: the sweeps from the
+// entry of the block that judged j up to j - 1 (all judged good) are run again from E_b, then sweep
+// j itself (outputs to a spare set, carried multipliers in place): bit for bit the memory that the
+// loop judging every launch leaves behind a failed verdict.
+extern "C" int revs_plan_stream_run_blocks(revs_plan_t *plan, int32_t max_steps, revs_stream_sets_t *st,
+                                           double scale, double eps, int32_t *kept_steps, double *rmax_last,
+                                           double *dmax_out, void *stream) {
+    REVS_REQUIRE(plan && st && kept_steps && rmax_last && max_steps >= 0 && max_steps < revs::kRecRing - 1 &&
+                 scale > 0.0 && eps > 0.0, "revs_plan_stream_run_blocks: bad argument (at most %d steps per call)",
+                 revs::kRecRing - 2);
     const revs_plan_desc_t &d = plan->d;
+    REVS_REQUIRE(plan->tree.n > 0 && d.node_of && plan->block > 1 && d.recompute_pe_new,
+                 "revs_plan_stream_run_blocks: needs a tree, node_of, recompute_pe_new and revs_plan_set_stream_block");
+    const bool warm = d.mode == REVS_MODE_RELAXED_PDHG && d.pdhg_dual != nullptr;
+    for (int i = 0; i < 4; ++i) {
+        REVS_REQUIRE(st->p_est[i] && st->p_sch[i] && st->gamma[i] && (!warm || st->pdhg_dual[i]),
+                     "revs_plan_stream_run_blocks: null buffer in set %d", i);
+        for (int j = 0; j < i; ++j)
+            REVS_REQUIRE(st->p_est[i] != st->p_est[j] && st->p_sch[i] != st->p_sch[j] && st->gamma[i] != st->gamma[j] &&
+                         (!warm || st->pdhg_dual[i] != st->pdhg_dual[j]),
+                         "revs_plan_stream_run_blocks: the four sets must be distinct buffers");
+        REVS_REQUIRE(st->p_est_next != st->p_est[i], "revs_plan_stream_run_blocks: p_est_next must not be in a set");
+    }
+    REVS_REQUIRE(st->p0 && st->p_est_next && (!warm || st->pdhg_dual[0] == d.pdhg_dual),
+                 "revs_plan_stream_run_blocks: p0 / p_est_next missing, or set 0 does not hold the plan's multipliers");
+    hipStream_t s = (hipStream_t)stream;
+    *kept_steps = 0;
+    *rmax_last = 0.0;
+    if (max_steps == 0) return REVS_OK;
+    if (plan->stream_seq > 0xFFFF0000u) {                // wrap, once in 4e9 launches: start over
+        const revs::StreamCtl ctl0{0u, 0u, 0ull};
+        if (hipStreamSynchronize(s) != hipSuccess ||
+            hipMemcpy(plan->ctl, &ctl0, sizeof(ctl0), hipMemcpyHostToDevice) != hipSuccess) {
+            revs::set_error("revs_plan_stream_run_blocks: resetting the control block failed");
+            return REVS_ELAUNCH;
+        }
+        plan->stream_seq = 0;
+    }
+    const unsigned int seq0 = plan->stream_seq + 1;
     const int64_t mt = (int64_t)d.m * d.T, nt = d.n_homes * (int64_t)d.T;
-    const int B = plan->block;
+    (void)nt;
+    const int B = plan->block, K = plan->inner;
+    const int nranks = plan->comm ? plan->comm->nranks : 1, rank = plan->comm ? plan->comm->rank : 0;
+    const int ntail = REVS_DMAX_SLOTS * nranks;
+    const int64_t stride = mt + ntail;                   // doubles per ring slice: node sums, then every rank's partial maxima
     // (the second stream costs a burst ~0.15 ms of host time in event and cross-stream calls: a
     // burst of one block has nothing to hide behind and stays on the caller's stream)
     const bool ov = plan->overlap != 0 && max_steps > B;
     const double vtol = eps * scale;
+    auto hip_ok = [&](hipError_t e, const char *what) -> int {
+        if (e == hipSuccess) return REVS_OK;
+        revs::set_error("revs_plan_stream_run_blocks: %s: %s", what, hipGetErrorString(e));
+        return REVS_ELAUNCH;
+    };
+    {   // the ring: two halves of B slices (one half without the second stream)
+        const size_t need = (size_t)2 * B * stride;
+        if (plan->ring_cap < need) {
+            if (plan->ring) { (void)hipStreamSynchronize(s); (void)hipFree(plan->ring); }
+            plan->ring = nullptr;
+            plan->ring_cap = 0;
+            if (hip_ok(hipMalloc((void **)&plan->ring, sizeof(double) * need), "hipMalloc(ring)") != REVS_OK)
+                return REVS_ELAUNCH;
+            plan->ring_cap = need;
+        }
+    }
     // block starts: k0[b], b = 0 .. nblocks (k0[nblocks] = max_steps)
     std::vector<int> k0s;
     for (int k = 0; k < max_steps;) {
@@ -757,31 +821,28 @@ static int stream_run_blocks(revs_plan_t *plan, int32_t max_steps, revs_stream_s
         while (k0s[b + 1] < j) ++b;
         return b;
     };
-    auto ring_of = [&](int b) { return plan->ring + (ov ? (int64_t)(b & 1) * B * mt : 0); };
-    auto sweep = [&](int k, int k0, double *ring, bool replay) -> int {
+    auto ring_of = [&](int b) { return plan->ring + (ov ? (int64_t)(b & 1) * B * stride : 0); };
+    // One launch: iterations k .. k + kin - 1 from set `in` to set `out`; their node sums and diff
+    // tails to slices (k - k0) .. of `ring` (replay: one scratch region, no tails).
+    auto sweep = [&](int k, int kin, int in, int out, double *slice0, bool replay, float *pe_next,
+                     bool y_in_place) -> int {
         revs::StreamExtra sx{};
         sx.ctl = plan->ctl;
         sx.seq = seq0 + (unsigned int)k + 1u;            // (the kernel skips when bad < seq: at or before k)
         sx.base_seq = replay ? sx.seq : seq0;            // (a replayed sweep is never skipped)
         sx.verdict = false;
         sx.flags = plan->flags_dev;
+        sx.kin = kin;
+        sx.pe_out = st->p_est[out];
+        sx.y_out = warm ? (y_in_place ? st->pdhg_dual[in] : st->pdhg_dual[out]) : nullptr;
+        sx.slice_stride = stride;
+        sx.diff_stride = st->diff_hist ? d.n_homes : 0;
+        sx.dmax_out = replay ? nullptr : slice0 + mt + (int64_t)rank * REVS_DMAX_SLOTS;
         return revs::agent_step_stream(
-            d.n_homes, d.T, d.cost, d.homes, d.load, st->p_est[k % 3],
-            d.recompute_pe_new ? nullptr : st->p_est[(k + 1) % 3], st->p_sch[k % 2], st->gamma[k % 2],
-            st->p_sch[(k + 1) % 2], st->gamma[(k + 1) % 2],
-            st->diff_hist ? st->diff_hist + (int64_t)k * d.n_homes : d.diff, d.dsq, d.status, d.pdhg_dual,
-            (float)d.kappa, d.mode, &d.pdhg, d.node_of, ring + (int64_t)(k - k0) * mt,
-            st->p_est[(k + 2) % 3], sx, s);
-    };
-    // the state iteration k0 starts from: P_est[k0], P_est[k0+1] (read by sweep k0+1, written
-    // before the block), P_sch[k0], Gamma[k0], and the PDHG residences' carried multipliers
-    const bool warm = d.mode == REVS_MODE_RELAXED_PDHG && d.pdhg_dual != nullptr;
-    const int narr = warm ? 5 : 4;
-    const int64_t cnt[5] = {nt, nt, nt, nt, d.pdhg.full_rows ? nt : d.n_homes};
-    auto state_of = [&](int k0, float **a) {
-        a[0] = st->p_est[k0 % 3]; a[1] = st->p_est[(k0 + 1) % 3];
-        a[2] = st->p_sch[k0 % 2]; a[3] = st->gamma[k0 % 2];
-        a[4] = d.pdhg_dual;
+            d.n_homes, d.T, d.cost, d.homes, d.load, st->p_est[in], nullptr, st->p_sch[in], st->gamma[in],
+            st->p_sch[out], st->gamma[out],
+            st->diff_hist ? st->diff_hist + (int64_t)k * d.n_homes : d.diff, d.dsq, d.status,
+            warm ? st->pdhg_dual[in] : nullptr, (float)d.kappa, d.mode, &d.pdhg, d.node_of, slice0, pe_next, sx, s);
     };
     // events of the overlapped form: [2 b] = block b's sweeps are done, [2 b + 1] = its verdicts are
     // in, [2 nblocks] = the side stream has finished this call
@@ -789,59 +850,68 @@ static int stream_run_blocks(revs_plan_t *plan, int32_t max_steps, revs_stream_s
         while ((int)plan->events.size() < 2 * nblocks + 1) {
             hipEvent_t e;
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
-                revs::set_error("revs_plan_stream_run: hipEventCreate failed");
+                revs::set_error("revs_plan_stream_run_blocks: hipEventCreate failed");
                 return REVS_ELAUNCH;
             }
             plan->events.push_back(e);
         }
-    auto hip_ok = [&](hipError_t e, const char *what) -> int {
-        if (e == hipSuccess) return REVS_OK;
-        revs::set_error("revs_plan_stream_run: %s: %s", what, hipGetErrorString(e));
-        return REVS_ELAUNCH;
-    };
     int rc = REVS_OK, launched = 0, checked = 0, failed_at = -1;
     double rm = 0.0;
     static const bool trace = getenv("REVS_PLAN_TRACE") != nullptr;
     const auto tr0 = std::chrono::steady_clock::now();
     timing_begin(plan, s);
-    rc = revs::stream_block_verdict(plan->ctl, seq0, seq0 - 1u, seq0, 1, d.T, plan->tree, st->p[0], mt,
-                                    d.vlo, d.vhi, vtol, plan->grp_bits, plan->rec_dev, s);
+    // the slices this call accumulates into start from zero (a failed call leaves them in any state)
+    rc = hip_ok(hipMemsetAsync(plan->ring, 0, sizeof(double) * (size_t)(ov && nblocks > 1 ? 2 * B : std::min(B, max_steps)) * stride, s),
+                "hipMemsetAsync(ring)");
+    if (rc == REVS_OK)
+        rc = revs::stream_block_verdict(plan->ctl, seq0, seq0 - 1u, seq0, 1, d.T, plan->tree, st->p0, mt, nullptr, 0,
+                                        false, d.vlo, d.vhi, vtol, plan->grp_bits, plan->grp_dmax, plan->rec_dev, s);
     hipStream_t q = ov ? plan->side : s;                 // where the collective and the verdicts go
+    std::vector<int> entry(nblocks + 1, 0);              // the set a block starts from
+    int cur = 0, prev = 1;                               // prev: the entry of the block before (kept intact as well)
     for (int b = 0; b < nblocks && rc == REVS_OK; ++b) {
         const int k0 = k0s[b], nb = k0s[b + 1] - k0;
         double *ring = ring_of(b);
+        entry[b] = cur;
+        int wk[2], nw = 0;
+        for (int i = 0; i < 4; ++i) if (i != cur && i != prev) wk[nw++] = i;
         // (overlapped: this block reuses the ring half of block b - 2, whose verdicts must be in
-        // and the half cleared -- they also decide whether this block is a no-op)
+        // and the half cleared -- they also decide whether this block is a no-op -- and rewrites
+        // the set block b - 2 started from)
         if (ov && b >= 2) rc = hip_ok(hipStreamWaitEvent(s, plan->events[2 * (b - 2) + 1], 0), "hipStreamWaitEvent");
-        if (rc == REVS_OK && b % kSaveEvery == 0) {
-            // generation (b / kSaveEvery) & 1: the other one may still be needed by a verdict that is not in yet
-            float *cur[5];
-            state_of(k0, cur);
-            rc = revs::stream_block_begin(plan->ctl, seq0, seq0 + (unsigned int)k0, cur,
-                                          plan->ck[(b / kSaveEvery) & 1], cnt, narr, plan->ring,
-                                          b == 0 ? (int64_t)(ov && nblocks > 1 ? 2 * B : std::min(B, max_steps)) * mt : 0, s);
+        int in = cur, w = 0;
+        for (int k = k0; k < k0 + nb && rc == REVS_OK;) {
+            const int kin = std::min(K, k0 + nb - k);
+            const bool last = (k + kin == max_steps);    // the call's last launch also prepares P_est[k+n+1]
+            rc = sweep(k, kin, in, wk[w], ring + (int64_t)(k - k0) * stride, false, last ? st->p_est_next : nullptr, false);
+            in = wk[w];
+            w ^= 1;
+            k += kin;
+            launched += kin;
         }
-        for (int k = k0; k < k0 + nb && rc == REVS_OK; ++k, ++launched) rc = sweep(k, k0, ring, false);
+        prev = cur;
+        cur = in;
         if (ov && rc == REVS_OK) rc = hip_ok(hipEventRecord(plan->events[2 * b], s), "hipEventRecord");
         if (ov && rc == REVS_OK) rc = hip_ok(hipStreamWaitEvent(q, plan->events[2 * b], 0), "hipStreamWaitEvent");
         if (rc == REVS_OK && plan->comm)
-            rc = revs_comm_allreduce_f64(plan->comm, ring, (int64_t)nb * mt, 0, q);
-        const int judged = b + 1 < nblocks ? nb : nb - 1;
-        if (rc == REVS_OK && judged > 0)
+            rc = revs_comm_allreduce_f64(plan->comm, ring, (int64_t)nb * stride, 0, q);
+        const bool lastb = b + 1 == nblocks;
+        const int judged = lastb ? nb - 1 : nb;
+        if (rc == REVS_OK)
             rc = revs::stream_block_verdict(plan->ctl, seq0, seq0 + (unsigned int)k0,
                                             seq0 + (unsigned int)k0 + 1u, judged, d.T, plan->tree,
-                                            ring, mt, d.vlo, d.vhi, vtol, plan->grp_bits, plan->rec_dev, q);
+                                            ring, stride, ring + mt, ntail, lastb, d.vlo, d.vhi, vtol,
+                                            plan->grp_bits, plan->grp_dmax, plan->rec_dev, q);
         // (the slices are accumulated into again two blocks on -- one block on without the second
         // stream; the last block's are cleared by the next call)
-        if (rc == REVS_OK && b + 1 < nblocks)
-            rc = hip_ok(hipMemsetAsync(ring, 0, sizeof(double) * (size_t)nb * mt, q), "hipMemsetAsync");
+        if (rc == REVS_OK && !lastb)
+            rc = hip_ok(hipMemsetAsync(ring, 0, sizeof(double) * (size_t)nb * stride, q), "hipMemsetAsync");
         if (ov && rc == REVS_OK) rc = hip_ok(hipEventRecord(plan->events[2 * b + 1], q), "hipEventRecord");
     }
-    // the sums of iteration max_steps (summed over the ranks, not judged yet) are the caller's
-    // st->p[0] after the rotation below
+    entry[nblocks] = cur;
+    // the sums of iteration max_steps (summed over the ranks, not judged yet) are the caller's st->p0
     if (rc == REVS_OK && launched == max_steps)
-        rc = hip_ok(hipMemcpyAsync(st->p[max_steps % 3],
-                                   ring_of(nblocks - 1) + (int64_t)(max_steps - k0s[nblocks - 1] - 1) * mt,
+        rc = hip_ok(hipMemcpyAsync(st->p0, ring_of(nblocks - 1) + (int64_t)(max_steps - k0s[nblocks - 1] - 1) * stride,
                                    sizeof(double) * mt, hipMemcpyDeviceToDevice, q), "hipMemcpyAsync");
     if (ov) {        // the caller's stream is done when the side stream is (also after an error above)
         int r2 = hip_ok(hipEventRecord(plan->events[2 * nblocks], q), "hipEventRecord");
@@ -850,15 +920,21 @@ static int stream_run_blocks(revs_plan_t *plan, int32_t max_steps, revs_stream_s
     }
     timing_end(plan, s);
     const auto tr1 = std::chrono::steady_clock::now();
-    for (; rc == REVS_OK && checked < launched && failed_at < 0; ++checked) {
-        const int v = stream_wait(plan, seq0 + (unsigned int)checked, s, &rm);
+    // records 0 .. launched - 1 are the iterations' verdicts; record `launched` carries the last
+    // iteration's max diff only
+    for (; rc == REVS_OK && checked <= launched && failed_at < 0; ++checked) {
+        double r = 0.0;
+        const int v = stream_wait(plan, seq0 + (unsigned int)checked, s, &r);
         if (v < 0) rc = v;
         else if (v == 1) failed_at = checked;
+        if (checked < launched) rm = r;
+        if (v >= 0 && dmax_out && checked >= 1)
+            dmax_out[checked - 1] = plan->rec_host[4 * ((seq0 + (unsigned int)checked) % revs::kRecRing) + 3];
     }
     if (trace) {
-        fprintf(stderr, "[revs_plan_stream_run] %d blocks of at most %d%s: %d launches in %.1f us, records "
-                "read %.1f us later (host away from the wait loop for at most %.1f us), failed at %d\n",
-                nblocks, B, ov ? ", overlapped" : "", launched,
+        fprintf(stderr, "[revs_plan_stream_run_blocks] %d blocks of at most %d, %d iterations per launch%s: %d iterations "
+                "enqueued in %.1f us, records read %.1f us later (host away from the wait loop for at most %.1f us), "
+                "failed at %d\n", nblocks, B, K, ov ? ", overlapped" : "", launched,
                 std::chrono::duration<double, std::micro>(tr1 - tr0).count(),
                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tr1).count(),
                 plan->t_wait, failed_at);
@@ -871,36 +947,49 @@ static int stream_run_blocks(revs_plan_t *plan, int32_t max_steps, revs_stream_s
         (void)hipStreamSynchronize(s);
     }
     int kept = rc != REVS_OK ? 0 : (failed_at >= 0 ? failed_at : launched);
+    int fin = cur;                                       // the set that holds the state at return
     if (rc == REVS_OK && failed_at >= 0) {
-        int from = failed_at, k0 = failed_at;
-        // Block bf judged it.  At the very end of bf (failed_at = first iteration of block bf + 1)
-        // with everything on one stream nothing behind it ran, and if bf + 1 saved the state, that
-        // is the state wanted.  Otherwise sweeps from failed_at on did run (overlapped: the next
-        // block was under way while the verdicts came in -- some of its workgroups silenced, some
-        // not, a state it saved possibly half written): back to the last state saved at or before bf.
+        // Block bf judged it.  If it is the first iteration of block bf + 1, that block's entry set IS
+        // the state wanted (a block never writes the set it started from).  Otherwise go back to bf's
+        // own entry and run the good sweeps k0 .. failed_at - 1 again, alternating between two sets
+        // that are not the entry.
         const int bf = failed_at > 0 ? block_of(failed_at) : -1;
-        if (bf >= 0 && (ov || failed_at < k0s[bf + 1])) {
-            const int bs = (bf / kSaveEvery) * kSaveEvery;
-            from = k0 = k0s[bs];
-            float *cur[5];
-            state_of(k0, cur);
-            float **saved = plan->ck[(bs / kSaveEvery) & 1];
-            for (int q2 = 0; q2 < narr && rc == REVS_OK; ++q2)
-                rc = hip_ok(hipMemcpyAsync(cur[q2], saved[q2], sizeof(float) * cnt[q2], hipMemcpyDeviceToDevice, s),
-                            "restoring the saved state");
+        int k = failed_at, in = entry[0];
+        if (bf >= 0) {
+            if (failed_at == k0s[bf + 1]) in = entry[bf + 1];
+            else { k = k0s[bf]; in = entry[bf]; }
         }
-        // the good sweeps again, and the failed iteration's own sweep, which writes to the spares
-        // only: the memory is then what a loop that judges every launch leaves behind a failed
-        // verdict.  (Their node sums go to one scratch slice: nobody reads them.)
-        for (int k = from; k <= failed_at && rc == REVS_OK; ++k) rc = sweep(k, k, plan->ring, true);
+        int wk[2], nw = 0;
+        for (int i = 0; i < 4 && nw < 2; ++i) if (i != in) wk[nw++] = i;
+        int w = 0;
+        while (k < failed_at && rc == REVS_OK) {
+            const int kin = std::min(K, failed_at - k);
+            rc = sweep(k, kin, in, wk[w], plan->ring, true, nullptr, false);
+            in = wk[w];
+            w ^= 1;
+            k += kin;
+        }
+        // ... and the failed iteration's own sweep, as the loop that judges every launch runs it:
+        // outputs to a spare set, the carried multipliers updated in place
+        int spare = 0;
+        while (spare == in) ++spare;
+        if (rc == REVS_OK) rc = sweep(failed_at, 1, in, spare, plan->ring, true, st->p_est_next, true);
+        fin = in;
         if (rc != REVS_OK || hipStreamSynchronize(s) != hipSuccess) {
-            if (rc == REVS_OK) revs::set_error("revs_plan_stream_run: replaying the block failed");
+            if (rc == REVS_OK) revs::set_error("revs_plan_stream_run_blocks: replaying the block failed");
             rc = REVS_ELAUNCH;
             kept = 0;
         }
     }
     *kept_steps = kept;
-    stream_rotate(st, kept, d.n_homes);
+    if (rc == REVS_OK && fin != 0) {                     // roles: set 0 = the state at return
+        std::swap(st->p_est[0], st->p_est[fin]);
+        std::swap(st->p_sch[0], st->p_sch[fin]);
+        std::swap(st->gamma[0], st->gamma[fin]);
+        std::swap(st->pdhg_dual[0], st->pdhg_dual[fin]);
+    }
+    if (rc == REVS_OK && warm) plan->d.pdhg_dual = st->pdhg_dual[0];
+    if (st->diff_hist) st->diff_hist += (int64_t)kept * d.n_homes;
     return rc;
 }
 
@@ -936,8 +1025,7 @@ extern "C" int revs_plan_stream_run(revs_plan_t *plan, int32_t max_steps, revs_s
     }
     const unsigned int seq0 = plan->stream_seq + 1;
     const int64_t mt = (int64_t)d.m * d.T;
-    if (plan->block > 1)
-        return stream_run_blocks(plan, max_steps, st, scale, eps, kept_steps, rmax_last, seq0, s);
+    REVS_REQUIRE(plan->block <= 1, "revs_plan_stream_run: verdicts by blocks go through revs_plan_stream_run_blocks");
     auto launch = [&](int k) -> int {               // step k of this call (roles by rotation)
         revs::StreamExtra sx;
         sx.ctl = plan->ctl;

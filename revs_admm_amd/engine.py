@@ -118,9 +118,14 @@ class OperatorOptions:
     # Residences sharded: the verdicts of this many consecutive iterations are taken together,
     # after ONE all-reduce of their node sums (revs_plan_set_stream_block) -- a collective per
     # sweep would make the collective's latency the step.  1: every iteration, as on one GPU.
-    # stream_block_single: use blocks on one GPU too (how the tests drive the roll-back).
+    # stream_block_single: blocks on one GPU too (default: the same loop on one GPU and on eight;
+    # False = every launch judges itself there, the round-2 form the tests compare against).
     stream_block: int = 32
-    stream_block_single: bool = False
+    stream_block_single: bool = True
+    # ... and, with blocks, this many consecutive ADMM iterations per sweep launch: no verdict is
+    # needed between them, so every residence's state stays in registers (revs_agent_step_multi;
+    # profiles read and written once per stream_inner iterations, same bits as one launch each)
+    stream_inner: int = 4
     # ... with the all-reduce and the verdicts of a block on a second stream, beside the sweeps of
     # the next block (the collective is hidden as long as it is shorter than a block of sweeps)
     stream_overlap: bool = True
@@ -432,6 +437,11 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
             if self._plan is not None:
                 check(self.lib.revs_plan_set_comm(self._plan, self._comm), "revs_plan_set_comm")
         self._block = 0
+        self._sets = None               # buffer pools of the block form (allocated on first use)
+        # max_h diff[h] (lpsolver.py:284) of the iterations whose sweeps folded it on the device:
+        # {iteration number (1-based, as the reference's diff[k]): value}
+        self.max_diff = {}
+        self._dmax_buf = (C.c_double * 1024)()
         self.stream_calls = []          # (launches enqueued, iterations kept) of every native burst
         # arguments of revs_plan_stream_run, built once (a burst of 20 sweeps is 0.4 ms: every
         # microsecond of Python around it is a microsecond of idle GPU)
@@ -442,10 +452,14 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
         self._scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
         self._pn0 = None
         if (self._plan is not None and self._tree is not None and self.op.stream_block > 1
-                and (self._comm is not None or self.op.stream_block_single)):
+                and self.recompute_pe_new and (self._comm is not None or self.op.stream_block_single)):
             self._block = min(int(self.op.stream_block), _lib.STREAM_BLOCK_MAX)
             check(self.lib.revs_plan_set_stream_block(self._plan, self._block, int(self.op.stream_overlap)),
                   "revs_plan_set_stream_block")
+            self._inner = max(1, min(int(self.op.stream_inner), _lib.AGENT_MAX_INNER))
+            check(self.lib.revs_plan_set_stream_inner(self._plan, self._inner), "revs_plan_set_stream_inner")
+            self._sets_st = _lib.StreamSets()
+            self._sets_ref = C.byref(self._sets_st)
         # R (float) for the voltage check
         self.R32 = up(Rn.astype(np.float32))
         self.node_load = torch.zeros(M, T, **f32)

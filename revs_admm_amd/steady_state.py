@@ -60,6 +60,8 @@ class SteadyStateMixin:
         i-th iteration done here (run(): solve_ADMM's per-iteration diff without a host round
         trip per iteration)."""
         o = self.op
+        if self._block:
+            return self._stream_run_blocks(count, hist)
         p0 = self._fused_p
         d0 = _dp(p0)
         if self._pn0 is None:
@@ -67,10 +69,7 @@ class SteadyStateMixin:
         rest = [b for b in (self._pn0, self.p_alt, self.p_alt2) if _dp(b) != d0]
         # p[1] must be zero on entry.  The last launch of a fully kept call has just cleared the
         # array that is p[1] now (roles rotate): no fill launch then
-        # (verdicts by blocks: the sweeps accumulate into the plan's ring, p[1] and p[2] are not used)
-        if self._block:
-            pass
-        elif self._p_clear is not None and _dp(self._p_clear) != d0:
+        if self._p_clear is not None and _dp(self._p_clear) != d0:
             dc = _dp(self._p_clear)
             rest = [self._p_clear] + [b for b in rest if _dp(b) != dc]
         else:
@@ -103,7 +102,7 @@ class SteadyStateMixin:
         self.P_sch, self.P_sch_alt = by[st.p_sch[0]], by[st.p_sch[1]]
         self.G, self.G_alt = by[st.gamma[0]], by[st.gamma[1]]
         self._fused_p = by[st.p[0]]
-        self._p_clear = by[st.p[1]] if (n == count and not self._block) else None
+        self._p_clear = by[st.p[1]] if n == count else None
         self._prod_ahead = False
         self._ar_ahead = self.group is not None
         if n:
@@ -120,6 +119,78 @@ class SteadyStateMixin:
             return n
         # iteration n's verdict failed (its sweep wrote to the spares only; every launch behind
         # it was a no-op): finish it as step() does for a discarded speculative sweep
+        self._fused_ready = False
+        self._spec_discard(None, False)
+        self.P_est, self.P_est_new = self.P_est_new, self.P_est
+        self.iteration += 1
+        if hist is not None:
+            hist[n].copy_(self.diff)
+        return n + 1
+
+    def _stream_run_blocks(self, count, hist=None):
+        """_stream_run with the verdicts taken by blocks and `stream_inner` iterations per launch
+        (revs_plan_stream_run_blocks): the state rotates through four sets of buffers, so that a
+        failed verdict deep inside a burst is undone without copies."""
+        o = self.op
+        if self._sets is None:
+            z = lambda t: torch.zeros_like(t)
+            self._sets = dict(pe=[self.P_est, self.P_est_new, self.P_est_alt, z(self.P_est), z(self.P_est)],
+                              ps=[self.P_sch, self.P_sch_alt, z(self.P_sch), z(self.P_sch)],
+                              g=[self.G, self.G_alt, z(self.G), z(self.G)],
+                              y=([self.pdhg_dual] + [z(self.pdhg_dual) for _ in range(3)]
+                                 if self.pdhg_dual is not None else None))
+        p0 = self._fused_p
+        if self.group is not None and not self._ar_ahead:
+            self._allreduce(p0)
+        pool = self._sets
+
+        def roles(first, tensors, skip=()):
+            rest = [t for t in tensors if t is not first and all(t is not x for x in skip)]
+            return [first] + rest
+
+        pes = roles(self.P_est, pool["pe"], skip=(self.P_est_new,))
+        pss, gs = roles(self.P_sch, pool["ps"]), roles(self.G, pool["g"])
+        ys = roles(self.pdhg_dual, pool["y"]) if pool["y"] is not None else [None] * 4
+        assert len(pes) == len(pss) == len(gs) == len(ys) == 4
+        st, by = self._sets_st, {}
+        for i in range(4):
+            for arr, t in ((st.p_est, pes[i]), (st.p_sch, pss[i]), (st.gamma, gs[i]), (st.pdhg_dual, ys[i])):
+                arr[i] = None if t is None else _dp(t)
+                if t is not None:
+                    by[_dp(t)] = t
+        st.p0, st.p_est_next = _dp(p0), _dp(self.P_est_new)
+        st.diff_hist = None if hist is None else hist.data_ptr()
+        count = min(count, self._burst, 1000)
+        kept, rm = self._stream_out
+        check(self.lib.revs_plan_stream_run_blocks(self._plan, count, self._sets_ref, self._scale, o.eps,
+                                                   self._stream_out_ref[0], self._stream_out_ref[1],
+                                                   C.addressof(self._dmax_buf), self.stream),
+              "revs_plan_stream_run_blocks")
+        n = kept.value
+        self.stream_calls.append((count, n))
+        self._burst = min(4 * self._burst, o.stream_burst_max) if n == count else o.stream_burst
+        self.P_est, self.P_est_alt = by[st.p_est[0]], by[st.p_est[1]]
+        self.P_sch, self.P_sch_alt = by[st.p_sch[0]], by[st.p_sch[1]]
+        self.G, self.G_alt = by[st.gamma[0]], by[st.gamma[1]]
+        if pool["y"] is not None:
+            self.pdhg_dual = by[st.pdhg_dual[0]]       # (the plan already points at it)
+        self._p_clear = None
+        self._prod_ahead = False
+        self._ar_ahead = self.group is not None
+        for i in range(n):
+            self.max_diff[self.iteration + i + 1] = self._dmax_buf[i]
+        if n:
+            self.op_iters_hist.extend([1] * n)
+            self.op_path_hist.extend(["dual"] * n)
+            self.newton_hist.extend([(0, 1, 0)] * n)
+            self.op_converged = True
+            self.spec_hist[0] += n
+            self._spec_back = 1
+            self.iteration += n
+        if n == count:
+            if hist is not None:
+                self.diff.copy_(hist[n - 1])
+            return n
         self._fused_ready = False
         self._spec_discard(None, False)
         self.P_est, self.P_est_new = self.P_est_new, self.P_est

@@ -212,7 +212,7 @@ def test_process_group_path_on_one_gpu(gpu_lib):
         # the streaming steady state with the library's OWN communicator in the loop: sweep ->
         # ncclAllReduce of the node sums on the compute stream -> sweep, launches made in chunks,
         # no host read in between (revs_plan_stream_run) == the one-GPU run, bit for bit
-        a = _engine(w2, "pdhg")
+        a = _engine(w2, "pdhg", op=OperatorOptions(stream_block_single=False))   # every launch judges itself
         b = _engine(w2, "pdhg", group=dist.group.WORLD)
         assert b._comm is not None and b._tree is not None
         for chunk in (3, 40, 37):
@@ -698,8 +698,8 @@ _RAGGED = (1, 7, 30, 2, 50, 64, 11)
     ("pdhg", 8000, 200, 3, 1.02, 24, 5, _RAGGED),                   # a failed verdict at the head of a call
     ("binary", 8000, 200, 3, 0.5, 24, 7, _RAGGED),
     ("pdhg", 3000, 200, 3, 1.02, 96, 4, _RAGGED)])
-@pytest.mark.parametrize("overlap", [False, True])
-def test_block_verdicts_equal_per_launch_verdicts(gpu_lib, mode, n, nodes, seed, stress, T, block, chunks, overlap):
+@pytest.mark.parametrize("overlap,inner", [(False, 4), (True, 4), (True, 1), (False, 3), (True, 8)])
+def test_block_verdicts_equal_per_launch_verdicts(gpu_lib, mode, n, nodes, seed, stress, T, block, chunks, overlap, inner):
     """The sharded form of the streaming loop -- `block` sweeps run unjudged, their node sums go to
     a ring, one launch judges the whole block, and a failed iteration inside a block is undone
     from the state the block saved (revs_plan_set_stream_block) -- against the loop where every
@@ -715,9 +715,9 @@ def test_block_verdicts_equal_per_launch_verdicts(gpu_lib, mode, n, nodes, seed,
     if small:
         w.load, w.cost = f32(w.load), f32(w.cost)
     kw = dict(stream_burst=16, stream_burst_max=64) if small else {}
-    a = _engine(w, mode, op=OperatorOptions(**kw))
+    a = _engine(w, mode, op=OperatorOptions(stream_block_single=False, **kw))
     b = _engine(w, mode, op=OperatorOptions(stream_block=block, stream_block_single=True,
-                                            stream_overlap=overlap, **kw))
+                                            stream_overlap=overlap, stream_inner=inner, **kw))
     assert a._block == 0 and b._block == block
     for chunk in chunks:
         a.run_steps(chunk)
@@ -728,6 +728,7 @@ def test_block_verdicts_equal_per_launch_verdicts(gpu_lib, mode, n, nodes, seed,
             assert torch_equal(getattr(a, name), getattr(b, name)), (name, a.iteration)
         if a._fused_ready:
             assert b._fused_ready and torch_equal(a._fused_p, b._fused_p)
+            assert torch_equal(a.P_est_new, b.P_est_new)          # the prepared estimate P_est[k+1]
     assert a.spec_hist == b.spec_hist and a.chain_hist == b.chain_hist and a.spec_hist[0] > 60
     assert a.op_iters_hist == b.op_iters_hist and a.newton_hist == b.newton_hist
     failed = [(c, k) for c, k in b.stream_calls if k < c]
@@ -742,7 +743,8 @@ def test_block_verdicts_equal_per_launch_verdicts(gpu_lib, mode, n, nodes, seed,
         np.testing.assert_array_equal(x, y)
 
 
-@pytest.mark.parametrize("mode,block", [("pdhg", 0), ("relaxed_exact", 0), ("binary", 0), ("pdhg", 5)])
+@pytest.mark.parametrize("mode,block", [("pdhg", 0), ("relaxed_exact", 0), ("binary", 0), ("pdhg", 5),
+                                        ("relaxed_exact", 32), ("binary", 8)])
 def test_run_collects_every_iterations_diff_on_the_device(gpu_lib, mode, block):
     """AdmmEngine.run (what lpsolver.solve_ADMM calls) lets the steady-state launches write each
     iteration's diff into a history on the device and fetches it in one piece; the rows must be
@@ -764,6 +766,12 @@ def test_run_collects_every_iterations_diff_on_the_device(gpu_lib, mode, block):
     d = b.run(K)
     assert b.spec_hist == a.spec_hist and b.spec_hist[0] > 30      # the streaming loop did the work
     assert len(b.stream_calls) < 15                                # ... in bursts, not iteration by iteration
+    if block:
+        # the convergence record: max_h diff[h] of every streamed iteration, folded on the device by
+        # the sweeps and the verdict launches, equals the maximum of that iteration's row
+        assert 30 < len(b.max_diff) <= b.spec_hist[0]
+        for k, v in b.max_diff.items():
+            assert v == float(d[k - 1].max()), (k, v, float(d[k - 1].max()))
     if mode == "pdhg":
         # (a discarded PDHG sweep leaves other warm-start multipliers when it ran inside a burst)
         np.testing.assert_allclose(d, ref, rtol=0, atol=2e-6)
