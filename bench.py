@@ -64,6 +64,20 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s ach
 F64_MFMA_PEAK_TFLOPS = 78.6    # MI355X datasheet, dense f64 matrix
 
 
+def multi_bytes_per_home(T, pdhg_dual, hist=False, inner=1):
+    """Algorithmic HBM bytes of one launch of the multi-iteration sweep per residence
+    (revs_agent_step_multi): reads LOAD, P_est, P_sch, G (4 profiles), the
+    32-byte record and the node index; writes P_est, P_sch, G (3 profiles), dsq, status and diff
+    (one float per inner iteration when the history is kept, else one); the carried PDHG
+    multiplier each way.  The call's last launch also writes the prepared estimate (not counted)."""
+    b = 4 * 4 * T + 32 + 4 + 3 * 4 * T + 8 + 4 * (inner if hist else 1)
+    if pdhg_dual == "full":
+        b += 2 * 4 * T
+    elif pdhg_dual:
+        b += 2 * 4
+    return b
+
+
 def agent_bytes_per_home(T, pdhg_dual, fused=True, recompute=False):
     """Algorithmic HBM bytes of one sweep launch per residence:
     reads LOAD, P_est[k], P_est[k+1], P_sch[k], G[k] (5 profiles) + the 32-byte home record;
@@ -321,6 +335,7 @@ def main():
         ms = C.c_double()
         if native and eng.lib.revs_plan_stream_elapsed_ms(eng._plan, C.addressof(ms)) == 0:
             dt_ev = ms.value * 1e-3
+            timed_steps.launches = int(eng.lib.revs_plan_stream_launches(eng._plan))
         else:                       # (no streaming burst in the region: nothing to price)
             dt_ev = e0.elapsed_time(e1) * 1e-3 if not native else float("nan")
         if native:
@@ -355,6 +370,7 @@ def main():
     inner0 = len(eng.op_iters_hist)
     # ---- the timed region: exactly K steps ----
     dt, dt_ev = timed_steps(eng, args.steps)
+    n_launch = getattr(timed_steps, "launches", 0) or args.steps     # residence-sweep launches in the region
     kept = eng.spec_hist[0] - spec0[0]
     streamed = bool(eng._tree is not None and kept == args.steps)
     inner = eng.op_iters_hist[inner0:]
@@ -385,14 +401,26 @@ def main():
     gemm_flops = 2.0 * eng.M * eng.M * args.T
 
     # how many ADMM iterations until max_h diff stays at the eps-residual (continues the run)
+    # -- from the max diff every streamed iteration leaves in its record (folded on the device by the
+    # sweeps and the verdict launches: no extra launch, no read-back of diff); iterations that ran
+    # outside the streaming loop are judged by revs_residual_finalize as before
     iters_to_eps = None
     if args.mode != "binary" and not args.no_converge:
-        while eng.iteration < 600:
-            rp, rd, dmax, conv = eng.residuals(args.eps)
-            if conv:
-                iters_to_eps = eng.iteration
-                break
-            eng.run_steps(5)
+        seen = 0
+        while eng.iteration < 800 and iters_to_eps is None:
+            for it in sorted(k for k in eng.max_diff if k > seen):
+                if eng.max_diff[it] <= args.eps:
+                    iters_to_eps = it
+                    break
+                seen = it
+            if iters_to_eps is None:
+                if eng.iteration not in eng.max_diff:
+                    rp, rd, dmax, conv = eng.residuals(args.eps)
+                    if conv:
+                        iters_to_eps = eng.iteration
+                        break
+                eng.run_steps(32)
+        rp, rd, dmax, conv = eng.residuals(args.eps)
     state = eng.get_state() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
 
     # ---- the other regimes, first-class (one GPU) ----
@@ -434,9 +462,13 @@ def main():
         warm = (None if eng.pdhg_dual is None else
                 ("full" if eng.pdhg_dual.dim() == 2 else "scalar"))
         rec = bool(getattr(eng, "recompute_pe_new", False))
-        bph = agent_bytes_per_home(args.T, warm, fused=True, recompute=rec)
+        inner = int(getattr(eng, "_inner", 1)) if eng._block else 1
+        if eng._block:
+            bph = multi_bytes_per_home(args.T, warm, hist=False, inner=inner)
+        else:
+            bph = agent_bytes_per_home(args.T, warm, fused=True, recompute=rec)
         bytes_per_launch = bph * n_local
-        launch_ms = dt_ev / args.steps * 1e3 if streamed else None
+        launch_ms = dt_ev / n_launch * 1e3 if streamed else None
         ach = bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms else None
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "agent_traffic.json")
@@ -482,7 +514,8 @@ def main():
                    ", one collective per iteration"),
                 "voltage_rows": ("tree form of R p inside the sweep's launch" if streamed else
                                  "dense f64 product R p on the matrix cores"),
-                "launches_per_step": 1 if streamed else 2,
+                "launches_per_step": (n_launch / args.steps) if streamed else 2,
+                "iterations_per_sweep_launch": inner if streamed else 1,
                 "recompute_pe_new": rec,
                 "collective": (None if world == 1 and group is None else
                                ("hook communicator over gloo, all ranks on cuda:0 (rehearsal)" if args.share_gpu
@@ -492,16 +525,23 @@ def main():
                 "clock_warmup_products": args.clock_warm,
             },
             "roofline": {
-                "kernel": "agent_step_kernel (home QP sweep + dual update + next operator home pass"
-                          + (" + voltage rows of T slots in its first T workgroups)" if streamed else ")"),
+                "kernel": ("agent_step_kernel<MULTI> (%d ADMM iterations of every residence per launch: home QP "
+                           "sweeps + dual updates + next operator home passes, state in registers; voltage "
+                           "rows judged by blocks of %d iterations in their own launch)" % (inner, eng._block)
+                           if streamed and eng._block else
+                           "agent_step_kernel (home QP sweep + dual update + next operator home pass"
+                           + (" + voltage rows of T slots in its first T workgroups)" if streamed else ")")),
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": ach / HBM_PEAK_GBS if ach else None,
                 # PMC counters are collected in separate rocprofv3 passes of this command and
                 # committed under profiles/; NOT measured inside this run
                 "traffic": traffic, "traffic_source": traffic_src,
                 "bytes_per_home": bph, "bytes_per_launch": bytes_per_launch,
-                # two HIP events around the K timed launches on their stream / K: the launch
-                # duration INCLUDING the inter-kernel boundary (rocprofv3's kernel time is shorter)
+                "bytes_per_home_per_iteration": bph / inner,
+                "sweep_launches_timed": n_launch,
+                # two HIP events around the timed region on the launches' stream / number of sweep
+                # launches in it: the launch duration INCLUDING the inter-kernel boundaries and the
+                # block verdict launches that share the stream (rocprofv3's kernel time is shorter)
                 "avg_launch_ms": launch_ms,
                 "frac_of_achievable_copy_rate": (ach / 6290.0) if ach else None,   # 6.29 TB/s: float4 copy
                 "pdhg_iters_mean": pdhg_it,

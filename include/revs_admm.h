@@ -784,9 +784,9 @@ int revs_plan_stream_run(revs_plan_t *plan, int32_t max_steps, revs_stream_state
  *         at entry set 0 is the state (P_est[k], P_sch[k], G[k]; its pdhg_dual must be the plan's),
  *         the others are scratch; at return set 0 is the state after the kept iterations (the roles
  *         are permuted, the plan's pdhg_dual follows -- see revs_plan_set_pdhg_dual).
- *         p0: node sums of the estimate P_est[k+1] (all-reduced) in, those of P_est[k+kept+1] out
- *         when every iteration was kept; p_est_next (a buffer outside the sets): P_est[k+kept+1]
- *         itself then; diff_hist as in revs_stream_state_t.
+ *         p0: node sums of the estimate P_est[k+1] (all-reduced); p0_out (another array): those of
+ *         P_est[k+kept+1] when every iteration was kept; p_est_next (a buffer outside the sets):
+ *         P_est[k+kept+1] itself then; diff_hist as in revs_stream_state_t.
  *   dmax_out  NULL, or double[max_steps]: [i] = max_h diff[h] of the i-th iteration of this call
  *         (lpsolver.py:284 -- the convergence measure), for the kept iterations: folded on the
  *         device by the sweeps (REVS_DMAX_SLOTS partial maxima per rank in the tail of every ring
@@ -805,7 +805,8 @@ typedef struct {
     float *p_sch[4];
     float *gamma[4];
     float *pdhg_dual[4];
-    double *p0;
+    const double *p0;
+    double *p0_out;
     float *p_est_next;
     float *diff_hist;
 } revs_stream_sets_t;
@@ -824,6 +825,8 @@ int revs_plan_set_pdhg_dual(revs_plan_t *plan, float *pdhg_dual);
  * synchronised, and re-arms.  What bench.py prices the sweep kernel's launch duration with. */
 int revs_plan_stream_timing(revs_plan_t *plan, int32_t enable);
 int revs_plan_stream_elapsed_ms(revs_plan_t *plan, double *ms);
+/* ... and the number of residence-sweep launches enqueued between the two events */
+int64_t revs_plan_stream_launches(revs_plan_t *plan);
 /* Bits OR-ed by the sweeps launched through the plan since the last clear: 1 = a residence's
  * window cannot reach 90 % SOC (the reference prints "No solution found", lpsolver.py:153-155),
  * 2 = a PDHG residence hit max_iter before its tolerance.  Meaningful after the stream has

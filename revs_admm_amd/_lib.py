@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librevs_admm.so")
+# (REVS_LIB: a tuning build of the same sources made with `python -m revs_admm_amd.build --out`)
+LIB_PATH = os.environ.get("REVS_LIB") or os.path.join(HERE, "librevs_admm.so")
 
 # numpy mirror of revs_home_t (include/revs_admm.h)
 HOME_DTYPE = np.dtype([("ev", "<i4"), ("start", "<i4"), ("end", "<i4"), ("nmin", "<i4"),
@@ -78,7 +79,8 @@ class StreamState(C.Structure):
 class StreamSets(C.Structure):
     """revs_stream_sets_t"""
     _fields_ = [("p_est", C.c_void_p * 4), ("p_sch", C.c_void_p * 4), ("gamma", C.c_void_p * 4),
-                ("pdhg_dual", C.c_void_p * 4), ("p0", C.c_void_p), ("p_est_next", C.c_void_p),
+                ("pdhg_dual", C.c_void_p * 4), ("p0", C.c_void_p), ("p0_out", C.c_void_p),
+                ("p_est_next", C.c_void_p),
                 ("diff_hist", C.c_void_p)]
 
 
@@ -187,6 +189,7 @@ SIGNATURES = {
     "revs_plan_stream_run_blocks": (C.c_int, [_p, _i32, C.POINTER(StreamSets), _f64, _f64, _p, _p, _p, _p]),
     "revs_plan_stream_timing": (C.c_int, [_p, C.c_int32]),
     "revs_plan_stream_elapsed_ms": (C.c_int, [_p, _p]),
+    "revs_plan_stream_launches": (_i64, [_p]),
     "revs_plan_stream_run": (C.c_int, [_p, _i32, C.POINTER(StreamState), _f64, _f64, _p, _p, _p]),
     "revs_plan_status_flags": (_i32, [_p, _i32]),
     "revs_op_dual_step_pending": (C.c_int, [_i32, _p, _p, _p, _p, _p, _f64, _f64, _p, _i32, _p, _p, _p]),

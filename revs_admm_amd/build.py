@@ -38,20 +38,26 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
+def build(force: bool = False, verbose: bool = False, out: str | None = None, extra=()) -> str:
+    """`out` / `extra`: a tuning build beside the product's (other -D flags, another file name:
+    loaded with REVS_LIB=path, see _lib.py) -- tools/ only."""
+    if out is None and not force and not _stale():
         return LIB
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     cmd = [hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-           "-x", "hip", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-           "-o", LIB] + srcs
+           "-x", "hip", "-I", os.path.join(ROOT, "include"), "-I", CSRC, *extra,
+           "-o", out or LIB] + srcs
     if verbose:
         print(" ".join(cmd), flush=True)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed:\n{r.stdout}\n{r.stderr}")
-    return LIB
+    return out or LIB
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    args = [a for a in sys.argv[1:] if a != "--force"]
+    if args and args[0] == "--out":         # python -m revs_admm_amd.build --out lib_x.so -DREVS_...=..
+        print(build(force=True, verbose=True, out=os.path.abspath(args[1]), extra=tuple(args[2:])))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

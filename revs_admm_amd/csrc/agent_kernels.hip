@@ -575,16 +575,14 @@ void agent_step_kernel(const AgentArgs a) {
     }
 
     // ---- g, dual update, residual terms of this iteration (lpsolver.py:275-284) ----
-    float ss = 0.f, dd = 0.f;
+    float ss = 0.f;
 #pragma unroll
     for (int j = 0; j < SPL; ++j) {
         const float g = p[j] + L[j];                        // lpsolver.py:64-65
         const float chk = pen[j] - g;                       // lpsolver.py:280
         gn[j] = g;
         gmn[j] = gm[j] + 0.5f * kappa * chk;                // lpsolver.py:282
-        const float dg = g - pso[j];
         ss += valid[j] ? chk * chk : 0.f;
-        dd += valid[j] ? dg * dg : 0.f;
     }
     // next evaluation's home pass (same arithmetic as op_dual_eval_kernel with d = 0)
     if (need_pe2) {
@@ -598,7 +596,6 @@ void agent_step_kernel(const AgentArgs a) {
     // only when somebody asks for them (no workgroup reduction in the sweep, which is VALU
     // issue bound)
     const float ssg = group_sum<LPA>(ss);
-    ddg = group_sum<LPA>(dd);
     // lpsolver.py:284; hardware sqrt and reciprocal (1 ulp each) instead of the IEEE sequences
     dfh = live ? __builtin_amdgcn_sqrtf(ssg) * __builtin_amdgcn_rcpf((float)T) : 0.f;
     sticky |= status & 3;
@@ -625,6 +622,15 @@ void agent_step_kernel(const AgentArgs a) {
     }
 
     // ---- stores: the state after the last inner iteration ----
+    {   // kappa |dP_sch|'s per-home term of the last iteration (the dual residual, on request)
+        float dd = 0.f;
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+            const float dg = gn[j] - pso[j];
+            dd += valid[j] ? dg * dg : 0.f;
+        }
+        ddg = group_sum<LPA>(dd);
+    }
     const int64_t crow = agent * (int64_t)(T + 1);
     float socv[SPL];
     if (a.c_out) {      // the SOC trajectory (a prefix sum over the slots) only where it is returned
@@ -993,25 +999,29 @@ int agent_step_stream(int64_t n_homes, int32_t T, const float *cost, const revs_
 struct BlockVerdict {
     StreamCtl *ctl;
     unsigned int base_seq, gate_seq;      // no-op when a launch numbered base_seq..gate_seq failed
-    unsigned int first_seq;               // slice g holds the sums judged for iteration first_seq + g
-    int32_t nb, T;                        // slices judged
-    int32_t ndmax;                        // slices whose tail is folded: nb, or nb + 1 (the call's last slice)
+    unsigned int first_seq;               // slice g (counting `pre` as slice 0) is judged for iteration first_seq + g
+    int32_t nb, T;                        // slices judged, `pre` included
+    int32_t ndmax;                        // records written: nb, or nb + 1 (the call's last slice: its tail only)
     TreeArgs tree;
-    const double *ring;
-    long long stride;                     // doubles from one slice to the next
-    const double *tail;                   // slice g's partial maxima of diff at tail + g * stride, or NULL
-    int32_t ntail;
+    const double *pre;                    // NULL, or the node sums of the call's first iteration (the caller's array)
+    double *ring;                         // the ring slices follow: slice g - (pre != NULL) at ring + that * stride
+    long long stride;                     // doubles from one ring slice to the next
+    int32_t mt, ntail;                    // node sums, then ntail partial maxima of diff (all ranks') per ring slice
+    double *hand_over;                    // NULL, or where the call's last slice (ring slice nb - (pre != NULL)) is copied to
     double vlo, vhi, vtol;
     unsigned long long *grp_bits;         // [nb] device words, zero on entry and on exit
     double *grp_dmax;                     // [ndmax] device words
     double *rec;                          // the record ring (device address of pinned memory)
 };
-// Workgroup (g, t): slot t of slice g; workgroup t == 0 of a slice also folds the slice's tail --
-// the partial maxima of diff that the sweep which produced the slice left (every rank in its own
-// REVS_DMAX_SLOTS words: the all-reduce's sum IS the gather) -- into max_h diff[h] of that sweep's
-// iteration; one extra workgroup does the same for the call's last slice, whose rows the next call
-// judges.  The last workgroup to finish writes the records {rmax, failed, seq, max diff of the
-// iteration before} and the lowest failed number into the control word.
+constexpr int kHandOverGroups = 8;        // workgroups that copy the call's last slice to the caller
+// Workgroup (g, t): slot t of slice g -- it clears what it has read, so the slice is ready for the
+// block that accumulates into it next; workgroup t == 0 of a ring slice also folds (and clears)
+// the slice's tail -- the partial maxima of diff that the sweep which produced the slice left,
+// every rank in its own REVS_DMAX_SLOTS words: the all-reduce's sum IS the gather -- into max_h
+// diff[h] of that sweep's iteration.  With hand_over, kHandOverGroups more workgroups move the
+// call's last slice (its rows are the next call's to judge) to the caller's array, clear it, and
+// fold its tail.  The last workgroup to finish writes the records {rmax, failed, seq, max diff
+// of the iteration before} and the lowest failed number into the control word.
 __global__ __launch_bounds__(256) void stream_block_verdict_kernel(const BlockVerdict b) {
     extern __shared__ double tree_lds[];
     {
@@ -1019,20 +1029,31 @@ __global__ __launch_bounds__(256) void stream_block_verdict_kernel(const BlockVe
         if (bad >= b.base_seq && bad <= b.gate_seq) return;
     }
     const int tid = threadIdx.x;
-    const int njudge = b.nb * b.T;
+    const int njudge = b.nb * b.T, npre = b.pre ? 1 : 0;
     const bool extra = (int)blockIdx.x >= njudge;
-    const int g = extra ? b.nb : (int)blockIdx.x / b.T, t = extra ? 0 : (int)blockIdx.x - g * b.T;
+    const int g = extra ? b.nb : (int)blockIdx.x / b.T, t = extra ? (int)blockIdx.x - njudge : (int)blockIdx.x - g * b.T;
+    double *slice = b.ring + (long long)(g - npre) * b.stride;       // (g == 0 with pre: not a ring slice)
+    const bool ring_slice = !(b.pre && g == 0);
     __shared__ double dm_s[4];
-    if (t == 0 && b.tail && g < b.ndmax) {
+    if (t == 0 && ring_slice && b.ntail > 0) {
         double v = 0.0;
-        for (int i = tid; i < b.ntail; i += 256) v = fmax(v, b.tail[(long long)g * b.stride + i]);
+        for (int i = tid; i < b.ntail; i += 256) { v = fmax(v, slice[b.mt + i]); slice[b.mt + i] = 0.0; }
         v = wave_max_d(v);
         if ((tid & 63) == 0) dm_s[tid >> 6] = v;
         __syncthreads();
-        if (tid == 0) b.grp_dmax[g] = fmax(fmax(dm_s[0], dm_s[1]), fmax(dm_s[2], dm_s[3]));
+        if (tid == 0)
+            __hip_atomic_store(&b.grp_dmax[g], fmax(fmax(dm_s[0], dm_s[1]), fmax(dm_s[2], dm_s[3])),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     double rmax = 0.0;
-    if (!extra) rmax = tree_rmax(b.tree, b.ring + (long long)g * b.stride, b.T, t, b.vlo, b.vhi, tree_lds, nullptr);
+    if (!extra) {
+        rmax = ring_slice ? tree_rmax(b.tree, slice, b.T, t, b.vlo, b.vhi, tree_lds, nullptr, slice)
+                          : tree_rmax(b.tree, b.pre, b.T, t, b.vlo, b.vhi, tree_lds, nullptr, nullptr);
+    } else {
+        const long long per = (b.mt + kHandOverGroups - 1) / kHandOverGroups;
+        const long long i0 = t * per, i1 = i0 + per < b.mt ? i0 + per : b.mt;
+        for (long long i = i0 + tid; i < i1; i += 256) { b.hand_over[i] = slice[i]; slice[i] = 0.0; }
+    }
     __shared__ int last_s;
     __shared__ unsigned int bad_s;
     if (tid == 0) {
@@ -1062,7 +1083,8 @@ __global__ __launch_bounds__(256) void stream_block_verdict_kernel(const BlockVe
         volatile double *rec = b.rec + 4 * (seq % kRecRing);
         rec[0] = r;
         rec[1] = failed ? 1.0 : 0.0;
-        rec[3] = b.tail ? __hip_atomic_load(&b.grp_dmax[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1.0;
+        rec[3] = (b.ntail > 0 && !(b.pre && q == 0))
+                     ? __hip_atomic_load(&b.grp_dmax[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1.0;
         __threadfence_system();
         rec[2] = (double)seq;
     }
@@ -1076,17 +1098,17 @@ __global__ __launch_bounds__(256) void stream_block_verdict_kernel(const BlockVe
 
 int stream_block_verdict(StreamCtl *ctl, unsigned int base_seq, unsigned int gate_seq,
                          unsigned int first_seq, int32_t nb, int32_t T, const TreeArgs &tree,
-                         const double *ring, int64_t stride, const double *tail, int32_t ntail,
-                         bool tail_extra, double vlo, double vhi, double vtol,
+                         const double *pre, double *ring, int64_t stride, int32_t mt, int32_t ntail,
+                         double *hand_over, double vlo, double vhi, double vtol,
                          unsigned long long *grp_bits, double *grp_dmax, double *rec, void *stream) {
-    REVS_REQUIRE(ctl && nb >= 0 && nb < kRecRing && (nb > 0 || tail_extra) && T > 0 && tree.n > 0 &&
-                 tree.n <= REVS_TREE_MAX && tree.n % 8 == 0 && tree.pack && tree.w && ring && stride > 0 &&
-                 vlo <= vhi && vtol >= 0.0 && grp_bits && grp_dmax && rec && (!tail_extra || tail) &&
-                 (!tail || ntail > 0), "stream_block_verdict: bad argument");
-    const BlockVerdict b{ctl, base_seq, gate_seq, first_seq, nb, T, nb + (tail_extra ? 1 : 0), tree, ring,
-                         (long long)stride, tail, ntail, vlo, vhi, vtol, grp_bits, grp_dmax, rec};
-    hipLaunchKernelGGL(stream_block_verdict_kernel, dim3((unsigned)(nb * T + (tail_extra ? 1 : 0))), dim3(256),
-                       tree_lds_bytes(tree.n), (hipStream_t)stream, b);
+    REVS_REQUIRE(ctl && nb >= 0 && nb < kRecRing && (nb > 0 || hand_over) && T > 0 && tree.n > 0 &&
+                 tree.n <= REVS_TREE_MAX && tree.n % 8 == 0 && tree.pack && tree.w && ring && stride >= mt + ntail &&
+                 mt > 0 && ntail >= 0 && vlo <= vhi && vtol >= 0.0 && grp_bits && grp_dmax && rec &&
+                 (!pre || nb >= 1), "stream_block_verdict: bad argument");
+    const BlockVerdict b{ctl, base_seq, gate_seq, first_seq, nb, T, nb + (hand_over ? 1 : 0), tree, pre, ring,
+                         (long long)stride, mt, ntail, hand_over, vlo, vhi, vtol, grp_bits, grp_dmax, rec};
+    hipLaunchKernelGGL(stream_block_verdict_kernel, dim3((unsigned)(nb * T + (hand_over ? kHandOverGroups : 0))),
+                       dim3(256), tree_lds_bytes(tree.n), (hipStream_t)stream, b);
     REVS_CHECK_LAUNCH("stream_block_verdict");
     return REVS_OK;
 }

@@ -35,16 +35,17 @@ int agent_step_stream(int64_t n_homes, int32_t T, const float *cost, const revs_
                       double *p_next, float *p_est_next, const StreamExtra &sx, void *stream);
 
 // Verdicts by blocks (agent_kernels.hip).  A no-op when a launch numbered base_seq..gate_seq has
-// failed its verdict.  Judges `nb` slices of node sums (slice g at ring + g * stride: the sums
-// iteration first_seq + g consumes), folds every slice's tail (ntail partial maxima of diff at
-// tail + g * stride, left by the sweep that produced the slice; tail == NULL: none) and, with
-// tail_extra, the tail of slice nb as well; writes the records {rmax, failed, seq, max diff of the
-// iteration before} of first_seq .. first_seq + nb (+ 1) and the lowest failed number into the
-// control word.
+// failed its verdict.  Judges `nb` slices of node sums -- `pre` (the caller's array: the sums of
+// the call's first iteration; NULL: none) and then ring slices at ring + g * stride, each `mt`
+// node sums followed by `ntail` partial maxima of diff left by the sweep that produced the slice
+// -- for the iterations first_seq, first_seq + 1, ...; clears every ring slice it has read; with
+// hand_over, copies the ring slice after the judged ones (the call's last: its rows are the next
+// call's to judge) there, clears it and folds its tail; writes the records {rmax, failed, seq,
+// max diff of the iteration before} and the lowest failed number into the control word.
 int stream_block_verdict(StreamCtl *ctl, unsigned int base_seq, unsigned int gate_seq,
                          unsigned int first_seq, int32_t nb, int32_t T, const TreeArgs &tree,
-                         const double *ring, int64_t stride, const double *tail, int32_t ntail,
-                         bool tail_extra, double vlo, double vhi, double vtol,
+                         const double *pre, double *ring, int64_t stride, int32_t mt, int32_t ntail,
+                         double *hand_over, double vlo, double vhi, double vtol,
                          unsigned long long *grp_bits, double *grp_dmax, double *rec, void *stream);
 
 }  // namespace revs

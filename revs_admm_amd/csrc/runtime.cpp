@@ -58,6 +58,7 @@ struct revs_plan {
     int32_t inner = 1;                     // ADMM iterations per sweep launch (revs_plan_set_stream_inner)
     double *ring = nullptr;                // device: node sums (+ diff tails) of two blocks, double[2][block][stride]
     size_t ring_cap = 0;                   // ... doubles allocated
+    bool ring_dirty = true;                // the ring is not known to be all zero (fresh, or a call failed)
     unsigned long long *grp_bits = nullptr;                // device: per-slice maxima, zero between launches
     double *grp_dmax = nullptr;            // device: per-slice max diff
     hipStream_t side = nullptr;
@@ -65,6 +66,7 @@ struct revs_plan {
     // optional timing of the bursts on their own stream (revs_plan_stream_timing)
     hipEvent_t tev[2] = {nullptr, nullptr};
     int32_t timing = 0;                    // 0 off, 1 armed (next burst records tev[0]), 2 open
+    int64_t timed_launches = 0;            // residence-sweep launches between the two events
 };
 
 // Host-side acceptance test of a chained Newton iteration (operator_newton.py: _chain_launch): the
@@ -610,7 +612,7 @@ extern "C" int revs_plan_set_stream_block(revs_plan_t *plan, int32_t block, int3
     REVS_REQUIRE(d.n_homes > 0 && d.node_of, "revs_plan_set_stream_block: the plan has no residences / node_of");
     REVS_REQUIRE(d.recompute_pe_new, "revs_plan_set_stream_block: verdicts by blocks need recompute_pe_new");
     if (!plan->grp_bits) {
-        const size_t gb = sizeof(unsigned long long) * (REVS_STREAM_BLOCK_MAX + 1);
+        const size_t gb = sizeof(unsigned long long) * (REVS_STREAM_BLOCK_MAX + 4);   // (+ the call's first iteration, + the handed-over slice)
         hipError_t e = hipMalloc((void **)&plan->grp_bits, gb);
         if (e == hipSuccess) e = hipMemset(plan->grp_bits, 0, gb);
         if (e == hipSuccess) e = hipMalloc((void **)&plan->grp_dmax, gb);
@@ -667,9 +669,13 @@ extern "C" int revs_plan_stream_elapsed_ms(revs_plan_t *plan, double *ms) {
     return REVS_OK;
 }
 
+extern "C" int64_t revs_plan_stream_launches(revs_plan_t *plan) {
+    return plan ? plan->timed_launches : 0;
+}
+
 // two HIP events around the bursts since revs_plan_stream_timing, on the bursts' own stream
 static void timing_begin(revs_plan_t *plan, hipStream_t s) {
-    if (plan->timing == 1 && hipEventRecord(plan->tev[0], s) == hipSuccess) plan->timing = 2;
+    if (plan->timing == 1 && hipEventRecord(plan->tev[0], s) == hipSuccess) { plan->timing = 2; plan->timed_launches = 0; }
 }
 static void timing_end(revs_plan_t *plan, hipStream_t s) {
     if (plan->timing == 2) (void)hipEventRecord(plan->tev[1], s);
@@ -765,8 +771,9 @@ extern "C" int revs_plan_stream_run_blocks(revs_plan_t *plan, int32_t max_steps,
                          "revs_plan_stream_run_blocks: the four sets must be distinct buffers");
         REVS_REQUIRE(st->p_est_next != st->p_est[i], "revs_plan_stream_run_blocks: p_est_next must not be in a set");
     }
-    REVS_REQUIRE(st->p0 && st->p_est_next && (!warm || st->pdhg_dual[0] == d.pdhg_dual),
-                 "revs_plan_stream_run_blocks: p0 / p_est_next missing, or set 0 does not hold the plan's multipliers");
+    REVS_REQUIRE(st->p0 && st->p0_out && st->p0 != st->p0_out && st->p_est_next &&
+                 (!warm || st->pdhg_dual[0] == d.pdhg_dual),
+                 "revs_plan_stream_run_blocks: p0 / p0_out / p_est_next missing, or set 0 does not hold the plan's multipliers");
     hipStream_t s = (hipStream_t)stream;
     *kept_steps = 0;
     *rmax_last = 0.0;
@@ -805,6 +812,7 @@ extern "C" int revs_plan_stream_run_blocks(revs_plan_t *plan, int32_t max_steps,
             if (hip_ok(hipMalloc((void **)&plan->ring, sizeof(double) * need), "hipMalloc(ring)") != REVS_OK)
                 return REVS_ELAUNCH;
             plan->ring_cap = need;
+            plan->ring_dirty = true;
         }
     }
     // block starts: k0[b], b = 0 .. nblocks (k0[nblocks] = max_steps)
@@ -860,12 +868,12 @@ extern "C" int revs_plan_stream_run_blocks(revs_plan_t *plan, int32_t max_steps,
     static const bool trace = getenv("REVS_PLAN_TRACE") != nullptr;
     const auto tr0 = std::chrono::steady_clock::now();
     timing_begin(plan, s);
-    // the slices this call accumulates into start from zero (a failed call leaves them in any state)
-    rc = hip_ok(hipMemsetAsync(plan->ring, 0, sizeof(double) * (size_t)(ov && nblocks > 1 ? 2 * B : std::min(B, max_steps)) * stride, s),
-                "hipMemsetAsync(ring)");
-    if (rc == REVS_OK)
-        rc = revs::stream_block_verdict(plan->ctl, seq0, seq0 - 1u, seq0, 1, d.T, plan->tree, st->p0, mt, nullptr, 0,
-                                        false, d.vlo, d.vhi, vtol, plan->grp_bits, plan->grp_dmax, plan->rec_dev, s);
+    // The slices a call accumulates into are zero: every verdict launch clears what it has judged.
+    // Only a fresh ring, or one a failed call left behind (silenced launches judge nothing), is cleared here.
+    if (plan->ring_dirty) {
+        rc = hip_ok(hipMemsetAsync(plan->ring, 0, sizeof(double) * plan->ring_cap, s), "hipMemsetAsync(ring)");
+        plan->ring_dirty = false;
+    }
     hipStream_t q = ov ? plan->side : s;                 // where the collective and the verdicts go
     std::vector<int> entry(nblocks + 1, 0);              // the set a block starts from
     int cur = 0, prev = 1;                               // prev: the entry of the block before (kept intact as well)
@@ -884,6 +892,7 @@ extern "C" int revs_plan_stream_run_blocks(revs_plan_t *plan, int32_t max_steps,
             const int kin = std::min(K, k0 + nb - k);
             const bool last = (k + kin == max_steps);    // the call's last launch also prepares P_est[k+n+1]
             rc = sweep(k, kin, in, wk[w], ring + (int64_t)(k - k0) * stride, false, last ? st->p_est_next : nullptr, false);
+            ++plan->timed_launches;
             in = wk[w];
             w ^= 1;
             k += kin;
@@ -895,24 +904,20 @@ extern "C" int revs_plan_stream_run_blocks(revs_plan_t *plan, int32_t max_steps,
         if (ov && rc == REVS_OK) rc = hip_ok(hipStreamWaitEvent(q, plan->events[2 * b], 0), "hipStreamWaitEvent");
         if (rc == REVS_OK && plan->comm)
             rc = revs_comm_allreduce_f64(plan->comm, ring, (int64_t)nb * stride, 0, q);
+        // block 0's launch also judges the call's first iteration (the caller's st->p0: its sweep ran
+        // unjudged, like every other sweep of the block); the last block's also hands the call's last
+        // slice over to the caller (st->p0_out) and folds its tail into the extra record
         const bool lastb = b + 1 == nblocks;
-        const int judged = lastb ? nb - 1 : nb;
+        const int judged = (lastb ? nb - 1 : nb) + (b == 0 ? 1 : 0);
         if (rc == REVS_OK)
             rc = revs::stream_block_verdict(plan->ctl, seq0, seq0 + (unsigned int)k0,
-                                            seq0 + (unsigned int)k0 + 1u, judged, d.T, plan->tree,
-                                            ring, stride, ring + mt, ntail, lastb, d.vlo, d.vhi, vtol,
+                                            seq0 + (unsigned int)k0 + (b == 0 ? 0u : 1u), judged, d.T, plan->tree,
+                                            b == 0 ? st->p0 : nullptr, ring, stride, (int32_t)mt, ntail,
+                                            lastb ? st->p0_out : nullptr, d.vlo, d.vhi, vtol,
                                             plan->grp_bits, plan->grp_dmax, plan->rec_dev, q);
-        // (the slices are accumulated into again two blocks on -- one block on without the second
-        // stream; the last block's are cleared by the next call)
-        if (rc == REVS_OK && !lastb)
-            rc = hip_ok(hipMemsetAsync(ring, 0, sizeof(double) * (size_t)nb * stride, q), "hipMemsetAsync");
         if (ov && rc == REVS_OK) rc = hip_ok(hipEventRecord(plan->events[2 * b + 1], q), "hipEventRecord");
     }
     entry[nblocks] = cur;
-    // the sums of iteration max_steps (summed over the ranks, not judged yet) are the caller's st->p0
-    if (rc == REVS_OK && launched == max_steps)
-        rc = hip_ok(hipMemcpyAsync(st->p0, ring_of(nblocks - 1) + (int64_t)(max_steps - k0s[nblocks - 1] - 1) * stride,
-                                   sizeof(double) * mt, hipMemcpyDeviceToDevice, q), "hipMemcpyAsync");
     if (ov) {        // the caller's stream is done when the side stream is (also after an error above)
         int r2 = hip_ok(hipEventRecord(plan->events[2 * nblocks], q), "hipEventRecord");
         if (r2 == REVS_OK) r2 = hip_ok(hipStreamWaitEvent(s, plan->events[2 * nblocks], 0), "hipStreamWaitEvent");
@@ -945,6 +950,7 @@ extern "C" int revs_plan_stream_run_blocks(revs_plan_t *plan, int32_t max_steps,
     if (failed_at >= 0 || rc != REVS_OK) {
         if (ov) (void)hipStreamSynchronize(plan->side);
         (void)hipStreamSynchronize(s);
+        plan->ring_dirty = true;
     }
     int kept = rc != REVS_OK ? 0 : (failed_at >= 0 ? failed_at : launched);
     int fin = cur;                                       // the set that holds the state at return
@@ -1067,6 +1073,7 @@ extern "C" int revs_plan_stream_run(revs_plan_t *plan, int32_t max_steps, revs_s
     for (; launched < max_steps; ++launched) {
         const auto a = trace ? std::chrono::steady_clock::now() : tr0;
         if ((rc = launch(launched)) != REVS_OK) goto out;
+        ++plan->timed_launches;
         if (trace)
             slowest = std::max(slowest, std::chrono::duration<double, std::micro>(
                                             std::chrono::steady_clock::now() - a).count());

@@ -70,8 +70,11 @@ struct alignas(16) TreeD2 { double v[2]; };
 // dependent global load costs 2-3 us there), so ALL the static data of a thread -- four 16-bit
 // indices per position packed in one 64-bit word, and the weights -- are requested at the very
 // top, and the only dependent global access is the gather of the node sums behind them.
+// p_clear != NULL (the same array as p, writable): every node sum read is set to zero behind the
+// read -- the block verdicts leave the ring slice they judged ready for the next accumulation.
 __device__ __forceinline__ double tree_rmax(const TreeArgs &tr, const double *p, int T, int t,
-                                            double vlo, double vhi, double *lds, double *v_out) {
+                                            double vlo, double vhi, double *lds, double *v_out,
+                                            double *p_clear = nullptr) {
     const int tid = threadIdx.x, n = tr.n, j0 = 8 * tid;
     const bool act = j0 < n;
     double *base = lds + 2, *red0 = lds + 2 + REVS_TREE_MAX, *red1 = red0 + 4;
@@ -93,6 +96,13 @@ __device__ __forceinline__ double tree_rmax(const TreeArgs &tr, const double *p,
         for (int i = 0; i < 8; ++i) {
             const int s = (int)(pk[i] & 0xFFFFu) - 1;
             a[i] = s >= 0 ? p[(int64_t)s * T + t] : 0.0;
+        }
+        if (p_clear) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int s = (int)(pk[i] & 0xFFFFu) - 1;
+                if (s >= 0) p_clear[(int64_t)s * T + t] = 0.0;
+            }
         }
     }
 #pragma unroll

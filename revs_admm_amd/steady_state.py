@@ -158,7 +158,10 @@ class SteadyStateMixin:
                 arr[i] = None if t is None else _dp(t)
                 if t is not None:
                     by[_dp(t)] = t
-        st.p0, st.p_est_next = _dp(p0), _dp(self.P_est_new)
+        if self._pn0 is None:
+            self._pn0 = self.pnq[0]
+        p0_out = self.p_alt if p0 is self._pn0 else self._pn0      # (the sums handed over for the next call)
+        st.p0, st.p0_out, st.p_est_next = _dp(p0), _dp(p0_out), _dp(self.P_est_new)
         st.diff_hist = None if hist is None else hist.data_ptr()
         count = min(count, self._burst, 1000)
         kept, rm = self._stream_out
@@ -177,6 +180,8 @@ class SteadyStateMixin:
         self._p_clear = None
         self._prod_ahead = False
         self._ar_ahead = self.group is not None
+        if n == count:
+            self._fused_p = p0_out
         for i in range(n):
             self.max_diff[self.iteration + i + 1] = self._dmax_buf[i]
         if n:
