@@ -37,6 +37,13 @@ extern "C" {
 /* the sweep leaves the largest diff of an iteration (the convergence measure, lpsolver.py:284) as
  * REVS_DMAX_SLOTS partial maxima, workgroup b into slot b % REVS_DMAX_SLOTS */
 #define REVS_DMAX_SLOTS 64
+/* the radial feeder as a tree (documented at revs_tree_voltage below) */
+#define REVS_TREE_MAX 2048
+typedef struct {
+    int32_t n;
+    const uint64_t *pack;
+    const double *w;
+} revs_tree_t;
 
 /* ---- per-residence data -------------------------------------------------
  * One record per home; replaces homes[h]["EV"] of the reference
@@ -507,6 +514,40 @@ int revs_op_dual_select_model_step(int32_t m, int32_t T, const double *sel_parti
                                    int32_t max_pivots, double *k_full, double *yhat, int32_t *info,
                                    double scale, double eps, double *y_trial, double *lin_out,
                                    void *stream);
+/* ---- the same evaluation behind the tree form of R p (see "the feeder as a tree" below) ----
+ * On a radial feeder v = R p is three prefix sums over the nodes in DFS preorder: one workgroup per
+ * slot computes its slot's voltages in O(nodes) and judges its rows on the spot -- no 33 MB matrix
+ * stream, no K-split slabs, one block of partial sums per slot (the selection then runs with
+ * sel_nblk = 1).  Same outputs as revs_op_dual_rows / revs_op_dual_select (rows of nodes without
+ * residences have no position in the tree: their v, violation and multiplier stay zero).
+ * revs_op_dual_rows_tree: pnq = the node sums p | N | q of the home pass; zero_out: an array (not
+ * pnq) cleared on the way, or NULL; with_select != 0: the candidate selection of every slot in the
+ * same launch (else the caller runs it: revs_agent_step_select with sel_nblk = 1).
+ * revs_op_dual_evaluate_tree: revs_op_dual_evaluate with phase bit 1 done this way (phase bit 0 --
+ * the product R^T y for the home pass's shifts, when use_y -- is unchanged).
+ * revs_op_dual_tree_select_model_step: rows, selection, small model and step of every slot in ONE
+ * launch (revs_op_dual_select_model_step with the rows in front; n_free = pnq + m T). */
+int revs_op_dual_rows_tree(int32_t m, int32_t T, const revs_tree_t *tree_host, const double *pnq,
+                           const double *y, double vlo, double vhi, int32_t kadd, double *vfull,
+                           double *viol, double *partial, double *zero_out, int64_t *cand_idx,
+                           int32_t *cand_cnt, double *cand_val, double *stats, double seq,
+                           int32_t with_select, void *stream);
+int revs_op_dual_evaluate_tree(int32_t phase, int32_t m, int32_t T, const int64_t *node_ptr,
+                               const float *p_est, const float *p_sch, const float *gamma,
+                               const double *R, const revs_tree_t *tree_host, const double *y,
+                               int32_t use_y, double kappa, double vlo, double vhi, int32_t kadd,
+                               int32_t ksplit, double *d_slabs, double *pnq, float *p_est_new,
+                               double *vfull, double *viol, double *partial, int64_t *cand_idx,
+                               int32_t *cand_cnt, double *cand_val, double *stats, double seq,
+                               void *stream);
+int revs_op_dual_tree_select_model_step(int32_t m, int32_t T, const revs_tree_t *tree_host,
+                                        const double *pnq, const double *y, double vlo, double vhi,
+                                        int32_t kadd, double *vfull, double *viol, double *partial,
+                                        int64_t *cand_idx, int32_t *cand_cnt, double *cand_val,
+                                        double *stats, double seq, const double *R, double kappa,
+                                        double delta, int32_t max_pivots, double *k_full, double *yhat,
+                                        int32_t *info, double scale, double eps, double *y_trial,
+                                        double *lin_out, void *stream);
 /* Host only (no GPU work): the acceptance test of such a chained iteration on the two stats
  * blocks (double[T][8], as revs_op_dual_select writes them; s1[8 t + 4] = the step kernel's
  * linear term) -- returns 1 iff the driver's own checks (operator_newton.py:
@@ -692,12 +733,6 @@ int revs_plan_chain_run(revs_plan_t *plan, int32_t max_steps, revs_chain_state_t
  *   w[j]    2 r of the edge from j to its parent (double)
  * revs_tree_voltage: one workgroup per slot; v_out double[m][T] (rows with src; may be NULL),
  * rmax_out double[T] = largest violation max(v - vhi, vlo - v, 0) over the checked rows. */
-#define REVS_TREE_MAX 2048
-typedef struct {
-    int32_t n;
-    const uint64_t *pack;
-    const double *w;
-} revs_tree_t;
 int revs_tree_voltage(int32_t m, int32_t T, const revs_tree_t *tree_host, const double *p,
                       double vlo, double vhi, double *v_out, double *rmax_out, void *stream);
 

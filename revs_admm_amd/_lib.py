@@ -174,6 +174,14 @@ SIGNATURES = {
     "revs_op_dual_select_model_step": (C.c_int, [_i32, _i32, _p, _i32, _p, _f64, _f64, _i32, _p, _p, _p,
                                                 _p, _p, _p, _f64, _p, _p, _f64, _f64, _i32, _p, _p, _p,
                                                 _f64, _f64, _p, _p, _p]),
+    "revs_op_dual_rows_tree": (C.c_int, [_i32, _i32, C.POINTER(Tree), _p, _p, _f64, _f64, _i32, _p, _p, _p, _p,
+                                         _p, _p, _p, _p, _f64, _i32, _p]),
+    "revs_op_dual_evaluate_tree": (C.c_int, [_i32, _i32, _i32, _p, _p, _p, _p, _p, C.POINTER(Tree), _p, _i32,
+                                             _f64, _f64, _f64, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p,
+                                             _p, _f64, _p]),
+    "revs_op_dual_tree_select_model_step": (C.c_int, [_i32, _i32, C.POINTER(Tree), _p, _p, _f64, _f64, _i32, _p,
+                                                      _p, _p, _p, _p, _p, _p, _f64, _p, _f64, _f64, _i32, _p, _p,
+                                                      _p, _f64, _f64, _p, _p, _p]),
     "revs_newton_chain_accept": (C.c_int, [_i32, _p, _p, _f64, _f64, _i32, _i32, _i32, _p, _p]),
     "revs_tree_voltage": (C.c_int, [_i32, _i32, C.POINTER(Tree), _p, _f64, _f64, _p, _p, _p]),
     "revs_comm_unique_id": (C.c_int, [_p]),

@@ -20,6 +20,7 @@
 // iterations of the same cost.
 #include "common.h"
 #include "select_body.h"
+#include "tree_body.h"
 
 namespace revs {
 
@@ -147,6 +148,88 @@ __global__ __launch_bounds__(256) void op_dual_rows_kernel(
         }
         double *o = partial + ((int64_t)blockIdx.x * T + t) * 4;
         o[0] = a; o[1] = b; o[2] = c; o[3] = d;
+    }
+}
+
+// The same bookkeeping behind the tree form of R p (tree_body.h): one workgroup per slot computes
+// v = R p of its slot in O(nodes) -- the node sums of a slot are 16 KB where the dense product
+// streams the 33 MB of R -- and judges its rows on the spot; partial has ONE block per slot
+// (nblk = 1 for the selection).  Rows of nodes without residences carry no position in the tree:
+// their v, violation and multiplier are zero and stay so (the arrays start from zero).
+struct TreeRowsArgs {
+    TreeArgs tree;
+    int m, T;
+    const double *p;          // node sums p[m][T]
+    const double *qn;         // -(kappa/2) sum g^2 per node and slot (pnq + 2 m T)
+    const double *y;
+    double vlo, vhi;
+    double *vfull, *viol, *partial, *zero_out;
+};
+__device__ __forceinline__ void tree_rows_body(const TreeRowsArgs &a, const int t, double *lds) {
+    const int tid = threadIdx.x, j0 = 8 * tid, T = a.T;
+    const bool act = j0 < a.tree.n;
+    // the multipliers and dual terms of this thread's rows: requested before the scans
+    double yv[8], qv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { yv[i] = 0.0; qv[i] = 0.0; }
+    if (act) {
+        unsigned long long pk0[8];
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            const TreeU2 u = *reinterpret_cast<const TreeU2 *>(a.tree.pack + j0 + i);
+            pk0[i] = u.v[0]; pk0[i + 1] = u.v[1];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int s = (int)(pk0[i] & 0xFFFFu) - 1;
+            yv[i] = s >= 0 ? a.y[(int64_t)s * T + t] : 0.0;
+            qv[i] = s >= 0 ? a.qn[(int64_t)s * T + t] : 0.0;
+        }
+    }
+    if (a.zero_out)
+        for (int r = tid; r < a.m; r += 256) a.zero_out[(int64_t)r * T + t] = 0.0;
+    unsigned long long pk[8];
+    double v8[8];
+    tree_voltage(a.tree, a.p, T, t, lds, v8, pk, nullptr);
+    double rmax = 0.0, dsum = 0.0, nsup = 0.0, nvio = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int s = (int)(pk[i] & 0xFFFFu) - 1;
+        if (s >= 0) {
+            const int64_t o = (int64_t)s * T + t;
+            const double v = v8[i], y1 = yv[i];
+            const bool up = y1 > 0.0 || (y1 == 0.0 && v > a.vhi);
+            const double b = up ? a.vhi : a.vlo;
+            const double vi = fmax(fmax(v - a.vhi, a.vlo - v), 0.0);
+            rmax = fmax(rmax, y1 != 0.0 ? fabs(v - b) : vi);
+            dsum += qv[i] - fmax(a.vhi * y1, a.vlo * y1);
+            nsup += y1 != 0.0 ? 1.0 : 0.0;
+            nvio += (y1 == 0.0 && vi > 0.0) ? 1.0 : 0.0;
+            a.vfull[o] = v;
+            a.viol[o] = y1 != 0.0 ? 0.0 : vi;
+        }
+    }
+    rmax = wave_max_d(rmax); dsum = wave_sum_d(dsum); nsup = wave_sum_d(nsup); nvio = wave_sum_d(nvio);
+    __shared__ double rr[4][4];
+    if ((tid & 63) == 0) { rr[0][tid >> 6] = rmax; rr[1][tid >> 6] = dsum; rr[2][tid >> 6] = nsup; rr[3][tid >> 6] = nvio; }
+    __syncthreads();
+    if (tid == 0) {
+        double *o = a.partial + (int64_t)t * 4;
+        o[0] = fmax(fmax(rr[0][0], rr[0][1]), fmax(rr[0][2], rr[0][3]));
+        o[1] = ((rr[1][0] + rr[1][1]) + rr[1][2]) + rr[1][3];
+        o[2] = ((rr[2][0] + rr[2][1]) + rr[2][2]) + rr[2][3];
+        o[3] = ((rr[3][0] + rr[3][1]) + rr[3][2]) + rr[3][3];
+    }
+}
+
+// rows by the tree form, then (SELECT) the candidate selection of the same slot in the same workgroup
+template <bool SELECT>
+__global__ __launch_bounds__(256) void op_tree_rows_kernel(const TreeRowsArgs ta, const SelectArgs sa) {
+    extern __shared__ double tree_lds[];
+    tree_rows_body(ta, blockIdx.x, tree_lds);
+    if constexpr (SELECT) {
+        __syncthreads();                    // this workgroup's v, violations and sums, in global memory
+        dual_select_body<true>(sa, blockIdx.x);
     }
 }
 
@@ -667,6 +750,23 @@ __global__ __launch_bounds__(256) void op_dual_select_model_step_kernel(const Se
                         rmax / fa.scale > fa.eps ? 1.0 : 0.0, fa.ytrial, fa.lin_out, fa.ycopy, sa.m);
 }
 
+// ... and with the slot's rows by the tree form in front (the whole operator side of a chained
+// Newton iteration between two home passes is then ONE launch of T workgroups)
+__global__ __launch_bounds__(256) void op_tree_select_model_step_kernel(const TreeRowsArgs ta, const SelectArgs sa,
+                                                                        const FusedArgs fa) {
+    extern __shared__ double tree_lds[];
+    const int t = blockIdx.x;
+    tree_rows_body(ta, t, tree_lds);
+    __syncthreads();
+    const double rmax = dual_select_body<true>(sa, t);
+    __syncthreads();
+    small_model_body(t, sa.m, sa.T, fa.R, fa.Nn, sa.cidx, sa.ccnt, sa.cval, fa.inv_kappa, fa.delta,
+                     fa.max_pivots, fa.Kall, fa.yhat, fa.info);
+    __syncthreads();
+    dual_step_body<256>(t, sa.T, sa.cidx, sa.ccnt, sa.cval, fa.yhat,
+                        rmax / fa.scale > fa.eps ? 1.0 : 0.0, fa.ytrial, fa.lin_out, fa.ycopy, sa.m);
+}
+
 }  // namespace revs
 
 using namespace revs;
@@ -844,13 +944,58 @@ extern "C" int revs_op_dual_step_pending(int32_t T, const int64_t *cand_idx, con
     return REVS_OK;
 }
 
+static bool tree_ok(const revs_tree_t *tree) {
+    return tree && tree->n > 0 && tree->n <= REVS_TREE_MAX && tree->n % 8 == 0 && tree->pack && tree->w;
+}
+
+extern "C" int revs_op_dual_rows_tree(int32_t m, int32_t T, const revs_tree_t *tree, const double *pnq,
+                                      const double *y, double vlo, double vhi, int32_t kadd, double *vfull,
+                                      double *viol, double *partial, double *zero_out, int64_t *cand_idx,
+                                      int32_t *cand_cnt, double *cand_val, double *stats, double seq,
+                                      int32_t with_select, void *stream) {
+    REVS_REQUIRE(m > 0 && m <= 16384 && T > 0 && T <= 256 && tree_ok(tree) && pnq && y && vfull && viol &&
+                 partial && vlo <= vhi && kadd >= 0 && zero_out != pnq &&
+                 (!with_select || (cand_idx && cand_cnt && cand_val && stats)),
+                 "revs_op_dual_rows_tree: bad argument (tree nodes <= %d)", REVS_TREE_MAX);
+    const TreeArgs tr{tree->n, (const unsigned long long *)tree->pack, tree->w};
+    const TreeRowsArgs ta{tr, m, T, pnq, pnq + 2 * (int64_t)m * T, y, vlo, vhi, vfull, viol, partial, zero_out};
+    const SelectArgs sa{m, T, 1, kadd, partial, y, vfull, viol, vlo, vhi, seq, cand_idx, cand_cnt, cand_val, stats};
+    if (with_select)
+        hipLaunchKernelGGL((op_tree_rows_kernel<true>), dim3(T), dim3(256), tree_lds_bytes(tree->n), S_(stream), ta, sa);
+    else
+        hipLaunchKernelGGL((op_tree_rows_kernel<false>), dim3(T), dim3(256), tree_lds_bytes(tree->n), S_(stream), ta, sa);
+    REVS_CHECK_LAUNCH("revs_op_dual_rows_tree");
+    return REVS_OK;
+}
+
+extern "C" int revs_op_dual_tree_select_model_step(
+        int32_t m, int32_t T, const revs_tree_t *tree, const double *pnq, const double *y, double vlo,
+        double vhi, int32_t kadd, double *vfull, double *viol, double *partial, int64_t *cand_idx,
+        int32_t *cand_cnt, double *cand_val, double *stats, double seq, const double *R, double kappa,
+        double delta, int32_t max_pivots, double *k_full, double *yhat, int32_t *info, double scale,
+        double eps, double *y_trial, double *lin_out, void *stream) {
+    REVS_REQUIRE(m > 0 && m <= 16384 && T > 0 && T <= 256 && tree_ok(tree) && pnq && y && vfull && viol &&
+                 partial && cand_idx && cand_cnt && cand_val && stats && vlo <= vhi && kadd >= 0 && R && k_full &&
+                 yhat && info && kappa > 0 && delta >= 0 && max_pivots > 0 && scale > 0.0 && y_trial &&
+                 y_trial != y && lin_out, "revs_op_dual_tree_select_model_step: bad argument");
+    const TreeArgs tr{tree->n, (const unsigned long long *)tree->pack, tree->w};
+    const TreeRowsArgs ta{tr, m, T, pnq, pnq + 2 * (int64_t)m * T, y, vlo, vhi, vfull, viol, partial, nullptr};
+    const SelectArgs sa{m, T, 1, kadd, partial, y, vfull, viol, vlo, vhi, seq, cand_idx, cand_cnt, cand_val, stats};
+    const FusedArgs fa{R, pnq + (int64_t)m * T, y, 1.0 / kappa, delta, scale, eps, max_pivots, k_full, yhat,
+                       y_trial, lin_out, info};
+    hipLaunchKernelGGL(op_tree_select_model_step_kernel, dim3(T), dim3(256), tree_lds_bytes(tree->n), S_(stream),
+                       ta, sa, fa);
+    REVS_CHECK_LAUNCH("revs_op_dual_tree_select_model_step");
+    return REVS_OK;
+}
+
 // One evaluation of the dual function as a single host call (the driver's steady state is
 // host-bound otherwise: five launches of 3-12 us each).  phase bit 0: R^T y (when use_y)
 // and the home pass; phase bit 1: R p, row bookkeeping (one launch with tile_counters and
 // T <= 32, see revs_op_dual_product_rows) and candidate lists; with phase bit 2 the candidate-list kernel is left to the
 // caller (revs_agent_step_select runs it inside the home sweep's launch).  A driver that shards residences runs phase 1, all-reduces
 // pnq, then runs phase 2.
-extern "C" int revs_op_dual_evaluate(int32_t phase, int32_t m, int32_t T, const int64_t *node_ptr,
+static int dual_evaluate_impl(int32_t phase, int32_t m, int32_t T, const int64_t *node_ptr,
                                      const float *p_est, const float *p_sch, const float *gamma,
                                      const double *R, const double *Rt, const double *y,
                                      int32_t use_y, double kappa, double vlo, double vhi,
@@ -859,7 +1004,7 @@ extern "C" int revs_op_dual_evaluate(int32_t phase, int32_t m, int32_t T, const 
                                      double *vfull, double *viol, double *partial,
                                      int64_t *cand_idx, int32_t *cand_cnt, double *cand_val,
                                      double *stats, double seq, uint32_t *tile_counters,
-                                     void *stream) {
+                                     const revs_tree_t *tree, void *stream) {
     REVS_REQUIRE(phase >= 1 && phase <= 7 && (!(phase & 4) || (phase & 2)) && y && pnq,
                  "revs_op_dual_evaluate: bad argument");
     int rc;
@@ -872,6 +1017,10 @@ extern "C" int revs_op_dual_evaluate(int32_t phase, int32_t m, int32_t T, const 
         rc = revs_op_dual_eval(m, T, node_ptr, p_est, p_sch, gamma, ksplit,
                                use_y ? d_slabs : nullptr, kappa, pnq, p_est_new, stream);
         if (rc != REVS_OK) return rc;
+    }
+    if ((phase & 2) && tree) {      // R p of a radial feeder in O(nodes), rows (and selection) per slot
+        return revs_op_dual_rows_tree(m, T, tree, pnq, y, vlo, vhi, kadd, vfull, viol, partial, nullptr,
+                                      cand_idx, cand_cnt, cand_val, stats, seq, !(phase & 4), stream);
     }
     if (phase & 2) {
         REVS_REQUIRE(Rt && v_slabs, "revs_op_dual_evaluate: Rt / v_slabs missing");
@@ -898,4 +1047,34 @@ extern "C" int revs_op_dual_evaluate(int32_t phase, int32_t m, int32_t T, const 
         }
     }
     return REVS_OK;
+}
+
+extern "C" int revs_op_dual_evaluate(int32_t phase, int32_t m, int32_t T, const int64_t *node_ptr,
+                                     const float *p_est, const float *p_sch, const float *gamma,
+                                     const double *R, const double *Rt, const double *y,
+                                     int32_t use_y, double kappa, double vlo, double vhi,
+                                     int32_t kadd, int32_t ksplit, double *d_slabs,
+                                     double *v_slabs, double *pnq, float *p_est_new,
+                                     double *vfull, double *viol, double *partial,
+                                     int64_t *cand_idx, int32_t *cand_cnt, double *cand_val,
+                                     double *stats, double seq, uint32_t *tile_counters,
+                                     void *stream) {
+    return dual_evaluate_impl(phase, m, T, node_ptr, p_est, p_sch, gamma, R, Rt, y, use_y, kappa, vlo, vhi, kadd,
+                              ksplit, d_slabs, v_slabs, pnq, p_est_new, vfull, viol, partial, cand_idx, cand_cnt,
+                              cand_val, stats, seq, tile_counters, nullptr, stream);
+}
+
+extern "C" int revs_op_dual_evaluate_tree(int32_t phase, int32_t m, int32_t T, const int64_t *node_ptr,
+                                          const float *p_est, const float *p_sch, const float *gamma,
+                                          const double *R, const revs_tree_t *tree, const double *y,
+                                          int32_t use_y, double kappa, double vlo, double vhi,
+                                          int32_t kadd, int32_t ksplit, double *d_slabs, double *pnq,
+                                          float *p_est_new, double *vfull, double *viol, double *partial,
+                                          int64_t *cand_idx, int32_t *cand_cnt, double *cand_val,
+                                          double *stats, double seq, void *stream) {
+    REVS_REQUIRE(tree_ok(tree), "revs_op_dual_evaluate_tree: bad tree (at most %d nodes, a multiple of 8)",
+                 REVS_TREE_MAX);
+    return dual_evaluate_impl(phase, m, T, node_ptr, p_est, p_sch, gamma, R, nullptr, y, use_y, kappa, vlo, vhi,
+                              kadd, ksplit, d_slabs, nullptr, pnq, p_est_new, vfull, viol, partial, cand_idx,
+                              cand_cnt, cand_val, stats, seq, nullptr, tree, stream);
 }

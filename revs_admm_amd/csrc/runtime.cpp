@@ -322,24 +322,41 @@ extern "C" int revs_plan_chain_step(revs_plan_t *plan, const double *y, double *
                                      d.pnq, p_est_new, d.vfull, d.viol, d.partial, ci[k], cc[k], cv[k],
                                      st[k], 0.0, plan->counters, stream);
     };
+    // With the feeder as a tree the operator side between the home passes is the tree form of R p:
+    // rows, selection, small model and step of every slot in ONE launch of T workgroups, the trial's
+    // rows in another (its selection rides in the sweep's launch) -- no matrix stream at all.
+    const bool tf = plan->tree.n > 0;
+    const revs_tree_t trh{plan->tree.n, (const uint64_t *)plan->tree.pack, plan->tree.w};
     int rc;
     if ((rc = home_pass(y, use_y, sup0)) != REVS_OK) return rc;
-    if ((rc = rows(y, use_y, 0)) != REVS_OK) return rc;
-    rc = revs_op_dual_select_model_step(d.m, d.T, d.partial, sel_nblk, y, d.vlo, d.vhi, d.kadd, d.vfull,
-                                        d.viol, ci[0], cc[0], cv[0], st[0], 0.0, d.R,
-                                        d.pnq + (int64_t)d.m * d.T, d.kappa, d.delta, d.max_pivots,
-                                        d.k_full, d.yhat, d.info, scale, d.eps, y_trial, st[1] + 4,
-                                        stream);
+    if (tf) {
+        rc = revs_op_dual_tree_select_model_step(d.m, d.T, &trh, d.pnq, y, d.vlo, d.vhi, d.kadd, d.vfull, d.viol,
+                                                 d.partial, ci[0], cc[0], cv[0], st[0], 0.0, d.R, d.kappa, d.delta,
+                                                 d.max_pivots, d.k_full, d.yhat, d.info, scale, d.eps, y_trial,
+                                                 st[1] + 4, stream);
+    } else {
+        if ((rc = rows(y, use_y, 0)) != REVS_OK) return rc;
+        rc = revs_op_dual_select_model_step(d.m, d.T, d.partial, sel_nblk, y, d.vlo, d.vhi, d.kadd, d.vfull,
+                                            d.viol, ci[0], cc[0], cv[0], st[0], 0.0, d.R,
+                                            d.pnq + (int64_t)d.m * d.T, d.kappa, d.delta, d.max_pivots,
+                                            d.k_full, d.yhat, d.info, scale, d.eps, y_trial, st[1] + 4,
+                                            stream);
+    }
     if (rc != REVS_OK) return rc;
     if ((rc = home_pass(y_trial, 1, chain_few ? 0 : -1)) != REVS_OK) return rc;
-    if ((rc = rows(y_trial, 1, 1)) != REVS_OK) return rc;
+    if (tf)
+        rc = revs_op_dual_rows_tree(d.m, d.T, &trh, d.pnq, y_trial, d.vlo, d.vhi, d.kadd, d.vfull, d.viol, d.partial,
+                                    nullptr, ci[1], cc[1], cv[1], st[1], 0.0, 0, stream);
+    else
+        rc = rows(y_trial, 1, 1);
+    if (rc != REVS_OK) return rc;
     if (ev_mid) (void)hipEventRecord((hipEvent_t)ev_mid, s);
     const double seq = -(plan->seq += 1.0);          // (negative: not a spec-step tag)
     rc = revs_agent_step_select(d.n_homes, d.T, d.cost, d.homes, d.load, p_est, p_est_new, p_sch,
                                 gamma, p_sch_out, gamma_out, s_out, c_out, d.diff, d.dsq, d.status,
                                 d.pdhg_dual, (float)d.kappa, d.mode, &d.pdhg, d.m, d.partial, y_trial,
                                 d.vlo, d.vhi, d.kadd, d.vfull, d.viol, ci[1], cc[1], cv[1], st[1], seq,
-                                nullptr, nullptr, nullptr, sel_nblk, stream);
+                                nullptr, nullptr, nullptr, tf ? 1 : sel_nblk, stream);
     if (rc != REVS_OK) return rc;
     if (ev_end) (void)hipEventRecord((hipEvent_t)ev_end, s);
     const volatile double *tg = d.stats1_host;

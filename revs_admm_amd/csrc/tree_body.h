@@ -61,26 +61,19 @@ struct TreeArgs {
 struct alignas(16) TreeU2 { unsigned long long v[2]; };
 struct alignas(16) TreeD2 { double v[2]; };
 
-// Largest violation max(v - vhi, vlo - v, 0) over the checked rows of slot t (every thread
-// gets it); v_out[src][t] = v when v_out != NULL.  `lds`: tree_lds_bytes() bytes, 16-byte aligned.
-// Two things shape this body.  Registers: it runs inside the residence sweep's kernel, whose
-// occupancy (8 wavefronts per SIMD, 64 VGPRs) it must not lower -- two 8-double vectors per
-// thread (thread tid owns positions 8 tid .. 8 tid + 7) beside the static data.  Latency: its 24
-// or 96 workgroups are the launch's critical path when memory is saturated by the sweep (every
-// dependent global load costs 2-3 us there), so ALL the static data of a thread -- four 16-bit
-// indices per position packed in one 64-bit word, and the weights -- are requested at the very
-// top, and the only dependent global access is the gather of the node sums behind them.
+// The voltages themselves: v[i] = (R p)[src] at this thread's positions 8 tid + i (0 where the
+// position carries no checked row), pk[i] = the positions' packed indices (row = (pk & 0xFFFF) - 1).
 // p_clear != NULL (the same array as p, writable): every node sum read is set to zero behind the
 // read -- the block verdicts leave the ring slice they judged ready for the next accumulation.
-__device__ __forceinline__ double tree_rmax(const TreeArgs &tr, const double *p, int T, int t,
-                                            double vlo, double vhi, double *lds, double *v_out,
-                                            double *p_clear = nullptr) {
+// Ends with the workgroup past a barrier; lds[2 ..] may be reused by the caller after its own barrier.
+__device__ __forceinline__ void tree_voltage(const TreeArgs &tr, const double *p, int T, int t,
+                                             double *lds, double (&a)[8], unsigned long long (&pk)[8],
+                                             double *p_clear) {
     const int tid = threadIdx.x, n = tr.n, j0 = 8 * tid;
     const bool act = j0 < n;
     double *base = lds + 2, *red0 = lds + 2 + REVS_TREE_MAX, *red1 = red0 + 4;
     if (tid == 0) lds[1] = 0.0;                                 // base[-1]
-    unsigned long long pk[8];
-    double a[8], b[8];
+    double b[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { pk[i] = 0ull; a[i] = 0.0; b[i] = 0.0; }
     if (act) {
@@ -142,16 +135,38 @@ __device__ __forceinline__ double tree_rmax(const TreeArgs &tr, const double *p,
     }
     __syncthreads();
     // v_j = Pre[j] - F_excl[cle[j]] on the checked rows,  F_excl[c] = base[c - 1]
-    double rmax = 0.0;
-    if (act) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int s = (int)(pk[i] & 0xFFFFu) - 1;
-            if (s >= 0) {
-                const double v = (a[i] + pex) - base[(int)(pk[i] >> 48) - 1];
-                rmax = fmax(rmax, fmax(fmax(v - vhi, vlo - v), 0.0));
-                if (v_out) v_out[(int64_t)s * T + t] = v;
-            }
+    for (int i = 0; i < 8; ++i) {
+        const int s = (int)(pk[i] & 0xFFFFu) - 1;
+        a[i] = (act && s >= 0) ? (a[i] + pex) - base[(int)(pk[i] >> 48) - 1] : 0.0;
+    }
+}
+
+// Largest violation max(v - vhi, vlo - v, 0) over the checked rows of slot t (every thread
+// gets it); v_out[src][t] = v when v_out != NULL.  `lds`: tree_lds_bytes() bytes, 16-byte aligned.
+// Two things shape this body.  Registers: it runs inside the residence sweep's kernel, whose
+// occupancy (8 wavefronts per SIMD, 64 VGPRs) it must not lower -- two 8-double vectors per
+// thread (thread tid owns positions 8 tid .. 8 tid + 7) beside the static data.  Latency: its 24
+// or 96 workgroups are the launch's critical path when memory is saturated by the sweep (every
+// dependent global load costs 2-3 us there), so ALL the static data of a thread -- four 16-bit
+// indices per position packed in one 64-bit word, and the weights -- are requested at the very
+// top, and the only dependent global access is the gather of the node sums behind them.
+__device__ __forceinline__ double tree_rmax(const TreeArgs &tr, const double *p, int T, int t,
+                                            double vlo, double vhi, double *lds, double *v_out,
+                                            double *p_clear = nullptr) {
+    const int tid = threadIdx.x;
+    double *red1 = lds + 2 + REVS_TREE_MAX + 4;
+    unsigned long long pk[8];
+    double a[8];
+    tree_voltage(tr, p, T, t, lds, a, pk, p_clear);
+    double rmax = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int s = (int)(pk[i] & 0xFFFFu) - 1;
+        if (s >= 0) {
+            const double v = a[i];
+            rmax = fmax(rmax, fmax(fmax(v - vhi, vlo - v), 0.0));
+            if (v_out) v_out[(int64_t)s * T + t] = v;
         }
     }
 #pragma unroll

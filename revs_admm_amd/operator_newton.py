@@ -25,6 +25,16 @@ class DualNewtonMixin:
         if (phase & 2) and not (phase & 4):
             self._eval_seq += 1.0
             tag = self._pending_tag[k] = self._eval_seq + 0.5
+        if self._tree is not None and self._plan is not None:
+            # the feeder as a tree: R p and the rows of every slot in O(nodes), one workgroup per slot
+            check(lib.revs_op_dual_evaluate_tree(
+                phase, M, T, ptr(self.node_ptr), ptr(self.P_est), ptr(self.P_sch), ptr(self.G),
+                ptr(self.R64), C.byref(self._tree), ptr(y), int(use_y), self.kappa, self.vlo, self.vhi,
+                self.op.newton_kadd, self.ksplit1, ptr(self.d_sl), ptr(self.pnq), ptr(self.P_est_new),
+                ptr(self.vfull), ptr(self.violw), ptr(self.d_part), ptr(self.c_idx[k]),
+                ptr(self.c_cnt[k]), ptr(self.c_val[k]), self.stats_dev[k], tag, self.stream),
+                "revs_op_dual_evaluate_tree")
+            return
         check(lib.revs_op_dual_evaluate(
             phase, M, T, ptr(self.node_ptr), ptr(self.P_est), ptr(self.P_sch), ptr(self.G),
             ptr(self.R64), ptr(self.R64T), ptr(y), int(use_y), self.kappa, self.vlo, self.vhi,
@@ -230,6 +240,9 @@ class DualNewtonMixin:
         # sequence tag the last selection writes)
         nb = (M + 31) // 32
         nb = nb if (T <= 32 and nb <= 256) else 0
+        tf = self._tree is not None and self._plan is not None     # rows by the tree form of R p
+        if tf:
+            nb = 1
         use_y = self._y_support
         if use_y and self._sup is not None:       # as _dual_launch, the selection left out
             self._dual_home_pass_rows(ycur, self._sup)
@@ -237,14 +250,22 @@ class DualNewtonMixin:
             self._dual_phase(1, ycur, use_y, 0)
         if self.group is not None:
             self._allreduce(self.pnq)
-        self._dual_phase(2 | 4, ycur, use_y, 0)
-        # selection, small model and step of every slot in one launch
-        check(lib.revs_op_dual_select_model_step(
-            M, T, ptr(self.d_part), nb, ptr(ycur), self.vlo, self.vhi, o.newton_kadd,
-            ptr(self.vfull), ptr(self.violw), ptr(self.c_idx[0]), ptr(self.c_cnt[0]),
-            ptr(self.c_val[0]), self.stats_dev[0], 0.0, ptr(self.R64), ptr(self.pnq[1]), self.kappa,
-            o.newton_delta, o.newton_pivots, ptr(self.k_full), ptr(self.yhat), self.info_dev, scale,
-            o.eps, ptr(ytrial), self.stats_dev[1] + 32, st), "revs_op_dual_select_model_step")
+        if tf:       # rows, selection, small model and step of every slot in ONE launch
+            check(lib.revs_op_dual_tree_select_model_step(
+                M, T, C.byref(self._tree), ptr(self.pnq), ptr(ycur), self.vlo, self.vhi, o.newton_kadd,
+                ptr(self.vfull), ptr(self.violw), ptr(self.d_part), ptr(self.c_idx[0]), ptr(self.c_cnt[0]),
+                ptr(self.c_val[0]), self.stats_dev[0], 0.0, ptr(self.R64), self.kappa, o.newton_delta,
+                o.newton_pivots, ptr(self.k_full), ptr(self.yhat), self.info_dev, scale, o.eps, ptr(ytrial),
+                self.stats_dev[1] + 32, st), "revs_op_dual_tree_select_model_step")
+        else:
+            self._dual_phase(2 | 4, ycur, use_y, 0)
+            # selection, small model and step of every slot in one launch
+            check(lib.revs_op_dual_select_model_step(
+                M, T, ptr(self.d_part), nb, ptr(ycur), self.vlo, self.vhi, o.newton_kadd,
+                ptr(self.vfull), ptr(self.violw), ptr(self.c_idx[0]), ptr(self.c_cnt[0]),
+                ptr(self.c_val[0]), self.stats_dev[0], 0.0, ptr(self.R64), ptr(self.pnq[1]), self.kappa,
+                o.newton_delta, o.newton_pivots, ptr(self.k_full), ptr(self.yhat), self.info_dev, scale,
+                o.eps, ptr(ytrial), self.stats_dev[1] + 32, st), "revs_op_dual_select_model_step")
         if self._chain_few:                       # d = R^T y / kappa from the rows of set 0
             self._dual_home_pass_rows(ytrial, 0)
         else:
