@@ -38,7 +38,10 @@ extern "C" {
  * REVS_DMAX_SLOTS partial maxima, workgroup b into slot b % REVS_DMAX_SLOTS */
 #define REVS_DMAX_SLOTS 64
 /* the radial feeder as a tree (documented at revs_tree_voltage below) */
-#define REVS_TREE_MAX 2048
+#define REVS_TREE_MAX 16384
+/* ... of which a launch that judges its own rows (revs_plan_stream_run with block <= 1) and the
+ * Newton evaluations' tree form hold this many (one workgroup of 256 threads, 8 positions each) */
+#define REVS_TREE_SWEEP_MAX 2048
 typedef struct {
     int32_t n;
     const uint64_t *pack;

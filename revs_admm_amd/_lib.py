@@ -87,7 +87,8 @@ class StreamSets(C.Structure):
 # revs_host_allreduce_fn
 HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64, C.c_int32)
 
-TREE_MAX = 2048          # REVS_TREE_MAX
+TREE_MAX = 16384         # REVS_TREE_MAX
+TREE_SWEEP_MAX = 2048    # REVS_TREE_SWEEP_MAX
 STREAM_BLOCK_MAX = 256   # REVS_STREAM_BLOCK_MAX
 AGENT_MAX_INNER = 8      # REVS_AGENT_MAX_INNER
 

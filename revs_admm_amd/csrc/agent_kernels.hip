@@ -951,7 +951,7 @@ static int agent_step_impl(int64_t n_homes, int32_t T, const float *cost,
         a.dmax_out = sx->dmax_out;
         if (sx->y_out) a.y_out = sx->y_out;
     } else if (sx) {
-        REVS_REQUIRE(sx->ctl && sx->rec && sx->p_in && sx->tree.n > 0 && sx->tree.n <= REVS_TREE_MAX && sx->tree.n % 8 == 0 &&
+        REVS_REQUIRE(sx->ctl && sx->rec && sx->p_in && sx->tree.n > 0 && sx->tree.n <= REVS_TREE_SWEEP_MAX && sx->tree.n % 8 == 0 &&
                      sx->tree.pack && sx->tree.w &&
                      sx->m > 0 && sx->vlo <= sx->vhi && sx->vtol >= 0.0 && !sel,
                      "revs_agent_step: bad streaming argument");
@@ -996,6 +996,19 @@ int agent_step_stream(int64_t n_homes, int32_t T, const float *cost, const revs_
 // did run worked from an estimate that is not the operator's answer: the state a block starts
 // from is never overwritten while its verdicts are pending (the sweeps of a block rotate through
 // the other sets of buffers, runtime.cpp), and the host goes back to it.
+// more than 64 KB of dynamic LDS (the big tree shapes) has to be granted per kernel, once
+template <int NT, int IPT, typename K>
+static bool tree_big_lds(K kernel, size_t lds) {
+    if (lds <= 64 * 1024) return true;
+    static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+        revs::set_error("tree form: %zu bytes of LDS refused: %s", lds, hipGetErrorString(e));
+        return false;
+    }
+    return true;
+}
+
 struct BlockVerdict {
     StreamCtl *ctl;
     unsigned int base_seq, gate_seq;      // no-op when a launch numbered base_seq..gate_seq failed
@@ -1022,7 +1035,8 @@ constexpr int kHandOverGroups = 8;        // workgroups that copy the call's las
 // call's last slice (its rows are the next call's to judge) to the caller's array, clear it, and
 // fold its tail.  The last workgroup to finish writes the records {rmax, failed, seq, max diff
 // of the iteration before} and the lowest failed number into the control word.
-__global__ __launch_bounds__(256) void stream_block_verdict_kernel(const BlockVerdict b) {
+template <int NT, int IPT>
+__global__ __launch_bounds__(NT) void stream_block_verdict_kernel(const BlockVerdict b) {
     extern __shared__ double tree_lds[];
     {
         const unsigned int bad = b.ctl->bad_seq;
@@ -1034,25 +1048,28 @@ __global__ __launch_bounds__(256) void stream_block_verdict_kernel(const BlockVe
     const int g = extra ? b.nb : (int)blockIdx.x / b.T, t = extra ? (int)blockIdx.x - njudge : (int)blockIdx.x - g * b.T;
     double *slice = b.ring + (long long)(g - npre) * b.stride;       // (g == 0 with pre: not a ring slice)
     const bool ring_slice = !(b.pre && g == 0);
-    __shared__ double dm_s[4];
+    __shared__ double dm_s[NT / 64];
     if (t == 0 && ring_slice && b.ntail > 0) {
         double v = 0.0;
-        for (int i = tid; i < b.ntail; i += 256) { v = fmax(v, slice[b.mt + i]); slice[b.mt + i] = 0.0; }
+        for (int i = tid; i < b.ntail; i += NT) { v = fmax(v, slice[b.mt + i]); slice[b.mt + i] = 0.0; }
         v = wave_max_d(v);
         if ((tid & 63) == 0) dm_s[tid >> 6] = v;
         __syncthreads();
-        if (tid == 0)
-            __hip_atomic_store(&b.grp_dmax[g], fmax(fmax(dm_s[0], dm_s[1]), fmax(dm_s[2], dm_s[3])),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) {
+            double dm = dm_s[0];
+#pragma unroll
+            for (int w = 1; w < NT / 64; ++w) dm = fmax(dm, dm_s[w]);
+            __hip_atomic_store(&b.grp_dmax[g], dm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     double rmax = 0.0;
     if (!extra) {
-        rmax = ring_slice ? tree_rmax(b.tree, slice, b.T, t, b.vlo, b.vhi, tree_lds, nullptr, slice)
-                          : tree_rmax(b.tree, b.pre, b.T, t, b.vlo, b.vhi, tree_lds, nullptr, nullptr);
+        rmax = ring_slice ? tree_rmax<NT, IPT>(b.tree, slice, b.T, t, b.vlo, b.vhi, tree_lds, nullptr, slice)
+                          : tree_rmax<NT, IPT>(b.tree, b.pre, b.T, t, b.vlo, b.vhi, tree_lds, nullptr, nullptr);
     } else {
         const long long per = (b.mt + kHandOverGroups - 1) / kHandOverGroups;
         const long long i0 = t * per, i1 = i0 + per < b.mt ? i0 + per : b.mt;
-        for (long long i = i0 + tid; i < i1; i += 256) { b.hand_over[i] = slice[i]; slice[i] = 0.0; }
+        for (long long i = i0 + tid; i < i1; i += NT) { b.hand_over[i] = slice[i]; slice[i] = 0.0; }
     }
     __shared__ int last_s;
     __shared__ unsigned int bad_s;
@@ -1068,7 +1085,7 @@ __global__ __launch_bounds__(256) void stream_block_verdict_kernel(const BlockVe
     }
     __syncthreads();
     if (!last_s) return;
-    for (int q = tid; q < b.ndmax; q += 256) {
+    for (int q = tid; q < b.ndmax; q += NT) {
         const bool judged = q < b.nb;
         double r = 0.0;
         if (judged) {
@@ -1102,22 +1119,34 @@ int stream_block_verdict(StreamCtl *ctl, unsigned int base_seq, unsigned int gat
                          double *hand_over, double vlo, double vhi, double vtol,
                          unsigned long long *grp_bits, double *grp_dmax, double *rec, void *stream) {
     REVS_REQUIRE(ctl && nb >= 0 && nb < kRecRing && (nb > 0 || hand_over) && T > 0 && tree.n > 0 &&
-                 tree.n <= REVS_TREE_MAX && tree.n % 8 == 0 && tree.pack && tree.w && ring && stride >= mt + ntail &&
+                 tree.n <= REVS_TREE_MAX && tree.n % tree_shape(tree.n).ipt == 0 && tree.pack && tree.w && ring && stride >= mt + ntail &&
                  mt > 0 && ntail >= 0 && vlo <= vhi && vtol >= 0.0 && grp_bits && grp_dmax && rec &&
                  (!pre || nb >= 1), "stream_block_verdict: bad argument");
     const BlockVerdict b{ctl, base_seq, gate_seq, first_seq, nb, T, nb + (hand_over ? 1 : 0), tree, pre, ring,
                          (long long)stride, mt, ntail, hand_over, vlo, vhi, vtol, grp_bits, grp_dmax, rec};
-    hipLaunchKernelGGL(stream_block_verdict_kernel, dim3((unsigned)(nb * T + (hand_over ? kHandOverGroups : 0))),
-                       dim3(256), tree_lds_bytes(tree.n), (hipStream_t)stream, b);
+    const dim3 grid((unsigned)(nb * T + (hand_over ? kHandOverGroups : 0)));
+    const size_t lds = tree_lds_bytes(tree.n);
+    const TreeShape sh = tree_shape(tree.n);
+#define VK(NT, IPT)                                                                                            \
+    do {                                                                                                       \
+        if (!tree_big_lds<NT, IPT>(stream_block_verdict_kernel<NT, IPT>, lds)) return REVS_ELAUNCH;            \
+        hipLaunchKernelGGL((stream_block_verdict_kernel<NT, IPT>), grid, dim3(NT), lds, (hipStream_t)stream, b); \
+    } while (0)
+    if (sh.nt == 256) VK(256, 8);
+    else if (sh.nt == 512) VK(512, 8);
+    else if (sh.ipt == 8) VK(1024, 8);
+    else VK(1024, 16);
+#undef VK
     REVS_CHECK_LAUNCH("stream_block_verdict");
     return REVS_OK;
 }
 
-__global__ __launch_bounds__(256) void tree_voltage_kernel(TreeArgs tr, const double *p, int T,
-                                                           double vlo, double vhi, double *v_out,
-                                                           double *rmax_out) {
+template <int NT, int IPT>
+__global__ __launch_bounds__(NT) void tree_voltage_kernel(TreeArgs tr, const double *p, int T,
+                                                          double vlo, double vhi, double *v_out,
+                                                          double *rmax_out) {
     extern __shared__ double tree_lds[];
-    const double r = tree_rmax(tr, p, T, (int)blockIdx.x, vlo, vhi, tree_lds, v_out);
+    const double r = tree_rmax<NT, IPT>(tr, p, T, (int)blockIdx.x, vlo, vhi, tree_lds, v_out);
     if (threadIdx.x == 0 && rmax_out) rmax_out[blockIdx.x] = r;
 }
 }  // namespace revs
@@ -1125,11 +1154,23 @@ __global__ __launch_bounds__(256) void tree_voltage_kernel(TreeArgs tr, const do
 extern "C" int revs_tree_voltage(int32_t m, int32_t T, const revs_tree_t *tree, const double *p,
                                  double vlo, double vhi, double *v_out, double *rmax_out,
                                  void *stream) {
-    REVS_REQUIRE(m > 0 && T > 0 && tree && p && tree->n > 0 && tree->n <= REVS_TREE_MAX && tree->n % 8 == 0 && tree->pack && tree->w && vlo <= vhi,
-                 "revs_tree_voltage: bad argument (tree nodes <= %d)", REVS_TREE_MAX);
+    REVS_REQUIRE(m > 0 && T > 0 && tree && p && tree->n > 0 && tree->n <= REVS_TREE_MAX &&
+                 tree->n % tree_shape(tree->n).ipt == 0 && tree->pack && tree->w && vlo <= vhi,
+                 "revs_tree_voltage: bad argument (tree nodes <= %d, a multiple of 8; of 16 beyond 8192)", REVS_TREE_MAX);
     const TreeArgs tr{tree->n, (const unsigned long long *)tree->pack, tree->w};
-    hipLaunchKernelGGL(tree_voltage_kernel, dim3(T), dim3(256), tree_lds_bytes(tree->n),
-                       (hipStream_t)stream, tr, p, T, vlo, vhi, v_out, rmax_out);
+    const size_t lds = tree_lds_bytes(tree->n);
+    const TreeShape sh = tree_shape(tree->n);
+#define VK(NT, IPT)                                                                                    \
+    do {                                                                                               \
+        if (!tree_big_lds<NT, IPT>(tree_voltage_kernel<NT, IPT>, lds)) return REVS_ELAUNCH;            \
+        hipLaunchKernelGGL((tree_voltage_kernel<NT, IPT>), dim3(T), dim3(NT), lds, (hipStream_t)stream, \
+                           tr, p, T, vlo, vhi, v_out, rmax_out);                                       \
+    } while (0)
+    if (sh.nt == 256) VK(256, 8);
+    else if (sh.nt == 512) VK(512, 8);
+    else if (sh.ipt == 8) VK(1024, 8);
+    else VK(1024, 16);
+#undef VK
     REVS_CHECK_LAUNCH("revs_tree_voltage");
     return REVS_OK;
 }

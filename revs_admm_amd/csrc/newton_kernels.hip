@@ -190,7 +190,7 @@ __device__ __forceinline__ void tree_rows_body(const TreeRowsArgs &a, const int 
         for (int r = tid; r < a.m; r += 256) a.zero_out[(int64_t)r * T + t] = 0.0;
     unsigned long long pk[8];
     double v8[8];
-    tree_voltage(a.tree, a.p, T, t, lds, v8, pk, nullptr);
+    tree_voltage<256, 8>(a.tree, a.p, T, t, lds, v8, pk, nullptr);
     double rmax = 0.0, dsum = 0.0, nsup = 0.0, nvio = 0.0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -945,7 +945,7 @@ extern "C" int revs_op_dual_step_pending(int32_t T, const int64_t *cand_idx, con
 }
 
 static bool tree_ok(const revs_tree_t *tree) {
-    return tree && tree->n > 0 && tree->n <= REVS_TREE_MAX && tree->n % 8 == 0 && tree->pack && tree->w;
+    return tree && tree->n > 0 && tree->n <= REVS_TREE_SWEEP_MAX && tree->n % 8 == 0 && tree->pack && tree->w;
 }
 
 extern "C" int revs_op_dual_rows_tree(int32_t m, int32_t T, const revs_tree_t *tree, const double *pnq,
@@ -956,7 +956,7 @@ extern "C" int revs_op_dual_rows_tree(int32_t m, int32_t T, const revs_tree_t *t
     REVS_REQUIRE(m > 0 && m <= 16384 && T > 0 && T <= 256 && tree_ok(tree) && pnq && y && vfull && viol &&
                  partial && vlo <= vhi && kadd >= 0 && zero_out != pnq &&
                  (!with_select || (cand_idx && cand_cnt && cand_val && stats)),
-                 "revs_op_dual_rows_tree: bad argument (tree nodes <= %d)", REVS_TREE_MAX);
+                 "revs_op_dual_rows_tree: bad argument (tree nodes <= %d)", REVS_TREE_SWEEP_MAX);
     const TreeArgs tr{tree->n, (const unsigned long long *)tree->pack, tree->w};
     const TreeRowsArgs ta{tr, m, T, pnq, pnq + 2 * (int64_t)m * T, y, vlo, vhi, vfull, viol, partial, zero_out};
     const SelectArgs sa{m, T, 1, kadd, partial, y, vfull, viol, vlo, vhi, seq, cand_idx, cand_cnt, cand_val, stats};
@@ -1073,7 +1073,7 @@ extern "C" int revs_op_dual_evaluate_tree(int32_t phase, int32_t m, int32_t T, c
                                           int64_t *cand_idx, int32_t *cand_cnt, double *cand_val,
                                           double *stats, double seq, void *stream) {
     REVS_REQUIRE(tree_ok(tree), "revs_op_dual_evaluate_tree: bad tree (at most %d nodes, a multiple of 8)",
-                 REVS_TREE_MAX);
+                 REVS_TREE_SWEEP_MAX);
     return dual_evaluate_impl(phase, m, T, node_ptr, p_est, p_sch, gamma, R, nullptr, y, use_y, kappa, vlo, vhi,
                               kadd, ksplit, d_slabs, nullptr, pnq, p_est_new, vfull, viol, partial, cand_idx,
                               cand_cnt, cand_val, stats, seq, nullptr, tree, stream);

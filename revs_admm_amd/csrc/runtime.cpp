@@ -325,7 +325,7 @@ extern "C" int revs_plan_chain_step(revs_plan_t *plan, const double *y, double *
     // With the feeder as a tree the operator side between the home passes is the tree form of R p:
     // rows, selection, small model and step of every slot in ONE launch of T workgroups, the trial's
     // rows in another (its selection rides in the sweep's launch) -- no matrix stream at all.
-    const bool tf = plan->tree.n > 0;
+    const bool tf = plan->tree.n > 0 && plan->tree.n <= REVS_TREE_SWEEP_MAX;
     const revs_tree_t trh{plan->tree.n, (const uint64_t *)plan->tree.pack, plan->tree.w};
     int rc;
     if ((rc = home_pass(y, use_y, sup0)) != REVS_OK) return rc;
@@ -609,8 +609,8 @@ extern "C" int revs_comm_allreduce_f64(revs_comm_t *comm, double *buf, int64_t c
 extern "C" int revs_plan_set_tree(revs_plan_t *plan, const revs_tree_t *t) {
     REVS_REQUIRE(plan, "revs_plan_set_tree: null plan");
     if (!t || t->n == 0) { plan->tree = revs::TreeArgs{}; return REVS_OK; }
-    REVS_REQUIRE(t->n > 0 && t->n <= REVS_TREE_MAX && t->n % 8 == 0 && t->pack && t->w,
-                 "revs_plan_set_tree: bad tree (at most %d nodes, a multiple of 8)", REVS_TREE_MAX);
+    REVS_REQUIRE(t->n > 0 && t->n <= REVS_TREE_MAX && t->n % revs::tree_shape(t->n).ipt == 0 && t->pack && t->w,
+                 "revs_plan_set_tree: bad tree (at most %d nodes, a multiple of 8; of 16 beyond 8192)", REVS_TREE_MAX);
     plan->tree = revs::TreeArgs{t->n, (const unsigned long long *)t->pack, t->w};
     return REVS_OK;
 }
@@ -1023,7 +1023,9 @@ extern "C" int revs_plan_stream_run(revs_plan_t *plan, int32_t max_steps, revs_s
                  scale > 0.0 && eps > 0.0, "revs_plan_stream_run: bad argument (at most %d steps per call)",
                  revs::kRecRing - 1);
     const revs_plan_desc_t &d = plan->d;
-    REVS_REQUIRE(plan->tree.n > 0 && d.node_of, "revs_plan_stream_run: the plan has no tree / node_of");
+    REVS_REQUIRE(plan->tree.n > 0 && plan->tree.n <= REVS_TREE_SWEEP_MAX && d.node_of,
+                 "revs_plan_stream_run: the plan has no tree / node_of, or a tree of more than %d nodes (those are "
+                 "judged by blocks: revs_plan_stream_run_blocks)", REVS_TREE_SWEEP_MAX);
     for (int i = 0; i < 3; ++i)
         REVS_REQUIRE(st->p_est[i] && st->p[i] && (i == 2 || (st->p_sch[i] && st->gamma[i])),
                      "revs_plan_stream_run: null buffer");

@@ -107,7 +107,7 @@ class OperatorOptions:
     # How the steady state judges the voltage rows of an estimate: "dense" = the f64 matrix-core
     # product R p (always possible); "tree" = two tree passes over the radial feeder, O(nodes)
     # instead of O(nodes^2), inside the sweep's own launch (needs the feeder: `feeder=` of
-    # AdmmEngine); "auto" = tree when a feeder of at most REVS_TREE_MAX nodes was given.
+    # AdmmEngine); "auto" = tree when a feeder of at most REVS_TREE_MAX (16 384) nodes was given.
     voltage: str = "auto"
     # streaming steady state: launches enqueued per native call.  Starts at stream_burst, x4 after
     # every call whose launches were all kept (up to stream_burst_max), back to stream_burst after
@@ -384,6 +384,7 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
         self._burst = max(1, int(self.op.stream_burst))
         self._p_clear = None             # the node-sum array the last streaming launch cleared
         self._tree = None
+        self._tree_newton = False        # Newton evaluations judge their rows by the tree form too
         self._comm = None
         if feeder is not None and self.op.voltage in ("auto", "tree"):
             par, er, cons = feeder
@@ -407,6 +408,7 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
                 if self._plan is not None:
                     check(self.lib.revs_plan_set_tree(self._plan, C.byref(self._tree)),
                           "revs_plan_set_tree")
+                    self._tree_newton = tr["n"] <= _lib.TREE_SWEEP_MAX
             elif self.op.voltage == "tree":
                 raise ValueError(f"feeder has {len(par)} nodes; the tree form holds {_lib.TREE_MAX}")
         elif self.op.voltage == "tree":

@@ -15,7 +15,8 @@ def feeder_tree(parent, edge_r, cons_of, checked):
     Returns dict(n, src, end, eo, cle, w, pack) of numpy arrays (see include/revs_admm.h; the device
     gets `pack` and `w`, the separate index arrays serve tree_voltage_host)."""
     parent = np.asarray(parent, np.int64)
-    pad = (-len(parent)) % 8                 # the kernel's threads own 8 consecutive positions:
+    # the kernel's threads own 8 consecutive positions (16 in the shape for more than 8192 nodes):
+    pad = (-len(parent)) % (8 if -(-len(parent) // 8) * 8 <= 8192 else 16)
     if pad:                                  # pad with weightless nodes hanging off the substation
         parent = np.concatenate([parent, np.full(pad, -1, np.int64)])
         edge_r = np.concatenate([np.asarray(edge_r, np.float64), np.zeros(pad)])

@@ -48,6 +48,7 @@ class SteadyStateMixin:
         library's own communicator."""
         o = self.op
         return (self._plan is not None and self._tree is not None and o.solver == "newton"
+                and (self._block or self._tree.n <= _lib.TREE_SWEEP_MAX)     # (big trees: judged by blocks only)
                 and o.speculate and self._spec_ok and o.fuse_home_pass and not self._y_support
                 and (self.group is None or self._comm is not None))
 

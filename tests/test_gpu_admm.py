@@ -653,9 +653,10 @@ def test_tiny_runs_match_oracle(gpu_lib, n, M, T):
     assert np.abs(S - S_ref).max() < 2e-3 and np.abs(P - P_ref).max() < 2e-3
 
 
-@pytest.mark.parametrize("mode,stress,T", [("pdhg", 1.02, 24), ("relaxed_exact", 1.0, 24), ("binary", 0.5, 24),
-                                           ("pdhg", 1.02, 96)])
-def test_streaming_steady_state_equals_dense_product_path(gpu_lib, mode, stress, T):
+@pytest.mark.parametrize("mode,stress,T,nodes", [("pdhg", 1.02, 24, 200), ("relaxed_exact", 1.0, 24, 200),
+                                                 ("binary", 0.5, 24, 200), ("pdhg", 1.02, 96, 200),
+                                                 ("pdhg", 1.02, 24, 4096), ("relaxed_exact", 1.02, 24, 8192)])
+def test_streaming_steady_state_equals_dense_product_path(gpu_lib, mode, stress, T, nodes):
     """The steady state as ONE launch per iteration -- rows judged inside the sweep's launch by
     the tree form of R p, later launches silenced on the device after a failed verdict, the
     host only keeping the queue full (revs_plan_stream_run) -- against the path that multiplies
@@ -665,12 +666,15 @@ def test_streaming_steady_state_equals_dense_product_path(gpu_lib, mode, stress,
     from helpers import f32
     from revs_admm_amd.engine import OperatorOptions
     from revs_admm_amd.synthetic import make_workload
-    w = make_workload(8000 if T == 24 else 3000, T, n_nodes=200, seed=3, binary_feasible=(mode == "binary"),
-                      stress=stress)
+    w = make_workload((8000 if T == 24 else 3000) if nodes == 200 else 3 * nodes, T, n_nodes=nodes, seed=3,
+                      binary_feasible=(mode == "binary"), stress=stress)
     w.load, w.cost = f32(w.load), f32(w.cost)
     a = _engine(w, mode, op=OperatorOptions(voltage="dense"))
     b = _engine(w, mode, op=OperatorOptions(voltage="tree", stream_burst=3, stream_burst_max=24))
     assert a._tree is None and b._tree is not None
+    # (feeders of more than REVS_TREE_SWEEP_MAX nodes: the verdict launches use the bigger workgroup
+    # shapes, the Newton evaluations keep the dense product)
+    assert b._tree_newton == (nodes <= 2048) and b._block == 32
     for chunk in (1, 7, 30, 2, 50):
         a.run_steps(chunk)
         b.run_steps(chunk)

@@ -496,7 +496,8 @@ def test_model_problem_sizes(gpu_lib, a):
         assert obj(u) <= obj(s * ref[t, :a]) + 1e-5 * (abs(obj(s * ref[t, :a])) + 1e-300)
 
 
-@pytest.mark.parametrize("case", ["synthetic2048", "golden1691", "tiny", "gaps"])
+@pytest.mark.parametrize("case", ["synthetic2048", "golden1691", "tiny", "gaps", "synthetic4096", "synthetic8192",
+                                  "synthetic3000", "synthetic16384", "synthetic12001"])
 def test_tree_voltage_matches_dense_product(gpu_lib, case, golden, feeder_R):
     """revs_tree_voltage (R p as three prefix sums over the feeder in DFS preorder) == the dense
     float64 product Rn @ p at every checked row, to 1e-12 relative; rmax per slot == the largest
@@ -521,7 +522,10 @@ def test_tree_voltage_matches_dense_product(gpu_lib, case, golden, feeder_R):
         Rn, T = feeder_R, 96
         checked = np.ones(len(res), bool)
     else:
-        M, T = {"synthetic2048": (2048, 24), "tiny": (1, 7), "gaps": (300, 33)}[case]
+        # (beyond 2048 nodes: workgroups of 512 x 8, 1024 x 8 and 1024 x 16 positions)
+        M, T = {"synthetic2048": (2048, 24), "tiny": (1, 7), "gaps": (300, 33), "synthetic4096": (4096, 24),
+                "synthetic8192": (8192, 5), "synthetic3000": (3000, 24), "synthetic16384": (16384, 3),
+                "synthetic12001": (12001, 4)}[case]
         w = make_workload(max(M * 3, 10), 24, n_nodes=M, seed=4)
         par, er, cons = w.feeder
         Rn = w.Rn
