@@ -406,20 +406,17 @@ def main():
     # outside the streaming loop are judged by revs_residual_finalize as before
     iters_to_eps = None
     if args.mode != "binary" and not args.no_converge:
-        seen = 0
-        while eng.iteration < 800 and iters_to_eps is None:
-            for it in sorted(k for k in eng.max_diff if k > seen):
-                if eng.max_diff[it] <= args.eps:
-                    iters_to_eps = it
-                    break
-                seen = it
+        # AdmmEngine.run's rule: max diff <= eps for 8 iterations in a row (an iteration outside the
+        # streaming loop -- rows binding -- has no record and breaks the stretch)
+        seen, good = 0, 0
+        while eng.iteration < 1000 and iters_to_eps is None:
+            while seen < eng.iteration and iters_to_eps is None:
+                seen += 1
+                good = good + 1 if eng.max_diff.get(seen, np.inf) <= args.eps else 0
+                if good >= 8:
+                    iters_to_eps = seen - 7
             if iters_to_eps is None:
-                if eng.iteration not in eng.max_diff:
-                    rp, rd, dmax, conv = eng.residuals(args.eps)
-                    if conv:
-                        iters_to_eps = eng.iteration
-                        break
-                eng.run_steps(32)
+                eng.run_steps(64)
         rp, rd, dmax, conv = eng.residuals(args.eps)
     state = eng.get_state() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
 
@@ -564,6 +561,8 @@ def main():
                 "operator_voltage_rows": int(eng.M * args.T),
                 "admm_residual_primal": rp, "admm_residual_dual": rd, "admm_max_diff": dmax,
                 "admm_iters_to_eps": iters_to_eps, "eps": args.eps,
+                "admm_iters_to_eps_rule": "first of 8 consecutive iterations with max_h diff[h] <= eps, from the "
+                                          "records the streaming launches fold on the device",
                 # whole-run view: transient + steady iterations of a 400-iteration run
                 "amortized_400_iterations_solves_per_sec":
                     (n_total * 400 / ((np.sum(spin_ms) + (400 - args.spinup) * dt / args.steps * 1e3)

@@ -74,7 +74,9 @@ typedef struct {
 typedef struct {
     int32_t max_iter;     /* PDHG iteration cap (multiple of check)           */
     int32_t check;        /* convergence test every `check` iterations        */
-    float   tol;          /* stop when max(|dx|, |dy|/sigma) <= tol           */
+    float   tol;          /* stop when max(|dx|, |dy|/sigma) <= tol; 0 (default) = automatic: 1e-4
+                             where the polish below finishes the solve, 1e-6 with polish = 0 or
+                             full_rows; < 0: never before max_iter */
     float   tau_scale;    /* tau   = tau_scale   / ||K||   (0 = automatic)    */
     float   sigma_scale;  /* sigma = sigma_scale / ||K||   (0 = automatic)    */
     int32_t full_rows;    /* 0 (default): presolved -- with p >= 0 the SOC is
@@ -82,6 +84,11 @@ typedef struct {
                              of lpsolver.py:101-109 can bind; K is that single row and
                              the dual one scalar per home (automatic scales 0.5 / 2).
                              1: keep all T SOC rows (K = prefix sum; scales 0.25 / 4) */
+    int32_t polish;       /* presolved form only, 1 (default): after PDHG has stopped, two
+                             semismooth Newton steps on the terminal row's multiplier with the
+                             schedule in closed form x(mu) = clip(-b - delta mu, 0, w) -- the exact
+                             optimum of the piece PDHG identified (the KKT conditions of
+                             lpsolver.py:83-128's relaxation to float rounding) */
 } revs_pdhg_t;
 
 const char *revs_version(void);
@@ -92,7 +99,7 @@ const char *revs_last_error(void);
  * stats).  Fails with REVS_EINVAL when host_ptr is not mapped pinned memory. */
 int revs_host_device_ptr(void *host_ptr, void **dev_ptr_out);
 
-/* Defaults used when `pdhg` is NULL: 4000, 4, 1e-6, automatic scales, presolved rows */
+/* Defaults used when `pdhg` is NULL: 4000, 4, automatic tolerance and scales, presolved rows, polish */
 void revs_pdhg_defaults(revs_pdhg_t *out_host);
 
 /* Number of chunk records (3 doubles each) revs_residual_finalize uses for n_homes; size its

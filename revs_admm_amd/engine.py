@@ -851,7 +851,8 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
                                  "charging window cannot reach 90% state of charge")
         if f & 2:
             raise _lib.RevsError("REVS_ENOTCONV: a residence's PDHG iteration reached max_iter "
-                                 f"({self.pdhg.max_iter}) before its tolerance ({self.pdhg.tol:g})")
+                                 f"({self.pdhg.max_iter}) before its tolerance "
+                                 f"({self.pdhg.tol:g}{' = automatic' if self.pdhg.tol == 0 else ''})")
 
     def __del__(self):
         try:
@@ -864,35 +865,57 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
         except Exception:
             pass
 
-    def run(self, iter_max=15):
-        """Full solve_ADMM loop; returns diff (iter_max, n) in the caller's home order.
+    def run(self, iter_max=15, eps=None, patience=8):
+        """Full solve_ADMM loop; returns diff (iterations, n) in the caller's home order.
         The per-iteration diff of every residence (lpsolver.py:284) is collected on the device --
         the steady-state launches write their row themselves -- and fetched in pieces of at most
         2 GB: the host is not in the loop of the iterations, only a residence that cannot reach
-        90 % SOC is reported right after the first iteration, as the reference does."""
+        90 % SOC is reported right after the first iteration, as the reference does.
+        The reference always runs iter_max iterations (lpsolver.py:254).  With `eps` the run also
+        stops once max_h diff[h] <= eps has held for `patience` consecutive iterations (diff[2] is
+        ~0 in every run and rows that start to bind make it jump: one iteration proves nothing) --
+        judged on the records the streaming launches leave (`max_diff`: folded on the device, no
+        read-back of diff), at the end of the burst in which it happened; one more iteration then
+        writes the schedules.  `converged_at`: the first iteration of that stretch, or None."""
         diffs = torch.empty((iter_max, self.n), dtype=torch.float32)
         rows = max(1, min(iter_max, int(2e9) // (4 * max(self.n, 1))))
         hist = torch.empty((rows, self.n), dtype=torch.float32, device=self.dev)
         inv = torch.from_numpy(np.ascontiguousarray(self.inv_perm, dtype=np.int64)).to(self.dev)
-        k = 0
+        self.converged_at = None
+        k, it0, good, seen, stop = 0, self.iteration, 0, self.iteration, False
         while k < iter_max:
             base, r = k, 0
             while r < rows and k < iter_max:
-                last = k == iter_max - 1
+                last = k == iter_max - 1 or stop
                 if (not last and self._stream_ok() and self._fused_ready):
-                    done = self._stream_run(min(rows - r, iter_max - 1 - k), hist[r:])
+                    # (with eps: bursts of at most 64, so that the run ends soon after the stretch)
+                    done = self._stream_run(min(rows - r, iter_max - 1 - k, 64 if eps is not None else rows),
+                                            hist[r:])
                 else:
                     self.step(write_sc=last)
                     hist[r].copy_(self.diff)
                     done = 1
                     if k == 0:
                         self.check_status()          # (synchronises once)
+                    if eps is not None and self.iteration not in self.max_diff:
+                        self.max_diff[self.iteration] = float(self.diff.max().item()) if self.n else 0.0
                 k += done
                 r += done
+                if stop:
+                    break
+                if eps is not None:                  # the stretch of iterations at or below eps so far
+                    while seen < it0 + k and not stop:
+                        seen += 1
+                        good = good + 1 if self.max_diff.get(seen, np.inf) <= eps else 0
+                        if good >= patience:
+                            self.converged_at = seen - patience + 1
+                            stop = True
             # (back to the caller's home order on the device: one gather, one copy)
             diffs[base:k].copy_(hist[:r].index_select(1, inv))
+            if stop and last:
+                break
         self.check_status()
-        return diffs.numpy()
+        return diffs[:k].numpy()
 
     # ------------------------------------------------------- state in / out
     def set_state(self, P_est, P_sch, G, iteration=None):

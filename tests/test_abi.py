@@ -47,7 +47,7 @@ def test_argument_validation_without_gpu(lib):
     from revs_admm_amd._lib import PDHG
     pd = PDHG()
     lib.revs_pdhg_defaults(C.byref(pd))
-    assert (pd.max_iter, pd.check) == (4000, 4) and abs(pd.tol - 1e-6) < 1e-12
+    assert (pd.max_iter, pd.check, pd.polish, pd.tol) == (4000, 4, 1, 0.0)
     assert lib.revs_residual_num_chunks(100000) == 25               # 4096 homes per chunk
     assert lib.revs_residual_num_chunks(10) == 1 and lib.revs_residual_num_chunks(10 ** 7) == 256
     assert lib.revs_residual_num_chunks(0) == 0

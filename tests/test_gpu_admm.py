@@ -694,9 +694,10 @@ _RAGGED = (1, 7, 30, 2, 50, 64, 11)
 
 
 @pytest.mark.parametrize("mode,n,nodes,seed,stress,T,block,chunks", [
-    ("pdhg", 20000, 512, 0, 1.0, 24, 32, (40, 400, 400)),          # rows start to bind ~190 sweeps into a burst
+    ("pdhg", 20000, 512, 0, 1.0, 24, 40, (40, 400, 400)),          # rows start to bind 192 sweeps into a burst
     ("pdhg", 20000, 512, 0, 1.0, 24, 7, (40, 400, 400)),
-    ("pdhg", 20000, 512, 0, 1.0, 24, 193, (40, 400, 400)),        # ... exactly at a block's end
+    ("pdhg", 20000, 512, 0, 1.0, 24, 32, (40, 400, 400)),         # ... at the first iteration of a block
+    ("pdhg", 20000, 512, 0, 1.0, 24, 192, (40, 400, 400)),
     ("relaxed_exact", 20000, 512, 0, 1.01, 24, 5, (40, 400, 400)),
     ("pdhg", 8000, 200, 0, 1.1, 24, 16, (40, 400, 400)),
     ("pdhg", 8000, 200, 3, 1.02, 24, 5, _RAGGED),                   # a failed verdict at the head of a call
@@ -738,8 +739,8 @@ def test_block_verdicts_equal_per_launch_verdicts(gpu_lib, mode, n, nodes, seed,
     failed = [(c, k) for c, k in b.stream_calls if k < c]
     if mode != "binary":
         assert failed, b.stream_calls
-    if block == 193:    # the first iteration of the next block: nothing behind it ran on one stream
-        assert (400, 193) in failed, failed
+    if block in (192, 32) and mode == "pdhg" and n == 20000:    # the first iteration of the next block
+        assert (400, 192) in failed, failed
     elif not small:     # ... inside a block: the sweeps behind the failed one had run
         assert any(k > block and k % block != 0 for c, k in failed), failed
     a.step(write_sc=True); b.step(write_sc=True)

@@ -150,6 +150,52 @@ def test_distributed_converges_to_centralized(gpu_lib, T, iters, bound):
         assert (a is None) == (b is None) and (a is None or abs(a - b) <= 2), (eps, a, b)
 
 
+def test_iterations_to_the_eps_residual_match_the_oracle(gpu_lib):
+    """BASELINE's target names "ADMM residual <= 1e-4": the iteration from which max_h diff[h]
+    (lpsolver.py:284, the reference's only convergence measure) stays at or below 1e-4 -- 708 on the
+    600 x 24 feeder of the centralized comparison -- must be the oracle's to +-2, and so must the
+    3e-4 and 1e-3 crossings.  The GPU run is ONE AdmmEngine.run(760): the steady state streams by
+    blocks of 32 iterations, 8 per launch, and the convergence record (max diff of every streamed
+    iteration, folded on the device by the sweeps and the verdict launches) must equal the maximum
+    of that iteration's diff row exactly."""
+    from helpers import f32, oracle_homes
+    from oracle import revs_oracle as ro
+    from revs_admm_amd.synthetic import make_workload
+    iters = 760
+    w = make_workload(600, 24, n_nodes=60, seed=11, binary_feasible=False, stress=1.0)
+    w.load, w.cost = f32(w.load), f32(w.cost)
+    e = _engine(w, "pdhg")
+    d = e.run(iters)
+    d_ref, *_ = ro.solve_ADMM(oracle_homes(w), w.Rn, w.node_of, w.cost, w.kappa, iters, w.vset, w.vlow, w.vhigh,
+                              mode="relaxed", util_method="dual")
+    got = {eps: _settles_at(d, eps) for eps in (1e-3, 3e-4, 1e-4)}
+    want = {eps: _settles_at(d_ref, eps) for eps in (1e-3, 3e-4, 1e-4)}
+    print(f"settles at or below eps from iteration (GPU / oracle): {got} / {want}; streamed iterations "
+          f"{len(e.max_diff)}, kept / discarded {e.spec_hist}")
+    assert want[1e-4] is not None and 600 < want[1e-4] < iters
+    for eps in want:
+        assert got[eps] is not None and abs(got[eps] - want[eps]) <= 2, (eps, got, want)
+    assert np.abs(d - d_ref).max() < 1e-3 * max(1.0, d_ref.max())
+    late = slice(iters // 2, iters)
+    assert np.abs(d[late] - d_ref[late]).max() < 0.02 * d_ref[late].max() + 2e-6
+    # the device-side record
+    assert len(e.max_diff) > 600
+    for k, v in e.max_diff.items():
+        assert v == float(d[k - 1].max()), (k, v)
+    # ... and a run that stops on it: max diff <= 3e-4 for 8 iterations in a row, judged on those
+    # records (iterations outside the streaming loop -- rows binding -- are read back), schedules
+    # written by one more iteration
+    e2 = _engine(w, "pdhg")
+    d2 = e2.run(iters, eps=3e-4, patience=8)
+    mx = d.max(axis=1)
+    first = next(k for k in range(8, iters) if (mx[k - 7:k + 1] <= 3e-4).all()) - 7 + 1     # (1-based)
+    print(f"run(eps=3e-4) stopped after {len(d2)} iterations, converged_at {e2.converged_at} (first stretch of 8: {first})")
+    assert e2.converged_at == first and first + 7 <= len(d2) <= first + 7 + 64 + 1
+    np.testing.assert_array_equal(d2, d[:len(d2)])
+    P2, S2, C2 = e2.result()
+    assert np.abs(S2.sum(1) - (C2[:, -1] - C2[:, 0]) * np.where(w.homes["ev"] == 1, w.homes["capacity"], 0)).max() < 1e-3
+
+
 @pytest.mark.parametrize("mode,T,stress", [("pdhg", 24, 1.02), ("pdhg", 24, 1.3), ("relaxed_exact", 24, 1.0),
                                            ("pdhg", 96, 1.02)])
 def test_long_horizon_matches_oracle(gpu_lib, mode, T, stress):
@@ -192,19 +238,20 @@ def test_long_horizon_matches_oracle(gpu_lib, mode, T, stress):
         assert e.chain_hist[0] > 0
     assert np.abs(d[seen] - d_ref[seen]).max() < 1e-3 * max(1.0, d_ref.max())
     # late iterations: diff is ~5e-4; compare relative to ITS scale, not to the transient's.
-    # PDHG residences stop on a step-size test (1e-6 in p / rating): their schedules sit within
-    # ~1e-3 kW of the exact optimum, which is 4e-5 in diff -- the stated tolerance of the closed
-    # loop; the closed-form residences follow the oracle to float rounding.
+    # Round 3: PDHG residences finish with the KKT polish (two semismooth Newton steps on the
+    # terminal row's multiplier, the schedule in closed form) and follow the oracle as the
+    # closed-form residences do -- to float rounding (measured 0.2 %; 3.4 % with the step-size
+    # test alone, which left schedules ~1e-3 kW off in the closed loop).
     late = seen[seen >= iters // 2]
-    rel = 0.10 if mode == "pdhg" else 0.02
+    rel = 0.02
     assert np.abs(d[late] - d_ref[late]).max() < rel * d_ref[late].max() + 2e-6
-    assert np.abs(S - S_ref).max() < 3e-3 and np.abs(P - P_ref).max() < 3e-3
+    assert np.abs(S - S_ref).max() < 5e-4 and np.abs(P - P_ref).max() < 5e-4
     pe = e.P_est.cpu().numpy()[e.inv_perm]
-    assert np.abs(pe - tr.P_est[-1]).max() < 3e-3
+    assert np.abs(pe - tr.P_est[-1]).max() < 5e-4
     for eps in (3e-3, 1e-3):
         a, b = _settles_at(d, eps, seen), _settles_at(d_ref, eps, seen)
         print(f"  settles below {eps:g} (over the iterations read) at GPU {a}, oracle {b}")
-        assert (a is None) == (b is None) and (a is None or abs(a - b) <= 5), (eps, a, b)
+        assert (a is None) == (b is None) and (a is None or abs(a - b) <= 2), (eps, a, b)
 
 
 def test_binary_teacher_forced_long(gpu_lib):
