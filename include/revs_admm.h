@@ -720,6 +720,38 @@ typedef struct {
 int revs_plan_chain_run(revs_plan_t *plan, int32_t max_steps, revs_chain_state_t *st,
                         int32_t chain_few, int32_t *kept_steps, void *stream);
 
+/* The binding steady state with ONE pass over the residences per ADMM iteration (one GPU, the
+ * feeder as a tree of at most REVS_TREE_SWEEP_MAX nodes, few multipliers per slot: the row-wise
+ * form of the shifts).  revs_plan_chain_step makes three passes over the residences per iteration
+ * (two evaluations' home passes and the sweep) and five launches; here the sweep forms the
+ * operator's answer for the trial multipliers itself -- pen = max(g0 - d[node], 0), the evaluation
+ * kernel's arithmetic -- and folds BOTH evaluations' node sums into its own pass: those of the trial
+ * on the current state (its verdict) and those of the same multipliers on the state it has just
+ * produced (the next iteration's first evaluation).  The operator side is ONE launch of 2 T
+ * workgroups behind the sweep: [0, T) judge the trial (rows by the tree form, selection: the stats
+ * the host polls), [T, 2T) already run rows, selection, small model and step of the NEXT iteration.
+ * The host accepts iteration k on the same test as revs_plan_chain_step
+ * (revs_newton_chain_accept) while that launch is still busy, and enqueues the next sweep behind
+ * it: no gap, two launches per iteration.  A rejected iteration leaves the state untouched (the
+ * sweep wrote to the spares only) for the caller's general loop.
+ *   st   y / y_trial / y_spare: three multiplier arrays (double[m][T]); roles rotate by the kept
+ *        iterations (y = the accepted multipliers at return); use_y, sup0 as revs_chain_state_t
+ *        (sup0 = -1 at return); state buffers as there; s_out / c_out: NULL, or where the FIRST
+ *        iteration of the call writes schedules and SOC;
+ *        resume: in, 1 = the previous call kept all its iterations and nothing has touched the
+ *        state or the multipliers since (its last launch has already prepared this call's first
+ *        iteration); out, 1 = this call ended that way. */
+typedef struct {
+    double *y, *y_trial, *y_spare;
+    int32_t use_y, sup0;
+    float *p_est, *p_est_new;
+    float *p_sch, *p_sch_alt, *gamma, *gamma_alt;
+    float *s_out, *c_out;
+    int32_t resume;
+} revs_chain_fold_state_t;
+int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, revs_chain_fold_state_t *st,
+                             int32_t *kept_steps, void *stream);
+
 /* ---- the feeder as a tree: R p in O(nodes) ------------------------------------------
  * The reference forms the LinDistFlow sensitivity matrix R = 2 F D F^T densely
  * (lpsolver.py:17-26) and checks R_res g[:,t] against the limits (lpsolver.py:188-193).  On

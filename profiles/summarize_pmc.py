@@ -20,9 +20,12 @@ import pandas as pd
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, tag = sys.argv[1], sys.argv[2]
 homes, T, bytes_per_home = 100_000, 24, int(os.environ.get("REVS_BYTES_PER_HOME", "728"))
-grid = ((homes + 31) // 32 + T) * 256
+# round 3: the steady state's launches are the multi-iteration sweep (template argument MULTI = true,
+# 8 ADMM iterations per launch); round 2: one iteration per launch with T verdict workgroups in front
+multi = tag >= "r03"
+grid = ((homes + 31) // 32 + (0 if multi else T)) * 256
 rows, res = [], {}
-for name in ("fetch", "write", "sq"):
+for name in ("fetch", "write", "sq", "sq2"):
     f = os.path.join(src, name, f"{name}_counter_collection.csv")
     if not os.path.exists(f):
         continue
@@ -30,6 +33,8 @@ for name in ("fetch", "write", "sq"):
     df = df[df.Kernel_Name.str.contains("revs::")]
     df["kernel"] = df.Kernel_Name.str.replace(r"\(.*", "", regex=True).str.replace("void ", "")
     df["stream_launch"] = df.Kernel_Name.str.contains("agent_step") & (df.Grid_Size == grid)
+    if multi:
+        df["stream_launch"] &= df.Kernel_Name.str.contains(r"(?:true|1)>\(", regex=True)
     df["dur_us"] = (df.End_Timestamp - df.Start_Timestamp) / 1e3
     g = df.groupby(["kernel", "stream_launch", "Counter_Name"]).agg(
         calls=("Counter_Value", "size"), mean=("Counter_Value", "mean"),
@@ -40,8 +45,11 @@ for name in ("fetch", "write", "sq"):
         res[n] = float(v)
 pd.concat(rows).to_csv(os.path.join(ROOT, "profiles", f"{tag}_pmc_summary.csv"), index=False, float_format="%.1f")
 fetch, write = res["FETCH_SIZE"] * 2 * 1024, res["WRITE_SIZE"] * 1024
+extra = {k: res[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES",
+                            "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_BUSY_CYCLES") if k in res}
 json.dump({"homes": homes, "T": T, "mode": "pdhg", "fetch_bytes_corrected": fetch, "write_bytes": write,
            "hbm_bytes_per_launch": fetch + write, "algorithmic_bytes_per_launch": bytes_per_home * homes,
+           "iterations_per_launch": 8 if multi else 1, "sq_counters_per_launch": extra,
            "source": f"profiles/{tag}_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate "
                      "passes of `bench.py --steps 60 --no-extras --no-cpu-baseline --no-converge --clock-warm 0`, "
                      "the streaming launches of each pass; counters in KiB, FETCH_SIZE x2 per "

@@ -66,6 +66,14 @@ class ChainState(C.Structure):
                 ("p_sch_alt", C.c_void_p), ("gamma", C.c_void_p), ("gamma_alt", C.c_void_p)]
 
 
+class ChainFoldState(C.Structure):
+    """revs_chain_fold_state_t"""
+    _fields_ = [("y", C.c_void_p), ("y_trial", C.c_void_p), ("y_spare", C.c_void_p), ("use_y", C.c_int32),
+                ("sup0", C.c_int32), ("p_est", C.c_void_p), ("p_est_new", C.c_void_p), ("p_sch", C.c_void_p),
+                ("p_sch_alt", C.c_void_p), ("gamma", C.c_void_p), ("gamma_alt", C.c_void_p),
+                ("s_out", C.c_void_p), ("c_out", C.c_void_p), ("resume", C.c_int32)]
+
+
 class Tree(C.Structure):
     """revs_tree_t"""
     _fields_ = [("n", C.c_int32), ("pack", C.c_void_p), ("w", C.c_void_p)]
@@ -111,6 +119,7 @@ SIGNATURES = {
     "revs_plan_chain_step": (C.c_int, [_p, _p, _p, _i32, _i32, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p,
                                       _p, _p, _p, _p]),
     "revs_plan_chain_run": (C.c_int, [_p, _i32, C.POINTER(ChainState), _i32, _p, _p]),
+    "revs_plan_chain_fold_run": (C.c_int, [_p, _i32, C.POINTER(ChainFoldState), _p, _p]),
     "revs_plan_spec_run": (C.c_int, [_p, _i32, _p, C.POINTER(SpecState), _f64, _f64, _p, _p, _p, _p]),
     "revs_plan_spec_step": (C.c_int, [_p, _i32, _p, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _p,
                                       _p, _p, C.POINTER(C.c_double), _p, _p, _p]),

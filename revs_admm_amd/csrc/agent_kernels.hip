@@ -93,6 +93,19 @@ struct AgentArgs {
     float *y_out;
     long long slice_stride, diff_stride;
     double *dmax_out;
+    // The folded chain (revs_plan_chain_fold_run, template argument CHAIN): the operator's multipliers
+    // are NOT zero.  The sweep forms the operator's answer itself, pen = max(g0 - d[node], 0) with the
+    // shifts d = R^T y / kappa of the trial multipliers (sh_a, double[sh_m][T]: the evaluation
+    // kernel's arithmetic, bit for bit -- the operator launch before this sweep computes them) and
+    // writes it to pe_out; it accumulates that evaluation's node sums p | N | -(kappa/2) sum g^2 into
+    // fold_a and, after the dual update, those of the evaluation of the SAME multipliers on the state
+    // it has just produced into fold_b (both double[3][sh_m][T], zero on entry; shifts sh_b: the
+    // same sums taken in the order that evaluation's own home pass would take them): one pass over
+    // the residences per ADMM iteration while rows keep binding.
+    const double *sh_a, *sh_b;
+    int32_t sh_m;
+    double sh_kappa;
+    double *fold_a, *fold_b;
 };
 constexpr int kMaxInner = REVS_AGENT_MAX_INNER;
 #ifndef REVS_AGENT_MULTI_WAVES
@@ -191,11 +204,13 @@ __device__ __forceinline__ void stream_verdict_body(const AgentArgs &a, const in
 // profiles, the PDHG constants of the residence -- does not fit 64 VGPRs: the multi-iteration
 // form trades occupancy for registers, it is bound by instruction issue, not by memory latency);
 // without it the body runs once and compiles to the one-iteration kernel.
-constexpr int agent_waves(int spl, bool full_rows, bool multi) {
-    return (spl <= 4 && !full_rows) ? (multi ? REVS_AGENT_MULTI_WAVES : 8) : 4;
+// CHAIN: the folded chain's sweep (see AgentArgs::sh_R): one iteration, shifts and two sets of
+// node-sum accumulators in LDS, doubles in flight -- like MULTI it gives up occupancy for registers.
+constexpr int agent_waves(int spl, bool full_rows, bool multi, bool chain) {
+    return (spl <= 4 && !full_rows) ? (multi ? REVS_AGENT_MULTI_WAVES : (chain ? 5 : 8)) : 4;
 }
-template <int LPA, int SPL, int MODE, bool FULL_ROWS = false, bool MULTI = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(agent_waves(SPL, FULL_ROWS, MULTI))))
+template <int LPA, int SPL, int MODE, bool FULL_ROWS = false, bool MULTI = false, bool CHAIN = false>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(agent_waves(SPL, FULL_ROWS, MULTI, CHAIN))))
 void agent_step_kernel(const AgentArgs a) {
     constexpr int kHomesPerBlock = kBlock / LPA;
     // An earlier launch of this call failed its verdict: this launch must write nothing.  The
@@ -281,10 +296,24 @@ void agent_step_kernel(const AgentArgs a) {
     }
     if (silenced) return;
     int base = 0;
-    if (a.p_next) {      // (behind the loads: the barrier does not wait for them)
-        for (int i = tid; i < kin * kNodeLoc * kSlots; i += kBlock) (&nacc[0][0][0])[i] = 0.0;
-        if (tid < kAcc) dmx[tid] = 0u;
+    __shared__ double dsh[CHAIN ? 2 : 1][CHAIN ? kNodeLoc : 1][CHAIN ? kSlots : 1];   // shifts of this workgroup's nodes: list order, row order
+    // fold_a, fold_b: p | N | sum g^2 -- the addends rounded so that the sums are exact in any order
+    // (revs_q36 / revs_q32, common.h): the bits the evaluation kernel's fixed-order sums give
+    __shared__ double facc[CHAIN ? 2 : 1][3][CHAIN ? kNodeLoc : 1][CHAIN ? kSlots : 1];
+    if (a.p_next || CHAIN) {      // (behind the loads: the barrier does not wait for them)
+        if (a.p_next) {
+            for (int i = tid; i < kin * kNodeLoc * kSlots; i += kBlock) (&nacc[0][0][0])[i] = 0.0;
+            if (tid < kAcc) dmx[tid] = 0u;
+        }
         base = a.node_of[first < a.n ? first : a.n - 1];
+        if constexpr (CHAIN) {
+            for (int i = tid; i < 2 * 3 * kNodeLoc * kSlots; i += kBlock) (&facc[0][0][0][0])[i] = 0.0;
+            for (int i = tid; i < kNodeLoc * T; i += kBlock) {
+                const int l = i / T, t = i - l * T;
+                dsh[0][l][t] = base + l < a.sh_m ? a.sh_a[(int64_t)(base + l) * T + t] : 0.0;
+                dsh[1][l][t] = base + l < a.sh_m ? a.sh_b[(int64_t)(base + l) * T + t] : 0.0;
+            }
+        }
         __syncthreads();
     }
     const bool full = live && tfull;
@@ -299,6 +328,33 @@ void agent_step_kernel(const AgentArgs a) {
             pen[j] = (valid[j] && g0 > 0.f) ? g0 : 0.f;
         }
     }
+    const int node = ((a.p_next || CHAIN) && live) ? a.node_of[agent] : 0;
+    double dl[CHAIN ? SPL : 1];      // the shifts of this lane's slots
+    if constexpr (CHAIN) {
+        // the operator's answer of this iteration, as op_dual_eval_kernel forms it, and its node sums
+        const int loc = node - base;
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+            dl[j] = valid[j] ? (loc < kNodeLoc ? dsh[0][loc][t0 + j] : a.sh_a[(int64_t)node * T + t0 + j]) : 0.0;
+            const double g0 = (double)revs_g0f(pe[j], pso[j], gm[j], inv_kf);
+            const bool fr = valid[j] && g0 > dl[j];
+            const double g = fr ? g0 - dl[j] : 0.0;
+            pen[j] = (float)g;
+            if (fr) {
+                const double gq = revs_q36(g), g2 = revs_q32(g * g);
+                if (loc < kNodeLoc) {
+                    unsafeAtomicAdd(&facc[0][0][loc][t0 + j], gq);
+                    unsafeAtomicAdd(&facc[0][1][loc][t0 + j], 1.0);
+                    unsafeAtomicAdd(&facc[0][2][loc][t0 + j], g2);
+                } else {
+                    const int64_t o = (int64_t)node * T + t0 + j, mt = (int64_t)a.sh_m * T;
+                    unsafeAtomicAdd(&a.fold_a[o], gq);
+                    unsafeAtomicAdd(&a.fold_a[o + mt], 1.0);
+                    unsafeAtomicAdd(&a.fold_a[o + 2 * mt], -0.5 * a.sh_kappa * g2);
+                }
+            }
+        }
+    }
     const bool ev = h.ev != 0;
 #pragma unroll
     for (int j = 0; j < SPL; ++j) {
@@ -306,7 +362,6 @@ void agent_step_kernel(const AgentArgs a) {
         win[j] = ev && valid[j] && (t >= h.start) && (t < h.end);
     }
     const ScanMasks<LPA> mk(lig);
-    const int node = (a.p_next && live) ? a.node_of[agent] : 0;
 
     // ---- what a residence's PDHG passes need and no ADMM iteration changes (hoisted out of the
     // loop over the inner iterations) ----
@@ -634,6 +689,29 @@ void agent_step_kernel(const AgentArgs a) {
             pe2[j] = (valid[j] && g0 > 0.f) ? g0 : 0.f;
         }
     }
+    if constexpr (CHAIN) {      // the evaluation of the same multipliers on the state just produced
+        const int loc = node - base;
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) {
+            const double g0 = (double)revs_g0f(pen[j], gn[j], gmn[j], inv_kf);
+            const double ds = valid[j] ? (loc < kNodeLoc ? dsh[1][loc][t0 + j] : a.sh_b[(int64_t)node * T + t0 + j]) : 0.0;
+            const bool fr = valid[j] && g0 > ds;
+            const double g = fr ? g0 - ds : 0.0;
+            if (fr) {
+                const double gq = revs_q36(g), g2 = revs_q32(g * g);
+                if (loc < kNodeLoc) {
+                    unsafeAtomicAdd(&facc[1][0][loc][t0 + j], gq);
+                    unsafeAtomicAdd(&facc[1][1][loc][t0 + j], 1.0);
+                    unsafeAtomicAdd(&facc[1][2][loc][t0 + j], g2);
+                } else {
+                    const int64_t o = (int64_t)node * T + t0 + j, mt = (int64_t)a.sh_m * T;
+                    unsafeAtomicAdd(&a.fold_b[o], gq);
+                    unsafeAtomicAdd(&a.fold_b[o + mt], 1.0);
+                    unsafeAtomicAdd(&a.fold_b[o + 2 * mt], -0.5 * a.sh_kappa * g2);
+                }
+            }
+        }
+    }
     // per-home residual terms; the norms over all homes are folded by revs_residual_finalize
     // only when somebody asks for them (no workgroup reduction in the sweep, which is VALU
     // issue bound)
@@ -738,6 +816,19 @@ void agent_step_kernel(const AgentArgs a) {
                                                           (bid & (REVS_DMAX_SLOTS - 1))),
                                    (unsigned long long)__double_as_longlong((double)__uint_as_float(dmx[tid])),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if constexpr (CHAIN) {
+        __syncthreads();
+        const int64_t mt = (int64_t)a.sh_m * T;
+        for (int i = tid; i < 2 * 3 * kNodeLoc * T; i += kBlock) {
+            const int f = i / (3 * kNodeLoc * T), r0 = i - f * (3 * kNodeLoc * T);
+            const int q = r0 / (kNodeLoc * T), r1 = r0 - q * (kNodeLoc * T);
+            const int l = r1 / T, t = r1 - l * T;
+            const double v = facc[f][q][l][t];
+            if (v != 0.0 && base + l < a.sh_m)
+                unsafeAtomicAdd((f ? a.fold_b : a.fold_a) + q * mt + (int64_t)(base + l) * T + t,
+                                q == 2 ? -0.5 * a.sh_kappa * v : v);
+        }
     }
 }
 
@@ -873,6 +964,20 @@ template <int LPA, int SPL>
 static void launch_agent(const AgentArgs &a, int mode, dim3 grid, hipStream_t s) {
     // dynamic LDS: only a launch whose first workgroups run the tree form of R p needs any
     const size_t lds = a.tree.n > 0 ? tree_lds_bytes(a.tree.n) : 0;
+    if (a.sh_a) {        // the folded chain's sweep
+        switch (mode) {
+            case REVS_MODE_BINARY:
+                hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_BINARY, false, false, true>), grid, dim3(kBlock), 0, s, a);
+                break;
+            case REVS_MODE_RELAXED_PDHG:
+                hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_RELAXED_PDHG, false, false, true>), grid, dim3(kBlock), 0, s, a);
+                break;
+            default:
+                hipLaunchKernelGGL((agent_step_kernel<LPA, SPL, REVS_MODE_RELAXED_EXACT, false, false, true>), grid, dim3(kBlock), 0, s, a);
+                break;
+        }
+        return;
+    }
     if (a.kin > 1) {     // several iterations per launch (no verdict workgroups in these launches)
         switch (mode) {
             case REVS_MODE_BINARY:
@@ -959,7 +1064,7 @@ static int agent_step_impl(int64_t n_homes, int32_t T, const float *cost,
                            float kappa, int32_t mode, const revs_pdhg_t *pdhg_host,
                            const SelectArgs *sel, const int32_t *node_of, double *p_next,
                            float *pe2_out, void *stream, const StreamExtra *sx = nullptr,
-                           unsigned int *flags = nullptr) {
+                           unsigned int *flags = nullptr, const ChainFold *cf = nullptr) {
     REVS_REQUIRE(n_homes > 0, "revs_agent_step: n_homes=%lld", (long long)n_homes);
     REVS_REQUIRE(T > 0 && T <= REVS_MAX_T, "revs_agent_step: T=%d outside 1..%d", T, REVS_MAX_T);
     REVS_REQUIRE(cost && homes && load && p_est_old && p_sch && gamma && p_sch_out &&
@@ -981,6 +1086,16 @@ static int agent_step_impl(int64_t n_homes, int32_t T, const float *cost,
     a.ctl = nullptr; a.seq = 0; a.base_seq = 0; a.tree = TreeArgs{}; a.p_in = nullptr; a.p_zero = nullptr;
     a.vtol = 0.0; a.rec = nullptr; a.flags = flags; a.m = 0;
     a.kin = 1; a.pe_out = nullptr; a.y_out = pdhg_dual; a.slice_stride = 0; a.diff_stride = 0; a.dmax_out = nullptr;
+    a.sh_a = nullptr; a.sh_b = nullptr; a.sh_m = 0; a.sh_kappa = 0.0;
+    a.fold_a = nullptr; a.fold_b = nullptr;
+    if (cf) {
+        REVS_REQUIRE(cf->sh_a && cf->sh_b && cf->m > 0 && cf->kappa > 0 && cf->fold_a && cf->fold_b &&
+                     cf->fold_a != cf->fold_b && cf->pe_out && node_of && !p_est_new && !p_next && !sel && !sx &&
+                     !(pdhg_host && pdhg_host->full_rows),
+                     "revs_agent_step: bad argument of the folded chain's sweep");
+        a.sh_a = cf->sh_a; a.sh_b = cf->sh_b; a.sh_m = cf->m; a.sh_kappa = cf->kappa;
+        a.fold_a = cf->fold_a; a.fold_b = cf->fold_b; a.pe_out = cf->pe_out;
+    }
     if (sx && !sx->verdict) {         // judged by blocks (stream_block_verdict): silencing only
         REVS_REQUIRE(!sel, "revs_agent_step: bad streaming argument");      // (ctl == NULL: never silenced)
         a.ctl = sx->ctl; a.seq = sx->seq; a.base_seq = sx->base_seq; a.flags = sx->flags;
@@ -1028,6 +1143,16 @@ int agent_step_stream(int64_t n_homes, int32_t T, const float *cost, const revs_
     return agent_step_impl(n_homes, T, cost, homes, load, p_est_old, p_est_new, p_sch, gamma,
                            p_sch_out, gamma_out, nullptr, nullptr, diff, dsq, status, pdhg_dual,
                            kappa, mode, pdhg_host, nullptr, node_of, p_next, p_est_next, stream, &sx);
+}
+
+int agent_step_chain(int64_t n_homes, int32_t T, const float *cost, const revs_home_t *homes,
+                     const float *load, const float *p_est, const float *p_sch, const float *gamma,
+                     float *p_sch_out, float *gamma_out, float *s_out, float *c_out, float *diff, float *dsq,
+                     int32_t *status, float *pdhg_dual, float kappa, int32_t mode, const revs_pdhg_t *pdhg_host,
+                     const int32_t *node_of, const ChainFold &cf, unsigned int *flags, void *stream) {
+    return agent_step_impl(n_homes, T, cost, homes, load, p_est, nullptr, p_sch, gamma, p_sch_out, gamma_out,
+                           s_out, c_out, diff, dsq, status, pdhg_dual, kappa, mode, pdhg_host, nullptr,
+                           node_of, nullptr, nullptr, stream, nullptr, flags, &cf);
 }
 
 // ---- verdicts by blocks (sharded streaming steady state, runtime.cpp) --------------------

@@ -133,6 +133,15 @@ __device__ __forceinline__ float revs_g0f(float pe, float ps, float gm, float in
     return __builtin_fmaf(-gm, inv_kf, 0.5f * (pe + ps));
 }
 
+// Node sums that do not depend on the order of summation.  The operator's evaluations sum, per node
+// and slot, the residences' answers g (kW) and their squares in double.  Rounded to a multiple of
+// 2^-36 (2^-32 for the squares) first, every partial sum below 2^17 (2^21) is a 53-bit number and
+// each floating-point addition is EXACT: the evaluation kernel's fixed-order sums and the atomics of
+// a sweep that folds the same evaluation give the same bits -- and the rounding (1.5e-11 kW) is far
+// below the 1e-8 relative tolerance of the voltage rows (rounding g to float first, 1e-7 kW, is not).
+__device__ __forceinline__ double revs_q36(double g) { return __builtin_rint(g * 68719476736.0) * (1.0 / 68719476736.0); }
+__device__ __forceinline__ double revs_q32(double g2) { return __builtin_rint(g2 * 4294967296.0) * (1.0 / 4294967296.0); }
+
 // clip(v, lo, hi) as one v_med3_f32 (lo <= hi)
 __device__ __forceinline__ float clip3(float v, float lo, float hi) {
     return __builtin_amdgcn_fmed3f(v, lo, hi);

@@ -34,6 +34,54 @@ int agent_step_stream(int64_t n_homes, int32_t T, const float *cost, const revs_
                       int32_t mode, const revs_pdhg_t *pdhg_host, const int32_t *node_of,
                       double *p_next, float *p_est_next, const StreamExtra &sx, void *stream);
 
+// The folded chain's sweep (AgentArgs::sh_a in agent_kernels.hip): the residences' iteration with
+// the operator's answer formed inside, pen = max(g0 - d[node], 0), d = sh_a (double[m][T]: the shifts
+// R^T y / kappa of the trial multipliers, written by the operator launch before); pe_out receives
+// it; fold_a / fold_b (double[3][m][T], zero on entry) receive the node sums p | N | -(kappa/2) sum g^2
+// of that evaluation and of the evaluation of the same multipliers on the new state (shifts sh_b).
+struct ChainFold {
+    const double *sh_a, *sh_b;
+    int32_t m;
+    double kappa;
+    double *fold_a, *fold_b;
+    float *pe_out;
+};
+int agent_step_chain(int64_t n_homes, int32_t T, const float *cost, const revs_home_t *homes,
+                     const float *load, const float *p_est, const float *p_sch, const float *gamma,
+                     float *p_sch_out, float *gamma_out, float *s_out, float *c_out, float *diff, float *dsq,
+                     int32_t *status, float *pdhg_dual, float kappa, int32_t mode, const revs_pdhg_t *pdhg_host,
+                     const int32_t *node_of, const ChainFold &cf, unsigned int *flags, void *stream);
+
+// The folded chain's operator launch (newton_kernels.hip: op_chain_kv_kernel).  One side = one
+// evaluation judged by the tree form: its node sums pnq (p | N | q), the multipliers, scratch for
+// the rows (vfull, viol, partial -- the two sides run in ONE launch: separate scratch), the
+// candidate set and stats block its selection fills, tagged `seq`.  e2 (has_e2): the trial of the
+// iteration before -- rows and selection only; e1: rows, selection, small model and step into
+// y_trial (lin_out: the linear term, into the trial's stats block).  clr0 / clr1: double[3 m T]
+// arrays cleared on the way (NULL: none).
+struct ChainKvSide {
+    const double *pnq, *y;
+    double *vfull, *viol, *partial;
+    int64_t *cidx;
+    int32_t *ccnt;
+    double *cval, *stats;
+    double seq;
+};
+struct ChainKv {
+    int32_t m, T, kadd, has_e2;
+    TreeArgs tree;
+    double vlo, vhi, kappa, delta, scale, eps;
+    int32_t max_pivots;
+    ChainKvSide e1, e2;
+    const double *R;
+    double *k_full, *yhat;
+    int32_t *info;
+    double *y_trial, *lin_out;
+    double *clr0, *clr1;
+    double *sh_a, *sh_b;     // out: the shifts R^T y_trial / kappa (double[m][T]) in list order / in row order
+};
+int chain_kv_launch(const ChainKv &c, void *stream);
+
 // Verdicts by blocks (agent_kernels.hip).  A no-op when a launch numbered base_seq..gate_seq has
 // failed its verdict.  Judges `nb` slices of node sums -- `pre` (the caller's array: the sums of
 // the call's first iteration; NULL: none) and then ring slices at ring + g * stride, each `mt`

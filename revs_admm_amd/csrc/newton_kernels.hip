@@ -21,6 +21,7 @@
 #include "common.h"
 #include "select_body.h"
 #include "tree_body.h"
+#include "internal.h"
 
 namespace revs {
 
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(256) void op_dual_eval_kernel(
                 yv[k] = i0 + k < cnt ? sp.y[f[k] * T + t] : 0.0;
             }
 #pragma unroll
-            for (int k = 0; k < 8; ++k) d += rv[k] * yv[k];
+            for (int k = 0; k < 8; ++k) d = __builtin_fma(rv[k], yv[k], d);    // (explicit: chain_shifts_body repeats it)
         }
         d *= inv_k;
     }
@@ -84,9 +85,9 @@ __global__ __launch_bounds__(256) void op_dual_eval_kernel(
             const double g0 = (double)revs_g0f(pe[o], ps[o], gm[o], inv_kf);
             const bool fr = g0 > d;
             const double g = fr ? g0 - d : 0.0;
-            ap += g;
+            ap += revs_q36(g);              // (order-independent sums: common.h)
             an += fr ? 1.0 : 0.0;
-            aq += g * g;
+            aq += revs_q32(g * g);
             if (pe_new) pe_new[o] = (float)g;
         }
     }
@@ -765,6 +766,200 @@ __global__ __launch_bounds__(256) void op_tree_select_model_step_kernel(const Tr
     __syncthreads();
     dual_step_body<256>(t, sa.T, sa.cidx, sa.ccnt, sa.cval, fa.yhat,
                         rmax / fa.scale > fa.eps ? 1.0 : 0.0, fa.ytrial, fa.lin_out, fa.ycopy, sa.m);
+}
+
+// The folded chain's operator launch (revs_plan_chain_fold_run): behind the sweep of iteration k,
+// workgroups [0, T) judge the trial of iteration k (rows by the tree form and selection on the sums
+// the sweep folded: the verdict the host polls), workgroups [T, 2T) already run rows, selection,
+// small model and step of iteration k + 1 on the sums of the SAME multipliers on the new state --
+// speculative only in that the host may reject iteration k, in which case nobody reads them.  All
+// workgroups clear their share of the two sum arrays the NEXT sweep accumulates into.
+// d[node][t] = (R^T y)[node][t] / kappa from the rows of slot t's candidate list, in the list's order
+// -- op_dual_eval_kernel's SparseD loop, term for term -- and with the rows that carry a multiplier
+// taken in ascending row order: the order of the list the NEXT evaluation's home pass would read (a
+// selection lists the rows with y != 0 first, by row).  (Lists of more than 8 rows never pass the
+// chain's acceptance test: list order will do for the second one.)
+__device__ __forceinline__ void chain_shifts_body(const int t, int m, int T, const double *__restrict__ R,
+                                                  const int64_t *__restrict__ cidx, const int32_t *__restrict__ ccnt,
+                                                  const double *__restrict__ y, double inv_kappa,
+                                                  double *__restrict__ sh_a, double *__restrict__ sh_b) {
+    const int cnt = ccnt[t];
+    const int64_t *si = cidx + (int64_t)t * kAmax;
+    if (cnt <= 8) {
+        // The list and its multipliers do not depend on the node: fetched once, compacted to the rows
+        // that carry a multiplier (a term with y = 0 adds exactly nothing) and sorted once -- all
+        // uniform over the workgroup; per node only the loads of R are left, all independent.
+        int64_t f[8], fl[8], fs[8];
+        double yv[8], yl[8], ys[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] = k < cnt ? si[k] : 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) yv[k] = k < cnt ? y[f[k] * T + t] : 0.0;
+        int ns = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { fl[k] = 0; yl[k] = 0.0; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (yv[k] != 0.0) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) if (q == ns) { fl[q] = f[k]; yl[q] = yv[k]; }
+                ++ns;
+            }
+        }
+        int64_t last = -1;
+        bool same = true;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            int64_t best = 0x7FFFFFFFFFFFFFFFll;
+            double yb = 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k < ns && fl[k] > last && fl[k] < best) { best = fl[k]; yb = yl[k]; }
+            fs[r] = r < ns ? best : 0;
+            ys[r] = r < ns ? yb : 0.0;
+            same = same && (r >= ns || fs[r] == fl[r]);
+            last = best;
+        }
+        // (eight nodes per pass with every load of the pass in flight before the first use: the loop is
+        // latency, not bandwidth)
+        for (int n0 = threadIdx.x; n0 < m; n0 += 8 * 256) {
+            double ra[8][4], rb[8][4];
+            const int kk = ns < 4 ? ns : 4;         // rows beyond four (rare) go through the second loop below
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int node = n0 + 256 * i;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    ra[i][k] = (k < kk && node < m) ? R[fl[k] * m + node] : 0.0;
+                    rb[i][k] = (!same && k < kk && node < m) ? R[fs[k] * m + node] : 0.0;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int node = n0 + 256 * i;
+                if (node >= m) continue;
+                double d = 0.0, ds = 0.0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < kk) { d = __builtin_fma(ra[i][k], yl[k], d); ds = __builtin_fma(rb[i][k], ys[k], ds); }
+#pragma unroll
+                for (int k = 4; k < 8; ++k)
+                    if (k < ns) {
+                        d = __builtin_fma(R[fl[k] * m + node], yl[k], d);
+                        if (!same) ds = __builtin_fma(R[fs[k] * m + node], ys[k], ds);
+                    }
+                if (same) ds = d;
+                sh_a[(int64_t)node * T + t] = d * inv_kappa;
+                sh_b[(int64_t)node * T + t] = ds * inv_kappa;
+            }
+        }
+        return;
+    }
+    for (int node = threadIdx.x; node < m; node += 256) {
+        double d = 0.0;
+        for (int i0 = 0; i0 < cnt; i0 += 8) {
+            int64_t f[8];
+            double rv[8], yv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] = i0 + k < cnt ? si[i0 + k] : 0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                rv[k] = R[f[k] * m + node];
+                yv[k] = i0 + k < cnt ? y[f[k] * T + t] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d = __builtin_fma(rv[k], yv[k], d);
+        }
+        sh_a[(int64_t)node * T + t] = d * inv_kappa;
+        sh_b[(int64_t)node * T + t] = d * inv_kappa;
+    }
+}
+
+struct ChainKvArgs {
+    int has_e2;
+    TreeRowsArgs e2;
+    SelectArgs s2;
+    TreeRowsArgs e1;
+    SelectArgs s1;
+    FusedArgs f1;
+    double *clr0, *clr1;
+    long long clr_count;
+    double *sh_a, *sh_b;
+};
+__global__ __launch_bounds__(256) void op_chain_kv_kernel(const ChainKvArgs k) {
+    extern __shared__ double tree_lds[];
+    const int T = k.s1.T;
+    {
+        const long long per = (k.clr_count + gridDim.x - 1) / gridDim.x;
+        const long long i0 = blockIdx.x * per, i1 = i0 + per < k.clr_count ? i0 + per : k.clr_count;
+        for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
+            if (k.clr0) k.clr0[i] = 0.0;
+            if (k.clr1) k.clr1[i] = 0.0;
+        }
+    }
+    if (k.has_e2 && (int)blockIdx.x < T) {
+        tree_rows_body(k.e2, blockIdx.x, tree_lds);
+        __syncthreads();
+        dual_select_body<true>(k.s2, blockIdx.x);
+        return;
+    }
+    const int t = (int)blockIdx.x - (k.has_e2 ? T : 0);
+#ifdef REVS_KV_STAMPS      // tuning build: wall-clock ticks (100 MHz) at the stage boundaries of every slot
+#define KV_STAMP(i) do { if (threadIdx.x == 0) k.sh_b[(long long)k.s1.m * T + 8 * t + (i)] = (double)wall_clock64(); } while (0)
+#else
+#define KV_STAMP(i) do { } while (0)
+#endif
+    KV_STAMP(0);
+    tree_rows_body(k.e1, t, tree_lds);
+    __syncthreads();
+    KV_STAMP(1);
+    const double rmax = dual_select_body<true>(k.s1, t);
+    __syncthreads();
+    KV_STAMP(2);
+    small_model_body(t, k.s1.m, k.s1.T, k.f1.R, k.f1.Nn, k.s1.cidx, k.s1.ccnt, k.s1.cval, k.f1.inv_kappa, k.f1.delta,
+                     k.f1.max_pivots, k.f1.Kall, k.f1.yhat, k.f1.info);
+    __syncthreads();
+    KV_STAMP(3);
+    dual_step_body<256>(t, k.s1.T, k.s1.cidx, k.s1.ccnt, k.s1.cval, k.f1.yhat,
+                        rmax / k.f1.scale > k.f1.eps ? 1.0 : 0.0, k.f1.ytrial, k.f1.lin_out, k.f1.ycopy, k.s1.m);
+    __syncthreads();                        // the trial's column (first wavefront), in global memory
+    KV_STAMP(4);
+    chain_shifts_body(t, k.s1.m, k.s1.T, k.f1.R, k.s1.cidx, k.s1.ccnt, k.f1.ytrial, k.f1.inv_kappa, k.sh_a, k.sh_b);
+    __syncthreads();
+    KV_STAMP(5);
+#undef KV_STAMP
+}
+
+int chain_kv_launch(const ChainKv &c, void *stream) {
+    REVS_REQUIRE(c.m > 0 && c.m <= 16384 && c.T > 0 && c.T <= 256 && c.tree.n > 0 && c.tree.n <= REVS_TREE_SWEEP_MAX &&
+                 c.e1.pnq && c.e1.y && c.e1.vfull && c.e1.viol && c.e1.partial && c.e1.cidx && c.e1.ccnt && c.e1.cval &&
+                 c.e1.stats && c.R && c.k_full && c.yhat && c.info && c.y_trial && c.lin_out && c.y_trial != c.e1.y &&
+                 c.sh_a && c.sh_b && c.sh_a != c.sh_b &&
+                 (!c.has_e2 || (c.e2.pnq && c.e2.y && c.e2.vfull && c.e2.viol && c.e2.partial && c.e2.cidx &&
+                                c.e2.ccnt && c.e2.cval && c.e2.stats && c.e2.vfull != c.e1.vfull)),
+                 "chain_kv_launch: bad argument");
+    const int64_t mt = (int64_t)c.m * c.T;
+    ChainKvArgs k;
+    k.has_e2 = c.has_e2;
+    auto rows = [&](const ChainKvSide &s) {
+        return TreeRowsArgs{c.tree, c.m, c.T, s.pnq, s.pnq + 2 * mt, s.y, c.vlo, c.vhi, s.vfull, s.viol, s.partial, nullptr};
+    };
+    auto sel = [&](const ChainKvSide &s) {
+        return SelectArgs{c.m, c.T, 1, c.kadd, s.partial, s.y, s.vfull, s.viol, c.vlo, c.vhi, s.seq, s.cidx, s.ccnt, s.cval, s.stats};
+    };
+    k.e1 = rows(c.e1);
+    k.s1 = sel(c.e1);
+    k.s1.lazy = c.has_e2 != 0;      // (the entry launch's stats are read behind the first verdict too, but cost nothing extra)
+    k.e2 = rows(c.has_e2 ? c.e2 : c.e1);
+    k.s2 = sel(c.has_e2 ? c.e2 : c.e1);
+    k.f1 = FusedArgs{c.R, c.e1.pnq + mt, c.e1.y, 1.0 / c.kappa, c.delta, c.scale, c.eps, c.max_pivots, c.k_full, c.yhat,
+                     c.y_trial, c.lin_out, c.info};
+    k.clr0 = c.clr0; k.clr1 = c.clr1; k.clr_count = 3 * mt;
+    k.sh_a = c.sh_a; k.sh_b = c.sh_b;
+    hipLaunchKernelGGL(op_chain_kv_kernel, dim3((c.has_e2 ? 2 : 1) * c.T), dim3(256), tree_lds_bytes(c.tree.n),
+                       (hipStream_t)stream, k);
+    REVS_CHECK_LAUNCH("chain_kv_launch");
+    return REVS_OK;
 }
 
 }  // namespace revs

@@ -65,6 +65,18 @@ struct revs_plan {
     std::vector<hipEvent_t> events;        // pool: sweeps-done / verdicts-done per block, end of call
     // optional timing of the bursts on their own stream (revs_plan_stream_timing)
     hipEvent_t tev[2] = {nullptr, nullptr};
+    // folded chain (revs_plan_chain_fold_run): sums of the trial's evaluation E2 / of the next
+    // iteration's evaluation E1 by iteration parity, the E2 side's row scratch, the odd parity's
+    // candidate sets and stats blocks ([0]: the evaluation's, [1]: the trial's)
+    double *fold_e2[2] = {nullptr, nullptr}, *fold_e1[2] = {nullptr, nullptr};
+    double *fold_v[3] = {nullptr, nullptr, nullptr};
+    double *fold_sh[2] = {nullptr, nullptr};           // the trial's shifts R^T y / kappa, list order / row order
+    int64_t *fold_ci[2] = {nullptr, nullptr};
+    int32_t *fold_cc[2] = {nullptr, nullptr};
+    double *fold_cv[2] = {nullptr, nullptr};
+    double *fold_st_host[2] = {nullptr, nullptr}, *fold_st_dev[2] = {nullptr, nullptr};
+    int32_t fold_par = 0;                  // parity of the iteration a resumed call starts with
+    bool fold_ready = false;               // ... whose rows / model / step the last call has already run
     int32_t timing = 0;                    // 0 off, 1 armed (next burst records tev[0]), 2 open
     int64_t timed_launches = 0;            // residence-sweep launches between the two events
 };
@@ -96,7 +108,7 @@ extern "C" int revs_newton_chain_accept(int32_t T, const double *s0, const doubl
         const double *a = s0 + 8 * t, *b = s1 + 8 * t;
         const double D = a[1];
         if (a[0] / scale > eps &&                        // pending slot: Armijo on the full step
-            !(b[1] >= D + 1e-4 * b[4] - 1e-13 * (D < 0 ? -D : D)))
+            !(b[1] >= D + 1e-4 * b[4] - 1e-11 * (D < 0 ? -D : D)))
             return 0;
         if (b[2] > amax) return 0;
         const double r = b[0] / scale;
@@ -166,6 +178,16 @@ extern "C" void revs_plan_destroy(revs_plan_t *plan) {
     if (plan->ring) (void)hipFree(plan->ring);
     if (plan->grp_bits) (void)hipFree(plan->grp_bits);
     if (plan->grp_dmax) (void)hipFree(plan->grp_dmax);
+    for (int i = 0; i < 2; ++i) {
+        if (plan->fold_e2[i]) (void)hipFree(plan->fold_e2[i]);
+        if (plan->fold_e1[i]) (void)hipFree(plan->fold_e1[i]);
+        if (plan->fold_ci[i]) (void)hipFree(plan->fold_ci[i]);
+        if (plan->fold_cc[i]) (void)hipFree(plan->fold_cc[i]);
+        if (plan->fold_cv[i]) (void)hipFree(plan->fold_cv[i]);
+        if (plan->fold_st_host[i]) (void)hipHostFree(plan->fold_st_host[i]);
+    }
+    for (double *v : plan->fold_v) if (v) (void)hipFree(v);
+    for (double *v : plan->fold_sh) if (v) (void)hipFree(v);
     for (hipEvent_t e : plan->events) (void)hipEventDestroy(e);
     for (hipEvent_t e : plan->tev) if (e) (void)hipEventDestroy(e);
     if (plan->side) (void)hipStreamDestroy(plan->side);
@@ -458,6 +480,232 @@ extern "C" int revs_plan_chain_run(revs_plan_t *plan, int32_t max_steps, revs_ch
     return REVS_OK;
 }
 
+
+// The binding steady state with ONE pass over the residences per ADMM iteration (see revs_admm.h).
+// Per iteration k (parity par = k & 1, candidate sets / stats S0[par], S1[par]):
+//   sweep     the residences' iteration with the operator's answer for the trial multipliers formed
+//             inside (shifts from S0[par]'s lists), P_sch / G to the spares, pen to p_est_new; folds
+//             the trial's node sums into fold_e2[par] and the sums of the same multipliers on the
+//             new state into fold_e1[par ^ 1]
+//   KV        [0, T): rows + selection of the trial -> S1[par] (the verdict the host polls);
+//             [T, 2T): rows, selection, small model, step of iteration k + 1 -> S0[par ^ 1], the
+//             next trial in y_spare; clears fold_e2[par ^ 1], fold_e1[par]
+// then revs_newton_chain_accept on S0[par], S1[par]; accepted: roles rotate and iteration k + 1
+// starts with its sweep -- its operator work is done.  The first iteration of a call that does not
+// resume evaluates the multipliers with the evaluation kernel first.
+static int fold_alloc(revs_plan_t *plan) {
+    const revs_plan_desc_t &d = plan->d;
+    if (plan->fold_e2[0]) return REVS_OK;
+    const size_t mt = (size_t)d.m * d.T;
+    hipError_t e = hipSuccess;
+    auto dev = [&](void **p, size_t bytes) {
+        if (e == hipSuccess) e = hipMalloc(p, bytes);
+        if (e == hipSuccess) e = hipMemset(*p, 0, bytes);
+    };
+    for (int i = 0; i < 2; ++i) {
+        dev((void **)&plan->fold_e2[i], sizeof(double) * 3 * mt);
+        dev((void **)&plan->fold_e1[i], sizeof(double) * 3 * mt);
+        dev((void **)&plan->fold_ci[i], sizeof(int64_t) * (size_t)d.T * REVS_DUAL_AMAX);
+        dev((void **)&plan->fold_cc[i], sizeof(int32_t) * (size_t)d.T);
+        dev((void **)&plan->fold_cv[i], sizeof(double) * (size_t)d.T * 3 * REVS_DUAL_AMAX);
+        if (e == hipSuccess) {
+            void *h = nullptr, *dp = nullptr;
+            e = hipHostMalloc(&h, sizeof(double) * 8 * (size_t)d.T, hipHostMallocMapped);
+            if (e == hipSuccess) {
+                memset(h, 0, sizeof(double) * 8 * (size_t)d.T);
+                e = hipHostGetDevicePointer(&dp, h, 0);
+            }
+            plan->fold_st_host[i] = (double *)h;
+            plan->fold_st_dev[i] = (double *)dp;
+        }
+    }
+    dev((void **)&plan->fold_v[0], sizeof(double) * mt);
+    dev((void **)&plan->fold_v[1], sizeof(double) * mt);
+    dev((void **)&plan->fold_v[2], sizeof(double) * (size_t)d.T * 4);
+    dev((void **)&plan->fold_sh[0], sizeof(double) * mt);
+    dev((void **)&plan->fold_sh[1], sizeof(double) * (mt + 8 * (size_t)d.T));     // (+ the tuning build's stage stamps)
+    if (e != hipSuccess) {
+        revs::set_error("revs_plan_chain_fold_run: allocating the folded chain's buffers: %s", hipGetErrorString(e));
+        return REVS_ELAUNCH;
+    }
+    return REVS_OK;
+}
+
+extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, revs_chain_fold_state_t *st,
+                                        int32_t *kept_steps, void *stream) {
+    REVS_REQUIRE(plan && max_steps >= 0 && st && kept_steps && st->y && st->y_trial && st->y_spare &&
+                 st->y != st->y_trial && st->y != st->y_spare && st->y_trial != st->y_spare && st->p_est &&
+                 st->p_est_new && st->p_sch && st->p_sch_alt && st->gamma && st->gamma_alt,
+                 "revs_plan_chain_fold_run: bad argument");
+    const revs_plan_desc_t &d = plan->d;
+    REVS_REQUIRE(plan->tree.n > 0 && plan->tree.n <= REVS_TREE_SWEEP_MAX && d.node_of && d.cand_idx1 && d.cand_cnt1 &&
+                 d.cand_val1 && d.stats1 && d.stats1_host && d.yhat && d.k_full && d.info && d.max_pivots > 0 &&
+                 d.eps > 0 && !d.pdhg.full_rows,
+                 "revs_plan_chain_fold_run: needs the feeder as a tree (at most %d nodes), node_of, the chain's "
+                 "buffers and the presolved PDHG form", REVS_TREE_SWEEP_MAX);
+    *kept_steps = 0;
+    if (fold_alloc(plan) != REVS_OK) return REVS_ELAUNCH;
+    hipStream_t s = (hipStream_t)stream;
+    struct Set { int64_t *ci; int32_t *cc; double *cv; double *st; const double *st_host; };
+    auto set_of = [&](int par, int which) -> Set {
+        if (par == 0)
+            return which == 0 ? Set{d.cand_idx, d.cand_cnt, d.cand_val, d.stats, d.stats_host}
+                              : Set{d.cand_idx1, d.cand_cnt1, d.cand_val1, d.stats1, d.stats1_host};
+        return Set{plan->fold_ci[which], plan->fold_cc[which], plan->fold_cv[which], plan->fold_st_dev[which],
+                   plan->fold_st_host[which]};
+    };
+    const double scale = std::max(std::max(std::fabs(d.vlo), std::fabs(d.vhi)), 1e-300);
+    const revs_tree_t trh{plan->tree.n, (const uint64_t *)plan->tree.pack, plan->tree.w};
+    const int64_t mt = (int64_t)d.m * d.T;
+    bool have_k1 = st->resume != 0 && plan->fold_ready;
+    int par = have_k1 ? plan->fold_par : 0;
+    plan->fold_ready = false;
+    st->resume = 0;
+    int rc = REVS_OK;
+    for (int32_t k = 0; k < max_steps; ++k) {
+        const Set S0 = set_of(par, 0), S1 = set_of(par, 1), S0n = set_of(par ^ 1, 0), S1n = set_of(par ^ 1, 1);
+        if (!have_k1) {
+            // entry: the multipliers' evaluation by the evaluation kernel (row-wise shifts from the
+            // caller's list `sup0` when it has one), rows / selection / model / step in one launch
+            if (st->use_y && st->sup0 >= 0) {
+                int64_t *const ci[2] = {d.cand_idx, d.cand_idx1};
+                int32_t *const cc[2] = {d.cand_cnt, d.cand_cnt1};
+                rc = revs_op_dual_eval_rows(d.m, d.T, d.node_ptr, st->p_est, st->p_sch, st->gamma, d.R, ci[st->sup0],
+                                            cc[st->sup0], st->y, d.kappa, d.pnq, st->p_est_new, stream);
+            } else {
+                rc = revs_op_dual_evaluate(1, d.m, d.T, d.node_ptr, st->p_est, st->p_sch, st->gamma, d.R, d.Rt, st->y,
+                                           st->use_y, d.kappa, d.vlo, d.vhi, d.kadd, d.ksplit, d.d_slabs, d.v_slabs,
+                                           d.pnq, st->p_est_new, d.vfull, d.viol, d.partial, d.cand_idx, d.cand_cnt,
+                                           d.cand_val, d.stats, 0.0, nullptr, stream);
+            }
+            if (rc != REVS_OK) return rc;
+            {   // rows, selection, small model, step and the trial's shifts: the operator launch without a trial to judge
+                revs::ChainKv c0{};
+                c0.m = d.m; c0.T = d.T; c0.kadd = d.kadd; c0.has_e2 = 0;
+                c0.tree = plan->tree;
+                c0.vlo = d.vlo; c0.vhi = d.vhi; c0.kappa = d.kappa; c0.delta = d.delta; c0.scale = scale; c0.eps = d.eps;
+                c0.max_pivots = d.max_pivots;
+                c0.e1 = revs::ChainKvSide{d.pnq, st->y, d.vfull, d.viol, d.partial, S0.ci, S0.cc, S0.cv, S0.st, 0.0};
+                c0.R = d.R; c0.k_full = d.k_full; c0.yhat = d.yhat; c0.info = d.info;
+                c0.y_trial = st->y_trial;
+                c0.lin_out = S1.st + 4;
+                c0.clr0 = nullptr; c0.clr1 = nullptr;
+                c0.sh_a = plan->fold_sh[0]; c0.sh_b = plan->fold_sh[1];
+                rc = revs::chain_kv_launch(c0, stream);
+            }
+            if (rc != REVS_OK) return rc;
+            // (the arrays this iteration's sweep accumulates into start from zero)
+            if (hipMemsetAsync(plan->fold_e2[par], 0, sizeof(double) * 3 * mt, s) != hipSuccess ||
+                hipMemsetAsync(plan->fold_e1[par ^ 1], 0, sizeof(double) * 3 * mt, s) != hipSuccess) {
+                revs::set_error("revs_plan_chain_fold_run: hipMemsetAsync failed");
+                return REVS_ELAUNCH;
+            }
+        }
+        const revs::ChainFold cf{plan->fold_sh[0], plan->fold_sh[1], d.m, d.kappa, plan->fold_e2[par],
+                                 plan->fold_e1[par ^ 1], st->p_est_new};
+        rc = revs::agent_step_chain(d.n_homes, d.T, d.cost, d.homes, d.load, st->p_est, st->p_sch, st->gamma,
+                                    st->p_sch_alt, st->gamma_alt, st->s_out, st->c_out, d.diff, d.dsq, d.status,
+                                    d.pdhg_dual, (float)d.kappa, d.mode, &d.pdhg, d.node_of, cf, plan->flags_dev, stream);
+        if (rc != REVS_OK) return rc;
+        const double seq = -(plan->seq += 1.0);
+        revs::ChainKv c{};
+        c.m = d.m; c.T = d.T; c.kadd = d.kadd; c.has_e2 = 1;
+        c.tree = plan->tree;
+        c.vlo = d.vlo; c.vhi = d.vhi; c.kappa = d.kappa; c.delta = d.delta; c.scale = scale; c.eps = d.eps;
+        c.max_pivots = d.max_pivots;
+        c.e2 = revs::ChainKvSide{plan->fold_e2[par], st->y_trial, plan->fold_v[0], plan->fold_v[1], plan->fold_v[2],
+                                 S1.ci, S1.cc, S1.cv, S1.st, seq};
+        c.e1 = revs::ChainKvSide{plan->fold_e1[par ^ 1], st->y_trial, d.vfull, d.viol, d.partial,
+                                 S0n.ci, S0n.cc, S0n.cv, S0n.st, 0.0};
+        c.R = d.R; c.k_full = d.k_full; c.yhat = d.yhat; c.info = d.info;
+        c.y_trial = st->y_spare;
+        c.lin_out = S1n.st + 4;
+        c.clr0 = plan->fold_e2[par ^ 1];
+        c.clr1 = plan->fold_e1[par];
+        c.sh_a = plan->fold_sh[0];
+        c.sh_b = plan->fold_sh[1];
+        rc = revs::chain_kv_launch(c, stream);
+        if (rc != REVS_OK) return rc;
+        // the trial's verdict: poll its tags (pinned memory), then the driver's own acceptance test
+        const volatile double *tg = S1.st_host;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int t = 0; t < d.T; ++t) {
+            unsigned spins = 0;
+            while (tg[8 * t + 5] != seq) {
+                if ((++spins & 0xFFFF) == 0) {
+                    if (hipStreamQuery(s) == hipSuccess && tg[8 * t + 5] != seq) {
+                        revs::set_error("revs_plan_chain_fold_run: stream idle but stats tag missing");
+                        return REVS_ELAUNCH;
+                    }
+                    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+                        (void)hipStreamSynchronize(s);
+                        revs::set_error("revs_plan_chain_fold_run: timed out waiting for the trial's verdict");
+                        return REVS_ELAUNCH;
+                    }
+                }
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        int32_t nsum = 0, nmax = 0;
+        const int acc = revs_newton_chain_accept(d.T, S0.st_host, S1.st_host, scale, d.eps, REVS_DUAL_AMAX, d.kadd, 1,
+                                                 &nsum, &nmax);
+        static const bool ftrace = getenv("REVS_FOLD_TRACE") != nullptr;
+        if (ftrace && !acc) {
+            double r0 = 0, r1 = 0, ncm = 0;
+            int arm = 0;
+            for (int t = 0; t < d.T; ++t) {
+                const double *a = S0.st_host + 8 * t, *b = S1.st_host + 8 * t;
+                r0 = std::max(r0, a[0] / scale);
+                r1 = std::max(r1, b[0] / scale);
+                ncm = std::max(ncm, a[2] + std::min(a[3], (double)d.kadd));
+                if (a[0] / scale > d.eps && !(b[1] >= a[1] + 1e-4 * b[4] - 1e-11 * std::fabs(a[1]))) {
+                    ++arm;
+                    fprintf(stderr, "   slot %d: D0 %.17g D1 %.17g lin %.6g gain %.6g rows0 %.3g rows1 %.3g ns %g nv %g\n", t, a[1], b[1],
+                            b[4], b[1] - a[1], a[0] / scale, b[0] / scale, a[2], a[3]);
+                }
+            }
+            fprintf(stderr, "[fold] iteration %d (par %d, resumed %d) rejected: rows before %.3g after %.3g candidates %g armijo failures %d\n",
+                    k, par, (int)have_k1, r0, r1, ncm, arm);
+        }
+        if (!acc) return REVS_OK;             // the caller's general loop takes this iteration (state untouched)
+        double *y_old = st->y;
+        st->y = st->y_trial;
+        st->y_trial = st->y_spare;
+        st->y_spare = y_old;
+        st->use_y = nsum > 0;
+        st->sup0 = -1;
+        std::swap(st->p_sch, st->p_sch_alt);
+        std::swap(st->gamma, st->gamma_alt);
+        std::swap(st->p_est, st->p_est_new);
+        st->s_out = nullptr;                  // (schedules are written by the call's first iteration only)
+        st->c_out = nullptr;
+        ++*kept_steps;
+        par ^= 1;
+        static const bool no_pipe = getenv("REVS_FOLD_NO_PIPE") != nullptr;     // (debugging aid)
+        have_k1 = !no_pipe;
+    }
+    plan->fold_ready = have_k1;
+    plan->fold_par = par;
+    st->resume = have_k1 ? 1 : 0;
+#ifdef REVS_KV_STAMPS
+    {
+        std::vector<double> h(8 * (size_t)d.T);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h.data(), plan->fold_sh[1] + mt, sizeof(double) * h.size(), hipMemcpyDeviceToHost);
+        double mx[5] = {0, 0, 0, 0, 0};
+        int worst = 0;
+        for (int t = 0; t < d.T; ++t) {
+            if (h[8 * t + 5] - h[8 * t] > h[8 * worst + 5] - h[8 * worst]) worst = t;
+            for (int i = 0; i < 5; ++i) mx[i] = std::max(mx[i], (h[8 * t + i + 1] - h[8 * t + i]) * 0.01);
+        }
+        fprintf(stderr, "[kv stamps, us] slowest slot %d: rows %.1f select %.1f model %.1f step %.1f shifts %.1f | max over slots: "
+                "%.1f %.1f %.1f %.1f %.1f\n", worst, (h[8 * worst + 1] - h[8 * worst]) * 0.01, (h[8 * worst + 2] - h[8 * worst + 1]) * 0.01,
+                (h[8 * worst + 3] - h[8 * worst + 2]) * 0.01, (h[8 * worst + 4] - h[8 * worst + 3]) * 0.01,
+                (h[8 * worst + 5] - h[8 * worst + 4]) * 0.01, mx[0], mx[1], mx[2], mx[3], mx[4]);
+    }
+#endif
+    return REVS_OK;
+}
 
 // ---- RCCL communicator owned by the library (see revs_admm.h) ---------------------------
 // librccl.so.1 is opened at run time: the copy already mapped into the process when there is

@@ -28,6 +28,11 @@ struct SelectArgs {
     int64_t *cidx;
     int32_t *ccnt;
     double *cval, *stats;
+    // lazy: nobody polls this evaluation's tag (the folded chain's speculative next iteration: the
+    // host reads its stats only after a later launch's verdict) -- the stats are stored without the
+    // system-scope fence in front of the tag, which otherwise holds thread 0 (and at the next
+    // barrier the whole workgroup) for a round trip to host memory
+    bool lazy = false;
 };
 
 // Stage 2, one workgroup per slot: fold the partials (fixed order), and -- only for a slot
@@ -98,7 +103,7 @@ __device__ __forceinline__ double dual_select_body(const SelectArgs &sa, const i
         stats[t * 8 + 3] = (double)nv;
         // stats may live in pinned host memory: a host that polls [5] for this evaluation's
         // sequence number sees [0..3] complete (system-scope release before the tag)
-        __threadfence_system();
+        if (!sa.lazy) __threadfence_system();
         reinterpret_cast<volatile double *>(stats)[t * 8 + 5] = seq;
     }
     int64_t *ci = cidx + (int64_t)t * kAmax;

@@ -93,6 +93,10 @@ class OperatorOptions:
     newton_max: int = 60         # Newton iterations per operator solve
     newton_kadd: int = 6         # violated rows admitted to a slot's model per iteration
     chain: bool = True           # binding steady state: one Newton iteration enqueued unread
+    # ... and folded (one GPU, feeder as a tree): the sweep forms the operator's answer for the trial
+    # itself and folds both evaluations' node sums into its own pass -- one pass over the residences
+    # and two launches per iteration instead of three passes and five (revs_plan_chain_fold_run)
+    chain_fold: bool = True
     newton_delta: float = 1e-10  # relative diagonal shift of the model Hessian
     newton_pivots: int = 300     # block-pivoting limit per model problem
     newton_ls: int = 30          # Armijo halvings
@@ -285,6 +289,8 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
         self._eval_seq = 0.0                           # tags of the other evaluations: 1, 2, ...
         self._pending_tag = [None, None]
         self.chain_hist = [0, 0]                       # chained Newton iterations kept / redone
+        self._y_spare = None                           # third multiplier array (folded chain)
+        self._fold_resume = False                      # the folded chain's pipeline is primed for the next iteration
         self._spec_ok = False
         self._spec_wait, self._spec_back = 0, 1
         self._sup = None
@@ -518,6 +524,7 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
         self._p_clear = None
         o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
         self._fused_ready = False
+        self._fold_resume = False
         if o.solver == "newton" and not admm_only:
             if self._operator_solve_newton():
                 return True
@@ -599,6 +606,7 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
         (lpsolver.py:269-284) in one kernel launch.  With `to_alt` P_sch[k+1] and G[k+1] go
         to the spare buffers (speculative launch, see step)."""
         self._fused_ready = False
+        self._fold_resume = False
         ps_out, g_out = (self.P_sch_alt, self.G_alt) if to_alt else (self.P_sch, self.G)
         check(self.lib.revs_agent_step_out(
             self.n, self.T, ptr(self.cost), ptr(self.homes), ptr(self.load), ptr(self.P_est),
@@ -639,6 +647,7 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
             return
         self._p_clear = None                 # (every other path rewrites the node-sum arrays)
         if o.solver == "newton" and o.speculate and self._spec_ok:
+            self._fold_resume = False
             # steady state: the multipliers of the last iteration are expected to stand
             scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
             if self._plan is not None:               # one native call: enqueue, wait, judge
@@ -726,6 +735,10 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
             # binding steady state: the last solve was one Newton iteration on the small model;
             # enqueue the same again, and the sweep behind it, before reading anything
             self._fused_ready = False
+            if not events and self._fold_ok():
+                self._chain_run(1, write_sc)         # (books the iteration itself)
+                return
+            self._fold_resume = False
             if self._plan is not None and self.group is None:
                 # one native call: the six launches, the wait and the verdict
                 acc, nsum, nmax = C.c_int32(), C.c_int32(), C.c_int32()
@@ -932,6 +945,7 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
         self._fused_p = None
         self._p_clear = None
         self._chain_ok = False
+        self._fold_resume = False
         if iteration is not None:
             self.iteration = int(iteration)
 

@@ -114,6 +114,7 @@ class DualNewtonMixin:
         o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
         A = _lib.DUAL_AMAX
         scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
+        self._fold_resume = False
         ycur, ytrial = self.yd
         cur = 0
         # (`_sup`: a candidate set that lists every row of the current multipliers, while there
@@ -188,7 +189,9 @@ class DualNewtonMixin:
                           "revs_op_dual_step")
                     stn = self._dual_evaluate(ytrial, True, nxt, sup=cur if few else None)
                 evals += 1
-                okk = stn[:, 1] >= D + 1e-4 * stn[:, 4] - 1e-13 * np.abs(D)
+                # (slack 1e-11 |D|: the evaluations sum the squares rounded to 2^-32 so that the sums do
+                # not depend on their order -- a rounding of ~1e-13 |D| per evaluation)
+                okk = stn[:, 1] >= D + 1e-4 * stn[:, 4] - 1e-11 * np.abs(D)
                 pending &= ~okk
                 if not pending.any():
                     break
@@ -328,12 +331,22 @@ class DualNewtonMixin:
         self.op_path_hist.append("dual")
         self.op_converged = True
 
-    def _chain_run(self, count):
-        """Up to `count` iterations of the binding steady state inside one native call
-        (revs_plan_chain_run); the first one that is not the usual outcome is finished here as
+    def _fold_ok(self):
+        """The folded chain applies (revs_plan_chain_fold_run): one GPU, the native plan, the feeder as
+        a tree the Newton evaluations use, few multipliers per slot (row-wise shifts), presolved PDHG."""
+        return (self._plan is not None and self.group is None and self._tree_newton and self._chain_few
+                and self.op.chain_fold and not self.pdhg.full_rows)
+
+    def _chain_run(self, count, write_sc=False):
+        """Up to `count` iterations of the binding steady state inside one native call -- the folded
+        chain (one pass over the residences and two launches per iteration) where it applies, else
+        revs_plan_chain_run; the first iteration that is not the usual outcome is finished here as
         step() would.  Returns the number of iterations done (at least one)."""
         self._fused_ready = False
         self._p_clear = None
+        if self._fold_ok():
+            return self._chain_fold_run(count, write_sc)
+        self._fold_resume = False
         ys = (self.yd[0], self.yd[1])
         bufs = (self.P_est, self.P_est_new, self.P_sch, self.P_sch_alt, self.G, self.G_alt)
         sup0 = self._sup if (self._y_support and self._sup is not None) else -1
@@ -363,6 +376,54 @@ class DualNewtonMixin:
             return n
         # the call stopped at an iteration for the general loop (its launches are made)
         self._chain_finish(False, 0, 0, False)
+        self.P_est, self.P_est_new = self.P_est_new, self.P_est
+        self.iteration += 1
+        return n + 1
+
+    def _chain_fold_run(self, count, write_sc=False):
+        if self._y_spare is None:
+            self._y_spare = torch.zeros_like(self.yd[0])
+        ys = (self.yd[0], self.yd[1], self._y_spare)
+        bufs = (self.P_est, self.P_est_new, self.P_sch, self.P_sch_alt, self.G, self.G_alt)
+        sup0 = self._sup if (self._y_support and self._sup is not None) else -1
+        st = _lib.ChainFoldState(ptr(ys[0]), ptr(ys[1]), ptr(ys[2]), int(self._y_support), sup0,
+                                 *[ptr(t) for t in bufs], ptr(self.S) if write_sc else None,
+                                 ptr(self.Csoc) if write_sc else None, int(self._fold_resume))
+        kept = C.c_int32()
+        check(self.lib.revs_plan_chain_fold_run(self._plan, count, C.byref(st), C.addressof(kept), self.stream),
+              "revs_plan_chain_fold_run")
+        n = kept.value
+        by = {t.data_ptr(): t for t in bufs}
+        self.P_est, self.P_est_new = by[st.p_est], by[st.p_est_new]
+        self.P_sch, self.P_sch_alt = by[st.p_sch], by[st.p_sch_alt]
+        self.G, self.G_alt = by[st.gamma], by[st.gamma_alt]
+        yb = {t.data_ptr(): t for t in ys}
+        self.yd = [yb[st.y], yb[st.y_trial]]
+        self._y_spare = yb[st.y_spare]
+        self._fold_resume = bool(st.resume)
+        if n:
+            self.model_calls[0] += n
+            self.newton_hist.extend([(1, 2, -1)] * n)      # (pivot counts not read)
+            self._pre_kept, self._chain_ok, self._spec_ok = True, True, False
+            self._y_support = bool(st.use_y)
+            self._sup = None         # (the lists of the accepted multipliers may sit in the plan's own sets)
+            self.op_iters_hist.extend([2] * n)
+            self.op_path_hist.extend(["dual"] * n)
+            self.op_converged = True
+            self.chain_hist[0] += n
+            self.iteration += n
+        if n == count:
+            return n
+        # the call stopped at an iteration that is the general loop's: a fresh solve from the current
+        # multipliers (the folded chain's stats and lists are its own), then the sweep on its answer
+        self._sup = None
+        ok = self._operator_solve_newton()
+        self.chain_hist[1] += 1
+        if not ok:
+            self._fast_cold = True
+            self.op_cold = True
+            self._require_converged(self.operator_solve(admm_only=True))
+        self.agent_step(write_sc and n == 0)
         self.P_est, self.P_est_new = self.P_est_new, self.P_est
         self.iteration += 1
         return n + 1

@@ -61,6 +61,7 @@ class SteadyStateMixin:
         i-th iteration done here (run(): solve_ADMM's per-iteration diff without a host round
         trip per iteration)."""
         o = self.op
+        self._fold_resume = False
         if self._block:
             return self._stream_run_blocks(count, hist)
         p0 = self._fused_p

@@ -496,7 +496,7 @@ class FakeKernels:
         if not r0.max() > eps or ncand.max() > 8 or (a[:, 2].max() + kadd <= 48) != bool(chain_few):
             return 0
         pend = r0 > eps
-        okk = b[:, 1] >= a[:, 1] + 1e-4 * b[:, 4] - 1e-13 * np.abs(a[:, 1])
+        okk = b[:, 1] >= a[:, 1] + 1e-4 * b[:, 4] - 1e-11 * np.abs(a[:, 1])
         if (pend & ~okk).any() or (b[:, 2] > amax).any() or not r1.max() <= eps:
             return 0
         C.c_int32.from_address(int(nsup_sum)).value = int(b[:, 2].sum())

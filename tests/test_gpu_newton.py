@@ -77,9 +77,11 @@ def test_dual_evaluate_and_model_match_numpy(gpu_lib, n, M, T, n_mult):
     torch.cuda.synchronize()
     g = {k: v.cpu().numpy() for k, v in gb.items()}
     # home pass: node sums, free counts (exact), dual value parts; P_est_new
-    np.testing.assert_allclose(g["pnq"][0], cb["pnq"][0], rtol=1e-12, atol=1e-12)
+    # (round 3: p and the squares are summed rounded to 2^-36 / 2^-32, so that the sums do not depend
+    # on their order: 1.5e-11 kW and 2.3e-10 kW^2 per residence and slot)
+    np.testing.assert_allclose(g["pnq"][0], cb["pnq"][0], rtol=1e-12, atol=2e-9)
     np.testing.assert_array_equal(g["pnq"][1], cb["pnq"][1])
-    np.testing.assert_allclose(g["pnq"][2], cb["pnq"][2], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(g["pnq"][2], cb["pnq"][2], rtol=1e-12, atol=1e-7)
     assert (g["pnq"][1][2] == 0).all() and (g["pnq"][0][2] == 0).all()      # the empty node
     np.testing.assert_allclose(g["pe_new"], cb["pe_new"], rtol=1e-6, atol=1e-7)
     assert (g["pe_new"] == 0).any() and (g["pe_new"] > 0).any()             # clamps are exercised
@@ -361,7 +363,7 @@ def test_sweep_with_selection_and_next_home_pass(gpu_lib, mode):
                                     ptr(pnq2), ptr(pe_ref), None))
     torch.cuda.synchronize()
     assert torch.equal(pe2, pe_ref) and (pe2 == 0).any() and (pe2 > 0).any()
-    np.testing.assert_allclose(p_next.cpu().numpy(), pnq2[0].cpu().numpy(), rtol=1e-13, atol=1e-12)
+    np.testing.assert_allclose(p_next.cpu().numpy(), pnq2[0].cpu().numpy(), rtol=1e-13, atol=2e-9)
 
 
 @pytest.mark.parametrize("n_mult,kadd", [(3, 4), (1, 6), (6, 6)])

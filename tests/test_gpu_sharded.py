@@ -72,14 +72,15 @@ def two_rank_runs(gpu_lib, tmp_path_factory):
 
 
 def _reference(case):
-    """The one-process run, every launch judging itself (no blocks, no communicator)."""
+    """The one-process run, every launch judging itself (no blocks, no communicator; the binding
+    steady state chained as the sharded engine chains it -- the folded chain is the one-GPU form)."""
     sys.path.insert(0, HERE)
     from sharded_worker import make_case, run_chunks
     from revs_admm_amd.engine import AdmmEngine, OperatorOptions
     w = make_case(case)
     e = AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, kappa=w.kappa, vset=w.vset, vlow=w.vlow,
                    vhigh=w.vhigh, mode=case["mode"], feeder=w.feeder,
-                   op=OperatorOptions(stream_block_single=False, **(case.get("burst") or {})))
+                   op=OperatorOptions(stream_block_single=False, chain_fold=False, **(case.get("burst") or {})))
     assert e._block == 0 and e._comm is None
     return w, run_chunks(e, case["chunks"], case["mode"])
 

@@ -16,7 +16,7 @@ for _ in range(30):
 e.run_steps(5)
 marks = {}
 lib = e.lib
-orig = lib.revs_plan_stream_run
+orig = lib.revs_plan_stream_run_blocks
 def native(*a):
     marks["n0"] = time.perf_counter()
     r = orig(*a)
@@ -24,7 +24,7 @@ def native(*a):
     return r
 class L:      # proxy so that only this entry point is wrapped
     def __getattr__(self, k):
-        return native if k == "revs_plan_stream_run" else getattr(lib, k)
+        return native if k == "revs_plan_stream_run_blocks" else getattr(lib, k)
 e.lib = L()
 res = []
 for rep in range(12):

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Round profiles on the GPU box (run through gpurun from the repo root): bench lines, rocprofv3 kernel
+# stats, PMC passes (FETCH / WRITE / SQ in separate runs, as MI355X_MICROARCH.md prescribes) and the
+# binding / binary regimes.  Writes under gpurun_out/prof_$TAG; copy the summaries into profiles/.
+TAG=${1:-r03}
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/prof_$TAG
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py > $O/bench_line.json 2> $O/bench_line.err
+python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_line_driver_steps20.json 2> $O/bench20.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o k -- python3 $R/bench.py --no-extras --no-cpu-baseline --no-converge > $O/kt.log 2>&1
+cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
+for pass in fetch:FETCH_SIZE write:WRITE_SIZE "sq:SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY" "sq2:SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
+  name=${pass%%:*}; ctr=${pass#*:}
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc/$name -o $name -- python3 $R/bench.py --steps 64 --no-extras --no-cpu-baseline --no-converge --clock-warm 0 > $O/pmc_$name.log 2>&1
+done
+for reg in binding binary; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/reg_$reg -o s -- python3 $R/tools/regime_run.py --regime $reg > $O/reg_$reg.log 2>&1
+  cp $(find $O/reg_$reg -name "*kernel_stats.csv" | head -1) $O/${reg}_kernel_stats.csv
+  rm -rf $O/reg_$reg
+done
+rm -rf $O/kt
+# keep only the counter csvs of the pmc passes (the traces are large)
+find $O/pmc -type f ! -name "*counter_collection.csv" -delete
+ls -la $O $O/pmc/*
