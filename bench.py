@@ -23,19 +23,24 @@ stream, beside the next 32 sweeps (verdicts by blocks).
 
 The timed steps start `--spinup` (30) iterations into the run: the first ~10 iterations are a
 transient in which voltage rows bind hard and residences are clamped (operator QP: a few
-Newton iterations on its dual, f64 products on the matrix cores); afterwards the estimate
-respects every row and an iteration is ONE launch -- the rows judged by the tree form of R p in
-the launch's first T workgroups, all residences in the others (`AdmmEngine.run_steps`,
-revs_plan_stream_run).  The transient's cost, the binding regime, binary residences and the
-125 000 x 96 shape of BASELINE config 4 are measured in the same run and reported as
-first-class fields beside the headline.
+Newton iterations on its dual); afterwards the estimate respects every row and the iterations
+stream (`AdmmEngine.run_steps`, revs_plan_stream_run_blocks): a sweep launch carries 8 ADMM
+iterations of every residence with the state in registers, the voltage rows of a block of 32
+iterations are judged by the tree form of R p in one launch (on a second stream for bursts longer
+than a block), a failed verdict is rolled back through the four rotating sets of state buffers,
+and the max diff of every iteration -- the convergence test -- is folded on the device into the
+records the host reads.  The transient's cost, the binding regime (folded chain), binary
+residences and the 125 000 x 96 shape of BASELINE config 4 are measured in the same run and
+reported as first-class fields beside the headline.
 
 Prints ONE JSON line (rank 0).  `value` = home-QP solves per second, whole job, inputs resident
 in HBM.  `roofline`: the sweep kernel against HBM -- algorithmic bytes per launch / average
-launch duration from two HIP events around the K timed launches on their stream;
-`roofline_matvec`: the f64 matrix-core product R p of the operator's Newton path;
-`cpu_baseline`: the oracle's vectorised home QP over all residences on this box's cores
-(one process per core) plus the operator's voltage product, same state, same run.
+launch duration from two HIP events around the timed region on its stream / sweep launches in it;
+`roofline_valu`: the same kernel against VALU issue (what bounds it since round 3);
+`roofline_binding`: the binding regime's launches; `roofline_matvec`: the f64 matrix-core product
+R p (feeders given only as a matrix); `cpu_baseline`: the oracle's vectorised home QP over all
+residences on this box's cores (one process per core) plus the operator's voltage product, same
+state, same run.
 """
 from __future__ import annotations
 
@@ -577,6 +582,57 @@ def main():
                 },
             },
         }
+        # VALU issue: the multi-iteration sweep is bound by instruction issue, not by HBM (its bytes per
+        # ADMM iteration are 1/8 of the one-iteration sweep's).  Instructions per launch from the committed
+        # SQ counter pass (profiles/agent_traffic.json, same workload), duration live (avg_launch_ms).
+        # Peak: one wave64 VALU instruction per 4 cycles per SIMD (16 lanes per SIMD and cycle: the
+        # 157.3 TFLOP/s fp32 vector peak counts packed FMAs) x 1024 SIMDs x 2.4 GHz; measured on this
+        # chip with tools/probes/valu_rate.hip: 1.56-1.76 ns per v_fma_f32 per SIMD at 4-8 wavefronts.
+        valu = None
+        try:
+            tj = json.load(open(tpath))
+            c = tj.get("sq_counters_per_launch", {})
+            if (tj.get("homes") == n_local and tj.get("T") == args.T and tj.get("mode") == args.mode
+                    and tj.get("iterations_per_launch") == inner and c.get("SQ_INSTS_VALU") and launch_ms):
+                peak = 1024 * 2.4e9 / 4
+                ach_v = c["SQ_INSTS_VALU"] / (launch_ms * 1e-3)
+                valu = {"kernel": "agent_step_kernel<MULTI>", "bound": "valu-issue", "achieved": ach_v / 1e9,
+                        "peak": peak / 1e9, "unit": "G wave64 VALU instructions/s", "frac": ach_v / peak,
+                        "valu_instructions_per_launch": c["SQ_INSTS_VALU"],
+                        "valu_instructions_per_wavefront_and_iteration": c["SQ_INSTS_VALU"] / max(c.get("SQ_WAVES", 1), 1) / inner,
+                        "salu_instructions_per_launch": c.get("SQ_INSTS_SALU"),
+                        "valu_busy_share_of_launch": (c["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (launch_ms * 1e-3 * 2.4e9)
+                                                      if c.get("SQ_ACTIVE_INST_VALU") else None),
+                        "source": tj.get("source")}
+        except Exception:
+            valu = None
+        out["roofline_valu"] = valu
+        # the binding regime's launches (rocprofv3 kernel stats committed under profiles/, same command as
+        # tools/regime_run.py): the folded chain's sweep against HBM, and the operator launch, which is a
+        # latency chain of 2 T workgroups, not a bandwidth or arithmetic kernel
+        rb = None
+        try:
+            import csv
+            rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r03_binding_kernel_stats.csv"))))
+            sw = next(r for r in rows if "agent_step_kernel" in r["Name"] and r["Name"].rstrip().endswith("true>(revs::AgentArgs)")
+                      and ", false, true>" in r["Name"])
+            kv = next(r for r in rows if "op_chain_kv_kernel" in r["Name"])
+            if (args.homes, args.T) == (100_000, 24) and "value_binding" in extras:
+                b7 = (4 * 4 * args.T + 32 + 4 + 3 * 4 * args.T + 12 + 8) * 100_000
+                t_sw, t_kv = float(sw["AverageNs"]) * 1e-9, float(kv["AverageNs"]) * 1e-9
+                rb = {"kernel": "agent_step_kernel<CHAIN> (residence sweep with the operator's answer for the trial "
+                                "formed inside and both evaluations' node sums folded in)",
+                      "bound": "hbm", "achieved": b7 / t_sw / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": b7 / t_sw / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": t_sw * 1e3, "bytes_per_launch": b7,
+                      "operator_launch": {"kernel": "op_chain_kv_kernel (2 T workgroups: trial verdict + next "
+                                                    "iteration's rows / selection / model / step / shifts)",
+                                          "avg_launch_ms": t_kv * 1e3, "bound": "latency (one workgroup per slot)"},
+                      "ms_per_step_live": extras["value_binding"]["ms_per_step"],
+                      "source": "profiles/r03_binding_kernel_stats.csv (rocprofv3 --kernel-trace --stats of "
+                                "tools/regime_run.py --regime binding); ms_per_step_live from this run"}
+        except Exception:
+            rb = None
+        out["roofline_binding"] = rb
         out.update(extras)
         out["cpu_baseline"] = cpu_baseline(w, state) if state is not None else None
         print(json.dumps(out), flush=True)

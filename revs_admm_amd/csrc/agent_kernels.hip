@@ -95,7 +95,7 @@ struct AgentArgs {
     double *dmax_out;
     // The folded chain (revs_plan_chain_fold_run, template argument CHAIN): the operator's multipliers
     // are NOT zero.  The sweep forms the operator's answer itself, pen = max(g0 - d[node], 0) with the
-    // shifts d = R^T y / kappa of the trial multipliers (sh_a, double[sh_m][T]: the evaluation
+    // shifts d = R^T y / kappa of the trial multipliers (sh_a, double[T][sh_m], slot-major: the evaluation
     // kernel's arithmetic, bit for bit -- the operator launch before this sweep computes them) and
     // writes it to pe_out; it accumulates that evaluation's node sums p | N | -(kappa/2) sum g^2 into
     // fold_a and, after the dual update, those of the evaluation of the SAME multipliers on the state
@@ -310,8 +310,8 @@ void agent_step_kernel(const AgentArgs a) {
             for (int i = tid; i < 2 * 3 * kNodeLoc * kSlots; i += kBlock) (&facc[0][0][0][0])[i] = 0.0;
             for (int i = tid; i < kNodeLoc * T; i += kBlock) {
                 const int l = i / T, t = i - l * T;
-                dsh[0][l][t] = base + l < a.sh_m ? a.sh_a[(int64_t)(base + l) * T + t] : 0.0;
-                dsh[1][l][t] = base + l < a.sh_m ? a.sh_b[(int64_t)(base + l) * T + t] : 0.0;
+                dsh[0][l][t] = base + l < a.sh_m ? a.sh_a[(int64_t)t * a.sh_m + base + l] : 0.0;
+                dsh[1][l][t] = base + l < a.sh_m ? a.sh_b[(int64_t)t * a.sh_m + base + l] : 0.0;
             }
         }
         __syncthreads();
@@ -335,7 +335,7 @@ void agent_step_kernel(const AgentArgs a) {
         const int loc = node - base;
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
-            dl[j] = valid[j] ? (loc < kNodeLoc ? dsh[0][loc][t0 + j] : a.sh_a[(int64_t)node * T + t0 + j]) : 0.0;
+            dl[j] = valid[j] ? (loc < kNodeLoc ? dsh[0][loc][t0 + j] : a.sh_a[(int64_t)(t0 + j) * a.sh_m + node]) : 0.0;
             const double g0 = (double)revs_g0f(pe[j], pso[j], gm[j], inv_kf);
             const bool fr = valid[j] && g0 > dl[j];
             const double g = fr ? g0 - dl[j] : 0.0;
@@ -694,7 +694,7 @@ void agent_step_kernel(const AgentArgs a) {
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
             const double g0 = (double)revs_g0f(pen[j], gn[j], gmn[j], inv_kf);
-            const double ds = valid[j] ? (loc < kNodeLoc ? dsh[1][loc][t0 + j] : a.sh_b[(int64_t)node * T + t0 + j]) : 0.0;
+            const double ds = valid[j] ? (loc < kNodeLoc ? dsh[1][loc][t0 + j] : a.sh_b[(int64_t)(t0 + j) * a.sh_m + node]) : 0.0;
             const bool fr = valid[j] && g0 > ds;
             const double g = fr ? g0 - ds : 0.0;
             if (fr) {

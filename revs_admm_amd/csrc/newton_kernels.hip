@@ -166,8 +166,14 @@ struct TreeRowsArgs {
     double vlo, vhi;
     double *vfull, *viol, *partial, *zero_out;
 };
-__device__ __forceinline__ void tree_rows_body(const TreeRowsArgs &a, const int t, double *lds) {
+// rows_lds != NULL (double[3 m + 4] of LDS): the slot's multipliers, voltages and violations by row and
+// the four sums are left THERE for a selection that follows in the same workgroup
+// (SelectArgs::rows_lds) instead of in the global columns vfull / viol.
+__device__ __forceinline__ void tree_rows_body(const TreeRowsArgs &a, const int t, double *lds,
+                                               double *rows_lds = nullptr) {
     const int tid = threadIdx.x, j0 = 8 * tid, T = a.T;
+    if (rows_lds)      // (rows without a position in the tree: zero; the scans' barriers order this)
+        for (int i = tid; i < 3 * a.m; i += 256) rows_lds[i] = 0.0;
     const bool act = j0 < a.tree.n;
     // the multipliers and dual terms of this thread's rows: requested before the scans
     double yv[8], qv[8];
@@ -206,8 +212,14 @@ __device__ __forceinline__ void tree_rows_body(const TreeRowsArgs &a, const int 
             dsum += qv[i] - fmax(a.vhi * y1, a.vlo * y1);
             nsup += y1 != 0.0 ? 1.0 : 0.0;
             nvio += (y1 == 0.0 && vi > 0.0) ? 1.0 : 0.0;
-            a.vfull[o] = v;
-            a.viol[o] = y1 != 0.0 ? 0.0 : vi;
+            if (rows_lds) {
+                rows_lds[s] = y1;
+                rows_lds[a.m + s] = v;
+                rows_lds[2 * a.m + s] = y1 != 0.0 ? 0.0 : vi;
+            } else {
+                a.vfull[o] = v;
+                a.viol[o] = y1 != 0.0 ? 0.0 : vi;
+            }
         }
     }
     rmax = wave_max_d(rmax); dsum = wave_sum_d(dsum); nsup = wave_sum_d(nsup); nvio = wave_sum_d(nvio);
@@ -220,6 +232,7 @@ __device__ __forceinline__ void tree_rows_body(const TreeRowsArgs &a, const int 
         o[1] = ((rr[1][0] + rr[1][1]) + rr[1][2]) + rr[1][3];
         o[2] = ((rr[2][0] + rr[2][1]) + rr[2][2]) + rr[2][3];
         o[3] = ((rr[3][0] + rr[3][1]) + rr[3][2]) + rr[3][3];
+        if (rows_lds) { rows_lds[3 * a.m] = o[0]; rows_lds[3 * a.m + 1] = o[1]; rows_lds[3 * a.m + 2] = o[2]; rows_lds[3 * a.m + 3] = o[3]; }
     }
 }
 
@@ -774,7 +787,8 @@ __global__ __launch_bounds__(256) void op_tree_select_model_step_kernel(const Tr
 // small model and step of iteration k + 1 on the sums of the SAME multipliers on the new state --
 // speculative only in that the host may reject iteration k, in which case nobody reads them.  All
 // workgroups clear their share of the two sum arrays the NEXT sweep accumulates into.
-// d[node][t] = (R^T y)[node][t] / kappa from the rows of slot t's candidate list, in the list's order
+// d[t][node] (slot-major: a slot's workgroup writes its column contiguously) = (R^T y)[node][t] / kappa
+// from the rows of slot t's candidate list, in the list's order
 // -- op_dual_eval_kernel's SparseD loop, term for term -- and with the rows that carry a multiplier
 // taken in ascending row order: the order of the list the NEXT evaluation's home pass would read (a
 // selection lists the rows with y != 0 first, by row).  (Lists of more than 8 rows never pass the
@@ -849,8 +863,8 @@ __device__ __forceinline__ void chain_shifts_body(const int t, int m, int T, con
                         if (!same) ds = __builtin_fma(R[fs[k] * m + node], ys[k], ds);
                     }
                 if (same) ds = d;
-                sh_a[(int64_t)node * T + t] = d * inv_kappa;
-                sh_b[(int64_t)node * T + t] = ds * inv_kappa;
+                sh_a[(int64_t)t * m + node] = d * inv_kappa;
+                sh_b[(int64_t)t * m + node] = ds * inv_kappa;
             }
         }
         return;
@@ -870,8 +884,8 @@ __device__ __forceinline__ void chain_shifts_body(const int t, int m, int T, con
 #pragma unroll
             for (int k = 0; k < 8; ++k) d = __builtin_fma(rv[k], yv[k], d);
         }
-        sh_a[(int64_t)node * T + t] = d * inv_kappa;
-        sh_b[(int64_t)node * T + t] = d * inv_kappa;
+        sh_a[(int64_t)t * m + node] = d * inv_kappa;
+        sh_b[(int64_t)t * m + node] = d * inv_kappa;
     }
 }
 
@@ -897,10 +911,14 @@ __global__ __launch_bounds__(256) void op_chain_kv_kernel(const ChainKvArgs k) {
             if (k.clr1) k.clr1[i] = 0.0;
         }
     }
+    // (the rows of a slot go to its selection through LDS: double[3 m + 4] behind the tree's scan buffer)
+    double *rows_lds = tree_lds + (tree_lds_bytes(k.e1.tree.n) / sizeof(double) + 1) / 2 * 2;
     if (k.has_e2 && (int)blockIdx.x < T) {
-        tree_rows_body(k.e2, blockIdx.x, tree_lds);
+        tree_rows_body(k.e2, blockIdx.x, tree_lds, rows_lds);
         __syncthreads();
-        dual_select_body<true>(k.s2, blockIdx.x);
+        SelectArgs s2 = k.s2;
+        s2.rows_lds = rows_lds;
+        dual_select_body<true>(s2, blockIdx.x);
         return;
     }
     const int t = (int)blockIdx.x - (k.has_e2 ? T : 0);
@@ -910,10 +928,12 @@ __global__ __launch_bounds__(256) void op_chain_kv_kernel(const ChainKvArgs k) {
 #define KV_STAMP(i) do { } while (0)
 #endif
     KV_STAMP(0);
-    tree_rows_body(k.e1, t, tree_lds);
+    tree_rows_body(k.e1, t, tree_lds, rows_lds);
     __syncthreads();
     KV_STAMP(1);
-    const double rmax = dual_select_body<true>(k.s1, t);
+    SelectArgs s1 = k.s1;
+    s1.rows_lds = rows_lds;
+    const double rmax = dual_select_body<true>(s1, t);
     __syncthreads();
     KV_STAMP(2);
     small_model_body(t, k.s1.m, k.s1.T, k.f1.R, k.f1.Nn, k.s1.cidx, k.s1.ccnt, k.s1.cval, k.f1.inv_kappa, k.f1.delta,
@@ -956,8 +976,16 @@ int chain_kv_launch(const ChainKv &c, void *stream) {
                      c.y_trial, c.lin_out, c.info};
     k.clr0 = c.clr0; k.clr1 = c.clr1; k.clr_count = 3 * mt;
     k.sh_a = c.sh_a; k.sh_b = c.sh_b;
-    hipLaunchKernelGGL(op_chain_kv_kernel, dim3((c.has_e2 ? 2 : 1) * c.T), dim3(256), tree_lds_bytes(c.tree.n),
-                       (hipStream_t)stream, k);
+    const size_t lds = ((tree_lds_bytes(c.tree.n) / sizeof(double) + 1) / 2 * 2 + 3 * (size_t)c.m + 4) * sizeof(double);
+    if (lds > 64 * 1024) {       // (more than 64 KB of dynamic LDS has to be granted, once)
+        static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&op_chain_kv_kernel),
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+        if (e != hipSuccess) {
+            revs::set_error("chain_kv_launch: %zu bytes of LDS refused: %s", lds, hipGetErrorString(e));
+            return REVS_ELAUNCH;
+        }
+    }
+    hipLaunchKernelGGL(op_chain_kv_kernel, dim3((c.has_e2 ? 2 : 1) * c.T), dim3(256), lds, (hipStream_t)stream, k);
     REVS_CHECK_LAUNCH("chain_kv_launch");
     return REVS_OK;
 }

@@ -33,6 +33,11 @@ struct SelectArgs {
     // system-scope fence in front of the tag, which otherwise holds thread 0 (and at the next
     // barrier the whole workgroup) for a round trip to host memory
     bool lazy = false;
+    // rows_lds != NULL: the rows' multipliers, voltages and violations of THIS slot staged in LDS by
+    // the workgroup's own row kernel (double[3][m], by row: y | v | violation) and its four sums in
+    // rows_lds[3 m ..]: read instead of the global columns (a column of a [m][T] array is m cache
+    // lines: each column read or write costs a latency-bound workgroup ~2 us)
+    const double *rows_lds = nullptr;
 };
 
 // Stage 2, one workgroup per slot: fold the partials (fixed order), and -- only for a slot
@@ -51,6 +56,10 @@ __device__ __forceinline__ double dual_select_body(const SelectArgs &sa, const i
     const double *__restrict__ partial = sa.partial, *__restrict__ y = sa.y;
     const double *__restrict__ vfull = sa.vfull, *__restrict__ viol = sa.viol;
     const double vlo = sa.vlo, vhi = sa.vhi, seq = sa.seq;
+    const double *const rl = sa.rows_lds;
+    auto y_at = [&](int r) { return rl ? rl[r] : y[(int64_t)r * T + t]; };
+    auto v_at = [&](int r) { return rl ? rl[m + r] : vfull[(int64_t)r * T + t]; };
+    auto viol_at = [&](int r) { return rl ? rl[2 * m + r] : viol[(int64_t)r * T + t]; };
     int64_t *__restrict__ cidx = sa.cidx;
     int32_t *__restrict__ ccnt = sa.ccnt;
     double *__restrict__ cval = sa.cval, *__restrict__ stats = sa.stats;
@@ -71,20 +80,20 @@ __device__ __forceinline__ double dual_select_body(const SelectArgs &sa, const i
     {
         double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
         for (int k = tid; k < nblk; k += 256) {
-            const double *o = partial + ((int64_t)k * T + t) * 4;
+            const double *o = rl ? rl + 3 * m : partial + ((int64_t)k * T + t) * 4;
             a = fmax(a, o[0]); b += o[1]; c += o[2]; d += o[3];
         }
         if (eager) {
 #pragma unroll
             for (int j = 0; j < kPer; ++j) {
                 const int r = r0 + j;
-                ysv[j] = r < r1 ? y[(int64_t)r * T + t] : 0.0;
-                vsv[j] = r < r1 ? vfull[(int64_t)r * T + t] : 0.0;
+                ysv[j] = r < r1 ? y_at(r) : 0.0;
+                vsv[j] = r < r1 ? v_at(r) : 0.0;
             }
 #pragma unroll
             for (int i = 0; i < kLoc; ++i) {
                 const int r = tid + 256 * i;
-                loc[i] = r < m ? viol[(int64_t)r * T + t] : 0.0;
+                loc[i] = r < m ? viol_at(r) : 0.0;
             }
         }
         a = wave_max_d(a); b = wave_sum_d(b); c = wave_sum_d(c); d = wave_sum_d(d);
@@ -118,7 +127,7 @@ __device__ __forceinline__ double dual_select_body(const SelectArgs &sa, const i
 #pragma unroll
         for (int j = 0; j < kPer; ++j) nsup += ysv[j] != 0.0 ? 1 : 0;
     } else {
-        for (int r = r0; r < r1; ++r) nsup += y[(int64_t)r * T + t] != 0.0 ? 1 : 0;
+        for (int r = r0; r < r1; ++r) nsup += y_at(r) != 0.0 ? 1 : 0;
     }
     // exclusive prefix over the workgroup: scan inside the wavefront, then the wavefronts' totals
     int incl = nsup;
@@ -145,12 +154,11 @@ __device__ __forceinline__ double dual_select_body(const SelectArgs &sa, const i
         }
     } else {
         for (int r = r0; r < r1 && nsup > 0; ++r) {
-            const int64_t i = (int64_t)r * T + t;
-            const double yv = y[i];
+            const double yv = y_at(r);
             if (yv != 0.0) {
                 ci[pos] = r;
                 cs[pos] = yv > 0.0 ? 1.0 : -1.0;
-                cg[pos] = vfull[i] - (yv > 0.0 ? vhi : vlo);
+                cg[pos] = v_at(r) - (yv > 0.0 ? vhi : vlo);
                 cy[pos] = yv;
                 ++pos;
             }
@@ -182,7 +190,7 @@ __device__ __forceinline__ double dual_select_body(const SelectArgs &sa, const i
                 if (loc[i] > bv) { bv = loc[i]; bi = tid + 256 * i; }   // ascending r: ties keep the lower row
         } else {
             for (int r = tid, i = 0; r < m; r += 256, ++i) {
-                const double x = viol[(int64_t)r * T + t];
+                const double x = viol_at(r);
                 if (x > bv && !((took >> i) & 1ull)) { bv = x; bi = r; }
             }
         }
@@ -218,7 +226,7 @@ __device__ __forceinline__ double dual_select_body(const SelectArgs &sa, const i
     __syncthreads();
     if (tid < added) {
         const int bi = chosen[tid];
-        const double v = vfull[(int64_t)bi * T + t];
+        const double v = v_at(bi);
         const bool up = v > vhi;
         ci[ns + tid] = bi;
         cs[ns + tid] = up ? 1.0 : -1.0;
