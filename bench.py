@@ -387,10 +387,13 @@ def main():
     # launch before every sweep, verdict read by the host): what the tree form replaces
     dense = None
     if eng._tree is not None and eng._plan is not None and world == 1:
-        tree, eng._tree = eng._tree, None
+        import ctypes as C
+        tree, eng._tree = eng._tree, None                    # (the engine and its native plan both drop the tree)
+        eng.lib.revs_plan_set_tree(eng._plan, None)
         eng.run_steps(args.warmup)
         d_dt, _ = timed_steps(eng, args.steps)
         eng._tree = tree
+        eng.lib.revs_plan_set_tree(eng._plan, C.byref(tree))
         dense = {"ms_per_step": d_dt / args.steps * 1e3, "value": n_total * args.steps / d_dt}
 
     # the f64 matrix-core product of the operator's Newton path: R p (M x M x T)

@@ -34,7 +34,8 @@ for name in ("fetch", "write", "sq", "sq2"):
     df["kernel"] = df.Kernel_Name.str.replace(r"\(.*", "", regex=True).str.replace("void ", "")
     df["stream_launch"] = df.Kernel_Name.str.contains("agent_step") & (df.Grid_Size == grid)
     if multi:
-        df["stream_launch"] &= df.Kernel_Name.str.contains(r"(?:true|1)>\(", regex=True)
+        # template arguments <LPA, SPL, MODE, FULL_ROWS, MULTI, CHAIN>: MULTI = true, CHAIN = false
+        df["stream_launch"] &= df.Kernel_Name.str.contains(", true, false>(", regex=False)
     df["dur_us"] = (df.End_Timestamp - df.Start_Timestamp) / 1e3
     g = df.groupby(["kernel", "stream_launch", "Counter_Name"]).agg(
         calls=("Counter_Value", "size"), mean=("Counter_Value", "mean"),

@@ -25,7 +25,7 @@ class DualNewtonMixin:
         if (phase & 2) and not (phase & 4):
             self._eval_seq += 1.0
             tag = self._pending_tag[k] = self._eval_seq + 0.5
-        if self._tree_newton:
+        if self._tree_newton and self._tree is not None:
             # the feeder as a tree: R p and the rows of every slot in O(nodes), one workgroup per slot
             check(lib.revs_op_dual_evaluate_tree(
                 phase, M, T, ptr(self.node_ptr), ptr(self.P_est), ptr(self.P_sch), ptr(self.G),
@@ -243,7 +243,7 @@ class DualNewtonMixin:
         # sequence tag the last selection writes)
         nb = (M + 31) // 32
         nb = nb if (T <= 32 and nb <= 256) else 0
-        tf = self._tree_newton                                     # rows by the tree form of R p
+        tf = self._tree_newton and self._tree is not None          # rows by the tree form of R p
         if tf:
             nb = 1
         use_y = self._y_support
@@ -334,7 +334,8 @@ class DualNewtonMixin:
     def _fold_ok(self):
         """The folded chain applies (revs_plan_chain_fold_run): one GPU, the native plan, the feeder as
         a tree the Newton evaluations use, few multipliers per slot (row-wise shifts), presolved PDHG."""
-        return (self._plan is not None and self.group is None and self._tree_newton and self._chain_few
+        return (self._plan is not None and self.group is None and self._tree_newton and self._tree is not None
+                and self._chain_few
                 and self.op.chain_fold and not self.pdhg.full_rows)
 
     def _chain_run(self, count, write_sc=False):
