@@ -560,6 +560,11 @@ def main():
                 # 6 flop per byte of R at T = 24: the product streams the matrix
                 "matrix_stream_GBs": 8.0 * eng.M * eng.M / (gemm_ms * 1e-3) / 1e9,
                 "matrix_stream_frac_of_hbm_peak": 8.0 * eng.M * eng.M / (gemm_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "on_path": "since round 3 only for feeders given as a matrix, and in the Newton evaluations of "
+                           "feeders beyond the tree form's 2048 nodes: the steady state, the Newton evaluations and "
+                           "the binding chain judge their rows by the tree form of R p",
+                "mfma_counters": "profiles/r03_pmc_mfma.csv (131 072 v_mfma_f64_16x16x4 per launch, matrix pipes "
+                                 "busy 8 192 of ~32 000 cycles per SIMD: 25 %; x 24/32 useful tile columns)",
             },
             "value_dense_product_path": dense,
             "breakdown": {

@@ -1216,6 +1216,12 @@ extern "C" int revs_plan_stream_run_blocks(revs_plan_t *plan, int32_t max_steps,
         if (ov) (void)hipStreamSynchronize(plan->side);
         (void)hipStreamSynchronize(s);
         plan->ring_dirty = true;
+        // The sticky status word has collected bits from sweeps that are now undone (they ran on an
+        // estimate that was not the operator's answer): "a PDHG residence stopped at its cap" is a
+        // statement about such a sweep's problem, not about the trajectory -- dropped here and set
+        // again by the replay below for the sweeps that stand.  ("No solution" does not depend on
+        // the estimate: kept.)
+        if (plan->flags_host) *(volatile unsigned int *)plan->flags_host &= ~2u;
     }
     int kept = rc != REVS_OK ? 0 : (failed_at >= 0 ? failed_at : launched);
     int fin = cur;                                       // the set that holds the state at return
