@@ -238,6 +238,8 @@ def main():
                     help="operator: violated rows admitted to a slot's model per Newton iteration")
     ap.add_argument("--stream-block", type=int, default=None,
                     help="sharded steady state: iterations per all-reduce / verdict launch (default 32)")
+    ap.add_argument("--stream-inner", type=int, default=None,
+                    help="steady state: ADMM iterations per sweep launch (default: OperatorOptions.stream_inner)")
     ap.add_argument("--no-stream-overlap", action="store_true",
                     help="sharded steady state: collective and verdicts on the compute stream")
     ap.add_argument("--no-converge", action="store_true",
@@ -307,6 +309,8 @@ def main():
             opts.newton_kadd = args.op_kadd
         if args.stream_block is not None:
             opts.stream_block = args.stream_block
+        if args.stream_inner is not None:
+            opts.stream_inner = args.stream_inner
         opts.stream_overlap = not args.no_stream_overlap
         eng = AdmmEngine(w.cost, w.homes[lo:hi], w.load[lo:hi], w.node_of[lo:hi], w.Rn, kappa=w.kappa,
                          vset=w.vset, vlow=w.vlow, vhigh=w.vhigh, mode=mode, device=dev, group=group,

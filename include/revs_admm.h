@@ -32,8 +32,10 @@ extern "C" {
 /* Largest T the agent kernels are instantiated for. */
 #define REVS_MAX_T 192
 /* consecutive ADMM iterations one launch of the residence sweep can carry in registers
- * (streaming steady state, multipliers zero; revs_plan_set_stream_inner) */
-#define REVS_AGENT_MAX_INNER 8
+ * (streaming steady state, multipliers zero; revs_plan_set_stream_inner); a launch's LDS holds one
+ * set of node-sum accumulators per iteration, so the library uses at most
+ * revs_agent_max_inner(T) <= REVS_AGENT_MAX_INNER of them: 16 up to T = 32, 8 up to 96, 4 beyond */
+#define REVS_AGENT_MAX_INNER 16
 /* the sweep leaves the largest diff of an iteration (the convergence measure, lpsolver.py:284) as
  * REVS_DMAX_SLOTS partial maxima, workgroup b into slot b % REVS_DMAX_SLOTS */
 #define REVS_DMAX_SLOTS 64
@@ -588,6 +590,7 @@ int revs_newton_chain_accept(int32_t T, const double *s0, const double *s1, doub
  *   dmax_out                   NULL, or (same stride) REVS_DMAX_SLOTS doubles per iteration: atomic max
  *                              (on the bit pattern of a non-negative double) of the residences' diff
  *                              of iteration g + i; the maximum over the slots is max_h diff[h] */
+int32_t revs_agent_max_inner(int32_t T);
 int revs_agent_step_multi(int64_t n_homes, int32_t T, const float *cost, const revs_home_t *homes,
                           const float *load, const float *p_est, const float *p_sch, const float *gamma,
                           float *p_est_out, float *p_sch_out, float *gamma_out, float *p_est_next,

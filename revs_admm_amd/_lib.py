@@ -99,7 +99,7 @@ HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_
 TREE_MAX = 16384         # REVS_TREE_MAX
 TREE_SWEEP_MAX = 2048    # REVS_TREE_SWEEP_MAX
 STREAM_BLOCK_MAX = 256   # REVS_STREAM_BLOCK_MAX
-AGENT_MAX_INNER = 8      # REVS_AGENT_MAX_INNER
+AGENT_MAX_INNER = 16     # REVS_AGENT_MAX_INNER
 
 
 class RevsError(RuntimeError):
@@ -134,6 +134,7 @@ SIGNATURES = {
                                          _p, _p, _p, _f32, _i32, C.POINTER(PDHG), _i32, _p, _p,
                                          _f64, _f64, _i32, _p, _p, _p, _p, _p, _p, _f64, _p, _p, _p,
                                          _i32, _p]),
+    "revs_agent_max_inner": (_i32, [_i32]),
     "revs_agent_step_multi": (C.c_int, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p,
                                         _p, _p, _f32, _i32, C.POINTER(PDHG), _p, _p, _i64, _p, _i32, _p]),
     "revs_op_dual_product_rows": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _f64, _f64, _i32, _p, _p, _p,

@@ -108,6 +108,9 @@ struct AgentArgs {
     double *fold_a, *fold_b;
 };
 constexpr int kMaxInner = REVS_AGENT_MAX_INNER;
+constexpr int shape_max_inner(int slots) {      // inner iterations whose node-sum accumulators fit 24 KB of LDS
+    return 24576 / (4 * slots * 8) >= kMaxInner ? kMaxInner : (24576 / (4 * slots * 8) >= 8 ? 8 : (24576 / (4 * slots * 8) >= 4 ? 4 : (24576 / (4 * slots * 8) >= 2 ? 2 : 1)));
+}
 #ifndef REVS_AGENT_MULTI_WAVES
 #define REVS_AGENT_MULTI_WAVES 5     // wavefronts per SIMD of the multi-iteration sweep (tuning: build with -D)
 #endif
@@ -252,7 +255,8 @@ void agent_step_kernel(const AgentArgs a) {
     // 74 at 125 000 x 96, where a wavefront holds 4 residences and the memory-side f64 atomics
     // quadruple.)
     constexpr int kNodeLoc = 4, kSlots = LPA * SPL;
-    constexpr int kAcc = MULTI ? kMaxInner : 1;
+    // (at most 24 KB of accumulators per workgroup: 16 iterations up to 32 slots per group, 8 up to 96, 4 beyond)
+    constexpr int kAcc = MULTI ? shape_max_inner(kSlots) : 1;
     __shared__ double nacc[kAcc][kNodeLoc][kSlots];
     __shared__ unsigned int dmx[kAcc];
     const int64_t first = (int64_t)bid * kHomesPerBlock;
@@ -1099,8 +1103,8 @@ static int agent_step_impl(int64_t n_homes, int32_t T, const float *cost,
     if (sx && !sx->verdict) {         // judged by blocks (stream_block_verdict): silencing only
         REVS_REQUIRE(!sel, "revs_agent_step: bad streaming argument");      // (ctl == NULL: never silenced)
         a.ctl = sx->ctl; a.seq = sx->seq; a.base_seq = sx->base_seq; a.flags = sx->flags;
-        REVS_REQUIRE(sx->kin >= 1 && sx->kin <= REVS_AGENT_MAX_INNER && sx->slice_stride >= 0 && sx->diff_stride >= 0,
-                     "revs_agent_step: kin=%d outside 1..%d", sx->kin, REVS_AGENT_MAX_INNER);
+        REVS_REQUIRE(sx->kin >= 1 && sx->kin <= revs_agent_max_inner(T) && sx->slice_stride >= 0 && sx->diff_stride >= 0,
+                     "revs_agent_step: kin=%d outside 1..%d (T = %d)", sx->kin, revs_agent_max_inner(T), T);
         REVS_REQUIRE(sx->kin == 1 || (!p_est_new && p_next && sx->pe_out && !s_out && !c_out &&
                                       sx->slice_stride >= (int64_t)0),
                      "revs_agent_step: several iterations per launch need the recomputed estimate, node sums "
@@ -1356,6 +1360,12 @@ extern "C" int revs_agent_step_out(int64_t n_homes, int32_t T, const float *cost
                            kappa, mode, pdhg_host, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
+extern "C" int32_t revs_agent_max_inner(int32_t T) {
+    if (T <= 0 || T > REVS_MAX_T) return 0;
+    const Shape sh = pick_shape(T);
+    return shape_max_inner(sh.lpa * sh.spl);
+}
+
 extern "C" int revs_agent_step_multi(int64_t n_homes, int32_t T, const float *cost, const revs_home_t *homes,
                                      const float *load, const float *p_est, const float *p_sch,
                                      const float *gamma, float *p_est_out, float *p_sch_out,
@@ -1364,8 +1374,8 @@ extern "C" int revs_agent_step_multi(int64_t n_homes, int32_t T, const float *co
                                      float kappa, int32_t mode, const revs_pdhg_t *pdhg_host,
                                      const int32_t *node_of, double *p_next, int64_t slice_stride,
                                      double *dmax_out, int32_t kin, void *stream) {
-    REVS_REQUIRE(p_est_out && node_of && p_next && kin >= 1 && kin <= REVS_AGENT_MAX_INNER,
-                 "revs_agent_step_multi: bad argument (kin = %d, at most %d)", kin, REVS_AGENT_MAX_INNER);
+    REVS_REQUIRE(p_est_out && node_of && p_next && kin >= 1 && kin <= revs_agent_max_inner(T),
+                 "revs_agent_step_multi: bad argument (kin = %d, at most %d at T = %d)", kin, revs_agent_max_inner(T), T);
     REVS_REQUIRE(p_est_out != p_est && p_sch_out != p_sch && gamma_out != gamma,
                  "revs_agent_step_multi: the state is not updated in place");
     StreamExtra sx{};

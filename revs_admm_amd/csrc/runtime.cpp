@@ -45,7 +45,7 @@ struct revs_plan {
     double t_launch = 0.0, t_wait = 0.0;   // host time in launches / waiting (REVS_PLAN_TRACE)
     // streaming steady state (revs_plan_stream_run)
     revs::StreamCtl *ctl = nullptr;        // device
-    double *rec_host = nullptr;            // pinned: double[kRecRing][4] = {rmax, failed, seq, -}
+    double *rec_host = nullptr;            // pinned: double[kRecRing][4] = {rmax, failed, seq, max diff of the iteration before}
     double *rec_dev = nullptr;             // its device-side address
     unsigned int *flags_host = nullptr;    // pinned: OR of the residences' status bits
     unsigned int *flags_dev = nullptr;
@@ -1055,7 +1055,7 @@ extern "C" int revs_plan_stream_run_blocks(revs_plan_t *plan, int32_t max_steps,
     const unsigned int seq0 = plan->stream_seq + 1;
     const int64_t mt = (int64_t)d.m * d.T, nt = d.n_homes * (int64_t)d.T;
     (void)nt;
-    const int B = plan->block, K = plan->inner;
+    const int B = plan->block, K = std::min(plan->inner, revs_agent_max_inner(d.T));
     const int nranks = plan->comm ? plan->comm->nranks : 1, rank = plan->comm ? plan->comm->rank : 0;
     const int ntail = REVS_DMAX_SLOTS * nranks;
     const int64_t stride = mt + ntail;                   // doubles per ring slice: node sums, then every rank's partial maxima

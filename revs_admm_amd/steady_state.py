@@ -1,6 +1,8 @@
 """The steady state of lpsolver.solve_ADMM's loop (reference lpsolver.py:254-287) while the
-operator's multipliers are zero: one launch per iteration, verdicts on the device, bursts enqueued
-by the native loop revs_plan_stream_run; and what follows a failed verdict.
+operator's multipliers are zero: bursts enqueued by the native loops -- revs_plan_stream_run_blocks
+(the default since round 3: eight iterations per launch, verdicts by blocks, four rotating sets of
+state buffers) or revs_plan_stream_run (every launch judges itself, section
+3.5) -- verdicts and the convergence record on the device; and what follows a failed verdict.
 Methods of AdmmEngine (mixed in by engine.py)."""
 from __future__ import annotations
 

@@ -5,7 +5,7 @@
 Both ranks use cuda:0 (RCCL refuses two ranks on one device, so the node sums travel through the
 library's hook communicator -- revs_comm_create_hook -- over a gloo group); each owns a
 node-aligned half of the residences and runs the REAL kernels and the REAL native loops
-(revs_plan_stream_run / stream_run_blocks).  After every chunk of run_steps the rank stores its
+(revs_plan_stream_run / revs_plan_stream_run_blocks).  After every chunk of run_steps the rank stores its
 shard's state, in the caller's home order, for the parent to compare with the one-process run.
 Hooks: "gloo" = the real all-reduce; "noop" = nothing is exchanged; "first_slice" = the all-reduce
 is done, but only the first M x T slice of a multi-slice buffer keeps its sums (the others are left

@@ -714,11 +714,13 @@ _RAGGED = (1, 7, 30, 2, 50, 64, 11)
     ("pdhg", 8000, 200, 3, 1.02, 24, 5, _RAGGED),                   # a failed verdict at the head of a call
     ("binary", 8000, 200, 3, 0.5, 24, 7, _RAGGED),
     ("pdhg", 3000, 200, 3, 1.02, 96, 4, _RAGGED)])
-@pytest.mark.parametrize("overlap,inner", [(False, 4), (True, 4), (True, 1), (False, 3), (True, 8)])
+@pytest.mark.parametrize("overlap,inner", [(False, 4), (True, 16), (True, 1), (False, 3), (True, 8)])
 def test_block_verdicts_equal_per_launch_verdicts(gpu_lib, mode, n, nodes, seed, stress, T, block, chunks, overlap, inner):
-    """The sharded form of the streaming loop -- `block` sweeps run unjudged, their node sums go to
-    a ring, one launch judges the whole block, and a failed iteration inside a block is undone
-    from the state the block saved (revs_plan_set_stream_block) -- against the loop where every
+    """The block form of the streaming loop (the default, sharded or not) -- `block` iterations run
+    unjudged, their node sums go to a ring, one launch judges the whole block, `inner` consecutive
+    iterations are ONE launch that keeps the residences' state in registers, and a failed iteration
+    inside a block is undone from the set of buffers the block started from
+    (revs_plan_stream_run_blocks) -- against the loop where every
     launch judges itself: same kept / discarded iterations, same memory bit for bit (profiles,
     carried PDHG multipliers, node sums handed to the next call), through failures at the head
     of a call and deep inside a burst (sweeps behind the failed one had run and are undone).

@@ -1,6 +1,6 @@
 """The sharded native loop with REAL partial sums (lpsolver.py:254-287: the loop whose iterates all
 ranks must share).  Two processes, both on cuda:0, each with a node-aligned half of the residences,
-run the real kernels and the real revs_plan_stream_run / stream_run_blocks; the node sums travel
+run the real kernels and the real revs_plan_stream_run / revs_plan_stream_run_blocks; the node sums travel
 through the library's hook communicator (revs_comm_create_hook) over gloo.  State after every chunk
 must equal the one-process run bit for bit -- and must NOT when the collective is dropped or
 applied to the wrong extent (negative controls)."""
