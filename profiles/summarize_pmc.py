@@ -37,6 +37,10 @@ for name in ("fetch", "write", "sq", "sq2"):
         # template arguments <LPA, SPL, MODE, FULL_ROWS, MULTI, CHAIN>: MULTI = true, CHAIN = false
         df["stream_launch"] &= df.Kernel_Name.str.contains(", true, false>(", regex=False)
     df["dur_us"] = (df.End_Timestamp - df.Start_Timestamp) / 1e3
+    if multi and df.stream_launch.any():
+        # full-length launches only (a burst's remainder launch carries fewer iterations)
+        full = df[df.stream_launch].dur_us.max()
+        df["stream_launch"] &= df.dur_us >= 0.85 * full
     g = df.groupby(["kernel", "stream_launch", "Counter_Name"]).agg(
         calls=("Counter_Value", "size"), mean=("Counter_Value", "mean"),
         mean_dur_us=("dur_us", "mean")).reset_index()
@@ -50,7 +54,8 @@ extra = {k: res[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES", "SQ_A
                             "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_BUSY_CYCLES") if k in res}
 json.dump({"homes": homes, "T": T, "mode": "pdhg", "fetch_bytes_corrected": fetch, "write_bytes": write,
            "hbm_bytes_per_launch": fetch + write, "algorithmic_bytes_per_launch": bytes_per_home * homes,
-           "iterations_per_launch": 8 if multi else 1, "sq_counters_per_launch": extra,
+           "iterations_per_launch": int(os.environ.get("REVS_ITERS_PER_LAUNCH", "16")) if multi else 1,
+           "sq_counters_per_launch": extra,
            "source": f"profiles/{tag}_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate "
                      "passes of `bench.py --steps 60 --no-extras --no-cpu-baseline --no-converge --clock-warm 0`, "
                      "the streaming launches of each pass; counters in KiB, FETCH_SIZE x2 per "
