@@ -40,6 +40,82 @@ __device__ __forceinline__ int dpp_i(int v) {
     return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
 }
 
+// ---- reductions over the 64 lanes of a wavefront without the LDS permute network -------------
+// __shfl_xor of a double is two ds_bpermute_b32 (a round trip through the LDS crossbar each, ~40
+// cycles) per step and the six steps depend on each other: ~260 cycles per reduction, which is what
+// a latency-bound workgroup of the operator's launches spends its time on.  Here: v_permlane32_swap /
+// v_permlane16_swap (gfx950) for the two steps across rows, DPP row rotations inside the rows --
+// ~70 cycles, and the SAME association as the xor butterfly 32, 16, 8, 4, 2, 1 (after the step at
+// distance 2d a lane's value depends on its index mod 2d only, so a rotation by d inside the row of
+// 16 delivers exactly the butterfly partner's value): the sums keep their bits
+// (tools/probes/wave_reduce.hip).
+template <int CTRL>
+__device__ __forceinline__ double dpp_rot_d(double v) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, true);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// (a, b) = (the value of this lane's partner half, own half) in some order: lanes i and i ^ 32 (SWAP32)
+// or i ^ 16 both get the pair {v_i, v_partner}
+template <bool SWAP32>
+__device__ __forceinline__ void swap_pair_d(double v, double &a0, double &a1) {
+    const long long b = __double_as_longlong(v);
+    const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+    if constexpr (SWAP32) {
+        const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        a0 = __longlong_as_double(((long long)h[0] << 32) | l[0]);
+        a1 = __longlong_as_double(((long long)h[1] << 32) | l[1]);
+    } else {
+        const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        a0 = __longlong_as_double(((long long)h[0] << 32) | l[0]);
+        a1 = __longlong_as_double(((long long)h[1] << 32) | l[1]);
+    }
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+    double a0, a1;
+    swap_pair_d<true>(v, a0, a1);  v = a0 + a1;
+    swap_pair_d<false>(v, a0, a1); v = a0 + a1;
+    v += dpp_rot_d<0x128>(v);      // row_ror:8
+    v += dpp_rot_d<0x124>(v);
+    v += dpp_rot_d<0x122>(v);
+    v += dpp_rot_d<0x121>(v);
+    return v;
+}
+__device__ __forceinline__ double wave_max_d(double v) {
+    double a0, a1;
+    swap_pair_d<true>(v, a0, a1);  v = fmax(a0, a1);
+    swap_pair_d<false>(v, a0, a1); v = fmax(a0, a1);
+    v = fmax(v, dpp_rot_d<0x128>(v));
+    v = fmax(v, dpp_rot_d<0x124>(v));
+    v = fmax(v, dpp_rot_d<0x122>(v));
+    v = fmax(v, dpp_rot_d<0x121>(v));
+    return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+    const auto a = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    v = min((int)a[0], (int)a[1]);
+    const auto b = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    v = min((int)b[0], (int)b[1]);
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, true));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, true));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x122, 0xf, 0xf, true));
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x121, 0xf, 0xf, true));
+    return v;
+}
+// inclusive prefix sum of an int over the wavefront (row_shr steps, then the row totals across)
+__device__ __forceinline__ int wave_incl_scan_i(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // Sum / max over an aligned group of LPA lanes, result in every lane of the group.
 template <int LPA>
 __device__ __forceinline__ float group_sum(float v) {
@@ -148,3 +224,16 @@ __device__ __forceinline__ float clip3(float v, float lo, float hi) {
 }
 
 }  // namespace revs
+
+// Tuning build (-DREVS_KV_STAMPS): wall-clock ticks (100 MHz) at up to 32 points of a slot's way through the
+// folded chain's operator launch, written by thread 0 of the workgroups from kvs_first on.
+#ifdef REVS_KV_STAMPS
+namespace revs {            // (one copy per translation unit: only the operator kernels' copy is ever set)
+static __device__ double *kvs_ptr = nullptr;
+static __device__ int kvs_first = 0;
+}
+#define REVS_KVS(t, i) do { if (threadIdx.x == 0 && revs::kvs_ptr && (int)blockIdx.x >= revs::kvs_first) \
+        revs::kvs_ptr[32 * (t) + (i)] = (double)wall_clock64(); } while (0)
+#else
+#define REVS_KVS(t, i) do { } while (0)
+#endif

@@ -165,39 +165,46 @@ struct TreeRowsArgs {
     const double *y;
     double vlo, vhi;
     double *vfull, *viol, *partial, *zero_out;
+    double *ycopy_out = nullptr;   // != NULL: the slot's multipliers are copied there, row by row (the next trial's start)
 };
 // rows_lds != NULL (double[3 m + 4] of LDS): the slot's multipliers, voltages and violations by row and
 // the four sums are left THERE for a selection that follows in the same workgroup
 // (SelectArgs::rows_lds) instead of in the global columns vfull / viol.
+struct NoPrefetch { __device__ void operator()() const {} };
+// after_pack(): the caller's own loads, issued behind the packed indices (the first thing every gather
+// waits for) and in front of everything else
+template <class F = NoPrefetch>
 __device__ __forceinline__ void tree_rows_body(const TreeRowsArgs &a, const int t, double *lds,
-                                               double *rows_lds = nullptr) {
+                                               double *rows_lds = nullptr, F &&after_pack = F()) {
     const int tid = threadIdx.x, j0 = 8 * tid, T = a.T;
-    if (rows_lds)      // (rows without a position in the tree: zero; the scans' barriers order this)
-        for (int i = tid; i < 3 * a.m; i += 256) rows_lds[i] = 0.0;
     const bool act = j0 < a.tree.n;
-    // the multipliers and dual terms of this thread's rows: requested before the scans
-    double yv[8], qv[8];
+    // the positions' packed indices first: every gather below -- multipliers, dual terms, and the node
+    // sums inside tree_voltage -- waits for them and for nothing else
+    unsigned long long pk[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { yv[i] = 0.0; qv[i] = 0.0; }
+    for (int i = 0; i < 8; ++i) pk[i] = 0ull;
     if (act) {
-        unsigned long long pk0[8];
 #pragma unroll
         for (int i = 0; i < 8; i += 2) {
             const TreeU2 u = *reinterpret_cast<const TreeU2 *>(a.tree.pack + j0 + i);
-            pk0[i] = u.v[0]; pk0[i + 1] = u.v[1];
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int s = (int)(pk0[i] & 0xFFFFu) - 1;
-            yv[i] = s >= 0 ? a.y[(int64_t)s * T + t] : 0.0;
-            qv[i] = s >= 0 ? a.qn[(int64_t)s * T + t] : 0.0;
+            pk[i] = u.v[0]; pk[i + 1] = u.v[1];
         }
     }
+    after_pack();
+    if (rows_lds)      // (rows without a position in the tree: zero; the scans' barriers order this)
+        for (int i = tid; i < 3 * a.m; i += 256) rows_lds[i] = 0.0;
     if (a.zero_out)
         for (int r = tid; r < a.m; r += 256) a.zero_out[(int64_t)r * T + t] = 0.0;
-    unsigned long long pk[8];
+    double yv[8], qv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int s = (int)(pk[i] & 0xFFFFu) - 1;
+        yv[i] = s >= 0 ? a.y[(int64_t)s * T + t] : 0.0;
+        qv[i] = s >= 0 ? a.qn[(int64_t)s * T + t] : 0.0;
+    }
     double v8[8];
-    tree_voltage<256, 8>(a.tree, a.p, T, t, lds, v8, pk, nullptr);
+    REVS_KVS(t, 1);
+    tree_voltage<256, 8, true>(a.tree, a.p, T, t, lds, v8, pk, nullptr);
     double rmax = 0.0, dsum = 0.0, nsup = 0.0, nvio = 0.0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -212,6 +219,7 @@ __device__ __forceinline__ void tree_rows_body(const TreeRowsArgs &a, const int 
             dsum += qv[i] - fmax(a.vhi * y1, a.vlo * y1);
             nsup += y1 != 0.0 ? 1.0 : 0.0;
             nvio += (y1 == 0.0 && vi > 0.0) ? 1.0 : 0.0;
+            if (a.ycopy_out) a.ycopy_out[o] = y1;
             if (rows_lds) {
                 rows_lds[s] = y1;
                 rows_lds[a.m + s] = v;
@@ -222,6 +230,7 @@ __device__ __forceinline__ void tree_rows_body(const TreeRowsArgs &a, const int 
             }
         }
     }
+    REVS_KVS(t, 6);
     rmax = wave_max_d(rmax); dsum = wave_sum_d(dsum); nsup = wave_sum_d(nsup); nvio = wave_sum_d(nvio);
     __shared__ double rr[4][4];
     if ((tid & 63) == 0) { rr[0][tid >> 6] = rmax; rr[1][tid >> 6] = dsum; rr[2][tid >> 6] = nsup; rr[3][tid >> 6] = nvio; }
@@ -519,7 +528,7 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
 template <int A>
 __device__ __forceinline__ void small_bpp(const double (&Ks)[8][8], const double *cs,
                                           const double *cg, const double *cy, double delta,
-                                          int max_pivots, double *yo, int32_t *info) {
+                                          int max_pivots, double *yo, int32_t *info, const int nfill = kAmax) {
     // One thread, everything in registers: rows >= a and non-basic rows are masked to the
     // identity, so every loop below has compile-time bounds.
     double s[A], c[A], u[A], cyv[A], K[A][A];
@@ -532,7 +541,7 @@ __device__ __forceinline__ void small_bpp(const double (&Ks)[8][8], const double
         tr += Ks[i][i];
     }
     if (!(tr > 0.0)) {                      // K = 0: leave the multipliers where they are
-        for (int i = 0; i < kAmax; ++i) yo[i] = i < A ? cy[i] : 0.0;
+        for (int i = 0; i < nfill; ++i) yo[i] = i < A ? cy[i] : 0.0;
         *info = 0;
         return;
     }
@@ -611,7 +620,7 @@ __device__ __forceinline__ void small_bpp(const double (&Ks)[8][8], const double
     }
 #pragma unroll
     for (int i = 0; i < A; ++i) yo[i] = s[i] * fmax(u[i], 0.0);
-    for (int i = A; i < kAmax; ++i) yo[i] = 0.0;
+    for (int i = A; i < nfill; ++i) yo[i] = 0.0;
     *info = done == 1 ? piv : -piv;
 }
 
@@ -648,6 +657,7 @@ __device__ __forceinline__ void small_model_body(
     double acc[kSmall * (kSmall + 1) / 2];
 #pragma unroll
     for (int p = 0; p < kSmall * (kSmall + 1) / 2; ++p) acc[p] = 0.0;
+    REVS_KVS(t, 12);
 #pragma unroll 8
     for (int mm = tid; mm < m; mm += 256) {
         const double nv = Nn[(int64_t)mm * T + t];
@@ -664,12 +674,14 @@ __device__ __forceinline__ void small_model_body(
     }
     __shared__ double part[4][kSmall * (kSmall + 1) / 2];
     __shared__ double Ks[kSmall][kSmall];
+    REVS_KVS(t, 13);
 #pragma unroll
     for (int p = 0; p < kSmall * (kSmall + 1) / 2; ++p) {
         const double v = wave_sum_d(acc[p]);
         if ((tid & 63) == 0) part[tid >> 6][p] = v;
     }
     __syncthreads();
+    REVS_KVS(t, 14);
     if (tid < kSmall * kSmall) {
         const int i = tid / kSmall, j = tid % kSmall;
         const int lo = i < j ? i : j, hi = i < j ? j : i;
@@ -679,6 +691,7 @@ __device__ __forceinline__ void small_model_body(
         if (i < a && j < a) Kall[(int64_t)t * kAmax * kAmax + i * kAmax + j] = v;
     }
     __syncthreads();
+    REVS_KVS(t, 15);
     if (tid != 0) return;
     switch (a) {                            // one thread; loops sized by the candidate count
         case 1: small_bpp<1>(Ks, cvs[0], cvs[1], cvs[2], delta, max_pivots, yo, info + t); break;
@@ -690,6 +703,7 @@ __device__ __forceinline__ void small_model_body(
         case 7: small_bpp<7>(Ks, cvs[0], cvs[1], cvs[2], delta, max_pivots, yo, info + t); break;
         default: small_bpp<8>(Ks, cvs[0], cvs[1], cvs[2], delta, max_pivots, yo, info + t); break;
     }
+    REVS_KVS(t, 16);
 }
 
 __global__ __launch_bounds__(256) void op_dual_model_small_kernel(
@@ -836,6 +850,7 @@ __device__ __forceinline__ void chain_shifts_body(const int t, int m, int T, con
         }
         // (eight nodes per pass with every load of the pass in flight before the first use: the loop is
         // latency, not bandwidth)
+        REVS_KVS(t, 19);
         for (int n0 = threadIdx.x; n0 < m; n0 += 8 * 256) {
             double ra[8][4], rb[8][4];
             const int kk = ns < 4 ? ns : 4;         // rows beyond four (rare) go through the second loop below
@@ -889,6 +904,174 @@ __device__ __forceinline__ void chain_shifts_body(const int t, int m, int T, con
     }
 }
 
+
+// Small model, step and the trial's shifts of one slot in one piece -- the folded chain's usual case: at
+// most 8 candidates (the list in LDS, left there by the selection: SlotLists) and at most 2048 rows.
+// The same arithmetic, term for term, as small_model_body + dual_step_body + chain_shifts_body (the
+// stand-alone launches of the general loop give the same bits), without their trips through memory:
+// the candidates' rows of R are fetched ONCE -- the Gram sums and the shifts R^T y read the same
+// elements, 8 nodes x 8 rows per thread, kept in registers across the pivoting -- the column of N is
+// requested by the caller before the rows are even judged (nn[j] = N[tid + 256 j][t]), the wavefront
+// sums run over the a (a + 1) / 2 entries that exist, and multipliers, step and list stay in LDS.
+__device__ __forceinline__ void chain_fast_body(
+        const int t, const int m, const int T, const double *__restrict__ R, const double (&nn)[8],
+        const SlotLists *ll, const double inv_kappa, const double delta, const int max_pivots, const double al,
+        double *__restrict__ Kall, double *__restrict__ yhat, int32_t *__restrict__ info,
+        double *__restrict__ ytrial, double *__restrict__ lin_out, double *__restrict__ sh_a,
+        double *__restrict__ sh_b) {
+    const int tid = threadIdx.x;
+    // (what is the same for every lane is told to the compiler: scalar registers, scalar address arithmetic)
+    auto uni_i = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+    auto uni_d = [&](double v) {
+        const long long b = __double_as_longlong(v);
+        return __longlong_as_double(((long long)uni_i((int)(b >> 32)) << 32) | (unsigned int)uni_i((int)b));
+    };
+    const int a = uni_i(ll->cnt);           // 1 .. 8 (the caller checked)
+    long long f[kSmall];
+#pragma unroll
+    for (int i = 0; i < kSmall; ++i) f[i] = i < a ? (long long)uni_i((int)ll->ci[i]) : -1;
+    double r[8][kSmall];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int mm = tid + 256 * j;
+#pragma unroll
+        for (int i = 0; i < kSmall; ++i) r[j][i] = (f[i] >= 0 && mm < m) ? R[f[i] * m + mm] : 0.0;
+    }
+    REVS_KVS(t, 12);
+    double acc[kSmall * (kSmall + 1) / 2];
+#pragma unroll
+    for (int p = 0; p < kSmall * (kSmall + 1) / 2; ++p) acc[p] = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (tid + 256 * j < m) {
+            int p = 0;
+#pragma unroll
+            for (int i = 0; i < kSmall; ++i) {
+                const double rn = r[j][i] * nn[j];
+#pragma unroll
+                for (int jj = i; jj < kSmall; ++jj) acc[p++] += rn * r[j][jj];
+            }
+        }
+    }
+    __shared__ double part[4][kSmall * (kSmall + 1) / 2];
+    __shared__ double Ks[kSmall][kSmall];
+    __shared__ double yo_s[kSmall];
+    REVS_KVS(t, 13);
+    {
+        int p = 0;
+#pragma unroll
+        for (int i = 0; i < kSmall; ++i)
+#pragma unroll
+            for (int jj = i; jj < kSmall; ++jj, ++p)
+                if (jj < a) {               // uniform
+                    const double v = wave_sum_d(acc[p]);
+                    if ((tid & 63) == 0) part[tid >> 6][p] = v;
+                }
+    }
+    __syncthreads();
+    REVS_KVS(t, 14);
+    if (tid < kSmall * kSmall) {
+        const int i = tid / kSmall, j = tid % kSmall;
+        if (i < a && j < a) {
+            const int lo = i < j ? i : j, hi = i < j ? j : i;
+            const int p = lo * kSmall - lo * (lo - 1) / 2 + (hi - lo);
+            const double v = (((part[0][p] + part[1][p]) + part[2][p]) + part[3][p]) * inv_kappa;
+            Ks[i][j] = v;
+            Kall[(int64_t)t * kAmax * kAmax + i * kAmax + j] = v;
+        }
+    }
+    __syncthreads();
+    REVS_KVS(t, 15);
+    if (tid == 0) {
+        int32_t inf;
+        switch (a) {                        // one thread; loops sized by the candidate count
+            case 1: small_bpp<1>(Ks, ll->cs, ll->cg, ll->cy, delta, max_pivots, yo_s, &inf, kSmall); break;
+            case 2: small_bpp<2>(Ks, ll->cs, ll->cg, ll->cy, delta, max_pivots, yo_s, &inf, kSmall); break;
+            case 3: small_bpp<3>(Ks, ll->cs, ll->cg, ll->cy, delta, max_pivots, yo_s, &inf, kSmall); break;
+            case 4: small_bpp<4>(Ks, ll->cs, ll->cg, ll->cy, delta, max_pivots, yo_s, &inf, kSmall); break;
+            case 5: small_bpp<5>(Ks, ll->cs, ll->cg, ll->cy, delta, max_pivots, yo_s, &inf, kSmall); break;
+            case 6: small_bpp<6>(Ks, ll->cs, ll->cg, ll->cy, delta, max_pivots, yo_s, &inf, kSmall); break;
+            case 7: small_bpp<7>(Ks, ll->cs, ll->cg, ll->cy, delta, max_pivots, yo_s, &inf, kSmall); break;
+            default: small_bpp<8>(Ks, ll->cs, ll->cg, ll->cy, delta, max_pivots, yo_s, &inf, kSmall); break;
+        }
+        info[t] = inf;
+        REVS_KVS(t, 16);
+    }
+    __syncthreads();
+    if (tid < kAmax) yhat[(int64_t)t * kAmax + tid] = tid < kSmall ? yo_s[tid] : 0.0;
+    // the step (dual_step_body), every thread for itself: y_trial at the candidates, in list order
+    double yn[kSmall];
+#pragma unroll
+    for (int i = 0; i < kSmall; ++i) {
+        const double yo = ll->cy[i], yh = yo_s[i];
+        yn[i] = uni_d(i < a ? (al == 1.0 ? yh : (al == 0.0 ? yo : yo + al * (yh - yo))) : 0.0);
+    }
+    if (tid < 64) {
+        double lin = 0.0;
+        if (tid < a) {
+            double mine = 0.0;
+#pragma unroll
+            for (int i = 0; i < kSmall; ++i) mine = i == tid ? yn[i] : mine;
+            ytrial[ll->ci[tid] * T + t] = mine;
+            lin += ll->cg[tid] * (mine - ll->cy[tid]);
+        }
+        lin = wave_sum_d(lin);
+        if (tid == 0) lin_out[t * 8] = lin;
+    }
+    REVS_KVS(t, 18);
+    // the shifts (chain_shifts_body): list order -- a term with y = 0 adds exactly nothing, so the rows
+    // need no compaction -- and, where it differs, ascending row order of the rows that carry a multiplier
+    int ord[kSmall], ns = 0;
+    bool same = true;
+    {   // list order restricted to the rows with a multiplier ascending already (the usual case)?
+        long long last = -1;
+#pragma unroll
+        for (int k2 = 0; k2 < kSmall; ++k2)
+            if (k2 < a && yn[k2] != 0.0) { same = same && f[k2] > last; last = f[k2]; }
+    }
+#pragma unroll
+    for (int q = 0; q < kSmall; ++q) ord[q] = -1;
+    if (!same) {
+        long long last = -1;
+#pragma unroll
+        for (int q = 0; q < kSmall; ++q) {
+            long long best = 0x7FFFFFFFFFFFFFFFll;
+            int bk = -1;
+#pragma unroll
+            for (int k2 = 0; k2 < kSmall; ++k2)
+                if (k2 < a && yn[k2] != 0.0 && f[k2] > last && f[k2] < best) { best = f[k2]; bk = k2; }
+            ord[q] = bk;
+            if (bk >= 0) { ++ns; last = best; }
+        }
+    }
+    REVS_KVS(t, 19);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int node = tid + 256 * j;
+        if (node >= m) continue;
+        double d = 0.0;
+#pragma unroll
+        for (int k2 = 0; k2 < kSmall; ++k2)
+            if (k2 < a) d = __builtin_fma(r[j][k2], yn[k2], d);
+        double ds = d;
+        if (!same) {
+            ds = 0.0;
+#pragma unroll
+            for (int q = 0; q < kSmall; ++q) {
+                if (q < ns) {
+                    double rv = 0.0, yq = 0.0;
+#pragma unroll
+                    for (int k2 = 0; k2 < kSmall; ++k2)
+                        if (k2 == ord[q]) { rv = r[j][k2]; yq = yn[k2]; }
+                    ds = __builtin_fma(rv, yq, ds);
+                }
+            }
+        }
+        sh_a[(int64_t)t * m + node] = d * inv_kappa;
+        sh_b[(int64_t)t * m + node] = ds * inv_kappa;
+    }
+}
+
 struct ChainKvArgs {
     int has_e2;
     TreeRowsArgs e2;
@@ -902,15 +1085,7 @@ struct ChainKvArgs {
 };
 __global__ __launch_bounds__(256) void op_chain_kv_kernel(const ChainKvArgs k) {
     extern __shared__ double tree_lds[];
-    const int T = k.s1.T;
-    {
-        const long long per = (k.clr_count + gridDim.x - 1) / gridDim.x;
-        const long long i0 = blockIdx.x * per, i1 = i0 + per < k.clr_count ? i0 + per : k.clr_count;
-        for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
-            if (k.clr0) k.clr0[i] = 0.0;
-            if (k.clr1) k.clr1[i] = 0.0;
-        }
-    }
+    const int T = k.s1.T, m = k.s1.m;
     // (the rows of a slot go to its selection through LDS: double[3 m + 4] behind the tree's scan buffer)
     double *rows_lds = tree_lds + (tree_lds_bytes(k.e1.tree.n) / sizeof(double) + 1) / 2 * 2;
     if (k.has_e2 && (int)blockIdx.x < T) {
@@ -919,34 +1094,55 @@ __global__ __launch_bounds__(256) void op_chain_kv_kernel(const ChainKvArgs k) {
         SelectArgs s2 = k.s2;
         s2.rows_lds = rows_lds;
         dual_select_body<true>(s2, blockIdx.x);
+        // the verdict is out: these workgroups have time left -- they clear the two sum arrays the NEXT
+        // sweep accumulates into (behind everything the other half of the launch has to fetch)
+        const long long per = (k.clr_count + T - 1) / T;
+        const long long i0 = blockIdx.x * per, i1 = i0 + per < k.clr_count ? i0 + per : k.clr_count;
+        for (long long i = i0 + threadIdx.x; i < i1; i += 256) {
+            if (k.clr0) k.clr0[i] = 0.0;
+            if (k.clr1) k.clr1[i] = 0.0;
+        }
         return;
     }
     const int t = (int)blockIdx.x - (k.has_e2 ? T : 0);
-#ifdef REVS_KV_STAMPS      // tuning build: wall-clock ticks (100 MHz) at the stage boundaries of every slot
-#define KV_STAMP(i) do { if (threadIdx.x == 0) k.sh_b[(long long)k.s1.m * T + 8 * t + (i)] = (double)wall_clock64(); } while (0)
-#else
-#define KV_STAMP(i) do { } while (0)
-#endif
+    // (tuning build: stamps 0 | 1-6 rows | 7-10 selection | 11-16 model | 17 step | 18-20 shifts)
+#define KV_STAMP(i) REVS_KVS(t, i)
     KV_STAMP(0);
-    tree_rows_body(k.e1, t, tree_lds, rows_lds);
+    // this slot's column of N (the model's weights): needed after the selection, requested now
+    double nn[8];
+    __shared__ SlotLists lists;
+    tree_rows_body(k.e1, t, tree_lds, rows_lds, [&]() {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int mm = threadIdx.x + 256 * j;
+            nn[j] = mm < m ? k.f1.Nn[(int64_t)mm * T + t] : 0.0;
+        }
+    });
     __syncthreads();
-    KV_STAMP(1);
+    KV_STAMP(7);
     SelectArgs s1 = k.s1;
     s1.rows_lds = rows_lds;
+    s1.ll = &lists;
     const double rmax = dual_select_body<true>(s1, t);
     __syncthreads();
-    KV_STAMP(2);
-    small_model_body(t, k.s1.m, k.s1.T, k.f1.R, k.f1.Nn, k.s1.cidx, k.s1.ccnt, k.s1.cval, k.f1.inv_kappa, k.f1.delta,
+    KV_STAMP(11);
+    const double al = rmax / k.f1.scale > k.f1.eps ? 1.0 : 0.0;
+    if (lists.cnt >= 1 && lists.cnt <= kSmall && m <= 2048) {       // uniform
+        chain_fast_body(t, m, T, k.f1.R, nn, &lists, k.f1.inv_kappa, k.f1.delta, k.f1.max_pivots, al, k.f1.Kall,
+                        k.f1.yhat, k.f1.info, k.f1.ytrial, k.f1.lin_out, k.sh_a, k.sh_b);
+        KV_STAMP(20);
+        return;
+    }
+    small_model_body(t, m, T, k.f1.R, k.f1.Nn, k.s1.cidx, k.s1.ccnt, k.s1.cval, k.f1.inv_kappa, k.f1.delta,
                      k.f1.max_pivots, k.f1.Kall, k.f1.yhat, k.f1.info);
     __syncthreads();
-    KV_STAMP(3);
-    dual_step_body<256>(t, k.s1.T, k.s1.cidx, k.s1.ccnt, k.s1.cval, k.f1.yhat,
-                        rmax / k.f1.scale > k.f1.eps ? 1.0 : 0.0, k.f1.ytrial, k.f1.lin_out, k.f1.ycopy, k.s1.m);
+    KV_STAMP(17);
+    dual_step_body<256>(t, T, k.s1.cidx, k.s1.ccnt, k.s1.cval, k.f1.yhat, al, k.f1.ytrial, k.f1.lin_out, nullptr, m);
     __syncthreads();                        // the trial's column (first wavefront), in global memory
-    KV_STAMP(4);
-    chain_shifts_body(t, k.s1.m, k.s1.T, k.f1.R, k.s1.cidx, k.s1.ccnt, k.f1.ytrial, k.f1.inv_kappa, k.sh_a, k.sh_b);
+    KV_STAMP(18);
+    chain_shifts_body(t, m, T, k.f1.R, k.s1.cidx, k.s1.ccnt, k.f1.ytrial, k.f1.inv_kappa, k.sh_a, k.sh_b);
     __syncthreads();
-    KV_STAMP(5);
+    KV_STAMP(20);
 #undef KV_STAMP
 }
 
@@ -968,6 +1164,7 @@ int chain_kv_launch(const ChainKv &c, void *stream) {
         return SelectArgs{c.m, c.T, 1, c.kadd, s.partial, s.y, s.vfull, s.viol, c.vlo, c.vhi, s.seq, s.cidx, s.ccnt, s.cval, s.stats};
     };
     k.e1 = rows(c.e1);
+    k.e1.ycopy_out = c.y_trial;     // the next trial starts from this evaluation's multipliers: copied by the rows' pass
     k.s1 = sel(c.e1);
     k.s1.lazy = c.has_e2 != 0;      // (the entry launch's stats are read behind the first verdict too, but cost nothing extra)
     k.e2 = rows(c.has_e2 ? c.e2 : c.e1);
@@ -979,12 +1176,20 @@ int chain_kv_launch(const ChainKv &c, void *stream) {
     const size_t lds = ((tree_lds_bytes(c.tree.n) / sizeof(double) + 1) / 2 * 2 + 3 * (size_t)c.m + 4) * sizeof(double);
     if (lds > 64 * 1024) {       // (more than 64 KB of dynamic LDS has to be granted, once)
         static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&op_chain_kv_kernel),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096);
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384);
         if (e != hipSuccess) {
             revs::set_error("chain_kv_launch: %zu bytes of LDS refused: %s", lds, hipGetErrorString(e));
             return REVS_ELAUNCH;
         }
     }
+#ifdef REVS_KV_STAMPS
+    {
+        double *sp = c.sh_b + mt;
+        const int first = c.has_e2 ? c.T : 0;
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(kvs_ptr), &sp, sizeof(sp), 0, hipMemcpyHostToDevice, (hipStream_t)stream);
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(kvs_first), &first, sizeof(first), 0, hipMemcpyHostToDevice, (hipStream_t)stream);
+    }
+#endif
     hipLaunchKernelGGL(op_chain_kv_kernel, dim3((c.has_e2 ? 2 : 1) * c.T), dim3(256), lds, (hipStream_t)stream, k);
     REVS_CHECK_LAUNCH("chain_kv_launch");
     return REVS_OK;

@@ -523,7 +523,7 @@ static int fold_alloc(revs_plan_t *plan) {
     dev((void **)&plan->fold_v[1], sizeof(double) * mt);
     dev((void **)&plan->fold_v[2], sizeof(double) * (size_t)d.T * 4);
     dev((void **)&plan->fold_sh[0], sizeof(double) * mt);
-    dev((void **)&plan->fold_sh[1], sizeof(double) * (mt + 8 * (size_t)d.T));     // (+ the tuning build's stage stamps)
+    dev((void **)&plan->fold_sh[1], sizeof(double) * (mt + 32 * (size_t)d.T));     // (+ the tuning build's stage stamps)
     if (e != hipSuccess) {
         revs::set_error("revs_plan_chain_fold_run: allocating the folded chain's buffers: %s", hipGetErrorString(e));
         return REVS_ELAUNCH;
@@ -689,19 +689,22 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
     st->resume = have_k1 ? 1 : 0;
 #ifdef REVS_KV_STAMPS
     {
-        std::vector<double> h(8 * (size_t)d.T);
+        std::vector<double> h(32 * (size_t)d.T);
         (void)hipStreamSynchronize(s);
         (void)hipMemcpy(h.data(), plan->fold_sh[1] + mt, sizeof(double) * h.size(), hipMemcpyDeviceToHost);
-        double mx[5] = {0, 0, 0, 0, 0};
         int worst = 0;
-        for (int t = 0; t < d.T; ++t) {
-            if (h[8 * t + 5] - h[8 * t] > h[8 * worst + 5] - h[8 * worst]) worst = t;
-            for (int i = 0; i < 5; ++i) mx[i] = std::max(mx[i], (h[8 * t + i + 1] - h[8 * t + i]) * 0.01);
+        for (int t = 0; t < d.T; ++t)
+            if (h[32 * t + 20] - h[32 * t] > h[32 * worst + 20] - h[32 * worst]) worst = t;
+        // 0 start | 1-6 rows | 7-10 selection | 11-16 model | 17 step | 18-20 shifts: microseconds since the slot's start
+        fprintf(stderr, "[kv stamps, us since start] slowest slot %d:", worst);
+        for (int i = 1; i <= 20; ++i) fprintf(stderr, " %d:%.1f", i, (h[32 * worst + i] - h[32 * worst]) * 0.01);
+        fprintf(stderr, "\n[kv stamps, mean over slots]            ");
+        for (int i = 1; i <= 20; ++i) {
+            double acc = 0;
+            for (int t = 0; t < d.T; ++t) acc += (h[32 * t + i] - h[32 * t]) * 0.01;
+            fprintf(stderr, " %d:%.1f", i, acc / d.T);
         }
-        fprintf(stderr, "[kv stamps, us] slowest slot %d: rows %.1f select %.1f model %.1f step %.1f shifts %.1f | max over slots: "
-                "%.1f %.1f %.1f %.1f %.1f\n", worst, (h[8 * worst + 1] - h[8 * worst]) * 0.01, (h[8 * worst + 2] - h[8 * worst + 1]) * 0.01,
-                (h[8 * worst + 3] - h[8 * worst + 2]) * 0.01, (h[8 * worst + 4] - h[8 * worst + 3]) * 0.01,
-                (h[8 * worst + 5] - h[8 * worst + 4]) * 0.01, mx[0], mx[1], mx[2], mx[3], mx[4]);
+        fprintf(stderr, "\n");
     }
 #endif
     return REVS_OK;

@@ -10,16 +10,14 @@ constexpr int kAmax = REVS_DUAL_AMAX;
 static_assert(kAmax == 128, "candidate sets are two 64-bit words / two wavefronts");
 constexpr int kWords = kAmax / 64;
 
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
-}
-__device__ __forceinline__ double wave_max_d(double v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = fmax(v, __shfl_xor(v, d, 64));
-    return v;
-}
+// A slot's candidate list in LDS (SelectArgs::ll): what the selection also writes to cidx / ccnt / cval,
+// for a model step that follows in the same workgroup (the folded chain) without a trip through memory.
+struct SlotLists {
+    long long ci[kAmax];
+    double cs[kAmax], cg[kAmax], cy[kAmax];
+    int cnt;
+    double rmax;
+};
 
 struct SelectArgs {
     int m, T, nblk, kadd;
@@ -38,6 +36,7 @@ struct SelectArgs {
     // rows_lds[3 m ..]: read instead of the global columns (a column of a [m][T] array is m cache
     // lines: each column read or write costs a latency-bound workgroup ~2 us)
     const double *rows_lds = nullptr;
+    SlotLists *ll = nullptr;
 };
 
 // Stage 2, one workgroup per slot: fold the partials (fixed order), and -- only for a slot
@@ -68,6 +67,8 @@ __device__ __forceinline__ double dual_select_body(const SelectArgs &sa, const i
     // keep the vector pipe busy, and the host is waiting for their verdict: raised priority
     if (!EAGER) __builtin_amdgcn_s_setprio(3);
     __shared__ int cnt_s[4];
+    __shared__ int vcount;
+    if (EAGER && tid == 0) vcount = 0;     // (ordered by the first barrier below)
     __shared__ double red_s[4][4];
     __shared__ double best_v[4];
     __shared__ int best_i[4];
@@ -102,6 +103,7 @@ __device__ __forceinline__ double dual_select_body(const SelectArgs &sa, const i
         }
     }
     __syncthreads();
+    REVS_KVS(t, 8);
     const int ns = (int)(((red_s[2][0] + red_s[2][1]) + red_s[2][2]) + red_s[2][3]);
     const int nv = (int)(((red_s[3][0] + red_s[3][1]) + red_s[3][2]) + red_s[3][3]);
     const double rmax_t = fmax(fmax(red_s[0][0], red_s[0][1]), fmax(red_s[0][2], red_s[0][3]));
@@ -117,8 +119,9 @@ __device__ __forceinline__ double dual_select_body(const SelectArgs &sa, const i
     }
     int64_t *ci = cidx + (int64_t)t * kAmax;
     double *cs = cval + (int64_t)t * 3 * kAmax, *cg = cs + kAmax, *cy = cg + kAmax;
+    SlotLists *const ll = sa.ll;
     if (ns > kAmax || (ns == 0 && nv == 0)) {   // uniform: too many multipliers / nothing to do
-        if (tid == 0) ccnt[t] = ns > kAmax ? -1 : 0;
+        if (tid == 0) { ccnt[t] = ns > kAmax ? -1 : 0; if (ll) ll->cnt = ns > kAmax ? -1 : 0; }
         if (tid < kAmax) { ci[tid] = 0; cs[tid] = 1.0; cg[tid] = 0.0; cy[tid] = 0.0; }
         return rmax_t;
     }
@@ -130,12 +133,7 @@ __device__ __forceinline__ double dual_select_body(const SelectArgs &sa, const i
         for (int r = r0; r < r1; ++r) nsup += y_at(r) != 0.0 ? 1 : 0;
     }
     // exclusive prefix over the workgroup: scan inside the wavefront, then the wavefronts' totals
-    int incl = nsup;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(incl, d, 64);
-        if ((tid & 63) >= d) incl += o;
-    }
+    const int incl = wave_incl_scan_i(nsup);
     if ((tid & 63) == 63) cnt_s[tid >> 6] = incl;
     __syncthreads();
     int pos = incl - nsup;
@@ -145,10 +143,12 @@ __device__ __forceinline__ double dual_select_body(const SelectArgs &sa, const i
         for (int j = 0; j < kPer; ++j) {
             const double yv = ysv[j];
             if (yv != 0.0) {
+                const double sg = yv > 0.0 ? 1.0 : -1.0, gr = vsv[j] - (yv > 0.0 ? vhi : vlo);
                 ci[pos] = r0 + j;
-                cs[pos] = yv > 0.0 ? 1.0 : -1.0;
-                cg[pos] = vsv[j] - (yv > 0.0 ? vhi : vlo);
+                cs[pos] = sg;
+                cg[pos] = gr;
                 cy[pos] = yv;
+                if (ll) { ll->ci[pos] = r0 + j; ll->cs[pos] = sg; ll->cg[pos] = gr; ll->cy[pos] = yv; }
                 ++pos;
             }
         }
@@ -156,16 +156,19 @@ __device__ __forceinline__ double dual_select_body(const SelectArgs &sa, const i
         for (int r = r0; r < r1 && nsup > 0; ++r) {
             const double yv = y_at(r);
             if (yv != 0.0) {
+                const double sg = yv > 0.0 ? 1.0 : -1.0, gr = v_at(r) - (yv > 0.0 ? vhi : vlo);
                 ci[pos] = r;
-                cs[pos] = yv > 0.0 ? 1.0 : -1.0;
-                cg[pos] = v_at(r) - (yv > 0.0 ? vhi : vlo);
+                cs[pos] = sg;
+                cg[pos] = gr;
                 cy[pos] = yv;
+                if (ll) { ll->ci[pos] = r; ll->cs[pos] = sg; ll->cg[pos] = gr; ll->cy[pos] = yv; }
                 ++pos;
             }
         }
     }
     const int room = min(min(kadd, kAmax - ns), nv);
     int added = 0;
+    REVS_KVS(t, 9);
     // Row r is always scanned by thread r % 256.  Up to 4096 rows a thread keeps its (at most
     // 16) violations in registers and zeroes the one that is taken; beyond that it re-reads
     // them and remembers the taken ones in a register mask -- either way no global store has
@@ -174,14 +177,48 @@ __device__ __forceinline__ double dual_select_body(const SelectArgs &sa, const i
 #pragma unroll
         for (int i = 0; i < kLoc; ++i) {
             const int r = tid + 256 * i;
-            loc[i] = r < m ? viol[(int64_t)r * T + t] : 0.0;
+            loc[i] = r < m ? viol_at(r) : 0.0;
         }
     }
     unsigned long long took = 0ull;
     __shared__ double best_v2[2][4];
     __shared__ int best_i2[2][4];
     __shared__ int chosen[kAmax];
-    for (int k = 0; k < room; ++k) {
+    constexpr int kRank = 256;
+    __shared__ double vval[EAGER ? kRank : 1];
+    __shared__ int vrow[EAGER ? kRank : 1];
+    const bool by_rank = EAGER && room > 0 && nv <= kRank;
+    if (by_rank) {
+        // Few violated rows (nv of them carry a positive entry): instead of `room` rounds of a block-wide
+        // arg-max with a barrier each, collect them (any order) and let each compute its own place in the
+        // order the rounds would take them -- larger violation first, ties to the lower row.
+        auto put = [&](double x, int r) {
+            if (x > 0.0) {
+                const int q = atomicAdd(&vcount, 1);
+                if (q < kRank) { vval[q] = x; vrow[q] = r; }
+            }
+        };
+        if (inreg) {
+#pragma unroll
+            for (int i = 0; i < kLoc; ++i) put(loc[i], tid + 256 * i);
+        } else {
+            for (int r = tid; r < m; r += 256) put(viol_at(r), r);
+        }
+        __syncthreads();
+        const int nq = min(vcount, kRank);
+        if (tid < nq) {
+            const double x = vval[tid];
+            const int r = vrow[tid];
+            int rank = 0;
+            for (int j = 0; j < nq; ++j) {
+                const double xj = vval[j];
+                rank += (xj > x || (xj == x && vrow[j] < r)) ? 1 : 0;
+            }
+            if (rank < room) chosen[rank] = r;
+        }
+        added = min(room, nq);
+    }
+    for (int k = 0; k < (by_rank ? 0 : room); ++k) {
         double bv = 0.0;
         int bi = m;
         if (inreg) {
@@ -194,11 +231,10 @@ __device__ __forceinline__ double dual_select_body(const SelectArgs &sa, const i
                 if (x > bv && !((took >> i) & 1ull)) { bv = x; bi = r; }
             }
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const double ov = __shfl_xor(bv, d, 64);
-            const int oi = __shfl_xor(bi, d, 64);
-            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        {   // the wavefront's largest violation, ties to the lower row
+            const double wv = wave_max_d(bv);
+            bi = wave_min_i(bv == wv ? bi : 0x7FFFFFFF);
+            bv = wv;
         }
         const int pp = k & 1;
         if ((tid & 63) == 0) { best_v2[pp][tid >> 6] = bv; best_i2[pp][tid >> 6] = bi; }
@@ -224,6 +260,7 @@ __device__ __forceinline__ double dual_select_body(const SelectArgs &sa, const i
     // the chosen rows' entries, one thread each: a global load inside the round loop would
     // cost every round a memory latency (the other wavefronts wait at the barrier)
     __syncthreads();
+    REVS_KVS(t, 10);
     if (tid < added) {
         const int bi = chosen[tid];
         const double v = v_at(bi);
@@ -232,10 +269,14 @@ __device__ __forceinline__ double dual_select_body(const SelectArgs &sa, const i
         cs[ns + tid] = up ? 1.0 : -1.0;
         cg[ns + tid] = v - (up ? vhi : vlo);
         cy[ns + tid] = 0.0;
+        if (ll) { ll->ci[ns + tid] = bi; ll->cs[ns + tid] = up ? 1.0 : -1.0; ll->cg[ns + tid] = v - (up ? vhi : vlo); ll->cy[ns + tid] = 0.0; }
     }
     const int cnt = ns + added;
-    if (tid == 0) ccnt[t] = cnt;
-    if (tid >= cnt && tid < kAmax) { ci[tid] = 0; cs[tid] = 1.0; cg[tid] = 0.0; cy[tid] = 0.0; }
+    if (tid == 0) { ccnt[t] = cnt; if (ll) ll->cnt = cnt; }
+    if (tid >= cnt && tid < kAmax) {
+        ci[tid] = 0; cs[tid] = 1.0; cg[tid] = 0.0; cy[tid] = 0.0;
+        if (ll) { ll->ci[tid] = 0; ll->cs[tid] = 1.0; ll->cg[tid] = 0.0; ll->cy[tid] = 0.0; }
+    }
     return rmax_t;
 }
 

@@ -78,6 +78,7 @@ struct alignas(16) TreeD2 { double v[2]; };
 // p_clear != NULL (the same array as p, writable): every node sum read is set to zero behind the
 // read -- the block verdicts leave the ring slice they judged ready for the next accumulation.
 // `lds`: tree_lds_bytes() bytes, 16-byte aligned.  Ends without a barrier behind its last LDS reads.
+// PK_LOADED: the caller has fetched pk[] already (it gathers other columns by the same rows).
 // Two things shape this body.  Registers: in the 256 x 8 shape it runs inside the residence sweep's
 // kernel, whose occupancy (8 wavefronts per SIMD, 64 VGPRs) it must not lower -- two IPT-double
 // vectors per thread beside the static data.  Latency: its workgroups are a launch's critical
@@ -85,7 +86,7 @@ struct alignas(16) TreeD2 { double v[2]; };
 // ALL the static data of a thread -- four 16-bit indices per position packed in one 64-bit word,
 // and the weights -- are requested at the very top, and the only dependent global access is the
 // gather of the node sums behind them.
-template <int NT, int IPT>
+template <int NT, int IPT, bool PK_LOADED = false>
 __device__ __forceinline__ void tree_voltage(const TreeArgs &tr, const double *p, int T, int t,
                                              double *lds, double (&a)[IPT], unsigned long long (&pk)[IPT],
                                              double *p_clear) {
@@ -95,13 +96,15 @@ __device__ __forceinline__ void tree_voltage(const TreeArgs &tr, const double *p
     if (tid == 0) lds[1] = 0.0;                                 // base[-1]
     double b[IPT];
 #pragma unroll
-    for (int i = 0; i < IPT; ++i) { pk[i] = 0ull; a[i] = 0.0; b[i] = 0.0; }
+    for (int i = 0; i < IPT; ++i) { if (!PK_LOADED) pk[i] = 0ull; a[i] = 0.0; b[i] = 0.0; }
     if (act) {
 #pragma unroll
         for (int i = 0; i < IPT; i += 2) {
-            const TreeU2 u = *reinterpret_cast<const TreeU2 *>(tr.pack + j0 + i);
+            if (!PK_LOADED) {
+                const TreeU2 u = *reinterpret_cast<const TreeU2 *>(tr.pack + j0 + i);
+                pk[i] = u.v[0]; pk[i + 1] = u.v[1];
+            }
             const TreeD2 wv = *reinterpret_cast<const TreeD2 *>(tr.w + j0 + i);
-            pk[i] = u.v[0]; pk[i + 1] = u.v[1];
             b[i] = wv.v[0]; b[i + 1] = wv.v[1];                 // (b holds the weights until phase 2)
         }
         // C: inclusive prefix of the injections in preorder
@@ -120,7 +123,9 @@ __device__ __forceinline__ void tree_voltage(const TreeArgs &tr, const double *p
     }
 #pragma unroll
     for (int i = 1; i < IPT; ++i) a[i] += a[i - 1];
+    REVS_KVS(t, 2);
     const double cex = block_excl_offset<NT>(a[IPT - 1], red0);   // C_excl at j0
+    REVS_KVS(t, 3);
     if (act) {
 #pragma unroll
         for (int i = 0; i < IPT; i += 2)
@@ -141,6 +146,7 @@ __device__ __forceinline__ void tree_voltage(const TreeArgs &tr, const double *p
             *reinterpret_cast<TreeD2 *>(base + j0 + i) = TreeD2{{a[i], a[i + 1]}};
     }
     __syncthreads();
+    REVS_KVS(t, 4);
     // the same values in end-order, then both prefixes: Pre over preorder (a), F over end-order (b)
 #pragma unroll
     for (int i = 0; i < IPT; ++i) b[i] = act ? base[(int)((pk[i] >> 32) & 0xFFFFu)] : 0.0;
@@ -154,6 +160,7 @@ __device__ __forceinline__ void tree_voltage(const TreeArgs &tr, const double *p
             *reinterpret_cast<TreeD2 *>(base + j0 + i) = TreeD2{{b[i] + fex, b[i + 1] + fex}};
     }
     __syncthreads();
+    REVS_KVS(t, 5);
     // v_j = Pre[j] - F_excl[cle[j]] on the checked rows,  F_excl[c] = base[c - 1]
 #pragma unroll
     for (int i = 0; i < IPT; ++i) {
@@ -183,8 +190,7 @@ __device__ __forceinline__ double tree_rmax(const TreeArgs &tr, const double *p,
             if (v_out) v_out[(int64_t)s * T + t] = v;
         }
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) rmax = fmax(rmax, __shfl_xor(rmax, d, 64));
+    rmax = wave_max_d(rmax);
     __syncthreads();                                            // (red1 was the scans': every read is done)
     if ((tid & 63) == 0) red1[tid >> 6] = rmax;
     __syncthreads();
