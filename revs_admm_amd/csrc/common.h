@@ -226,14 +226,17 @@ __device__ __forceinline__ float clip3(float v, float lo, float hi) {
 }  // namespace revs
 
 // Tuning build (-DREVS_KV_STAMPS): wall-clock ticks (100 MHz) at up to 32 points of a slot's way through the
-// folded chain's operator launch, written by thread 0 of the workgroups from kvs_first on.
-#ifdef REVS_KV_STAMPS
-namespace revs {            // (one copy per translation unit: only the operator kernels' copy is ever set)
-static __device__ double *kvs_ptr = nullptr;
-static __device__ int kvs_first = 0;
+// folded chain's operator launch, written by thread 0 of its second half's workgroups.
+#if defined(REVS_KV_STAMPS) && defined(REVS_KVS_TU)      // (the operator kernels' translation unit only)
+namespace revs {
+// (the pointer sits in LDS, put there by thread 0 of a stamped workgroup: reading it waits for no
+// outstanding vector load -- a stamp must not order the code it measures)
+static __shared__ double *kvs_lds;
 }
-#define REVS_KVS(t, i) do { if (threadIdx.x == 0 && revs::kvs_ptr && (int)blockIdx.x >= revs::kvs_first) \
-        revs::kvs_ptr[32 * (t) + (i)] = (double)wall_clock64(); } while (0)
+#define REVS_KVS_BEGIN(ptr) do { if (threadIdx.x == 0) revs::kvs_lds = (ptr); } while (0)
+#define REVS_KVS(t, i) do { if (threadIdx.x == 0 && revs::kvs_lds) \
+        revs::kvs_lds[32 * (t) + (i)] = (double)wall_clock64(); } while (0)
 #else
+#define REVS_KVS_BEGIN(ptr) do { } while (0)
 #define REVS_KVS(t, i) do { } while (0)
 #endif

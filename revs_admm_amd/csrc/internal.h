@@ -79,6 +79,10 @@ struct ChainKv {
     double *y_trial, *lin_out;
     double *clr0, *clr1;
     double *sh_a, *sh_b;     // out: the shifts R^T y_trial / kappa (double[m][T]) in list order / in row order
+    // the candidate lists of the launch whose step produced e1.y (= e2.y): every row that carries a
+    // multiplier is on them, so the slots need not gather the multipliers' columns (NULL: unknown)
+    const int64_t *prev_cidx = nullptr;
+    const int32_t *prev_ccnt = nullptr;
 };
 int chain_kv_launch(const ChainKv &c, void *stream);
 

@@ -18,6 +18,7 @@
 //     1 home pass                 op_dual_eval_kernel, HBM bound (3 float reads + 1 write)
 // per evaluation, and a run needs 5-15 evaluations where the ADMM form needed 10^2-10^4
 // iterations of the same cost.
+#define REVS_KVS_TU
 #include "common.h"
 #include "select_body.h"
 #include "tree_body.h"
@@ -191,8 +192,14 @@ __device__ __forceinline__ void tree_rows_body(const TreeRowsArgs &a, const int 
         }
     }
     after_pack();
+    REVS_KVS(t, 21);
     if (rows_lds)      // (rows without a position in the tree: zero; the scans' barriers order this)
         for (int i = tid; i < 3 * a.m; i += 256) rows_lds[i] = 0.0;
+    REVS_KVS(t, 22);
+#ifdef REVS_KV_STAMPS
+    asm volatile("" :: "v"(pk[0]), "v"(pk[7]));
+    REVS_KVS(t, 23);
+#endif
     if (a.zero_out)
         for (int r = tid; r < a.m; r += 256) a.zero_out[(int64_t)r * T + t] = 0.0;
     double yv[8], qv[8];
@@ -248,6 +255,7 @@ __device__ __forceinline__ void tree_rows_body(const TreeRowsArgs &a, const int 
 // rows by the tree form, then (SELECT) the candidate selection of the same slot in the same workgroup
 template <bool SELECT>
 __global__ __launch_bounds__(256) void op_tree_rows_kernel(const TreeRowsArgs ta, const SelectArgs sa) {
+    REVS_KVS_BEGIN(nullptr);
     extern __shared__ double tree_lds[];
     tree_rows_body(ta, blockIdx.x, tree_lds);
     if constexpr (SELECT) {
@@ -258,6 +266,7 @@ __global__ __launch_bounds__(256) void op_tree_rows_kernel(const TreeRowsArgs ta
 
 // Stage 2 (select_body.h), one workgroup per slot, as its own kernel.
 __global__ __launch_bounds__(256) void op_dual_select_kernel(const SelectArgs sa) {
+    REVS_KVS_BEGIN(nullptr);
     dual_select_body<true>(sa, blockIdx.x);
 }
 
@@ -711,6 +720,7 @@ __global__ __launch_bounds__(256) void op_dual_model_small_kernel(
         const int64_t *__restrict__ cidx, const int32_t *__restrict__ ccnt,
         const double *__restrict__ cval, double inv_kappa, double delta, int max_pivots,
         double *__restrict__ Kall, double *__restrict__ yhat, int32_t *__restrict__ info) {
+    REVS_KVS_BEGIN(nullptr);
     small_model_body(blockIdx.x, m, T, R, Nn, cidx, ccnt, cval, inv_kappa, delta, max_pivots, Kall,
                      yhat, info);
 }
@@ -768,6 +778,7 @@ struct FusedArgs {
 };
 __global__ __launch_bounds__(256) void op_dual_select_model_step_kernel(const SelectArgs sa,
                                                                         const FusedArgs fa) {
+    REVS_KVS_BEGIN(nullptr);
     const int t = blockIdx.x;
     const double rmax = dual_select_body<true>(sa, t);
     __syncthreads();                        // this workgroup's lists, written to global memory
@@ -782,6 +793,7 @@ __global__ __launch_bounds__(256) void op_dual_select_model_step_kernel(const Se
 // Newton iteration between two home passes is then ONE launch of T workgroups)
 __global__ __launch_bounds__(256) void op_tree_select_model_step_kernel(const TreeRowsArgs ta, const SelectArgs sa,
                                                                         const FusedArgs fa) {
+    REVS_KVS_BEGIN(nullptr);
     extern __shared__ double tree_lds[];
     const int t = blockIdx.x;
     tree_rows_body(ta, t, tree_lds);
@@ -905,6 +917,218 @@ __device__ __forceinline__ void chain_shifts_body(const int t, int m, int T, con
 }
 
 
+// ---- rows and selection of one slot when the multipliers' support is known beforehand ----------------
+// (the folded chain past its entry).  The multipliers a launch evaluates were produced by the previous
+// launch's step from ITS candidate list, so every row with y != 0 is on that list (at most 8 rows here):
+//  * no column of y is gathered -- a column of a [m][T] array is m cache lines, ~1.7 us of a
+//    workgroup's L1 fill rate each -- its few entries are fetched through the list;
+//  * the new list's head (the rows with a multiplier, ascending) is known before the voltages are: the
+//    caller can fetch those rows of R at once (`after_pack`), a memory latency off the model step;
+//  * the violated rows are collected as the voltages are judged and placed by rank (the order the
+//    arg-max rounds of dual_select_body would take them), the support's entries are written straight
+//    from the judging threads: no row-indexed staging of v / violations, no compaction scan.
+// Same lists, stats and partial sums, bit for bit, as tree_rows_body + dual_select_body.
+
+// (what is the same for every lane is told to the compiler: scalar registers, scalar arithmetic)
+__device__ __forceinline__ int uni_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uni_d(double v) {
+    const long long b = __double_as_longlong(v);
+    return __longlong_as_double(((long long)uni_i((int)(b >> 32)) << 32) | (unsigned int)uni_i((int)b));
+}
+
+// The previous list's rows with a multiplier, ascending: sup / ysup (uniform), their number.  f / yv: the
+// list's first 8 rows and the multipliers there (uniform), pc its length (0 .. 8).  Straight-line code: a
+// taken branch costs a wavefront ~20 cycles (tools/probes/icache_probe.hip), a scalar select one.
+__device__ __forceinline__ int chain_support_sort(const int pc, const long long (&f)[8], const double (&yv)[8],
+                                                  long long (&sup)[8], double (&ysup)[8]) {
+    constexpr long long kNone = 0x7FFFFFFFFFFFFFFFll;
+    int ns = 0;
+    long long last = -1;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {           // selection sort, uniform: rows are distinct
+        long long best = kNone;
+        double yb = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const bool take = k < pc && yv[k] != 0.0 && f[k] > last && f[k] < best;
+            best = take ? f[k] : best;
+            yb = take ? yv[k] : yb;
+        }
+        const bool have = best != kNone;
+        sup[q] = have ? best : -1;
+        ysup[q] = have ? yb : 0.0;
+        ns += have ? 1 : 0;
+        last = have ? best : last;
+    }
+    return ns;
+}
+
+constexpr int kRankMax = 256;
+struct ChainSelScratch {        // LDS of chain_rows_select_body
+    double vval[kRankMax], vv[kRankMax];
+    int vrow[kRankMax];
+    int chosen[kAmax];
+    double vsup[8];
+    double rr[4][4];
+    int vcount;
+};
+
+// Returns false (uniform; nothing published yet) when the previous list is unusable (overflowed, or longer
+// than 8) or more than kRankMax rows are violated: the caller runs the general bodies instead.
+// rmax_out: the slot's largest row residual; sup / ns_out: the support (the new list's head).
+// Loads: two round trips -- {tree indices and weights, the previous list, first()'s} then {the list's
+// multipliers, the gathers of node sums and dual terms, second()'s (which knows the support)}.
+template <class F1, class F2>
+__device__ __forceinline__ bool chain_rows_select_body(const TreeRowsArgs &a, const SelectArgs &sa, const int t,
+                                                       double *lds, double *ylds, ChainSelScratch &cs_,
+                                                       const int64_t *__restrict__ pci, const int32_t *__restrict__ pcc,
+                                                       long long (&sup)[8], int &ns_out,
+                                                       F1 &&first, F2 &&second, double &rmax_out) {
+    const int tid = threadIdx.x, j0 = 8 * tid, T = a.T, m = a.m;
+    const bool act = j0 < a.tree.n;
+    unsigned long long pk[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pk[i] = 0ull;
+    if (act) {
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            const TreeU2 u = *reinterpret_cast<const TreeU2 *>(a.tree.pack + j0 + i);
+            pk[i] = u.v[0]; pk[i + 1] = u.v[1];
+        }
+    }
+    const int pc_raw = pcc[t];
+    long long f_raw[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f_raw[k] = pci[(int64_t)t * kAmax + k];   // (entries beyond the count: row 0)
+    double wgt[8];
+    tree_fetch_w<256, 8>(a.tree, wgt);
+    first();
+    for (int i = tid; i < m; i += 256) ylds[i] = 0.0;
+    if (tid == 0) cs_.vcount = 0;
+    const int pc = uni_i(pc_raw);
+    if (pc < 0 || pc > 8) return false;
+    long long f[8];
+    double yv[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) f[k] = (long long)uni_i((int)f_raw[k]);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) yv[k] = a.y[f[k] * T + t];
+    double v8[8], qv[8];
+    tree_gather_p<256, 8>(a.tree, a.p, T, t, pk, v8, nullptr);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int s = (int)(pk[i] & 0xFFFFu) - 1;
+        const double q = a.qn[(int64_t)(s >= 0 ? s : 0) * T + t];
+        qv[i] = s >= 0 ? q : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) yv[k] = uni_d(yv[k]);
+    double ysup[8];
+    const int ns = chain_support_sort(pc, f, yv, sup, ysup);
+    ns_out = ns;
+    second();
+    __syncthreads();
+    if (tid < 8 && tid < ns) {
+        double mine = 0.0;
+        long long row = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { mine = q == tid ? ysup[q] : mine; row = q == tid ? sup[q] : row; }
+        ylds[row] = mine;                   // (read behind the scans' barriers)
+    }
+    REVS_KVS(t, 1);
+    tree_scan<256, 8>(a.tree, t, lds, v8, wgt, pk);
+    double rmax = 0.0, dsum = 0.0, nsup = 0.0, nvio = 0.0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int s = (int)(pk[i] & 0xFFFFu) - 1;
+        if (s >= 0) {
+            const double v = v8[i], y1 = ylds[s];
+            const bool up = y1 > 0.0 || (y1 == 0.0 && v > a.vhi);
+            const double b = up ? a.vhi : a.vlo;
+            const double vi = fmax(fmax(v - a.vhi, a.vlo - v), 0.0);
+            rmax = fmax(rmax, y1 != 0.0 ? fabs(v - b) : vi);
+            dsum += qv[i] - fmax(a.vhi * y1, a.vlo * y1);
+            nsup += y1 != 0.0 ? 1.0 : 0.0;
+            nvio += (y1 == 0.0 && vi > 0.0) ? 1.0 : 0.0;
+            if (a.ycopy_out) a.ycopy_out[(int64_t)s * T + t] = y1;
+            if (y1 != 0.0) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) if (sup[q] == (long long)s) cs_.vsup[q] = v;
+            } else if (vi > 0.0) {
+                const int q = atomicAdd(&cs_.vcount, 1);
+                if (q < kRankMax) { cs_.vval[q] = vi; cs_.vv[q] = v; cs_.vrow[q] = s; }
+            }
+        }
+    }
+    REVS_KVS(t, 6);
+    rmax = wave_max_d(rmax); dsum = wave_sum_d(dsum); nsup = wave_sum_d(nsup); nvio = wave_sum_d(nvio);
+    if ((tid & 63) == 0) { cs_.rr[0][tid >> 6] = rmax; cs_.rr[1][tid >> 6] = dsum; cs_.rr[2][tid >> 6] = nsup; cs_.rr[3][tid >> 6] = nvio; }
+    __syncthreads();
+    REVS_KVS(t, 7);
+    const double o0 = fmax(fmax(cs_.rr[0][0], cs_.rr[0][1]), fmax(cs_.rr[0][2], cs_.rr[0][3]));
+    const double o1 = ((cs_.rr[1][0] + cs_.rr[1][1]) + cs_.rr[1][2]) + cs_.rr[1][3];
+    const double o2 = ((cs_.rr[2][0] + cs_.rr[2][1]) + cs_.rr[2][2]) + cs_.rr[2][3];
+    const double o3 = ((cs_.rr[3][0] + cs_.rr[3][1]) + cs_.rr[3][2]) + cs_.rr[3][3];
+    const int nv = (int)o3;
+    if (nv > kRankMax || (int)o2 != ns) return false;      // (uniform; the second never happens)
+    // what dual_select_body folds from the one block of partials: max(0, .) and 0 + .
+    const double rmax_t = fmax(0.0, o0);
+    if (tid == 0) {
+        double *o = a.partial + (int64_t)t * 4;
+        o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3;
+        double *stats = sa.stats;
+        stats[t * 8 + 0] = rmax_t;
+        stats[t * 8 + 1] = 0.0 + o1;
+        stats[t * 8 + 2] = (double)ns;
+        stats[t * 8 + 3] = (double)nv;
+        if (!sa.lazy) __threadfence_system();
+        reinterpret_cast<volatile double *>(stats)[t * 8 + 5] = sa.seq;
+    }
+    rmax_out = rmax_t;
+    int64_t *ci = sa.cidx + (int64_t)t * kAmax;
+    double *cs = sa.cval + (int64_t)t * 3 * kAmax, *cg = cs + kAmax, *cy = cg + kAmax;
+    SlotLists *const ll = sa.ll;
+    const int room = (ns == 0 && nv == 0) ? 0 : min(min(sa.kadd, kAmax - ns), nv);
+    const int nq = min(cs_.vcount, kRankMax);
+    if (room > 0 && tid < nq) {
+        const double x = cs_.vval[tid];
+        const int r = cs_.vrow[tid];
+        int rank = 0;
+        for (int j = 0; j < nq; ++j) {
+            const double xj = cs_.vval[j];
+            rank += (xj > x || (xj == x && cs_.vrow[j] < r)) ? 1 : 0;
+        }
+        if (rank < room) cs_.chosen[rank] = tid;
+    }
+    const int added = min(room, nq);
+    __syncthreads();
+    REVS_KVS(t, 10);
+    const int cnt = ns + added;
+    if (tid < kAmax) {
+        long long e_ci = 0;
+        double e_cs = 1.0, e_cg = 0.0, e_cy = 0.0;
+        if (tid < ns) {
+            double yv = 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (q == tid) { yv = ysup[q]; e_ci = sup[q]; }
+            e_cs = yv > 0.0 ? 1.0 : -1.0;
+            e_cg = cs_.vsup[tid] - (yv > 0.0 ? a.vhi : a.vlo);
+            e_cy = yv;
+        } else if (tid < cnt) {
+            const int q = cs_.chosen[tid - ns];
+            const double v = cs_.vv[q];
+            const bool up = v > a.vhi;
+            e_ci = cs_.vrow[q];
+            e_cs = up ? 1.0 : -1.0;
+            e_cg = v - (up ? a.vhi : a.vlo);
+        }
+        ci[tid] = e_ci; cs[tid] = e_cs; cg[tid] = e_cg; cy[tid] = e_cy;
+        if (ll) { ll->ci[tid] = e_ci; ll->cs[tid] = e_cs; ll->cg[tid] = e_cg; ll->cy[tid] = e_cy; }
+    }
+    if (tid == 0) { sa.ccnt[t] = cnt; if (ll) ll->cnt = cnt; }
+    return true;
+}
+
 // Small model, step and the trial's shifts of one slot in one piece -- the folded chain's usual case: at
 // most 8 candidates (the list in LDS, left there by the selection: SlotLists) and at most 2048 rows.
 // The same arithmetic, term for term, as small_model_body + dual_step_body + chain_shifts_body (the
@@ -913,66 +1137,64 @@ __device__ __forceinline__ void chain_shifts_body(const int t, int m, int T, con
 // elements, 8 nodes x 8 rows per thread, kept in registers across the pivoting -- the column of N is
 // requested by the caller before the rows are even judged (nn[j] = N[tid + 256 j][t]), the wavefront
 // sums run over the a (a + 1) / 2 entries that exist, and multipliers, step and list stay in LDS.
+template <int A>
 __device__ __forceinline__ void chain_fast_body(
         const int t, const int m, const int T, const double *__restrict__ R, const double (&nn)[8],
+        double (&r)[8][kSmall], const int npre,
         const SlotLists *ll, const double inv_kappa, const double delta, const int max_pivots, const double al,
         double *__restrict__ Kall, double *__restrict__ yhat, int32_t *__restrict__ info,
         double *__restrict__ ytrial, double *__restrict__ lin_out, double *__restrict__ sh_a,
         double *__restrict__ sh_b) {
+    // A = the candidate count: every loop below has compile-time bounds and no branch on it -- straight-line
+    // code (a taken branch costs a wavefront ~20 cycles, and these workgroups are nothing but latency)
     const int tid = threadIdx.x;
-    // (what is the same for every lane is told to the compiler: scalar registers, scalar address arithmetic)
-    auto uni_i = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
-    auto uni_d = [&](double v) {
-        const long long b = __double_as_longlong(v);
-        return __longlong_as_double(((long long)uni_i((int)(b >> 32)) << 32) | (unsigned int)uni_i((int)b));
-    };
-    const int a = uni_i(ll->cnt);           // 1 .. 8 (the caller checked)
-    long long f[kSmall];
+    long long f[A];
 #pragma unroll
-    for (int i = 0; i < kSmall; ++i) f[i] = i < a ? (long long)uni_i((int)ll->ci[i]) : -1;
-    double r[8][kSmall];
+    for (int i = 0; i < A; ++i) f[i] = (long long)uni_i((int)ll->ci[i]);
+    // (the first npre rows -- the support known before the voltages were -- are here already)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int mm = tid + 256 * j;
+    for (int i = 0; i < A; ++i) {
+        if (i >= npre) {                    // uniform
 #pragma unroll
-        for (int i = 0; i < kSmall; ++i) r[j][i] = (f[i] >= 0 && mm < m) ? R[f[i] * m + mm] : 0.0;
-    }
-    REVS_KVS(t, 12);
-    double acc[kSmall * (kSmall + 1) / 2];
-#pragma unroll
-    for (int p = 0; p < kSmall * (kSmall + 1) / 2; ++p) acc[p] = 0.0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        if (tid + 256 * j < m) {
-            int p = 0;
-#pragma unroll
-            for (int i = 0; i < kSmall; ++i) {
-                const double rn = r[j][i] * nn[j];
-#pragma unroll
-                for (int jj = i; jj < kSmall; ++jj) acc[p++] += rn * r[j][jj];
+            for (int j = 0; j < 8; ++j) {
+                const int mm = tid + 256 * j;
+                const double v = R[f[i] * m + (mm < m ? mm : 0)];
+                r[j][i] = mm < m ? v : 0.0;
             }
         }
     }
-    __shared__ double part[4][kSmall * (kSmall + 1) / 2];
+    REVS_KVS(t, 12);
+    constexpr int kTri = kSmall * (kSmall + 1) / 2;
+    auto tri = [](int i, int jj) { return i * kSmall - i * (i - 1) / 2 + (jj - i); };   // (i <= jj)
+    double acc[kTri];
+#pragma unroll
+    for (int p = 0; p < kTri; ++p) acc[p] = 0.0;
+    // (nodes beyond m carry r = 0 and N = 0: their terms add exactly nothing)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+            const double rn = r[j][i] * nn[j];
+#pragma unroll
+            for (int jj = i; jj < A; ++jj) acc[tri(i, jj)] += rn * r[j][jj];
+        }
+    }
+    __shared__ double part[4][kTri];
     __shared__ double Ks[kSmall][kSmall];
     __shared__ double yo_s[kSmall];
     REVS_KVS(t, 13);
-    {
-        int p = 0;
 #pragma unroll
-        for (int i = 0; i < kSmall; ++i)
+    for (int i = 0; i < A; ++i)
 #pragma unroll
-            for (int jj = i; jj < kSmall; ++jj, ++p)
-                if (jj < a) {               // uniform
-                    const double v = wave_sum_d(acc[p]);
-                    if ((tid & 63) == 0) part[tid >> 6][p] = v;
-                }
-    }
+        for (int jj = i; jj < A; ++jj) {
+            const double v = wave_sum_d(acc[tri(i, jj)]);
+            if ((tid & 63) == 0) part[tid >> 6][tri(i, jj)] = v;
+        }
     __syncthreads();
     REVS_KVS(t, 14);
     if (tid < kSmall * kSmall) {
         const int i = tid / kSmall, j = tid % kSmall;
-        if (i < a && j < a) {
+        if (i < A && j < A) {
             const int lo = i < j ? i : j, hi = i < j ? j : i;
             const int p = lo * kSmall - lo * (lo - 1) / 2 + (hi - lo);
             const double v = (((part[0][p] + part[1][p]) + part[2][p]) + part[3][p]) * inv_kappa;
@@ -984,34 +1206,25 @@ __device__ __forceinline__ void chain_fast_body(
     REVS_KVS(t, 15);
     if (tid == 0) {
         int32_t inf;
-        switch (a) {                        // one thread; loops sized by the candidate count
-            case 1: small_bpp<1>(Ks, ll->cs, ll->cg, ll->cy, delta, max_pivots, yo_s, &inf, kSmall); break;
-            case 2: small_bpp<2>(Ks, ll->cs, ll->cg, ll->cy, delta, max_pivots, yo_s, &inf, kSmall); break;
-            case 3: small_bpp<3>(Ks, ll->cs, ll->cg, ll->cy, delta, max_pivots, yo_s, &inf, kSmall); break;
-            case 4: small_bpp<4>(Ks, ll->cs, ll->cg, ll->cy, delta, max_pivots, yo_s, &inf, kSmall); break;
-            case 5: small_bpp<5>(Ks, ll->cs, ll->cg, ll->cy, delta, max_pivots, yo_s, &inf, kSmall); break;
-            case 6: small_bpp<6>(Ks, ll->cs, ll->cg, ll->cy, delta, max_pivots, yo_s, &inf, kSmall); break;
-            case 7: small_bpp<7>(Ks, ll->cs, ll->cg, ll->cy, delta, max_pivots, yo_s, &inf, kSmall); break;
-            default: small_bpp<8>(Ks, ll->cs, ll->cg, ll->cy, delta, max_pivots, yo_s, &inf, kSmall); break;
-        }
+        small_bpp<A>(Ks, ll->cs, ll->cg, ll->cy, delta, max_pivots, yo_s, &inf, kSmall);
         info[t] = inf;
         REVS_KVS(t, 16);
     }
     __syncthreads();
     if (tid < kAmax) yhat[(int64_t)t * kAmax + tid] = tid < kSmall ? yo_s[tid] : 0.0;
     // the step (dual_step_body), every thread for itself: y_trial at the candidates, in list order
-    double yn[kSmall];
+    double yn[A];
 #pragma unroll
-    for (int i = 0; i < kSmall; ++i) {
+    for (int i = 0; i < A; ++i) {
         const double yo = ll->cy[i], yh = yo_s[i];
-        yn[i] = uni_d(i < a ? (al == 1.0 ? yh : (al == 0.0 ? yo : yo + al * (yh - yo))) : 0.0);
+        yn[i] = uni_d(al == 1.0 ? yh : (al == 0.0 ? yo : yo + al * (yh - yo)));
     }
     if (tid < 64) {
         double lin = 0.0;
-        if (tid < a) {
+        if (tid < A) {
             double mine = 0.0;
 #pragma unroll
-            for (int i = 0; i < kSmall; ++i) mine = i == tid ? yn[i] : mine;
+            for (int i = 0; i < A; ++i) mine = i == tid ? yn[i] : mine;
             ytrial[ll->ci[tid] * T + t] = mine;
             lin += ll->cg[tid] * (mine - ll->cy[tid]);
         }
@@ -1021,50 +1234,60 @@ __device__ __forceinline__ void chain_fast_body(
     REVS_KVS(t, 18);
     // the shifts (chain_shifts_body): list order -- a term with y = 0 adds exactly nothing, so the rows
     // need no compaction -- and, where it differs, ascending row order of the rows that carry a multiplier
-    int ord[kSmall], ns = 0;
     bool same = true;
     {   // list order restricted to the rows with a multiplier ascending already (the usual case)?
         long long last = -1;
 #pragma unroll
-        for (int k2 = 0; k2 < kSmall; ++k2)
-            if (k2 < a && yn[k2] != 0.0) { same = same && f[k2] > last; last = f[k2]; }
+        for (int k2 = 0; k2 < A; ++k2) {
+            const bool nz = yn[k2] != 0.0;
+            same = same && (!nz || f[k2] > last);
+            last = nz ? f[k2] : last;
+        }
     }
+    REVS_KVS(t, 19);
+    if (same) {
 #pragma unroll
-    for (int q = 0; q < kSmall; ++q) ord[q] = -1;
-    if (!same) {
+        for (int j = 0; j < 8; ++j) {
+            const int node = tid + 256 * j;
+            double d = 0.0;
+#pragma unroll
+            for (int k2 = 0; k2 < A; ++k2) d = __builtin_fma(r[j][k2], yn[k2], d);
+            if (node < m) {
+                sh_a[(int64_t)t * m + node] = d * inv_kappa;
+                sh_b[(int64_t)t * m + node] = d * inv_kappa;
+            }
+        }
+        return;
+    }
+    int ord[A], ns = 0;
+    {
         long long last = -1;
 #pragma unroll
-        for (int q = 0; q < kSmall; ++q) {
+        for (int q = 0; q < A; ++q) {
             long long best = 0x7FFFFFFFFFFFFFFFll;
             int bk = -1;
 #pragma unroll
-            for (int k2 = 0; k2 < kSmall; ++k2)
-                if (k2 < a && yn[k2] != 0.0 && f[k2] > last && f[k2] < best) { best = f[k2]; bk = k2; }
+            for (int k2 = 0; k2 < A; ++k2)
+                if (yn[k2] != 0.0 && f[k2] > last && f[k2] < best) { best = f[k2]; bk = k2; }
             ord[q] = bk;
             if (bk >= 0) { ++ns; last = best; }
         }
     }
-    REVS_KVS(t, 19);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int node = tid + 256 * j;
         if (node >= m) continue;
-        double d = 0.0;
+        double d = 0.0, ds = 0.0;
 #pragma unroll
-        for (int k2 = 0; k2 < kSmall; ++k2)
-            if (k2 < a) d = __builtin_fma(r[j][k2], yn[k2], d);
-        double ds = d;
-        if (!same) {
-            ds = 0.0;
+        for (int k2 = 0; k2 < A; ++k2) d = __builtin_fma(r[j][k2], yn[k2], d);
 #pragma unroll
-            for (int q = 0; q < kSmall; ++q) {
-                if (q < ns) {
-                    double rv = 0.0, yq = 0.0;
+        for (int q = 0; q < A; ++q) {
+            if (q < ns) {
+                double rv = 0.0, yq = 0.0;
 #pragma unroll
-                    for (int k2 = 0; k2 < kSmall; ++k2)
-                        if (k2 == ord[q]) { rv = r[j][k2]; yq = yn[k2]; }
-                    ds = __builtin_fma(rv, yq, ds);
-                }
+                for (int k2 = 0; k2 < A; ++k2)
+                    if (k2 == ord[q]) { rv = r[j][k2]; yq = yn[k2]; }
+                ds = __builtin_fma(rv, yq, ds);
             }
         }
         sh_a[(int64_t)t * m + node] = d * inv_kappa;
@@ -1082,18 +1305,34 @@ struct ChainKvArgs {
     double *clr0, *clr1;
     long long clr_count;
     double *sh_a, *sh_b;
+    const int64_t *prev_ci;
+    const int32_t *prev_cc;
+    double *stamps;             // tuning build only
 };
 __global__ __launch_bounds__(256) void op_chain_kv_kernel(const ChainKvArgs k) {
     extern __shared__ double tree_lds[];
     const int T = k.s1.T, m = k.s1.m;
+    REVS_KVS_BEGIN((k.has_e2 && (int)blockIdx.x < T) ? nullptr : k.stamps);
     // (the rows of a slot go to its selection through LDS: double[3 m + 4] behind the tree's scan buffer)
     double *rows_lds = tree_lds + (tree_lds_bytes(k.e1.tree.n) / sizeof(double) + 1) / 2 * 2;
+    __shared__ ChainSelScratch sel_s;
+    long long sup[8];
     if (k.has_e2 && (int)blockIdx.x < T) {
-        tree_rows_body(k.e2, blockIdx.x, tree_lds, rows_lds);
-        __syncthreads();
-        SelectArgs s2 = k.s2;
-        s2.rows_lds = rows_lds;
-        dual_select_body<true>(s2, blockIdx.x);
+        const int t2 = blockIdx.x;
+        double rm2;
+        int ns2;
+        bool done = false;
+        if (k.prev_cc)
+            done = chain_rows_select_body(k.e2, k.s2, t2, tree_lds, rows_lds, sel_s, k.prev_ci, k.prev_cc, sup, ns2,
+                                          NoPrefetch(), NoPrefetch(), rm2);
+        if (!done) {
+            __syncthreads();
+            tree_rows_body(k.e2, t2, tree_lds, rows_lds);
+            __syncthreads();
+            SelectArgs s2 = k.s2;
+            s2.rows_lds = rows_lds;
+            dual_select_body<true>(s2, t2);
+        }
         // the verdict is out: these workgroups have time left -- they clear the two sum arrays the NEXT
         // sweep accumulates into (behind everything the other half of the launch has to fetch)
         const long long per = (k.clr_count + T - 1) / T;
@@ -1108,28 +1347,71 @@ __global__ __launch_bounds__(256) void op_chain_kv_kernel(const ChainKvArgs k) {
     // (tuning build: stamps 0 | 1-6 rows | 7-10 selection | 11-16 model | 17 step | 18-20 shifts)
 #define KV_STAMP(i) REVS_KVS(t, i)
     KV_STAMP(0);
-    // this slot's column of N (the model's weights): needed after the selection, requested now
-    double nn[8];
     __shared__ SlotLists lists;
-    tree_rows_body(k.e1, t, tree_lds, rows_lds, [&]() {
+    double nn[8], r[8][kSmall];
+    int npre = 0;
+    // this slot's column of N (the model's weights) and the rows of R of the multipliers' support: needed
+    // after the selection, requested in front of it
+    auto fetch_nn = [&]() {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int mm = threadIdx.x + 256 * j;
-            nn[j] = mm < m ? k.f1.Nn[(int64_t)mm * T + t] : 0.0;
+            const double v = k.f1.Nn[(int64_t)(mm < m ? mm : 0) * T + t];
+            nn[j] = mm < m ? v : 0.0;
         }
-    });
-    __syncthreads();
-    KV_STAMP(7);
-    SelectArgs s1 = k.s1;
-    s1.rows_lds = rows_lds;
-    s1.ll = &lists;
-    const double rmax = dual_select_body<true>(s1, t);
+    };
+    double rmax = 0.0;
+    bool done = false;
+    if (k.prev_cc) {
+        SelectArgs s1 = k.s1;
+        s1.ll = &lists;
+        int ns1 = 0;
+        done = chain_rows_select_body(k.e1, s1, t, tree_lds, rows_lds, sel_s, k.prev_ci, k.prev_cc, sup, ns1, fetch_nn,
+                                      [&]() {
+            if (m <= 2048) {
+#pragma unroll
+                for (int q = 0; q < kSmall; ++q) {
+                    if (q < ns1) {          // uniform
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const int mm = threadIdx.x + 256 * j;
+                            const double v = k.f1.R[sup[q] * m + (mm < m ? mm : 0)];
+                            r[j][q] = mm < m ? v : 0.0;
+                        }
+                    }
+                }
+            }
+        }, rmax);
+        if (done && m <= 2048) npre = ns1;
+    }
+    if (!done) {
+        __syncthreads();
+        tree_rows_body(k.e1, t, tree_lds, rows_lds, fetch_nn);
+        __syncthreads();
+        KV_STAMP(7);
+        SelectArgs s1 = k.s1;
+        s1.rows_lds = rows_lds;
+        s1.ll = &lists;
+        rmax = dual_select_body<true>(s1, t);
+    }
     __syncthreads();
     KV_STAMP(11);
     const double al = rmax / k.f1.scale > k.f1.eps ? 1.0 : 0.0;
-    if (lists.cnt >= 1 && lists.cnt <= kSmall && m <= 2048) {       // uniform
-        chain_fast_body(t, m, T, k.f1.R, nn, &lists, k.f1.inv_kappa, k.f1.delta, k.f1.max_pivots, al, k.f1.Kall,
-                        k.f1.yhat, k.f1.info, k.f1.ytrial, k.f1.lin_out, k.sh_a, k.sh_b);
+    const int cnt1 = uni_i(lists.cnt);
+    if (cnt1 >= 1 && cnt1 <= kSmall && m <= 2048) {
+#define REVS_FAST(A) chain_fast_body<A>(t, m, T, k.f1.R, nn, r, npre, &lists, k.f1.inv_kappa, k.f1.delta, k.f1.max_pivots, al, \
+                                        k.f1.Kall, k.f1.yhat, k.f1.info, k.f1.ytrial, k.f1.lin_out, k.sh_a, k.sh_b)
+        switch (cnt1) {
+            case 1: REVS_FAST(1); break;
+            case 2: REVS_FAST(2); break;
+            case 3: REVS_FAST(3); break;
+            case 4: REVS_FAST(4); break;
+            case 5: REVS_FAST(5); break;
+            case 6: REVS_FAST(6); break;
+            case 7: REVS_FAST(7); break;
+            default: REVS_FAST(8); break;
+        }
+#undef REVS_FAST
         KV_STAMP(20);
         return;
     }
@@ -1173,23 +1455,17 @@ int chain_kv_launch(const ChainKv &c, void *stream) {
                      c.y_trial, c.lin_out, c.info};
     k.clr0 = c.clr0; k.clr1 = c.clr1; k.clr_count = 3 * mt;
     k.sh_a = c.sh_a; k.sh_b = c.sh_b;
+    k.prev_ci = c.prev_cidx; k.prev_cc = c.prev_cidx ? c.prev_ccnt : nullptr;
     const size_t lds = ((tree_lds_bytes(c.tree.n) / sizeof(double) + 1) / 2 * 2 + 3 * (size_t)c.m + 4) * sizeof(double);
     if (lds > 64 * 1024) {       // (more than 64 KB of dynamic LDS has to be granted, once)
         static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&op_chain_kv_kernel),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 16384);
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         if (e != hipSuccess) {
             revs::set_error("chain_kv_launch: %zu bytes of LDS refused: %s", lds, hipGetErrorString(e));
             return REVS_ELAUNCH;
         }
     }
-#ifdef REVS_KV_STAMPS
-    {
-        double *sp = c.sh_b + mt;
-        const int first = c.has_e2 ? c.T : 0;
-        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(kvs_ptr), &sp, sizeof(sp), 0, hipMemcpyHostToDevice, (hipStream_t)stream);
-        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(kvs_first), &first, sizeof(first), 0, hipMemcpyHostToDevice, (hipStream_t)stream);
-    }
-#endif
+    k.stamps = c.sh_b + mt;
     hipLaunchKernelGGL(op_chain_kv_kernel, dim3((c.has_e2 ? 2 : 1) * c.T), dim3(256), lds, (hipStream_t)stream, k);
     REVS_CHECK_LAUNCH("chain_kv_launch");
     return REVS_OK;

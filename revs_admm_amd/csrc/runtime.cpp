@@ -624,6 +624,8 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
         c.clr1 = plan->fold_e1[par];
         c.sh_a = plan->fold_sh[0];
         c.sh_b = plan->fold_sh[1];
+        c.prev_cidx = S0.ci;                  // the lists of the launch whose step wrote y_trial
+        c.prev_ccnt = S0.cc;
         rc = revs::chain_kv_launch(c, stream);
         if (rc != REVS_OK) return rc;
         // the trial's verdict: poll its tags (pinned memory), then the driver's own acceptance test
@@ -697,9 +699,9 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
             if (h[32 * t + 20] - h[32 * t] > h[32 * worst + 20] - h[32 * worst]) worst = t;
         // 0 start | 1-6 rows | 7-10 selection | 11-16 model | 17 step | 18-20 shifts: microseconds since the slot's start
         fprintf(stderr, "[kv stamps, us since start] slowest slot %d:", worst);
-        for (int i = 1; i <= 20; ++i) fprintf(stderr, " %d:%.1f", i, (h[32 * worst + i] - h[32 * worst]) * 0.01);
+        for (int i = 1; i <= 23; ++i) fprintf(stderr, " %d:%.1f", i, (h[32 * worst + i] - h[32 * worst]) * 0.01);
         fprintf(stderr, "\n[kv stamps, mean over slots]            ");
-        for (int i = 1; i <= 20; ++i) {
+        for (int i = 1; i <= 23; ++i) {
             double acc = 0;
             for (int t = 0; t < d.T; ++t) acc += (h[32 * t + i] - h[32 * t]) * 0.01;
             fprintf(stderr, " %d:%.1f", i, acc / d.T);

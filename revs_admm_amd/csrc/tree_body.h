@@ -86,27 +86,28 @@ struct alignas(16) TreeD2 { double v[2]; };
 // ALL the static data of a thread -- four 16-bit indices per position packed in one 64-bit word,
 // and the weights -- are requested at the very top, and the only dependent global access is the
 // gather of the node sums behind them.
-template <int NT, int IPT, bool PK_LOADED = false>
-__device__ __forceinline__ void tree_voltage(const TreeArgs &tr, const double *p, int T, int t,
-                                             double *lds, double (&a)[IPT], unsigned long long (&pk)[IPT],
-                                             double *p_clear) {
-    const int tid = threadIdx.x, n = tr.n, j0 = IPT * tid;
-    const bool act = j0 < n;
-    double *base = lds + 2, *red0 = lds + 2 + NT * IPT, *red1 = red0 + NT / 64;
-    if (tid == 0) lds[1] = 0.0;                                 // base[-1]
-    double b[IPT];
+// The three pieces of tree_voltage, for callers that order their own loads around them:
+// the weights (static), the gather of the node sums (waits for the packed indices), the scans.
+template <int NT, int IPT>
+__device__ __forceinline__ void tree_fetch_w(const TreeArgs &tr, double (&b)[IPT]) {
+    const int j0 = IPT * threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < IPT; ++i) { if (!PK_LOADED) pk[i] = 0ull; a[i] = 0.0; b[i] = 0.0; }
-    if (act) {
+    for (int i = 0; i < IPT; ++i) b[i] = 0.0;
+    if (j0 < tr.n) {
 #pragma unroll
         for (int i = 0; i < IPT; i += 2) {
-            if (!PK_LOADED) {
-                const TreeU2 u = *reinterpret_cast<const TreeU2 *>(tr.pack + j0 + i);
-                pk[i] = u.v[0]; pk[i + 1] = u.v[1];
-            }
             const TreeD2 wv = *reinterpret_cast<const TreeD2 *>(tr.w + j0 + i);
-            b[i] = wv.v[0]; b[i + 1] = wv.v[1];                 // (b holds the weights until phase 2)
+            b[i] = wv.v[0]; b[i + 1] = wv.v[1];
         }
+    }
+}
+template <int NT, int IPT>
+__device__ __forceinline__ void tree_gather_p(const TreeArgs &tr, const double *p, int T, int t,
+                                              const unsigned long long (&pk)[IPT], double (&a)[IPT], double *p_clear) {
+    const int j0 = IPT * threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) a[i] = 0.0;
+    if (j0 < tr.n) {
         // C: inclusive prefix of the injections in preorder
 #pragma unroll
         for (int i = 0; i < IPT; ++i) {
@@ -121,6 +122,15 @@ __device__ __forceinline__ void tree_voltage(const TreeArgs &tr, const double *p
             }
         }
     }
+}
+// a: the gathered node sums, b: the weights (both zero beyond the tree); out: a = the voltages
+template <int NT, int IPT>
+__device__ __forceinline__ void tree_scan(const TreeArgs &tr, int t, double *lds, double (&a)[IPT], double (&b)[IPT],
+                                          const unsigned long long (&pk)[IPT]) {
+    const int tid = threadIdx.x, n = tr.n, j0 = IPT * tid;
+    const bool act = j0 < n;
+    double *base = lds + 2, *red0 = lds + 2 + NT * IPT, *red1 = red0 + NT / 64;
+    if (tid == 0) lds[1] = 0.0;                                 // base[-1]
 #pragma unroll
     for (int i = 1; i < IPT; ++i) a[i] += a[i - 1];
     REVS_KVS(t, 2);
@@ -167,6 +177,28 @@ __device__ __forceinline__ void tree_voltage(const TreeArgs &tr, const double *p
         const int s = (int)(pk[i] & 0xFFFFu) - 1;
         a[i] = (act && s >= 0) ? (a[i] + pex) - base[(int)(pk[i] >> 48) - 1] : 0.0;
     }
+}
+
+template <int NT, int IPT, bool PK_LOADED = false>
+__device__ __forceinline__ void tree_voltage(const TreeArgs &tr, const double *p, int T, int t,
+                                             double *lds, double (&a)[IPT], unsigned long long (&pk)[IPT],
+                                             double *p_clear) {
+    const int j0 = IPT * threadIdx.x;
+    if (!PK_LOADED) {
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) pk[i] = 0ull;
+        if (j0 < tr.n) {
+#pragma unroll
+            for (int i = 0; i < IPT; i += 2) {
+                const TreeU2 u = *reinterpret_cast<const TreeU2 *>(tr.pack + j0 + i);
+                pk[i] = u.v[0]; pk[i + 1] = u.v[1];
+            }
+        }
+    }
+    double b[IPT];                                              // (b holds the weights until phase 2)
+    tree_fetch_w<NT, IPT>(tr, b);
+    tree_gather_p<NT, IPT>(tr, p, T, t, pk, a, p_clear);
+    tree_scan<NT, IPT>(tr, t, lds, a, b, pk);
 }
 
 // Largest violation max(v - vhi, vlo - v, 0) over the checked rows of slot t (every thread
