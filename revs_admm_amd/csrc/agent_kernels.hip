@@ -109,8 +109,10 @@ struct AgentArgs {
 };
 constexpr int kMaxInner = REVS_AGENT_MAX_INNER;
 constexpr int shape_max_inner(int slots) {      // inner iterations whose node-sum accumulators fit 24 KB of LDS
-    return 24576 / (4 * slots * 8) >= kMaxInner ? kMaxInner : (24576 / (4 * slots * 8) >= 8 ? 8 : (24576 / (4 * slots * 8) >= 4 ? 4 : (24576 / (4 * slots * 8) >= 2 ? 2 : 1)));
+    const int fit = 24576 / (4 * slots * 8);
+    return fit >= kMaxInner ? kMaxInner : (fit >= 16 ? 16 : (fit >= 8 ? 8 : (fit >= 4 ? 4 : (fit >= 2 ? 2 : 1))));
 }
+
 #ifndef REVS_AGENT_MULTI_WAVES
 #define REVS_AGENT_MULTI_WAVES 5     // wavefronts per SIMD of the multi-iteration sweep (tuning: build with -D)
 #endif

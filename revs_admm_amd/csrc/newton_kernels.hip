@@ -1415,6 +1415,18 @@ __global__ __launch_bounds__(256) void op_chain_kv_kernel(const ChainKvArgs k) {
         KV_STAMP(20);
         return;
     }
+    if (cnt1 == 0) {
+        // a slot without multipliers or violated rows: what the three bodies below would do with an empty
+        // list -- yhat = the (zero) multipliers, no step, lin = 0, shifts zero -- without their loops
+        if (threadIdx.x < kAmax) k.f1.yhat[(int64_t)t * kAmax + threadIdx.x] = 0.0;
+        if (threadIdx.x == 0) { k.f1.info[t] = 0; k.f1.lin_out[t * 8] = 0.0; }
+        for (int node = threadIdx.x; node < m; node += 256) {
+            k.sh_a[(int64_t)t * m + node] = 0.0;
+            k.sh_b[(int64_t)t * m + node] = 0.0;
+        }
+        KV_STAMP(20);
+        return;
+    }
     small_model_body(t, m, T, k.f1.R, k.f1.Nn, k.s1.cidx, k.s1.ccnt, k.s1.cval, k.f1.inv_kappa, k.f1.delta,
                      k.f1.max_pivots, k.f1.Kall, k.f1.yhat, k.f1.info);
     __syncthreads();

@@ -129,7 +129,7 @@ class OperatorOptions:
     # ... and, with blocks, this many consecutive ADMM iterations per sweep launch: no verdict is
     # needed between them, so every residence's state stays in registers (revs_agent_step_multi;
     # profiles read and written once per stream_inner iterations, same bits as one launch each)
-    stream_inner: int = 16       # (the library bounds it by the launch's LDS: 16 up to T = 32, 8 up to 96)
+    stream_inner: int = 32       # (the library bounds it by the launch's LDS: 32 up to T = 24, 16 up to 48, 8 up to 96)
     # ... with the all-reduce and the verdicts of a block on a second stream, beside the sweeps of
     # the next block (the collective is hidden as long as it is shorter than a block of sweeps)
     stream_overlap: bool = True
@@ -467,6 +467,7 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
             self._inner = max(1, min(int(self.op.stream_inner), int(self.lib.revs_agent_max_inner(T))))
             check(self.lib.revs_plan_set_stream_inner(self._plan, self._inner), "revs_plan_set_stream_inner")
             self._sets_st = _lib.StreamSets()
+            self._sets_by, self._sets_sig, self._pn_ptr = {}, None, {}
             self._sets_ref = C.byref(self._sets_st)
         # R (float) for the voltage check
         self.R32 = up(Rn.astype(np.float32))

@@ -147,25 +147,32 @@ class SteadyStateMixin:
         if self.group is not None and not self._ar_ahead:
             self._allreduce(p0)
         pool = self._sets
+        st, by = self._sets_st, self._sets_by
+        # The native call leaves the sets in the order the next call wants them (slot 0 = the state).  As long
+        # as nothing else has touched the engine's tensors since, the struct is handed back as it is.
+        sig = (id(self.P_est), id(self.P_est_new), id(self.P_sch), id(self.G), id(self.pdhg_dual))
+        if sig != self._sets_sig:
+            def roles(first, tensors, skip=()):
+                rest = [t for t in tensors if t is not first and all(t is not x for x in skip)]
+                return [first] + rest
 
-        def roles(first, tensors, skip=()):
-            rest = [t for t in tensors if t is not first and all(t is not x for x in skip)]
-            return [first] + rest
-
-        pes = roles(self.P_est, pool["pe"], skip=(self.P_est_new,))
-        pss, gs = roles(self.P_sch, pool["ps"]), roles(self.G, pool["g"])
-        ys = roles(self.pdhg_dual, pool["y"]) if pool["y"] is not None else [None] * 4
-        assert len(pes) == len(pss) == len(gs) == len(ys) == 4
-        st, by = self._sets_st, {}
-        for i in range(4):
-            for arr, t in ((st.p_est, pes[i]), (st.p_sch, pss[i]), (st.gamma, gs[i]), (st.pdhg_dual, ys[i])):
-                arr[i] = None if t is None else _dp(t)
-                if t is not None:
-                    by[_dp(t)] = t
+            pes = roles(self.P_est, pool["pe"], skip=(self.P_est_new,))
+            pss, gs = roles(self.P_sch, pool["ps"]), roles(self.G, pool["g"])
+            ys = roles(self.pdhg_dual, pool["y"]) if pool["y"] is not None else [None] * 4
+            assert len(pes) == len(pss) == len(gs) == len(ys) == 4
+            for i in range(4):
+                for arr, t in ((st.p_est, pes[i]), (st.p_sch, pss[i]), (st.gamma, gs[i]), (st.pdhg_dual, ys[i])):
+                    arr[i] = None if t is None else _dp(t)
+                    if t is not None:
+                        by[_dp(t)] = t
+            st.p_est_next = _dp(self.P_est_new)
         if self._pn0 is None:
             self._pn0 = self.pnq[0]
+            self._pn_ptr = {id(self._pn0): _dp(self._pn0), id(self.p_alt): _dp(self.p_alt)}
         p0_out = self.p_alt if p0 is self._pn0 else self._pn0      # (the sums handed over for the next call)
-        st.p0, st.p0_out, st.p_est_next = _dp(p0), _dp(p0_out), _dp(self.P_est_new)
+        pp = self._pn_ptr
+        st.p0 = pp[id(p0)] if id(p0) in pp else _dp(p0)
+        st.p0_out = pp[id(p0_out)]
         st.diff_hist = None if hist is None else hist.data_ptr()
         count = min(count, self._burst, 1000)
         kept, rm = self._stream_out
@@ -181,13 +188,15 @@ class SteadyStateMixin:
         self.G, self.G_alt = by[st.gamma[0]], by[st.gamma[1]]
         if pool["y"] is not None:
             self.pdhg_dual = by[st.pdhg_dual[0]]       # (the plan already points at it)
+        self._sets_sig = ((id(self.P_est), id(self.P_est_new), id(self.P_sch), id(self.G), id(self.pdhg_dual))
+                          if n == count else None)
         self._p_clear = None
         self._prod_ahead = False
         self._ar_ahead = self.group is not None
         if n == count:
             self._fused_p = p0_out
-        for i in range(n):
-            self.max_diff[self.iteration + i + 1] = self._dmax_buf[i]
+        it = self.iteration
+        self.max_diff.update(zip(range(it + 1, it + n + 1), self._dmax_buf[:n]))
         if n:
             self.op_iters_hist.extend([1] * n)
             self.op_path_hist.extend(["dual"] * n)

@@ -714,7 +714,7 @@ _RAGGED = (1, 7, 30, 2, 50, 64, 11)
     ("pdhg", 8000, 200, 3, 1.02, 24, 5, _RAGGED),                   # a failed verdict at the head of a call
     ("binary", 8000, 200, 3, 0.5, 24, 7, _RAGGED),
     ("pdhg", 3000, 200, 3, 1.02, 96, 4, _RAGGED)])
-@pytest.mark.parametrize("overlap,inner", [(False, 4), (True, 16), (True, 1), (False, 3), (True, 8)])
+@pytest.mark.parametrize("overlap,inner", [(False, 4), (True, 16), (True, 1), (False, 3), (True, 32)])
 def test_block_verdicts_equal_per_launch_verdicts(gpu_lib, mode, n, nodes, seed, stress, T, block, chunks, overlap, inner):
     """The block form of the streaming loop (the default, sharded or not) -- `block` iterations run
     unjudged, their node sums go to a ring, one launch judges the whole block, `inner` consecutive
