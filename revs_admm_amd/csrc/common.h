@@ -236,7 +236,9 @@ static __shared__ double *kvs_lds;
 #define REVS_KVS_BEGIN(ptr) do { if (threadIdx.x == 0) revs::kvs_lds = (ptr); } while (0)
 #define REVS_KVS(t, i) do { if (threadIdx.x == 0 && revs::kvs_lds) \
         revs::kvs_lds[32 * (t) + (i)] = (double)wall_clock64(); } while (0)
+#define REVS_KVV(t, i, val) do { if (threadIdx.x == 0 && revs::kvs_lds) revs::kvs_lds[32 * (t) + (i)] = (double)(val); } while (0)
 #else
 #define REVS_KVS_BEGIN(ptr) do { } while (0)
 #define REVS_KVS(t, i) do { } while (0)
+#define REVS_KVV(t, i, val) do { } while (0)
 #endif

@@ -970,6 +970,8 @@ struct ChainSelScratch {        // LDS of chain_rows_select_body
     int chosen[kAmax];
     double vsup[8];
     double rr[4][4];
+    double best_v[2][4];
+    int best_r[2][4];
     int vcount;
 };
 
@@ -1090,17 +1092,34 @@ __device__ __forceinline__ bool chain_rows_select_body(const TreeRowsArgs &a, co
     SlotLists *const ll = sa.ll;
     const int room = (ns == 0 && nv == 0) ? 0 : min(min(sa.kadd, kAmax - ns), nv);
     const int nq = min(cs_.vcount, kRankMax);
-    if (room > 0 && tid < nq) {
-        const double x = cs_.vval[tid];
-        const int r = cs_.vrow[tid];
-        int rank = 0;
-        for (int j = 0; j < nq; ++j) {
-            const double xj = cs_.vval[j];
-            rank += (xj > x || (xj == x && cs_.vrow[j] < r)) ? 1 : 0;
-        }
-        if (rank < room) cs_.chosen[rank] = tid;
-    }
     const int added = min(room, nq);
+    REVS_KVS(t, 8);
+    REVS_KVV(t, 24, nq); REVS_KVV(t, 25, ns); REVS_KVV(t, 26, room);
+    if (room > 0) {
+        // the violated rows sit one per thread: `added` rounds of a block-wide arg-max over registers, one barrier
+        // each (counting every row's rank instead costs a pass over all of them through LDS)
+        double x = tid < nq ? cs_.vval[tid] : 0.0;
+        const int r = tid < nq ? cs_.vrow[tid] : 0x7FFFFFFF;
+        for (int k2 = 0; k2 < added; ++k2) {
+            const double wv = wave_max_d(x);
+            const int wr = wave_min_i(x == wv ? r : 0x7FFFFFFF);
+            const int pp = k2 & 1;
+            if ((tid & 63) == 0) { cs_.best_v[pp][tid >> 6] = wv; cs_.best_r[pp][tid >> 6] = wr; }
+            __syncthreads();
+            double bv = cs_.best_v[pp][0];
+            int br = cs_.best_r[pp][0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const double ov = cs_.best_v[pp][w];
+                const int orow = cs_.best_r[pp][w];
+                const bool take = ov > bv || (ov == bv && orow < br);
+                bv = take ? ov : bv;
+                br = take ? orow : br;
+            }
+            if (tid < nq && r == br) { x = 0.0; cs_.chosen[k2] = tid; }
+        }
+    }
+    REVS_KVS(t, 9);
     __syncthreads();
     REVS_KVS(t, 10);
     const int cnt = ns + added;

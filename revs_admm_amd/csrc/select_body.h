@@ -189,9 +189,9 @@ __device__ __forceinline__ double dual_select_body(const SelectArgs &sa, const i
     __shared__ int vrow[EAGER ? kRank : 1];
     const bool by_rank = EAGER && room > 0 && nv <= kRank;
     if (by_rank) {
-        // Few violated rows (nv of them carry a positive entry): instead of `room` rounds of a block-wide
-        // arg-max with a barrier each, collect them (any order) and let each compute its own place in the
-        // order the rounds would take them -- larger violation first, ties to the lower row.
+        // Few violated rows (nv of them carry a positive entry): collected (any order) one per thread, so
+        // that the `room` rounds of the block-wide arg-max below compare registers instead of scanning
+        // every thread's share of the rows -- larger violation first, ties to the lower row.
         auto put = [&](double x, int r) {
             if (x > 0.0) {
                 const int q = atomicAdd(&vcount, 1);
@@ -206,15 +206,25 @@ __device__ __forceinline__ double dual_select_body(const SelectArgs &sa, const i
         }
         __syncthreads();
         const int nq = min(vcount, kRank);
-        if (tid < nq) {
-            const double x = vval[tid];
-            const int r = vrow[tid];
-            int rank = 0;
-            for (int j = 0; j < nq; ++j) {
-                const double xj = vval[j];
-                rank += (xj > x || (xj == x && vrow[j] < r)) ? 1 : 0;
+        double x = tid < nq ? vval[tid] : 0.0;
+        const int r = tid < nq ? vrow[tid] : 0x7FFFFFFF;
+        for (int k = 0; k < min(room, nq); ++k) {      // (one candidate per thread: the rounds scan nothing)
+            const double wv = wave_max_d(x);
+            const int wr = wave_min_i(x == wv ? r : 0x7FFFFFFF);
+            const int pp = k & 1;
+            if ((tid & 63) == 0) { best_v2[pp][tid >> 6] = wv; best_i2[pp][tid >> 6] = wr; }
+            __syncthreads();
+            double bv = best_v2[pp][0];
+            int br = best_i2[pp][0];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) {
+                const double ov = best_v2[pp][w];
+                const int orow = best_i2[pp][w];
+                const bool take = ov > bv || (ov == bv && orow < br);
+                bv = take ? ov : bv;
+                br = take ? orow : br;
             }
-            if (rank < room) chosen[rank] = r;
+            if (tid < nq && r == br) { x = 0.0; chosen[k] = r; }
         }
         added = min(room, nq);
     }
