@@ -607,13 +607,17 @@ def main():
             if (tj.get("homes") == n_local and tj.get("T") == args.T and tj.get("mode") == args.mode
                     and tj.get("iterations_per_launch") == inner and c.get("SQ_INSTS_VALU") and launch_ms):
                 peak = 1024 * 2.4e9 / 4
-                ach_v = c["SQ_INSTS_VALU"] / (launch_ms * 1e-3)
+                # (the counters are per launch of `inner` iterations; the timed launches carry
+                # steps / n_launch of them each -- 20 in the driver's run)
+                it_launch = args.steps / n_launch
+                ach_v = c["SQ_INSTS_VALU"] * (it_launch / inner) / (launch_ms * 1e-3)
                 valu = {"kernel": "agent_step_kernel<MULTI>", "bound": "valu-issue", "achieved": ach_v / 1e9,
                         "peak": peak / 1e9, "unit": "G wave64 VALU instructions/s", "frac": ach_v / peak,
-                        "valu_instructions_per_launch": c["SQ_INSTS_VALU"],
+                        "valu_instructions_per_launch": c["SQ_INSTS_VALU"] * (it_launch / inner),
+                        "iterations_per_timed_launch": it_launch,
                         "valu_instructions_per_wavefront_and_iteration": c["SQ_INSTS_VALU"] / max(c.get("SQ_WAVES", 1), 1) / inner,
                         "salu_instructions_per_launch": c.get("SQ_INSTS_SALU"),
-                        "valu_busy_share_of_launch": (c["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (launch_ms * 1e-3 * 2.4e9)
+                        "valu_busy_share_of_launch": (c["SQ_ACTIVE_INST_VALU"] * (it_launch / inner) * 4 / 1024 / (launch_ms * 1e-3 * 2.4e9)
                                                       if c.get("SQ_ACTIVE_INST_VALU") else None),
                         "source": tj.get("source")}
         except Exception:

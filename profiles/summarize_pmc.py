@@ -54,7 +54,7 @@ extra = {k: res[k] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES", "SQ_A
                             "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_BUSY_CYCLES") if k in res}
 json.dump({"homes": homes, "T": T, "mode": "pdhg", "fetch_bytes_corrected": fetch, "write_bytes": write,
            "hbm_bytes_per_launch": fetch + write, "algorithmic_bytes_per_launch": bytes_per_home * homes,
-           "iterations_per_launch": int(os.environ.get("REVS_ITERS_PER_LAUNCH", "16")) if multi else 1,
+           "iterations_per_launch": int(os.environ.get("REVS_ITERS_PER_LAUNCH", "32")) if multi else 1,
            "sq_counters_per_launch": extra,
            "source": f"profiles/{tag}_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate "
                      "passes of `bench.py --steps 60 --no-extras --no-cpu-baseline --no-converge --clock-warm 0`, "

@@ -13,7 +13,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -o k -- python3 $R
 cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/bench_kernel_stats.csv
 for pass in fetch:FETCH_SIZE write:WRITE_SIZE "sq:SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY" "sq2:SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"; do
   name=${pass%%:*}; ctr=${pass#*:}
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc/$name -o $name -- python3 $R/bench.py --steps 64 --warmup 16 --no-extras --no-cpu-baseline --no-converge --clock-warm 0 > $O/pmc_$name.log 2>&1
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc/$name -o $name -- python3 $R/bench.py --steps 128 --warmup 32 --no-extras --no-cpu-baseline --no-converge --clock-warm 0 > $O/pmc_$name.log 2>&1
 done
 for reg in binding binary; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/reg_$reg -o s -- python3 $R/tools/regime_run.py --regime $reg > $O/reg_$reg.log 2>&1
