@@ -616,7 +616,7 @@ def main():
                         "valu_instructions_per_launch": c["SQ_INSTS_VALU"] * (it_launch / inner),
                         "iterations_per_timed_launch": it_launch,
                         "valu_instructions_per_wavefront_and_iteration": c["SQ_INSTS_VALU"] / max(c.get("SQ_WAVES", 1), 1) / inner,
-                        "salu_instructions_per_launch": c.get("SQ_INSTS_SALU"),
+                        "salu_instructions_per_launch": (c["SQ_INSTS_SALU"] * (it_launch / inner) if c.get("SQ_INSTS_SALU") else None),
                         "valu_busy_share_of_launch": (c["SQ_ACTIVE_INST_VALU"] * (it_launch / inner) * 4 / 1024 / (launch_ms * 1e-3 * 2.4e9)
                                                       if c.get("SQ_ACTIVE_INST_VALU") else None),
                         "source": tj.get("source")}

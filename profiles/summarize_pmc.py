@@ -57,7 +57,7 @@ json.dump({"homes": homes, "T": T, "mode": "pdhg", "fetch_bytes_corrected": fetc
            "iterations_per_launch": int(os.environ.get("REVS_ITERS_PER_LAUNCH", "32")) if multi else 1,
            "sq_counters_per_launch": extra,
            "source": f"profiles/{tag}_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate "
-                     "passes of `bench.py --steps 60 --no-extras --no-cpu-baseline --no-converge --clock-warm 0`, "
+                     "passes of `bench.py --steps 128 --warmup 32 --no-extras --no-cpu-baseline --no-converge --clock-warm 0`, "
                      "the streaming launches of each pass; counters in KiB, FETCH_SIZE x2 per "
                      "MI355X_MICROARCH.md; not measured inside the bench run)"},
           open(os.path.join(ROOT, "profiles", "agent_traffic.json"), "w"), indent=1)

@@ -348,6 +348,9 @@ void agent_step_kernel(const AgentArgs a) {
             pen[j] = (float)g;
             if (fr) {
                 const double gq = revs_q36(g), g2 = revs_q32(g * g);
+#ifdef REVS_CHAIN_NO_FACC      // (tuning build: what do the accumulators cost?  wrong sums)
+                if (gq == -1.0) facc[0][0][0][0] = g2;
+#else
                 if (loc < kNodeLoc) {
                     unsafeAtomicAdd(&facc[0][0][loc][t0 + j], gq);
                     unsafeAtomicAdd(&facc[0][1][loc][t0 + j], 1.0);
@@ -358,6 +361,7 @@ void agent_step_kernel(const AgentArgs a) {
                     unsafeAtomicAdd(&a.fold_a[o + mt], 1.0);
                     unsafeAtomicAdd(&a.fold_a[o + 2 * mt], -0.5 * a.sh_kappa * g2);
                 }
+#endif
             }
         }
     }
@@ -705,6 +709,9 @@ void agent_step_kernel(const AgentArgs a) {
             const double g = fr ? g0 - ds : 0.0;
             if (fr) {
                 const double gq = revs_q36(g), g2 = revs_q32(g * g);
+#ifdef REVS_CHAIN_NO_FACC
+                if (gq == -1.0) facc[1][0][0][0] = g2;
+#else
                 if (loc < kNodeLoc) {
                     unsafeAtomicAdd(&facc[1][0][loc][t0 + j], gq);
                     unsafeAtomicAdd(&facc[1][1][loc][t0 + j], 1.0);
@@ -715,6 +722,7 @@ void agent_step_kernel(const AgentArgs a) {
                     unsafeAtomicAdd(&a.fold_b[o + mt], 1.0);
                     unsafeAtomicAdd(&a.fold_b[o + 2 * mt], -0.5 * a.sh_kappa * g2);
                 }
+#endif
             }
         }
     }
@@ -1212,13 +1220,28 @@ constexpr int kHandOverGroups = 8;        // workgroups that copy the call's las
 template <int NT, int IPT>
 __global__ __launch_bounds__(NT) void stream_block_verdict_kernel(const BlockVerdict b) {
     extern __shared__ double tree_lds[];
+    const int tid = threadIdx.x;
+    const int njudge = b.nb * b.T, npre = b.pre ? 1 : 0;
+    const bool extra = (int)blockIdx.x >= njudge;
+    // (the tree's static data are requested in front of the control word's test: one round trip, not two)
+    unsigned long long pk0[IPT];
+    double wgt0[IPT];
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) pk0[i] = 0ull;
+    if (!extra) {
+        if (IPT * tid < b.tree.n) {
+#pragma unroll
+            for (int i = 0; i < IPT; i += 2) {
+                const TreeU2 u = *reinterpret_cast<const TreeU2 *>(b.tree.pack + IPT * tid + i);
+                pk0[i] = u.v[0]; pk0[i + 1] = u.v[1];
+            }
+        }
+        tree_fetch_w<NT, IPT>(b.tree, wgt0);
+    }
     {
         const unsigned int bad = b.ctl->bad_seq;
         if (bad >= b.base_seq && bad <= b.gate_seq) return;
     }
-    const int tid = threadIdx.x;
-    const int njudge = b.nb * b.T, npre = b.pre ? 1 : 0;
-    const bool extra = (int)blockIdx.x >= njudge;
     const int g = extra ? b.nb : (int)blockIdx.x / b.T, t = extra ? (int)blockIdx.x - njudge : (int)blockIdx.x - g * b.T;
     double *slice = b.ring + (long long)(g - npre) * b.stride;       // (g == 0 with pre: not a ring slice)
     const bool ring_slice = !(b.pre && g == 0);
@@ -1238,8 +1261,8 @@ __global__ __launch_bounds__(NT) void stream_block_verdict_kernel(const BlockVer
     }
     double rmax = 0.0;
     if (!extra) {
-        rmax = ring_slice ? tree_rmax<NT, IPT>(b.tree, slice, b.T, t, b.vlo, b.vhi, tree_lds, nullptr, slice)
-                          : tree_rmax<NT, IPT>(b.tree, b.pre, b.T, t, b.vlo, b.vhi, tree_lds, nullptr, nullptr);
+        rmax = ring_slice ? tree_rmax<NT, IPT, true>(b.tree, slice, b.T, t, b.vlo, b.vhi, tree_lds, nullptr, slice, pk0, wgt0)
+                          : tree_rmax<NT, IPT, true>(b.tree, b.pre, b.T, t, b.vlo, b.vhi, tree_lds, nullptr, nullptr, pk0, wgt0);
     } else {
         const long long per = (b.mt + kHandOverGroups - 1) / kHandOverGroups;
         const long long i0 = t * per, i1 = i0 + per < b.mt ? i0 + per : b.mt;

@@ -1171,22 +1171,33 @@ extern "C" int revs_plan_stream_run_blocks(revs_plan_t *plan, int32_t max_steps,
         }
         prev = cur;
         cur = in;
-        if (ov && rc == REVS_OK) rc = hip_ok(hipEventRecord(plan->events[2 * b], s), "hipEventRecord");
-        if (ov && rc == REVS_OK) rc = hip_ok(hipStreamWaitEvent(q, plan->events[2 * b], 0), "hipStreamWaitEvent");
+        // The call's last block has nothing to run beside: without a collective its verdicts go behind its
+        // sweeps on the caller's stream -- no hop between streams in front of the launch the host waits for
+        // (a burst of one block never leaves the stream) -- once the block before has been judged (the
+        // verdict launches share their arrival counter).
+        const bool lastb = b + 1 == nblocks;
+        const bool on_main = ov && lastb && !plan->comm;
+        hipStream_t vq = on_main ? s : q;
+        if (on_main) {
+            if (b >= 1 && rc == REVS_OK)
+                rc = hip_ok(hipStreamWaitEvent(s, plan->events[2 * (b - 1) + 1], 0), "hipStreamWaitEvent");
+        } else {
+            if (ov && rc == REVS_OK) rc = hip_ok(hipEventRecord(plan->events[2 * b], s), "hipEventRecord");
+            if (ov && rc == REVS_OK) rc = hip_ok(hipStreamWaitEvent(q, plan->events[2 * b], 0), "hipStreamWaitEvent");
+        }
         if (rc == REVS_OK && plan->comm)
             rc = revs_comm_allreduce_f64(plan->comm, ring, (int64_t)nb * stride, 0, q);
         // block 0's launch also judges the call's first iteration (the caller's st->p0: its sweep ran
         // unjudged, like every other sweep of the block); the last block's also hands the call's last
         // slice over to the caller (st->p0_out) and folds its tail into the extra record
-        const bool lastb = b + 1 == nblocks;
         const int judged = (lastb ? nb - 1 : nb) + (b == 0 ? 1 : 0);
         if (rc == REVS_OK)
             rc = revs::stream_block_verdict(plan->ctl, seq0, seq0 + (unsigned int)k0,
                                             seq0 + (unsigned int)k0 + (b == 0 ? 0u : 1u), judged, d.T, plan->tree,
                                             b == 0 ? st->p0 : nullptr, ring, stride, (int32_t)mt, ntail,
                                             lastb ? st->p0_out : nullptr, d.vlo, d.vhi, vtol,
-                                            plan->grp_bits, plan->grp_dmax, plan->rec_dev, q);
-        if (ov && rc == REVS_OK) rc = hip_ok(hipEventRecord(plan->events[2 * b + 1], q), "hipEventRecord");
+                                            plan->grp_bits, plan->grp_dmax, plan->rec_dev, vq);
+        if (ov && rc == REVS_OK) rc = hip_ok(hipEventRecord(plan->events[2 * b + 1], vq), "hipEventRecord");
     }
     entry[nblocks] = cur;
     if (ov) {        // the caller's stream is done when the side stream is (also after an error above)

@@ -203,15 +203,26 @@ __device__ __forceinline__ void tree_voltage(const TreeArgs &tr, const double *p
 
 // Largest violation max(v - vhi, vlo - v, 0) over the checked rows of slot t (every thread
 // gets it); v_out[src][t] = v when v_out != NULL.
-template <int NT = 256, int IPT = 8>
+// PRE: the caller has fetched pk[] and the weights wgt[] already (tree_fetch_w), e.g. in front of a test
+// it has to wait for anyway.
+template <int NT = 256, int IPT = 8, bool PRE = false>
 __device__ __forceinline__ double tree_rmax(const TreeArgs &tr, const double *p, int T, int t,
                                             double vlo, double vhi, double *lds, double *v_out,
-                                            double *p_clear = nullptr) {
+                                            double *p_clear = nullptr, unsigned long long *pk_pre = nullptr,
+                                            double *wgt_pre = nullptr) {
     const int tid = threadIdx.x;
     double *red1 = lds + 2 + NT * IPT + NT / 64;
     unsigned long long pk[IPT];
     double a[IPT];
-    tree_voltage<NT, IPT>(tr, p, T, t, lds, a, pk, p_clear);
+    if constexpr (PRE) {
+        double b[IPT];
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) { pk[i] = pk_pre[i]; b[i] = wgt_pre[i]; }
+        tree_gather_p<NT, IPT>(tr, p, T, t, pk, a, p_clear);
+        tree_scan<NT, IPT>(tr, t, lds, a, b, pk);
+    } else {
+        tree_voltage<NT, IPT>(tr, p, T, t, lds, a, pk, p_clear);
+    }
     double rmax = 0.0;
 #pragma unroll
     for (int i = 0; i < IPT; ++i) {
