@@ -743,7 +743,10 @@ int revs_plan_chain_run(revs_plan_t *plan, int32_t max_steps, revs_chain_state_t
  *        iteration of the call writes schedules and SOC;
  *        resume: in, 1 = the previous call kept all its iterations and nothing has touched the
  *        state or the multipliers since (its last launch has already prepared this call's first
- *        iteration); out, 1 = this call ended that way. */
+ *        iteration); out, 1 = this call ended that way; out, 2 = the call stopped at an iteration whose
+ *        full Newton step passed the line search but left the rows above the tolerance: y IS that step
+ *        (y_trial the multipliers before it), the state is untouched, and the caller's loop continues the
+ *        operator's solve from y. */
 typedef struct {
     double *y, *y_trial, *y_spare;
     int32_t use_y, sup0;
@@ -751,6 +754,7 @@ typedef struct {
     float *p_sch, *p_sch_alt, *gamma, *gamma_alt;
     float *s_out, *c_out;
     int32_t resume;
+    int32_t pivots;     /* out, with resume = 2: pivots taken by the model of the step y */
 } revs_chain_fold_state_t;
 int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, revs_chain_fold_state_t *st,
                              int32_t *kept_steps, void *stream);

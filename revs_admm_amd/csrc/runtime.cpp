@@ -70,6 +70,7 @@ struct revs_plan {
     // candidate sets and stats blocks ([0]: the evaluation's, [1]: the trial's)
     double *fold_e2[2] = {nullptr, nullptr}, *fold_e1[2] = {nullptr, nullptr};
     double *fold_v[3] = {nullptr, nullptr, nullptr};
+    int32_t *fold_info[2] = {nullptr, nullptr};        // the models' pivot counts, by iteration parity
     double *fold_sh[2] = {nullptr, nullptr};           // the trial's shifts R^T y / kappa, list order / row order
     int64_t *fold_ci[2] = {nullptr, nullptr};
     int32_t *fold_cc[2] = {nullptr, nullptr};
@@ -84,9 +85,12 @@ struct revs_plan {
 // Host-side acceptance test of a chained Newton iteration (operator_newton.py: _chain_launch): the
 // checks AdmmEngine._operator_solve_newton would make on the two evaluations' stats, for the
 // one outcome that needs no further launch.  See include/revs_admm.h.
-extern "C" int revs_newton_chain_accept(int32_t T, const double *s0, const double *s1, double scale,
-                                        double eps, int32_t amax, int32_t kadd, int32_t chain_few,
-                                        int32_t *nsup_sum, int32_t *nsup_max) {
+// why: 0 accepted | 1 everything holds but the rows after the step are still above the tolerance (the
+// step itself is a good Newton step: another iteration from it) | 2 anything else
+static int chain_accept_impl(int32_t T, const double *s0, const double *s1, double scale, double eps,
+                             int32_t amax, int32_t kadd, int32_t chain_few, int32_t *nsup_sum,
+                             int32_t *nsup_max, int *why) {
+    *why = 2;
     if (!s0 || !s1 || T <= 0 || !(scale > 0.0) || !nsup_sum || !nsup_max) return 0;
     double rmax0 = 0.0, ns_max = 0.0, ncand_max = 0.0;
     for (int t = 0; t < T; ++t) {
@@ -116,10 +120,18 @@ extern "C" int revs_newton_chain_accept(int32_t T, const double *s0, const doubl
         sum += b[2];
         mx = b[2] > mx ? b[2] : mx;
     }
-    if (!(rmax1 <= eps)) return 0;                       // needs another iteration
     *nsup_sum = (int32_t)sum;
     *nsup_max = (int32_t)mx;
+    if (!(rmax1 <= eps)) { *why = 1; return 0; }         // needs another iteration
+    *why = 0;
     return 1;
+}
+
+extern "C" int revs_newton_chain_accept(int32_t T, const double *s0, const double *s1, double scale,
+                                        double eps, int32_t amax, int32_t kadd, int32_t chain_few,
+                                        int32_t *nsup_sum, int32_t *nsup_max) {
+    int why = 0;
+    return chain_accept_impl(T, s0, s1, scale, eps, amax, kadd, chain_few, nsup_sum, nsup_max, &why);
 }
 
 extern "C" revs_plan_t *revs_plan_create(const revs_plan_desc_t *desc) {
@@ -187,6 +199,7 @@ extern "C" void revs_plan_destroy(revs_plan_t *plan) {
         if (plan->fold_st_host[i]) (void)hipHostFree(plan->fold_st_host[i]);
     }
     for (double *v : plan->fold_v) if (v) (void)hipFree(v);
+    for (int32_t *v : plan->fold_info) if (v) (void)hipFree(v);
     for (double *v : plan->fold_sh) if (v) (void)hipFree(v);
     for (hipEvent_t e : plan->events) (void)hipEventDestroy(e);
     for (hipEvent_t e : plan->tev) if (e) (void)hipEventDestroy(e);
@@ -522,6 +535,8 @@ static int fold_alloc(revs_plan_t *plan) {
     dev((void **)&plan->fold_v[0], sizeof(double) * mt);
     dev((void **)&plan->fold_v[1], sizeof(double) * mt);
     dev((void **)&plan->fold_v[2], sizeof(double) * (size_t)d.T * 4);
+    dev((void **)&plan->fold_info[0], sizeof(int32_t) * (size_t)d.T);
+    dev((void **)&plan->fold_info[1], sizeof(int32_t) * (size_t)d.T);
     dev((void **)&plan->fold_sh[0], sizeof(double) * mt);
     dev((void **)&plan->fold_sh[1], sizeof(double) * (mt + 32 * (size_t)d.T));     // (+ the tuning build's stage stamps)
     if (e != hipSuccess) {
@@ -586,7 +601,7 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
                 c0.vlo = d.vlo; c0.vhi = d.vhi; c0.kappa = d.kappa; c0.delta = d.delta; c0.scale = scale; c0.eps = d.eps;
                 c0.max_pivots = d.max_pivots;
                 c0.e1 = revs::ChainKvSide{d.pnq, st->y, d.vfull, d.viol, d.partial, S0.ci, S0.cc, S0.cv, S0.st, 0.0};
-                c0.R = d.R; c0.k_full = d.k_full; c0.yhat = d.yhat; c0.info = d.info;
+                c0.R = d.R; c0.k_full = d.k_full; c0.yhat = d.yhat; c0.info = plan->fold_info[par];
                 c0.y_trial = st->y_trial;
                 c0.lin_out = S1.st + 4;
                 c0.clr0 = nullptr; c0.clr1 = nullptr;
@@ -617,7 +632,7 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
                                  S1.ci, S1.cc, S1.cv, S1.st, seq};
         c.e1 = revs::ChainKvSide{plan->fold_e1[par ^ 1], st->y_trial, d.vfull, d.viol, d.partial,
                                  S0n.ci, S0n.cc, S0n.cv, S0n.st, 0.0};
-        c.R = d.R; c.k_full = d.k_full; c.yhat = d.yhat; c.info = d.info;
+        c.R = d.R; c.k_full = d.k_full; c.yhat = d.yhat; c.info = plan->fold_info[par ^ 1];     // (iteration k + 1's model)
         c.y_trial = st->y_spare;
         c.lin_out = S1n.st + 4;
         c.clr0 = plan->fold_e2[par ^ 1];
@@ -649,8 +664,9 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
         }
         std::atomic_thread_fence(std::memory_order_acquire);
         int32_t nsum = 0, nmax = 0;
-        const int acc = revs_newton_chain_accept(d.T, S0.st_host, S1.st_host, scale, d.eps, REVS_DUAL_AMAX, d.kadd, 1,
-                                                 &nsum, &nmax);
+        int why = 0;
+        const int acc = chain_accept_impl(d.T, S0.st_host, S1.st_host, scale, d.eps, REVS_DUAL_AMAX, d.kadd, 1,
+                                          &nsum, &nmax, &why);
         static const bool ftrace = getenv("REVS_FOLD_TRACE") != nullptr;
         if (ftrace && !acc) {
             double r0 = 0, r1 = 0, ncm = 0;
@@ -669,7 +685,28 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
             fprintf(stderr, "[fold] iteration %d (par %d, resumed %d) rejected: rows before %.3g after %.3g candidates %g armijo failures %d\n",
                     k, par, (int)have_k1, r0, r1, ncm, arm);
         }
-        if (!acc) return REVS_OK;             // the caller's general loop takes this iteration (state untouched)
+        if (!acc) {
+            // The caller's general loop takes this iteration (state untouched).  When the trial is a good
+            // Newton step that merely left the rows above the tolerance -- the usual rejection with on/off
+            // chargers -- the multipliers are handed back AT the trial (resume = 2): the caller goes on
+            // from it instead of making the same step again.
+            if (why == 1) {
+                std::swap(st->y, st->y_trial);
+                st->use_y = 1;
+                st->sup0 = -1;
+                st->resume = 2;
+                // (the pivots the step's model took: the caller's books count them with the solve it finishes)
+                std::vector<int32_t> inf((size_t)d.T, 0);
+                if (hipMemcpyAsync(inf.data(), plan->fold_info[par], sizeof(int32_t) * inf.size(), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                    hipStreamSynchronize(s) != hipSuccess) {
+                    revs::set_error("revs_plan_chain_fold_run: reading the pivot counts failed");
+                    return REVS_ELAUNCH;
+                }
+                st->pivots = 0;
+                for (int32_t v : inf) st->pivots += v < 0 ? -v : v;
+            }
+            return REVS_OK;
+        }
         double *y_old = st->y;
         st->y = st->y_trial;
         st->y_trial = st->y_spare;

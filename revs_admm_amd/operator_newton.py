@@ -347,6 +347,11 @@ class DualNewtonMixin:
         self._p_clear = None
         if self._fold_ok():
             return self._chain_fold_run(count, write_sc)
+        return self._chain_run_phases(count, write_sc)
+
+    def _chain_run_phases(self, count, write_sc=False):
+        """revs_plan_chain_run: the chained iteration as five launches and three passes over the
+        residences (sharded runs, feeders without a tree, and the folded chain's second Newton step)."""
         self._fold_resume = False
         ys = (self.yd[0], self.yd[1])
         bufs = (self.P_est, self.P_est_new, self.P_sch, self.P_sch_alt, self.G, self.G_alt)
@@ -401,7 +406,8 @@ class DualNewtonMixin:
         yb = {t.data_ptr(): t for t in ys}
         self.yd = [yb[st.y], yb[st.y_trial]]
         self._y_spare = yb[st.y_spare]
-        self._fold_resume = bool(st.resume)
+        stepped = st.resume == 2          # stopped behind a good Newton step that needs another: y is that step
+        self._fold_resume = st.resume == 1
         if n:
             self.model_calls[0] += n
             self.newton_hist.extend([(1, 2, -1)] * n)      # (pivot counts not read)
@@ -415,10 +421,21 @@ class DualNewtonMixin:
             self.iteration += n
         if n == count:
             return n
+        if stepped:
+            # the operator's solve goes on from the step the chain has made: one chained iteration issued
+            # in phases (evaluation, model, step, evaluation, sweep), the general loop behind it
+            self._y_support, self._sup = True, None
+            if not (write_sc and n == 0):      # (schedules are written by the general path only)
+                done = self._chain_run_phases(1)
+                self._book_step_before(st.pivots)
+                return n + done
+            step_pivots = st.pivots
         # the call stopped at an iteration that is the general loop's: a fresh solve from the current
         # multipliers (the folded chain's stats and lists are its own), then the sweep on its answer
         self._sup = None
         ok = self._operator_solve_newton()
+        if ok and stepped:
+            self._book_step_before(step_pivots)
         self.chain_hist[1] += 1
         if not ok:
             self._fast_cold = True
@@ -428,6 +445,16 @@ class DualNewtonMixin:
         self.P_est, self.P_est_new = self.P_est_new, self.P_est
         self.iteration += 1
         return n + 1
+
+    def _book_step_before(self, pivots):
+        """The solve just booked went on from a Newton step the folded chain had made: one iteration,
+        one evaluation (the step's own; the one at the old multipliers is the solve's first either way)
+        and the step's pivots belong to it."""
+        if self.newton_hist:
+            nw, ev, pv = self.newton_hist[-1]
+            self.newton_hist[-1] = (nw + 1, ev + 1, pv + pivots if pv >= 0 else pv)
+        if self.op_iters_hist:
+            self.op_iters_hist[-1] += 1
 
     def _chain_finish(self, accepted, nsum, nmax, write_sc):
         """After the chain's launches: book the usual outcome, or hand both evaluations to the
