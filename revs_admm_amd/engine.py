@@ -290,6 +290,7 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
         self._pending_tag = [None, None]
         self.chain_hist = [0, 0]                       # chained Newton iterations kept / redone
         self._y_spare = None                           # third multiplier array (folded chain)
+        self.fold_steps = 0                            # folded-chain iterations that went on from their own Newton step
         self._fold_resume = False                      # the folded chain's pipeline is primed for the next iteration
         self._spec_ok = False
         self._spec_wait, self._spec_back = 0, 1

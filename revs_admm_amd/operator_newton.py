@@ -425,6 +425,7 @@ class DualNewtonMixin:
             # the operator's solve goes on from the step the chain has made: one chained iteration issued
             # in phases (evaluation, model, step, evaluation, sweep), the general loop behind it
             self._y_support, self._sup = True, None
+            self.fold_steps += 1
             if not (write_sc and n == 0):      # (schedules are written by the general path only)
                 done = self._chain_run_phases(1)
                 self._book_step_before(st.pivots)

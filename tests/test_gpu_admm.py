@@ -595,6 +595,10 @@ def test_chained_newton_iteration_changes_nothing(gpu_lib, mode, stress):
         runs.append((d, e.result(), e.yd[0].cpu().numpy(), e))
     (d1, r1, y1, e1), (d0, r0, y0, e0) = runs
     assert e1.chain_hist[0] > 5 and e0.chain_hist == [0, 0], (e1.chain_hist, e1.newton_hist[-20:])
+    if mode == "binary":
+        # (on/off chargers: some iterations need a second Newton step -- the folded chain hands its own
+        # step back, revs_chain_fold_state_t::resume = 2, and the solve goes on from it)
+        assert e1.fold_steps > 0 and e0.fold_steps == 0
     if mode == "pdhg":
         assert np.abs(d1 - d0).max() < 1e-5 and max(np.abs(a - b).max() for a, b in zip(r1, r0)) < 1e-4
         return
