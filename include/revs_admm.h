@@ -746,7 +746,9 @@ int revs_plan_chain_run(revs_plan_t *plan, int32_t max_steps, revs_chain_state_t
  *        iteration); out, 1 = this call ended that way; out, 2 = the call stopped at an iteration whose
  *        full Newton step passed the line search but left the rows above the tolerance: y IS that step
  *        (y_trial the multipliers before it), the state is untouched, and the caller's loop continues the
- *        operator's solve from y. */
+ *        operator's solve from y.  (Up to two such steps per iteration are taken inside the call: the
+ *        trial's evaluation on the current state is what the sweep has folded, so the operator launch runs
+ *        on those sums and sweep and launch are made again: `redone`.) */
 typedef struct {
     double *y, *y_trial, *y_spare;
     int32_t use_y, sup0;
@@ -755,6 +757,8 @@ typedef struct {
     float *s_out, *c_out;
     int32_t resume;
     int32_t pivots;     /* out, with resume = 2: pivots taken by the model of the step y */
+    int32_t redone;     /* out: Newton steps beyond the first that the call's LAST iteration took inside the call
+                           (a kept one: the call returns behind it; or, with resume = 2, the one handed back) */
 } revs_chain_fold_state_t;
 int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, revs_chain_fold_state_t *st,
                              int32_t *kept_steps, void *stream);

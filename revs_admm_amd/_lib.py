@@ -71,7 +71,8 @@ class ChainFoldState(C.Structure):
     _fields_ = [("y", C.c_void_p), ("y_trial", C.c_void_p), ("y_spare", C.c_void_p), ("use_y", C.c_int32),
                 ("sup0", C.c_int32), ("p_est", C.c_void_p), ("p_est_new", C.c_void_p), ("p_sch", C.c_void_p),
                 ("p_sch_alt", C.c_void_p), ("gamma", C.c_void_p), ("gamma_alt", C.c_void_p),
-                ("s_out", C.c_void_p), ("c_out", C.c_void_p), ("resume", C.c_int32), ("pivots", C.c_int32)]
+                ("s_out", C.c_void_p), ("c_out", C.c_void_p), ("resume", C.c_int32), ("pivots", C.c_int32),
+                ("redone", C.c_int32)]
 
 
 class Tree(C.Structure):

@@ -577,9 +577,39 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
     plan->fold_ready = false;
     st->resume = 0;
     int rc = REVS_OK;
+    st->redone = 0;
+    st->pivots = 0;
+    // redo: Newton steps beyond the first that the current iteration has taken.  A trial that passes the
+    // line search but leaves the rows above the tolerance IS the general loop's next Newton iterate, and its
+    // evaluation on the current state is what the sweep has just folded (fold_e2[par]): the operator launch
+    // without a verdict half runs rows / selection / model / step on those sums, and the iteration's sweep
+    // and operator launch are made again from there -- the general loop's iterates, without its round trips.
+    int redo = 0;
+    bool redo_pending = false;
+    constexpr int kMaxRedo = 2;
     for (int32_t k = 0; k < max_steps; ++k) {
         const Set S0 = set_of(par, 0), S1 = set_of(par, 1), S0n = set_of(par ^ 1, 0), S1n = set_of(par ^ 1, 1);
-        if (!have_k1) {
+        if (redo_pending) {
+            redo_pending = false;
+            revs::ChainKv c0{};
+            c0.m = d.m; c0.T = d.T; c0.kadd = d.kadd; c0.has_e2 = 0;
+            c0.tree = plan->tree;
+            c0.vlo = d.vlo; c0.vhi = d.vhi; c0.kappa = d.kappa; c0.delta = d.delta; c0.scale = scale; c0.eps = d.eps;
+            c0.max_pivots = d.max_pivots;
+            c0.e1 = revs::ChainKvSide{plan->fold_e2[par], st->y, d.vfull, d.viol, d.partial, S0.ci, S0.cc, S0.cv, S0.st, 0.0};
+            c0.R = d.R; c0.k_full = d.k_full; c0.yhat = d.yhat; c0.info = plan->fold_info[par];
+            c0.y_trial = st->y_trial;
+            c0.lin_out = S1.st + 4;
+            c0.clr0 = nullptr; c0.clr1 = nullptr;
+            c0.sh_a = plan->fold_sh[0]; c0.sh_b = plan->fold_sh[1];
+            rc = revs::chain_kv_launch(c0, stream);
+            if (rc != REVS_OK) return rc;
+            if (hipMemsetAsync(plan->fold_e2[par], 0, sizeof(double) * 3 * mt, s) != hipSuccess ||
+                hipMemsetAsync(plan->fold_e1[par ^ 1], 0, sizeof(double) * 3 * mt, s) != hipSuccess) {
+                revs::set_error("revs_plan_chain_fold_run: hipMemsetAsync failed");
+                return REVS_ELAUNCH;
+            }
+        } else if (!have_k1) {
             // entry: the multipliers' evaluation by the evaluation kernel (row-wise shifts from the
             // caller's list `sup0` when it has one), rows / selection / model / step in one launch
             if (st->use_y && st->sup0 >= 0) {
@@ -690,6 +720,19 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
             // Newton step that merely left the rows above the tolerance -- the usual rejection with on/off
             // chargers -- the multipliers are handed back AT the trial (resume = 2): the caller goes on
             // from it instead of making the same step again.
+            if (why == 1 && redo < kMaxRedo) {
+                double *y_old = st->y;          // y := the step; the next trial goes where the speculative one went
+                st->y = st->y_trial;
+                st->y_trial = st->y_spare;
+                st->y_spare = y_old;
+                st->use_y = 1;
+                st->sup0 = -1;
+                ++redo;
+                redo_pending = true;
+                --k;
+                continue;
+            }
+            st->redone = redo;
             if (why == 1) {
                 std::swap(st->y, st->y_trial);
                 st->use_y = 1;
@@ -722,6 +765,10 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
         par ^= 1;
         static const bool no_pipe = getenv("REVS_FOLD_NO_PIPE") != nullptr;     // (debugging aid)
         have_k1 = !no_pipe;
+        if (redo > 0) {                       // (the caller books this iteration's extra Newton steps: it is the call's last)
+            st->redone = redo;
+            break;
+        }
     }
     plan->fold_ready = have_k1;
     plan->fold_par = par;

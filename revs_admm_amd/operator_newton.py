@@ -419,7 +419,11 @@ class DualNewtonMixin:
             self.op_converged = True
             self.chain_hist[0] += n
             self.iteration += n
-        if n == count:
+            if st.redone and not stepped:      # the last kept iteration took more Newton steps inside the call
+                self.fold_steps += st.redone
+                self.newton_hist[-1] = (1 + st.redone, 2 + st.redone, -1)
+                self.op_iters_hist[-1] = 2 + st.redone
+        if n == count or (n and st.redone and not stepped and st.resume == 1):
             return n
         if stepped:
             # the operator's solve goes on from the step the chain has made: one chained iteration issued
@@ -428,7 +432,7 @@ class DualNewtonMixin:
             self.fold_steps += 1
             if not (write_sc and n == 0):      # (schedules are written by the general path only)
                 done = self._chain_run_phases(1)
-                self._book_step_before(st.pivots)
+                self._book_step_before(st.pivots, 1 + st.redone)
                 return n + done
             step_pivots = st.pivots
         # the call stopped at an iteration that is the general loop's: a fresh solve from the current
@@ -436,7 +440,7 @@ class DualNewtonMixin:
         self._sup = None
         ok = self._operator_solve_newton()
         if ok and stepped:
-            self._book_step_before(step_pivots)
+            self._book_step_before(step_pivots, 1 + st.redone)
         self.chain_hist[1] += 1
         if not ok:
             self._fast_cold = True
@@ -447,15 +451,15 @@ class DualNewtonMixin:
         self.iteration += 1
         return n + 1
 
-    def _book_step_before(self, pivots):
-        """The solve just booked went on from a Newton step the folded chain had made: one iteration,
-        one evaluation (the step's own; the one at the old multipliers is the solve's first either way)
-        and the step's pivots belong to it."""
+    def _book_step_before(self, pivots, steps=1):
+        """The solve just booked went on from `steps` Newton steps the folded chain had made: an
+        iteration and an evaluation each (the step's own; the one at the old multipliers is the solve's
+        first either way), and the last step's pivots, belong to it (earlier steps' are not read)."""
         if self.newton_hist:
             nw, ev, pv = self.newton_hist[-1]
-            self.newton_hist[-1] = (nw + 1, ev + 1, pv + pivots if pv >= 0 else pv)
+            self.newton_hist[-1] = (nw + steps, ev + steps, pv + pivots if (pv >= 0 and steps == 1) else -1)
         if self.op_iters_hist:
-            self.op_iters_hist[-1] += 1
+            self.op_iters_hist[-1] += steps
 
     def _chain_finish(self, accepted, nsum, nmax, write_sc):
         """After the chain's launches: book the usual outcome, or hand both evaluations to the

@@ -189,7 +189,11 @@ def test_process_group_path_on_one_gpu(gpu_lib):
                         op=OperatorOptions(solver=solver, node_fast=fast))
             db = b.run(5)
             if solver == "newton":
-                assert set(b.op_path_hist) == {"dual"} and a.newton_hist == b.newton_hist
+                # (Newton iterations and evaluations of every solve; pivots where the one-GPU run read them:
+                # an iteration finished inside the folded chain, second Newton step included, books -1)
+                assert set(b.op_path_hist) == {"dual"}
+                assert [h[:2] for h in a.newton_hist] == [h[:2] for h in b.newton_hist]
+                assert all(x[2] == y[2] for x, y in zip(a.newton_hist, b.newton_hist) if x[2] >= 0)
                 assert max(n for n, _, _ in b.newton_hist) >= 1   # rows bind on the way
             else:
                 assert max(b.op_iters_hist) >= 25                 # rows bind on the way
