@@ -1167,18 +1167,22 @@ __device__ __forceinline__ void chain_fast_body(
     // A = the candidate count: every loop below has compile-time bounds and no branch on it -- straight-line
     // code (a taken branch costs a wavefront ~20 cycles, and these workgroups are nothing but latency)
     const int tid = threadIdx.x;
+    REVS_KVS(t, 27);
     long long f[A];
 #pragma unroll
     for (int i = 0; i < A; ++i) f[i] = (long long)uni_i((int)ll->ci[i]);
+    REVS_KVS(t, 28);
     // (the first npre rows -- the support known before the voltages were -- are here already)
 #pragma unroll
     for (int i = 0; i < A; ++i) {
         if (i >= npre) {                    // uniform
 #pragma unroll
+            // (nodes beyond m read element 0 of the row and are never used: their N is zero in the Gram sums,
+            // their shifts are not stored -- no select on the loaded value, which would make every row wait
+            // for its own loads before the next row's are issued)
             for (int j = 0; j < 8; ++j) {
                 const int mm = tid + 256 * j;
-                const double v = R[f[i] * m + (mm < m ? mm : 0)];
-                r[j][i] = mm < m ? v : 0.0;
+                r[j][i] = R[f[i] * m + (mm < m ? mm : 0)];
             }
         }
     }
@@ -1188,7 +1192,7 @@ __device__ __forceinline__ void chain_fast_body(
     double acc[kTri];
 #pragma unroll
     for (int p = 0; p < kTri; ++p) acc[p] = 0.0;
-    // (nodes beyond m carry r = 0 and N = 0: their terms add exactly nothing)
+    // (nodes beyond m carry N = 0 and a finite r: their terms add exactly nothing)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
 #pragma unroll
@@ -1394,8 +1398,7 @@ __global__ __launch_bounds__(256) void op_chain_kv_kernel(const ChainKvArgs k) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             const int mm = threadIdx.x + 256 * j;
-                            const double v = k.f1.R[sup[q] * m + (mm < m ? mm : 0)];
-                            r[j][q] = mm < m ? v : 0.0;
+                            r[j][q] = k.f1.R[sup[q] * m + (mm < m ? mm : 0)];
                         }
                     }
                 }

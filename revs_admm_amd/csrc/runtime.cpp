@@ -784,7 +784,8 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
         // 0 start | 1-6 rows | 7-10 selection | 11-16 model | 17 step | 18-20 shifts: microseconds since the slot's start
         fprintf(stderr, "[kv stamps, us since start] slowest slot %d:", worst);
         for (int i = 1; i <= 23; ++i) fprintf(stderr, " %d:%.1f", i, (h[32 * worst + i] - h[32 * worst]) * 0.01);
-        fprintf(stderr, " | violated %g support %g room %g", h[32 * worst + 24], h[32 * worst + 25], h[32 * worst + 26]);
+        fprintf(stderr, " | violated %g support %g room %g | fast body at %.1f, list read %.1f", h[32 * worst + 24], h[32 * worst + 25], h[32 * worst + 26],
+                (h[32 * worst + 27] - h[32 * worst]) * 0.01, (h[32 * worst + 28] - h[32 * worst]) * 0.01);
         fprintf(stderr, "\n[kv stamps, mean over slots]            ");
         for (int i = 1; i <= 23; ++i) {
             double acc = 0;
