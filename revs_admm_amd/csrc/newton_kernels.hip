@@ -204,14 +204,20 @@ __device__ __forceinline__ void tree_rows_body(const TreeRowsArgs &a, const int 
         for (int r = tid; r < a.m; r += 256) a.zero_out[(int64_t)r * T + t] = 0.0;
     double yv[8], qv[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 8; ++i) {           // (positions without a row fetch row 0: masked behind the scans)
         const int s = (int)(pk[i] & 0xFFFFu) - 1;
-        yv[i] = s >= 0 ? a.y[(int64_t)s * T + t] : 0.0;
-        qv[i] = s >= 0 ? a.qn[(int64_t)s * T + t] : 0.0;
+        yv[i] = a.y[(int64_t)(s >= 0 ? s : 0) * T + t];
+        qv[i] = a.qn[(int64_t)(s >= 0 ? s : 0) * T + t];
     }
     double v8[8];
     REVS_KVS(t, 1);
-    tree_voltage<256, 8, true>(a.tree, a.p, T, t, lds, v8, pk, nullptr);
+    tree_voltage<256, 8, true, true>(a.tree, a.p, T, t, lds, v8, pk, nullptr);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const bool has = (pk[i] & 0xFFFFu) != 0ull;
+        yv[i] = has ? yv[i] : 0.0;
+        qv[i] = has ? qv[i] : 0.0;
+    }
     double rmax = 0.0, dsum = 0.0, nsup = 0.0, nvio = 0.0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -1016,7 +1022,7 @@ __device__ __forceinline__ bool chain_rows_select_body(const TreeRowsArgs &a, co
 #pragma unroll
     for (int k = 0; k < 8; ++k) yv[k] = a.y[f[k] * T + t];
     double v8[8], qv[8];
-    tree_gather_p<256, 8>(a.tree, a.p, T, t, pk, v8, nullptr);
+    tree_gather_p<256, 8, true>(a.tree, a.p, T, t, pk, v8, nullptr);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int s = (int)(pk[i] & 0xFFFFu) - 1;
@@ -1038,7 +1044,7 @@ __device__ __forceinline__ bool chain_rows_select_body(const TreeRowsArgs &a, co
         ylds[row] = mine;                   // (read behind the scans' barriers)
     }
     REVS_KVS(t, 1);
-    tree_scan<256, 8>(a.tree, t, lds, v8, wgt, pk);
+    tree_scan<256, 8, true>(a.tree, t, lds, v8, wgt, pk);
     double rmax = 0.0, dsum = 0.0, nsup = 0.0, nvio = 0.0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {

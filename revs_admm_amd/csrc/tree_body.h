@@ -101,7 +101,11 @@ __device__ __forceinline__ void tree_fetch_w(const TreeArgs &tr, double (&b)[IPT
         }
     }
 }
-template <int NT, int IPT>
+// STRAIGHT: positions without a row fetch row 0 -- straight-line loads, nothing waits or branches here --
+// and are masked where the values are first used (tree_scan<.., true>).  For the latency-bound operator
+// launches; inside the sweep's kernel the eight values in flight at once would cost registers (spills at
+// its 64-register cap).
+template <int NT, int IPT, bool STRAIGHT = false>
 __device__ __forceinline__ void tree_gather_p(const TreeArgs &tr, const double *p, int T, int t,
                                               const unsigned long long (&pk)[IPT], double (&a)[IPT], double *p_clear) {
     const int j0 = IPT * threadIdx.x;
@@ -112,7 +116,8 @@ __device__ __forceinline__ void tree_gather_p(const TreeArgs &tr, const double *
 #pragma unroll
         for (int i = 0; i < IPT; ++i) {
             const int s = (int)(pk[i] & 0xFFFFu) - 1;
-            a[i] = s >= 0 ? p[(int64_t)s * T + t] : 0.0;
+            if constexpr (STRAIGHT) a[i] = p[(int64_t)(s >= 0 ? s : 0) * T + t];
+            else a[i] = s >= 0 ? p[(int64_t)s * T + t] : 0.0;
         }
         if (p_clear) {
 #pragma unroll
@@ -124,13 +129,17 @@ __device__ __forceinline__ void tree_gather_p(const TreeArgs &tr, const double *
     }
 }
 // a: the gathered node sums, b: the weights (both zero beyond the tree); out: a = the voltages
-template <int NT, int IPT>
+template <int NT, int IPT, bool MASK = false>
 __device__ __forceinline__ void tree_scan(const TreeArgs &tr, int t, double *lds, double (&a)[IPT], double (&b)[IPT],
                                           const unsigned long long (&pk)[IPT]) {
     const int tid = threadIdx.x, n = tr.n, j0 = IPT * tid;
     const bool act = j0 < n;
     double *base = lds + 2, *red0 = lds + 2 + NT * IPT, *red1 = red0 + NT / 64;
     if (tid == 0) lds[1] = 0.0;                                 // base[-1]
+    if constexpr (MASK) {
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) a[i] = (act && (pk[i] & 0xFFFFu) != 0ull) ? a[i] : 0.0;
+    }
 #pragma unroll
     for (int i = 1; i < IPT; ++i) a[i] += a[i - 1];
     REVS_KVS(t, 2);
@@ -179,7 +188,7 @@ __device__ __forceinline__ void tree_scan(const TreeArgs &tr, int t, double *lds
     }
 }
 
-template <int NT, int IPT, bool PK_LOADED = false>
+template <int NT, int IPT, bool PK_LOADED = false, bool STRAIGHT = false>
 __device__ __forceinline__ void tree_voltage(const TreeArgs &tr, const double *p, int T, int t,
                                              double *lds, double (&a)[IPT], unsigned long long (&pk)[IPT],
                                              double *p_clear) {
@@ -197,8 +206,8 @@ __device__ __forceinline__ void tree_voltage(const TreeArgs &tr, const double *p
     }
     double b[IPT];                                              // (b holds the weights until phase 2)
     tree_fetch_w<NT, IPT>(tr, b);
-    tree_gather_p<NT, IPT>(tr, p, T, t, pk, a, p_clear);
-    tree_scan<NT, IPT>(tr, t, lds, a, b, pk);
+    tree_gather_p<NT, IPT, STRAIGHT>(tr, p, T, t, pk, a, p_clear);
+    tree_scan<NT, IPT, STRAIGHT>(tr, t, lds, a, b, pk);
 }
 
 // Largest violation max(v - vhi, vlo - v, 0) over the checked rows of slot t (every thread
@@ -218,8 +227,8 @@ __device__ __forceinline__ double tree_rmax(const TreeArgs &tr, const double *p,
         double b[IPT];
 #pragma unroll
         for (int i = 0; i < IPT; ++i) { pk[i] = pk_pre[i]; b[i] = wgt_pre[i]; }
-        tree_gather_p<NT, IPT>(tr, p, T, t, pk, a, p_clear);
-        tree_scan<NT, IPT>(tr, t, lds, a, b, pk);
+        tree_gather_p<NT, IPT, true>(tr, p, T, t, pk, a, p_clear);
+        tree_scan<NT, IPT, true>(tr, t, lds, a, b, pk);
     } else {
         tree_voltage<NT, IPT>(tr, p, T, t, lds, a, pk, p_clear);
     }
