@@ -16,7 +16,6 @@ struct SlotLists {
     long long ci[kAmax];
     double cs[kAmax], cg[kAmax], cy[kAmax];
     int cnt;
-    double rmax;
 };
 
 struct SelectArgs {
@@ -187,8 +186,8 @@ __device__ __forceinline__ double dual_select_body(const SelectArgs &sa, const i
     constexpr int kRank = 256;
     __shared__ double vval[EAGER ? kRank : 1];
     __shared__ int vrow[EAGER ? kRank : 1];
-    const bool by_rank = EAGER && room > 0 && nv <= kRank;
-    if (by_rank) {
+    const bool collected = EAGER && room > 0 && nv <= kRank;
+    if (collected) {
         // Few violated rows (nv of them carry a positive entry): collected (any order) one per thread, so
         // that the `room` rounds of the block-wide arg-max below compare registers instead of scanning
         // every thread's share of the rows -- larger violation first, ties to the lower row.
@@ -228,7 +227,7 @@ __device__ __forceinline__ double dual_select_body(const SelectArgs &sa, const i
         }
         added = min(room, nq);
     }
-    for (int k = 0; k < (by_rank ? 0 : room); ++k) {
+    for (int k = 0; k < (collected ? 0 : room); ++k) {
         double bv = 0.0;
         int bi = m;
         if (inreg) {
