@@ -227,7 +227,7 @@ __device__ __forceinline__ double tree_rmax(const TreeArgs &tr, const double *p,
         double b[IPT];
 #pragma unroll
         for (int i = 0; i < IPT; ++i) { pk[i] = pk_pre[i]; b[i] = wgt_pre[i]; }
-        tree_gather_p<NT, IPT, true>(tr, p, T, t, pk, a, p_clear);
+        tree_gather_p<NT, IPT, true>(tr, p, T, t, pk, a, nullptr);
         tree_scan<NT, IPT, true>(tr, t, lds, a, b, pk);
     } else {
         tree_voltage<NT, IPT>(tr, p, T, t, lds, a, pk, p_clear);
@@ -249,6 +249,15 @@ __device__ __forceinline__ double tree_rmax(const TreeArgs &tr, const double *p,
     double r = red1[0];
 #pragma unroll
     for (int w = 1; w < NT / 64; ++w) r = fmax(r, red1[w]);
+    if constexpr (PRE) {
+        if (p_clear && IPT * tid < tr.n) {      // (behind everything: the column's stores are off the verdict's path)
+#pragma unroll
+            for (int i = 0; i < IPT; ++i) {
+                const int s = (int)(pk[i] & 0xFFFFu) - 1;
+                if (s >= 0) p_clear[(int64_t)s * T + t] = 0.0;
+            }
+        }
+    }
     return r;
 }
 
