@@ -44,15 +44,33 @@ def build(force: bool = False, verbose: bool = False, out: str | None = None, ex
     if out is None and not force and not _stale():
         return LIB
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    cmd = [hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
-           "-x", "hip", "-I", os.path.join(ROOT, "include"), "-I", CSRC, *extra,
-           "-o", out or LIB] + srcs
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"hipcc failed:\n{r.stdout}\n{r.stderr}")
-    return out or LIB
+    target = out or LIB
+    common = [hipcc(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC",
+              "-I", os.path.join(ROOT, "include"), "-I", CSRC, *extra]
+    # one hipcc per source, side by side (the operator kernels alone take over a minute), then the link
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    with tempfile.TemporaryDirectory(prefix="revs_build_") as tmp:
+        objs = [os.path.join(tmp, os.path.splitext(os.path.basename(s))[0] + ".o") for s in srcs]
+
+        def compile_one(pair):
+            src, obj = pair
+            cmd = common + ["-x", "hip", "-c", src, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            return subprocess.run(cmd, capture_output=True, text=True)
+
+        with ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as pool:
+            for r in pool.map(compile_one, zip(srcs, objs)):
+                if r.returncode != 0:
+                    raise RuntimeError(f"hipcc failed:\n{r.stdout}\n{r.stderr}")
+        link = [hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared", "-o", target] + objs
+        if verbose:
+            print(" ".join(link), flush=True)
+        r = subprocess.run(link, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc (link) failed:\n{r.stdout}\n{r.stderr}")
+    return target
 
 
 if __name__ == "__main__":
