@@ -34,7 +34,7 @@ extern "C" {
 /* consecutive ADMM iterations one launch of the residence sweep can carry in registers
  * (streaming steady state, multipliers zero; revs_plan_set_stream_inner); a launch's LDS holds one
  * set of node-sum accumulators per iteration, so the library uses at most
- * revs_agent_max_inner(T) <= REVS_AGENT_MAX_INNER of them: 32 up to T = 24, 16 up to 48, 8 up to 96, 4 beyond */
+ * revs_agent_max_inner(T) <= REVS_AGENT_MAX_INNER of them: 32 up to T = 24, 16 up to 96, 8 up to 192, 4 beyond */
 #define REVS_AGENT_MAX_INNER 32
 /* the sweep leaves the largest diff of an iteration (the convergence measure, lpsolver.py:284) as
  * REVS_DMAX_SLOTS partial maxima, workgroup b into slot b % REVS_DMAX_SLOTS */

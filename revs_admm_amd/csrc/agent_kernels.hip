@@ -108,8 +108,12 @@ struct AgentArgs {
     double *fold_a, *fold_b;
 };
 constexpr int kMaxInner = REVS_AGENT_MAX_INNER;
+// nodes whose sums a workgroup accumulates in LDS (residences are sorted by node; the others' go straight to
+// global memory): 4 -- but 2 where a lane group is 16 lanes wide with more than 3 slots each (16 residences
+// per workgroup: two nodes unless nodes hold fewer than 8 residences), which buys T = 96 its 16 inner iterations
+constexpr int shape_node_loc(int slots) { return slots > 48 ? 2 : 4; }
 constexpr int shape_max_inner(int slots) {      // inner iterations whose node-sum accumulators fit 24 KB of LDS
-    const int fit = 24576 / (4 * slots * 8);
+    const int fit = 24576 / (shape_node_loc(slots) * slots * 8);
     return fit >= kMaxInner ? kMaxInner : (fit >= 16 ? 16 : (fit >= 8 ? 8 : (fit >= 4 ? 4 : (fit >= 2 ? 2 : 1))));
 }
 
@@ -256,7 +260,7 @@ void agent_step_kernel(const AgentArgs a) {
     // slot, no LDS and no workgroup barrier -- 19.5 us against 18.4 at T = 24, and 149 us against
     // 74 at 125 000 x 96, where a wavefront holds 4 residences and the memory-side f64 atomics
     // quadruple.)
-    constexpr int kNodeLoc = 4, kSlots = LPA * SPL;
+    constexpr int kSlots = LPA * SPL, kNodeLoc = shape_node_loc(kSlots);
     // (at most 24 KB of accumulators per workgroup: 16 iterations up to 32 slots per group, 8 up to 96, 4 beyond)
     constexpr int kAcc = MULTI ? shape_max_inner(kSlots) : 1;
     __shared__ double nacc[kAcc][kNodeLoc][kSlots];

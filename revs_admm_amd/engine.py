@@ -129,7 +129,7 @@ class OperatorOptions:
     # ... and, with blocks, this many consecutive ADMM iterations per sweep launch: no verdict is
     # needed between them, so every residence's state stays in registers (revs_agent_step_multi;
     # profiles read and written once per stream_inner iterations, same bits as one launch each)
-    stream_inner: int = 32       # (the library bounds it by the launch's LDS: 32 up to T = 24, 16 up to 48, 8 up to 96)
+    stream_inner: int = 32       # (the library bounds it by the launch's LDS: 32 up to T = 24, 16 up to 96, 8 up to 192)
     # ... with the all-reduce and the verdicts of a block on a second stream, beside the sweeps of
     # the next block (the collective is hidden as long as it is shorter than a block of sweeps)
     stream_overlap: bool = True
