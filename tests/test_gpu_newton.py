@@ -554,3 +554,25 @@ def test_tree_voltage_matches_dense_product(gpu_lib, case, golden, feeder_R):
     want = np.maximum(np.maximum(ref - vhi, vlo - ref), 0.0)[checked].max(axis=0)
     np.testing.assert_allclose(drm.cpu().numpy(), want, rtol=0, atol=1e-12 * np.abs(ref).max())
     assert (want > 0).any()
+
+
+@pytest.mark.gpu
+def test_wavefront_reductions_keep_the_butterfly_bits(gpu_lib, tmp_path):
+    """wave_sum_d (common.h: v_permlane32_swap / v_permlane16_swap + DPP row rotations) must give the xor
+    butterfly's sums bit for bit -- the general loop's stand-alone kernels and the folded chain share it, and
+    round 2's stored trajectories were made with the shuffles.  tools/probes/wave_reduce.hip carries both
+    forms (the library's own header against the shuffles) and reports the mismatches over 65 536 random
+    doubles of mixed magnitude, and wave_max_d / wave_min_i / wave_incl_scan_i against their shuffle forms."""
+    import os
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "tools", "probes", "wave_reduce.hip")
+    exe = str(tmp_path / "wave_reduce")
+    subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", "-I", os.path.join(root, "include"),
+                    "-I", os.path.join(root, "revs_admm_amd", "csrc"), src, "-o", exe], check=True, capture_output=True)
+    out = subprocess.run([exe], capture_output=True, text=True).stdout
+    assert "mismatches 0 of 65536; max / min / scan disagreements 0;" in out, out
