@@ -762,6 +762,9 @@ typedef struct {
 } revs_chain_fold_state_t;
 int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, revs_chain_fold_state_t *st,
                              int32_t *kept_steps, void *stream);
+/* Newton steps beyond the first that revs_plan_chain_fold_run takes inside the call per iteration
+ * (default 2; 0: every such iteration is handed back at its step, resume = 2). */
+int revs_plan_set_fold_redo(revs_plan_t *plan, int32_t steps);
 
 /* ---- the feeder as a tree: R p in O(nodes) ------------------------------------------
  * The reference forms the LinDistFlow sensitivity matrix R = 2 F D F^T densely

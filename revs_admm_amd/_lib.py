@@ -206,6 +206,7 @@ SIGNATURES = {
     "revs_plan_set_comm": (C.c_int, [_p, _p]),
     "revs_plan_set_stream_block": (C.c_int, [_p, C.c_int32, C.c_int32]),
     "revs_plan_set_stream_inner": (C.c_int, [_p, C.c_int32]),
+    "revs_plan_set_fold_redo": (C.c_int, [_p, C.c_int32]),
     "revs_plan_set_pdhg_dual": (C.c_int, [_p, _p]),
     "revs_plan_stream_run_blocks": (C.c_int, [_p, _i32, C.POINTER(StreamSets), _f64, _f64, _p, _p, _p, _p]),
     "revs_plan_stream_timing": (C.c_int, [_p, C.c_int32]),

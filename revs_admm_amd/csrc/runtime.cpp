@@ -56,6 +56,7 @@ struct revs_plan {
     int32_t block = 0;                     // iterations judged together; <= 1: every launch judges itself
     int32_t overlap = 0;                   // all-reduce + verdicts of a block on `side`, beside the next block's sweeps
     int32_t inner = 1;                     // ADMM iterations per sweep launch (revs_plan_set_stream_inner)
+    int32_t fold_redo = 2;                 // Newton steps beyond the first inside the folded chain (revs_plan_set_fold_redo)
     double *ring = nullptr;                // device: node sums (+ diff tails) of two blocks, double[2][block][stride]
     size_t ring_cap = 0;                   // ... doubles allocated
     bool ring_dirty = true;                // the ring is not known to be all zero (fresh, or a call failed)
@@ -586,7 +587,7 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
     // and operator launch are made again from there -- the general loop's iterates, without its round trips.
     int redo = 0;
     bool redo_pending = false;
-    constexpr int kMaxRedo = 2;
+    const int kMaxRedo = plan->fold_redo;
     for (int32_t k = 0; k < max_steps; ++k) {
         const Set S0 = set_of(par, 0), S1 = set_of(par, 1), S0n = set_of(par ^ 1, 0), S1n = set_of(par ^ 1, 1);
         if (redo_pending) {
@@ -982,6 +983,12 @@ extern "C" int revs_plan_set_stream_block(revs_plan_t *plan, int32_t block, int3
     }
     plan->block = block;
     plan->overlap = overlap != 0;
+    return REVS_OK;
+}
+
+extern "C" int revs_plan_set_fold_redo(revs_plan_t *plan, int32_t steps) {
+    REVS_REQUIRE(plan && steps >= 0 && steps <= 8, "revs_plan_set_fold_redo: steps=%d outside 0..8", steps);
+    plan->fold_redo = steps;
     return REVS_OK;
 }
 

@@ -97,6 +97,7 @@ class OperatorOptions:
     # itself and folds both evaluations' node sums into its own pass -- one pass over the residences
     # and two launches per iteration instead of three passes and five (revs_plan_chain_fold_run)
     chain_fold: bool = True
+    fold_redo: int = 2           # Newton steps beyond the first taken inside the folded chain per iteration (0: handed back)
     newton_delta: float = 1e-10  # relative diagonal shift of the model Hessian
     newton_pivots: int = 300     # block-pivoting limit per model problem
     newton_ls: int = 30          # Armijo halvings
@@ -386,6 +387,7 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
             if not self._plan:
                 raise _lib.RevsError("revs_plan_create failed: "
                                      + self.lib.revs_last_error().decode())
+            check(self.lib.revs_plan_set_fold_redo(self._plan, int(self.op.fold_redo)), "revs_plan_set_fold_redo")
         # third node-sum buffer and the feeder as a tree: streaming steady state
         self.p_alt2 = nz()
         self._burst = max(1, int(self.op.stream_burst))

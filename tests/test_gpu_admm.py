@@ -580,8 +580,8 @@ def test_native_step_and_fused_home_pass_change_nothing(gpu_lib, mode, T, monkey
         cmp(r[2], ref[2])
 
 
-@pytest.mark.parametrize("mode,stress", [("binary", 1.0), ("relaxed_exact", 1.3), ("pdhg", 1.3)])
-def test_chained_newton_iteration_changes_nothing(gpu_lib, mode, stress):
+@pytest.mark.parametrize("mode,stress,redo", [("binary", 1.0, 2), ("binary", 1.0, 0), ("relaxed_exact", 1.3, 2), ("pdhg", 1.3, 2)])
+def test_chained_newton_iteration_changes_nothing(gpu_lib, mode, stress, redo):
     """The binding steady state enqueued whole (evaluation, small model, step decided on the
     device, evaluation, sweep: engine._chain_launch) against the driver that reads every
     evaluation before going on: same schedules and multipliers, bit for bit.  (PDHG homes: to
@@ -594,7 +594,9 @@ def test_chained_newton_iteration_changes_nothing(gpu_lib, mode, stress):
     w.load, w.cost = f32(w.load), f32(w.cost)
     runs = []
     for chain in (True, False):
-        e = _engine(w, mode, op=OperatorOptions(chain=chain))
+        # (redo = 0: a trial that needs a second Newton step is handed back at the step and the solve goes on
+        # in the caller's loop; 2: the second and third steps are taken inside the native call)
+        e = _engine(w, mode, op=OperatorOptions(chain=chain, fold_redo=redo))
         d = e.run(60)
         runs.append((d, e.result(), e.yd[0].cpu().numpy(), e))
     (d1, r1, y1, e1), (d0, r0, y0, e0) = runs
