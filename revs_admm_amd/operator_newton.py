@@ -426,6 +426,8 @@ class DualNewtonMixin:
                 self.op_iters_hist[-1] = 2 + st.redone
         if n == count or (n and st.redone and not stepped and st.resume == 1):
             return n
+        if st.redone or stepped:               # y is a Newton step the call has made: it carries multipliers
+            self._y_support = True
         if stepped:
             # the operator's solve goes on from the step the chain has made: one chained iteration issued
             # in phases (evaluation, model, step, evaluation, sweep), the general loop behind it
