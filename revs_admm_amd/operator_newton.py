@@ -420,7 +420,7 @@ class DualNewtonMixin:
             self.op_converged = True
             self.chain_hist[0] += n
             self.iteration += n
-            if st.redone and not stepped:      # the last kept iteration took more Newton steps inside the call
+            if st.redone and st.resume == 1:   # the last kept iteration took more Newton steps inside the call
                 self.fold_steps += st.redone
                 self.newton_hist[-1] = (1 + st.redone, 2 + st.redone, -1)
                 self.op_iters_hist[-1] = 2 + st.redone
@@ -437,13 +437,12 @@ class DualNewtonMixin:
                 done = self._chain_run_phases(1)
                 self._book_step_before(st.pivots, 1 + st.redone)
                 return n + done
-            step_pivots = st.pivots
         # the call stopped at an iteration that is the general loop's: a fresh solve from the current
         # multipliers (the folded chain's stats and lists are its own), then the sweep on its answer
         self._sup = None
         ok = self._operator_solve_newton()
-        if ok and stepped:
-            self._book_step_before(step_pivots, 1 + st.redone)
+        if ok and (stepped or st.redone):
+            self._book_step_before(st.pivots if stepped else 0, (1 if stepped else 0) + st.redone)
         self.chain_hist[1] += 1
         if not ok:
             self._fast_cold = True
