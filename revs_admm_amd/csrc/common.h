@@ -84,6 +84,24 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     v += dpp_rot_d<0x121>(v);
     return v;
 }
+// N independent sums at once, level by level: the chains of different values interleave (one after the
+// other each is ~18 dependent instructions with nothing to fill the gaps).  Same association as wave_sum_d.
+template <int N>
+__device__ __forceinline__ void wave_sum_multi_d(double (&v)[N]) {
+    double a0, a1;
+#pragma unroll
+    for (int e = 0; e < N; ++e) { swap_pair_d<true>(v[e], a0, a1); v[e] = a0 + a1; }
+#pragma unroll
+    for (int e = 0; e < N; ++e) { swap_pair_d<false>(v[e], a0, a1); v[e] = a0 + a1; }
+#pragma unroll
+    for (int e = 0; e < N; ++e) v[e] += dpp_rot_d<0x128>(v[e]);
+#pragma unroll
+    for (int e = 0; e < N; ++e) v[e] += dpp_rot_d<0x124>(v[e]);
+#pragma unroll
+    for (int e = 0; e < N; ++e) v[e] += dpp_rot_d<0x122>(v[e]);
+#pragma unroll
+    for (int e = 0; e < N; ++e) v[e] += dpp_rot_d<0x121>(v[e]);
+}
 __device__ __forceinline__ double wave_max_d(double v) {
     double a0, a1;
     swap_pair_d<true>(v, a0, a1);  v = fmax(a0, a1);

@@ -1212,13 +1212,29 @@ __device__ __forceinline__ void chain_fast_body(
     __shared__ double Ks[kSmall][kSmall];
     __shared__ double yo_s[kSmall];
     REVS_KVS(t, 13);
+    {
+        // the A (A + 1) / 2 sums level by level (their chains interleave), then ONE store: lane e keeps entry e
+        constexpr int kN = A * (A + 1) / 2;
+        double red[kN];
+        int e = 0;
 #pragma unroll
-    for (int i = 0; i < A; ++i)
+        for (int i = 0; i < A; ++i)
 #pragma unroll
-        for (int jj = i; jj < A; ++jj) {
-            const double v = wave_sum_d(acc[tri(i, jj)]);
-            if ((tid & 63) == 0) part[tid >> 6][tri(i, jj)] = v;
-        }
+            for (int jj = i; jj < A; ++jj) red[e++] = acc[tri(i, jj)];
+        wave_sum_multi_d<kN>(red);
+        double mine = 0.0;
+        int slot = 0;
+        e = 0;
+#pragma unroll
+        for (int i = 0; i < A; ++i)
+#pragma unroll
+            for (int jj = i; jj < A; ++jj, ++e) {
+                const bool me = (tid & 63) == e;
+                mine = me ? red[e] : mine;
+                slot = me ? tri(i, jj) : slot;
+            }
+        if ((tid & 63) < kN) part[tid >> 6][slot] = mine;
+    }
     __syncthreads();
     REVS_KVS(t, 14);
     if (tid < kSmall * kSmall) {
