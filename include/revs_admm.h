@@ -44,6 +44,9 @@ extern "C" {
 /* ... of which a launch that judges its own rows (revs_plan_stream_run with block <= 1) and the
  * Newton evaluations' tree form hold this many (one workgroup of 256 threads, 8 positions each) */
 #define REVS_TREE_SWEEP_MAX 2048
+/* rows (constraint nodes) the folded chain's operator launch holds: a slot's multipliers, voltages and
+ * violations are staged in one workgroup's LDS (revs_plan_chain_fold_run) */
+#define REVS_CHAIN_FOLD_MAX_M 4096
 typedef struct {
     int32_t n;
     const uint64_t *pack;

@@ -21,7 +21,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, tag = sys.argv[1], sys.argv[2]
 homes, T, bytes_per_home = 100_000, 24, int(os.environ.get("REVS_BYTES_PER_HOME", "728"))
 # round 3: the steady state's launches are the multi-iteration sweep (template argument MULTI = true,
-# 8 ADMM iterations per launch); round 2: one iteration per launch with T verdict workgroups in front
+# up to 32 ADMM iterations per launch -- only the full-length launches are summarised); round 2: one iteration
+# per launch with T verdict workgroups in front
 multi = tag >= "r03"
 grid = ((homes + 31) // 32 + (0 if multi else T)) * 256
 rows, res = [], {}

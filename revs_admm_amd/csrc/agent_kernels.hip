@@ -435,6 +435,9 @@ void agent_step_kernel(const AgentArgs a) {
     float p[SPL], gn[SPL], gmn[SPL], pe2[SPL];
     int status = 0, sticky = 0;
     float ddg = 0.f, dfh = 0.f;
+    unsigned dmx_mine = 0u;                                  // lane i: the wavefront's max diff of inner iteration i
+    float *diff_it = a.diff + (live ? agent : 0);
+    double *pnext_it = a.p_next ? a.p_next + (int64_t)node * T + t0 : nullptr;     // this lane's first slot, this iteration's slice
     const bool need_pe2 = a.p_next != nullptr;
 #pragma unroll 1
     for (int it = 0;; ++it) {
@@ -489,10 +492,11 @@ void agent_step_kernel(const AgentArgs a) {
             lo[j] = (t0 + j == T - 1) ? lo_last : 0.f;
             // warm start: primal from the previous schedule (P_sch[k] - LOAD), dual from
             // the previous iteration's multipliers when the caller keeps them
-            x[j] = a.y_state ? fminf(fmaxf((pso[j] - L[j]) * inv_rate, 0.f), w[j]) : 0.f;
+            x[j] = a.y_state ? clip3((pso[j] - L[j]) * inv_rate, 0.f, w[j]) : 0.f;
         }
         const bool infeasible = pd_infeasible;
         bool done = !ev || infeasible;
+        bool unpolished = false;
         int iters = 0;
         const int check = max(a.pd.check, 1);
         if constexpr (!FULL_ROWS) {
@@ -528,7 +532,7 @@ void agent_step_kernel(const AgentArgs a) {
                 for (int c = 1; c < check; ++c) iterate1(std::false_type{});
                 float res = iterate1(std::true_type{});
                 iters += done ? 0 : check;
-                res = group_max<LPA>(res);
+                res = group_max_nonneg<LPA>(res);
                 done = done || (res <= pd_tol);
             }
             // KKT polish on the piece PDHG has identified.  For the terminal row's multiplier mu
@@ -545,29 +549,57 @@ void agent_step_kernel(const AgentArgs a) {
                 // PDHG stopped; the loop ends as soon as every residence of the wavefront is there)
 #pragma unroll 1
                 for (int r = 0;; ++r) {
-                    float sxm = 0.f, nf = 0.f;
+                    float sxm = 0.f, u[SPL];
 #pragma unroll
                     for (int j = 0; j < SPL; ++j) {
-                        const float u = fmaf(-delta, mu, -b[j]);
-                        sxm += clip3(u, 0.f, w[j]);
-                        nf += (u > 0.f && u < w[j]) ? 1.f : 0.f;
+                        u[j] = fmaf(-delta, mu, -b[j]);
+                        sxm += clip3(u[j], 0.f, w[j]);
                     }
                     sxm = group_sum<LPA>(sxm);
-                    nf = group_sum<LPA>(nf);
                     const float S = delta * sxm;
                     const bool up = mu > 0.f || (mu == 0.f && S > hi);
                     const bool dn = mu < 0.f || (mu == 0.f && S < lo_last);
                     const float tgt = up ? hi : (dn ? lo_last : S);
                     fine = fine || fabsf(S - tgt) <= 5e-7f * fmaxf(1.f, fabsf(tgt));
                     if (r == 6 || __all(fine)) break;
+                    // The step: S is piecewise linear in mu with slope -delta^2 x (slots strictly inside their box),
+                    // counted in the direction the step has to go (a slot sitting exactly on a bound moves one way only).
+                    const bool rise = S > tgt;               // mu has to rise (S falls with mu)
+                    // (falling: the same test on w - u -- "0 <= u < w" is "0 < w - u <= w" -- so that both directions
+                    // are one select and two compares per slot, no branch)
+                    float nf = 0.f, uu[SPL];
+#pragma unroll
+                    for (int j = 0; j < SPL; ++j) {
+                        uu[j] = rise ? u[j] : w[j] - u[j];
+                        nf += ((uu[j] > 0.f) & (uu[j] <= w[j])) ? 1.f : 0.f;
+                    }
+                    nf = group_sum<LPA>(nf);
                     float mun = nf > 0.f ? fmaf((S - tgt) * inv_d2, __builtin_amdgcn_rcpf(nf), mu) : mu;
+                    if (__any(!fine & (nf == 0.f))) {
+                        // (rare) flat in that direction: no slot moves until mu reaches the nearest breakpoint there --
+                        // where the first slot leaves w (mu rising: mu_j = -(b_j + w_j) / delta) or leaves 0 (falling:
+                        // mu_j = -b_j / delta)
+                        float bp = -INFINITY;                // max over the candidates of -mu_j delta (rising) / +mu_j delta (falling)
+#pragma unroll
+                        for (int j = 0; j < SPL; ++j) {
+                            const float m = rise ? b[j] + w[j] : -b[j];
+                            bp = ((uu[j] > w[j]) & (w[j] > 0.f)) ? fmaxf(bp, m) : bp;
+                        }
+                        bp = group_max<LPA>(bp) * (delta * inv_d2);
+                        // (a hair beyond it, so that the slot counts as inside its box whatever the rounding)
+                        const float hair = 1e-6f * (fabsf(bp) + 1.f);
+                        const float jump = rise ? hair - bp : bp - hair;
+                        mun = ((nf == 0.f) & (bp > -INFINITY)) ? jump : mun;
+                    }
                     mun = up ? fmaxf(mun, 0.f) : (dn ? fminf(mun, 0.f) : mun);     // a multiplier keeps its sign
                     mu = fine ? mu : mun;
                 }
-                // (a residence the steps did not settle -- no free slot left to move -- keeps PDHG's iterate)
+                // (a residence the steps did not settle keeps PDHG's iterate -- at PDHG's own, looser tolerance:
+                // status bit 2 says so)
 #pragma unroll
                 for (int j = 0; j < SPL; ++j) x[j] = fine ? clip3(fmaf(-delta, mu, -b[j]), 0.f, w[j]) : x[j];
                 yy = fine ? mu * inv_sig1 : yy;
+                unpolished = !fine;
             }
             yy = ev ? yy : 0.f;
         } else {
@@ -629,7 +661,8 @@ void agent_step_kernel(const AgentArgs a) {
         for (int j = 0; j < SPL; ++j) p[j] = (ev && !infeasible) ? x[j] * h.rating : 0.f;
         // bit 1: the iteration cap was reached before the tolerance (the schedule is then only
         // as good as max_iter passes make it: surfaced, not silently accepted)
-        status = (iters << 8) | ((ev && !infeasible && !done) ? 2 : 0) | (infeasible ? 1 : 0);
+        // bit 2: the KKT polish did not settle (the schedule is PDHG's iterate at its step tolerance)
+        status = (iters << 8) | (unpolished ? 4 : 0) | ((ev && !infeasible && !done) ? 2 : 0) | (infeasible ? 1 : 0);
     } else {
         // closed form: p_t = clip(u_t + nu, 0, ub_t), u = -q/kappa; nu is the
         // multiplier of the terminal SOC rows (the only ones that can bind when
@@ -736,22 +769,31 @@ void agent_step_kernel(const AgentArgs a) {
     const float ssg = group_sum<LPA>(ss);
     // lpsolver.py:284; hardware sqrt and reciprocal (1 ulp each) instead of the IEEE sequences
     dfh = live ? __builtin_amdgcn_sqrtf(ssg) * __builtin_amdgcn_rcpf((float)T) : 0.f;
-    sticky |= status & 3;
-    if (live && lig == 0) {
-        a.diff[(long long)it * a.diff_stride + agent] = dfh;
-        if (a.dmax_out) atomicMax(&dmx[it], __float_as_uint(dfh));     // (dfh >= 0: the bit patterns order)
+    sticky |= status & 7;
+    if (live && lig == 0) *diff_it = dfh;
+    diff_it += a.diff_stride;
+    if (a.dmax_out) {
+        // the wavefront's largest diff of this iteration, kept by lane `it` (dfh >= 0: the bit patterns order; every
+        // lane of a group holds its residence's value): no LDS traffic and no scalar code inside the loop -- an
+        // atomicMax from the eight leading lanes compiles to a scalar loop over them, 56 SALU + 8 v_readlane per
+        // iteration -- and one LDS atomic per lane and launch behind it
+        const unsigned m = wave_max_groups_u<LPA>(__float_as_uint(dfh));
+        dmx_mine = (tid & 63) == it ? m : dmx_mine;
     }
     if (a.p_next && live) {
+        // (floats widened to double: the node sums are exact, whatever the order; a slot that does not exist or an
+        // answer of zero adds +0.0 to an accumulator nobody reads / exactly nothing: straight-line LDS adds)
         const int loc = node - base;
+        if (loc < kNodeLoc) {
 #pragma unroll
-        for (int j = 0; j < SPL; ++j) {
-            if (pe2[j] > 0.f) {      // (floats widened to double: the node sums are exact, whatever the order)
-                if (loc < kNodeLoc) unsafeAtomicAdd(&nacc[it][loc][t0 + j], (double)pe2[j]);
-                else unsafeAtomicAdd(&a.p_next[(long long)it * a.slice_stride + (int64_t)node * T + t0 + j],
-                                     (double)pe2[j]);
-            }
+            for (int j = 0; j < SPL; ++j) unsafeAtomicAdd(&nacc[it][loc][t0 + j], (double)pe2[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < SPL; ++j)
+                if (pe2[j] > 0.f) unsafeAtomicAdd(pnext_it + j, (double)pe2[j]);
         }
     }
+    if (a.p_next) pnext_it += a.slice_stride;
     if (!MULTI || it + 1 >= kin) break;
     // the next iteration of the same residences: P_est[g+1] = this iteration's estimate, P_est[g+2]
     // the one just prepared -- exactly the floats a launch per iteration would write and read back
@@ -819,6 +861,7 @@ void agent_step_kernel(const AgentArgs a) {
                                   __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (a.p_next) {
+        if (a.dmax_out && (tid & 63) < kin && dmx_mine != 0u) atomicMax(&dmx[tid & 63], dmx_mine);
         __syncthreads();
         for (int i = tid; i < kin * kNodeLoc * T; i += kBlock) {
             const int itq = i / (kNodeLoc * T), r = i - itq * (kNodeLoc * T);

@@ -156,6 +156,38 @@ __device__ __forceinline__ float group_max(float v) {
     return v;
 }
 
+// max over a group of NON-NEGATIVE floats (their bit patterns order as unsigned integers): v_max_u32 with the DPP
+// move folded in -- fmaxf of a DPP-moved value costs a canonicalising v_max_f32 x, x on top of the move and the max
+template <int LPA>
+__device__ __forceinline__ float group_max_nonneg(float v) {
+    unsigned u = __float_as_uint(v);
+    if constexpr (LPA >= 2) u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0xB1, 0xf, 0xf, true));
+    if constexpr (LPA >= 4) u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x4E, 0xf, 0xf, true));
+    if constexpr (LPA >= 8) u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x141, 0xf, 0xf, true));
+    if constexpr (LPA >= 16) u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x140, 0xf, 0xf, true));
+    if constexpr (LPA >= 32) u = max(u, (unsigned)__shfl_xor((int)u, 16, 64));
+    if constexpr (LPA >= 64) u = max(u, (unsigned)__shfl_xor((int)u, 32, 64));
+    return __uint_as_float(u);
+}
+// max of a non-negative float over the whole wavefront, in EVERY lane, when the LPA lanes of each aligned group
+// already agree: DPP rotations inside the rows of 16, then v_permlane16_swap / v_permlane32_swap (gfx950) across
+template <int LPA>
+__device__ __forceinline__ unsigned wave_max_groups_u(unsigned u) {
+    if constexpr (LPA < 2) u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x121, 0xf, 0xf, true));   // row_ror:1
+    if constexpr (LPA < 4) u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x122, 0xf, 0xf, true));
+    if constexpr (LPA < 8) u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x124, 0xf, 0xf, true));
+    if constexpr (LPA < 16) u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x128, 0xf, 0xf, true));
+    if constexpr (LPA < 32) {
+        const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        u = max((unsigned)a[0], (unsigned)a[1]);
+    }
+    if constexpr (LPA < 64) {
+        const auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        u = max((unsigned)b[0], (unsigned)b[1]);
+    }
+    return u;
+}
+
 // Exclusive prefix / suffix sums over the lanes of a group (lig = lane index inside
 // the group).  Each Hillis-Steele step is written as s = fma(dpp(s), mask, s) with a
 // 0/1 lane mask so that the compiler can fold the DPP move into one v_fmac_f32_dpp;

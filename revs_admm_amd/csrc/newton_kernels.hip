@@ -1513,6 +1513,9 @@ int chain_kv_launch(const ChainKv &c, void *stream) {
     k.sh_a = c.sh_a; k.sh_b = c.sh_b;
     k.prev_ci = c.prev_cidx; k.prev_cc = c.prev_cidx ? c.prev_ccnt : nullptr;
     const size_t lds = ((tree_lds_bytes(c.tree.n) / sizeof(double) + 1) / 2 * 2 + 3 * (size_t)c.m + 4) * sizeof(double);
+    // (a slot's rows are staged in LDS: 3 m doubles beside the tree's scan buffer and ~30 KB of static LDS)
+    REVS_REQUIRE(c.m <= REVS_CHAIN_FOLD_MAX_M && lds <= 128 * 1024,
+                 "chain_kv_launch: m = %d rows do not fit the operator launch's LDS (at most %d)", c.m, REVS_CHAIN_FOLD_MAX_M);
     if (lds > 64 * 1024) {       // (more than 64 KB of dynamic LDS has to be granted, once)
         static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&op_chain_kv_kernel),
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);

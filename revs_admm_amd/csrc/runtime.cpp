@@ -559,6 +559,8 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
                  d.eps > 0 && !d.pdhg.full_rows,
                  "revs_plan_chain_fold_run: needs the feeder as a tree (at most %d nodes), node_of, the chain's "
                  "buffers and the presolved PDHG form", REVS_TREE_SWEEP_MAX);
+    REVS_REQUIRE(d.m <= REVS_CHAIN_FOLD_MAX_M, "revs_plan_chain_fold_run: m = %d constraint nodes, the folded chain's "
+                 "operator launch holds %d (use revs_plan_chain_run)", d.m, REVS_CHAIN_FOLD_MAX_M);
     *kept_steps = 0;
     if (fold_alloc(plan) != REVS_OK) return REVS_ELAUNCH;
     hipStream_t s = (hipStream_t)stream;
@@ -647,6 +649,8 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
                 return REVS_ELAUNCH;
             }
         }
+        // (every earlier sweep of this call has ended -- its verdict was read -- so the status word is final for them)
+        const unsigned int flags_before = plan->flags_host ? *(volatile unsigned int *)plan->flags_host : 0u;
         const revs::ChainFold cf{plan->fold_sh[0], plan->fold_sh[1], d.m, d.kappa, plan->fold_e2[par],
                                  plan->fold_e1[par ^ 1], st->p_est_new};
         rc = revs::agent_step_chain(d.n_homes, d.T, d.cost, d.homes, d.load, st->p_est, st->p_sch, st->gamma,
@@ -717,6 +721,18 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
                     k, par, (int)have_k1, r0, r1, ncm, arm);
         }
         if (!acc) {
+            // The speculative sweep of a rejected or redone iteration does not stand, and neither does what it
+            // said about its own problems: "a PDHG residence stopped at its cap" is dropped from the sticky
+            // status word, as revs_plan_stream_run_blocks does behind a roll-back (the sweep that replaces it
+            // sets the bit again if it is true of the problem that counts; "no solution" does not depend on
+            // the estimate: kept).  The carried PDHG multipliers ARE left where that sweep put them: another
+            // warm start of the same problems.
+            // (the sweep ended before the operator launch whose tags have just been read began: its bits are in;
+            // what the sweeps that stand had said before it was launched is kept)
+            if (plan->flags_host) {
+                volatile unsigned int *fw = (volatile unsigned int *)plan->flags_host;
+                *fw = (*fw & ~2u) | (flags_before & 2u);
+            }
             // The caller's general loop takes this iteration (state untouched).  When the trial is a good
             // Newton step that merely left the rows above the tolerance -- the usual rejection with on/off
             // chargers -- the multipliers are handed back AT the trial (resume = 2): the caller goes on

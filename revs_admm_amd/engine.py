@@ -871,6 +871,17 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
                                  f"({self.pdhg.max_iter}) before its tolerance "
                                  f"({self.pdhg.tol:g}{' = automatic' if self.pdhg.tol == 0 else ''})")
 
+    def _max_diff_all_ranks(self):
+        """max_h diff[h] of the iteration just finished over EVERY rank's residences (the streaming
+        loop's records are global already: each rank's partial maxima travel with the all-reduce).
+        run(eps=) decides on it when to stop, and a rank that stopped on its own residences' maximum
+        alone would leave the others waiting in their next all-reduce."""
+        mx = torch.tensor([float(self.diff.max().item()) if self.n else 0.0], dtype=torch.float64,
+                          device=self.dev)
+        if self.group is not None:
+            self._allreduce(mx, torch.distributed.ReduceOp.MAX)
+        return float(mx.item())
+
     def __del__(self):
         try:
             if getattr(self, "_plan", None):
@@ -915,7 +926,7 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
                     if k == 0:
                         self.check_status()          # (synchronises once)
                     if eps is not None and self.iteration not in self.max_diff:
-                        self.max_diff[self.iteration] = float(self.diff.max().item()) if self.n else 0.0
+                        self.max_diff[self.iteration] = self._max_diff_all_ranks()
                 k += done
                 r += done
                 if stop:

@@ -336,7 +336,7 @@ class DualNewtonMixin:
         a tree the Newton evaluations use, few multipliers per slot (row-wise shifts), presolved PDHG."""
         # (the operator launch stages a slot's rows in LDS: 3 M doubles beside the tree's 16 KB and its own 30 KB)
         return (self._plan is not None and self.group is None and self._tree_newton and self._tree is not None
-                and self.M <= 4096 and self._chain_few
+                and self.M <= _lib.CHAIN_FOLD_MAX_M and self._chain_few
                 and self.op.chain_fold and not self.pdhg.full_rows)
 
     def _chain_run(self, count, write_sc=False):

@@ -84,3 +84,63 @@ def test_two_ranks_equal_one_rank(tmp_path, mode, solver, stress, iters):
     # voltage profile R.(aggregate load): identical on both ranks after the all-reduce
     np.testing.assert_array_equal(r[0]["v"], r[1]["v"])
     np.testing.assert_allclose(r[0]["v"], e.voltage().numpy(), rtol=1e-5, atol=1e-7)
+
+
+def _eps_worker(rank, world, port, eps, out):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import torch.distributed as dist
+    from fake_kernels import FakeKernels
+    from helpers import f32
+    from revs_admm_amd.engine import AdmmEngine
+    from revs_admm_amd.synthetic import make_workload
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w = make_workload(240, 12, n_nodes=24, seed=6, stress=1.02)
+    w.load, w.cost = f32(w.load), f32(w.cost)
+    lo, hi = w.shard(rank, world)
+    e = AdmmEngine(w.cost, w.homes[lo:hi], w.load[lo:hi], w.node_of[lo:hi], w.Rn, kappa=w.kappa,
+                   vset=w.vset, vlow=w.vlow, vhigh=w.vhigh, mode="relaxed_exact", device="cpu",
+                   group=dist.group.WORLD, _kernels=FakeKernels())
+    d = e.run(80, eps=eps, patience=3)
+    np.savez(out.format(rank=rank), d=d, at=-1 if e.converged_at is None else e.converged_at,
+             md=[e.max_diff[k] for k in sorted(e.max_diff)], own=d.max(axis=1))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_run_eps_stops_every_rank_at_the_same_iteration(tmp_path):
+    """AdmmEngine.run(eps=) with residences sharded: iterations that go through step() record
+    max_h diff over EVERY rank's residences (a rank deciding on its own residences'
+    maximum stops alone and the others hang in their next all-reduce)."""
+    import torch.multiprocessing as mp
+    sys.path.insert(0, HERE)
+    from fake_kernels import FakeKernels
+    from helpers import f32
+    from revs_admm_amd.engine import AdmmEngine
+    from revs_admm_amd.synthetic import make_workload
+    w = make_workload(240, 12, n_nodes=24, seed=6, stress=1.02)
+    w.load, w.cost = f32(w.load), f32(w.cost)
+    e = AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, kappa=w.kappa, vset=w.vset, vlow=w.vlow,
+                   vhigh=w.vhigh, mode="relaxed_exact", device="cpu", _kernels=FakeKernels())
+    d_all = e.run(40)
+    # an eps that one half of the residences reaches well before the other half does
+    half = [d_all[:, :120].max(axis=1), d_all[:, 120:].max(axis=1)]
+    gap = [k for k in range(8, 40) if min(half[0][k], half[1][k]) < 0.7 * max(half[0][k], half[1][k])]
+    assert gap, "workload: the halves' maxima never differ enough to tell the two rules apart"
+    k = gap[len(gap) // 2]
+    eps = float(np.sqrt(half[0][k] * half[1][k]))
+    port = 29500 + ((os.getpid() + 977) % 2000)
+    out = str(tmp_path / "e{rank}.npz")
+    mp.spawn(_eps_worker, args=(2, port, eps, out), nprocs=2, join=True)
+    r = [np.load(out.format(rank=q)) for q in range(2)]
+    assert r[0]["d"].shape[0] == r[1]["d"].shape[0]              # same number of iterations
+    assert int(r[0]["at"]) == int(r[1]["at"]) and int(r[0]["at"]) > 0
+    np.testing.assert_array_equal(r[0]["md"], r[1]["md"])       # the records are global
+    both = np.maximum(r[0]["own"], r[1]["own"])
+    np.testing.assert_allclose(r[0]["md"], both[:len(r[0]["md"])], rtol=1e-6)
+    # ... and the one-rank run stops at the same iteration
+    e1 = AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, kappa=w.kappa, vset=w.vset, vlow=w.vlow,
+                    vhigh=w.vhigh, mode="relaxed_exact", device="cpu", _kernels=FakeKernels())
+    d1 = e1.run(80, eps=eps, patience=3)
+    assert e1.converged_at == int(r[0]["at"]) and d1.shape[0] == r[0]["d"].shape[0]
