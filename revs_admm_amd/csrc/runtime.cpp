@@ -192,8 +192,7 @@ extern "C" void revs_plan_destroy(revs_plan_t *plan) {
     if (plan->grp_bits) (void)hipFree(plan->grp_bits);
     if (plan->grp_dmax) (void)hipFree(plan->grp_dmax);
     for (int i = 0; i < 2; ++i) {
-        if (plan->fold_e2[i]) (void)hipFree(plan->fold_e2[i]);
-        if (plan->fold_e1[i]) (void)hipFree(plan->fold_e1[i]);
+        if (plan->fold_e2[i]) (void)hipFree(plan->fold_e2[i]);      // (fold_e1[i ^ 1] is its second half)
         if (plan->fold_ci[i]) (void)hipFree(plan->fold_ci[i]);
         if (plan->fold_cc[i]) (void)hipFree(plan->fold_cc[i]);
         if (plan->fold_cv[i]) (void)hipFree(plan->fold_cv[i]);
@@ -517,8 +516,10 @@ static int fold_alloc(revs_plan_t *plan) {
         if (e == hipSuccess) e = hipMemset(*p, 0, bytes);
     };
     for (int i = 0; i < 2; ++i) {
-        dev((void **)&plan->fold_e2[i], sizeof(double) * 3 * mt);
-        dev((void **)&plan->fold_e1[i], sizeof(double) * 3 * mt);
+        // the two sum arrays one sweep accumulates into -- fold_e2[par] | fold_e1[par ^ 1] -- are one
+        // allocation: sharded, ONE all-reduce per iteration covers both
+        dev((void **)&plan->fold_e2[i], sizeof(double) * 6 * mt);
+        if (e == hipSuccess) plan->fold_e1[i ^ 1] = plan->fold_e2[i] + 3 * mt;
         dev((void **)&plan->fold_ci[i], sizeof(int64_t) * (size_t)d.T * REVS_DUAL_AMAX);
         dev((void **)&plan->fold_cc[i], sizeof(int32_t) * (size_t)d.T);
         dev((void **)&plan->fold_cv[i], sizeof(double) * (size_t)d.T * 3 * REVS_DUAL_AMAX);
@@ -627,6 +628,7 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
                                            d.cand_val, d.stats, 0.0, nullptr, stream);
             }
             if (rc != REVS_OK) return rc;
+            if (plan->comm && (rc = revs_comm_allreduce_f64(plan->comm, d.pnq, 3 * mt, 0, stream)) != REVS_OK) return rc;
             {   // rows, selection, small model, step and the trial's shifts: the operator launch without a trial to judge
                 revs::ChainKv c0{};
                 c0.m = d.m; c0.T = d.T; c0.kadd = d.kadd; c0.has_e2 = 0;
@@ -657,6 +659,10 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
                                     st->p_sch_alt, st->gamma_alt, st->s_out, st->c_out, d.diff, d.dsq, d.status,
                                     d.pdhg_dual, (float)d.kappa, d.mode, &d.pdhg, d.node_of, cf, plan->flags_dev, stream);
         if (rc != REVS_OK) return rc;
+        // Residences sharded: every rank's sweep has folded its own residences' addends -- exact and order-independent
+        // (revs_q36 / revs_q32), so the all-reduced sums are the one-process sums bit for bit.  Both arrays in ONE
+        // collective per iteration (6 M T doubles); everything behind it is replicated and deterministic.
+        if (plan->comm && (rc = revs_comm_allreduce_f64(plan->comm, plan->fold_e2[par], 6 * mt, 0, stream)) != REVS_OK) return rc;
         const double seq = -(plan->seq += 1.0);
         revs::ChainKv c{};
         c.m = d.m; c.T = d.T; c.kadd = d.kadd; c.has_e2 = 1;

@@ -798,8 +798,9 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
                     done += self._stream_run(count - done)
                 continue
             native = self._plan is not None and self.group is None and o.solver == "newton"
-            if native and o.chain and self._chain_ok and not (o.speculate and self._spec_ok):
-                done += self._chain_run(count - done)
+            if ((native or (o.solver == "newton" and self._fold_ok())) and o.chain and self._chain_ok
+                    and not (o.speculate and self._spec_ok)):
+                done += self._chain_run(count - done)        # (sharded: the folded chain only)
                 continue
             if not (native and o.speculate and self._spec_ok and o.fuse_home_pass
                     and not self._y_support):

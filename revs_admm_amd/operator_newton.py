@@ -332,10 +332,13 @@ class DualNewtonMixin:
         self.op_converged = True
 
     def _fold_ok(self):
-        """The folded chain applies (revs_plan_chain_fold_run): one GPU, the native plan, the feeder as
-        a tree the Newton evaluations use, few multipliers per slot (row-wise shifts), presolved PDHG."""
+        """The folded chain applies (revs_plan_chain_fold_run): the native plan (sharded: with the library's
+        own communicator in it -- the folded sums are exact and order-independent, one all-reduce of both
+        arrays per iteration), the feeder as a tree the Newton evaluations use, few multipliers per slot
+        (row-wise shifts), presolved PDHG."""
         # (the operator launch stages a slot's rows in LDS: 3 M doubles beside the tree's 16 KB and its own 30 KB)
-        return (self._plan is not None and self.group is None and self._tree_newton and self._tree is not None
+        return (self._plan is not None and (self.group is None or self._comm is not None)
+                and self._tree_newton and self._tree is not None
                 and self.M <= _lib.CHAIN_FOLD_MAX_M and self._chain_few
                 and self.op.chain_fold and not self.pdhg.full_rows)
 
@@ -354,6 +357,19 @@ class DualNewtonMixin:
         """revs_plan_chain_run: the chained iteration as five launches and three passes over the
         residences (sharded runs, feeders without a tree, and the folded chain's second Newton step)."""
         self._fold_resume = False
+        if self.group is not None:
+            # sharded: ONE chained iteration issued in phases around the all-reduces of the node sums
+            # (revs_plan_chain_run is the one-GPU loop), judged and booked as step() does
+            self._chain_launch(write_sc, lambda i: None)
+            if self._chain_accept():
+                self.P_sch, self.P_sch_alt = self.P_sch_alt, self.P_sch
+                self.G, self.G_alt = self.G_alt, self.G
+                self.chain_hist[0] += 1
+            else:
+                self._chain_finish(False, 0, 0, write_sc)
+            self.P_est, self.P_est_new = self.P_est_new, self.P_est
+            self.iteration += 1
+            return 1
         ys = (self.yd[0], self.yd[1])
         bufs = (self.P_est, self.P_est_new, self.P_sch, self.P_sch_alt, self.G, self.G_alt)
         sup0 = self._sup if (self._y_support and self._sup is not None) else -1

@@ -207,9 +207,9 @@ def test_process_group_path_on_one_gpu(gpu_lib):
         # long enough for the steady state: the native two-phase iteration around the all-reduce
         # of p (home pass folded into the sweep, kept and discarded sweeps) == the one-GPU run
         w2 = make_workload(3000, 24, n_nodes=100, seed=5, binary_feasible=False, stress=1.02)
-        # (the folded chain is the one-GPU form of the binding steady state; with a group the chain is
-        # issued in phases around the all-reduces: the reference runs that form too)
-        a = _engine(w2, "pdhg", op=OperatorOptions(chain_fold=False))
+        # (round 4: with the library's communicator the binding steady state runs through the folded chain
+        # sharded too -- one all-reduce of both folded sum arrays per iteration)
+        a = _engine(w2, "pdhg")
         b = _engine(w2, "pdhg", group=dist.group.WORLD)
         da, db = a.run(25), b.run(25)
         assert b._plan is not None and b.spec_hist == a.spec_hist and a.spec_hist[0] > 0 < a.spec_hist[1]
@@ -218,7 +218,7 @@ def test_process_group_path_on_one_gpu(gpu_lib):
         # the streaming steady state with the library's OWN communicator in the loop: sweep ->
         # ncclAllReduce of the node sums on the compute stream -> sweep, launches made in chunks,
         # no host read in between (revs_plan_stream_run) == the one-GPU run, bit for bit
-        a = _engine(w2, "pdhg", op=OperatorOptions(stream_block_single=False, chain_fold=False))   # every launch judges itself
+        a = _engine(w2, "pdhg", op=OperatorOptions(stream_block_single=False))   # every launch judges itself
         b = _engine(w2, "pdhg", group=dist.group.WORLD)
         assert b._comm is not None and b._tree is not None
         for chunk in (3, 40, 37):

@@ -37,6 +37,15 @@ CASES = [
          burst=_SMALL_BURST,
          configs=[dict(tag="b4ov", block=4, overlap=True, hook="gloo"),
                   dict(tag="b32", block=32, overlap=False, hook="gloo")]),
+    # rows that keep binding: the folded chain (revs_plan_chain_fold_run) with residences sharded -- ONE all-reduce
+    # of both folded sum arrays (6 M T doubles) per iteration; PDHG residences and the reference's on/off chargers
+    dict(name="fold", mode="pdhg", n=8000, nodes=200, seed=3, stress=1.3, T=24, chunks=(60, 1, 47, 40), f32=True, fold=True,
+         configs=[dict(tag="b32ov", block=32, overlap=True, hook="gloo"),
+                  dict(tag="noop", block=32, overlap=True, hook="noop")]),
+    dict(name="fold_binary", mode="binary", n=8000, nodes=200, seed=3, stress=1.0, T=24, chunks=(50, 40, 30), f32=True,
+         fold=True,
+         configs=[dict(tag="b32", block=32, overlap=False, hook="gloo"),
+                  dict(tag="noop", block=32, overlap=False, hook="noop")]),
     dict(name="t96", mode="pdhg", n=3000, nodes=200, seed=3, stress=1.02, T=96, chunks=_RAGGED, f32=True,
          burst=_SMALL_BURST,
          configs=[dict(tag="b4ov", block=4, overlap=True, hook="gloo"),
@@ -73,14 +82,14 @@ def two_rank_runs(gpu_lib, tmp_path_factory):
 
 def _reference(case):
     """The one-process run, every launch judging itself (no blocks, no communicator; the binding
-    steady state chained as the sharded engine chains it -- the folded chain is the one-GPU form)."""
+    steady state through the folded chain, as the sharded engine runs it since round 4)."""
     sys.path.insert(0, HERE)
     from sharded_worker import make_case, run_chunks
     from revs_admm_amd.engine import AdmmEngine, OperatorOptions
     w = make_case(case)
     e = AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, kappa=w.kappa, vset=w.vset, vlow=w.vlow,
                    vhigh=w.vhigh, mode=case["mode"], feeder=w.feeder,
-                   op=OperatorOptions(stream_block_single=False, chain_fold=False, **(case.get("burst") or {})))
+                   op=OperatorOptions(stream_block_single=False, **(case.get("burst") or {})))
     assert e._block == 0 and e._comm is None
     return w, run_chunks(e, case["chunks"], case["mode"])
 
@@ -110,10 +119,13 @@ def _mismatch(case, ref, shards):
 def test_two_ranks_with_real_partial_sums_equal_one_rank(two_rank_runs, case):
     w, ref = _reference(case)
     failed = [(int(c), int(k)) for c, k in ref["stream_calls"] if k < c]
-    if case["mode"] != "binary":
-        assert failed, ref["stream_calls"]                 # failed verdicts were crossed
-    assert ref["spec_hist"][0] > 60
     mt = w.M * w.T
+    if case.get("fold"):
+        assert ref["chain_hist"][0] > 30, ref["chain_hist"]    # the binding steady state did the work
+    else:
+        if case["mode"] != "binary":
+            assert failed, ref["stream_calls"]             # failed verdicts were crossed
+        assert ref["spec_hist"][0] > 60
     for cfg in case["configs"]:
         shards = [np.load(two_rank_runs / f"{case['name']}_{cfg['tag']}_r{r}.npz") for r in range(2)]
         assert int(shards[0]["lo"]) == 0 and int(shards[0]["hi"]) == int(shards[1]["lo"]) > 0
@@ -125,7 +137,10 @@ def test_two_ranks_with_real_partial_sums_equal_one_rank(two_rank_runs, case):
             assert np.array_equal(shards[0]["hook_calls"], shards[1]["hook_calls"])
             sizes = shards[0]["hook_calls"]
             slice_ = mt + 2 * 64          # a ring slice: the node sums, then REVS_DMAX_SLOTS partial maxima of diff per rank
-            if cfg["block"] > 1:
+            if case.get("fold"):
+                # the folded chain ran sharded: one collective of both folded arrays per chained iteration
+                assert (sizes == 6 * mt).sum() >= ref["chain_hist"][0] - 20, ((sizes == 6 * mt).sum(), ref["chain_hist"])
+            elif cfg["block"] > 1:
                 blocks = sizes[(sizes >= slice_) & (sizes % slice_ == 0)]
                 assert len(blocks) > 3 and blocks.max() <= cfg["block"] * slice_
                 assert blocks.max() == min(cfg["block"], max(case["chunks"])) * slice_ or case["chunks"] is _RAGGED
@@ -136,4 +151,4 @@ def test_two_ranks_with_real_partial_sums_equal_one_rank(two_rank_runs, case):
             # negative controls: without the sums of the other rank (or with only one slice of
             # them) the verdicts are taken on wrong voltages -- the run must come out different
             assert bad, cfg
-            assert any(b.startswith(("P_sch", "G_", "stream_calls", "spec_hist")) for b in bad), bad[:8]
+            assert any(b.startswith(("P_sch", "G_", "stream_calls", "spec_hist", "chain_hist", "op_iters")) for b in bad), bad[:8]
