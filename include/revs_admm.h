@@ -46,7 +46,7 @@ extern "C" {
 #define REVS_TREE_SWEEP_MAX 2048
 /* rows (constraint nodes) the folded chain's operator launch holds: a slot's multipliers, voltages and
  * violations are staged in one workgroup's LDS (revs_plan_chain_fold_run) */
-#define REVS_CHAIN_FOLD_MAX_M 4096
+#define REVS_CHAIN_FOLD_MAX_M 2048
 typedef struct {
     int32_t n;
     const uint64_t *pack;

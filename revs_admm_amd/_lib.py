@@ -99,7 +99,7 @@ HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_
 
 TREE_MAX = 16384         # REVS_TREE_MAX
 TREE_SWEEP_MAX = 2048    # REVS_TREE_SWEEP_MAX
-CHAIN_FOLD_MAX_M = 4096  # REVS_CHAIN_FOLD_MAX_M
+CHAIN_FOLD_MAX_M = 2048  # REVS_CHAIN_FOLD_MAX_M
 STREAM_BLOCK_MAX = 256   # REVS_STREAM_BLOCK_MAX
 AGENT_MAX_INNER = 32     # REVS_AGENT_MAX_INNER
 

@@ -99,7 +99,7 @@ struct AgentArgs {
     // kernel's arithmetic, bit for bit -- the operator launch before this sweep computes them) and
     // writes it to pe_out; it accumulates that evaluation's node sums p | N | -(kappa/2) sum g^2 into
     // fold_a and, after the dual update, those of the evaluation of the SAME multipliers on the state
-    // it has just produced into fold_b (both double[3][sh_m][T], zero on entry; shifts sh_b: the
+    // it has just produced into fold_b (both double[T][sh_m][4] = {p, N, q, 0}, slot-major, zero on entry; shifts sh_b: the
     // same sums taken in the order that evaluation's own home pass would take them): one pass over
     // the residences per ADMM iteration while rows keep binding.
     const double *sh_a, *sh_b;
@@ -340,9 +340,60 @@ void agent_step_kernel(const AgentArgs a) {
     }
     const int node = ((a.p_next || CHAIN) && live) ? a.node_of[agent] : 0;
     double dl[CHAIN ? SPL : 1];      // the shifts of this lane's slots
+    // One node under the whole wavefront (the usual case: residences are sorted by node, ~6 wavefronts per node) and
+    // its accumulators in LDS: the eight residences' addends are summed across the lane groups first -- exact sums,
+    // any order gives the evaluation kernel's bits -- and ONE group issues the LDS atomics: 8 lanes on 8 addresses
+    // instead of 64 lanes on 8 (an LDS atomic serialises the lanes that share an address; eighteen of them per
+    // wavefront were the folded sweep's bound).
+    bool fold_uni = false;
+    int fold_loc = 0;
+    if constexpr (CHAIN) {
+        const int n0 = __builtin_amdgcn_readfirstlane(node);
+        fold_loc = n0 - base;
+        fold_uni = __all(!live || node == n0) && fold_loc < kNodeLoc;
+    }
+    // p | N | sum g^2 of one evaluation into accumulator set f (fold_a / fold_b behind it); zero addends where the
+    // residence is clamped
+    auto fold_add = [&](const int f, const double (&gq)[CHAIN ? SPL : 1], const double (&cn)[CHAIN ? SPL : 1],
+                        const double (&g2)[CHAIN ? SPL : 1]) {
+        if constexpr (CHAIN) {
+            double *const glob = f ? a.fold_b : a.fold_a;
+            if (fold_uni) {
+#pragma unroll
+                for (int j = 0; j < SPL; ++j) {
+                    const double s0 = wave_sum_over_groups_d<LPA>(gq[j]);
+                    const double s1 = wave_sum_over_groups_d<LPA>(cn[j]);
+                    const double s2 = wave_sum_over_groups_d<LPA>(g2[j]);
+                    if ((tid & 63) < LPA) {
+                        unsafeAtomicAdd(&facc[f][0][fold_loc][t0 + j], s0);
+                        unsafeAtomicAdd(&facc[f][1][fold_loc][t0 + j], s1);
+                        unsafeAtomicAdd(&facc[f][2][fold_loc][t0 + j], s2);
+                    }
+                }
+            } else {
+                const int loc = node - base;
+#pragma unroll
+                for (int j = 0; j < SPL; ++j) {
+                    if (cn[j] != 0.0) {
+                        if (loc < kNodeLoc) {
+                            unsafeAtomicAdd(&facc[f][0][loc][t0 + j], gq[j]);
+                            unsafeAtomicAdd(&facc[f][1][loc][t0 + j], 1.0);
+                            unsafeAtomicAdd(&facc[f][2][loc][t0 + j], g2[j]);
+                        } else {
+                            const int64_t o = 4 * ((int64_t)(t0 + j) * a.sh_m + node);      // [T][m][4]: {p, N, q, 0} per slot and node
+                            unsafeAtomicAdd(&glob[o], gq[j]);
+                            unsafeAtomicAdd(&glob[o + 1], 1.0);
+                            unsafeAtomicAdd(&glob[o + 2], -0.5 * a.sh_kappa * g2[j]);
+                        }
+                    }
+                }
+            }
+        }
+    };
     if constexpr (CHAIN) {
         // the operator's answer of this iteration, as op_dual_eval_kernel forms it, and its node sums
         const int loc = node - base;
+        double gq[SPL], cn[SPL], g2[SPL];
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
             dl[j] = valid[j] ? (loc < kNodeLoc ? dsh[0][loc][t0 + j] : a.sh_a[(int64_t)(t0 + j) * a.sh_m + node]) : 0.0;
@@ -350,24 +401,11 @@ void agent_step_kernel(const AgentArgs a) {
             const bool fr = valid[j] && g0 > dl[j];
             const double g = fr ? g0 - dl[j] : 0.0;
             pen[j] = (float)g;
-            if (fr) {
-                const double gq = revs_q36(g), g2 = revs_q32(g * g);
-#ifdef REVS_CHAIN_NO_FACC      // (tuning build: what do the accumulators cost?  wrong sums)
-                if (gq == -1.0) facc[0][0][0][0] = g2;
-#else
-                if (loc < kNodeLoc) {
-                    unsafeAtomicAdd(&facc[0][0][loc][t0 + j], gq);
-                    unsafeAtomicAdd(&facc[0][1][loc][t0 + j], 1.0);
-                    unsafeAtomicAdd(&facc[0][2][loc][t0 + j], g2);
-                } else {
-                    const int64_t o = (int64_t)node * T + t0 + j, mt = (int64_t)a.sh_m * T;
-                    unsafeAtomicAdd(&a.fold_a[o], gq);
-                    unsafeAtomicAdd(&a.fold_a[o + mt], 1.0);
-                    unsafeAtomicAdd(&a.fold_a[o + 2 * mt], -0.5 * a.sh_kappa * g2);
-                }
-#endif
-            }
+            gq[j] = revs_q36(g);            // (g = 0 where clamped: zero addends)
+            cn[j] = fr ? 1.0 : 0.0;
+            g2[j] = revs_q32(g * g);
         }
+        fold_add(0, gq, cn, g2);
     }
     const bool ev = h.ev != 0;
 #pragma unroll
@@ -738,30 +776,18 @@ void agent_step_kernel(const AgentArgs a) {
     }
     if constexpr (CHAIN) {      // the evaluation of the same multipliers on the state just produced
         const int loc = node - base;
+        double gq[SPL], cn[SPL], g2[SPL];
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
             const double g0 = (double)revs_g0f(pen[j], gn[j], gmn[j], inv_kf);
             const double ds = valid[j] ? (loc < kNodeLoc ? dsh[1][loc][t0 + j] : a.sh_b[(int64_t)(t0 + j) * a.sh_m + node]) : 0.0;
             const bool fr = valid[j] && g0 > ds;
             const double g = fr ? g0 - ds : 0.0;
-            if (fr) {
-                const double gq = revs_q36(g), g2 = revs_q32(g * g);
-#ifdef REVS_CHAIN_NO_FACC
-                if (gq == -1.0) facc[1][0][0][0] = g2;
-#else
-                if (loc < kNodeLoc) {
-                    unsafeAtomicAdd(&facc[1][0][loc][t0 + j], gq);
-                    unsafeAtomicAdd(&facc[1][1][loc][t0 + j], 1.0);
-                    unsafeAtomicAdd(&facc[1][2][loc][t0 + j], g2);
-                } else {
-                    const int64_t o = (int64_t)node * T + t0 + j, mt = (int64_t)a.sh_m * T;
-                    unsafeAtomicAdd(&a.fold_b[o], gq);
-                    unsafeAtomicAdd(&a.fold_b[o + mt], 1.0);
-                    unsafeAtomicAdd(&a.fold_b[o + 2 * mt], -0.5 * a.sh_kappa * g2);
-                }
-#endif
-            }
+            gq[j] = revs_q36(g);
+            cn[j] = fr ? 1.0 : 0.0;
+            g2[j] = revs_q32(g * g);
         }
+        fold_add(1, gq, cn, g2);
     }
     // per-home residual terms; the norms over all homes are folded by revs_residual_finalize
     // only when somebody asks for them (no workgroup reduction in the sweep, which is VALU
@@ -880,14 +906,16 @@ void agent_step_kernel(const AgentArgs a) {
     }
     if constexpr (CHAIN) {
         __syncthreads();
-        const int64_t mt = (int64_t)a.sh_m * T;
-        for (int i = tid; i < 2 * 3 * kNodeLoc * T; i += kBlock) {
-            const int f = i / (3 * kNodeLoc * T), r0 = i - f * (3 * kNodeLoc * T);
-            const int q = r0 / (kNodeLoc * T), r1 = r0 - q * (kNodeLoc * T);
-            const int l = r1 / T, t = r1 - l * T;
+        // (fold_a / fold_b are slot-major, [T][m][4] = {p, N, q, 0}: a slot's block is contiguous for the operator launch's
+        // coalesced read, and this workgroup's kNodeLoc nodes x 3 quantities of a slot are 12 consecutive threads on one
+        // or two cache lines)
+        for (int i = tid; i < 2 * T * kNodeLoc * 3; i += kBlock) {
+            const int f = i / (T * kNodeLoc * 3), r0 = i - f * (T * kNodeLoc * 3);
+            const int tl = r0 / 3, q = r0 - tl * 3;
+            const int t = tl / kNodeLoc, l = tl - t * kNodeLoc;
             const double v = facc[f][q][l][t];
             if (v != 0.0 && base + l < a.sh_m)
-                unsafeAtomicAdd((f ? a.fold_b : a.fold_a) + q * mt + (int64_t)(base + l) * T + t,
+                unsafeAtomicAdd((f ? a.fold_b : a.fold_a) + 4 * ((int64_t)t * a.sh_m + base + l) + q,
                                 q == 2 ? -0.5 * a.sh_kappa * v : v);
         }
     }

@@ -84,6 +84,19 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     v += dpp_rot_d<0x121>(v);
     return v;
 }
+// Sum over the 64 / LPA aligned lane groups of a wavefront, lane by lane (lane i of every group gets the sum of
+// lane i of all groups): the butterfly's steps at distance >= LPA only.
+template <int LPA>
+__device__ __forceinline__ double wave_sum_over_groups_d(double v) {
+    double a0, a1;
+    if constexpr (LPA <= 32) { swap_pair_d<true>(v, a0, a1);  v = a0 + a1; }
+    if constexpr (LPA <= 16) { swap_pair_d<false>(v, a0, a1); v = a0 + a1; }
+    if constexpr (LPA <= 8) v += dpp_rot_d<0x128>(v);      // row_ror:8
+    if constexpr (LPA <= 4) v += dpp_rot_d<0x124>(v);
+    if constexpr (LPA <= 2) v += dpp_rot_d<0x122>(v);
+    if constexpr (LPA <= 1) v += dpp_rot_d<0x121>(v);
+    return v;
+}
 // N independent sums at once, level by level: the chains of different values interleave (one after the
 // other each is ~18 dependent instructions with nothing to fill the gaps).  Same association as wave_sum_d.
 template <int N>

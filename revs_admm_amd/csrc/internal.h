@@ -37,8 +37,9 @@ int agent_step_stream(int64_t n_homes, int32_t T, const float *cost, const revs_
 // The folded chain's sweep (AgentArgs::sh_a in agent_kernels.hip): the residences' iteration with
 // the operator's answer formed inside, pen = max(g0 - d[node], 0), d = sh_a (double[m][T]: the shifts
 // R^T y / kappa of the trial multipliers, written by the operator launch before); pe_out receives
-// it; fold_a / fold_b (double[3][m][T], zero on entry) receive the node sums p | N | -(kappa/2) sum g^2
-// of that evaluation and of the evaluation of the same multipliers on the new state (shifts sh_b).
+// it; fold_a / fold_b (double[T][m][4] = {p, N, -(kappa/2) sum g^2, 0} per slot and node, zero on entry)
+// receive the node sums of that evaluation and of the evaluation of the same multipliers on the new state
+// (shifts sh_b).
 struct ChainFold {
     const double *sh_a, *sh_b;
     int32_t m;
@@ -57,7 +58,7 @@ int agent_step_chain(int64_t n_homes, int32_t T, const float *cost, const revs_h
 // the rows (vfull, viol, partial -- the two sides run in ONE launch: separate scratch), the
 // candidate set and stats block its selection fills, tagged `seq`.  e2 (has_e2): the trial of the
 // iteration before -- rows and selection only; e1: rows, selection, small model and step into
-// y_trial (lin_out: the linear term, into the trial's stats block).  clr0 / clr1: double[3 m T]
+// y_trial (lin_out: the linear term, into the trial's stats block).  clr0 / clr1: double[4 m T]
 // arrays cleared on the way (NULL: none).
 struct ChainKvSide {
     const double *pnq, *y;
@@ -66,6 +67,10 @@ struct ChainKvSide {
     int32_t *ccnt;
     double *cval, *stats;
     double seq;
+    // layout of pnq: 1 = planar double[3][m][T] (the evaluation kernel's), 4 = double[T][m][4] = {p, N, q, 0} per
+    // slot and node, slot-major (the folded sweep's: a slot's block is contiguous -- the operator launch reads it with
+    // coalesced loads in its first round trip and gathers by tree position from LDS)
+    int32_t es = 1;
 };
 struct ChainKv {
     int32_t m, T, kadd, has_e2;
@@ -83,6 +88,11 @@ struct ChainKv {
     // multiplier is on them, so the slots need not gather the multipliers' columns (NULL: unknown)
     const int64_t *prev_cidx = nullptr;
     const int32_t *prev_ccnt = nullptr;
+    // has_e2 launches keep e1's stats in device memory (e1.stats): fwd_src = where the PREVIOUS launch left the stats
+    // of the evaluation this launch's verdict belongs to, fwd_dst = the host-visible block the driver reads them from
+    // (copied by the verdict half in front of its tag; NULL: that evaluation wrote the host block itself)
+    const double *fwd_src = nullptr;
+    double *fwd_dst = nullptr;
 };
 int chain_kv_launch(const ChainKv &c, void *stream);
 

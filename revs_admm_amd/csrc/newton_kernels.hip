@@ -167,6 +167,8 @@ struct TreeRowsArgs {
     double vlo, vhi;
     double *vfull, *viol, *partial, *zero_out;
     double *ycopy_out = nullptr;   // != NULL: the slot's multipliers are copied there, row by row (the next trial's start)
+    int es = 1;                    // layout of p / qn (ChainKvSide::es): 1 = planar [m][T] arrays; 4 = the folded sweep's [T][m][4] =
+                                   // {p, N, q, 0} per slot and node, slot-major (p = base, qn = base + 2)
 };
 // rows_lds != NULL (double[3 m + 4] of LDS): the slot's multipliers, voltages and violations by row and
 // the four sums are left THERE for a selection that follows in the same workgroup
@@ -207,11 +209,17 @@ __device__ __forceinline__ void tree_rows_body(const TreeRowsArgs &a, const int 
     for (int i = 0; i < 8; ++i) {           // (positions without a row fetch row 0: masked behind the scans)
         const int s = (int)(pk[i] & 0xFFFFu) - 1;
         yv[i] = a.y[(int64_t)(s >= 0 ? s : 0) * T + t];
-        qv[i] = a.qn[(int64_t)(s >= 0 ? s : 0) * T + t];
+        qv[i] = a.es == 4 ? a.qn[4 * ((int64_t)t * a.m + (s >= 0 ? s : 0))] : a.qn[(int64_t)(s >= 0 ? s : 0) * T + t];
     }
     double v8[8];
     REVS_KVS(t, 1);
-    tree_voltage<256, 8, true, true>(a.tree, a.p, T, t, lds, v8, pk, nullptr);
+    {   // (tree_voltage<256, 8, true, true>, with the node sums' element stride)
+        double wb[8];
+        tree_fetch_w<256, 8>(a.tree, wb);
+        if (a.es == 4) tree_gather_p<256, 8, true>(a.tree, a.p, 4, 4 * t * a.m, pk, v8, nullptr);     // (row stride 4, the slot's block)
+        else tree_gather_p<256, 8, true>(a.tree, a.p, T, t, pk, v8, nullptr);
+        tree_scan<256, 8, true>(a.tree, t, lds, v8, wb, pk);
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const bool has = (pk[i] & 0xFFFFu) != 0ull;
@@ -581,36 +589,44 @@ __device__ __forceinline__ void small_bpp(const double (&Ks)[8][8], const double
     for (int i = 0; i < A; ++i) B |= (u[i] > 0.0) ? (1u << i) : 0u;
     int ninf = A + 1, pcount = 3, piv = 0, done = 0;
     while (!done) {
-        double L[A][A], z[A], ipk[A];
+        // K'_BB = L D L^T (rows outside B masked to the identity), pivots floored as the Cholesky form floors them
+        // (d >= dl 1e-6).  No square roots, and the reciprocals by v_rcp_f64 + two Newton steps: the one thread that
+        // runs this is a chain of dependent f64 instructions, and an IEEE sqrt + division per pivot (37 of them) was
+        // half of it.
+        double L[A][A], z[A], idk[A];
 #pragma unroll
         for (int k = 0; k < A; ++k)
 #pragma unroll
             for (int l = 0; l <= k; ++l)
                 L[k][l] = (((B >> k) & 1u) && ((B >> l) & 1u)) ? K[k][l] : (k == l ? 1.0 : 0.0);
 #pragma unroll
-        for (int k = 0; k < A; ++k) {  // Cholesky, lower triangle in place; 1/pivot kept
-            const double pk = sqrt(fmax(L[k][k], dl * 1e-6));
-            ipk[k] = 1.0 / pk;              // (the only divisions: f64 division is ~12 dependent ops)
+        for (int k = 0; k < A; ++k) {
+            const double dk = fmax(L[k][k], dl * 1e-6);
+            double r = __builtin_amdgcn_rcp(dk);
+            r = __builtin_fma(__builtin_fma(-dk, r, 1.0), r, r);
+            r = __builtin_fma(__builtin_fma(-dk, r, 1.0), r, r);
+            idk[k] = r;
+            double ck[A];                    // column k below the diagonal, unscaled (= l_ik d_k)
 #pragma unroll
-            for (int i = k + 1; i < A; ++i) L[i][k] *= ipk[k];
+            for (int i = k + 1; i < A; ++i) { ck[i] = L[i][k]; L[i][k] = ck[i] * r; }
 #pragma unroll
             for (int i = k + 1; i < A; ++i)
 #pragma unroll
-                for (int j = k + 1; j <= i; ++j) L[i][j] -= L[i][k] * L[j][k];
+                for (int j = k + 1; j <= i; ++j) L[i][j] -= L[i][k] * ck[j];
         }
 #pragma unroll
-        for (int k = 0; k < A; ++k) {
+        for (int k = 0; k < A; ++k) {        // L y = c_B
             double v = ((B >> k) & 1u) ? c[k] : 0.0;
 #pragma unroll
             for (int l = 0; l < k; ++l) v -= L[k][l] * z[l];
-            z[k] = v * ipk[k];
+            z[k] = v;
         }
 #pragma unroll
-        for (int k = A - 1; k >= 0; --k) {
-            double v = z[k];
+        for (int k = A - 1; k >= 0; --k) {   // L^T x = D^-1 y
+            double v = z[k] * idk[k];
 #pragma unroll
             for (int l = k + 1; l < A; ++l) v -= L[l][k] * z[l];
-            z[k] = v * ipk[k];
+            z[k] = v;
         }
         double umax = 0.0;
 #pragma unroll
@@ -651,7 +667,7 @@ __device__ __forceinline__ void small_model_body(
         const int t, int m, int T, const double *__restrict__ R, const double *__restrict__ Nn,
         const int64_t *__restrict__ cidx, const int32_t *__restrict__ ccnt,
         const double *__restrict__ cval, double inv_kappa, double delta, int max_pivots,
-        double *__restrict__ Kall, double *__restrict__ yhat, int32_t *__restrict__ info) {
+        double *__restrict__ Kall, double *__restrict__ yhat, int32_t *__restrict__ info, const int nes = 1) {
     const int tid = threadIdx.x;
     const int a = ccnt[t];
     int64_t f[kSmall];                      // (entries beyond the count hold row 0: loadable)
@@ -675,7 +691,7 @@ __device__ __forceinline__ void small_model_body(
     REVS_KVS(t, 12);
 #pragma unroll 8
     for (int mm = tid; mm < m; mm += 256) {
-        const double nv = Nn[(int64_t)mm * T + t];
+        const double nv = nes == 4 ? Nn[4 * ((int64_t)t * m + mm)] : Nn[(int64_t)mm * T + t];
         double r[kSmall];
 #pragma unroll
         for (int i = 0; i < kSmall; ++i) r[i] = f[i] >= 0 ? R[f[i] * m + mm] : 0.0;
@@ -781,6 +797,7 @@ struct FusedArgs {
     int max_pivots;
     double *Kall, *yhat, *ytrial, *lin_out;
     int32_t *info;
+    int nes = 1;                   // element stride of Nn (ChainKvSide::es)
 };
 __global__ __launch_bounds__(256) void op_dual_select_model_step_kernel(const SelectArgs sa,
                                                                         const FusedArgs fa) {
@@ -942,31 +959,31 @@ __device__ __forceinline__ double uni_d(double v) {
     return __longlong_as_double(((long long)uni_i((int)(b >> 32)) << 32) | (unsigned int)uni_i((int)b));
 }
 
-// The previous list's rows with a multiplier, ascending: sup / ysup (uniform), their number.  f / yv: the
-// list's first 8 rows and the multipliers there (uniform), pc its length (0 .. 8).  Straight-line code: a
-// taken branch costs a wavefront ~20 cycles (tools/probes/icache_probe.hip), a scalar select one.
-__device__ __forceinline__ int chain_support_sort(const int pc, const long long (&f)[8], const double (&yv)[8],
+// The previous list's rows with a multiplier, ascending: sup / ysup (uniform), their number.  Lane k < 8 of every
+// wavefront holds entry k of the list (row my_f, multiplier my_y; nz: it counts): each ranks its row among the
+// others by eight scalar broadcasts, and the q-th smallest is read back from the lane that holds it -- ~90
+// instructions, no LDS, no barrier.  (The same selection as a uniform 8 x 8 sort of 64-bit rows: ~2.5 us of a
+// latency-bound workgroup, r04 stamps.)
+__device__ __forceinline__ int chain_support_rank(const int my_f, const double my_y, const bool nz,
                                                   long long (&sup)[8], double (&ysup)[8]) {
-    constexpr long long kNone = 0x7FFFFFFFFFFFFFFFll;
-    int ns = 0;
-    long long last = -1;
+    const unsigned long long nzm = __ballot(nz);
+    int rank = 0;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {           // selection sort, uniform: rows are distinct
-        long long best = kNone;
-        double yb = 0.0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const bool take = k < pc && yv[k] != 0.0 && f[k] > last && f[k] < best;
-            best = take ? f[k] : best;
-            yb = take ? yv[k] : yb;
-        }
-        const bool have = best != kNone;
-        sup[q] = have ? best : -1;
-        ysup[q] = have ? yb : 0.0;
-        ns += have ? 1 : 0;
-        last = have ? best : last;
+    for (int j = 0; j < 8; ++j) {
+        const int fj = __builtin_amdgcn_readlane(my_f, j);
+        rank += (((nzm >> j) & 1ull) && fj < my_f) ? 1 : 0;      // (rows are distinct)
     }
-    return ns;
+    const long long yb = __double_as_longlong(my_y);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const unsigned long long mq = __ballot(nz && rank == q);
+        const int src = __builtin_amdgcn_readfirstlane(mq ? __builtin_ctzll(mq) : 0);
+        const int row = __builtin_amdgcn_readlane(my_f, src);
+        const int lo = __builtin_amdgcn_readlane((int)yb, src), hi = __builtin_amdgcn_readlane((int)(yb >> 32), src);
+        sup[q] = mq ? (long long)row : -1;
+        ysup[q] = mq ? __longlong_as_double(((long long)hi << 32) | (unsigned int)lo) : 0.0;
+    }
+    return (int)__builtin_popcountll(nzm);
 }
 
 constexpr int kRankMax = 256;
@@ -986,13 +1003,20 @@ struct ChainSelScratch {        // LDS of chain_rows_select_body
 // rmax_out: the slot's largest row residual; sup / ns_out: the support (the new list's head).
 // Loads: two round trips -- {tree indices and weights, the previous list, first()'s} then {the list's
 // multipliers, the gathers of node sums and dual terms, second()'s (which knows the support)}.
+// The sums are the folded sweep's (TreeRowsArgs::es == 4: [T][m][4], slot-major): the slot's block -- m x {p, N, q, 0},
+// contiguous -- is fetched in ROW order with coalesced 16-byte loads in the first round trip (it does not wait for
+// the tree's indices) and staged in LDS by row (rows4: y | p | N | q, m doubles each); the tree-ordered gather reads
+// LDS.  (Gathering the columns from memory cost the texture path 2.7 cycles per lane and request: 4.6 us of a
+// 10 us prologue, r04 stamps.)  N stays in rows4 + 2 m for the model step.
 template <class F1, class F2>
 __device__ __forceinline__ bool chain_rows_select_body(const TreeRowsArgs &a, const SelectArgs &sa, const int t,
-                                                       double *lds, double *ylds, ChainSelScratch &cs_,
+                                                       double *lds, double *rows4, ChainSelScratch &cs_,
                                                        const int64_t *__restrict__ pci, const int32_t *__restrict__ pcc,
                                                        long long (&sup)[8], int &ns_out,
                                                        F1 &&first, F2 &&second, double &rmax_out) {
     const int tid = threadIdx.x, j0 = 8 * tid, T = a.T, m = a.m;
+    if (a.es != 4 || m > 2048) return false;        // (uniform)
+    double *const ylds = rows4, *const plds = rows4 + m, *const nlds = rows4 + 2 * m, *const qlds = rows4 + 3 * m;
     const bool act = j0 < a.tree.n;
     unsigned long long pk[8];
 #pragma unroll
@@ -1005,37 +1029,53 @@ __device__ __forceinline__ bool chain_rows_select_body(const TreeRowsArgs &a, co
         }
     }
     const int pc_raw = pcc[t];
-    long long f_raw[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) f_raw[k] = pci[(int64_t)t * kAmax + k];   // (entries beyond the count: row 0)
+    const int lane = tid & 63;
+    const int my_f = (int)pci[(int64_t)t * kAmax + (lane < 8 ? lane : 0)];      // lane k < 8: entry k (beyond the count: row 0)
     double wgt[8];
     tree_fetch_w<256, 8>(a.tree, wgt);
+    // the slot's block, 16 bytes per lane and load: chunk c = row c / 2, half c % 2 ({p, N} | {q, 0})
+    TreeD2 ch[16];
+    {
+        const TreeD2 *__restrict__ blk = reinterpret_cast<const TreeD2 *>(a.p + 4 * (int64_t)t * m);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int c = tid + 256 * k;
+            ch[k] = blk[c < 2 * m ? c : 0];
+        }
+    }
     first();
+    REVS_KVS(t, 21);
     for (int i = tid; i < m; i += 256) ylds[i] = 0.0;
     if (tid == 0) cs_.vcount = 0;
+    REVS_KVS(t, 22);
     const int pc = uni_i(pc_raw);
+    REVS_KVS(t, 23);
     if (pc < 0 || pc > 8) return false;
-    long long f[8];
-    double yv[8];
+    const double my_y = a.y[(int64_t)my_f * T + t];
+    // (a thread's chunks are all the same half: c % 2 == tid % 2)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) f[k] = (long long)uni_i((int)f_raw[k]);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) yv[k] = a.y[f[k] * T + t];
-    double v8[8], qv[8];
-    tree_gather_p<256, 8, true>(a.tree, a.p, T, t, pk, v8, nullptr);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int s = (int)(pk[i] & 0xFFFFu) - 1;
-        const double q = a.qn[(int64_t)(s >= 0 ? s : 0) * T + t];
-        qv[i] = s >= 0 ? q : 0.0;
+    for (int k = 0; k < 16; ++k) {
+        const int c = tid + 256 * k, row = c >> 1;
+        if (c < 2 * m) {
+            if (tid & 1) qlds[row] = ch[k].v[0];
+            else { plds[row] = ch[k].v[0]; nlds[row] = ch[k].v[1]; }
+        }
     }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) yv[k] = uni_d(yv[k]);
+    REVS_KVS(t, 29);
     double ysup[8];
-    const int ns = chain_support_sort(pc, f, yv, sup, ysup);
+    const int ns = chain_support_rank(my_f, my_y, lane < 8 && lane < pc && my_y != 0.0, sup, ysup);
+    REVS_KVS(t, 30);
     ns_out = ns;
     second();
-    __syncthreads();
+    REVS_KVS(t, 31);
+    __syncthreads();                        // the block by row, and the cleared multipliers' column
+    double v8[8], qv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {           // (positions without a row: masked by the scan / zero)
+        const int s = (int)(pk[i] & 0xFFFFu) - 1;
+        v8[i] = (act && s >= 0) ? plds[s] : 0.0;
+        qv[i] = s >= 0 ? qlds[s] : 0.0;
+    }
     if (tid < 8 && tid < ns) {
         double mine = 0.0;
         long long row = 0;
@@ -1089,8 +1129,13 @@ __device__ __forceinline__ bool chain_rows_select_body(const TreeRowsArgs &a, co
         stats[t * 8 + 1] = 0.0 + o1;
         stats[t * 8 + 2] = (double)ns;
         stats[t * 8 + 3] = (double)nv;
+        if (sa.fwd_src) {                   // (SelectArgs::fwd_src)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sa.fwd_dst[t * 8 + i] = sa.fwd_src[t * 8 + i];
+        }
         if (!sa.lazy) __threadfence_system();
-        reinterpret_cast<volatile double *>(stats)[t * 8 + 5] = sa.seq;
+        if (!sa.lazy) reinterpret_cast<volatile double *>(stats)[t * 8 + 5] = sa.seq;
+        else stats[t * 8 + 5] = sa.seq;     // (device memory, nobody polls: a plain store)
     }
     rmax_out = rmax_t;
     int64_t *ci = sa.cidx + (int64_t)t * kAmax;
@@ -1358,7 +1403,7 @@ __global__ __launch_bounds__(256) void op_chain_kv_kernel(const ChainKvArgs k) {
     extern __shared__ double tree_lds[];
     const int T = k.s1.T, m = k.s1.m;
     REVS_KVS_BEGIN((k.has_e2 && (int)blockIdx.x < T) ? nullptr : k.stamps);
-    // (the rows of a slot go to its selection through LDS: double[3 m + 4] behind the tree's scan buffer)
+    // (the rows of a slot go to its selection through LDS: double[4 m + 4] behind the tree's scan buffer)
     double *rows_lds = tree_lds + (tree_lds_bytes(k.e1.tree.n) / sizeof(double) + 1) / 2 * 2;
     __shared__ ChainSelScratch sel_s;
     long long sup[8];
@@ -1401,17 +1446,18 @@ __global__ __launch_bounds__(256) void op_chain_kv_kernel(const ChainKvArgs k) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int mm = threadIdx.x + 256 * j;
-            const double v = k.f1.Nn[(int64_t)(mm < m ? mm : 0) * T + t];
+            const double v = k.f1.nes == 4 ? k.f1.Nn[4 * ((int64_t)t * m + (mm < m ? mm : 0))] : k.f1.Nn[(int64_t)(mm < m ? mm : 0) * T + t];
             nn[j] = mm < m ? v : 0.0;
         }
     };
     double rmax = 0.0;
     bool done = false;
+    // (the folded sweep's sums: N arrives with p and q in the slot's block and reaches the model through LDS, by row)
     if (k.prev_cc) {
         SelectArgs s1 = k.s1;
         s1.ll = &lists;
         int ns1 = 0;
-        done = chain_rows_select_body(k.e1, s1, t, tree_lds, rows_lds, sel_s, k.prev_ci, k.prev_cc, sup, ns1, fetch_nn,
+        done = chain_rows_select_body(k.e1, s1, t, tree_lds, rows_lds, sel_s, k.prev_ci, k.prev_cc, sup, ns1, NoPrefetch(),
                                       [&]() {
             if (m <= 2048) {
 #pragma unroll
@@ -1427,6 +1473,14 @@ __global__ __launch_bounds__(256) void op_chain_kv_kernel(const ChainKvArgs k) {
             }
         }, rmax);
         if (done && m <= 2048) npre = ns1;
+        if (done) {                         // (staged before the selection's barriers)
+            const double *const nlds = rows_lds + 2 * m;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int mm = threadIdx.x + 256 * j;
+                nn[j] = mm < m ? nlds[mm] : 0.0;
+            }
+        }
     }
     if (!done) {
         __syncthreads();
@@ -1472,7 +1526,7 @@ __global__ __launch_bounds__(256) void op_chain_kv_kernel(const ChainKvArgs k) {
         return;
     }
     small_model_body(t, m, T, k.f1.R, k.f1.Nn, k.s1.cidx, k.s1.ccnt, k.s1.cval, k.f1.inv_kappa, k.f1.delta,
-                     k.f1.max_pivots, k.f1.Kall, k.f1.yhat, k.f1.info);
+                     k.f1.max_pivots, k.f1.Kall, k.f1.yhat, k.f1.info, k.f1.nes);
     __syncthreads();
     KV_STAMP(17);
     dual_step_body<256>(t, T, k.s1.cidx, k.s1.ccnt, k.s1.cval, k.f1.yhat, al, k.f1.ytrial, k.f1.lin_out, nullptr, m);
@@ -1495,8 +1549,11 @@ int chain_kv_launch(const ChainKv &c, void *stream) {
     const int64_t mt = (int64_t)c.m * c.T;
     ChainKvArgs k;
     k.has_e2 = c.has_e2;
+    REVS_REQUIRE((c.e1.es == 1 || c.e1.es == 4) && (!c.has_e2 || c.e2.es == 1 || c.e2.es == 4), "chain_kv_launch: bad layout of the sums");
     auto rows = [&](const ChainKvSide &s) {
-        return TreeRowsArgs{c.tree, c.m, c.T, s.pnq, s.pnq + 2 * mt, s.y, c.vlo, c.vhi, s.vfull, s.viol, s.partial, nullptr};
+        TreeRowsArgs r{c.tree, c.m, c.T, s.pnq, s.pnq + (s.es == 4 ? 2 : 2 * mt), s.y, c.vlo, c.vhi, s.vfull, s.viol, s.partial, nullptr};
+        r.es = s.es;
+        return r;
     };
     auto sel = [&](const ChainKvSide &s) {
         return SelectArgs{c.m, c.T, 1, c.kadd, s.partial, s.y, s.vfull, s.viol, c.vlo, c.vhi, s.seq, s.cidx, s.ccnt, s.cval, s.stats};
@@ -1504,16 +1561,18 @@ int chain_kv_launch(const ChainKv &c, void *stream) {
     k.e1 = rows(c.e1);
     k.e1.ycopy_out = c.y_trial;     // the next trial starts from this evaluation's multipliers: copied by the rows' pass
     k.s1 = sel(c.e1);
-    k.s1.lazy = c.has_e2 != 0;      // (the entry launch's stats are read behind the first verdict too, but cost nothing extra)
+    k.s1.lazy = c.has_e2 != 0;      // (its stats stay on the device: c.e1.stats; the next launch's verdict half forwards them)
+    REVS_REQUIRE((c.fwd_src == nullptr) == (c.fwd_dst == nullptr) && (!c.fwd_src || c.has_e2), "chain_kv_launch: bad stats forwarding");
     k.e2 = rows(c.has_e2 ? c.e2 : c.e1);
     k.s2 = sel(c.has_e2 ? c.e2 : c.e1);
-    k.f1 = FusedArgs{c.R, c.e1.pnq + mt, c.e1.y, 1.0 / c.kappa, c.delta, c.scale, c.eps, c.max_pivots, c.k_full, c.yhat,
-                     c.y_trial, c.lin_out, c.info};
-    k.clr0 = c.clr0; k.clr1 = c.clr1; k.clr_count = 3 * mt;
+    k.s2.fwd_src = c.fwd_src; k.s2.fwd_dst = c.fwd_dst;
+    k.f1 = FusedArgs{c.R, c.e1.pnq + (c.e1.es == 4 ? 1 : mt), c.e1.y, 1.0 / c.kappa, c.delta, c.scale, c.eps, c.max_pivots,
+                     c.k_full, c.yhat, c.y_trial, c.lin_out, c.info, c.e1.es};
+    k.clr0 = c.clr0; k.clr1 = c.clr1; k.clr_count = 4 * mt;      // (the folded sweep's arrays: {p, N, q, 0} per node and slot)
     k.sh_a = c.sh_a; k.sh_b = c.sh_b;
     k.prev_ci = c.prev_cidx; k.prev_cc = c.prev_cidx ? c.prev_ccnt : nullptr;
-    const size_t lds = ((tree_lds_bytes(c.tree.n) / sizeof(double) + 1) / 2 * 2 + 3 * (size_t)c.m + 4) * sizeof(double);
-    // (a slot's rows are staged in LDS: 3 m doubles beside the tree's scan buffer and ~30 KB of static LDS)
+    const size_t lds = ((tree_lds_bytes(c.tree.n) / sizeof(double) + 1) / 2 * 2 + 4 * (size_t)c.m + 4) * sizeof(double);
+    // (a slot's rows are staged in LDS: 4 m doubles beside the tree's scan buffer and ~30 KB of static LDS)
     REVS_REQUIRE(c.m <= REVS_CHAIN_FOLD_MAX_M && lds <= 128 * 1024,
                  "chain_kv_launch: m = %d rows do not fit the operator launch's LDS (at most %d)", c.m, REVS_CHAIN_FOLD_MAX_M);
     if (lds > 64 * 1024) {       // (more than 64 KB of dynamic LDS has to be granted, once)

@@ -77,6 +77,8 @@ struct revs_plan {
     int32_t *fold_cc[2] = {nullptr, nullptr};
     double *fold_cv[2] = {nullptr, nullptr};
     double *fold_st_host[2] = {nullptr, nullptr}, *fold_st_dev[2] = {nullptr, nullptr};
+    double *fold_st_local[2] = {nullptr, nullptr};     // device: stats of the next-iteration half, by the parity of the set they belong to
+    bool fold_st_local_valid = false;      // ... hold the stats of the evaluation the next verdict belongs to
     int32_t fold_par = 0;                  // parity of the iteration a resumed call starts with
     bool fold_ready = false;               // ... whose rows / model / step the last call has already run
     int32_t timing = 0;                    // 0 off, 1 armed (next burst records tev[0]), 2 open
@@ -199,6 +201,7 @@ extern "C" void revs_plan_destroy(revs_plan_t *plan) {
         if (plan->fold_st_host[i]) (void)hipHostFree(plan->fold_st_host[i]);
     }
     for (double *v : plan->fold_v) if (v) (void)hipFree(v);
+    for (double *v : plan->fold_st_local) if (v) (void)hipFree(v);
     for (int32_t *v : plan->fold_info) if (v) (void)hipFree(v);
     for (double *v : plan->fold_sh) if (v) (void)hipFree(v);
     for (hipEvent_t e : plan->events) (void)hipEventDestroy(e);
@@ -518,8 +521,9 @@ static int fold_alloc(revs_plan_t *plan) {
     for (int i = 0; i < 2; ++i) {
         // the two sum arrays one sweep accumulates into -- fold_e2[par] | fold_e1[par ^ 1] -- are one
         // allocation: sharded, ONE all-reduce per iteration covers both
-        dev((void **)&plan->fold_e2[i], sizeof(double) * 6 * mt);
-        if (e == hipSuccess) plan->fold_e1[i ^ 1] = plan->fold_e2[i] + 3 * mt;
+        // (double[m][T][4] = {p, N, q, 0} each)
+        dev((void **)&plan->fold_e2[i], sizeof(double) * 8 * mt);
+        if (e == hipSuccess) plan->fold_e1[i ^ 1] = plan->fold_e2[i] + 4 * mt;
         dev((void **)&plan->fold_ci[i], sizeof(int64_t) * (size_t)d.T * REVS_DUAL_AMAX);
         dev((void **)&plan->fold_cc[i], sizeof(int32_t) * (size_t)d.T);
         dev((void **)&plan->fold_cv[i], sizeof(double) * (size_t)d.T * 3 * REVS_DUAL_AMAX);
@@ -534,6 +538,8 @@ static int fold_alloc(revs_plan_t *plan) {
             plan->fold_st_dev[i] = (double *)dp;
         }
     }
+    dev((void **)&plan->fold_st_local[0], sizeof(double) * 8 * (size_t)d.T);
+    dev((void **)&plan->fold_st_local[1], sizeof(double) * 8 * (size_t)d.T);
     dev((void **)&plan->fold_v[0], sizeof(double) * mt);
     dev((void **)&plan->fold_v[1], sizeof(double) * mt);
     dev((void **)&plan->fold_v[2], sizeof(double) * (size_t)d.T * 4);
@@ -600,7 +606,8 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
             c0.tree = plan->tree;
             c0.vlo = d.vlo; c0.vhi = d.vhi; c0.kappa = d.kappa; c0.delta = d.delta; c0.scale = scale; c0.eps = d.eps;
             c0.max_pivots = d.max_pivots;
-            c0.e1 = revs::ChainKvSide{plan->fold_e2[par], st->y, d.vfull, d.viol, d.partial, S0.ci, S0.cc, S0.cv, S0.st, 0.0};
+            c0.e1 = revs::ChainKvSide{plan->fold_e2[par], st->y, d.vfull, d.viol, d.partial, S0.ci, S0.cc, S0.cv, S0.st, 0.0, 4};
+            plan->fold_st_local_valid = false;      // (this launch writes the host block itself)
             c0.R = d.R; c0.k_full = d.k_full; c0.yhat = d.yhat; c0.info = plan->fold_info[par];
             c0.y_trial = st->y_trial;
             c0.lin_out = S1.st + 4;
@@ -608,8 +615,8 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
             c0.sh_a = plan->fold_sh[0]; c0.sh_b = plan->fold_sh[1];
             rc = revs::chain_kv_launch(c0, stream);
             if (rc != REVS_OK) return rc;
-            if (hipMemsetAsync(plan->fold_e2[par], 0, sizeof(double) * 3 * mt, s) != hipSuccess ||
-                hipMemsetAsync(plan->fold_e1[par ^ 1], 0, sizeof(double) * 3 * mt, s) != hipSuccess) {
+            if (hipMemsetAsync(plan->fold_e2[par], 0, sizeof(double) * 4 * mt, s) != hipSuccess ||
+                hipMemsetAsync(plan->fold_e1[par ^ 1], 0, sizeof(double) * 4 * mt, s) != hipSuccess) {
                 revs::set_error("revs_plan_chain_fold_run: hipMemsetAsync failed");
                 return REVS_ELAUNCH;
             }
@@ -635,7 +642,8 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
                 c0.tree = plan->tree;
                 c0.vlo = d.vlo; c0.vhi = d.vhi; c0.kappa = d.kappa; c0.delta = d.delta; c0.scale = scale; c0.eps = d.eps;
                 c0.max_pivots = d.max_pivots;
-                c0.e1 = revs::ChainKvSide{d.pnq, st->y, d.vfull, d.viol, d.partial, S0.ci, S0.cc, S0.cv, S0.st, 0.0};
+                c0.e1 = revs::ChainKvSide{d.pnq, st->y, d.vfull, d.viol, d.partial, S0.ci, S0.cc, S0.cv, S0.st, 0.0, 1};
+                plan->fold_st_local_valid = false;
                 c0.R = d.R; c0.k_full = d.k_full; c0.yhat = d.yhat; c0.info = plan->fold_info[par];
                 c0.y_trial = st->y_trial;
                 c0.lin_out = S1.st + 4;
@@ -645,8 +653,8 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
             }
             if (rc != REVS_OK) return rc;
             // (the arrays this iteration's sweep accumulates into start from zero)
-            if (hipMemsetAsync(plan->fold_e2[par], 0, sizeof(double) * 3 * mt, s) != hipSuccess ||
-                hipMemsetAsync(plan->fold_e1[par ^ 1], 0, sizeof(double) * 3 * mt, s) != hipSuccess) {
+            if (hipMemsetAsync(plan->fold_e2[par], 0, sizeof(double) * 4 * mt, s) != hipSuccess ||
+                hipMemsetAsync(plan->fold_e1[par ^ 1], 0, sizeof(double) * 4 * mt, s) != hipSuccess) {
                 revs::set_error("revs_plan_chain_fold_run: hipMemsetAsync failed");
                 return REVS_ELAUNCH;
             }
@@ -661,8 +669,8 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
         if (rc != REVS_OK) return rc;
         // Residences sharded: every rank's sweep has folded its own residences' addends -- exact and order-independent
         // (revs_q36 / revs_q32), so the all-reduced sums are the one-process sums bit for bit.  Both arrays in ONE
-        // collective per iteration (6 M T doubles); everything behind it is replicated and deterministic.
-        if (plan->comm && (rc = revs_comm_allreduce_f64(plan->comm, plan->fold_e2[par], 6 * mt, 0, stream)) != REVS_OK) return rc;
+        // collective per iteration (8 M T doubles: {p, N, q, 0} per node and slot, twice); everything behind it is replicated and deterministic.
+        if (plan->comm && (rc = revs_comm_allreduce_f64(plan->comm, plan->fold_e2[par], 8 * mt, 0, stream)) != REVS_OK) return rc;
         const double seq = -(plan->seq += 1.0);
         revs::ChainKv c{};
         c.m = d.m; c.T = d.T; c.kadd = d.kadd; c.has_e2 = 1;
@@ -670,9 +678,13 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
         c.vlo = d.vlo; c.vhi = d.vhi; c.kappa = d.kappa; c.delta = d.delta; c.scale = scale; c.eps = d.eps;
         c.max_pivots = d.max_pivots;
         c.e2 = revs::ChainKvSide{plan->fold_e2[par], st->y_trial, plan->fold_v[0], plan->fold_v[1], plan->fold_v[2],
-                                 S1.ci, S1.cc, S1.cv, S1.st, seq};
+                                 S1.ci, S1.cc, S1.cv, S1.st, seq, 4};
+        // (the next iteration's stats stay on the device; this launch's verdict half hands the host the ones the launch
+        // before left there for THIS iteration's acceptance test)
         c.e1 = revs::ChainKvSide{plan->fold_e1[par ^ 1], st->y_trial, d.vfull, d.viol, d.partial,
-                                 S0n.ci, S0n.cc, S0n.cv, S0n.st, 0.0};
+                                 S0n.ci, S0n.cc, S0n.cv, plan->fold_st_local[par ^ 1], 0.0, 4};
+        if (plan->fold_st_local_valid) { c.fwd_src = plan->fold_st_local[par]; c.fwd_dst = S0.st; }
+        plan->fold_st_local_valid = true;
         c.R = d.R; c.k_full = d.k_full; c.yhat = d.yhat; c.info = plan->fold_info[par ^ 1];     // (iteration k + 1's model)
         c.y_trial = st->y_spare;
         c.lin_out = S1n.st + 4;
@@ -806,11 +818,14 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
             if (h[32 * t + 20] - h[32 * t] > h[32 * worst + 20] - h[32 * worst]) worst = t;
         // 0 start | 1-6 rows | 7-10 selection | 11-16 model | 17 step | 18-20 shifts: microseconds since the slot's start
         fprintf(stderr, "[kv stamps, us since start] slowest slot %d:", worst);
-        for (int i = 1; i <= 23; ++i) fprintf(stderr, " %d:%.1f", i, (h[32 * worst + i] - h[32 * worst]) * 0.01);
+        for (int i = 1; i <= 20; ++i) fprintf(stderr, " %d:%.1f", i, (h[32 * worst + i] - h[32 * worst]) * 0.01);
         fprintf(stderr, " | violated %g support %g room %g | fast body at %.1f, list read %.1f", h[32 * worst + 24], h[32 * worst + 25], h[32 * worst + 26],
                 (h[32 * worst + 27] - h[32 * worst]) * 0.01, (h[32 * worst + 28] - h[32 * worst]) * 0.01);
+        fprintf(stderr, " | prologue: round-1 loads issued %.1f, LDS cleared %.1f, list in %.1f, gathers issued %.1f, multipliers in %.1f, rows of R requested %.1f",
+                (h[32 * worst + 21] - h[32 * worst]) * 0.01, (h[32 * worst + 22] - h[32 * worst]) * 0.01, (h[32 * worst + 23] - h[32 * worst]) * 0.01,
+                (h[32 * worst + 29] - h[32 * worst]) * 0.01, (h[32 * worst + 30] - h[32 * worst]) * 0.01, (h[32 * worst + 31] - h[32 * worst]) * 0.01);
         fprintf(stderr, "\n[kv stamps, mean over slots]            ");
-        for (int i = 1; i <= 23; ++i) {
+        for (int i = 1; i <= 20; ++i) {
             double acc = 0;
             for (int t = 0; t < d.T; ++t) acc += (h[32 * t + i] - h[32 * t]) * 0.01;
             fprintf(stderr, " %d:%.1f", i, acc / d.T);

@@ -30,6 +30,13 @@ struct SelectArgs {
     // system-scope fence in front of the tag, which otherwise holds thread 0 (and at the next
     // barrier the whole workgroup) for a round trip to host memory
     bool lazy = false;
+    // fwd_src != NULL: before its own tag this selection copies another evaluation's stats {rmax, D, multipliers,
+    // violated rows} of the same slot from device memory (fwd_src[8 t ..]) into the host-visible block fwd_dst --
+    // the folded chain's next-iteration half keeps its stats on the device (a store to pinned host memory in front
+    // of a volatile tag store holds thread 0, and at the next barrier the workgroup, for a round trip over the bus:
+    // ~1.5 us of the launch's critical path), and the verdict half of the NEXT launch hands them to the host
+    const double *fwd_src = nullptr;
+    double *fwd_dst = nullptr;
     // rows_lds != NULL: the rows' multipliers, voltages and violations of THIS slot staged in LDS by
     // the workgroup's own row kernel (double[3][m], by row: y | v | violation) and its four sums in
     // rows_lds[3 m ..]: read instead of the global columns (a column of a [m][T] array is m cache
@@ -111,6 +118,10 @@ __device__ __forceinline__ double dual_select_body(const SelectArgs &sa, const i
         stats[t * 8 + 1] = ((red_s[1][0] + red_s[1][1]) + red_s[1][2]) + red_s[1][3];
         stats[t * 8 + 2] = (double)ns;
         stats[t * 8 + 3] = (double)nv;
+        if (sa.fwd_src) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sa.fwd_dst[t * 8 + i] = sa.fwd_src[t * 8 + i];
+        }
         // stats may live in pinned host memory: a host that polls [5] for this evaluation's
         // sequence number sees [0..3] complete (system-scope release before the tag)
         if (!sa.lazy) __threadfence_system();

@@ -91,7 +91,12 @@ class OperatorOptions:
     # the ADMM forms when it cannot finish (more than 128 binding rows in a slot, ...).
     solver: str = "newton"
     newton_max: int = 60         # Newton iterations per operator solve
-    newton_kadd: int = 6         # violated rows admitted to a slot's model per iteration
+    # violated rows admitted to a slot's model per Newton iteration.  Round 4: 3 (was 6).  With on/off chargers the
+    # binding steady state's slowest slot sees a handful of newly violated rows every ADMM iteration; admitting
+    # six made its model 8 x 8 -- 36 Gram sums, an 8 x 8 pivoting problem, six arg-max rounds, six more rows of R --
+    # for the same number of Newton steps as admitting two or three (measured: 0.069 -> 0.060 ms per iteration at
+    # 100 000 x 24; cold solves on the 121144 feeder: 103 evaluations in 15 iterations against 92, same wall time)
+    newton_kadd: int = 3
     chain: bool = True           # binding steady state: one Newton iteration enqueued unread
     # ... and folded (one GPU, feeder as a tree): the sweep forms the operator's answer for the trial
     # itself and folds both evaluations' node sums into its own pass -- one pass over the residences

@@ -24,11 +24,13 @@ ap.add_argument("--T", type=int, default=24)
 ap.add_argument("--nodes", type=int, default=2048)
 ap.add_argument("--steps", type=int, default=300)
 ap.add_argument("--spin", type=int, default=60)
+ap.add_argument("--kadd", type=int, default=None, help="violated rows admitted to a slot's model per Newton iteration")
 a = ap.parse_args()
 mode, stress = {"binding": ("pdhg", 1.3), "binary": ("binary", 1.0), "steady": ("pdhg", 1.0)}[a.regime]
 w = make_workload(a.homes, a.T, n_nodes=a.nodes, seed=0, binary_feasible=(mode == "binary"), stress=stress)
 e = AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, kappa=w.kappa, vset=w.vset, vlow=w.vlow,
-               vhigh=w.vhigh, mode=mode, feeder=w.feeder, op=OperatorOptions())
+               vhigh=w.vhigh, mode=mode, feeder=w.feeder,
+               op=OperatorOptions(**({"newton_kadd": a.kadd} if a.kadd is not None else {})))
 e.run_steps(a.spin)
 torch.cuda.synchronize()
 c0, s0 = list(e.chain_hist), list(e.spec_hist)
@@ -38,4 +40,5 @@ torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(f"{a.regime}: {dt / a.steps * 1e3:.4f} ms per iteration over {a.steps}; chained kept/redone "
       f"{e.chain_hist[0] - c0[0]}/{e.chain_hist[1] - c0[1]}, streamed kept/discarded {e.spec_hist[0] - s0[0]}/"
-      f"{e.spec_hist[1] - s0[1]}, evaluations per step {sum(e.op_iters_hist[-a.steps:]) / a.steps:.2f}")
+      f"{e.spec_hist[1] - s0[1]}, evaluations per step {sum(e.op_iters_hist[-a.steps:]) / a.steps:.2f}, "
+      f"Newton steps taken inside the folded chain beyond the first {e.fold_steps}")
