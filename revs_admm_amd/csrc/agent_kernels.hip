@@ -215,8 +215,11 @@ __device__ __forceinline__ void stream_verdict_body(const AgentArgs &a, const in
 // without it the body runs once and compiles to the one-iteration kernel.
 // CHAIN: the folded chain's sweep (see AgentArgs::sh_R): one iteration, shifts and two sets of
 // node-sum accumulators in LDS, doubles in flight -- like MULTI it gives up occupancy for registers.
+#ifndef REVS_AGENT_CHAIN_WAVES
+#define REVS_AGENT_CHAIN_WAVES 6     // ... of the folded chain's sweep (tuning: build with -D; 5 / 6 / 7 / 8: 0.0469 / 0.0462 / 0.0466 / 0.0497 ms per binding iteration)
+#endif
 constexpr int agent_waves(int spl, bool full_rows, bool multi, bool chain) {
-    return (spl <= 4 && !full_rows) ? (multi ? REVS_AGENT_MULTI_WAVES : (chain ? 5 : 8)) : 4;
+    return (spl <= 4 && !full_rows) ? (multi ? REVS_AGENT_MULTI_WAVES : (chain ? REVS_AGENT_CHAIN_WAVES : 8)) : 4;
 }
 template <int LPA, int SPL, int MODE, bool FULL_ROWS = false, bool MULTI = false, bool CHAIN = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(agent_waves(SPL, FULL_ROWS, MULTI, CHAIN))))
@@ -296,6 +299,8 @@ void agent_step_kernel(const AgentArgs a) {
     }
     revs_home_t h;
     float yy_in = 0.f;
+    int node_ld = 0;            // (with the state: the node sums' accumulators are picked by it right behind the barrier)
+    if ((a.p_next || CHAIN) && live) node_ld = a.node_of[agent];
     if (live) {
         h = a.homes[agent];
         if constexpr (MODE == REVS_MODE_RELAXED_PDHG && !FULL_ROWS)
@@ -338,53 +343,34 @@ void agent_step_kernel(const AgentArgs a) {
             pen[j] = (valid[j] && g0 > 0.f) ? g0 : 0.f;
         }
     }
-    const int node = ((a.p_next || CHAIN) && live) ? a.node_of[agent] : 0;
+    const int node = node_ld;
     double dl[CHAIN ? SPL : 1];      // the shifts of this lane's slots
-    // One node under the whole wavefront (the usual case: residences are sorted by node, ~6 wavefronts per node) and
-    // its accumulators in LDS: the eight residences' addends are summed across the lane groups first -- exact sums,
-    // any order gives the evaluation kernel's bits -- and ONE group issues the LDS atomics: 8 lanes on 8 addresses
-    // instead of 64 lanes on 8 (an LDS atomic serialises the lanes that share an address; eighteen of them per
-    // wavefront were the folded sweep's bound).
-    bool fold_uni = false;
-    int fold_loc = 0;
-    if constexpr (CHAIN) {
-        const int n0 = __builtin_amdgcn_readfirstlane(node);
-        fold_loc = n0 - base;
-        fold_uni = __all(!live || node == n0) && fold_loc < kNodeLoc;
-    }
     // p | N | sum g^2 of one evaluation into accumulator set f (fold_a / fold_b behind it); zero addends where the
-    // residence is clamped
+    // residence is clamped.  The sweep's time follows its instruction count one to one (r04: summing the addends over
+    // the wavefront's lane groups first -- 8 lanes on 8 LDS addresses instead of 64 -- cost 160 VALU instructions per
+    // wavefront and 3 us per sweep, the LDS atomics' serialisation is not what bounds it): the local case is nine
+    // straight-line LDS adds per lane, one branch in front of them.
     auto fold_add = [&](const int f, const double (&gq)[CHAIN ? SPL : 1], const double (&cn)[CHAIN ? SPL : 1],
                         const double (&g2)[CHAIN ? SPL : 1]) {
         if constexpr (CHAIN) {
-            double *const glob = f ? a.fold_b : a.fold_a;
-            if (fold_uni) {
+            const int loc = node - base;
+            if (loc < kNodeLoc) {           // (lanes without a residence: node = 0 <= base, addends zero)
+                const int lc = loc < 0 ? 0 : loc;
 #pragma unroll
                 for (int j = 0; j < SPL; ++j) {
-                    const double s0 = wave_sum_over_groups_d<LPA>(gq[j]);
-                    const double s1 = wave_sum_over_groups_d<LPA>(cn[j]);
-                    const double s2 = wave_sum_over_groups_d<LPA>(g2[j]);
-                    if ((tid & 63) < LPA) {
-                        unsafeAtomicAdd(&facc[f][0][fold_loc][t0 + j], s0);
-                        unsafeAtomicAdd(&facc[f][1][fold_loc][t0 + j], s1);
-                        unsafeAtomicAdd(&facc[f][2][fold_loc][t0 + j], s2);
-                    }
+                    unsafeAtomicAdd(&facc[f][0][lc][t0 + j], gq[j]);
+                    unsafeAtomicAdd(&facc[f][1][lc][t0 + j], cn[j]);
+                    unsafeAtomicAdd(&facc[f][2][lc][t0 + j], g2[j]);
                 }
             } else {
-                const int loc = node - base;
+                double *const glob = f ? a.fold_b : a.fold_a;
 #pragma unroll
                 for (int j = 0; j < SPL; ++j) {
                     if (cn[j] != 0.0) {
-                        if (loc < kNodeLoc) {
-                            unsafeAtomicAdd(&facc[f][0][loc][t0 + j], gq[j]);
-                            unsafeAtomicAdd(&facc[f][1][loc][t0 + j], 1.0);
-                            unsafeAtomicAdd(&facc[f][2][loc][t0 + j], g2[j]);
-                        } else {
-                            const int64_t o = 4 * ((int64_t)(t0 + j) * a.sh_m + node);      // [T][m][4]: {p, N, q, 0} per slot and node
-                            unsafeAtomicAdd(&glob[o], gq[j]);
-                            unsafeAtomicAdd(&glob[o + 1], 1.0);
-                            unsafeAtomicAdd(&glob[o + 2], -0.5 * a.sh_kappa * g2[j]);
-                        }
+                        const int64_t o = 4 * ((int64_t)(t0 + j) * a.sh_m + node);      // [T][m][4]: {p, N, q, 0} per slot and node
+                        unsafeAtomicAdd(&glob[o], gq[j]);
+                        unsafeAtomicAdd(&glob[o + 1], 1.0);
+                        unsafeAtomicAdd(&glob[o + 2], -0.5 * a.sh_kappa * g2[j]);
                     }
                 }
             }

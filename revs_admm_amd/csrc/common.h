@@ -278,8 +278,18 @@ __device__ __forceinline__ float revs_g0f(float pe, float ps, float gm, float in
 // each floating-point addition is EXACT: the evaluation kernel's fixed-order sums and the atomics of
 // a sweep that folds the same evaluation give the same bits -- and the rounding (1.5e-11 kW) is far
 // below the 1e-8 relative tolerance of the voltage rows (rounding g to float first, 1e-7 kW, is not).
-__device__ __forceinline__ double revs_q36(double g) { return __builtin_rint(g * 68719476736.0) * (1.0 / 68719476736.0); }
-__device__ __forceinline__ double revs_q32(double g2) { return __builtin_rint(g2 * 4294967296.0) * (1.0 / 4294967296.0); }
+// (round to nearest even by adding and subtracting 3 x 2^15 / 3 x 2^19, whose unit in the last place is 2^-36 / 2^-32 --
+// for 0 <= g < 2^15 kW, 0 <= g^2 < 2^19: the same values as rint(g 2^36) 2^-36, two additions instead of three operations)
+__device__ __forceinline__ double revs_q36(double g) {
+    double r = g + 98304.0;
+    asm volatile("" : "+v"(r));             // (the compiler must not fold the pair away)
+    return r - 98304.0;
+}
+__device__ __forceinline__ double revs_q32(double g2) {
+    double r = g2 + 1572864.0;
+    asm volatile("" : "+v"(r));
+    return r - 1572864.0;
+}
 
 // clip(v, lo, hi) as one v_med3_f32 (lo <= hi)
 __device__ __forceinline__ float clip3(float v, float lo, float hi) {
