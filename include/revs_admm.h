@@ -737,9 +737,10 @@ int revs_plan_chain_run(revs_plan_t *plan, int32_t max_steps, revs_chain_state_t
  * workgroups behind the sweep: [0, T) judge the trial (rows by the tree form, selection: the stats
  * the host polls), [T, 2T) already run rows, selection, small model and step of the NEXT iteration.
  * The host accepts iteration k on the same test as revs_plan_chain_step
- * (revs_newton_chain_accept) while that launch is still busy, and enqueues the next sweep behind
- * it: no gap, two launches per iteration.  A rejected iteration leaves the state untouched (the
- * sweep wrote to the spares only) for the caller's general loop.
+ * (revs_newton_chain_accept) while that launch is still busy; the next sweep is already in the queue
+ * behind it (st->p_est_3 ...: enqueued unjudged, round 4): no gap, two launches per iteration.  A
+ * rejected iteration leaves the state untouched (the sweeps wrote to the spares only) for the caller's
+ * general loop.
  *   st   y / y_trial / y_spare: three multiplier arrays (double[m][T]); roles rotate by the kept
  *        iterations (y = the accepted multipliers at return); use_y, sup0 as revs_chain_state_t
  *        (sup0 = -1 at return); state buffers as there; s_out / c_out: NULL, or where the FIRST
@@ -762,6 +763,17 @@ typedef struct {
     int32_t pivots;     /* out, with resume = 2: pivots taken by the model of the step y */
     int32_t redone;     /* out: Newton steps beyond the first that the call's LAST iteration took inside the call
                            (a kept one: the call returns behind it; or, with resume = 2, the one handed back) */
+    /* A third set of state buffers (all three or none).  With it the sweep of iteration k + 1 is enqueued right
+     * behind the operator launch of iteration k, BEFORE the host has seen that iteration's verdict (it reads the
+     * spares iteration k wrote and writes this set): the host's poll - accept - launch turnaround (~6 us) is off the
+     * GPU's critical path.  A rejected iteration k leaves that sweep's output unused (the call waits for it);
+     * the three sets' roles rotate by the kept iterations. */
+    float *p_est_3, *p_sch_3, *gamma_3;
+    /* The residences' carried PDHG multipliers (float[n]; NULL x 3 when the plan has none): a sweep reads
+     * pdhg_dual and writes pdhg_dual_new (the unjudged one: reads that, writes pdhg_dual_3); roles rotate with the
+     * state, so a rejected iteration leaves the multipliers it started from untouched -- the sweep that replaces it
+     * starts from the same warm start, bit for bit.  At return the plan points at pdhg_dual. */
+    float *pdhg_dual, *pdhg_dual_new, *pdhg_dual_3;
 } revs_chain_fold_state_t;
 int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, revs_chain_fold_state_t *st,
                              int32_t *kept_steps, void *stream);

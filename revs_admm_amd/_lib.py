@@ -72,7 +72,8 @@ class ChainFoldState(C.Structure):
                 ("sup0", C.c_int32), ("p_est", C.c_void_p), ("p_est_new", C.c_void_p), ("p_sch", C.c_void_p),
                 ("p_sch_alt", C.c_void_p), ("gamma", C.c_void_p), ("gamma_alt", C.c_void_p),
                 ("s_out", C.c_void_p), ("c_out", C.c_void_p), ("resume", C.c_int32), ("pivots", C.c_int32),
-                ("redone", C.c_int32)]
+                ("redone", C.c_int32), ("p_est_3", C.c_void_p), ("p_sch_3", C.c_void_p), ("gamma_3", C.c_void_p),
+                ("pdhg_dual", C.c_void_p), ("pdhg_dual_new", C.c_void_p), ("pdhg_dual_3", C.c_void_p)]
 
 
 class Tree(C.Structure):

@@ -1170,6 +1170,7 @@ static int agent_step_impl(int64_t n_homes, int32_t T, const float *cost,
                      "revs_agent_step: bad argument of the folded chain's sweep");
         a.sh_a = cf->sh_a; a.sh_b = cf->sh_b; a.sh_m = cf->m; a.sh_kappa = cf->kappa;
         a.fold_a = cf->fold_a; a.fold_b = cf->fold_b; a.pe_out = cf->pe_out;
+        if (cf->y_out) a.y_out = cf->y_out;
     }
     if (sx && !sx->verdict) {         // judged by blocks (stream_block_verdict): silencing only
         REVS_REQUIRE(!sel, "revs_agent_step: bad streaming argument");      // (ctl == NULL: never silenced)

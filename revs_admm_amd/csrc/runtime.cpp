@@ -597,6 +597,39 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
     int redo = 0;
     bool redo_pending = false;
     const int kMaxRedo = plan->fold_redo;
+    // Sweeps enqueued ahead of their iteration's turn (st->p_est_3 ...): `swept` = this iteration's sweep is in the
+    // queue already.  Every sweep ORs its residences' status bits into its own host-visible word (three rotate: at
+    // most two sweeps are unjudged at any time); a word joins the sticky one when its iteration is kept.
+    REVS_REQUIRE((st->p_est_3 != nullptr) == (st->p_sch_3 != nullptr) && (st->p_est_3 != nullptr) == (st->gamma_3 != nullptr),
+                 "revs_plan_chain_fold_run: the third set of state buffers is all three or none");
+    static const bool no_spec = getenv("REVS_FOLD_NO_SPEC") != nullptr;     // (debugging aid)
+    const bool can_spec = st->p_est_3 != nullptr && !no_spec;
+    bool swept = false;
+    unsigned int sweep_no = 0;
+    volatile unsigned int *const fwords = plan->flags_host ? (volatile unsigned int *)plan->flags_host + 1 : nullptr;
+    if (fwords) fwords[0] = fwords[1] = fwords[2] = 0u;
+    const bool warm = d.mode == REVS_MODE_RELAXED_PDHG && d.pdhg_dual != nullptr;
+    REVS_REQUIRE(!warm || !st->pdhg_dual || (st->pdhg_dual == d.pdhg_dual && st->pdhg_dual_new && st->pdhg_dual_new != st->pdhg_dual &&
+                                              (!st->p_est_3 || (st->pdhg_dual_3 && st->pdhg_dual_3 != st->pdhg_dual &&
+                                                                st->pdhg_dual_3 != st->pdhg_dual_new))),
+                 "revs_plan_chain_fold_run: pdhg_dual must be the plan's, with distinct spares");
+    const bool ybuf = warm && st->pdhg_dual != nullptr;      // (else: updated in place, as before round 4)
+    auto sweep = [&](int parity, const float *pe, const float *ps, const float *gm, float *pe_out, float *ps_out, float *gm_out,
+                     float *s_out, float *c_out, float *y_in, float *y_out) -> int {
+        revs::ChainFold cf{plan->fold_sh[0], plan->fold_sh[1], d.m, d.kappa, plan->fold_e2[parity],
+                           plan->fold_e1[parity ^ 1], pe_out};
+        cf.y_out = ybuf ? y_out : nullptr;
+        int r = revs::agent_step_chain(d.n_homes, d.T, d.cost, d.homes, d.load, pe, ps, gm, ps_out, gm_out, s_out, c_out, d.diff,
+                                       d.dsq, d.status, ybuf ? y_in : d.pdhg_dual, (float)d.kappa, d.mode, &d.pdhg, d.node_of, cf,
+                                       plan->flags_dev ? plan->flags_dev + 1 + sweep_no % 3u : nullptr, stream);
+        ++sweep_no;
+        // Residences sharded: every rank's sweep has folded its own residences' addends -- exact and order-independent
+        // (revs_q36 / revs_q32), so the all-reduced sums are the one-process sums bit for bit.  Both arrays in ONE
+        // collective per iteration (8 M T doubles: {p, N, q, 0} per slot and node, twice); everything behind it is
+        // replicated and deterministic.
+        if (r == REVS_OK && plan->comm) r = revs_comm_allreduce_f64(plan->comm, plan->fold_e2[parity], 8 * mt, 0, stream);
+        return r;
+    };
     for (int32_t k = 0; k < max_steps; ++k) {
         const Set S0 = set_of(par, 0), S1 = set_of(par, 1), S0n = set_of(par ^ 1, 0), S1n = set_of(par ^ 1, 1);
         if (redo_pending) {
@@ -659,18 +692,13 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
                 return REVS_ELAUNCH;
             }
         }
-        // (every earlier sweep of this call has ended -- its verdict was read -- so the status word is final for them)
-        const unsigned int flags_before = plan->flags_host ? *(volatile unsigned int *)plan->flags_host : 0u;
-        const revs::ChainFold cf{plan->fold_sh[0], plan->fold_sh[1], d.m, d.kappa, plan->fold_e2[par],
-                                 plan->fold_e1[par ^ 1], st->p_est_new};
-        rc = revs::agent_step_chain(d.n_homes, d.T, d.cost, d.homes, d.load, st->p_est, st->p_sch, st->gamma,
-                                    st->p_sch_alt, st->gamma_alt, st->s_out, st->c_out, d.diff, d.dsq, d.status,
-                                    d.pdhg_dual, (float)d.kappa, d.mode, &d.pdhg, d.node_of, cf, plan->flags_dev, stream);
-        if (rc != REVS_OK) return rc;
-        // Residences sharded: every rank's sweep has folded its own residences' addends -- exact and order-independent
-        // (revs_q36 / revs_q32), so the all-reduced sums are the one-process sums bit for bit.  Both arrays in ONE
-        // collective per iteration (8 M T doubles: {p, N, q, 0} per node and slot, twice); everything behind it is replicated and deterministic.
-        if (plan->comm && (rc = revs_comm_allreduce_f64(plan->comm, plan->fold_e2[par], 8 * mt, 0, stream)) != REVS_OK) return rc;
+        const unsigned int word_k = swept ? (sweep_no - 1u) % 3u : sweep_no % 3u;      // this iteration's sweep's status word
+        if (!swept) {
+            rc = sweep(par, st->p_est, st->p_sch, st->gamma, st->p_est_new, st->p_sch_alt, st->gamma_alt, st->s_out, st->c_out,
+                       st->pdhg_dual, st->pdhg_dual_new);
+            if (rc != REVS_OK) return rc;
+        }
+        swept = false;
         const double seq = -(plan->seq += 1.0);
         revs::ChainKv c{};
         c.m = d.m; c.T = d.T; c.kadd = d.kadd; c.has_e2 = 1;
@@ -696,6 +724,15 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
         c.prev_ccnt = S0.cc;
         rc = revs::chain_kv_launch(c, stream);
         if (rc != REVS_OK) return rc;
+        // The next iteration's sweep, unjudged: it needs this launch's shifts and cleared sum arrays (stream order) and
+        // the state this iteration's sweep wrote; its own output goes to the third set.  (Not behind an iteration that
+        // took extra Newton steps: the call returns behind that one.)
+        const bool spec = can_spec && k + 1 < max_steps && redo == 0;
+        if (spec) {
+            rc = sweep(par ^ 1, st->p_est_new, st->p_sch_alt, st->gamma_alt, st->p_est_3, st->p_sch_3, st->gamma_3, nullptr, nullptr,
+                       st->pdhg_dual_new, st->pdhg_dual_3);
+            if (rc != REVS_OK) return rc;
+        }
         // the trial's verdict: poll its tags (pinned memory), then the driver's own acceptance test
         const volatile double *tg = S1.st_host;
         const auto t0 = std::chrono::steady_clock::now();
@@ -745,11 +782,16 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
             // sets the bit again if it is true of the problem that counts; "no solution" does not depend on
             // the estimate: kept).  The carried PDHG multipliers ARE left where that sweep put them: another
             // warm start of the same problems.
-            // (the sweep ended before the operator launch whose tags have just been read began: its bits are in;
-            // what the sweeps that stand had said before it was launched is kept)
-            if (plan->flags_host) {
-                volatile unsigned int *fw = (volatile unsigned int *)plan->flags_host;
-                *fw = (*fw & ~2u) | (flags_before & 2u);
+            // (each sweep has its own word: this one's and the unjudged next one's are dropped -- the latter once it
+            // has run; "no solution" does not depend on the estimate: kept)
+            if (spec && hipStreamSynchronize(s) != hipSuccess) {
+                revs::set_error("revs_plan_chain_fold_run: waiting for the unjudged sweep failed");
+                return REVS_ELAUNCH;
+            }
+            if (fwords) {
+                *(volatile unsigned int *)plan->flags_host |= (fwords[word_k] | (spec ? fwords[(word_k + 1u) % 3u] : 0u)) & 1u;
+                fwords[word_k] = 0u;
+                if (spec) fwords[(word_k + 1u) % 3u] = 0u;
             }
             // The caller's general loop takes this iteration (state untouched).  When the trial is a good
             // Newton step that merely left the rows above the tolerance -- the usual rejection with on/off
@@ -785,6 +827,10 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
             }
             return REVS_OK;
         }
+        if (fwords) {                         // this iteration's sweep stands: its status bits join the sticky word
+            *(volatile unsigned int *)plan->flags_host |= fwords[word_k];
+            fwords[word_k] = 0u;
+        }
         double *y_old = st->y;
         st->y = st->y_trial;
         st->y_trial = st->y_spare;
@@ -794,6 +840,14 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
         std::swap(st->p_sch, st->p_sch_alt);
         std::swap(st->gamma, st->gamma_alt);
         std::swap(st->p_est, st->p_est_new);
+        if (ybuf) { std::swap(st->pdhg_dual, st->pdhg_dual_new); plan->d.pdhg_dual = st->pdhg_dual; }
+        if (spec) {                           // (state k + 1 is current; the unjudged sweep read it and wrote the third set)
+            std::swap(st->p_sch_alt, st->p_sch_3);
+            std::swap(st->gamma_alt, st->gamma_3);
+            std::swap(st->p_est_new, st->p_est_3);
+            if (ybuf) std::swap(st->pdhg_dual_new, st->pdhg_dual_3);
+            swept = true;
+        }
         st->s_out = nullptr;                  // (schedules are written by the call's first iteration only)
         st->c_out = nullptr;
         ++*kept_steps;

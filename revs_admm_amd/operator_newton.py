@@ -407,19 +407,33 @@ class DualNewtonMixin:
         if self._y_spare is None:
             self._y_spare = torch.zeros_like(self.yd[0])
         ys = (self.yd[0], self.yd[1], self._y_spare)
+        # a third set of state buffers, borrowed from the pools the streaming loop rotates through: the next
+        # iteration's sweep is enqueued unjudged behind the operator launch (roles rotate by the kept iterations)
+        pool = self._state_pools()
         bufs = (self.P_est, self.P_est_new, self.P_sch, self.P_sch_alt, self.G, self.G_alt)
+        third = (next(t for t in pool["pe"] if t is not self.P_est and t is not self.P_est_new),
+                 next(t for t in pool["ps"] if t is not self.P_sch and t is not self.P_sch_alt),
+                 next(t for t in pool["g"] if t is not self.G and t is not self.G_alt))
         sup0 = self._sup if (self._y_support and self._sup is not None) else -1
         st = _lib.ChainFoldState(ptr(ys[0]), ptr(ys[1]), ptr(ys[2]), int(self._y_support), sup0,
                                  *[ptr(t) for t in bufs], ptr(self.S) if write_sc else None,
-                                 ptr(self.Csoc) if write_sc else None, int(self._fold_resume))
+                                 ptr(self.Csoc) if write_sc else None, int(self._fold_resume), 0, 0,
+                                 *[ptr(t) for t in third])
+        ypool = pool["y"]                # (the carried PDHG multipliers rotate with the state: a rejected sweep leaves them alone)
+        if ypool is not None:
+            ysp = [t for t in ypool if t is not self.pdhg_dual][:2]
+            st.pdhg_dual, st.pdhg_dual_new, st.pdhg_dual_3 = ptr(self.pdhg_dual), ptr(ysp[0]), ptr(ysp[1])
         kept = C.c_int32()
         check(self.lib.revs_plan_chain_fold_run(self._plan, count, C.byref(st), C.addressof(kept), self.stream),
               "revs_plan_chain_fold_run")
         n = kept.value
-        by = {t.data_ptr(): t for t in bufs}
+        by = {t.data_ptr(): t for t in bufs + third}
         self.P_est, self.P_est_new = by[st.p_est], by[st.p_est_new]
         self.P_sch, self.P_sch_alt = by[st.p_sch], by[st.p_sch_alt]
         self.G, self.G_alt = by[st.gamma], by[st.gamma_alt]
+        self.P_est_alt = by[st.p_est_3]      # (any pool member that is neither P_est nor P_est_new)
+        if ypool is not None:
+            self.pdhg_dual = next(t for t in ypool if t.data_ptr() == st.pdhg_dual)      # (the plan points at it already)
         yb = {t.data_ptr(): t for t in ys}
         self.yd = [yb[st.y], yb[st.y_trial]]
         self._y_spare = yb[st.y_spare]

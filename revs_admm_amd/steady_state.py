@@ -131,11 +131,10 @@ class SteadyStateMixin:
             hist[n].copy_(self.diff)
         return n + 1
 
-    def _stream_run_blocks(self, count, hist=None):
-        """_stream_run with the verdicts taken by blocks and `stream_inner` iterations per launch
-        (revs_plan_stream_run_blocks): the state rotates through four sets of buffers, so that a
-        failed verdict deep inside a burst is undone without copies."""
-        o = self.op
+    def _state_pools(self):
+        """The pools the residences' state buffers rotate through (allocated on first use): four sets for the
+        block form's roll-back without copies, of which the folded chain borrows a third set for the sweep it
+        enqueues unjudged.  self.P_est / P_est_new / P_est_alt / P_sch / P_sch_alt / G / G_alt are always members."""
         if self._sets is None:
             z = lambda t: torch.zeros_like(t)
             self._sets = dict(pe=[self.P_est, self.P_est_new, self.P_est_alt, z(self.P_est), z(self.P_est)],
@@ -143,6 +142,14 @@ class SteadyStateMixin:
                               g=[self.G, self.G_alt, z(self.G), z(self.G)],
                               y=([self.pdhg_dual] + [z(self.pdhg_dual) for _ in range(3)]
                                  if self.pdhg_dual is not None else None))
+        return self._sets
+
+    def _stream_run_blocks(self, count, hist=None):
+        """_stream_run with the verdicts taken by blocks and `stream_inner` iterations per launch
+        (revs_plan_stream_run_blocks): the state rotates through four sets of buffers, so that a
+        failed verdict deep inside a burst is undone without copies."""
+        o = self.op
+        self._state_pools()
         p0 = self._fused_p
         if self.group is not None and not self._ar_ahead:
             self._allreduce(p0)
