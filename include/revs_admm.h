@@ -781,6 +781,50 @@ int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, revs_chain_fo
  * (default 2; 0: every such iteration is handed back at its step, resume = 2). */
 int revs_plan_set_fold_redo(revs_plan_t *plan, int32_t steps);
 
+/* ---- the operator's Newton solve as ONE native call -----------------------------------------
+ * Utility(...).solve() (reference lpsolver.py:163-238, called at lpsolver.py:256-259) through its dual:
+ * the loop of revs_admm_amd/operator_newton.py:_operator_solve_newton -- evaluate the multipliers, and
+ * while rows are beyond eps: model of every slot on its candidate set (revs_op_dual_model_small when
+ * every slot has at most 8 candidates, else revs_op_dual_model), Armijo backtracking per slot on the
+ * dual value (step, evaluation of the trial; halve the pending slots' steps), the same stopping, stalling
+ * and hand-off tests -- with the launches, the waits on the pinned stats blocks, the line search and the
+ * bookkeeping in the library: one read of a stats block per evaluation and no interpreter in between
+ * (round 3 measured ~80 us per evaluation from Python for ~45 us of kernels).  Residences sharded: the
+ * plan's communicator (revs_plan_set_comm) all-reduces p | N | q between an evaluation's phases.
+ * Everything is deterministic: the iterates are those of the Python loop, bit for bit.
+ *   revs_plan_set_newton: the buffers the plan descriptor does not carry -- the general model's Gram
+ *        slabs (double[T][nks][128][128]), the step lengths (pinned host double[T] and its device
+ *        address: written by the host, read by the step kernel through the mapping), the host view of
+ *        desc.info (pinned int32[T]: the models' pivot counts) -- and the loop's limits.
+ *   st   in: y = the current multipliers, y_trial = scratch (double[m][T] each); use_y: y is not all zero;
+ *        sup: candidate set (0 / 1) that lists every row with y != 0 (few of them: row-wise shifts), or
+ *        -1; the state; have_first: stats block 0 already holds the evaluation of y on this state;
+ *        have_pre: ... and block 1 the evaluation of the chain's trial (small model on set 0, full step
+ *        for the slots not within tolerance), made with the row-wise shifts iff chain_few_in;
+ *        out: ok (P_est_new holds the answer to tolerance; else y has been cleared and the caller's ADMM
+ *        forms take the iteration), y / y_trial swapped so that y is the accepted array, newton / evals /
+ *        pivots / models_small / models_general, last_small, few, pre_kept (the accepted state is exactly
+ *        what the chain's launches left), cur (the candidate set of the accepted evaluation),
+ *        nsup_sum / nsup_max (rows with a multiplier: all slots / the fullest slot). */
+typedef struct {
+    double *k_slabs;
+    int32_t nks;
+    double *alpha_host;
+    const double *alpha_dev;
+    const int32_t *info_host;
+    int32_t newton_max, ls_max;
+} revs_newton_opts_t;
+int revs_plan_set_newton(revs_plan_t *plan, const revs_newton_opts_t *opts);
+typedef struct {
+    double *y, *y_trial;
+    int32_t use_y, sup;
+    const float *p_est, *p_sch, *gamma;
+    float *p_est_new;
+    int32_t have_first, have_pre, chain_few_in;
+    int32_t ok, newton, evals, pivots, models_small, models_general, last_small, few, pre_kept, cur, nsup_sum, nsup_max;
+} revs_newton_state_t;
+int revs_plan_newton_solve(revs_plan_t *plan, revs_newton_state_t *st, void *stream);
+
 /* ---- the feeder as a tree: R p in O(nodes) ------------------------------------------
  * The reference forms the LinDistFlow sensitivity matrix R = 2 F D F^T densely
  * (lpsolver.py:17-26) and checks R_res g[:,t] against the limits (lpsolver.py:188-193).  On

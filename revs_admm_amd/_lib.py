@@ -76,6 +76,23 @@ class ChainFoldState(C.Structure):
                 ("pdhg_dual", C.c_void_p), ("pdhg_dual_new", C.c_void_p), ("pdhg_dual_3", C.c_void_p)]
 
 
+class NewtonOpts(C.Structure):
+    """revs_newton_opts_t"""
+    _fields_ = [("k_slabs", C.c_void_p), ("nks", C.c_int32), ("alpha_host", C.c_void_p), ("alpha_dev", C.c_void_p),
+                ("info_host", C.c_void_p), ("newton_max", C.c_int32), ("ls_max", C.c_int32)]
+
+
+class NewtonState(C.Structure):
+    """revs_newton_state_t"""
+    _fields_ = [("y", C.c_void_p), ("y_trial", C.c_void_p), ("use_y", C.c_int32), ("sup", C.c_int32),
+                ("p_est", C.c_void_p), ("p_sch", C.c_void_p), ("gamma", C.c_void_p), ("p_est_new", C.c_void_p),
+                ("have_first", C.c_int32), ("have_pre", C.c_int32), ("chain_few_in", C.c_int32),
+                ("ok", C.c_int32), ("newton", C.c_int32), ("evals", C.c_int32), ("pivots", C.c_int32),
+                ("models_small", C.c_int32), ("models_general", C.c_int32), ("last_small", C.c_int32),
+                ("few", C.c_int32), ("pre_kept", C.c_int32), ("cur", C.c_int32), ("nsup_sum", C.c_int32),
+                ("nsup_max", C.c_int32)]
+
+
 class Tree(C.Structure):
     """revs_tree_t"""
     _fields_ = [("n", C.c_int32), ("pack", C.c_void_p), ("w", C.c_void_p)]
@@ -209,6 +226,8 @@ SIGNATURES = {
     "revs_plan_set_stream_block": (C.c_int, [_p, C.c_int32, C.c_int32]),
     "revs_plan_set_stream_inner": (C.c_int, [_p, C.c_int32]),
     "revs_plan_set_fold_redo": (C.c_int, [_p, C.c_int32]),
+    "revs_plan_set_newton": (C.c_int, [_p, C.POINTER(NewtonOpts)]),
+    "revs_plan_newton_solve": (C.c_int, [_p, C.POINTER(NewtonState), _p]),
     "revs_plan_set_pdhg_dual": (C.c_int, [_p, _p]),
     "revs_plan_stream_run_blocks": (C.c_int, [_p, _i32, C.POINTER(StreamSets), _f64, _f64, _p, _p, _p, _p]),
     "revs_plan_stream_timing": (C.c_int, [_p, C.c_int32]),

@@ -146,21 +146,28 @@ constexpr float kSocMax = 1.0f;      // lpsolver.py:102-103
 
 // rank of each of this lane's SPL keys among the group's LPA*SPL keys, ties to
 // the earlier slot: rank_j = #{tau : key_tau < key_j or (key_tau == key_j and tau < t_j)}
+// = #{tau : (key_tau, tau) < (key_j, t_j)} lexicographically: the key mapped to an integer of the same order in the
+// high word, the slot in the low word, ONE 64-bit compare and an add-with-carry per pair (the two float compares,
+// the slot compare and the mask logic were five vector and two scalar instructions per pair: 360 + 144 per
+// wavefront, most of the on/off charger's solve).
 template <int LPA, int SPL>
 __device__ __forceinline__ void group_rank(const float (&key)[SPL], int t0, int (&rank)[SPL]) {
+    int ord[SPL];
+    long long mine[SPL];
 #pragma unroll
-    for (int j = 0; j < SPL; ++j) rank[j] = 0;
+    for (int j = 0; j < SPL; ++j) {
+        const int b = __float_as_int(key[j]);
+        ord[j] = b ^ ((b >> 31) & 0x7fffffff);           // floats -> integers of the same order (-0 < +0: keys are sums, never -0)
+        mine[j] = ((long long)ord[j] << 32) | (unsigned int)(t0 + j);
+        rank[j] = 0;
+    }
 #pragma unroll 1
     for (int sl = 0; sl < LPA; ++sl) {
 #pragma unroll
         for (int sj = 0; sj < SPL; ++sj) {
-            const float other = __shfl(key[sj], sl, LPA);
-            const int tau = sl * SPL + sj;
+            const long long other = ((long long)__shfl(ord[sj], sl, LPA) << 32) | (unsigned int)(sl * SPL + sj);
 #pragma unroll
-            for (int j = 0; j < SPL; ++j) {
-                const int t = t0 + j;
-                rank[j] += (other < key[j]) || (other == key[j] && tau < t);
-            }
+            for (int j = 0; j < SPL; ++j) rank[j] += other < mine[j] ? 1 : 0;
         }
     }
 }

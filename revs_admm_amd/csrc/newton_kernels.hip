@@ -370,19 +370,35 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
     // K = (sum of the K-split slabs) / kappa, rows and columns < a (rounded up to 4)
     double *Kt = Kall + (int64_t)t * kAmax * kAmax;
     {
-        const int a4 = (a + 3) & ~3;
-        for (int e = tid; e < a4 * a4; e += 256) {
-            const int i = e / a4, j = e - i * a4;
-            const double *src = Kslab + (int64_t)t * nks * kAmax * kAmax + i * kAmax + j;
-            double acc = 0.0;
-            for (int q = 0; q < nks; ++q) acc += src[(int64_t)q * kAmax * kAmax];
-            Kt[i * kAmax + j] = acc * inv_kappa;
+        // (four elements per thread and pass, slab by slab: 4 loads in flight per round trip, same order of the sum)
+        const int a4 = (a + 3) & ~3, tot = a4 * a4;
+        for (int e0 = tid; e0 < tot; e0 += 4 * 256) {
+            const double *src[4];
+            double acc[4] = {0.0, 0.0, 0.0, 0.0};
+            int off[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int e = e0 + 256 * x, ec = e < tot ? e : 0;
+                const int i = ec / a4, j = ec - i * a4;
+                off[x] = i * kAmax + j;
+                src[x] = Kslab + (int64_t)t * nks * kAmax * kAmax + off[x];
+            }
+            for (int q = 0; q < nks; ++q) {
+                double v[4];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) v[x] = src[x][(int64_t)q * kAmax * kAmax];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) acc[x] += v[x];
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+                if (e0 + 256 * x < tot) Kt[off[x]] = acc[x] * inv_kappa;
         }
     }
     __syncthreads();
     extern __shared__ double Ls_dyn[];                    // [kAmax][kAmax + 1]
     auto Ls = [&](int i, int j) -> double & { return Ls_dyn[i * (kAmax + 1) + j]; };
-    __shared__ double s_s[kAmax], c_s[kAmax], u_s[kAmax], w_s[kAmax], wred[4];
+    __shared__ double s_s[kAmax], c_s[kAmax], u_s[kAmax], w_s[kAmax], wred[4], idk_s[kAmax];
     __shared__ int bl[kAmax];
     __shared__ unsigned long long Bsh[kWords], Vsh[kWords];
     __shared__ double dl_s, tolw_s, tolu_s;
@@ -461,39 +477,65 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
             Ls(k, l) = kp(bl[k], bl[l]);
         }
         __syncthreads();
-        // Cholesky, lower triangle in place
-        for (int k = 0; k < nb; ++k) {
-            if (tid == 0) Ls(k, k) = sqrt(fmax(Ls(k, k), dl * 1e-6));
-            __syncthreads();
-            const double pk = Ls(k, k);
-            for (int i = k + 1 + tid; i < nb; i += 256) Ls(i, k) /= pk;
-            __syncthreads();
-            const int rem = nb - k - 1;
-            for (int e = tid; e < rem * rem; e += 256) {
-                const int i = k + 1 + e / rem, j = k + 1 + e % rem;
-                if (j <= i) Ls(i, j) -= Ls(i, k) * Ls(j, k);
+        // K'_BB = L D L^T in place (unit lower L below the diagonal, D on it), pivots floored at dl 1e-6 as the
+        // Cholesky form floored its squares.  ONE barrier per column: every thread reads the pivot itself, the trailing
+        // update uses the column unscaled (A_ij -= A_ik A_jk / d_k) and column k - 1 is scaled to l_ik in the same
+        // phase (nobody reads it there); reciprocals by v_rcp_f64 + two Newton steps, kept in LDS for the solves.
+        // (Three barriers, a square root and a division by one thread per column: ~45 us per round at 59 rows, r04.)
+        {
+            const int ti = tid >> 4, tj = tid & 15;
+            double rprev = 0.0;
+            for (int k = 0; k < nb; ++k) {
+                const double dk = fmax(Ls(k, k), dl * 1e-6);
+                double r = __builtin_amdgcn_rcp(dk);
+                r = __builtin_fma(__builtin_fma(-dk, r, 1.0), r, r);
+                r = __builtin_fma(__builtin_fma(-dk, r, 1.0), r, r);
+                if (tid == 0) idk_s[k] = r;
+                if (k > 0) for (int i = k + tid; i < nb; i += 256) Ls(i, k - 1) *= rprev;      // column k - 1: l_i,k-1 (rows >= k)
+                for (int i = k + 1 + ti; i < nb; i += 16) {
+                    const double cik = Ls(i, k) * r;
+                    for (int j = k + 1 + tj; j <= i; j += 16) Ls(i, j) -= cik * Ls(j, k);
+                }
+                rprev = r;
+                __syncthreads();
             }
-            __syncthreads();
+            // (the last column has nothing below its diagonal)
         }
-        // triangular solves in wavefront 0: lane l holds components l and l + 64
+        // triangular solves in wavefront 0: lane l holds components l and l + 64; the pivot component reaches the
+        // others through v_readlane (k is uniform: no trip through the LDS crossbar per step), the next column of L
+        // is requested before the current one is used
         if (tid < 64) {
             double v0 = lane < nb ? c_s[bl[lane]] : 0.0;
             double v1 = lane + 64 < nb ? c_s[bl[lane + 64]] : 0.0;
+            auto bcast = [&](int k) -> double {
+                const long long b0 = __double_as_longlong(v0), b1 = __double_as_longlong(v1);
+                const int kk = k & 63;
+                const int lo = k < 64 ? __builtin_amdgcn_readlane((int)b0, kk) : __builtin_amdgcn_readlane((int)b1, kk);
+                const int hi = k < 64 ? __builtin_amdgcn_readlane((int)(b0 >> 32), kk) : __builtin_amdgcn_readlane((int)(b1 >> 32), kk);
+                return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+            };
+            // L y = c_B (unit diagonal)
+            double l0 = (lane > 0 && lane < nb) ? Ls(lane, 0) : 0.0, l1 = (lane + 64 < nb) ? Ls(lane + 64, 0) : 0.0;
             for (int k = 0; k < nb; ++k) {
-                const double src = k < 64 ? __shfl(v0, k, 64) : __shfl(v1, k - 64, 64);
-                const double zk = src / Ls(k, k);
-                if (lane == k) v0 = zk;
-                else if (lane > k && lane < nb) v0 -= Ls(lane, k) * zk;
-                if (lane + 64 == k) v1 = zk;
-                else if (lane + 64 > k && lane + 64 < nb) v1 -= Ls(lane + 64, k) * zk;
+                const double n0 = (k + 1 < nb && lane > k + 1 && lane < nb) ? Ls(lane, k + 1) : 0.0;
+                const double n1 = (k + 1 < nb && lane + 64 > k + 1 && lane + 64 < nb) ? Ls(lane + 64, k + 1) : 0.0;
+                const double yk = bcast(k);
+                if (lane > k) v0 -= l0 * yk;
+                if (lane + 64 > k) v1 -= l1 * yk;
+                l0 = n0; l1 = n1;
             }
+            // D^-1, then L^T x = y
+            v0 *= lane < nb ? idk_s[lane] : 0.0;
+            v1 *= lane + 64 < nb ? idk_s[lane + 64] : 0.0;
+            l0 = (nb >= 1 && lane < nb - 1) ? Ls(nb - 1, lane) : 0.0;
+            l1 = (nb >= 1 && lane + 64 < nb - 1) ? Ls(nb - 1, lane + 64) : 0.0;
             for (int k = nb - 1; k >= 0; --k) {
-                const double src = k < 64 ? __shfl(v0, k, 64) : __shfl(v1, k - 64, 64);
-                const double xk = src / Ls(k, k);
-                if (lane == k) v0 = xk;
-                else if (lane < k) v0 -= Ls(k, lane) * xk;
-                if (lane + 64 == k) v1 = xk;
-                else if (lane + 64 < k) v1 -= Ls(k, lane + 64) * xk;
+                const double n0 = (k >= 1 && lane < k - 1) ? Ls(k - 1, lane) : 0.0;
+                const double n1 = (k >= 1 && lane + 64 < k - 1) ? Ls(k - 1, lane + 64) : 0.0;
+                const double xk = bcast(k);
+                if (lane < k) v0 -= l0 * xk;
+                if (lane + 64 < k) v1 -= l1 * xk;
+                l0 = n0; l1 = n1;
             }
             u_s[lane] = 0.0; u_s[lane + 64] = 0.0;
             __builtin_amdgcn_wave_barrier();

@@ -77,6 +77,7 @@ struct revs_plan {
     int32_t *fold_cc[2] = {nullptr, nullptr};
     double *fold_cv[2] = {nullptr, nullptr};
     double *fold_st_host[2] = {nullptr, nullptr}, *fold_st_dev[2] = {nullptr, nullptr};
+    revs_newton_opts_t newton{};           // revs_plan_set_newton
     double *fold_st_local[2] = {nullptr, nullptr};     // device: stats of the next-iteration half, by the parity of the set they belong to
     bool fold_st_local_valid = false;      // ... hold the stats of the evaluation the next verdict belongs to
     int32_t fold_par = 0;                  // parity of the iteration a resumed call starts with
@@ -467,6 +468,191 @@ extern "C" int revs_plan_spec_run(revs_plan_t *plan, int32_t max_steps, const do
                 "waiting %.2f us per step\n", *kept_steps, us / *kept_steps, plan->t_launch / *kept_steps,
                 plan->t_wait / *kept_steps);
         plan->t_launch = plan->t_wait = 0.0;
+    }
+    return REVS_OK;
+}
+
+// ---- the operator's Newton solve as one native call (see revs_admm.h) ---------------------------
+extern "C" int revs_plan_set_newton(revs_plan_t *plan, const revs_newton_opts_t *o) {
+    REVS_REQUIRE(plan && o && o->k_slabs && o->nks >= 1 && o->nks <= 64 && o->alpha_host && o->alpha_dev && o->info_host &&
+                 o->newton_max >= 1 && o->ls_max >= 1, "revs_plan_set_newton: bad argument");
+    plan->newton = *o;
+    return REVS_OK;
+}
+
+extern "C" int revs_plan_newton_solve(revs_plan_t *plan, revs_newton_state_t *st, void *stream) {
+    REVS_REQUIRE(plan && st && st->y && st->y_trial && st->y != st->y_trial && st->p_est && st->p_sch && st->gamma &&
+                 st->p_est_new && st->sup >= -1 && st->sup <= 1, "revs_plan_newton_solve: bad argument");
+    const revs_plan_desc_t &d = plan->d;
+    const revs_newton_opts_t &o = plan->newton;
+    REVS_REQUIRE(o.k_slabs && d.cand_idx1 && d.cand_cnt1 && d.cand_val1 && d.stats1 && d.stats1_host && d.yhat && d.k_full &&
+                 d.info && d.max_pivots > 0 && d.eps > 0, "revs_plan_newton_solve: revs_plan_set_newton / the chain's buffers are missing");
+    const int T = d.T, A = REVS_DUAL_AMAX;
+    REVS_REQUIRE(T <= 256, "revs_plan_newton_solve: T = %d", T);
+    hipStream_t s = (hipStream_t)stream;
+    int64_t *const ci[2] = {d.cand_idx, d.cand_idx1};
+    int32_t *const cc[2] = {d.cand_cnt, d.cand_cnt1};
+    double *const cv[2] = {d.cand_val, d.cand_val1};
+    double *const sd[2] = {d.stats, d.stats1};
+    const double *const sh[2] = {d.stats_host, d.stats1_host};
+    const double scale = std::max(std::max(std::fabs(d.vlo), std::fabs(d.vhi)), 1e-300);
+    const int64_t mt = (int64_t)d.m * T;
+    const bool tf = plan->tree.n > 0 && plan->tree.n <= REVS_TREE_SWEEP_MAX;     // rows by the tree form of R p
+    const revs_tree_t trh{plan->tree.n, (const uint64_t *)plan->tree.pack, plan->tree.w};
+    double *ycur = st->y, *ytrial = st->y_trial;
+    // One evaluation of multipliers yy (p, N, D, the voltage rows, candidate lists and stats into set k; P_est_new =
+    // the answer for yy), waited for: the selection tags the pinned stats block behind a system-scope fence.
+    auto evaluate = [&](const double *yy, int uy, int k, int sup, double *out /* [T][8] */) -> int {
+        const double tag = (plan->seq += 1.0) + 0.25;      // (Python's evaluations: n + 0.5; the other native loops: whole numbers)
+        auto phase = [&](int ph) -> int {
+            if (tf)
+                return revs_op_dual_evaluate_tree(ph, d.m, T, d.node_ptr, st->p_est, st->p_sch, st->gamma, d.R, &trh, yy, uy,
+                                                  d.kappa, d.vlo, d.vhi, d.kadd, d.ksplit, d.d_slabs, d.pnq, st->p_est_new, d.vfull,
+                                                  d.viol, d.partial, ci[k], cc[k], cv[k], sd[k], tag, stream);
+            return revs_op_dual_evaluate(ph, d.m, T, d.node_ptr, st->p_est, st->p_sch, st->gamma, d.R, d.Rt, yy, uy, d.kappa,
+                                         d.vlo, d.vhi, d.kadd, d.ksplit, d.d_slabs, d.v_slabs, d.pnq, st->p_est_new, d.vfull, d.viol,
+                                         d.partial, ci[k], cc[k], cv[k], sd[k], tag, plan->counters, stream);
+        };
+        int rc;
+        if (uy && sup >= 0) {             // few multipliers: shifts straight from their rows of R, no dense product
+            rc = revs_op_dual_eval_rows(d.m, T, d.node_ptr, st->p_est, st->p_sch, st->gamma, d.R, ci[sup], cc[sup], yy, d.kappa,
+                                        d.pnq, st->p_est_new, stream);
+            if (rc == REVS_OK && plan->comm) rc = revs_comm_allreduce_f64(plan->comm, d.pnq, 3 * mt, 0, stream);
+            if (rc == REVS_OK) rc = phase(2);
+        } else if (!plan->comm) {
+            rc = phase(3);
+        } else {
+            rc = phase(1);
+            if (rc == REVS_OK) rc = revs_comm_allreduce_f64(plan->comm, d.pnq, 3 * mt, 0, stream);      // the only exchange
+            if (rc == REVS_OK) rc = phase(2);
+        }
+        if (rc != REVS_OK) return rc;
+        const volatile double *tg = sh[k];
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int t = 0; t < T; ++t) {
+            unsigned spins = 0;
+            while (tg[8 * t + 5] != tag) {
+                if ((++spins & 0xFFFF) == 0) {
+                    if (hipStreamQuery(s) == hipSuccess && tg[8 * t + 5] != tag) {
+                        revs::set_error("revs_plan_newton_solve: stream idle but stats tag missing");
+                        return REVS_ELAUNCH;
+                    }
+                    if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(120)) {
+                        (void)hipStreamSynchronize(s);
+                        revs::set_error("revs_plan_newton_solve: timed out waiting for an evaluation");
+                        return REVS_ELAUNCH;
+                    }
+                }
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        for (int i = 0; i < 8 * T; ++i) out[i] = tg[i];
+        return REVS_OK;
+    };
+    std::vector<double> stt(8 * (size_t)T), stn(8 * (size_t)T), alpha((size_t)T), Dv((size_t)T);
+    std::vector<char> pending((size_t)T);
+    int cur = 0, rc = REVS_OK;
+    if (st->have_first) for (int i = 0; i < 8 * T; ++i) stt[i] = d.stats_host[i];
+    else if ((rc = evaluate(ycur, st->use_y, 0, st->use_y ? st->sup : -1, stt.data())) != REVS_OK) return rc;
+    int evals = 1, newton = 0, pivots = 0, stall = 0, n_small = 0, n_general = 0;
+    bool ok_all = false, last_small = false, few = false, from_pre = st->have_pre != 0;
+    double best = INFINITY;
+    for (;;) {
+        double rmax = 0.0, ns_max = 0.0, nc_max = 0.0;
+        bool over = false, full = false;
+        for (int t = 0; t < T; ++t) {
+            const double *a = &stt[8 * t];
+            if (a[2] > A) over = true;                           // more multipliers than a model holds
+            const double r = a[0] / scale;
+            rmax = std::max(rmax, r);
+            // a slot whose model is full of multipliers while rows are still violated cannot take them in
+            if (a[2] >= A && a[3] > 0 && r > d.eps) full = true;
+            ns_max = std::max(ns_max, a[2]);
+            nc_max = std::max(nc_max, a[2] + std::min(a[3], std::min((double)d.kadd, A - a[2])));
+        }
+        if (over) break;
+        if (rmax <= d.eps) { ok_all = true; break; }
+        if (newton >= o.newton_max || full) break;
+        // ... and a solve that stopped improving is not worth more iterations
+        if (rmax < 0.5 * best) { best = rmax; stall = 0; }
+        else if (++stall >= 10) break;
+        ++newton;
+        last_small = nc_max <= 8;
+        few = ns_max + d.kadd <= 48;
+        // (the chain guessed how its trial's home pass gets d = R^T y / kappa -- row-wise or dense; another choice here
+        // would differ in the last bits: then the trial is made again)
+        const bool use_pre = st->have_pre && newton == 1 && last_small && few == (st->chain_few_in != 0);
+        if (!use_pre) {
+            if (last_small) {
+                ++n_small;
+                rc = revs_op_dual_model_small(d.m, T, d.R, d.pnq + mt, ci[cur], cc[cur], cv[cur], d.kappa, d.delta, d.max_pivots,
+                                              d.k_full, d.yhat, d.info, stream);
+            } else {
+                ++n_general;
+                rc = revs_op_dual_model(d.m, T, d.R, d.pnq + mt, ci[cur], cc[cur], cv[cur], d.kappa, d.delta, d.max_pivots, o.nks,
+                                        o.k_slabs, d.k_full, d.yhat, d.info, stream);
+            }
+            if (rc != REVS_OK) return rc;
+        } else {
+            ++n_small;                                            // (the chain ran this model on this set)
+        }
+        bool any_pending = false;
+        for (int t = 0; t < T; ++t) {
+            Dv[t] = stt[8 * t + 1];
+            pending[t] = stt[8 * t] / scale > d.eps;
+            alpha[t] = pending[t] ? 1.0 : 0.0;
+        }
+        const int nxt = 1 - cur;
+        for (int ls = 0; ls < o.ls_max; ++ls) {
+            if (use_pre && ls == 0) {
+                for (int i = 0; i < 8 * T; ++i) stn[i] = d.stats1_host[i];      // that trial and its evaluation: already there
+            } else {
+                from_pre = false;
+                for (int t = 0; t < T; ++t) o.alpha_host[t] = alpha[t];        // read by the step kernel through its mapping
+                if (hipMemcpyAsync(ytrial, ycur, sizeof(double) * mt, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+                    revs::set_error("revs_plan_newton_solve: copying the multipliers failed");
+                    return REVS_ELAUNCH;
+                }
+                rc = revs_op_dual_step(T, ci[cur], cc[cur], cv[cur], d.yhat, o.alpha_dev, ytrial, sd[nxt] + 4, stream);
+                if (rc == REVS_OK) rc = evaluate(ytrial, 1, nxt, few ? cur : -1, stn.data());
+                if (rc != REVS_OK) return rc;
+            }
+            ++evals;
+            // (slack 1e-11 |D|: the evaluations sum the squares rounded to 2^-32 so that the sums do not depend on their
+            // order -- a rounding of ~1e-13 |D| per evaluation)
+            any_pending = false;
+            for (int t = 0; t < T; ++t) {
+                const bool okk = stn[8 * t + 1] >= Dv[t] + 1e-4 * stn[8 * t + 4] - 1e-11 * std::fabs(Dv[t]);
+                if (okk) pending[t] = 0;
+                if (pending[t]) { any_pending = true; alpha[t] *= 0.5; }
+            }
+            if (!any_pending) break;
+        }
+        for (int t = 0; t < T; ++t) pivots += std::abs(o.info_host[t]);     // (the evaluation was waited for)
+        if (any_pending) break;                                   // no ascent found: leave it to the ADMM forms
+        std::swap(ycur, ytrial);
+        cur = nxt;
+        stt.swap(stn);
+    }
+    st->y = ycur;
+    st->y_trial = ytrial;
+    st->ok = ok_all;
+    st->newton = newton;
+    st->evals = evals;
+    st->pivots = pivots;
+    st->models_small = n_small;
+    st->models_general = n_general;
+    st->last_small = last_small;
+    st->few = newton >= 1 ? (few ? 1 : 0) : 0;
+    st->pre_kept = ok_all && from_pre && newton <= 1;
+    st->cur = cur;
+    double sum = 0.0, mx = 0.0;
+    for (int t = 0; t < T; ++t) { sum += stt[8 * t + 2]; mx = std::max(mx, stt[8 * t + 2]); }
+    st->nsup_sum = (int32_t)sum;
+    st->nsup_max = (int32_t)mx;
+    if (!ok_all && hipMemsetAsync(ycur, 0, sizeof(double) * mt, s) != hipSuccess) {
+        revs::set_error("revs_plan_newton_solve: clearing the multipliers failed");
+        return REVS_ELAUNCH;
     }
     return REVS_OK;
 }

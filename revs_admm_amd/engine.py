@@ -110,6 +110,10 @@ class OperatorOptions:
     # launches the home sweep right behind the operator's first evaluation, before the host
     # has seen that evaluation's verdict (P_sch / G go to spare buffers): the GPU never
     # waits for the host.  If rows turn out to need work, the sweep is simply run again.
+    # the Newton solve itself (evaluations, models, line search, stopping tests) as one native call where the plan
+    # exists (revs_plan_newton_solve: same iterates, no interpreter between the launches); False: the Python loop of
+    # operator_newton.py, which is also what runs on a process group without the library's communicator
+    native_newton: bool = True
     speculate: bool = True
     # One GPU, multipliers all zero: the speculative sweep also does the home pass of the NEXT
     # operator evaluation (one pass over the homes per ADMM iteration instead of two).
@@ -393,6 +397,9 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
                 raise _lib.RevsError("revs_plan_create failed: "
                                      + self.lib.revs_last_error().decode())
             check(self.lib.revs_plan_set_fold_redo(self._plan, int(self.op.fold_redo)), "revs_plan_set_fold_redo")
+            no = _lib.NewtonOpts(ptr(self.k_slabs), self.nks, self.alpha_h.data_ptr(), self.alpha_dev,
+                                 self.info_h.data_ptr(), int(self.op.newton_max), int(self.op.newton_ls))
+            check(self.lib.revs_plan_set_newton(self._plan, C.byref(no)), "revs_plan_set_newton")
         # third node-sum buffer and the feeder as a tree: streaming steady state
         self.p_alt2 = nz()
         self._burst = max(1, int(self.op.stream_burst))

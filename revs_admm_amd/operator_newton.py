@@ -112,6 +112,8 @@ class DualNewtonMixin:
         if that iteration turns out to be the one this loop would have run.  Sets
         `_pre_kept`: the accepted state is exactly the one `pre` (or `first`) left behind."""
         o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
+        if o.native_newton and self._plan is not None and (self.group is None or self._comm is not None):
+            return self._operator_solve_newton_native(first is not None, pre is not None)
         A = _lib.DUAL_AMAX
         scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
         self._fold_resume = False
@@ -225,6 +227,41 @@ class DualNewtonMixin:
         # the accepted evaluation's candidate set `cur` lists the rows with y != 0 first
         self._sup = cur if (self._y_support and stt[:, 2].max() + o.newton_kadd <= 48) else None
         self.op_iters_hist.append(evals)
+        self.op_path_hist.append("dual")
+        self.op_converged = True
+        return True
+
+    def _operator_solve_newton_native(self, have_first, have_pre):
+        """_operator_solve_newton's loop inside the library (revs_plan_newton_solve): same iterates and the
+        same bookkeeping, one native call per operator solve."""
+        o = self.op
+        self._fold_resume = False
+        ys = (self.yd[0], self.yd[1])
+        sup = self._sup if (self._y_support and self._sup is not None) else -1
+        st = _lib.NewtonState(ptr(ys[0]), ptr(ys[1]), int(self._y_support), sup, ptr(self.P_est), ptr(self.P_sch),
+                              ptr(self.G), ptr(self.P_est_new), int(have_first), int(have_pre), int(self._chain_few))
+        check(self.lib.revs_plan_newton_solve(self._plan, C.byref(st), self.stream), "revs_plan_newton_solve")
+        self._pending_tag = [None, None]         # (the stats blocks were written by the native loop, which waited itself)
+        self.yd = [ys[0], ys[1]] if st.y == ys[0].data_ptr() else [ys[1], ys[0]]
+        self.model_calls[0] += st.models_small
+        self.model_calls[1] += st.models_general
+        ok_all, newton = bool(st.ok), st.newton
+        self.newton_hist.append((newton, st.evals, st.pivots))
+        self._pre_kept = bool(st.pre_kept)
+        self._chain_ok = bool(ok_all and newton == 1 and st.last_small and st.evals == 2)
+        self._chain_few = bool(st.few)
+        if ok_all and newton == 0:
+            self._spec_wait = max(self._spec_wait - 1, 0)
+            self._spec_ok = self._spec_wait == 0
+        else:
+            self._spec_ok = False
+        if not ok_all:
+            self._y_support = False
+            self._sup = None
+            return False
+        self._y_support = st.nsup_sum > 0
+        self._sup = st.cur if (self._y_support and st.nsup_max + o.newton_kadd <= 48) else None
+        self.op_iters_hist.append(st.evals)
         self.op_path_hist.append("dual")
         self.op_converged = True
         return True

@@ -584,9 +584,7 @@ def test_native_step_and_fused_home_pass_change_nothing(gpu_lib, mode, T, monkey
 def test_chained_newton_iteration_changes_nothing(gpu_lib, mode, stress, redo):
     """The binding steady state enqueued whole (evaluation, small model, step decided on the
     device, evaluation, sweep: engine._chain_launch) against the driver that reads every
-    evaluation before going on: same schedules and multipliers, bit for bit.  (PDHG homes: to
-    1e-5 -- a sweep that is redone starts from the multipliers the discarded one left, another
-    warm start of the same home problems.)"""
+    evaluation before going on: same schedules and multipliers, bit for bit -- PDHG homes included."""
     from helpers import f32
     from revs_admm_amd.engine import OperatorOptions
     from revs_admm_amd.synthetic import make_workload
@@ -605,9 +603,8 @@ def test_chained_newton_iteration_changes_nothing(gpu_lib, mode, stress, redo):
         # (on/off chargers: some iterations need a second Newton step -- the folded chain hands its own
         # step back, revs_chain_fold_state_t::resume = 2, and the solve goes on from it)
         assert e1.fold_steps > 0 and e0.fold_steps == 0
-    if mode == "pdhg":
-        assert np.abs(d1 - d0).max() < 1e-5 and max(np.abs(a - b).max() for a, b in zip(r1, r0)) < 1e-4
-        return
+    # (PDHG homes too since round 4: the folded chain's sweeps write the carried multipliers to a spare array, so a
+    # rejected sweep leaves the warm start of the sweep that replaces it untouched)
     np.testing.assert_array_equal(d1, d0)
     for a, b in zip(r1, r0):
         np.testing.assert_array_equal(a, b)
@@ -832,3 +829,46 @@ def test_status_flags_surface_through_run_steps(gpu_lib):
     e.run_steps(3)
     with pytest.raises(_lib.RevsError, match="No solution found"):
         e.residuals()
+
+
+@pytest.mark.parametrize("case", ["binding", "stress6", "binary", "golden"])
+def test_native_newton_solve_equals_python_loop(gpu_lib, golden, feeder_R, case):
+    """revs_plan_newton_solve -- the operator's Newton solve (lpsolver.py:163-238 through its dual) as one
+    native call: evaluations, models, Armijo line search, stopping and hand-off tests in the library --
+    against the Python loop it mirrors (OperatorOptions(native_newton=False)): the same iterates, the same
+    Newton bookkeeping, bit for bit; on synthetic feeders (few rows: the small model; stress 6: a third of
+    the (residence, slot) pairs clamped, up to ten Newton iterations per solve), with on/off chargers, and
+    on the reference's 121144 feeder (up to 69 binding rows per slot: the general model)."""
+    from conftest import golden_homes
+    from helpers import f32
+    from revs_admm_amd.engine import AdmmEngine, OperatorOptions, pack_homes
+    from revs_admm_amd.synthetic import make_workload
+    runs = []
+    for native in (True, False):
+        op = OperatorOptions(native_newton=native)
+        if case == "golden":
+            z, fd = golden
+            oh, evi = golden_homes(z, "dis_a90_r4800", 4.8)
+            n = oh.LOAD.shape[0]
+            e = AdmmEngine(f32(z["tariff_shift6"]), pack_homes(oh.ev, 4.8, 20.0, 0.2, 11, 23), f32(oh.LOAD), np.arange(n),
+                           feeder_R, kappa=5.0, vset=1.03, vlow=0.95, vhigh=1.05, mode="binary", op=op)
+            iters = 15
+        else:
+            mode, stress, nh, nn = {"binding": ("pdhg", 1.3, 6000, 150), "stress6": ("relaxed_exact", 6.0, 8000, 200),
+                                    "binary": ("binary", 1.0, 6000, 150)}[case]
+            w = make_workload(nh, 24, n_nodes=nn, seed=5, binary_feasible=(mode == "binary"), stress=stress)
+            w.load, w.cost = f32(w.load), f32(w.cost)
+            e = _engine(w, mode, op=op)
+            iters = 30
+        d = e.run(iters)
+        runs.append((d, e.result(), e.yd[0].cpu().numpy(), list(e.newton_hist), list(e.op_iters_hist), list(e.model_calls),
+                     list(e.chain_hist), list(e.spec_hist)))
+    a, b = runs
+    assert max(h[0] for h in a[3]) >= (3 if case in ("stress6", "golden") else 1), a[3]      # real Newton solves on the way
+    if case == "golden":
+        assert a[5][1] > 0                                  # ... through the general model (more than 8 candidates)
+    assert a[3] == b[3] and a[4] == b[4] and a[5] == b[5] and a[6] == b[6] and a[7] == b[7]
+    np.testing.assert_array_equal(a[0], b[0])
+    for x, y in zip(a[1], b[1]):
+        np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(a[2], b[2])

@@ -47,8 +47,9 @@ def run(label, op):
 
 
 run("dual Newton (default)", OperatorOptions())
-for _k in (2, 3, 4):
-    run(f"dual Newton, kadd {_k}", OperatorOptions(newton_kadd=_k))
+if "--kadd" in sys.argv:
+    for _k in (2, 4, 6):
+        run(f"dual Newton, kadd {_k}", OperatorOptions(newton_kadd=_k))
 if "--admm" in sys.argv:
     for rv in (1.0, 25.0):
         run(f"ADMM forms, rho_v {rv}", OperatorOptions(solver="admm", rho_v_scale=rv))
