@@ -23,6 +23,7 @@
 #include "select_body.h"
 #include "tree_body.h"
 #include "internal.h"
+#include <type_traits>
 
 namespace revs {
 
@@ -354,6 +355,12 @@ __global__ __launch_bounds__(256) void op_dual_gram_kernel(
 // workgroup's dynamic LDS holds the 128 x 129 factor: 129 KB of the CU's 160 KB), swap
 // every infeasible index (u_i < 0 in B, w_i < 0 outside) while that shrinks their number,
 // else only the highest one -- finite for a positive definite K'.
+#ifdef REVS_BPP_STAMPS
+__device__ double g_bpp_stamps[256][32];
+#define BPP_STAMP(i) do { if (threadIdx.x == 0 && (i) < 32) g_bpp_stamps[blockIdx.x][i] = (double)wall_clock64(); } while (0)
+#else
+#define BPP_STAMP(i) do { } while (0)
+#endif
 __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
         const double *__restrict__ Kslab, int nks, double inv_kappa, double *__restrict__ Kall,
         const int32_t *__restrict__ ccnt, const double *__restrict__ cval, double delta,
@@ -367,6 +374,7 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
         if (tid == 0) info[t] = 0;
         return;
     }
+    BPP_STAMP(0);
     // K = (sum of the K-split slabs) / kappa, rows and columns < a (rounded up to 4)
     double *Kt = Kall + (int64_t)t * kAmax * kAmax;
     {
@@ -383,12 +391,18 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
                 off[x] = i * kAmax + j;
                 src[x] = Kslab + (int64_t)t * nks * kAmax * kAmax + off[x];
             }
-            for (int q = 0; q < nks; ++q) {
-                double v[4];
+            // (all slabs of the four elements requested before the first is added: one memory round trip per pass,
+            // not one per slab -- the slabs' 25 MB do not sit in a cache)
+            for (int q0 = 0; q0 < nks; q0 += 8) {
+                double v[8][4];
 #pragma unroll
-                for (int x = 0; x < 4; ++x) v[x] = src[x][(int64_t)q * kAmax * kAmax];
+                for (int q = 0; q < 8; ++q)
 #pragma unroll
-                for (int x = 0; x < 4; ++x) acc[x] += v[x];
+                    for (int x = 0; x < 4; ++x) v[q][x] = src[x][(int64_t)(q0 + q < nks ? q0 + q : 0) * kAmax * kAmax];
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+#pragma unroll
+                    for (int x = 0; x < 4; ++x) acc[x] += q0 + q < nks ? v[q][x] : 0.0;
             }
 #pragma unroll
             for (int x = 0; x < 4; ++x)
@@ -396,9 +410,10 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
         }
     }
     __syncthreads();
+    BPP_STAMP(1);
     extern __shared__ double Ls_dyn[];                    // [kAmax][kAmax + 1]
     auto Ls = [&](int i, int j) -> double & { return Ls_dyn[i * (kAmax + 1) + j]; };
-    __shared__ double s_s[kAmax], c_s[kAmax], u_s[kAmax], w_s[kAmax], wred[4], idk_s[kAmax];
+    __shared__ double s_s[kAmax], c_s[kAmax], u_s[kAmax], w_s[kAmax], wred[4], idk_s[kAmax], col_s[2][kAmax];
     __shared__ int bl[kAmax];
     __shared__ unsigned long long Bsh[kWords], Vsh[kWords];
     __shared__ double dl_s, tolw_s, tolu_s;
@@ -432,11 +447,23 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
     };
     // out_i = sum_j K'_ij u_j : 2 lanes per row, kAmax/2 columns each
     const int mi = tid >> 1, mp = tid & 1;
+    // (sixteen entries of the row in flight per round trip: one load per trip through the loop made this the
+    // kernel -- 64 dependent L2 latencies per product, a product per pivoting round; same order of the sum)
     auto matvec_row = [&]() -> double {
         double acc = 0.0;
-        if (mi < a)
-            for (int j = mp * (kAmax / 2); j < (mp + 1) * (kAmax / 2) && j < a; ++j)
-                acc += kp(mi, j) * u_s[j];
+        if (mi < a) {
+            const int j0 = mp * (kAmax / 2);
+            for (int jb = j0; jb < j0 + kAmax / 2 && jb < a; jb += 16) {
+                double kv[16];
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) kv[jj] = Kt[mi * kAmax + (jb + jj < a ? jb + jj : mi)];
+#pragma unroll
+                for (int jj = 0; jj < 16; ++jj) {
+                    const int j = jb + jj;
+                    if (j < a) acc += (s_s[mi] * s_s[j] * kv[jj] + (mi == j ? dl : 0.0)) * u_s[j];
+                }
+            }
+        }
         acc += __shfl_xor(acc, 1, 64);
         return acc;
     };
@@ -460,8 +487,11 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
         tolw_s = 1e-13 * cm;
     }
     int ninf = kAmax + 1, pcount = 3;       // thread 0's pivoting state
+    BPP_STAMP(2);
+    int round_ = 0;
     for (;;) {
         __syncthreads();
+        BPP_STAMP(3 + 4 * round_);
         unsigned long long B[kWords];
         int nb = 0;
 #pragma unroll
@@ -472,35 +502,66 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
             bl[pos] = tid;
         }
         __syncthreads();
-        for (int e = tid; e < nb * nb; e += 256) {
-            const int k = e / nb, l = e - k * nb;
-            Ls(k, l) = kp(bl[k], bl[l]);
-        }
-        __syncthreads();
-        // K'_BB = L D L^T in place (unit lower L below the diagonal, D on it), pivots floored at dl 1e-6 as the
-        // Cholesky form floored its squares.  ONE barrier per column: every thread reads the pivot itself, the trailing
-        // update uses the column unscaled (A_ij -= A_ik A_jk / d_k) and column k - 1 is scaled to l_ik in the same
-        // phase (nobody reads it there); reciprocals by v_rcp_f64 + two Newton steps, kept in LDS for the solves.
-        // (Three barriers, a square root and a division by one thread per column: ~45 us per round at 59 rows, r04.)
-        {
+        // K'_BB = L D L^T (unit lower L below the diagonal of Ls, 1 / D in idk_s), pivots floored at dl 1e-6 as the
+        // Cholesky form floored its squares.  The trailing matrix lives in REGISTERS: thread (ti, tj) owns the elements
+        // (i, j) with i % 16 = ti, j % 16 = tj; per column the sixteen-th of the threads that owns it publishes it (two
+        // alternating LDS buffers: ONE barrier per column), everybody reads the entries of its own rows and columns --
+        // independent LDS reads -- and updates its block with straight-line FMAs; the finished column goes to Ls, scaled,
+        // for the solves.  Reciprocals by v_rcp_f64 + two Newton steps.  (In-LDS updates -- two dependent LDS reads and
+        // a write per element, three barriers, a square root and a division by one thread per column -- took ~45 us per
+        // round at 59 rows; r04.)
+        auto factor = [&](auto nt_tag) {
+            constexpr int NT = decltype(nt_tag)::value;
             const int ti = tid >> 4, tj = tid & 15;
-            double rprev = 0.0;
-            for (int k = 0; k < nb; ++k) {
-                const double dk = fmax(Ls(k, k), dl * 1e-6);
-                double r = __builtin_amdgcn_rcp(dk);
-                r = __builtin_fma(__builtin_fma(-dk, r, 1.0), r, r);
-                r = __builtin_fma(__builtin_fma(-dk, r, 1.0), r, r);
-                if (tid == 0) idk_s[k] = r;
-                if (k > 0) for (int i = k + tid; i < nb; i += 256) Ls(i, k - 1) *= rprev;      // column k - 1: l_i,k-1 (rows >= k)
-                for (int i = k + 1 + ti; i < nb; i += 16) {
-                    const double cik = Ls(i, k) * r;
-                    for (int j = k + 1 + tj; j <= i; j += 16) Ls(i, j) -= cik * Ls(j, k);
+            double am[NT][NT];
+#pragma unroll
+            for (int x = 0; x < NT; ++x)
+#pragma unroll
+                for (int y = 0; y < NT; ++y) {
+                    const int i = ti + 16 * x, j = tj + 16 * y;
+                    am[x][y] = (i < nb && j <= i) ? kp(bl[i], bl[j]) : 0.0;
                 }
-                rprev = r;
-                __syncthreads();
+#pragma unroll
+            for (int yb = 0; yb < NT; ++yb) {
+                for (int kk = 0; kk < 16; ++kk) {
+                    const int k = 16 * yb + kk;
+                    if (k >= nb) break;                               // uniform
+                    double *const col = col_s[k & 1];
+                    if (tj == kk) {                                   // this column's owners: rows ti + 16 x
+#pragma unroll
+                        for (int x = 0; x < NT; ++x) col[ti + 16 * x] = am[x][yb];
+                    }
+                    __syncthreads();
+                    const double dk = fmax(col[k], dl * 1e-6);
+                    double r = __builtin_amdgcn_rcp(dk);
+                    r = __builtin_fma(__builtin_fma(-dk, r, 1.0), r, r);
+                    r = __builtin_fma(__builtin_fma(-dk, r, 1.0), r, r);
+                    double ci[NT], cj[NT];
+#pragma unroll
+                    for (int x = 0; x < NT; ++x) {
+                        const int i = ti + 16 * x, j = tj + 16 * x;
+                        ci[x] = (i > k && i < nb) ? col[i] * r : 0.0;
+                        cj[x] = (j > k && j < nb) ? col[j] : 0.0;
+                    }
+#pragma unroll
+                    for (int x = 0; x < NT; ++x)
+#pragma unroll
+                        for (int y = 0; y < NT; ++y) am[x][y] -= ci[x] * cj[y];
+                    if (tj == kk) {                                   // l_ik for the solves
+#pragma unroll
+                        for (int x = 0; x < NT; ++x) {
+                            const int i = ti + 16 * x;
+                            if (i > k && i < nb) Ls(i, k) = ci[x];
+                        }
+                        if (ti == 0) idk_s[k] = r;
+                    }
+                }
             }
-            // (the last column has nothing below its diagonal)
-        }
+        };
+        if (nb <= 64) factor(std::integral_constant<int, 4>{});
+        else factor(std::integral_constant<int, 8>{});
+        __syncthreads();
+        BPP_STAMP(4 + 4 * round_);
         // triangular solves in wavefront 0: lane l holds components l and l + 64; the pivot component reaches the
         // others through v_readlane (k is uniform: no trip through the LDS crossbar per step), the next column of L
         // is requested before the current one is used
@@ -543,10 +604,13 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
             if (lane + 64 < nb) u_s[bl[lane + 64]] = v1;
         }
         __syncthreads();
+        BPP_STAMP(5 + 4 * round_);
         {
             const double ku = matvec_row();
             if (mp == 0) w_s[mi] = mi < a ? ku - c_s[mi] : 0.0;
         }
+        BPP_STAMP(6 + 4 * round_);
+        ++round_;
         if (tid < kAmax) {
             const double um = wave_max_d(fabs(u_s[tid]));
             if (lane == 0) wred[wave] = um;
@@ -586,7 +650,16 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
     }
     if (tid < kAmax) yo[tid] = tid < a ? s_s[tid] * fmax(u_s[tid], 0.0) : 0.0;
     if (tid == 0) info[t] = done_s == 1 ? piv_s : -piv_s;
+    BPP_STAMP(31);
+#ifdef REVS_BPP_STAMPS
+    if (tid == 0) { g_bpp_stamps[blockIdx.x][30] = (double)a; g_bpp_stamps[blockIdx.x][29] = (double)piv_s; }
+#endif
 }
+#ifdef REVS_BPP_STAMPS
+extern "C" int revs_tuning_bpp_stamps(double *out_host) {
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_bpp_stamps), sizeof(double) * 256 * 32) == hipSuccess ? 0 : -1;
+}
+#endif
 
 // The LCP of at most 8 candidates by one thread, everything in registers (loops sized by the
 // template parameter): same regularisation, tolerances and pivoting rule as op_dual_bpp_kernel.
