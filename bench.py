@@ -164,6 +164,70 @@ def cpu_baseline(w, state, budget_s=20.0):
                       f"sums and the dense {w.M}x{w.M}x{w.T} voltage product ({t_op * 1e3:.0f} ms, numpy BLAS)"}
 
 
+# ---- the reference's own case: lpsolver.solve_ADMM's 15 iterations on the 121144 feeder ----------------
+def feeder_121144(torch, with_cpu):
+    """The reference's runs on its own feeder (tests/golden/revs_121144.npz: the network, base loads and tariff
+    of /root/reference's input files), through the product's call-surface helpers (compute_Rmat, feeder_arrays,
+    pack_homes as lpsolver.solve_ADMM uses them): iter_max = 15, on/off chargers (lpsolver.py:92-98, 243) --
+    BASELINE config 0's feeder at the stored run's 90 % adoption in community 2 (T = 24) and config 3 (all
+    communities, 90 %, T = 96: hourly data held over four 15-minute slots).  Wall time of the 15 iterations on a
+    warm engine (second run: code objects loaded), operator work, and -- with_cpu -- the oracle's
+    solve_ADMM(util_method="dual") of the same problem timed beside it (CPU baseline of this case)."""
+    import networkx as nx
+    from revs_admm_amd.engine import AdmmEngine, pack_homes
+    from revs_admm_amd.lpsolver import compute_Rmat, feeder_arrays
+    z = np.load(os.path.join(ROOT, "tests", "golden", "revs_121144.npz"))
+    g = nx.Graph()
+    for nid, lab in zip(z["node_id"], z["node_label"]):
+        g.add_node(int(nid), label=lab.decode())
+    for u, v, r in zip(z["edge_u"], z["edge_v"], z["edge_r"]):
+        g.add_edge(int(z["node_id"][u]), int(z["node_id"][v]), r=float(r))
+    res = [n for n in g if g.nodes[n]["label"] == "H"]
+    nonsub = [n for n in g.nodes if g.nodes[n]["label"] != "S"]
+    pos = {n: i for i, n in enumerate(nonsub)}
+    R = compute_Rmat(g)
+    ri = [pos[n] for n in res]
+    R_res = R[np.ix_(ri, ri)]
+    feeder = feeder_arrays(g, res)
+    row = {int(h): i for i, h in enumerate(z["res_id"])}
+    load_res = np.stack([z["LOAD"][row[h]] for h in res])
+    out = {}
+    for tag, T, ev_ids in (("com2_90pct_T24", 24, z["dis_a90_r4800_ev_homes"]), ("all_communities_90pct_T96", 96, None)):
+        rep = T // 24
+        if ev_ids is None:
+            np.random.seed(1234)                      # revs_fixture.py:174-177
+            ev_ids = np.random.choice(z["res_id"], int(0.9 * len(z["res_id"])), replace=False)
+        evset = set(int(h) for h in ev_ids)
+        ev = np.array([h in evset for h in res])
+        load = np.repeat(load_res, rep, axis=1)
+        cost = np.repeat(z["tariff_shift6"], rep)
+        homes = pack_homes(ev, 4.8, 20.0, 0.2, 11 * rep, 23 * rep)           # (the reference's slot arithmetic unchanged)
+        e = AdmmEngine(cost, homes, load, np.arange(len(res)), R_res, kappa=5.0, vset=1.03, vlow=0.95, vhigh=1.05,
+                       mode="binary", feeder=feeder)
+        e.run(15)
+        e.reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e.run(15)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        row_out = {"ms_15_iterations": dt * 1e3, "home_solves_per_sec": len(res) * 15 / dt, "residences": len(res),
+                   "ev_residences": int(ev.sum()), "T": T, "operator_evaluations": int(sum(e.op_iters_hist)),
+                   "newton_iterations": [int(h[0]) for h in e.newton_hist],
+                   "rows_judged_by": "tree form" if e._tree_newton else "dense f64 product",
+                   "chained_iterations": int(e.chain_hist[0])}
+        if with_cpu:
+            from oracle import revs_oracle as ro
+            oh = ro.homes_from_records(load, homes)
+            t0 = time.perf_counter()
+            ro.solve_ADMM(oh, R_res, np.arange(len(res)), cost, 5.0, 15, 1.03, 0.95, 1.05, mode="binary", util_method="dual")
+            row_out["cpu_oracle_ms_15_iterations"] = (time.perf_counter() - t0) * 1e3
+        out[tag] = row_out
+        del e
+        torch.cuda.empty_cache()
+    return out
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start N fresh ranks of this script (this
     process has made no GPU call and makes none), relay rank 0's stdout, exit with the first
@@ -500,6 +564,8 @@ def main():
         # BASELINE config 4's per-GPU shape
         if (args.homes, args.T) == (100_000, 24):
             extras["value_125k_T96"] = regime(125_000, 96, "pdhg", args.stress, 40, 100)
+        # the reference's own feeder and iteration count
+        extras["value_feeder_121144"] = feeder_121144(torch, not args.no_cpu_baseline)
 
     if rank == 0:
         warm = (None if eng.pdhg_dual is None else

@@ -977,6 +977,25 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
         if iteration is not None:
             self.iteration = int(iteration)
 
+    def reset(self):
+        """Back to iteration 0 of lpsolver.py:244-246 (P_est = P_sch = G = 0, no multipliers, cold operator):
+        the same engine -- buffers, plan, loaded code objects -- for another run of the same problem."""
+        z = np.zeros((self.n, self.T), np.float32)
+        self.set_state(z, z, z, iteration=0)
+        for y in self.yd:
+            y.zero_()
+        if self.pdhg_dual is not None:
+            self.pdhg_dual.zero_()
+        self._y_support = self._spec_ok = self._chain_few = False
+        self._sup = None
+        self._spec_wait, self._spec_back = 0, 1
+        self.op_cold = self._fast_cold = True
+        self._burst = max(1, int(self.op.stream_burst))
+        self.max_diff = {}
+        for h in (self.op_iters_hist, self.op_path_hist, self.newton_hist, self.stream_calls):
+            h.clear()
+        self.spec_hist, self.chain_hist, self.model_calls, self.fold_steps = [0, 0], [0, 0], [0, 0], 0
+
     def get_state(self):
         """(P_est[k], P_sch[k], G[k]) in the caller's home order."""
         return self._unsort(self.P_est), self._unsort(self.P_sch), self._unsort(self.G)

@@ -1,0 +1,19 @@
+"""Digest of a bench.py JSON line: python tools/show_bench.py file.json"""
+import json
+import sys
+
+j = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("ms_per_step", round(j["ms_per_step"], 5), "value", f"{j['value']:.4g}", "bursts", [round(x, 5) for x in j.get("bursts_ms_per_step", [])])
+for k in ("value_binding", "value_binary", "value_125k_T96"):
+    if j.get(k):
+        print(k, round(j[k]["ms_per_step"], 5), [round(x, 5) for x in j[k]["blocks_ms_per_step"]])
+if j.get("value_feeder_121144"):
+    for tag, r in j["value_feeder_121144"].items():
+        print(tag, {k: (round(v, 2) if isinstance(v, float) else v) for k, v in r.items() if k != "newton_iterations"})
+print("roofline", {k: j["roofline"][k] for k in ("achieved", "frac", "avg_launch_ms")})
+if j.get("roofline_valu"):
+    print("valu", {k: j["roofline_valu"][k] for k in ("frac", "valu_instructions_per_wavefront_and_iteration")})
+if j.get("cpu_baseline"):
+    print("cpu", round(j["cpu_baseline"]["value"]), j["cpu_baseline"]["cores"])
+t = j["breakdown"]["transient"]
+print("transient", round(t["ms_total"], 2), round(t["ms_per_step_mean"], 3), round(t["ms_per_step_max"], 2), "iters_to_eps", j["breakdown"]["admm_iters_to_eps"])
