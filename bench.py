@@ -486,17 +486,23 @@ def main():
     pdhg_it = float((st >> 8)[(st >> 8) > 0].mean()) if args.mode == "pdhg" and ((st >> 8) > 0).any() else None
 
     # the same regime with the rows judged by the dense f64 product on the matrix cores (its own
-    # launch before every sweep, verdict read by the host): what the tree form replaces
-    dense = None
-    if eng._tree is not None and eng._plan is not None and world == 1:
+    # launch before every sweep, verdict read by the host): what the tree form replaces.  (A short stretch: the
+    # run reaches the eps-residual near iteration 490 and the voltage boundary a few hundred iterations later.)
+    def dense_comparison():
+        if not (eng._tree is not None and eng._plan is not None and world == 1):
+            return None
         import ctypes as C
+        k = min(args.steps, 50)
         tree, eng._tree = eng._tree, None                    # (the engine and its native plan both drop the tree)
         eng.lib.revs_plan_set_tree(eng._plan, None)
         eng.run_steps(args.warmup)
-        d_dt, _ = timed_steps(eng, args.steps)
+        d_dt, _ = timed_steps(eng, k)
         eng._tree = tree
         eng.lib.revs_plan_set_tree(eng._plan, C.byref(tree))
-        dense = {"ms_per_step": d_dt / args.steps * 1e3, "value": n_total * args.steps / d_dt}
+        return {"ms_per_step": d_dt / k * 1e3, "value": n_total * k / d_dt, "steps": k}
+
+    dense_first = eng.iteration + args.warmup + min(args.steps, 50) < 440       # (else: behind the convergence count)
+    dense = dense_comparison() if dense_first else None
 
     # the f64 matrix-core product of the operator's Newton path: R p (M x M x T)
     reps = 200
@@ -528,6 +534,8 @@ def main():
             if iters_to_eps is None:
                 eng.run_steps(64)
         rp, rd, dmax, conv = eng.residuals(args.eps)
+    if not dense_first:
+        dense = dense_comparison()
     state = eng.get_state() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
 
     # ---- the other regimes, first-class (one GPU) ----
@@ -675,7 +683,7 @@ def main():
                 "on_path": "since round 3 only for feeders given as a matrix, and in the Newton evaluations of "
                            "feeders beyond the tree form's 2048 nodes: the steady state, the Newton evaluations and "
                            "the binding chain judge their rows by the tree form of R p",
-                "mfma_counters": "profiles/r03_pmc_mfma.csv (131 072 v_mfma_f64_16x16x4 per launch, matrix pipes "
+                "mfma_counters": "profiles/r03_pmc_mfma.csv (unchanged kernel; 131 072 v_mfma_f64_16x16x4 per launch, matrix pipes "
                                  "busy 8 192 of ~32 000 cycles per SIMD: 25 %; x 24/32 useful tile columns)",
             },
             # the same timed region counted on the residences that have a QP to solve
@@ -739,7 +747,9 @@ def main():
         rb = None
         try:
             import csv
-            rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r03_binding_kernel_stats.csv"))))
+            import glob
+            bfile = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_binding_kernel_stats.csv")))[-1]
+            rows = list(csv.DictReader(open(bfile)))
             sw = next(r for r in rows if "agent_step_kernel" in r["Name"] and r["Name"].rstrip().endswith("true>(revs::AgentArgs)")
                       and ", false, true>" in r["Name"])
             kv = next(r for r in rows if "op_chain_kv_kernel" in r["Name"])
@@ -754,11 +764,35 @@ def main():
                                                     "iteration's rows / selection / model / step / shifts)",
                                           "avg_launch_ms": t_kv * 1e3, "bound": "latency (one workgroup per slot)"},
                       "ms_per_step_live": extras["value_binding"]["ms_per_step"],
-                      "source": "profiles/r03_binding_kernel_stats.csv (rocprofv3 --kernel-trace --stats of "
+                      "source": f"profiles/{os.path.basename(bfile)} (rocprofv3 --kernel-trace --stats of "
                                 "tools/regime_run.py --regime binding); ms_per_step_live from this run"}
         except Exception:
             rb = None
         out["roofline_binding"] = rb
+        # BASELINE config 4's per-GPU shape: what bounds the T = 96 sweep (counters from the committed --pmc passes of
+        # tools/regime_run.py at 125 000 x 96, duration live from this run's value_125k_T96)
+        r96 = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "t96_traffic.json")))
+            c = tj["sq_counters_per_launch"]
+            if "value_125k_T96" in extras and tj["homes"] == 125_000 and tj["T"] == 96:
+                it, us = tj["iterations_per_launch"], tj["avg_launch_us_profiled"]
+                peak = 1024 * 2.4e9 / 4
+                r96 = {"kernel": tj["kernel"] + f" ({it} ADMM iterations of 125 000 residences x 96 slots per launch)",
+                       "bound": "valu-issue", "achieved": c["SQ_INSTS_VALU"] / (us * 1e-6) / 1e9, "peak": peak / 1e9,
+                       "unit": "G wave64 VALU instructions/s", "frac": c["SQ_INSTS_VALU"] / (us * 1e-6) / peak,
+                       "valu_busy_share_of_launch": c["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (us * 1e-6 * 2.4e9),
+                       "valu_instructions_per_wavefront_and_iteration": c["SQ_INSTS_VALU"] / c["SQ_WAVES"] / it,
+                       "salu_instructions_per_wavefront_and_iteration": c["SQ_INSTS_SALU"] / c["SQ_WAVES"] / it,
+                       "hbm": {"bound": "hbm", "achieved": tj["algorithmic_bytes_per_launch"] / (us * 1e-6) / 1e9,
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": tj["algorithmic_bytes_per_launch"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                               "traffic": tj["hbm_bytes_per_launch"], "bytes_per_launch": tj["algorithmic_bytes_per_launch"]},
+                       "avg_launch_ms_profiled": us * 1e-3, "ms_per_step_live": extras["value_125k_T96"]["ms_per_step"],
+                       "source": tj["source"]}
+        except Exception:
+            r96 = None
+        out["roofline_125k_T96"] = r96
         out.update(extras)
         out["cpu_baseline"] = cpu_baseline(w, state) if state is not None else None
         print(json.dumps(out), flush=True)

@@ -1411,9 +1411,11 @@ extern "C" int revs_plan_stream_run_blocks(revs_plan_t *plan, int32_t max_steps,
                          "revs_plan_stream_run_blocks: the four sets must be distinct buffers");
         REVS_REQUIRE(st->p_est_next != st->p_est[i], "revs_plan_stream_run_blocks: p_est_next must not be in a set");
     }
-    REVS_REQUIRE(st->p0 && st->p0_out && st->p0 != st->p0_out && st->p_est_next &&
-                 (!warm || st->pdhg_dual[0] == d.pdhg_dual),
-                 "revs_plan_stream_run_blocks: p0 / p0_out / p_est_next missing, or set 0 does not hold the plan's multipliers");
+    REVS_REQUIRE(st->p0 && st->p0_out && st->p0 != st->p0_out && st->p_est_next,
+                 "revs_plan_stream_run_blocks: p0 / p0_out / p_est_next missing (or p0 == p0_out)");
+    REVS_REQUIRE(!warm || st->pdhg_dual[0] == d.pdhg_dual,
+                 "revs_plan_stream_run_blocks: set 0 does not hold the plan's carried multipliers (%p, the plan's: %p)",
+                 (void *)st->pdhg_dual[0], (void *)d.pdhg_dual);
     hipStream_t s = (hipStream_t)stream;
     *kept_steps = 0;
     *rmax_last = 0.0;

@@ -176,7 +176,8 @@ class SteadyStateMixin:
         if self._pn0 is None:
             self._pn0 = self.pnq[0]
             self._pn_ptr = {id(self._pn0): _dp(self._pn0), id(self.p_alt): _dp(self.p_alt)}
-        p0_out = self.p_alt if p0 is self._pn0 else self._pn0      # (the sums handed over for the next call)
+        # (the sums handed over for the next call; by address: self.pnq[0] is a fresh view object wherever it is taken)
+        p0_out = self.p_alt if _dp(p0) == _dp(self._pn0) else self._pn0
         pp = self._pn_ptr
         st.p0 = pp[id(p0)] if id(p0) in pp else _dp(p0)
         st.p0_out = pp[id(p0_out)]

@@ -2,7 +2,7 @@
 # Round profiles on the GPU box (run through gpurun from the repo root): bench lines, rocprofv3 kernel
 # stats, PMC passes (FETCH / WRITE / SQ in separate runs, as MI355X_MICROARCH.md prescribes) and the
 # binding / binary regimes.  Writes under gpurun_out/prof_$TAG; copy the summaries into profiles/.
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
@@ -20,6 +20,17 @@ for reg in binding binary; do
   cp $(find $O/reg_$reg -name "*kernel_stats.csv" | head -1) $O/${reg}_kernel_stats.csv
   rm -rf $O/reg_$reg
 done
+# BASELINE config 4's per-GPU shape: SQ counters and HBM traffic of the T = 96 sweep (roofline_125k_T96)
+for pass in fetch:FETCH_SIZE write:WRITE_SIZE "sq:SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY"; do
+  name=${pass%%:*}; ctr=${pass#*:}
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_t96/$name -o $name -- python3 $R/tools/regime_run.py --regime steady --homes 125000 --T 96 --steps 128 --spin 48 > $O/pmc_t96_$name.log 2>&1
+  python3 $R/tools/pmc_kernels.py $O/pmc_t96/$name agent_step > $O/pmc_t96_$name.txt 2>&1
+done
+find $O/pmc_t96 -type f ! -name "*summary.csv" -delete
+# stage stamps of the folded chain's operator launch (tuning build, if present)
+if [ -f $R/tune/librevs_stamps.so ]; then
+  for reg in binding binary; do REVS_LIB=$R/tune/librevs_stamps.so python3 $R/tools/regime_run.py --regime $reg --steps 100 2>&1 | grep "kv stamps" > $O/kv_stamps_$reg.txt; done
+fi
 rm -rf $O/kt
 # keep only the counter csvs of the pmc passes (the traces are large)
 find $O/pmc -type f ! -name "*counter_collection.csv" -delete
