@@ -323,6 +323,8 @@ def main():
                          "timed region starts at steady GPU clocks (0: none)")
     ap.add_argument("--eps", type=float, default=1e-4, help="ADMM residual target")
     ap.add_argument("--pdhg-check", type=int, default=None, help="PDHG: convergence test period")
+    ap.add_argument("--lanes", type=int, default=None,
+                    help="lanes of a wavefront per residence (revs_pdhg_t::lanes: 16 or 32 at T <= 32; default: the engine's choice)")
     ap.add_argument("--op-kadd", type=int, default=None,
                     help="operator: violated rows admitted to a slot's model per Newton iteration")
     ap.add_argument("--stream-block", type=int, default=None,
@@ -403,10 +405,16 @@ def main():
         if args.stream_inner is not None:
             opts.stream_inner = args.stream_inner
         opts.stream_overlap = not args.no_stream_overlap
+        # few residences per GPU (BASELINE config 2 over eight GPUs: 12 500 each): 16 lanes x 2 slots per residence
+        # (revs_pdhg_t::lanes; measured at 12 500 / 25 000 / 50 000 x 24: 0.0044 / 0.0052 / 0.0069 ms per iteration
+        # against 0.0049 / 0.0040 / 0.0054 with the default 8 x 3 -- the per-iteration chain of a lone wavefront is
+        # its cross-lane reductions, not its per-slot work, so the wide shapes pay only below ~16 000 residences)
+        lanes = args.lanes if args.lanes is not None else (16 if (T <= 32 and hi - lo <= 16000) else 0)
+        build.lanes = lanes
         eng = AdmmEngine(w.cost, w.homes[lo:hi], w.load[lo:hi], w.node_of[lo:hi], w.Rn, kappa=w.kappa,
                          vset=w.vset, vlow=w.vlow, vhigh=w.vhigh, mode=mode, device=dev, group=group,
                          node_counts=counts, op=opts, feeder=w.feeder,
-                         pdhg=({"check": args.pdhg_check} if args.pdhg_check else None))
+                         pdhg=({k: v for k, v in (("check", args.pdhg_check), ("lanes", lanes or None)) if v is not None} or None))
         return w, eng, (lo, hi)
 
     def timed_steps(eng, k):
@@ -629,6 +637,7 @@ def main():
                             "value_binding / value_binary / value_125k_T96",
                 "homes_per_gpu": n_local, "homes_total": n_total, "T": args.T,
                 "nodes": args.nodes, "home_solver": args.mode, "kappa": w.kappa,
+                "lanes_per_residence": int(eng.pdhg.lanes) or "default (8 x 3 slots at T = 24)",
                 "adoption": args.adoption, "ev_residences_total": int((w.homes["ev"] != 0).sum()),
                 "operator_dtype": "f64", "parallelism": f"homes sharded x{world}, nodes replicated, "
                                                         "node sums all-reduced"

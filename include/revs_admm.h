@@ -34,7 +34,8 @@ extern "C" {
 /* consecutive ADMM iterations one launch of the residence sweep can carry in registers
  * (streaming steady state, multipliers zero; revs_plan_set_stream_inner); a launch's LDS holds one
  * set of node-sum accumulators per iteration, so the library uses at most
- * revs_agent_max_inner(T) <= REVS_AGENT_MAX_INNER of them: 32 up to T = 24, 16 up to 96, 8 up to 192, 4 beyond */
+ * revs_agent_max_inner(T, lanes) <= REVS_AGENT_MAX_INNER of them: 32 up to T = 24 (16 with the wide lane
+ * shapes), 16 up to 96, 8 up to 192, 4 beyond */
 #define REVS_AGENT_MAX_INNER 32
 /* the sweep leaves the largest diff of an iteration (the convergence measure, lpsolver.py:284) as
  * REVS_DMAX_SLOTS partial maxima, workgroup b into slot b % REVS_DMAX_SLOTS */
@@ -94,6 +95,12 @@ typedef struct {
                              schedule in closed form x(mu) = clip(-b - delta mu, 0, w) -- the exact
                              optimum of the piece PDHG identified (the KKT conditions of
                              lpsolver.py:83-128's relaxation to float rounding) */
+    int32_t lanes;        /* lanes of a wavefront that share one residence's T slots (every mode, not only PDHG):
+                             0 (default) = by T alone (8 lanes x 3 slots at T = 24: the fewest instructions per
+                             residence); 16 or 32 with T <= 32 = 2 / 1 slot(s) per lane -- a third of the per-slot work
+                             in every wavefront's instruction chain and 2 - 4 x the wavefronts: the shape for a GPU
+                             that holds few residences (BASELINE config 2 over eight GPUs: 12 500 each, 391 workgroups
+                             of the default shape on 256 compute units).  Other values, or T > 32: as 0. */
 } revs_pdhg_t;
 
 const char *revs_version(void);
@@ -593,7 +600,7 @@ int revs_newton_chain_accept(int32_t T, const double *s0, const double *s1, doub
  *   dmax_out                   NULL, or (same stride) REVS_DMAX_SLOTS doubles per iteration: atomic max
  *                              (on the bit pattern of a non-negative double) of the residences' diff
  *                              of iteration g + i; the maximum over the slots is max_h diff[h] */
-int32_t revs_agent_max_inner(int32_t T);
+int32_t revs_agent_max_inner(int32_t T, int32_t lanes);       /* lanes: revs_pdhg_t::lanes */
 int revs_agent_step_multi(int64_t n_homes, int32_t T, const float *cost, const revs_home_t *homes,
                           const float *load, const float *p_est, const float *p_sch, const float *gamma,
                           float *p_est_out, float *p_sch_out, float *gamma_out, float *p_est_next,

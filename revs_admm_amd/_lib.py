@@ -28,7 +28,7 @@ MODES = {"binary": MODE_BINARY, "relaxed": MODE_RELAXED_PDHG, "pdhg": MODE_RELAX
 class PDHG(C.Structure):
     _fields_ = [("max_iter", C.c_int32), ("check", C.c_int32), ("tol", C.c_float),
                 ("tau_scale", C.c_float), ("sigma_scale", C.c_float), ("full_rows", C.c_int32),
-                ("polish", C.c_int32)]
+                ("polish", C.c_int32), ("lanes", C.c_int32)]
 
 
 class PlanDesc(C.Structure):
@@ -154,7 +154,7 @@ SIGNATURES = {
                                          _p, _p, _p, _f32, _i32, C.POINTER(PDHG), _i32, _p, _p,
                                          _f64, _f64, _i32, _p, _p, _p, _p, _p, _p, _f64, _p, _p, _p,
                                          _i32, _p]),
-    "revs_agent_max_inner": (_i32, [_i32]),
+    "revs_agent_max_inner": (C.c_int32, [C.c_int32, C.c_int32]),
     "revs_agent_step_multi": (C.c_int, [_i64, _i32, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _p,
                                         _p, _p, _f32, _i32, C.POINTER(PDHG), _p, _p, _i64, _p, _i32, _p]),
     "revs_op_dual_product_rows": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _f64, _f64, _i32, _p, _p, _p,

@@ -1014,7 +1014,10 @@ __global__ __launch_bounds__(kBlock) void residence_kernel(
 
 // ---- dispatch ---------------------------------------------------------------
 struct Shape { int lpa, spl; };
-static Shape pick_shape(int T) {
+static Shape pick_shape(int T, int lanes = 0) {
+    // revs_pdhg_t::lanes: the wide shapes for a GPU that holds few residences
+    if (T <= 32 && lanes == 32) return {32, 1};
+    if (T <= 32 && lanes == 16) return {16, 2};
     // REVS_AGENT_SHAPE=LPAxSPL overrides the mapping for T <= 24 and 64 < T <= 96 (tuning
     // hook; read once: this runs twice per launch on the host's critical path)
     static const Shape env = [] {
@@ -1096,6 +1099,8 @@ static void launch_agent(const AgentArgs &a, int mode, dim3 grid, hipStream_t s)
 #define REVS_FOR_SHAPE(sh, CALL)                                   \
     do {                                                           \
         if (sh.lpa == 8 && sh.spl == 1) { CALL(8, 1); }            \
+        else if (sh.lpa == 32 && sh.spl == 1) { CALL(32, 1); }     \
+        else if (sh.lpa == 16 && sh.spl == 2) { CALL(16, 2); }     \
         else if (sh.lpa == 8 && sh.spl == 2) { CALL(8, 2); }       \
         else if (sh.lpa == 8 && sh.spl == 3) { CALL(8, 3); }       \
         else if (sh.lpa == 4 && sh.spl == 6) { CALL(4, 6); }       \
@@ -1122,11 +1127,12 @@ extern "C" void revs_pdhg_defaults(revs_pdhg_t *o) {
     o->sigma_scale = 0.f;
     o->full_rows = 0;
     o->polish = 1;
+    o->lanes = 0;
 }
 
-static int64_t agent_num_blocks(int64_t n_homes, int32_t T) {
+static int64_t agent_num_blocks(int64_t n_homes, int32_t T, int lanes) {
     if (n_homes <= 0 || T <= 0 || T > REVS_MAX_T) return 0;
-    const Shape sh = pick_shape(T);
+    const Shape sh = pick_shape(T, lanes);
     const int64_t per = kBlock / sh.lpa;
     return (n_homes + per - 1) / per;
 }
@@ -1182,8 +1188,9 @@ static int agent_step_impl(int64_t n_homes, int32_t T, const float *cost,
     if (sx && !sx->verdict) {         // judged by blocks (stream_block_verdict): silencing only
         REVS_REQUIRE(!sel, "revs_agent_step: bad streaming argument");      // (ctl == NULL: never silenced)
         a.ctl = sx->ctl; a.seq = sx->seq; a.base_seq = sx->base_seq; a.flags = sx->flags;
-        REVS_REQUIRE(sx->kin >= 1 && sx->kin <= revs_agent_max_inner(T) && sx->slice_stride >= 0 && sx->diff_stride >= 0,
-                     "revs_agent_step: kin=%d outside 1..%d (T = %d)", sx->kin, revs_agent_max_inner(T), T);
+        const int lanes_ = pdhg_host ? pdhg_host->lanes : 0;
+        REVS_REQUIRE(sx->kin >= 1 && sx->kin <= revs_agent_max_inner(T, lanes_) && sx->slice_stride >= 0 && sx->diff_stride >= 0,
+                     "revs_agent_step: kin=%d outside 1..%d (T = %d)", sx->kin, revs_agent_max_inner(T, lanes_), T);
         REVS_REQUIRE(sx->kin == 1 || (!p_est_new && p_next && sx->pe_out && !s_out && !c_out &&
                                       sx->slice_stride >= (int64_t)0),
                      "revs_agent_step: several iterations per launch need the recomputed estimate, node sums "
@@ -1204,8 +1211,8 @@ static int agent_step_impl(int64_t n_homes, int32_t T, const float *cost,
     if (pdhg_host) a.pd = *pdhg_host; else revs_pdhg_defaults(&a.pd);
     REVS_REQUIRE(a.pd.max_iter > 0 && a.pd.check > 0 && a.pd.tau_scale >= 0 && a.pd.sigma_scale >= 0,
                  "revs_agent_step: bad PDHG parameters");
-    const Shape sh = pick_shape(T);
-    const int64_t nblk = agent_num_blocks(n_homes, T);
+    const Shape sh = pick_shape(T, a.pd.lanes);
+    const int64_t nblk = agent_num_blocks(n_homes, T, a.pd.lanes);
     REVS_REQUIRE(nblk < (1ll << 31), "revs_agent_step: too many homes for one launch");
     const dim3 grid((unsigned)(nblk + a.nsel));
     hipStream_t s = (hipStream_t)stream;
@@ -1454,9 +1461,9 @@ extern "C" int revs_agent_step_out(int64_t n_homes, int32_t T, const float *cost
                            kappa, mode, pdhg_host, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
-extern "C" int32_t revs_agent_max_inner(int32_t T) {
+extern "C" int32_t revs_agent_max_inner(int32_t T, int32_t lanes) {
     if (T <= 0 || T > REVS_MAX_T) return 0;
-    const Shape sh = pick_shape(T);
+    const Shape sh = pick_shape(T, lanes);
     return shape_max_inner(sh.lpa * sh.spl);
 }
 
@@ -1468,8 +1475,9 @@ extern "C" int revs_agent_step_multi(int64_t n_homes, int32_t T, const float *co
                                      float kappa, int32_t mode, const revs_pdhg_t *pdhg_host,
                                      const int32_t *node_of, double *p_next, int64_t slice_stride,
                                      double *dmax_out, int32_t kin, void *stream) {
-    REVS_REQUIRE(p_est_out && node_of && p_next && kin >= 1 && kin <= revs_agent_max_inner(T),
-                 "revs_agent_step_multi: bad argument (kin = %d, at most %d at T = %d)", kin, revs_agent_max_inner(T), T);
+    const int lanes_ = pdhg_host ? pdhg_host->lanes : 0;
+    REVS_REQUIRE(p_est_out && node_of && p_next && kin >= 1 && kin <= revs_agent_max_inner(T, lanes_),
+                 "revs_agent_step_multi: bad argument (kin = %d, at most %d at T = %d)", kin, revs_agent_max_inner(T, lanes_), T);
     REVS_REQUIRE(p_est_out != p_est && p_sch_out != p_sch && gamma_out != gamma,
                  "revs_agent_step_multi: the state is not updated in place");
     StreamExtra sx{};

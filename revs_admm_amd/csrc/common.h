@@ -148,24 +148,38 @@ __device__ __forceinline__ int wave_incl_scan_i(int v) {
 }
 
 // Sum / max over an aligned group of LPA lanes, result in every lane of the group.
+// (the steps across rows of 16 lanes: v_permlane16_swap / v_permlane32_swap (gfx950) hand lanes i and i ^ 16 (i ^ 32) the
+// pair {own, partner} -- one VALU instruction where __shfl_xor is a trip through the LDS crossbar)
+__device__ __forceinline__ void swap_pair_f(float v, bool swap32, float &a0, float &a1) {
+    const unsigned b = __float_as_uint(v);
+    if (swap32) {
+        const auto r = __builtin_amdgcn_permlane32_swap(b, b, false, false);
+        a0 = __uint_as_float(r[0]); a1 = __uint_as_float(r[1]);
+    } else {
+        const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);
+        a0 = __uint_as_float(r[0]); a1 = __uint_as_float(r[1]);
+    }
+}
 template <int LPA>
 __device__ __forceinline__ float group_sum(float v) {
+    float a0, a1;
     if constexpr (LPA >= 2) v += dpp_f<0xB1>(v);            // quad_perm [1,0,3,2]
     if constexpr (LPA >= 4) v += dpp_f<0x4E>(v);            // quad_perm [2,3,0,1]
     if constexpr (LPA >= 8) v += dpp_f<0x141>(v);           // row_half_mirror
     if constexpr (LPA >= 16) v += dpp_f<0x140>(v);          // row_mirror
-    if constexpr (LPA >= 32) v += __shfl_xor(v, 16, 64);
-    if constexpr (LPA >= 64) v += __shfl_xor(v, 32, 64);
+    if constexpr (LPA >= 32) { swap_pair_f(v, false, a0, a1); v = a0 + a1; }
+    if constexpr (LPA >= 64) { swap_pair_f(v, true, a0, a1); v = a0 + a1; }
     return v;
 }
 template <int LPA>
 __device__ __forceinline__ float group_max(float v) {
+    float a0, a1;
     if constexpr (LPA >= 2) v = fmaxf(v, dpp_f<0xB1>(v));
     if constexpr (LPA >= 4) v = fmaxf(v, dpp_f<0x4E>(v));
     if constexpr (LPA >= 8) v = fmaxf(v, dpp_f<0x141>(v));
     if constexpr (LPA >= 16) v = fmaxf(v, dpp_f<0x140>(v));
-    if constexpr (LPA >= 32) v = fmaxf(v, __shfl_xor(v, 16, 64));
-    if constexpr (LPA >= 64) v = fmaxf(v, __shfl_xor(v, 32, 64));
+    if constexpr (LPA >= 32) { swap_pair_f(v, false, a0, a1); v = fmaxf(a0, a1); }
+    if constexpr (LPA >= 64) { swap_pair_f(v, true, a0, a1); v = fmaxf(a0, a1); }
     return v;
 }
 
@@ -178,8 +192,8 @@ __device__ __forceinline__ float group_max_nonneg(float v) {
     if constexpr (LPA >= 4) u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x4E, 0xf, 0xf, true));
     if constexpr (LPA >= 8) u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x141, 0xf, 0xf, true));
     if constexpr (LPA >= 16) u = max(u, (unsigned)__builtin_amdgcn_update_dpp(0, (int)u, 0x140, 0xf, 0xf, true));
-    if constexpr (LPA >= 32) u = max(u, (unsigned)__shfl_xor((int)u, 16, 64));
-    if constexpr (LPA >= 64) u = max(u, (unsigned)__shfl_xor((int)u, 32, 64));
+    if constexpr (LPA >= 32) { const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false); u = max((unsigned)r[0], (unsigned)r[1]); }
+    if constexpr (LPA >= 64) { const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false); u = max((unsigned)r[0], (unsigned)r[1]); }
     return __uint_as_float(u);
 }
 // max of a non-negative float over the whole wavefront, in EVERY lane, when the LPA lanes of each aligned group

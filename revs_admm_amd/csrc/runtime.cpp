@@ -1432,7 +1432,7 @@ extern "C" int revs_plan_stream_run_blocks(revs_plan_t *plan, int32_t max_steps,
     const unsigned int seq0 = plan->stream_seq + 1;
     const int64_t mt = (int64_t)d.m * d.T, nt = d.n_homes * (int64_t)d.T;
     (void)nt;
-    const int B = plan->block, K = std::min(plan->inner, revs_agent_max_inner(d.T));
+    const int B = plan->block, K = std::min(plan->inner, revs_agent_max_inner(d.T, d.pdhg.lanes));
     const int nranks = plan->comm ? plan->comm->nranks : 1, rank = plan->comm ? plan->comm->rank : 0;
     const int ntail = REVS_DMAX_SLOTS * nranks;
     const int64_t stride = mt + ntail;                   // doubles per ring slice: node sums, then every rank's partial maxima

@@ -479,7 +479,7 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
             self._block = min(int(self.op.stream_block), _lib.STREAM_BLOCK_MAX)
             check(self.lib.revs_plan_set_stream_block(self._plan, self._block, int(self.op.stream_overlap)),
                   "revs_plan_set_stream_block")
-            self._inner = max(1, min(int(self.op.stream_inner), int(self.lib.revs_agent_max_inner(T))))
+            self._inner = max(1, min(int(self.op.stream_inner), int(self.lib.revs_agent_max_inner(T, int(self.pdhg.lanes)))))
             check(self.lib.revs_plan_set_stream_inner(self._plan, self._inner), "revs_plan_set_stream_inner")
             self._sets_st = _lib.StreamSets()
             self._sets_by, self._sets_sig, self._pn_ptr = {}, None, {}

@@ -261,3 +261,53 @@ def test_edge_parameters(gpu_lib, mode):
         assert (r["S"][~oh.window()] == 0).all()
         assert (r["S"][~ok] == 0).all()                      # flagged homes get no schedule
         np.testing.assert_allclose(r["C"][ok][:, 0], np.where(oh.ev, oh.initial, 0)[ok], atol=1e-6)
+
+
+@pytest.mark.parametrize("lanes,T", [(16, 24), (32, 24), (16, 32), (32, 17)])
+@pytest.mark.parametrize("mode", ["pdhg", "relaxed_exact", "binary"])
+def test_wide_lane_shapes_match_oracle(gpu_lib, lanes, T, mode):
+    """revs_pdhg_t::lanes -- 16 lanes x 2 slots / 32 lanes x 1 slot per residence at T <= 32 (the shapes for a GPU
+    that holds few residences: BASELINE config 2's 12 500 per GPU) -- against the oracle at the default shape's
+    tolerances: continuous schedules within 5e-5 kW, on/off schedules identical up to equal-cost ties, the dual
+    update and diff of lpsolver.py:280-284; and the streaming loop runs on them (kin iterations per launch)."""
+    from oracle import revs_oracle as ro
+    n = 1501
+    w, oh = _prep(n, T, seed=300 + T + lanes, binary_feasible=(mode == "binary"))
+    pe_old, pe_new, ps, gm = _state(w, T + lanes)
+    r = _run_agent(gpu_lib, w, pe_old, pe_new, ps, gm, mode, dict(lanes=lanes))
+    r0 = _run_agent(gpu_lib, w, pe_old, pe_new, ps, gm, mode)
+    if mode == "binary":
+        p, s, g, st = ro.home_solve_binary(w.cost, oh, pe_old, ps, gm, w.kappa)
+        np.testing.assert_array_equal(r["S"], r0["S"])          # the ranking does not depend on the lane shape
+        same = np.isclose(r["S"], p, atol=1e-6).all(axis=1)
+        assert same.mean() > 0.995
+    else:
+        p, s, g, st = ro.home_solve_relaxed(w.cost, oh, pe_old, ps, gm, w.kappa)
+        assert np.abs(r["S"] - p).max() < 5e-5 * max(1.0, w.homes["rating"].max())
+        chk = pe_new - g
+        np.testing.assert_allclose(r["G"], gm + 0.5 * w.kappa * chk, atol=2e-3, rtol=1e-5)
+        np.testing.assert_allclose(r["diff"], np.linalg.norm(chk, axis=1) / T, atol=1e-4, rtol=1e-4)
+    assert gpu_lib.revs_agent_max_inner(T, lanes) == 16 and gpu_lib.revs_agent_max_inner(24, 0) == 32
+
+
+@pytest.mark.parametrize("lanes", [16, 32])
+def test_wide_lane_shapes_in_the_engine(gpu_lib, lanes):
+    """The whole loop on the wide shapes: transient, streaming steady state (16 iterations per launch, verdicts by
+    blocks) and the binding regime, against the oracle's run (relaxed homes; 5e-4 kW as the long-horizon test)."""
+    from helpers import f32, oracle_homes
+    from oracle import revs_oracle as ro
+    from revs_admm_amd.engine import AdmmEngine
+    from revs_admm_amd.synthetic import make_workload
+    w = make_workload(600, 24, n_nodes=60, seed=11, binary_feasible=False, stress=1.02)
+    w.load, w.cost = f32(w.load), f32(w.cost)
+    e = AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, kappa=w.kappa, vset=w.vset, vlow=w.vlow, vhigh=w.vhigh,
+                   mode="pdhg", feeder=w.feeder, pdhg={"lanes": lanes})
+    e.run_steps(59)
+    e.step(write_sc=True)
+    assert e.spec_hist[0] > 20 and e._inner == 16
+    d_ref, P_ref, S_ref, C_ref = ro.solve_ADMM(oracle_homes(w), w.Rn, w.node_of, w.cost, w.kappa, 60, w.vset, w.vlow, w.vhigh,
+                                               mode="relaxed", util_method="dual")
+    P, S, Cs = e.result()
+    assert np.abs(S - S_ref).max() < 5e-4
+    d_last = e.diff.cpu().numpy()[e.inv_perm]
+    assert np.abs(d_last - d_ref[59]).max() < 1e-3 * max(1.0, d_ref.max())

@@ -78,7 +78,7 @@ def main():
         print(f"kin={kl}: state {ok} duals {ok_y} node sums {ok_ring} dmax {ok_dmax} diff {ok_diff} next {ok_pen} "
               f"| dmax {dm} vs diff.max {got[3].max(1).values.cpu().numpy()}")
     # timing: ring contents grow with the repetitions (only the timing matters there)
-    for kin in range(1, int(lib.revs_agent_max_inner(T)) + 1):
+    for kin in range(1, int(lib.revs_agent_max_inner(T, 0)) + 1):
         ms = run([kin], reps=a.reps, timed=True)[-1]
         print(f"kin={kin}: {ms * 1e3:.2f} us per launch, {ms * 1e3 / kin:.2f} us per ADMM iteration")
 
