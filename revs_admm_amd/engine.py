@@ -23,7 +23,7 @@ import torch
 
 from . import _lib
 from ._lib import HOME_DTYPE, MODES, PDHG, check, ptr
-from .feeder import feeder_tree, tree_voltage_host  # noqa: F401  (re-exported)
+from .feeder import feeder_tree, tree_from_R, tree_voltage_host  # noqa: F401  (re-exported)
 from .operator_admm import AdmmFormsMixin
 from .operator_newton import DualNewtonMixin
 from .steady_state import SteadyStateMixin
@@ -407,6 +407,14 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
         self._tree = None
         self._tree_newton = False        # Newton evaluations judge their rows by the tree form too
         self._comm = None
+        recovered = False
+        if (feeder is None and self.op.voltage in ("auto", "tree") and M <= 4096 and self.op.solver == "newton"
+                and _kernels is None):
+            # the caller holds only the matrix (lpsolver.py:184-189 hands the solver R, not the network): a radial
+            # feeder is recovered from it -- junctions without a residence become extra tree nodes -- and verified
+            # against Rn below like a feeder the caller passed; anything else stays on the dense product
+            feeder = tree_from_R(Rn)
+            recovered = feeder is not None
         if feeder is not None and self.op.voltage in ("auto", "tree"):
             par, er, cons = feeder
             tr = None
@@ -421,8 +429,11 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
                 ref = (Rn @ probe) * (counts > 0)[:, None]
                 got = tree_voltage_host(tr, probe)
                 if np.abs(got - ref).max() > 1e-9 * max(np.abs(ref).max(), 1e-300):
-                    raise ValueError("feeder: the tree does not reproduce Rn (R[i][j] = 2 x the "
-                                     "resistance shared by the substation->i and ->j paths)")
+                    if not recovered:
+                        raise ValueError("feeder: the tree does not reproduce Rn (R[i][j] = 2 x the "
+                                         "resistance shared by the substation->i and ->j paths)")
+                    tr = None                              # (Rn is not a radial feeder's matrix: dense product)
+            if tr is not None:
                 self._tree_host = tr
                 self._tree_dev = {k: up(tr[k].view(np.int64) if k == "pack" else tr[k]) for k in ("pack", "w")}
                 self._tree = _lib.Tree(tr["n"], ptr(self._tree_dev["pack"]), ptr(self._tree_dev["w"]))

@@ -71,3 +71,65 @@ def tree_voltage_host(tree, p):
     out = np.zeros_like(p)
     out[src[src >= 0]] = v[src >= 0]
     return out
+
+
+def tree_from_R(R, rtol=1e-12):
+    """Recover a radial feeder from its LinDistFlow matrix alone (reference lpsolver.py:17-26, 184-189: callers
+    of the solver hold R = 2 F D F^T restricted to the residence nodes, not the network).  For a radial feeder
+    R[i][j] / 2 is the resistance shared by the substation->i and substation->j paths, R[i][i] / 2 the whole
+    path to i: a tree metric.  Rows are placed by increasing depth; row i hangs below the point at depth
+    c = max_j R[i][j] / 2 (over the rows placed so far) of the path to the row j that attains it -- an existing
+    node where one sits at that depth, else a new junction node splitting an edge (junctions of the feeder that
+    carry no residence are not rows of R).  Returns (parent, edge_r, cons_of) for AdmmEngine(feeder=...) /
+    feeder_tree -- at most 2 M nodes -- or None when R is not such a matrix (asymmetric, negative, or a common
+    path longer than one of the two paths).  The caller verifies the tree against R (a product with random
+    injections) before trusting it."""
+    R = np.asarray(R, np.float64)
+    M = R.shape[0]
+    if R.ndim != 2 or R.shape[1] != M or M == 0:
+        return None
+    scale = float(np.abs(R).max())
+    if not np.isfinite(scale) or scale <= 0.0 or np.abs(R - R.T).max() > rtol * scale or R.min() < -rtol * scale:
+        return None
+    tol = rtol * scale
+    depth = 0.5 * np.diag(R)
+    order = np.argsort(depth, kind="stable")
+    parent, edge_r, cons_of, ndepth = [], [], [], []       # tree nodes (rows and junctions)
+    node_of_row = np.full(M, -1, np.int64)
+    placed = []
+    for i in order:
+        di = depth[i]
+        if not placed:
+            c, j = 0.0, -1
+        else:
+            common = 0.5 * R[i, placed]
+            k = int(np.argmax(common))
+            c, j = float(common[k]), int(placed[k])
+            if c > min(di, depth[j]) + tol:
+                return None                                # a common path longer than a whole path: no tree
+        if c <= tol:
+            par = -1                                       # shares nothing with the others: its own lateral off the substation
+            c = 0.0
+        else:
+            # the point at depth c on the path substation -> j: walk up from j's node
+            b = int(node_of_row[j])
+            a = parent[b]
+            while a >= 0 and ndepth[a] >= c - tol:
+                b, a = a, parent[a]
+            if abs(ndepth[b] - c) <= tol:
+                par = b
+            else:                                          # between a and b: a junction the matrix has no row for
+                par = len(parent)
+                parent.append(a)
+                edge_r.append(c - (ndepth[a] if a >= 0 else 0.0))
+                cons_of.append(-1)
+                ndepth.append(c)
+                parent[b] = par
+                edge_r[b] = ndepth[b] - c
+        node_of_row[i] = len(parent)
+        parent.append(par)
+        edge_r.append(max(di - c, 0.0))
+        cons_of.append(int(i))
+        ndepth.append(di)
+        placed.append(i)
+    return np.asarray(parent, np.int64), np.asarray(edge_r, np.float64), np.asarray(cons_of, np.int64)

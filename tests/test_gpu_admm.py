@@ -436,6 +436,10 @@ def test_config3_all_communities_90pct_T96(gpu_lib, golden, feeder_R):
     oh = ro.Homes.uniform(LOAD, ev, 4.8, 20.0, 0.2, 44, 92)
     e = AdmmEngine(cost, pack_homes(ev, 4.8, 20.0, 0.2, 44, 92), LOAD, np.arange(n), feeder_R,
                    kappa=5.0, vset=1.03, vlow=0.95, vhigh=1.05, mode="relaxed_exact")
+    # (round 4: the engine gets the matrix only, as the reference's Utility does, recovers the radial feeder from it
+    # -- 1126 residence rows, junctions without a residence as extra tree nodes -- and judges every row by the tree
+    # form of R p: no dense product on this feeder)
+    assert e._tree is not None and e._tree_newton and 1126 <= e._tree.n <= 1696
     diffs = e.run(3)
     assert set(e.op_path_hist) == {"dual"}
     y = e.yd[0].cpu().numpy()

@@ -385,3 +385,34 @@ def test_plot_result_warns_and_returns():
     fx = REVS.__new__(REVS)
     with pytest.warns(RuntimeWarning, match="outside"):
         assert fx.plot_result(None, None, anything=1) is None
+
+
+def test_tree_recovered_from_the_matrix(golden, feeder_R):
+    """revs_admm_amd.feeder.tree_from_R: callers of lpsolver.solve_ADMM's operator hold R restricted to the
+    residence nodes (lpsolver.py:184-189), not the network.  A radial feeder is recovered from that matrix alone
+    -- junctions that carry no residence become extra tree nodes -- and reproduces it: the synthetic feeder
+    (every node a row) exactly as given, the 121144 feeder's 1126 residence rows with fewer nodes than the
+    network has (1691), within the tree form's 2048; a matrix that is not a feeder's is rejected or fails the
+    product check the engine makes."""
+    from revs_admm_amd.feeder import feeder_tree, tree_from_R, tree_voltage_host
+    from revs_admm_amd.synthetic import make_workload
+    rng = np.random.default_rng(0)
+    w = make_workload(3000, 24, n_nodes=300, seed=3)
+    par, er, cons = tree_from_R(w.Rn)
+    assert len(par) == w.M and sorted(cons) == list(range(w.M))
+    for R in (w.Rn, feeder_R):
+        M = R.shape[0]
+        tr = tree_from_R(R)
+        assert tr is not None and M <= len(tr[0]) <= 2048 and (np.sort(tr[2][tr[2] >= 0]) == np.arange(M)).all()
+        ft = feeder_tree(*tr, np.ones(M, bool))
+        probe = rng.uniform(0.5, 1.5, (M, 3))
+        ref = R @ probe
+        assert np.abs(tree_voltage_host(ft, probe) - ref).max() < 1e-11 * np.abs(ref).max()
+    assert len(tree_from_R(feeder_R)[0]) < 1691
+    A = rng.uniform(0, 1, (40, 40))
+    bad = tree_from_R(A @ A.T)
+    if bad is not None:                                      # (no tree metric: whatever comes out does not reproduce it)
+        ft = feeder_tree(*bad, np.ones(40, bool))
+        probe = rng.uniform(0.5, 1.5, (40, 2))
+        assert np.abs(tree_voltage_host(ft, probe) - (A @ A.T) @ probe).max() > 1e-6
+    assert tree_from_R(np.array([[1.0, 2.0], [0.5, 1.0]])) is None      # not symmetric
