@@ -446,6 +446,10 @@ def main():
             timed_steps.launches = int(eng.lib.revs_plan_stream_launches(eng._plan))
         else:                       # (no streaming burst in the region: nothing to price)
             dt_ev = e0.elapsed_time(e1) * 1e-3 if not native else float("nan")
+        cm, bm, ci = C.c_double(), C.c_double(), C.c_int32()
+        if native and world > 1 and eng.lib.revs_plan_collective_ms(eng._plan, C.addressof(cm), C.addressof(bm),
+                                                                    C.addressof(ci)) == 0:
+            timed_steps.collective = (cm.value, bm.value, ci.value)
         if native:
             eng.lib.revs_plan_stream_timing(eng._plan, 0)
         return dt, dt_ev
@@ -657,6 +661,14 @@ def main():
                              else "external (torch.distributed.run)" if world > 1 else "single process"),
                 "clock_warmup_products": args.clock_warm,
             },
+            # N > 1: the all-reduce of a block's node sums (events around it on the stream it is issued on) beside that
+            # block's sweep launches: the collective costs the step nothing while it is the shorter of the two
+            "collective": (None if not getattr(timed_steps, "collective", None) else
+                           {"collective_ms_per_block": timed_steps.collective[0],
+                            "block_sweeps_ms": timed_steps.collective[1],
+                            "iterations_in_that_block": timed_steps.collective[2],
+                            "bytes": int(timed_steps.collective[2]) * (eng.M * args.T + 64 * world) * 8,
+                            "hidden": bool(eng.op.stream_overlap and timed_steps.collective[0] < timed_steps.collective[1])}),
             "roofline": {
                 "kernel": ("agent_step_kernel<MULTI> (%d ADMM iterations of every residence per launch: home QP "
                            "sweeps + dual updates + next operator home passes, state in registers; voltage "

@@ -984,6 +984,12 @@ int revs_plan_stream_timing(revs_plan_t *plan, int32_t enable);
 int revs_plan_stream_elapsed_ms(revs_plan_t *plan, double *ms);
 /* ... and the number of residence-sweep launches enqueued between the two events */
 int64_t revs_plan_stream_launches(revs_plan_t *plan);
+/* ... and, with residences sharded and the timing armed, two more events around the all-reduce of the node sums of
+ * the last call's FIRST block (*iterations slices in one collective) on the stream it is issued on -- the second stream
+ * when the blocks overlap: *collective_ms = that all-reduce's duration, *block_ms = the duration of that block's sweep
+ * launches on the caller's stream (a collective that runs beside the next block's sweeps is hidden as long as it is
+ * the shorter one).  REVS_EINVAL when none has run since the timing was armed (one GPU). */
+int revs_plan_collective_ms(revs_plan_t *plan, double *collective_ms, double *block_ms, int32_t *iterations);
 /* Bits OR-ed by the sweeps launched through the plan since the last clear: 1 = a residence's
  * window cannot reach 90 % SOC (the reference prints "No solution found", lpsolver.py:153-155),
  * 2 = a PDHG residence hit max_iter before its tolerance.  Meaningful after the stream has

@@ -233,6 +233,7 @@ SIGNATURES = {
     "revs_plan_stream_timing": (C.c_int, [_p, C.c_int32]),
     "revs_plan_stream_elapsed_ms": (C.c_int, [_p, _p]),
     "revs_plan_stream_launches": (_i64, [_p]),
+    "revs_plan_collective_ms": (C.c_int, [_p, _p, _p, _p]),
     "revs_plan_stream_run": (C.c_int, [_p, _i32, C.POINTER(StreamState), _f64, _f64, _p, _p, _p]),
     "revs_plan_status_flags": (_i32, [_p, _i32]),
     "revs_op_dual_step_pending": (C.c_int, [_i32, _p, _p, _p, _p, _p, _f64, _f64, _p, _i32, _p, _p, _p]),

@@ -66,6 +66,9 @@ struct revs_plan {
     std::vector<hipEvent_t> events;        // pool: sweeps-done / verdicts-done per block, end of call
     // optional timing of the bursts on their own stream (revs_plan_stream_timing)
     hipEvent_t tev[2] = {nullptr, nullptr};
+    hipEvent_t cev[4] = {nullptr, nullptr, nullptr, nullptr};   // around a block's all-reduce / around that block's sweeps
+    bool cev_valid = false;
+    int32_t cev_nb = 0;                    // iterations of the timed block
     // folded chain (revs_plan_chain_fold_run): sums of the trial's evaluation E2 / of the next
     // iteration's evaluation E1 by iteration parity, the E2 side's row scratch, the odd parity's
     // candidate sets and stats blocks ([0]: the evaluation's, [1]: the trial's)
@@ -207,6 +210,7 @@ extern "C" void revs_plan_destroy(revs_plan_t *plan) {
     for (double *v : plan->fold_sh) if (v) (void)hipFree(v);
     for (hipEvent_t e : plan->events) (void)hipEventDestroy(e);
     for (hipEvent_t e : plan->tev) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : plan->cev) if (e) (void)hipEventDestroy(e);
     if (plan->side) (void)hipStreamDestroy(plan->side);
     delete plan;
 }
@@ -1291,7 +1295,29 @@ extern "C" int revs_plan_stream_timing(revs_plan_t *plan, int32_t enable) {
             revs::set_error("revs_plan_stream_timing: hipEventCreate failed");
             return REVS_ELAUNCH;
         }
+    for (hipEvent_t &e : plan->cev)
+        if (enable && plan->comm && !e && hipEventCreate(&e) != hipSuccess) {
+            revs::set_error("revs_plan_stream_timing: hipEventCreate failed");
+            return REVS_ELAUNCH;
+        }
     plan->timing = enable ? 1 : 0;
+    plan->cev_valid = false;
+    return REVS_OK;
+}
+
+extern "C" int revs_plan_collective_ms(revs_plan_t *plan, double *collective_ms, double *block_ms, int32_t *iterations) {
+    REVS_REQUIRE(plan && collective_ms && block_ms && iterations, "revs_plan_collective_ms: null argument");
+    REVS_REQUIRE(plan->cev_valid, "revs_plan_collective_ms: no block's all-reduce has been timed (one GPU, or revs_plan_stream_timing not armed)");
+    float a = 0.f, b = 0.f;
+    hipError_t e = hipEventElapsedTime(&a, plan->cev[0], plan->cev[1]);
+    if (e == hipSuccess) e = hipEventElapsedTime(&b, plan->cev[2], plan->cev[3]);
+    if (e != hipSuccess) {
+        revs::set_error("revs_plan_collective_ms: %s (synchronise the streams first)", hipGetErrorString(e));
+        return REVS_ELAUNCH;
+    }
+    *collective_ms = (double)a;
+    *block_ms = (double)b;
+    *iterations = plan->cev_nb;
     return REVS_OK;
 }
 
@@ -1530,6 +1556,8 @@ extern "C" int revs_plan_stream_run_blocks(revs_plan_t *plan, int32_t max_steps,
         // the set block b - 2 started from)
         if (ov && b >= 2) rc = hip_ok(hipStreamWaitEvent(s, plan->events[2 * (b - 2) + 1], 0), "hipStreamWaitEvent");
         int in = cur, w = 0;
+        const bool time_block = plan->timing != 0 && plan->comm && plan->cev[0] && b == 0;      // (a call's first block)
+        if (time_block && rc == REVS_OK) rc = hip_ok(hipEventRecord(plan->cev[2], s), "hipEventRecord");
         for (int k = k0; k < k0 + nb && rc == REVS_OK;) {
             const int kin = std::min(K, k0 + nb - k);
             const bool last = (k + kin == max_steps);    // the call's last launch also prepares P_est[k+n+1]
@@ -1540,6 +1568,7 @@ extern "C" int revs_plan_stream_run_blocks(revs_plan_t *plan, int32_t max_steps,
             k += kin;
             launched += kin;
         }
+        if (time_block && rc == REVS_OK) rc = hip_ok(hipEventRecord(plan->cev[3], s), "hipEventRecord");
         prev = cur;
         cur = in;
         // The call's last block has nothing to run beside: without a collective its verdicts go behind its
@@ -1556,8 +1585,15 @@ extern "C" int revs_plan_stream_run_blocks(revs_plan_t *plan, int32_t max_steps,
             if (ov && rc == REVS_OK) rc = hip_ok(hipEventRecord(plan->events[2 * b], s), "hipEventRecord");
             if (ov && rc == REVS_OK) rc = hip_ok(hipStreamWaitEvent(q, plan->events[2 * b], 0), "hipStreamWaitEvent");
         }
-        if (rc == REVS_OK && plan->comm)
-            rc = revs_comm_allreduce_f64(plan->comm, ring, (int64_t)nb * stride, 0, q);
+        if (rc == REVS_OK && plan->comm) {
+            if (time_block) rc = hip_ok(hipEventRecord(plan->cev[0], q), "hipEventRecord");
+            if (rc == REVS_OK) rc = revs_comm_allreduce_f64(plan->comm, ring, (int64_t)nb * stride, 0, q);
+            if (time_block && rc == REVS_OK) {
+                rc = hip_ok(hipEventRecord(plan->cev[1], q), "hipEventRecord");
+                plan->cev_valid = rc == REVS_OK;
+                plan->cev_nb = nb;
+            }
+        }
         // block 0's launch also judges the call's first iteration (the caller's st->p0: its sweep ran
         // unjudged, like every other sweep of the block); the last block's also hands the call's last
         // slice over to the caller (st->p0_out) and folds its tail into the extra record

@@ -152,3 +152,34 @@ def test_two_ranks_with_real_partial_sums_equal_one_rank(two_rank_runs, case):
             # them) the verdicts are taken on wrong voltages -- the run must come out different
             assert bad, cfg
             assert any(b.startswith(("P_sch", "G_", "stream_calls", "spec_hist", "chain_hist", "op_iters")) for b in bad), bad[:8]
+
+
+@pytest.mark.parametrize("transport", ["rccl", "share-gpu"])
+def test_bench_two_ranks_through_its_own_launcher(gpu_lib, transport):
+    """`python bench.py --gpus 2` end to end: the self-launcher (Popen children, never exec), sharding, the native
+    block loop with the library's communicator in it, max over ranks, rank 0's JSON line -- against the one-process
+    run of the same total workload (--scaling strong): the same ADMM residuals after the same 95 iterations.
+    "rccl": one rank per GPU over the library-owned RCCL communicator -- needs two GPUs, skipped on the one-GPU test
+    box; "share-gpu": both ranks on cuda:0 over the hook communicator (gloo), the same code path with a host-staged
+    transport."""
+    import torch
+    if transport == "rccl" and torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (the round-end test box has one)")
+    bench = os.path.join(os.path.dirname(HERE), "bench.py")
+    common = [sys.executable, bench, "--steps", "20", "--bursts", "3", "--homes", "20000", "--nodes", "512", "--scaling", "strong",
+              "--no-extras", "--no-cpu-baseline", "--no-converge", "--lanes", "0"]
+    env = dict(os.environ, OMP_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2", MKL_NUM_THREADS="2")
+    lines = []
+    for extra in (["--gpus", "1"], ["--gpus", "2"] + (["--share-gpu"] if transport == "share-gpu" else [])):
+        r = subprocess.run(common + extra, capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines.append(json.loads([ln for ln in r.stdout.splitlines() if ln.lstrip().startswith("{")][-1]))
+    one, two = lines
+    assert (one["n_gpus"], two["n_gpus"]) == (1, 2) and two["config"]["homes_total"] == one["config"]["homes_total"] == 20000
+    assert two["config"]["homes_per_gpu"] == 10000 and two["config"]["launcher"] == "bench.py spawned the ranks itself"
+    assert two["breakdown"]["steady_state_steps_kept_discarded"] == one["breakdown"]["steady_state_steps_kept_discarded"] == [60, 0]
+    for k in ("admm_residual_primal", "admm_residual_dual", "admm_max_diff"):      # (PDHG residences group by wavefront: not bit for bit)
+        assert two["breakdown"][k] == pytest.approx(one["breakdown"][k], rel=2e-3), k
+    c = two["collective"]
+    assert c is not None and c["collective_ms_per_block"] > 0 and c["iterations_in_that_block"] == 20 and c["bytes"] == 20 * (512 * 24 + 128) * 8
+    assert one["collective"] is None
