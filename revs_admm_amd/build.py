@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librevs_admm.so")
 SOURCES = ["runtime.cpp", "agent_kernels.hip", "operator_kernels.hip", "newton_kernels.hip",
            "gemm_kernels.hip"]
-HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "select_body.h"),
+HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "tuning.h"), os.path.join(CSRC, "select_body.h"),
            os.path.join(CSRC, "tree_body.h"), os.path.join(CSRC, "internal.h"),
            os.path.join(ROOT, "include", "revs_admm.h")]
 

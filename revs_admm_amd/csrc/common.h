@@ -312,20 +312,13 @@ __device__ __forceinline__ float clip3(float v, float lo, float hi) {
 
 }  // namespace revs
 
-// Tuning build (-DREVS_KV_STAMPS): wall-clock ticks (100 MHz) at up to 32 points of a slot's way through the
-// folded chain's operator launch, written by thread 0 of its second half's workgroups.
-#if defined(REVS_KV_STAMPS) && defined(REVS_KVS_TU)      // (the operator kernels' translation unit only)
-namespace revs {
-// (the pointer sits in LDS, put there by thread 0 of a stamped workgroup: reading it waits for no
-// outstanding vector load -- a stamp must not order the code it measures)
-static __shared__ double *kvs_lds;
-}
-#define REVS_KVS_BEGIN(ptr) do { if (threadIdx.x == 0) revs::kvs_lds = (ptr); } while (0)
-#define REVS_KVS(t, i) do { if (threadIdx.x == 0 && revs::kvs_lds) \
-        revs::kvs_lds[32 * (t) + (i)] = (double)wall_clock64(); } while (0)
-#define REVS_KVV(t, i, val) do { if (threadIdx.x == 0 && revs::kvs_lds) revs::kvs_lds[32 * (t) + (i)] = (double)(val); } while (0)
+// Stage stamps of the latency-bound operator launches exist in tuning builds only (csrc/tuning.h, never included by
+// the product build: python -m revs_admm_amd.build --out tune/lib.so -DREVS_TUNING -DREVS_KV_STAMPS | -DREVS_BPP_STAMPS)
+#ifdef REVS_TUNING
+#include "tuning.h"
 #else
 #define REVS_KVS_BEGIN(ptr) do { } while (0)
 #define REVS_KVS(t, i) do { } while (0)
 #define REVS_KVV(t, i, val) do { } while (0)
+#define BPP_STAMP(i) do { } while (0)
 #endif

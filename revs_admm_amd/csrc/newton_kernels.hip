@@ -355,12 +355,6 @@ __global__ __launch_bounds__(256) void op_dual_gram_kernel(
 // workgroup's dynamic LDS holds the 128 x 129 factor: 129 KB of the CU's 160 KB), swap
 // every infeasible index (u_i < 0 in B, w_i < 0 outside) while that shrinks their number,
 // else only the highest one -- finite for a positive definite K'.
-#ifdef REVS_BPP_STAMPS
-__device__ double g_bpp_stamps[256][32];
-#define BPP_STAMP(i) do { if (threadIdx.x == 0 && (i) < 32) g_bpp_stamps[blockIdx.x][i] = (double)wall_clock64(); } while (0)
-#else
-#define BPP_STAMP(i) do { } while (0)
-#endif
 __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
         const double *__restrict__ Kslab, int nks, double inv_kappa, double *__restrict__ Kall,
         const int32_t *__restrict__ ccnt, const double *__restrict__ cval, double delta,

@@ -114,6 +114,14 @@ class OperatorOptions:
     # exists (revs_plan_newton_solve: same iterates, no interpreter between the launches); False: the Python loop of
     # operator_newton.py, which is also what runs on a process group without the library's communicator
     native_newton: bool = True
+    # the steady-state / chained iterations as native calls on a plan (revs_plan_*); False: every iteration issued from
+    # Python (tests compare the two).  recompute_pe_new: with no multipliers the sweep recomputes the operator's answer
+    # from the three profiles it is a function of instead of reading it (same bits, one input stream less).
+    # library_comm: residences sharded over an nccl group -> the library's own RCCL communicator inside the native
+    # loops; False: torch.distributed issues the all-reduces from Python (round 1's form)
+    native_plan: bool = True
+    recompute_pe_new: bool = True
+    library_comm: bool = True
     speculate: bool = True
     # One GPU, multipliers all zero: the speculative sweep also does the home pass of the NEXT
     # operator evaluation (one pass over the homes per ADMM iteration instead of two).
@@ -361,8 +369,7 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
         self.recompute_pe_new = False
         self._ar_ahead = False           # ... already exchanged between the ranks
         self._prod_ahead = False         # ... and the product on them already enqueued
-        if (cuda and self.op.solver == "newton" and _kernels is None
-                and not os.environ.get("REVS_NO_PLAN")):
+        if cuda and self.op.solver == "newton" and _kernels is None and self.op.native_plan:
             d = _lib.PlanDesc()
             d.n_homes, d.m, d.T = n, M, T
             d.node_ptr, d.R, d.Rt = ptr(self.node_ptr), ptr(self.R64), ptr(self.R64T)
@@ -382,9 +389,8 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
             d.node_of = ptr(self.node_of_dev)
             # with no multipliers the sweep recomputes the operator's answer instead of reading it
             # (same bits, one input stream less: 20.0 -> 19.0 us per launch at 100k homes x 24,
-            # round 2; REVS_RECOMPUTE=0 restores the read)
-            rec = os.environ.get("REVS_RECOMPUTE", "").strip()
-            d.recompute_pe_new = int(rec not in ("0", "false", "no")) if rec else 1
+            # round 2; OperatorOptions(recompute_pe_new=False) restores the read)
+            d.recompute_pe_new = int(bool(self.op.recompute_pe_new))
             self.recompute_pe_new = bool(d.recompute_pe_new)
             d.cand_idx1, d.cand_cnt1, d.cand_val1 = (ptr(self.c_idx[1]), ptr(self.c_cnt[1]),
                                                      ptr(self.c_val[1]))
@@ -456,7 +462,7 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
                 raise _lib.RevsError("revs_comm_create_hook failed: " + self.lib.revs_last_error().decode())
             if self._plan is not None:
                 check(self.lib.revs_plan_set_comm(self._plan, self._comm), "revs_plan_set_comm")
-        elif group is not None and cuda and _kernels is None and not os.environ.get("REVS_NO_COMM"):
+        elif group is not None and cuda and _kernels is None and self.op.library_comm:
             # the library's own RCCL communicator: unique id from rank 0 over the caller's group
             ws, rk = torch.distributed.get_world_size(group), torch.distributed.get_rank(group)
             idb = (C.c_char * 128)()

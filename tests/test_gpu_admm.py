@@ -558,14 +558,9 @@ def test_native_step_and_fused_home_pass_change_nothing(gpu_lib, mode, T, monkey
     runs = []
     # (rec: the sweep recomputes the operator's steady-state answer instead of reading it --
     # the rule for large problems, forced here)
-    for plan, fuse, rec in ((True, True, "1"), (True, True, "0"), (True, False, "0"), (False, False, "0")):
-        monkeypatch.setenv("REVS_RECOMPUTE", rec)
-        if plan:
-            monkeypatch.delenv("REVS_NO_PLAN", raising=False)
-        else:
-            monkeypatch.setenv("REVS_NO_PLAN", "1")
-        e = _engine(w, mode, op=OperatorOptions(fuse_home_pass=fuse))
-        assert (e._plan is not None) == plan and e.recompute_pe_new == (rec == "1")
+    for plan, fuse, rec in ((True, True, True), (True, True, False), (True, False, False), (False, False, False)):
+        e = _engine(w, mode, op=OperatorOptions(fuse_home_pass=fuse, native_plan=plan, recompute_pe_new=rec))
+        assert (e._plan is not None) == plan and e.recompute_pe_new == (rec and plan)
         d = e.run(25)
         runs.append((d, e.result(), e.P_est.cpu().numpy(), list(e.spec_hist),
                      [h[0] for h in e.newton_hist]))

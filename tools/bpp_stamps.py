@@ -1,5 +1,5 @@
 """Stage stamps of op_dual_bpp_kernel's last launch on the 121144 feeder (tuning build:
-python -m revs_admm_amd.build --out tune/librevs_bpp.so -DREVS_BPP_STAMPS; REVS_LIB=tune/librevs_bpp.so python tools/bpp_stamps.py)."""
+python -m revs_admm_amd.build --out tune/librevs_bpp.so -DREVS_TUNING -DREVS_BPP_STAMPS; REVS_LIB=tune/librevs_bpp.so python tools/bpp_stamps.py)."""
 import ctypes as C
 import os
 import sys
