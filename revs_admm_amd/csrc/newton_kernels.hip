@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
     BPP_STAMP(1);
     extern __shared__ double Ls_dyn[];                    // [kAmax][kAmax + 1]
     auto Ls = [&](int i, int j) -> double & { return Ls_dyn[i * (kAmax + 1) + j]; };
-    __shared__ double s_s[kAmax], c_s[kAmax], u_s[kAmax], w_s[kAmax], wred[4], idk_s[kAmax], col_s[2][kAmax];
+    __shared__ double s_s[kAmax], c_s[kAmax], u_s[kAmax], w_s[kAmax], wred[4], idk_s[kAmax], col_s[2][4][kAmax];
     __shared__ int bl[kAmax];
     __shared__ unsigned long long Bsh[kWords], Vsh[kWords];
     __shared__ double dl_s, tolw_s, tolu_s;
@@ -497,13 +497,14 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
         }
         __syncthreads();
         // K'_BB = L D L^T (unit lower L below the diagonal of Ls, 1 / D in idk_s), pivots floored at dl 1e-6 as the
-        // Cholesky form floored its squares.  The trailing matrix lives in REGISTERS: thread (ti, tj) owns the elements
-        // (i, j) with i % 16 = ti, j % 16 = tj; per column the sixteen-th of the threads that owns it publishes it (two
-        // alternating LDS buffers: ONE barrier per column), everybody reads the entries of its own rows and columns --
-        // independent LDS reads -- and updates its block with straight-line FMAs; the finished column goes to Ls, scaled,
-        // for the solves.  Reciprocals by v_rcp_f64 + two Newton steps.  (In-LDS updates -- two dependent LDS reads and
-        // a write per element, three barriers, a square root and a division by one thread per column -- took ~45 us per
-        // round at 59 rows; r04.)
+        // Cholesky form floored its squares.  The trailing matrix lives in REGISTERS -- thread (ti, tj) owns the elements
+        // (i, j) with i % 16 = ti, j % 16 = tj -- and is eliminated FOUR columns per barrier: the threads that own a
+        // block's columns publish them (two alternating LDS buffers), every thread factors the 4 x 4 diagonal block for
+        // itself, forms the panel entries of its own rows and columns (independent LDS reads) and applies the rank-4
+        // update to its block with straight-line FMAs; the finished columns go to Ls, scaled, for the solves.
+        // Reciprocals by v_rcp_f64 + two Newton steps.  (Stage stamps, 50 rows: in-LDS Cholesky with three barriers, a
+        // square root and a division per column ~45 us per round; one column per barrier with the matrix in registers
+        // 24 us -- the barrier, the broadcast of the pivot and its reciprocal chain per column; r04.)
         auto factor = [&](auto nt_tag) {
             constexpr int NT = decltype(nt_tag)::value;
             const int ti = tid >> 4, tj = tid & 15;
@@ -515,39 +516,92 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
                     const int i = ti + 16 * x, j = tj + 16 * y;
                     am[x][y] = (i < nb && j <= i) ? kp(bl[i], bl[j]) : 0.0;
                 }
+            const double floor_ = dl * 1e-6;
 #pragma unroll
             for (int yb = 0; yb < NT; ++yb) {
-                for (int kk = 0; kk < 16; ++kk) {
-                    const int k = 16 * yb + kk;
-                    if (k >= nb) break;                               // uniform
-                    double *const col = col_s[k & 1];
-                    if (tj == kk) {                                   // this column's owners: rows ti + 16 x
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const int k0 = 16 * yb + 4 * q4;
+                    if (k0 >= nb) break;                              // uniform
+                    double (*const col)[kAmax] = col_s[(k0 >> 2) & 1];
+                    if ((tj >> 2) == q4) {                            // the owners of columns k0 .. k0 + 3: rows ti + 16 x
 #pragma unroll
-                        for (int x = 0; x < NT; ++x) col[ti + 16 * x] = am[x][yb];
+                        for (int x = 0; x < NT; ++x) col[tj & 3][ti + 16 * x] = am[x][yb];
                     }
                     __syncthreads();
-                    const double dk = fmax(col[k], dl * 1e-6);
-                    double r = __builtin_amdgcn_rcp(dk);
-                    r = __builtin_fma(__builtin_fma(-dk, r, 1.0), r, r);
-                    r = __builtin_fma(__builtin_fma(-dk, r, 1.0), r, r);
-                    double ci[NT], cj[NT];
+                    // the diagonal block, factored by every thread for itself: D4 = L4 diag(d) L4^T
+                    double D4[4][4], L4[4][4], r4[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int c = 0; c <= r; ++c) {
+                            const bool in = k0 + r < nb;              // (columns beyond the set: identity)
+                            D4[r][c] = in ? col[c][k0 + r] : (r == c ? 1.0 : 0.0);
+                        }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const double dk = fmax(D4[c][c], floor_);
+                        double r = __builtin_amdgcn_rcp(dk);
+                        r = __builtin_fma(__builtin_fma(-dk, r, 1.0), r, r);
+                        r = __builtin_fma(__builtin_fma(-dk, r, 1.0), r, r);
+                        r4[c] = r;
+#pragma unroll
+                        for (int rr = c + 1; rr < 4; ++rr) L4[rr][c] = D4[rr][c] * r;
+#pragma unroll
+                        for (int rr = c + 1; rr < 4; ++rr)
+#pragma unroll
+                            for (int cc = c + 1; cc <= rr; ++cc) D4[rr][cc] -= L4[rr][c] * D4[cc][c];
+                    }
+                    // the panel: for a row i below the block, w_i = L4^-1 A_i,block (the unscaled entries l_ic d_c) and
+                    // l_i = w_i / d; zero for rows inside or above the block
+                    double li[NT][4], wj[NT][4];
 #pragma unroll
                     for (int x = 0; x < NT; ++x) {
                         const int i = ti + 16 * x, j = tj + 16 * x;
-                        ci[x] = (i > k && i < nb) ? col[i] * r : 0.0;
-                        cj[x] = (j > k && j < nb) ? col[j] : 0.0;
+                        double pi[4], pj[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            pi[c] = (i > k0 + 3 && i < nb) ? col[c][i] : 0.0;
+                            pj[c] = (j > k0 + 3 && j < nb) ? col[c][j] : 0.0;
+                        }
+#pragma unroll
+                        for (int c = 1; c < 4; ++c)
+#pragma unroll
+                            for (int cc = 0; cc < c; ++cc) { pi[c] -= L4[c][cc] * pi[cc]; pj[c] -= L4[c][cc] * pj[cc]; }
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) { li[x][c] = pi[c] * r4[c]; wj[x][c] = pj[c]; }
                     }
 #pragma unroll
                     for (int x = 0; x < NT; ++x)
 #pragma unroll
-                        for (int y = 0; y < NT; ++y) am[x][y] -= ci[x] * cj[y];
-                    if (tj == kk) {                                   // l_ik for the solves
+                        for (int y = 0; y < NT; ++y)
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) am[x][y] -= li[x][c] * wj[y][c];
+                    // the finished columns for the solves: l_ic of the rows below the block (their owners' threads hold
+                    // them), the block's own sub-diagonal, 1 / d
+                    if ((tj >> 2) == q4) {
+                        const int c = tj & 3;
 #pragma unroll
                         for (int x = 0; x < NT; ++x) {
                             const int i = ti + 16 * x;
-                            if (i > k && i < nb) Ls(i, k) = ci[x];
+                            if (i > k0 + 3 && i < nb) Ls(i, k0 + c) = li[x][c];
                         }
-                        if (ti == 0) idk_s[k] = r;
+                    }
+                    if (tid < 16) {
+                        const int r = tid >> 2, c = tid & 3;
+                        if (c < r && k0 + r < nb) {
+                            double v = 0.0;
+#pragma unroll
+                            for (int rr = 1; rr < 4; ++rr)
+#pragma unroll
+                                for (int cc = 0; cc < rr; ++cc) v = (rr == r && cc == c) ? L4[rr][cc] : v;
+                            Ls(k0 + r, k0 + c) = v;
+                        }
+                        if (c == r && k0 + r < nb) {
+                            double v = r4[0];
+#pragma unroll
+                            for (int cc = 1; cc < 4; ++cc) v = cc == c ? r4[cc] : v;
+                            idk_s[k0 + r] = v;
+                        }
                     }
                 }
             }
@@ -557,8 +611,8 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
         __syncthreads();
         BPP_STAMP(4 + 4 * round_);
         // triangular solves in wavefront 0: lane l holds components l and l + 64; the pivot component reaches the
-        // others through v_readlane (k is uniform: no trip through the LDS crossbar per step), the next column of L
-        // is requested before the current one is used
+        // others through v_readlane (k is uniform: no trip through the LDS crossbar per step), and the entries of the
+        // next four columns of L are requested before the current four are used
         if (tid < 64) {
             double v0 = lane < nb ? c_s[bl[lane]] : 0.0;
             double v1 = lane + 64 < nb ? c_s[bl[lane + 64]] : 0.0;
@@ -569,28 +623,54 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
                 const int hi = k < 64 ? __builtin_amdgcn_readlane((int)(b0 >> 32), kk) : __builtin_amdgcn_readlane((int)(b1 >> 32), kk);
                 return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
             };
-            // L y = c_B (unit diagonal)
-            double l0 = (lane > 0 && lane < nb) ? Ls(lane, 0) : 0.0, l1 = (lane + 64 < nb) ? Ls(lane + 64, 0) : 0.0;
-            for (int k = 0; k < nb; ++k) {
-                const double n0 = (k + 1 < nb && lane > k + 1 && lane < nb) ? Ls(lane, k + 1) : 0.0;
-                const double n1 = (k + 1 < nb && lane + 64 > k + 1 && lane + 64 < nb) ? Ls(lane + 64, k + 1) : 0.0;
-                const double yk = bcast(k);
-                if (lane > k) v0 -= l0 * yk;
-                if (lane + 64 > k) v1 -= l1 * yk;
-                l0 = n0; l1 = n1;
+            // L y = c_B (unit diagonal): column k of L, rows lane and lane + 64
+            auto colf = [&](int k, double (&a0)[4], double (&a1)[4]) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    a0[c] = (k + c < nb && lane > k + c && lane < nb) ? Ls(lane, k + c) : 0.0;
+                    a1[c] = (k + c < nb && lane + 64 > k + c && lane + 64 < nb) ? Ls(lane + 64, k + c) : 0.0;
+                }
+            };
+            double c0[4], c1[4], n0[4], n1[4];
+            colf(0, c0, c1);
+            for (int kb = 0; kb < nb; kb += 4) {
+                colf(kb + 4, n0, n1);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int k = kb + c;
+                    if (k < nb) {                                     // uniform
+                        const double yk = bcast(k);
+                        v0 -= c0[c] * yk;                             // (zero where lane <= k)
+                        v1 -= c1[c] * yk;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { c0[c] = n0[c]; c1[c] = n1[c]; }
             }
-            // D^-1, then L^T x = y
+            // D^-1, then L^T x = y: row k of L, columns lane and lane + 64
             v0 *= lane < nb ? idk_s[lane] : 0.0;
             v1 *= lane + 64 < nb ? idk_s[lane + 64] : 0.0;
-            l0 = (nb >= 1 && lane < nb - 1) ? Ls(nb - 1, lane) : 0.0;
-            l1 = (nb >= 1 && lane + 64 < nb - 1) ? Ls(nb - 1, lane + 64) : 0.0;
-            for (int k = nb - 1; k >= 0; --k) {
-                const double n0 = (k >= 1 && lane < k - 1) ? Ls(k - 1, lane) : 0.0;
-                const double n1 = (k >= 1 && lane + 64 < k - 1) ? Ls(k - 1, lane + 64) : 0.0;
-                const double xk = bcast(k);
-                if (lane < k) v0 -= l0 * xk;
-                if (lane + 64 < k) v1 -= l1 * xk;
-                l0 = n0; l1 = n1;
+            auto rowb = [&](int k, double (&a0)[4], double (&a1)[4]) {      // rows k, k - 1, k - 2, k - 3
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    a0[c] = (k - c >= 0 && lane < k - c) ? Ls(k - c, lane) : 0.0;
+                    a1[c] = (k - c >= 0 && lane + 64 < k - c) ? Ls(k - c, lane + 64) : 0.0;
+                }
+            };
+            rowb(nb - 1, c0, c1);
+            for (int kb = nb - 1; kb >= 0; kb -= 4) {
+                rowb(kb - 4, n0, n1);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int k = kb - c;
+                    if (k >= 0) {                                     // uniform
+                        const double xk = bcast(k);
+                        v0 -= c0[c] * xk;                             // (zero where lane >= k)
+                        v1 -= c1[c] * xk;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { c0[c] = n0[c]; c1[c] = n1[c]; }
             }
             u_s[lane] = 0.0; u_s[lane + 64] = 0.0;
             __builtin_amdgcn_wave_barrier();
