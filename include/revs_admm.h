@@ -544,7 +544,9 @@ int revs_op_dual_select_model_step(int32_t m, int32_t T, const double *sel_parti
  * residences have no position in the tree: their v, violation and multiplier stay zero).
  * revs_op_dual_rows_tree: pnq = the node sums p | N | q of the home pass; zero_out: an array (not
  * pnq) cleared on the way, or NULL; with_select != 0: the candidate selection of every slot in the
- * same launch (else the caller runs it: revs_agent_step_select with sel_nblk = 1).
+ * same launch (else the caller runs it: revs_agent_step_select with sel_nblk = 1) -- the slot's rows then reach
+ * the selection through LDS where 3 m doubles fit beside the tree's scan buffer (m <= ~4 000), and vfull / viol
+ * are scratch of the call: NOT written.
  * revs_op_dual_evaluate_tree: revs_op_dual_evaluate with phase bit 1 done this way (phase bit 0 --
  * the product R^T y for the home pass's shifts, when use_y -- is unchanged).
  * revs_op_dual_tree_select_model_step: rows, selection, small model and step of every slot in ONE

@@ -268,10 +268,24 @@ __device__ __forceinline__ void tree_rows_body(const TreeRowsArgs &a, const int 
 }
 
 // rows by the tree form, then (SELECT) the candidate selection of the same slot in the same workgroup
+// (SELECT with `staged`: the slot's multipliers, voltages and violations reach the selection through LDS -- double[3 m + 4]
+// behind the tree's scan buffer -- instead of the global columns vfull / viol, which are then NOT written: two column
+// stores and three column loads of m cache lines each off a latency-bound workgroup)
 template <bool SELECT>
-__global__ __launch_bounds__(256) void op_tree_rows_kernel(const TreeRowsArgs ta, const SelectArgs sa) {
+__global__ __launch_bounds__(256) void op_tree_rows_kernel(const TreeRowsArgs ta, const SelectArgs sa, const int staged) {
     REVS_KVS_BEGIN(nullptr);
     extern __shared__ double tree_lds[];
+    if constexpr (SELECT) {
+        if (staged) {
+            double *rows_lds = tree_lds + (tree_lds_bytes(ta.tree.n) / sizeof(double) + 1) / 2 * 2;
+            tree_rows_body(ta, blockIdx.x, tree_lds, rows_lds);
+            __syncthreads();
+            SelectArgs s2 = sa;
+            s2.rows_lds = rows_lds;
+            dual_select_body<true>(s2, blockIdx.x);
+            return;
+        }
+    }
     tree_rows_body(ta, blockIdx.x, tree_lds);
     if constexpr (SELECT) {
         __syncthreads();                    // this workgroup's v, violations and sums, in global memory
@@ -1971,10 +1985,23 @@ extern "C" int revs_op_dual_rows_tree(int32_t m, int32_t T, const revs_tree_t *t
     const TreeArgs tr{tree->n, (const unsigned long long *)tree->pack, tree->w};
     const TreeRowsArgs ta{tr, m, T, pnq, pnq + 2 * (int64_t)m * T, y, vlo, vhi, vfull, viol, partial, zero_out};
     const SelectArgs sa{m, T, 1, kadd, partial, y, vfull, viol, vlo, vhi, seq, cand_idx, cand_cnt, cand_val, stats};
-    if (with_select)
-        hipLaunchKernelGGL((op_tree_rows_kernel<true>), dim3(T), dim3(256), tree_lds_bytes(tree->n), S_(stream), ta, sa);
-    else
-        hipLaunchKernelGGL((op_tree_rows_kernel<false>), dim3(T), dim3(256), tree_lds_bytes(tree->n), S_(stream), ta, sa);
+    if (with_select) {
+        // (the rows go to the selection through LDS where they fit: vfull / viol are scratch of this call then)
+        const size_t staged_lds = ((tree_lds_bytes(tree->n) / sizeof(double) + 1) / 2 * 2 + 3 * (size_t)m + 4) * sizeof(double);
+        const bool staged = staged_lds <= 120 * 1024;
+        if (staged && staged_lds > 64 * 1024) {
+            static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&op_tree_rows_kernel<true>),
+                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
+            if (e != hipSuccess) {
+                revs::set_error("revs_op_dual_rows_tree: %zu bytes of LDS refused: %s", staged_lds, hipGetErrorString(e));
+                return REVS_ELAUNCH;
+            }
+        }
+        hipLaunchKernelGGL((op_tree_rows_kernel<true>), dim3(T), dim3(256), staged ? staged_lds : tree_lds_bytes(tree->n), S_(stream),
+                           ta, sa, staged ? 1 : 0);
+    } else {
+        hipLaunchKernelGGL((op_tree_rows_kernel<false>), dim3(T), dim3(256), tree_lds_bytes(tree->n), S_(stream), ta, sa, 0);
+    }
     REVS_CHECK_LAUNCH("revs_op_dual_rows_tree");
     return REVS_OK;
 }
