@@ -31,6 +31,11 @@ find $O/pmc_t96 -type f ! -name "*summary.csv" -delete
 if [ -f $R/tune/librevs_stamps.so ]; then
   for reg in binding binary; do REVS_LIB=$R/tune/librevs_stamps.so python3 $R/tools/regime_run.py --regime $reg --steps 100 2>&1 | grep "kv stamps" > $O/kv_stamps_$reg.txt; done
 fi
+# the reference's own case: kernel stats of the 15-iteration runs on the 121144 feeder
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/feeder -o s -- python3 $R/tests/tools/feeder_iters.py > $O/feeder.log 2>&1
+cp $(find $O/feeder -name "*kernel_stats.csv" | head -1) $O/feeder_kernel_stats.csv
+rm -rf $O/feeder
+if [ -f $R/tune/librevs_bpp.so ]; then REVS_LIB=$R/tune/librevs_bpp.so python3 $R/tools/bpp_stamps.py 2>&1 | tail -2 > $O/bpp_stamps.txt; fi
 rm -rf $O/kt
 # keep only the counter csvs of the pmc passes (the traces are large)
 find $O/pmc -type f ! -name "*counter_collection.csv" -delete
