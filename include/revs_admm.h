@@ -90,11 +90,15 @@ typedef struct {
                              of lpsolver.py:101-109 can bind; K is that single row and
                              the dual one scalar per home (automatic scales 0.5 / 2).
                              1: keep all T SOC rows (K = prefix sum; scales 0.25 / 4) */
-    int32_t polish;       /* presolved form only, 1 (default): after PDHG has stopped, two
-                             semismooth Newton steps on the terminal row's multiplier with the
-                             schedule in closed form x(mu) = clip(-b - delta mu, 0, w) -- the exact
-                             optimum of the piece PDHG identified (the KKT conditions of
-                             lpsolver.py:83-128's relaxation to float rounding) */
+    int32_t polish;       /* presolved form only, bits.  1 (default): after PDHG has stopped, semismooth Newton
+                             steps on the terminal row's multiplier with the schedule in closed form
+                             x(mu) = clip(-b - delta mu, 0, w) -- the exact optimum of the piece PDHG identified
+                             (the KKT conditions of lpsolver.py:83-128's relaxation to float rounding).
+                             2: the same steps BEFORE PDHG, from the carried multiplier (ydual; zero without):
+                             a residence they settle (at most 6 steps) does not enter PDHG, a wavefront of such
+                             residences skips the loop -- in the closed loop that is nearly every solve after the
+                             first iterations (status >> 8, the PDHG passes, reads 0 for them); the rest go
+                             through PDHG and bit 0's steps as before.  Same optimum either way. */
     int32_t lanes;        /* lanes of a wavefront that share one residence's T slots (every mode, not only PDHG):
                              0 (default) = by T alone (8 lanes x 3 slots at T = 24: the fewest instructions per
                              residence); 16 or 32 with T <= 32 = 2 / 1 slot(s) per lane -- a third of the per-slot work

@@ -419,7 +419,7 @@ void agent_step_kernel(const AgentArgs a) {
     float w[SPL];
     bool pd_infeasible = false;
     // (pd.tol: > 0 as given, 0 = automatic, < 0 = never before max_iter)
-    const float pd_tol = a.pd.tol != 0.f ? a.pd.tol : ((FULL_ROWS || !a.pd.polish) ? 1e-6f : 1e-4f);
+    const float pd_tol = a.pd.tol != 0.f ? a.pd.tol : ((FULL_ROWS || !(a.pd.polish & 1)) ? 1e-6f : 1e-4f);
     if constexpr (MODE == REVS_MODE_RELAXED_PDHG) {
         const float rate = ev ? h.rating : 1.f;
         inv_rate = __builtin_amdgcn_rcpf(rate);
@@ -531,53 +531,13 @@ void agent_step_kernel(const AgentArgs a) {
         int iters = 0;
         const int check = max(a.pd.check, 1);
         if constexpr (!FULL_ROWS) {
-            // The sweep is VALU-issue bound and half of its instructions are this loop, so the
-            // iteration is arranged for the fewest operations:
-            //   x+ = clip((x - tau (sd y + b)) / (1 + tau), 0, w) = clip(a x - cb - s, 0, w),
-            //        a = 1/(1+tau), cb = tau a b (per slot, once), s = tau a sd y (one multiply)
-            //   K (2 x+ - x) = delta (2 sum x+ - sum x), with sum x carried from the last pass
-            float cb[SPL], sx = 0.f;
-#pragma unroll
-            for (int j = 0; j < SPL; ++j) { cb[j] = tau1 * inv1 * b[j]; sx += x[j]; }
-            auto iterate1 = [&](auto res_tag) -> float {
-                constexpr bool RES = decltype(res_tag)::value;
-                const float s = ts * yy;
-                float sn = 0.f, dmax = 0.f;
-#pragma unroll
-                for (int j = 0; j < SPL; ++j) {
-                    const float xn = clip3(fmaf(inv1, x[j], -cb[j]) - s, 0.f, w[j]);
-                    sn += xn;
-                    if constexpr (RES) dmax = fmaxf(dmax, fabsf(xn - x[j]));
-                    x[j] = xn;
-                }
-                const float acc = fmaf(2.0f, sn, -sx);
-                sx = sn;
-                const float v = fmaf(delta, group_sum<LPA>(acc), yy);
-                const float yn = v - clip3(v, lo_last, hi);
-                if constexpr (RES) dmax = fmaxf(dmax, fabsf(yn - yy));
-                yy = yn;
-                return dmax;
-            };
-            for (int k = 0; k < a.pd.max_iter; k += check) {
-                if (__all(done)) break;      // wave-uniform exit every wave reaches
-                for (int c = 1; c < check; ++c) iterate1(std::false_type{});
-                float res = iterate1(std::true_type{});
-                iters += done ? 0 : check;
-                res = group_max_nonneg<LPA>(res);
-                done = done || (res <= pd_tol);
-            }
-            // KKT polish on the piece PDHG has identified.  For the terminal row's multiplier mu
-            // (= sigma yy) the minimiser is x(mu) = clip(-b - delta mu, 0, w) and delta sum x(mu) is
-            // piecewise linear and nonincreasing in mu: semismooth Newton steps on "the row sits on
-            // the bound its multiplier's sign names" (or: mu = 0 and the row inside its bounds) land
-            // on the exact optimum of the identified piece -- the first-order method's tail
-            // (schedules 2e-5 kW off per solve at a 1e-6 step test, 1e-3 kW in the closed loop) is
-            // gone for the price of ~2 passes, and PDHG itself may stop much earlier (pd.tol).
-            if (a.pd.polish) {
-                float mu = sig1 * yy;
-                bool fine = !ev || infeasible;       // the row's KKT conditions hold at x(mu) to float rounding
-                // (a Newton step is exact while the free slots stay free: one or two steps from where
-                // PDHG stopped; the loop ends as soon as every residence of the wavefront is there)
+            // KKT Newton steps on the terminal row's multiplier (described at the polish below): one routine,
+            // run from the carried multiplier BEFORE PDHG (pd.polish bit 1: in the closed loop the multiplier
+            // moves little between ADMM iterations, the active piece is the old one and one or two steps
+            // land on the optimum -- a residence settled here skips PDHG, a wavefront of them the whole loop)
+            // and from PDHG's iterate after it (bit 0).  PDHG stays the globally convergent solver behind
+            // both: whatever the steps do not settle in 6 rounds goes through it.
+            auto kkt_newton = [&](float &mu, bool &fine) {
 #pragma unroll 1
                 for (int r = 0;; ++r) {
                     float sxm = 0.f, u[SPL];
@@ -625,11 +585,71 @@ void agent_step_kernel(const AgentArgs a) {
                     mun = up ? fmaxf(mun, 0.f) : (dn ? fminf(mun, 0.f) : mun);     // a multiplier keeps its sign
                     mu = fine ? mu : mun;
                 }
-                // (a residence the steps did not settle keeps PDHG's iterate -- at PDHG's own, looser tolerance:
-                // status bit 2 says so)
+            };
+            auto kkt_take = [&](float mu, bool fine) {
 #pragma unroll
                 for (int j = 0; j < SPL; ++j) x[j] = fine ? clip3(fmaf(-delta, mu, -b[j]), 0.f, w[j]) : x[j];
                 yy = fine ? mu * inv_sig1 : yy;
+            };
+            float mu_pre = sig1 * yy;
+            bool pre = false;
+            if (a.pd.polish & 2) {
+                pre = !ev || infeasible;
+                kkt_newton(mu_pre, pre);
+                kkt_take(mu_pre, pre);
+                done = done || pre;
+            }
+            // The sweep is VALU-issue bound and half of its instructions are this loop, so the
+            // iteration is arranged for the fewest operations:
+            //   x+ = clip((x - tau (sd y + b)) / (1 + tau), 0, w) = clip(a x - cb - s, 0, w),
+            //        a = 1/(1+tau), cb = tau a b (per slot, once), s = tau a sd y (one multiply)
+            //   K (2 x+ - x) = delta (2 sum x+ - sum x), with sum x carried from the last pass
+            float cb[SPL], sx = 0.f;
+#pragma unroll
+            for (int j = 0; j < SPL; ++j) { cb[j] = tau1 * inv1 * b[j]; sx += x[j]; }
+            auto iterate1 = [&](auto res_tag) -> float {
+                constexpr bool RES = decltype(res_tag)::value;
+                const float s = ts * yy;
+                float sn = 0.f, dmax = 0.f;
+#pragma unroll
+                for (int j = 0; j < SPL; ++j) {
+                    const float xn = clip3(fmaf(inv1, x[j], -cb[j]) - s, 0.f, w[j]);
+                    sn += xn;
+                    if constexpr (RES) dmax = fmaxf(dmax, fabsf(xn - x[j]));
+                    x[j] = xn;
+                }
+                const float acc = fmaf(2.0f, sn, -sx);
+                sx = sn;
+                const float v = fmaf(delta, group_sum<LPA>(acc), yy);
+                const float yn = v - clip3(v, lo_last, hi);
+                if constexpr (RES) dmax = fmaxf(dmax, fabsf(yn - yy));
+                yy = yn;
+                return dmax;
+            };
+            for (int k = 0; k < a.pd.max_iter; k += check) {
+                if (__all(done)) break;      // wave-uniform exit every wave reaches
+                for (int c = 1; c < check; ++c) iterate1(std::false_type{});
+                float res = iterate1(std::true_type{});
+                iters += done ? 0 : check;
+                res = group_max_nonneg<LPA>(res);
+                done = done || (res <= pd_tol);
+            }
+            // KKT polish on the piece PDHG has identified.  For the terminal row's multiplier mu
+            // (= sigma yy) the minimiser is x(mu) = clip(-b - delta mu, 0, w) and delta sum x(mu) is
+            // piecewise linear and nonincreasing in mu: semismooth Newton steps on "the row sits on
+            // the bound its multiplier's sign names" (or: mu = 0 and the row inside its bounds) land
+            // on the exact optimum of the identified piece -- the first-order method's tail
+            // (schedules 2e-5 kW off per solve at a 1e-6 step test, 1e-3 kW in the closed loop) is
+            // gone for the price of ~2 passes, and PDHG itself may stop much earlier (pd.tol).
+            if ((a.pd.polish & 1) && !__all(pre)) {
+                float mu = pre ? mu_pre : sig1 * yy;
+                bool fine = pre || !ev || infeasible;       // the row's KKT conditions hold at x(mu) to float rounding
+                // (a Newton step is exact while the free slots stay free: one or two steps from where
+                // PDHG stopped; the loop ends as soon as every residence of the wavefront is there)
+                kkt_newton(mu, fine);
+                // (a residence the steps did not settle keeps PDHG's iterate -- at PDHG's own, looser tolerance:
+                // status bit 2 says so)
+                kkt_take(mu, fine);
                 unpolished = !fine;
             }
             yy = ev ? yy : 0.f;

@@ -17,10 +17,11 @@ def _engine(w, mode, **kw):
 
 @pytest.mark.parametrize("solver", ["newton", "admm"])
 @pytest.mark.parametrize("stress", [0.9, 1.5])
-@pytest.mark.parametrize("mode,omode", [("relaxed_exact", "relaxed"), ("pdhg", "relaxed")])
+@pytest.mark.parametrize("mode,omode", [("relaxed_exact", "relaxed"), ("pdhg", "relaxed"), ("pdhg_presolve", "relaxed")])
 def test_relaxed_trajectory(gpu_lib, mode, omode, stress, solver):
     """Continuous homes: the iteration map is Lipschitz, so the whole trajectory must
-    follow the oracle.  Tolerance: 2e-3 kW on schedules, 1e-3 relative on diff."""
+    follow the oracle.  Tolerance: 2e-3 kW on schedules, 1e-3 relative on diff.
+    (pdhg_presolve: revs_pdhg_t::polish = 3, the KKT steps from the carried multiplier before PDHG.)"""
     from helpers import f32, oracle_homes
     from oracle import revs_oracle as ro
     from revs_admm_amd.synthetic import make_workload
@@ -28,7 +29,10 @@ def test_relaxed_trajectory(gpu_lib, mode, omode, stress, solver):
     w.load, w.cost = f32(w.load), f32(w.cost)
     iters = 8
     from revs_admm_amd.engine import OperatorOptions
-    e = _engine(w, mode, op=OperatorOptions(solver=solver))
+    kw = {}
+    if mode == "pdhg_presolve":
+        mode, kw = "pdhg", dict(pdhg=dict(polish=3))
+    e = _engine(w, mode, op=OperatorOptions(solver=solver), **kw)
     diffs = e.run(iters)
     P_sch, S, C = e.result()
     d_ref, P_ref, S_ref, C_ref = ro.solve_ADMM(oracle_homes(w), w.Rn, w.node_of, w.cost, w.kappa,

@@ -101,16 +101,20 @@ def test_binary_matches_oracle(gpu_lib, T, zero_state):
 
 
 @pytest.mark.parametrize("T,n", [(24, 2003), (96, 2003), (50, 2003), (192, 2003), (24, 10_000)])
-@pytest.mark.parametrize("mode", ["relaxed_exact", "pdhg"])
+@pytest.mark.parametrize("mode", ["relaxed_exact", "pdhg", "pdhg_presolve"])
 def test_relaxed_matches_oracle(gpu_lib, T, n, mode):
     """Continuous box+SOC QP (north star; n = 10 000 x T = 24 is BASELINE config 1 at its stated
     size).  float32 tolerance: 5e-5 kW absolute on schedules of 3.6-7.2 kW chargers for both solvers
     -- PDHG finishes with the KKT polish on the piece it identified (round 2: 2e-4, PDHG stopping at a
-    1e-6 step)."""
+    1e-6 step).  pdhg_presolve: revs_pdhg_t::polish = 3, the KKT steps also BEFORE PDHG -- here from a zero
+    multiplier (the cold start: the steps cross many pieces, PDHG takes whatever they leave)."""
     from oracle import revs_oracle as ro
     w, oh = _prep(n, T, seed=100 + T, binary_feasible=False)
     pe_old, pe_new, ps, gm = _state(w, T + 1)
-    r = _run_agent(gpu_lib, w, pe_old, pe_new, ps, gm, mode)
+    pdhg = None
+    if mode == "pdhg_presolve":
+        mode, pdhg = "pdhg", dict(polish=3)
+    r = _run_agent(gpu_lib, w, pe_old, pe_new, ps, gm, mode, pdhg)
     p, s, g, st = ro.home_solve_relaxed(w.cost, oh, pe_old, ps, gm, w.kappa)
     tol = 5e-5
     assert np.abs(r["S"] - p).max() < tol * max(1.0, w.homes["rating"].max())
@@ -219,6 +223,17 @@ def test_pdhg_warm_start(gpu_lib):
     it_cold = (cold["status"] >> 8)[oh.ev].mean()
     it_warm = (again["status"] >> 8)[oh.ev].mean()
     assert it_warm < 0.95 * it_cold, (it_cold, it_warm)
+    # polish bit 1: the KKT steps from the carried multiplier come first; near a solution's own multiplier they
+    # settle (nearly) every residence -- PDHG is not entered for those, the schedule is the same optimum
+    yd3 = torch.zeros(n, dtype=torch.float32, device="cuda:0")
+    first3 = _run_agent(gpu_lib, w, pe_old, pe_new, ps, gm, "pdhg", dict(polish=3), ydual=yd3)
+    assert np.abs(first3["S"] - first["S"]).max() < 5e-5 * 7.2
+    assert ((first3["status"] & 0xFF) == 0).all()
+    again3 = _run_agent(gpu_lib, w, pe_old, pe_new, first3["P_sch"], gm, "pdhg", dict(polish=3), ydual=yd3)
+    assert np.abs(again3["S"] - p).max() < 2e-4 * 7.2
+    assert ((again3["status"] >> 8)[oh.ev] == 0).mean() > 0.9 and ((again3["status"] & 0xFF) == 0).all()
+    # ... and the cold start settles most residences the same way (what is left runs PDHG, then the steps again)
+    assert ((first3["status"] >> 8)[oh.ev] == 0).mean() > 0.5
 
 
 @pytest.mark.parametrize("mode", ["binary", "relaxed_exact", "pdhg"])
