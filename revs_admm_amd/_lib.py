@@ -1,4 +1,5 @@
-"""ctypes binding of librevs_admm.so (include/revs_admm.h).
+"""ctypes binding of librevs_admm.so (include/revs_admm.h: the boundary; include/revs_admm_ops.h: the operator's
+building blocks the Python driver issues one by one).
 
 Loading fails loudly when the library has not been built: nothing in this
 package computes on the CPU instead.
@@ -129,7 +130,7 @@ class RevsError(RuntimeError):
 _p = C.c_void_p
 _i32, _i64, _f32, _f64 = C.c_int32, C.c_int64, C.c_float, C.c_double
 
-# name -> (restype, argtypes); every symbol include/revs_admm.h declares
+# name -> (restype, argtypes); every symbol include/revs_admm.h and include/revs_admm_ops.h declare
 SIGNATURES = {
     "revs_version": (C.c_char_p, []),
     "revs_last_error": (C.c_char_p, []),

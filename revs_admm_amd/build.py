@@ -20,7 +20,7 @@ SOURCES = ["runtime.cpp", "agent_kernels.hip", "operator_kernels.hip", "newton_k
            "gemm_kernels.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "tuning.h"), os.path.join(CSRC, "select_body.h"),
            os.path.join(CSRC, "tree_body.h"), os.path.join(CSRC, "internal.h"),
-           os.path.join(ROOT, "include", "revs_admm.h")]
+           os.path.join(ROOT, "include", "revs_admm.h"), os.path.join(ROOT, "include", "revs_admm_ops.h")]
 
 
 def hipcc() -> str:

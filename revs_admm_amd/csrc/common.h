@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
-#include "revs_admm.h"
+#include "revs_admm_ops.h"      // (includes revs_admm.h, the boundary)
 
 namespace revs {
 

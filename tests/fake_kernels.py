@@ -2,7 +2,7 @@
 host memory, so that the driver in revs_admm_amd/engine.py (sharding, the all-reduce
 of the node aggregate, stopping rules, rho adaptation) can be exercised under
 `gloo` with world_size 2 on a machine without a GPU.  Lives in tests/, is never
-imported by the product, and follows include/revs_admm.h argument for argument.
+imported by the product, and follows include/revs_admm.h / revs_admm_ops.h argument for argument.
 The home solve delegates to the oracle."""
 import ctypes as C
 

@@ -1,5 +1,5 @@
-"""The C-ABI library builds, loads, and exports exactly what include/revs_admm.h
-declares (no compute calls: there is no GPU here)."""
+"""The C-ABI library builds, loads, and exports exactly what include/revs_admm.h (the boundary)
+and include/revs_admm_ops.h (the operator's building blocks) declare (no compute calls: there is no GPU here)."""
 import os
 import re
 
@@ -8,10 +8,13 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_functions():
-    src = open(os.path.join(ROOT, "include", "revs_admm.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(revs_[a-z0-9_]+)\s*\(", src)))
+def header_functions(which=("revs_admm.h", "revs_admm_ops.h")):
+    names = set()
+    for h in which:
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(revs_[a-z0-9_]+)\s*\(", src))
+    return sorted(names)
 
 
 @pytest.fixture(scope="module")
@@ -26,6 +29,16 @@ def test_header_and_binding_agree():
     names = header_functions()
     assert len(names) >= 20
     assert names == sorted(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+
+
+def test_the_boundary_header_holds_no_operator_building_block():
+    """revs_admm.h is what a reference-side binding needs: the sweeps, the individual mode, the plan and its
+    native loops, the communicator.  The launches those loops are made of live in revs_admm_ops.h."""
+    boundary = header_functions(("revs_admm.h",))
+    assert not [n for n in boundary if n.startswith(("revs_op_", "revs_gemm_", "revs_aggregate_"))]
+    assert len(boundary) <= 45, len(boundary)
+    assert {"revs_agent_step", "revs_plan_create", "revs_plan_newton_solve", "revs_plan_stream_run_blocks",
+            "revs_plan_chain_fold_run", "revs_comm_create", "revs_residence_solve"} <= set(boundary)
 
 
 def test_every_declared_symbol_is_exported(lib):
