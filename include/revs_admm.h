@@ -42,8 +42,10 @@ extern "C" {
 #define REVS_DMAX_SLOTS 64
 /* the radial feeder as a tree (documented at revs_tree_voltage below) */
 #define REVS_TREE_MAX 16384
-/* ... of which a launch that judges its own rows (revs_plan_stream_run with block <= 1) and the
- * Newton evaluations' tree form hold this many (one workgroup of 256 threads, 8 positions each) */
+/* ... of which a launch that judges its own rows (revs_plan_stream_run with block <= 1) and the chained
+ * iteration's fused launches (rows + selection + model + step in one workgroup of 256 threads, 8 positions each:
+ * revs_plan_chain_step, revs_plan_chain_fold_run) hold this many.  The Newton evaluations' row launches
+ * (revs_plan_newton_solve, revs_op_dual_rows_tree) take every tree up to REVS_TREE_MAX since round 4. */
 #define REVS_TREE_SWEEP_MAX 2048
 /* rows (constraint nodes) the folded chain's operator launch holds: a slot's multipliers, voltages and
  * violations are staged in one workgroup's LDS (revs_plan_chain_fold_run) */

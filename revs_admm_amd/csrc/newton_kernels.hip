@@ -177,19 +177,21 @@ struct TreeRowsArgs {
 struct NoPrefetch { __device__ void operator()() const {} };
 // after_pack(): the caller's own loads, issued behind the packed indices (the first thing every gather
 // waits for) and in front of everything else
-template <class F = NoPrefetch>
+// NT x IPT: the workgroup's shape (tree_body.h; 256 x 8 inside the fused launches, the bigger ones in
+// op_tree_rows_big_kernel for feeders of more than 2048 nodes)
+template <class F = NoPrefetch, int NT = 256, int IPT = 8>
 __device__ __forceinline__ void tree_rows_body(const TreeRowsArgs &a, const int t, double *lds,
                                                double *rows_lds = nullptr, F &&after_pack = F()) {
-    const int tid = threadIdx.x, j0 = 8 * tid, T = a.T;
+    const int tid = threadIdx.x, j0 = IPT * tid, T = a.T;
     const bool act = j0 < a.tree.n;
     // the positions' packed indices first: every gather below -- multipliers, dual terms, and the node
     // sums inside tree_voltage -- waits for them and for nothing else
-    unsigned long long pk[8];
+    unsigned long long pk[IPT];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) pk[i] = 0ull;
+    for (int i = 0; i < IPT; ++i) pk[i] = 0ull;
     if (act) {
 #pragma unroll
-        for (int i = 0; i < 8; i += 2) {
+        for (int i = 0; i < IPT; i += 2) {
             const TreeU2 u = *reinterpret_cast<const TreeU2 *>(a.tree.pack + j0 + i);
             pk[i] = u.v[0]; pk[i + 1] = u.v[1];
         }
@@ -197,39 +199,39 @@ __device__ __forceinline__ void tree_rows_body(const TreeRowsArgs &a, const int 
     after_pack();
     REVS_KVS(t, 21);
     if (rows_lds)      // (rows without a position in the tree: zero; the scans' barriers order this)
-        for (int i = tid; i < 3 * a.m; i += 256) rows_lds[i] = 0.0;
+        for (int i = tid; i < 3 * a.m; i += NT) rows_lds[i] = 0.0;
     REVS_KVS(t, 22);
 #ifdef REVS_KV_STAMPS
-    asm volatile("" :: "v"(pk[0]), "v"(pk[7]));
+    asm volatile("" :: "v"(pk[0]), "v"(pk[IPT - 1]));
     REVS_KVS(t, 23);
 #endif
     if (a.zero_out)
-        for (int r = tid; r < a.m; r += 256) a.zero_out[(int64_t)r * T + t] = 0.0;
-    double yv[8], qv[8];
+        for (int r = tid; r < a.m; r += NT) a.zero_out[(int64_t)r * T + t] = 0.0;
+    double yv[IPT], qv[IPT];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {           // (positions without a row fetch row 0: masked behind the scans)
+    for (int i = 0; i < IPT; ++i) {           // (positions without a row fetch row 0: masked behind the scans)
         const int s = (int)(pk[i] & 0xFFFFu) - 1;
         yv[i] = a.y[(int64_t)(s >= 0 ? s : 0) * T + t];
         qv[i] = a.es == 4 ? a.qn[4 * ((int64_t)t * a.m + (s >= 0 ? s : 0))] : a.qn[(int64_t)(s >= 0 ? s : 0) * T + t];
     }
-    double v8[8];
+    double v8[IPT];
     REVS_KVS(t, 1);
-    {   // (tree_voltage<256, 8, true, true>, with the node sums' element stride)
-        double wb[8];
-        tree_fetch_w<256, 8>(a.tree, wb);
-        if (a.es == 4) tree_gather_p<256, 8, true>(a.tree, a.p, 4, 4 * t * a.m, pk, v8, nullptr);     // (row stride 4, the slot's block)
-        else tree_gather_p<256, 8, true>(a.tree, a.p, T, t, pk, v8, nullptr);
-        tree_scan<256, 8, true>(a.tree, t, lds, v8, wb, pk);
+    {   // (tree_voltage<NT, IPT, true, true>, with the node sums' element stride)
+        double wb[IPT];
+        tree_fetch_w<NT, IPT>(a.tree, wb);
+        if (a.es == 4) tree_gather_p<NT, IPT, true>(a.tree, a.p, 4, 4 * t * a.m, pk, v8, nullptr);     // (row stride 4, the slot's block)
+        else tree_gather_p<NT, IPT, true>(a.tree, a.p, T, t, pk, v8, nullptr);
+        tree_scan<NT, IPT, true>(a.tree, t, lds, v8, wb, pk);
     }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < IPT; ++i) {
         const bool has = (pk[i] & 0xFFFFu) != 0ull;
         yv[i] = has ? yv[i] : 0.0;
         qv[i] = has ? qv[i] : 0.0;
     }
     double rmax = 0.0, dsum = 0.0, nsup = 0.0, nvio = 0.0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < IPT; ++i) {
         const int s = (int)(pk[i] & 0xFFFFu) - 1;
         if (s >= 0) {
             const int64_t o = (int64_t)s * T + t;
@@ -254,17 +256,27 @@ __device__ __forceinline__ void tree_rows_body(const TreeRowsArgs &a, const int 
     }
     REVS_KVS(t, 6);
     rmax = wave_max_d(rmax); dsum = wave_sum_d(dsum); nsup = wave_sum_d(nsup); nvio = wave_sum_d(nvio);
-    __shared__ double rr[4][4];
+    constexpr int NW = NT / 64;
+    __shared__ double rr[4][NW];
     if ((tid & 63) == 0) { rr[0][tid >> 6] = rmax; rr[1][tid >> 6] = dsum; rr[2][tid >> 6] = nsup; rr[3][tid >> 6] = nvio; }
     __syncthreads();
     if (tid == 0) {
         double *o = a.partial + (int64_t)t * 4;
-        o[0] = fmax(fmax(rr[0][0], rr[0][1]), fmax(rr[0][2], rr[0][3]));
-        o[1] = ((rr[1][0] + rr[1][1]) + rr[1][2]) + rr[1][3];
-        o[2] = ((rr[2][0] + rr[2][1]) + rr[2][2]) + rr[2][3];
-        o[3] = ((rr[3][0] + rr[3][1]) + rr[3][2]) + rr[3][3];
+        double r0 = rr[0][0], r1 = rr[1][0], r2 = rr[2][0], r3 = rr[3][0];        // (wavefront order: fixed)
+#pragma unroll
+        for (int w = 1; w < NW; ++w) { r0 = fmax(r0, rr[0][w]); r1 += rr[1][w]; r2 += rr[2][w]; r3 += rr[3][w]; }
+        o[0] = r0; o[1] = r1; o[2] = r2; o[3] = r3;
         if (rows_lds) { rows_lds[3 * a.m] = o[0]; rows_lds[3 * a.m + 1] = o[1]; rows_lds[3 * a.m + 2] = o[2]; rows_lds[3 * a.m + 3] = o[3]; }
     }
+}
+
+// Rows by the tree form for feeders of more than 2048 nodes (the shapes of tree_body.h: 512 x 8, 1024 x 8, 1024 x 16):
+// v, violations and the slot's four sums to global memory; the selection follows as its own launch
+// (op_dual_select_kernel, nblk = 1).
+template <int NT, int IPT>
+__global__ __launch_bounds__(NT) void op_tree_rows_big_kernel(const TreeRowsArgs ta) {
+    extern __shared__ double tree_lds[];
+    tree_rows_body<NoPrefetch, NT, IPT>(ta, blockIdx.x, tree_lds);
 }
 
 // rows by the tree form, then (SELECT) the candidate selection of the same slot in the same workgroup
@@ -1969,8 +1981,22 @@ extern "C" int revs_op_dual_step_pending(int32_t T, const int64_t *cand_idx, con
     return REVS_OK;
 }
 
-static bool tree_ok(const revs_tree_t *tree) {
+static bool tree_ok(const revs_tree_t *tree) {       // the fused launches: one workgroup of 256 x 8 positions per slot
     return tree && tree->n > 0 && tree->n <= REVS_TREE_SWEEP_MAX && tree->n % 8 == 0 && tree->pack && tree->w;
+}
+static bool tree_ok_big(const revs_tree_t *tree) {   // the evaluations' row launches: every shape of tree_body.h
+    return tree && tree->n > 0 && tree->n <= REVS_TREE_MAX && tree->n % tree_shape(tree->n).ipt == 0 && tree->pack && tree->w;
+}
+template <int NT, int IPT, typename K>
+static bool rows_big_lds(K kernel, size_t lds) {     // more than 64 KB of dynamic LDS is granted per kernel, once
+    if (lds <= 64 * 1024) return true;
+    static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+        revs::set_error("revs_op_dual_rows_tree: %zu bytes of LDS refused: %s", lds, hipGetErrorString(e));
+        return false;
+    }
+    return true;
 }
 
 extern "C" int revs_op_dual_rows_tree(int32_t m, int32_t T, const revs_tree_t *tree, const double *pnq,
@@ -1978,13 +2004,33 @@ extern "C" int revs_op_dual_rows_tree(int32_t m, int32_t T, const revs_tree_t *t
                                       double *viol, double *partial, double *zero_out, int64_t *cand_idx,
                                       int32_t *cand_cnt, double *cand_val, double *stats, double seq,
                                       int32_t with_select, void *stream) {
-    REVS_REQUIRE(m > 0 && m <= 16384 && T > 0 && T <= 256 && tree_ok(tree) && pnq && y && vfull && viol &&
+    REVS_REQUIRE(m > 0 && m <= 16384 && T > 0 && T <= 256 && tree_ok_big(tree) && pnq && y && vfull && viol &&
                  partial && vlo <= vhi && kadd >= 0 && zero_out != pnq &&
                  (!with_select || (cand_idx && cand_cnt && cand_val && stats)),
-                 "revs_op_dual_rows_tree: bad argument (tree nodes <= %d)", REVS_TREE_SWEEP_MAX);
+                 "revs_op_dual_rows_tree: bad argument (tree nodes <= %d, a multiple of 8; of 16 beyond 8192)", REVS_TREE_MAX);
     const TreeArgs tr{tree->n, (const unsigned long long *)tree->pack, tree->w};
     const TreeRowsArgs ta{tr, m, T, pnq, pnq + 2 * (int64_t)m * T, y, vlo, vhi, vfull, viol, partial, zero_out};
     const SelectArgs sa{m, T, 1, kadd, partial, y, vfull, viol, vlo, vhi, seq, cand_idx, cand_cnt, cand_val, stats};
+    if (tree->n > REVS_TREE_SWEEP_MAX) {
+        // more than 2048 nodes: the rows by a workgroup of 512 or 1024 threads per slot, the selection behind it
+        const size_t lds = tree_lds_bytes(tree->n);
+        const TreeShape sh = tree_shape(tree->n);
+#define RK(NT, IPT)                                                                                           \
+        do {                                                                                                  \
+            if (!rows_big_lds<NT, IPT>(op_tree_rows_big_kernel<NT, IPT>, lds)) return REVS_ELAUNCH;           \
+            hipLaunchKernelGGL((op_tree_rows_big_kernel<NT, IPT>), dim3(T), dim3(NT), lds, S_(stream), ta);   \
+        } while (0)
+        if (sh.nt == 512) RK(512, 8);
+        else if (sh.ipt == 8) RK(1024, 8);
+        else RK(1024, 16);
+#undef RK
+        REVS_CHECK_LAUNCH("revs_op_dual_rows_tree");
+        if (with_select) {
+            hipLaunchKernelGGL(op_dual_select_kernel, dim3(T), dim3(256), 0, S_(stream), sa);
+            REVS_CHECK_LAUNCH("revs_op_dual_rows_tree (selection)");
+        }
+        return REVS_OK;
+    }
     if (with_select) {
         // (the rows go to the selection through LDS where they fit: vfull / viol are scratch of this call then)
         const size_t staged_lds = ((tree_lds_bytes(tree->n) / sizeof(double) + 1) / 2 * 2 + 3 * (size_t)m + 4) * sizeof(double);
@@ -2110,8 +2156,8 @@ extern "C" int revs_op_dual_evaluate_tree(int32_t phase, int32_t m, int32_t T, c
                                           float *p_est_new, double *vfull, double *viol, double *partial,
                                           int64_t *cand_idx, int32_t *cand_cnt, double *cand_val,
                                           double *stats, double seq, void *stream) {
-    REVS_REQUIRE(tree_ok(tree), "revs_op_dual_evaluate_tree: bad tree (at most %d nodes, a multiple of 8)",
-                 REVS_TREE_SWEEP_MAX);
+    REVS_REQUIRE(tree_ok_big(tree), "revs_op_dual_evaluate_tree: bad tree (at most %d nodes, a multiple of 8; of 16 beyond 8192)",
+                 REVS_TREE_MAX);
     return dual_evaluate_impl(phase, m, T, node_ptr, p_est, p_sch, gamma, R, nullptr, y, use_y, kappa, vlo, vhi,
                               kadd, ksplit, d_slabs, nullptr, pnq, p_est_new, vfull, viol, partial, cand_idx,
                               cand_cnt, cand_val, stats, seq, nullptr, tree, stream);

@@ -347,7 +347,7 @@ extern "C" int revs_plan_chain_step(revs_plan_t *plan, const double *y, double *
     double *const st[2] = {d.stats, d.stats1};
     const double scale = std::max(std::max(std::fabs(d.vlo), std::fabs(d.vhi)), 1e-300);
     const int nb32 = (d.m + 31) / 32;
-    const int sel_nblk = (d.T <= 32 && nb32 <= 256) ? nb32 : 0;
+    int sel_nblk = (d.T <= 32 && nb32 <= 256) ? nb32 : 0;
     // home pass of an evaluation of multipliers yy: row-wise from the lists of set `sup`, or dense
     auto home_pass = [&](const double *yy, int uy, int sup) -> int {
         if (uy && sup >= 0)
@@ -359,7 +359,15 @@ extern "C" int revs_plan_chain_step(revs_plan_t *plan, const double *y, double *
                                      st[0], 0.0, nullptr, stream);
     };
     // product R p and the row bookkeeping; the selection is left to the next launch
+    // (a feeder of more than REVS_TREE_SWEEP_MAX nodes: the fused launches below do not hold it, its rows still come
+    // from the tree form -- one block of partial sums per slot)
+    const bool big_tree = plan->tree.n > REVS_TREE_SWEEP_MAX;
+    const revs_tree_t trb{plan->tree.n, (const uint64_t *)plan->tree.pack, plan->tree.w};
+    if (big_tree) sel_nblk = 1;
     auto rows = [&](const double *yy, int uy, int k) -> int {
+        if (big_tree)
+            return revs_op_dual_rows_tree(d.m, d.T, &trb, d.pnq, yy, d.vlo, d.vhi, d.kadd, d.vfull, d.viol, d.partial,
+                                          nullptr, ci[k], cc[k], cv[k], st[k], 0.0, 0, stream);
         return revs_op_dual_evaluate(2 | 4, d.m, d.T, d.node_ptr, p_est, p_sch, gamma, d.R, d.Rt, yy, uy,
                                      d.kappa, d.vlo, d.vhi, d.kadd, d.ksplit, d.d_slabs, d.v_slabs,
                                      d.pnq, p_est_new, d.vfull, d.viol, d.partial, ci[k], cc[k], cv[k],
@@ -501,7 +509,7 @@ extern "C" int revs_plan_newton_solve(revs_plan_t *plan, revs_newton_state_t *st
     const double *const sh[2] = {d.stats_host, d.stats1_host};
     const double scale = std::max(std::max(std::fabs(d.vlo), std::fabs(d.vhi)), 1e-300);
     const int64_t mt = (int64_t)d.m * T;
-    const bool tf = plan->tree.n > 0 && plan->tree.n <= REVS_TREE_SWEEP_MAX;     // rows by the tree form of R p
+    const bool tf = plan->tree.n > 0;     // rows by the tree form of R p (every shape: revs_op_dual_rows_tree)
     const revs_tree_t trh{plan->tree.n, (const uint64_t *)plan->tree.pack, plan->tree.w};
     double *ycur = st->y, *ytrial = st->y_trial;
     // One evaluation of multipliers yy (p, N, D, the voltage rows, candidate lists and stats into set k; P_est_new =

@@ -411,7 +411,8 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
         self._burst = max(1, int(self.op.stream_burst))
         self._p_clear = None             # the node-sum array the last streaming launch cleared
         self._tree = None
-        self._tree_newton = False        # Newton evaluations judge their rows by the tree form too
+        self._tree_newton = False        # the fused launches of the chained iteration hold the tree (256 x 8 positions)
+        self._tree_eval = False          # Newton evaluations judge their rows by the tree form (every shape)
         self._comm = None
         recovered = False
         if (feeder is None and self.op.voltage in ("auto", "tree") and M <= 4096 and self.op.solver == "newton"
@@ -447,6 +448,7 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
                     check(self.lib.revs_plan_set_tree(self._plan, C.byref(self._tree)),
                           "revs_plan_set_tree")
                     self._tree_newton = tr["n"] <= _lib.TREE_SWEEP_MAX
+                    self._tree_eval = True
             elif self.op.voltage == "tree":
                 raise ValueError(f"feeder has {len(par)} nodes; the tree form holds {_lib.TREE_MAX}")
         elif self.op.voltage == "tree":

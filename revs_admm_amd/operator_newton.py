@@ -25,7 +25,7 @@ class DualNewtonMixin:
         if (phase & 2) and not (phase & 4):
             self._eval_seq += 1.0
             tag = self._pending_tag[k] = self._eval_seq + 0.5
-        if self._tree_newton and self._tree is not None:
+        if self._tree_eval and self._tree is not None:
             # the feeder as a tree: R p and the rows of every slot in O(nodes), one workgroup per slot
             check(lib.revs_op_dual_evaluate_tree(
                 phase, M, T, ptr(self.node_ptr), ptr(self.P_est), ptr(self.P_sch), ptr(self.G),
@@ -280,8 +280,8 @@ class DualNewtonMixin:
         # sequence tag the last selection writes)
         nb = (M + 31) // 32
         nb = nb if (T <= 32 and nb <= 256) else 0
-        tf = self._tree_newton and self._tree is not None          # rows by the tree form of R p
-        if tf:
+        tf = self._tree_newton and self._tree is not None          # rows by the tree form of R p, fused launches
+        if self._tree_eval and self._tree is not None:             # (one block of partial sums per slot)
             nb = 1
         use_y = self._y_support
         if use_y and self._sup is not None:       # as _dual_launch, the selection left out

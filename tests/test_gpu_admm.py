@@ -689,9 +689,10 @@ def test_streaming_steady_state_equals_dense_product_path(gpu_lib, mode, stress,
     a = _engine(w, mode, op=OperatorOptions(voltage="dense"))
     b = _engine(w, mode, op=OperatorOptions(voltage="tree", stream_burst=3, stream_burst_max=24))
     assert a._tree is None and b._tree is not None
-    # (feeders of more than REVS_TREE_SWEEP_MAX nodes: the verdict launches use the bigger workgroup
-    # shapes, the Newton evaluations keep the dense product)
-    assert b._tree_newton == (nodes <= 2048) and b._block == 32
+    # (feeders of more than REVS_TREE_SWEEP_MAX nodes: the verdict launches AND -- round 4 -- the Newton
+    # evaluations' row launches use the bigger workgroup shapes; only the chained iteration's fused launches
+    # are 256 x 8 positions)
+    assert b._tree_newton == (nodes <= 2048) and b._tree_eval and b._block == 32
     for chunk in (1, 7, 30, 2, 50):
         a.run_steps(chunk)
         b.run_steps(chunk)

@@ -556,6 +556,77 @@ def test_tree_voltage_matches_dense_product(gpu_lib, case, golden, feeder_R):
     assert (want > 0).any()
 
 
+@pytest.mark.parametrize("M,T", [(2048, 24), (4096, 24), (8192, 6), (12001, 5)])
+def test_rows_by_the_tree_form_equal_the_dense_rows(gpu_lib, M, T):
+    """The second half of a Newton evaluation -- voltages of the node sums, violations, the slot's four sums, the
+    candidate lists -- by the tree form of R p (revs_op_dual_rows_tree: 256 x 8 positions per workgroup up to
+    2048 nodes with the selection in the same launch; 512 x 8, 1024 x 8, 1024 x 16 beyond, round 4, with the
+    selection behind it) against the dense f64 product on the matrix cores (revs_op_dual_evaluate, phase 2):
+    same voltages to 1e-12 relative, same sums, same lists."""
+    import ctypes as C
+    import torch
+    from revs_admm_amd import _lib
+    from revs_admm_amd.engine import feeder_tree
+    from revs_admm_amd.synthetic import make_workload
+    rng = np.random.default_rng(M)
+    w = make_workload(max(M * 3, 10), 24, n_nodes=M, seed=4)
+    par, er, cons = w.feeder
+    Rn = w.Rn
+    tr = feeder_tree(par, er, cons, np.ones(M, bool))
+    pnq = np.zeros((3, M, T))
+    pnq[0] = rng.uniform(0.0, 4.0, (M, T))
+    pnq[1] = rng.integers(0, 5, (M, T))
+    pnq[2] = -rng.uniform(0.0, 30.0, (M, T))
+    ref = Rn @ pnq[0]
+    vhi, vlo = float(np.quantile(ref, 0.995)), float(np.quantile(ref, 0.002))
+    y = np.zeros((M, T))
+    for t in range(T):
+        rows = rng.choice(M, 4, replace=False)
+        y[rows, t] = rng.normal(0, 200.0, 4)
+    kadd, ks, kappa = 6, 4, 5.0
+    dev = "cuda:0"
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d = {"pack": up(tr["pack"].view(np.int64)), "w": up(tr["w"])}
+    tree = _lib.Tree(tr["n"], d["pack"].data_ptr(), d["w"].data_ptr())
+    dpnq, dy, dRt = up(pnq), up(y), up(np.ascontiguousarray(Rn.T))
+    nblk = int(gpu_lib.revs_op_dual_blocks(M))
+    out = {}
+    for which in ("dense", "tree"):
+        z = lambda shape, dt=torch.float64: torch.zeros(shape, dtype=dt, device=dev)
+        b = dict(vfull=z((M, T)), viol=z((M, T)), part=z((nblk, T, 4)), cidx=z((T, A), torch.int64),
+                 ccnt=z((T,), torch.int32), cval=z((T, 3, A)), stats=z((T, 8)), v_sl=z((ks, M, T)))
+        q = lambda t: t.data_ptr()
+        if which == "dense":
+            _lib.check(gpu_lib.revs_op_dual_evaluate(
+                2, M, T, None, None, None, None, None, q(dRt), q(dy), 1, kappa, vlo, vhi, kadd, ks, None,
+                q(b["v_sl"]), q(dpnq), None, q(b["vfull"]), q(b["viol"]), q(b["part"]), q(b["cidx"]), q(b["ccnt"]),
+                q(b["cval"]), q(b["stats"]), 3.0, None, None), "revs_op_dual_evaluate")
+        else:
+            _lib.check(gpu_lib.revs_op_dual_rows_tree(
+                M, T, C.byref(tree), q(dpnq), q(dy), vlo, vhi, kadd, q(b["vfull"]), q(b["viol"]), q(b["part"]), None,
+                q(b["cidx"]), q(b["ccnt"]), q(b["cval"]), q(b["stats"]), 3.0, 1, None), "revs_op_dual_rows_tree")
+        torch.cuda.synchronize()
+        out[which] = {k: v.cpu().numpy() for k, v in b.items()}
+    a_, b_ = out["dense"], out["tree"]
+    scale = np.abs(ref).max()
+    sa, sb = a_["stats"], b_["stats"]
+    # the slot's sums: largest row residual, the dual value's terms, supports, violated rows; tag
+    np.testing.assert_allclose(sb[:, 0], sa[:, 0], rtol=0, atol=1e-12 * scale)
+    np.testing.assert_allclose(sb[:, 1], sa[:, 1], rtol=1e-12)
+    np.testing.assert_array_equal(sb[:, 2:4], sa[:, 2:4])
+    assert (sb[:, 5] == 3.0).all() and (sa[:, 5] == 3.0).all()
+    assert (sa[:, 3] > 0).all() and (sa[:, 2] == 4).all()
+    np.testing.assert_array_equal(b_["ccnt"], a_["ccnt"])
+    for t in range(T):
+        n = int(a_["ccnt"][t])
+        np.testing.assert_array_equal(b_["cidx"][t, :n], a_["cidx"][t, :n])
+        np.testing.assert_allclose(b_["cval"][t, :, :n], a_["cval"][t, :, :n], rtol=0, atol=1e-12 * max(scale, 200.0))
+    if M <= 2048:
+        return                        # (rows staged in LDS: vfull / viol are scratch there)
+    np.testing.assert_allclose(b_["vfull"], a_["vfull"], rtol=0, atol=1e-12 * scale)
+    np.testing.assert_allclose(b_["viol"], a_["viol"], rtol=0, atol=1e-12 * scale)
+
+
 @pytest.mark.gpu
 def test_wavefront_reductions_keep_the_butterfly_bits(gpu_lib, tmp_path):
     """wave_sum_d (common.h: v_permlane32_swap / v_permlane16_swap + DPP row rotations) must give the xor

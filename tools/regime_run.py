@@ -25,12 +25,13 @@ ap.add_argument("--nodes", type=int, default=2048)
 ap.add_argument("--steps", type=int, default=300)
 ap.add_argument("--spin", type=int, default=60)
 ap.add_argument("--kadd", type=int, default=None, help="violated rows admitted to a slot's model per Newton iteration")
+ap.add_argument("--voltage", default="auto", help="auto (tree form where the feeder is known) | dense (the f64 product on the matrix cores)")
 a = ap.parse_args()
 mode, stress = {"binding": ("pdhg", 1.3), "binary": ("binary", 1.0), "steady": ("pdhg", 1.0)}[a.regime]
 w = make_workload(a.homes, a.T, n_nodes=a.nodes, seed=0, binary_feasible=(mode == "binary"), stress=stress)
 e = AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, kappa=w.kappa, vset=w.vset, vlow=w.vlow,
                vhigh=w.vhigh, mode=mode, feeder=w.feeder,
-               op=OperatorOptions(**({"newton_kadd": a.kadd} if a.kadd is not None else {})))
+               op=OperatorOptions(voltage=a.voltage, **({"newton_kadd": a.kadd} if a.kadd is not None else {})))
 e.run_steps(a.spin)
 torch.cuda.synchronize()
 c0, s0 = list(e.chain_hist), list(e.spec_hist)
