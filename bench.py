@@ -34,11 +34,16 @@ residences and the 125 000 x 96 shape of BASELINE config 4 are measured in the s
 reported as first-class fields beside the headline.
 
 Prints ONE JSON line (rank 0).  `value` = home-QP solves per second, whole job, inputs resident
-in HBM.  `roofline`: the sweep kernel against HBM -- algorithmic bytes per launch / average
+in HBM, from the MEDIAN of `--bursts` (15) timed regions of exactly `--steps` iterations each (every one
+bracketed by barrier + synchronize; all listed in `bursts_ms_per_step`); `value_ev_only` counts the residences
+with an EV alone (adoption is stated in config.workload); `value_kkt_presolve`: the same regime with
+revs_pdhg_t::polish = 3 (KKT steps from the carried multiplier before PDHG, which then is not entered);
+`value_feeder_121144`: the reference's own feeder, 15 iterations, on/off chargers, the oracle timed beside it;
+`collective` (N > 1): the block all-reduce's duration beside its block of sweeps.  `roofline`: the sweep kernel against HBM -- algorithmic bytes per launch / average
 launch duration from two HIP events around the timed region on its stream / sweep launches in it;
 `roofline_valu`: the same kernel against VALU issue (what bounds it since round 3);
 `roofline_binding`: the binding regime's launches; `roofline_matvec`: the f64 matrix-core product
-R p (feeders given only as a matrix); `cpu_baseline`: the oracle's vectorised home QP over all
+R p (feeders that are not radial); `roofline_125k_T96`: config 4's per-GPU shape from the committed PMC passes; `cpu_baseline`: the oracle's vectorised home QP over all
 residences on this box's cores (one process per core) plus the operator's voltage product, same
 state, same run.
 """
