@@ -20,6 +20,7 @@
 // Arithmetic: float (BASELINE north star); the per-home residual terms (diff, dsq) are
 // summed in double by the residual kernels on request, which also take the maximum of
 // diff over all homes (the reference's only convergence measure).
+#define REVS_AGENT_TU
 #include "common.h"
 #include "select_body.h"
 #include "tree_body.h"
@@ -1301,10 +1302,12 @@ struct BlockVerdict {
     double *hand_over;                    // NULL, or where the call's last slice (ring slice nb - (pre != NULL)) is copied to
     double vlo, vhi, vtol;
     unsigned long long *grp_bits;         // [nb] device words, zero on entry and on exit
+    unsigned long long *grp_arrive;       // [nb + 1] device words (low halves: arrival counts), zero on entry and on exit
     double *grp_dmax;                     // [ndmax] device words
     double *rec;                          // the record ring (device address of pinned memory)
 };
-constexpr int kHandOverGroups = 8;        // workgroups that copy the call's last slice to the caller
+constexpr int kHandOverGroups = 32;       // workgroups that copy the call's last slice to the caller
+constexpr int kGrpWords = REVS_STREAM_BLOCK_MAX + 4;   // per-slice words (+ the call's first iteration, + the handed-over slice)
 // Workgroup (g, t): slot t of slice g -- it clears what it has read, so the slice is ready for the
 // block that accumulates into it next; workgroup t == 0 of a ring slice also folds (and clears)
 // the slice's tail -- the partial maxima of diff that the sweep which produced the slice left,
@@ -1313,11 +1316,15 @@ constexpr int kHandOverGroups = 8;        // workgroups that copy the call's las
 // call's last slice (its rows are the next call's to judge) to the caller's array, clear it, and
 // fold its tail.  The last workgroup to finish writes the records {rmax, failed, seq, max diff
 // of the iteration before} and the lowest failed number into the control word.
-template <int NT, int IPT>
+// PAIR: a workgroup judges the slots 2 t and 2 t + 1 of its slice (tree_rmax_pair: half the scattered requests); the
+// host picks it where T is even and the arrays are 16-byte aligned.
+template <int NT, int IPT, bool PAIR = false>
 __global__ __launch_bounds__(NT) void stream_block_verdict_kernel(const BlockVerdict b) {
     extern __shared__ double tree_lds[];
     const int tid = threadIdx.x;
-    const int njudge = b.nb * b.T, npre = b.pre ? 1 : 0;
+    VD_STAMP(0);
+    const int per_slice = PAIR ? b.T / 2 : b.T;                 // workgroups per slice
+    const int njudge = b.nb * per_slice, npre = b.pre ? 1 : 0;
     const bool extra = (int)blockIdx.x >= njudge;
     // (the tree's static data are requested in front of the control word's test: one round trip, not two)
     unsigned long long pk0[IPT];
@@ -1338,7 +1345,8 @@ __global__ __launch_bounds__(NT) void stream_block_verdict_kernel(const BlockVer
         const unsigned int bad = b.ctl->bad_seq;
         if (bad >= b.base_seq && bad <= b.gate_seq) return;
     }
-    const int g = extra ? b.nb : (int)blockIdx.x / b.T, t = extra ? (int)blockIdx.x - njudge : (int)blockIdx.x - g * b.T;
+    VD_STAMP(1);
+    const int g = extra ? b.nb : (int)blockIdx.x / per_slice, t = extra ? (int)blockIdx.x - njudge : (int)blockIdx.x - g * per_slice;
     double *slice = b.ring + (long long)(g - npre) * b.stride;       // (g == 0 with pre: not a ring slice)
     const bool ring_slice = !(b.pre && g == 0);
     __shared__ double dm_s[NT / 64];
@@ -1357,27 +1365,54 @@ __global__ __launch_bounds__(NT) void stream_block_verdict_kernel(const BlockVer
     }
     double rmax = 0.0;
     if (!extra) {
-        rmax = ring_slice ? tree_rmax<NT, IPT, true>(b.tree, slice, b.T, t, b.vlo, b.vhi, tree_lds, nullptr, slice, pk0, wgt0)
-                          : tree_rmax<NT, IPT, true>(b.tree, b.pre, b.T, t, b.vlo, b.vhi, tree_lds, nullptr, nullptr, pk0, wgt0);
+        if constexpr (PAIR)
+            rmax = ring_slice ? tree_rmax_pair<NT, IPT>(b.tree, slice, b.T, 2 * t, b.vlo, b.vhi, tree_lds, slice, pk0, wgt0)
+                              : tree_rmax_pair<NT, IPT>(b.tree, b.pre, b.T, 2 * t, b.vlo, b.vhi, tree_lds, nullptr, pk0, wgt0);
+        else
+            rmax = ring_slice ? tree_rmax<NT, IPT, true>(b.tree, slice, b.T, t, b.vlo, b.vhi, tree_lds, nullptr, slice, pk0, wgt0)
+                              : tree_rmax<NT, IPT, true>(b.tree, b.pre, b.T, t, b.vlo, b.vhi, tree_lds, nullptr, nullptr, pk0, wgt0);
     } else {
+        // (eight loads in flight per trip: one element per trip made this loop the launch -- 24 dependent round
+        // trips, ~20 us of the 29 us a burst's verdict launch took)
         const long long per = (b.mt + kHandOverGroups - 1) / kHandOverGroups;
         const long long i0 = t * per, i1 = i0 + per < b.mt ? i0 + per : b.mt;
-        for (long long i = i0 + tid; i < i1; i += NT) { b.hand_over[i] = slice[i]; slice[i] = 0.0; }
+        for (long long ib = i0 + tid; ib < i1; ib += 8 * NT) {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = ib + q * NT < i1 ? slice[ib + q * NT] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (ib + q * NT < i1) { b.hand_over[ib + q * NT] = v[q]; slice[ib + q * NT] = 0.0; }
+        }
     }
     __shared__ int last_s;
     __shared__ unsigned int bad_s;
+    VD_STAMP(2);
     if (tid == 0) {
         if (!extra)
             __hip_atomic_fetch_max(&b.grp_bits[g], (unsigned long long)__double_as_longlong(rmax),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // performed before this workgroup is counted
-        const unsigned int old = __hip_atomic_fetch_add(&b.ctl->arrive, 1u, __ATOMIC_RELAXED,
-                                                        __HIP_MEMORY_SCOPE_AGENT);
-        last_s = old == gridDim.x - 1u;
+        // Arrivals in two levels: the T workgroups of a slice (the hand-over groups: a group of their own) count
+        // on the slice's word, the last of them on the launch's -- several hundred adds on ONE word are a serial
+        // chain of ~12 ns each at the end of a launch that a short burst has nothing to hide behind (776
+        // workgroups for a block of 32: 9 us; now 24 + 33 in a row).
+        unsigned int *const mine = reinterpret_cast<unsigned int *>(b.grp_arrive + g);
+        const unsigned int members = extra ? (unsigned int)kHandOverGroups : (unsigned int)per_slice;
+        const unsigned int old1 = __hip_atomic_fetch_add(mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = 0;
+        if (old1 == members - 1u) {
+            __hip_atomic_store(mine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int old = __hip_atomic_fetch_add(&b.ctl->arrive, 1u, __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT);
+            last_s = old == (unsigned int)(b.nb + (b.hand_over ? 1 : 0)) - 1u;
+        }
         bad_s = 0xFFFFFFFFu;
     }
+    VD_STAMP(3);
     __syncthreads();
     if (!last_s) return;
+    VD_STAMP(4);
     for (int q = tid; q < b.ndmax; q += NT) {
         const bool judged = q < b.nb;
         double r = 0.0;
@@ -1404,7 +1439,15 @@ __global__ __launch_bounds__(NT) void stream_block_verdict_kernel(const BlockVer
             __hip_atomic_store(&b.ctl->bad_seq, bad_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&b.ctl->arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    VD_STAMP(5);
 }
+#ifdef REVS_VD_STAMPS
+}  // namespace revs
+extern "C" int revs_tuning_verdict_stamps(double *out_host) {
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(revs::g_vd_stamps), sizeof(double) * 1024 * 8) == hipSuccess ? 0 : -1;
+}
+namespace revs {
+#endif
 
 int stream_block_verdict(StreamCtl *ctl, unsigned int base_seq, unsigned int gate_seq,
                          unsigned int first_seq, int32_t nb, int32_t T, const TreeArgs &tree,
@@ -1415,11 +1458,19 @@ int stream_block_verdict(StreamCtl *ctl, unsigned int base_seq, unsigned int gat
                  tree.n <= REVS_TREE_MAX && tree.n % tree_shape(tree.n).ipt == 0 && tree.pack && tree.w && ring && stride >= mt + ntail &&
                  mt > 0 && ntail >= 0 && vlo <= vhi && vtol >= 0.0 && grp_bits && grp_dmax && rec &&
                  (!pre || nb >= 1), "stream_block_verdict: bad argument");
+    // (the arrival words follow the maxima: revs_plan_set_stream_block allocates both halves)
     const BlockVerdict b{ctl, base_seq, gate_seq, first_seq, nb, T, nb + (hand_over ? 1 : 0), tree, pre, ring,
-                         (long long)stride, mt, ntail, hand_over, vlo, vhi, vtol, grp_bits, grp_dmax, rec};
-    const dim3 grid((unsigned)(nb * T + (hand_over ? kHandOverGroups : 0)));
+                         (long long)stride, mt, ntail, hand_over, vlo, vhi, vtol, grp_bits, grp_bits + kGrpWords, grp_dmax, rec};
     const size_t lds = tree_lds_bytes(tree.n);
     const TreeShape sh = tree_shape(tree.n);
+    // two slots per workgroup where a 16-byte request can fetch them (the 256 x 8 shape: registers)
+    const bool pair = sh.nt == 256 && T % 2 == 0 && stride % 2 == 0 && ((uintptr_t)ring & 15u) == 0 && (!pre || ((uintptr_t)pre & 15u) == 0);
+    const dim3 grid((unsigned)(nb * (pair ? T / 2 : T) + (hand_over ? kHandOverGroups : 0)));
+    if (pair) {
+        hipLaunchKernelGGL((stream_block_verdict_kernel<256, 8, true>), grid, dim3(256), lds, (hipStream_t)stream, b);
+        REVS_CHECK_LAUNCH("stream_block_verdict");
+        return REVS_OK;
+    }
 #define VK(NT, IPT)                                                                                            \
     do {                                                                                                       \
         if (!tree_big_lds<NT, IPT>(stream_block_verdict_kernel<NT, IPT>, lds)) return REVS_ELAUNCH;            \

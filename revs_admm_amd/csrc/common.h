@@ -313,7 +313,7 @@ __device__ __forceinline__ float clip3(float v, float lo, float hi) {
 }  // namespace revs
 
 // Stage stamps of the latency-bound operator launches exist in tuning builds only (csrc/tuning.h, never included by
-// the product build: python -m revs_admm_amd.build --out tune/lib.so -DREVS_TUNING -DREVS_KV_STAMPS | -DREVS_BPP_STAMPS)
+// the product build: python -m revs_admm_amd.build --out tune/lib.so -DREVS_TUNING -DREVS_KV_STAMPS | -DREVS_BPP_STAMPS | -DREVS_VD_STAMPS)
 #ifdef REVS_TUNING
 #include "tuning.h"
 #else
@@ -321,4 +321,5 @@ __device__ __forceinline__ float clip3(float v, float lo, float hi) {
 #define REVS_KVS(t, i) do { } while (0)
 #define REVS_KVV(t, i, val) do { } while (0)
 #define BPP_STAMP(i) do { } while (0)
+#define VD_STAMP(i) do { } while (0)
 #endif

@@ -1259,8 +1259,8 @@ extern "C" int revs_plan_set_stream_block(revs_plan_t *plan, int32_t block, int3
     REVS_REQUIRE(d.recompute_pe_new, "revs_plan_set_stream_block: verdicts by blocks need recompute_pe_new");
     if (!plan->grp_bits) {
         const size_t gb = sizeof(unsigned long long) * (REVS_STREAM_BLOCK_MAX + 4);   // (+ the call's first iteration, + the handed-over slice)
-        hipError_t e = hipMalloc((void **)&plan->grp_bits, gb);
-        if (e == hipSuccess) e = hipMemset(plan->grp_bits, 0, gb);
+        hipError_t e = hipMalloc((void **)&plan->grp_bits, 2 * gb);                    // (maxima, then the slices' arrival words)
+        if (e == hipSuccess) e = hipMemset(plan->grp_bits, 0, 2 * gb);
         if (e == hipSuccess) e = hipMalloc((void **)&plan->grp_dmax, gb);
         if (e == hipSuccess) e = hipMemset(plan->grp_dmax, 0, gb);
         if (e == hipSuccess && !plan->side) e = hipStreamCreateWithFlags(&plan->side, hipStreamNonBlocking);

@@ -261,6 +261,61 @@ __device__ __forceinline__ double tree_rmax(const TreeArgs &tr, const double *p,
     return r;
 }
 
+// tree_rmax for the slots t and t + 1 (t even, T even, p 16-byte aligned) of one array in one workgroup: ONE 16-byte
+// request per position fetches both slots' node sums, and one clears them -- the verdict launches are bound by the
+// rate of scattered lane requests (2048 gathers and 2048 clearing stores of 8 bytes per slot: ~2.7 cycles each through
+// a compute unit's texture path; 800 workgroups of a block of 32 took 42 us), not by the scans.  The scans of the
+// two slots run one after the other on the same LDS.  Returns max(rmax_t, rmax_t+1).
+template <int NT, int IPT>
+__device__ __forceinline__ double tree_rmax_pair(const TreeArgs &tr, const double *p, int T, int t, double vlo, double vhi,
+                                                 double *lds, double *p_clear, const unsigned long long *pk_pre,
+                                                 const double *wgt_pre) {
+    const int tid = threadIdx.x;
+    const bool act = IPT * tid < tr.n;
+    double *red1 = lds + 2 + NT * IPT + NT / 64;
+    unsigned long long pk[IPT];
+    double a0[IPT], a1[IPT], b[IPT];
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) { pk[i] = pk_pre[i]; a0[i] = 0.0; a1[i] = 0.0; }
+    if (act) {
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {       // (positions without a row fetch row 0: masked by the scans)
+            const int s = (int)(pk[i] & 0xFFFFu) - 1;
+            const TreeD2 v = *reinterpret_cast<const TreeD2 *>(p + (int64_t)(s >= 0 ? s : 0) * T + t);
+            a0[i] = v.v[0]; a1[i] = v.v[1];
+        }
+    }
+    double rmax = 0.0;
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) b[i] = wgt_pre[i];
+    tree_scan<NT, IPT, true>(tr, t, lds, a0, b, pk);
+#pragma unroll
+    for (int i = 0; i < IPT; ++i)
+        if ((pk[i] & 0xFFFFu) != 0ull) rmax = fmax(rmax, fmax(fmax(a0[i] - vhi, vlo - a0[i]), 0.0));
+    __syncthreads();                                            // (the first slot's last LDS reads are done)
+#pragma unroll
+    for (int i = 0; i < IPT; ++i) b[i] = wgt_pre[i];
+    tree_scan<NT, IPT, true>(tr, t + 1, lds, a1, b, pk);
+#pragma unroll
+    for (int i = 0; i < IPT; ++i)
+        if ((pk[i] & 0xFFFFu) != 0ull) rmax = fmax(rmax, fmax(fmax(a1[i] - vhi, vlo - a1[i]), 0.0));
+    rmax = wave_max_d(rmax);
+    __syncthreads();                                            // (red1 was the scans': every read is done)
+    if ((tid & 63) == 0) red1[tid >> 6] = rmax;
+    __syncthreads();
+    double r = red1[0];
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) r = fmax(r, red1[w]);
+    if (p_clear && act) {                       // (behind everything: the stores are off the verdict's path)
+#pragma unroll
+        for (int i = 0; i < IPT; ++i) {
+            const int s = (int)(pk[i] & 0xFFFFu) - 1;
+            if (s >= 0) *reinterpret_cast<TreeD2 *>(p_clear + (int64_t)s * T + t) = TreeD2{{0.0, 0.0}};
+        }
+    }
+    return r;
+}
+
 // Control block of the streaming steady state (device memory, owned by the plan).
 struct StreamCtl {
     unsigned int bad_seq;                 // sequence number of the last launch whose verdict failed (0: none yet)

@@ -4,6 +4,7 @@
 //                      launch (op_chain_kv_kernel), written by thread 0 of its second half's workgroups; printed by
 //                      revs_plan_chain_fold_run at the end of a call (tools/regime_run.py with REVS_LIB=<the build>)
 //   -DREVS_BPP_STAMPS  the same inside op_dual_bpp_kernel (tools/bpp_stamps.py)
+//   -DREVS_VD_STAMPS   the same inside stream_block_verdict_kernel, every workgroup (tools/verdict_stamps.py)
 #pragma once
 #if defined(REVS_KV_STAMPS) && defined(REVS_KVS_TU)      // (the operator kernels' translation unit only)
 namespace revs {
@@ -25,4 +26,10 @@ namespace revs { __device__ double g_bpp_stamps[256][32]; }
 #define BPP_STAMP(i) do { if (threadIdx.x == 0 && (i) < 32) revs::g_bpp_stamps[blockIdx.x][i] = (double)wall_clock64(); } while (0)
 #else
 #define BPP_STAMP(i) do { } while (0)
+#endif
+#if defined(REVS_VD_STAMPS) && defined(REVS_AGENT_TU)
+namespace revs { __device__ double g_vd_stamps[1024][8]; }
+#define VD_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 1024) revs::g_vd_stamps[blockIdx.x][i] = (double)wall_clock64(); } while (0)
+#else
+#define VD_STAMP(i) do { } while (0)
 #endif
