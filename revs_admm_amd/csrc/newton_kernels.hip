@@ -395,6 +395,11 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
         return;
     }
     BPP_STAMP(0);
+#ifdef REVS_BPP_STAMPS
+    if (tid == 0) g_bpp_stamps[blockIdx.x][28] = (double)clock64();
+#endif
+    extern __shared__ double Ls_dyn[];                    // [kAmax][kAmax + 1]
+    constexpr int kKl = 65;                               // row stride of the LDS copy of K (a <= 64)
     // K = (sum of the K-split slabs) / kappa, rows and columns < a (rounded up to 4)
     double *Kt = Kall + (int64_t)t * kAmax * kAmax;
     {
@@ -426,13 +431,21 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
             }
 #pragma unroll
             for (int x = 0; x < 4; ++x)
-                if (e0 + 256 * x < tot) Kt[off[x]] = acc[x] * inv_kappa;
+                if (e0 + 256 * x < tot) {
+                    const double kv_ = acc[x] * inv_kappa;
+                    Kt[off[x]] = kv_;
+                    // (at most 64 candidates: a copy of K in the half of the factor's LDS that 64 rows leave free -- the
+                    // products K' u of every round and the factorisations' first reads then take LDS trips, not
+                    // trips to the L2 behind the stores above)
+                    if (a <= 64) Ls_dyn[64 * (kAmax + 1) + (off[x] >> 7) * kKl + (off[x] & (kAmax - 1))] = kv_;
+                }
         }
     }
     __syncthreads();
     BPP_STAMP(1);
-    extern __shared__ double Ls_dyn[];                    // [kAmax][kAmax + 1]
     auto Ls = [&](int i, int j) -> double & { return Ls_dyn[i * (kAmax + 1) + j]; };
+    const double *const Kp = a <= 64 ? (const double *)(Ls_dyn + 64 * (kAmax + 1)) : (const double *)Kt;
+    const int ks = a <= 64 ? kKl : kAmax;
     __shared__ double s_s[kAmax], c_s[kAmax], u_s[kAmax], w_s[kAmax], wred[4], idk_s[kAmax], col_s[2][4][kAmax];
     __shared__ int bl[kAmax];
     __shared__ unsigned long long Bsh[kWords], Vsh[kWords];
@@ -445,7 +458,7 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
         const double s = in ? cs[tid] : 1.0;
         s_s[tid] = s;
         u_s[tid] = in ? fmax(s * cy[tid], 0.0) : 0.0;
-        const double tr = wave_sum_d(in ? Kt[tid * kAmax + tid] : 0.0);
+        const double tr = wave_sum_d(in ? Kp[tid * ks + tid] : 0.0);
         if (lane == 0) wred[wave] = tr;
     }
     __syncthreads();
@@ -463,7 +476,7 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
     }
     const double dl = dl_s;
     auto kp = [&](int i, int j) -> double {
-        return s_s[i] * s_s[j] * Kt[i * kAmax + j] + (i == j ? dl : 0.0);
+        return s_s[i] * s_s[j] * Kp[i * ks + j] + (i == j ? dl : 0.0);
     };
     // out_i = sum_j K'_ij u_j : 2 lanes per row, kAmax/2 columns each
     const int mi = tid >> 1, mp = tid & 1;
@@ -476,7 +489,7 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
             for (int jb = j0; jb < j0 + kAmax / 2 && jb < a; jb += 16) {
                 double kv[16];
 #pragma unroll
-                for (int jj = 0; jj < 16; ++jj) kv[jj] = Kt[mi * kAmax + (jb + jj < a ? jb + jj : mi)];
+                for (int jj = 0; jj < 16; ++jj) kv[jj] = Kp[mi * ks + (jb + jj < a ? jb + jj : mi)];
 #pragma unroll
                 for (int jj = 0; jj < 16; ++jj) {
                     const int j = jb + jj;
@@ -586,6 +599,8 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
                         double pi[4], pj[4];
 #pragma unroll
                         for (int c = 0; c < 4; ++c) {
+                            // (masked loads: the compiler's form -- a branch around each -- measured faster here than
+                            // all reads unconditional and waited for together: rows beyond the set are skipped whole)
                             pi[c] = (i > k0 + 3 && i < nb) ? col[c][i] : 0.0;
                             pj[c] = (j > k0 + 3 && j < nb) ? col[c][j] : 0.0;
                         }
@@ -609,7 +624,12 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
 #pragma unroll
                         for (int x = 0; x < NT; ++x) {
                             const int i = ti + 16 * x;
-                            if (i > k0 + 3 && i < nb) Ls(i, k0 + c) = li[x][c];
+                            // (li[x][c] by selects: a register array indexed by a lane's own value lives in scratch
+                            // memory -- every panel step paid sixteen scratch stores and a dependent load)
+                            double lv = li[x][0];
+#pragma unroll
+                            for (int cc = 1; cc < 4; ++cc) lv = cc == c ? li[x][cc] : lv;
+                            if (i > k0 + 3 && i < nb) Ls(i, k0 + c) = lv;
                         }
                     }
                     if (tid < 16) {
@@ -638,66 +658,96 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
         BPP_STAMP(4 + 4 * round_);
         // triangular solves in wavefront 0: lane l holds components l and l + 64; the pivot component reaches the
         // others through v_readlane (k is uniform: no trip through the LDS crossbar per step), and the entries of the
-        // next four columns of L are requested before the current four are used
+        // next four columns of L are requested before the current four are used.  Branch-free: every LDS read is
+        // made (clamped address) and masked afterwards, steps beyond the set multiply zeros, and the components
+        // below / from 64 are two loops -- as ternaries and `if (k < nb)` the compiler turned each read, each
+        // readlane and each step into a branch of its own: 326 cycles per column, 6.8 us per solve at 50 rows
+        // (stage stamps 20-22, r04).
         if (tid < 64) {
             double v0 = lane < nb ? c_s[bl[lane]] : 0.0;
             double v1 = lane + 64 < nb ? c_s[bl[lane + 64]] : 0.0;
-            auto bcast = [&](int k) -> double {
-                const long long b0 = __double_as_longlong(v0), b1 = __double_as_longlong(v1);
-                const int kk = k & 63;
-                const int lo = k < 64 ? __builtin_amdgcn_readlane((int)b0, kk) : __builtin_amdgcn_readlane((int)b1, kk);
-                const int hi = k < 64 ? __builtin_amdgcn_readlane((int)(b0 >> 32), kk) : __builtin_amdgcn_readlane((int)(b1 >> 32), kk);
+            auto lane_of = [](double v, int k) -> double {            // v of lane k (k uniform, 0..63)
+                const long long bb = __double_as_longlong(v);
+                const int lo = __builtin_amdgcn_readlane((int)bb, k);
+                const int hi = __builtin_amdgcn_readlane((int)(bb >> 32), k);
                 return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
             };
             // L y = c_B (unit diagonal): column k of L, rows lane and lane + 64
             auto colf = [&](int k, double (&a0)[4], double (&a1)[4]) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    a0[c] = (k + c < nb && lane > k + c && lane < nb) ? Ls(lane, k + c) : 0.0;
-                    a1[c] = (k + c < nb && lane + 64 > k + c && lane + 64 < nb) ? Ls(lane + 64, k + c) : 0.0;
+                    const int kc = k + c < kAmax ? k + c : kAmax - 1;
+                    const double x0 = Ls(lane, kc), x1 = Ls(lane + 64, kc);      // (always in bounds; masked below)
+                    a0[c] = (k + c < nb && lane > k + c && lane < nb) ? x0 : 0.0;
+                    a1[c] = (k + c < nb && lane + 64 < nb) ? x1 : 0.0;      // (lane + 64 > k + c below 64; tested from 64 on)
                 }
             };
             double c0[4], c1[4], n0[4], n1[4];
+            if (round_ == 0) BPP_STAMP(20);
             colf(0, c0, c1);
-            for (int kb = 0; kb < nb; kb += 4) {
+            const int nlo = nb < 64 ? nb : 64;
+            for (int kb = 0; kb < nlo; kb += 4) {                     // pivots among the components below 64
                 colf(kb + 4, n0, n1);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const int k = kb + c;
-                    if (k < nb) {                                     // uniform
-                        const double yk = bcast(k);
-                        v0 -= c0[c] * yk;                             // (zero where lane <= k)
-                        v1 -= c1[c] * yk;
-                    }
+                    const double yk = lane_of(v0, (kb + c) & 63);     // (a step beyond the set: its column is masked to zero)
+                    v0 -= c0[c] * yk;                                 // (zero where lane <= k)
+                    v1 -= c1[c] * yk;
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { c0[c] = n0[c]; c1[c] = n1[c]; }
             }
+            for (int kb = 64; kb < nb; kb += 4) {                     // ... from 64 on: they move components from 64 on only
+#pragma unroll
+                for (int c = 0; c < 4; ++c) c1[c] = lane + 64 > kb + c ? c1[c] : 0.0;
+                colf(kb + 4, n0, n1);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const double yk = lane_of(v1, (kb + c) & 63);
+                    v1 -= c1[c] * yk;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { c0[c] = n0[c]; c1[c] = n1[c]; }
+            }
+            if (round_ == 0) BPP_STAMP(21);
             // D^-1, then L^T x = y: row k of L, columns lane and lane + 64
             v0 *= lane < nb ? idk_s[lane] : 0.0;
             v1 *= lane + 64 < nb ? idk_s[lane + 64] : 0.0;
             auto rowb = [&](int k, double (&a0)[4], double (&a1)[4]) {      // rows k, k - 1, k - 2, k - 3
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    a0[c] = (k - c >= 0 && lane < k - c) ? Ls(k - c, lane) : 0.0;
-                    a1[c] = (k - c >= 0 && lane + 64 < k - c) ? Ls(k - c, lane + 64) : 0.0;
+                    const int kc = k - c > 0 ? k - c : 0;
+                    const double x0 = Ls(kc, lane), x1 = Ls(kc, lane + 64);
+                    a0[c] = (k - c >= 0 && k - c < nb && lane < k - c) ? x0 : 0.0;
+                    a1[c] = (k - c >= 0 && k - c < nb && lane + 64 < k - c) ? x1 : 0.0;
                 }
             };
-            rowb(nb - 1, c0, c1);
-            for (int kb = nb - 1; kb >= 0; kb -= 4) {
+            // (kb starts at the last row of the block of four that holds nb - 1, so that no block straddles 64; rows
+            // beyond the set hold whatever an earlier round left: masked)
+            const int ktop = ((nb - 1) | 3);                          // last row of the block of four that holds nb - 1
+            rowb(ktop, c0, c1);
+            for (int kb = ktop; kb >= 64; kb -= 4) {                  // pivots among the components from 64 on
                 rowb(kb - 4, n0, n1);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const int k = kb - c;
-                    if (k >= 0) {                                     // uniform
-                        const double xk = bcast(k);
-                        v0 -= c0[c] * xk;                             // (zero where lane >= k)
-                        v1 -= c1[c] * xk;
-                    }
+                    const double xk = lane_of(v1, (kb - c) & 63);     // (a row beyond the set: masked to zero, x_k = 0 anyway)
+                    v0 -= c0[c] * xk;                                 // (zero where lane >= k)
+                    v1 -= c1[c] * xk;
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) { c0[c] = n0[c]; c1[c] = n1[c]; }
             }
+            for (int kb = ktop < 63 ? ktop : 63; kb >= 0; kb -= 4) {  // ... below 64: they move components below 64 only
+                rowb(kb - 4, n0, n1);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const double xk = lane_of(v0, (kb - c) & 63);
+                    v0 -= c0[c] * xk;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { c0[c] = n0[c]; c1[c] = n1[c]; }
+            }
+            if (round_ == 0) BPP_STAMP(22);
             u_s[lane] = 0.0; u_s[lane + 64] = 0.0;
             __builtin_amdgcn_wave_barrier();
             if (lane < nb) u_s[bl[lane]] = v0;
@@ -752,7 +802,8 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
     if (tid == 0) info[t] = done_s == 1 ? piv_s : -piv_s;
     BPP_STAMP(31);
 #ifdef REVS_BPP_STAMPS
-    if (tid == 0) { g_bpp_stamps[blockIdx.x][30] = (double)a; g_bpp_stamps[blockIdx.x][29] = (double)piv_s; }
+    if (tid == 0) { g_bpp_stamps[blockIdx.x][30] = (double)a; g_bpp_stamps[blockIdx.x][29] = (double)piv_s;
+                    g_bpp_stamps[blockIdx.x][27] = (double)clock64(); }     // (shader clock ticks: [28] at the start)
 #endif
 }
 #ifdef REVS_BPP_STAMPS

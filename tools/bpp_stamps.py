@@ -26,7 +26,9 @@ lib = C.CDLL(_lib.LIB_PATH)
 buf = (C.c_double * (256 * 32))()
 assert lib.revs_tuning_bpp_stamps(buf) == 0
 h = np.frombuffer(buf, dtype=np.float64).reshape(256, 32)[:24]
-rel = (h[:, :29] - h[:, :1]) * 0.01
+rel = (h[:, :27] - h[:, :1]) * 0.01
+print("shader clock inside the launch: %.0f MHz" % ((h[0, 27] - h[0, 28]) / ((h[0, 31] - h[0, 0]) * 0.01)))
 worst = int(np.argmax(h[:, 31] - h[:, 0]))
 print("slowest slot", worst, "rows", h[worst, 30], "rounds", h[worst, 29], "total us", (h[worst, 31] - h[worst, 0]) * 0.01)
 print("stamps us (1 slabs summed | 2 set up | per round: lists, factored, solved, judged):", np.round(rel[worst, 1:3 + 4 * int(h[worst, 29])], 1))
+print("round 0's solves: start %.1f, forward done %.1f, backward done %.1f us" % tuple(rel[worst, 20:23]))
