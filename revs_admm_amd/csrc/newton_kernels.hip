@@ -339,16 +339,38 @@ __global__ __launch_bounds__(256) void op_dual_gram_kernel(
     double acc[4][4] = {};
     const int chunk = (m + nks - 1) / nks;
     const int k0 = ks * chunk, k1 = min(m, k0 + chunk);
-    for (int kk = k0; kk < k1; kk += KC) {
-        // stage: 256 threads = 8 rows x 32 columns per pass
+    // stage: 256 threads = 8 rows x 32 columns per pass.  All sixteen entries of a chunk are requested before the first is
+    // used (clamped addresses, masked afterwards: with the loads inside the tests the loop was sixteen dependent round trips
+    // per chunk -- 29 us per launch on the 121144 feeder), and the next chunk's before this chunk's products are formed.
+    int64_t rwi[8], rwj[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        rwi[q] = rows_i[(tid >> 5) + 8 * q];
+        rwj[q] = rows_j[(tid >> 5) + 8 * q];
+    }
+    double rvi[8], rvj[8], nv = 0.0;
+    auto fetch = [&](int kk) {
         const int c = kk + (tid & 31);
-        const double nv = c < k1 ? Nn[(int64_t)c * T + t] : 0.0;
-        for (int rr = tid >> 5; rr < 64; rr += 8) {
-            const int64_t ri = rows_i[rr], rj = rows_j[rr];
-            Ws[rr][tid & 31] = (ri >= 0 && c < k1) ? R[ri * m + c] * nv : 0.0;
-            Rs_[rr][tid & 31] = (rj >= 0 && c < k1) ? R[rj * m + c] : 0.0;
+        const int cc = c < k1 ? c : k1 - 1;
+        nv = Nn[(int64_t)cc * T + t];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            rvi[q] = R[(rwi[q] >= 0 ? rwi[q] : 0) * m + cc];
+            rvj[q] = R[(rwj[q] >= 0 ? rwj[q] : 0) * m + cc];
+        }
+    };
+    if (k0 < k1) fetch(k0);
+    for (int kk = k0; kk < k1; kk += KC) {
+        const bool cin = kk + (tid & 31) < k1;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int rr = (tid >> 5) + 8 * q;
+            const double wv_ = rvi[q] * nv;
+            Ws[rr][tid & 31] = (rwi[q] >= 0 && cin) ? wv_ : 0.0;
+            Rs_[rr][tid & 31] = (rwj[q] >= 0 && cin) ? rvj[q] : 0.0;
         }
         __syncthreads();
+        if (kk + KC < k1) fetch(kk + KC);                   // (uniform; in flight behind the products below)
         if (mine) {
 #pragma unroll 8
             for (int cc = 0; cc < KC; ++cc) {
