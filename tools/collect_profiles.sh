@@ -35,7 +35,12 @@ fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/feeder -o s -- python3 $R/tests/tools/feeder_iters.py > $O/feeder.log 2>&1
 cp $(find $O/feeder -name "*kernel_stats.csv" | head -1) $O/feeder_kernel_stats.csv
 rm -rf $O/feeder
-if [ -f $R/tune/librevs_bpp.so ]; then REVS_LIB=$R/tune/librevs_bpp.so python3 $R/tools/bpp_stamps.py 2>&1 | tail -2 > $O/bpp_stamps.txt; fi
+if [ -f $R/tune/librevs_bpp.so ]; then REVS_LIB=$R/tune/librevs_bpp.so python3 $R/tools/bpp_stamps.py 2>&1 | tail -4 > $O/bpp_stamps.txt; fi
+# the verdict launch behind a burst of 20 / a block of 32 iterations (tuning build), and the bursts' kernel trace
+if [ -f $R/tune/librevs_vd.so ]; then for k in 20 32; do REVS_LIB=$R/tune/librevs_vd.so python3 $R/tools/verdict_stamps.py $k 2>&1 | tail -7 > $O/verdict_stamps_$k.txt; done; fi
+rocprofv3 --kernel-trace --output-format csv -d $O/tr20 -o t -- python3 $R/bench.py --steps 20 --no-extras --no-cpu-baseline --no-converge > $O/tr20.log 2>&1
+python3 $R/tools/burst_trace.py $O/tr20 > $O/burst_trace_steps20.txt 2>&1
+rm -rf $O/tr20
 rm -rf $O/kt
 # keep only the counter csvs of the pmc passes (the traces are large)
 find $O/pmc -type f ! -name "*counter_collection.csv" -delete
