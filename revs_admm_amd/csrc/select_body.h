@@ -118,9 +118,12 @@ __device__ __forceinline__ double dual_select_body(const SelectArgs &sa, const i
         stats[t * 8 + 1] = ((red_s[1][0] + red_s[1][1]) + red_s[1][2]) + red_s[1][3];
         stats[t * 8 + 2] = (double)ns;
         stats[t * 8 + 3] = (double)nv;
-        if (sa.fwd_src) {
+        if (sa.fwd_src) {       // (all four read before the first is stored: the arrays may alias as far as the compiler knows)
+            double f[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) sa.fwd_dst[t * 8 + i] = sa.fwd_src[t * 8 + i];
+            for (int i = 0; i < 4; ++i) f[i] = sa.fwd_src[t * 8 + i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sa.fwd_dst[t * 8 + i] = f[i];
         }
         // stats may live in pinned host memory: a host that polls [5] for this evaluation's
         // sequence number sees [0..3] complete (system-scope release before the tag)
