@@ -91,12 +91,15 @@ class OperatorOptions:
     # the ADMM forms when it cannot finish (more than 128 binding rows in a slot, ...).
     solver: str = "newton"
     newton_max: int = 60         # Newton iterations per operator solve
-    # violated rows admitted to a slot's model per Newton iteration.  Round 4: 3 (was 6).  With on/off chargers the
+    # violated rows admitted to a slot's model per Newton iteration.  Round 4: 2 (was 6, then 3).  With on/off chargers the
     # binding steady state's slowest slot sees a handful of newly violated rows every ADMM iteration; admitting
     # six made its model 8 x 8 -- 36 Gram sums, an 8 x 8 pivoting problem, six arg-max rounds, six more rows of R --
     # for the same number of Newton steps as admitting two or three (measured: 0.069 -> 0.060 ms per iteration at
-    # 100 000 x 24; cold solves on the 121144 feeder: 103 evaluations in 15 iterations against 92, same wall time)
-    newton_kadd: int = 3
+    # 100 000 x 24; cold solves on the 121144 feeder: 103 evaluations in 15 iterations against 92, same wall time).
+    # 3 -> 2 once the pivoting kernel was faster: binary 0.054 -> 0.052, binding 0.0434 -> 0.0430 ms, the feeder's 15
+    # iterations 11.4 -> 10.9 ms, the transient 3.5 -> 3.3 ms.  (1 starves the cold solves: the 121144 feeder's hand
+    # themselves to the ADMM forms, 300 ms; 4 and more lengthen the chained iteration's slowest slot.)
+    newton_kadd: int = 2
     chain: bool = True           # binding steady state: one Newton iteration enqueued unread
     # ... and folded (one GPU, feeder as a tree): the sweep forms the operator's answer for the trial
     # itself and folds both evaluations' node sums into its own pass -- one pass over the residences

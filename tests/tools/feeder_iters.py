@@ -48,7 +48,7 @@ def run(label, op):
 
 run("dual Newton (default)", OperatorOptions())
 if "--kadd" in sys.argv:
-    for _k in (2, 4, 6, 8, 12, 16):
+    for _k in (1, 2, 4, 8):
         run(f"dual Newton, kadd {_k}", OperatorOptions(newton_kadd=_k))
 if "--admm" in sys.argv:
     for rv in (1.0, 25.0):
