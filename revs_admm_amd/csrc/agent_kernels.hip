@@ -1278,14 +1278,7 @@ int agent_step_chain(int64_t n_homes, int32_t T, const float *cost, const revs_h
 // more than 64 KB of dynamic LDS (the big tree shapes) has to be granted per kernel, once
 template <int NT, int IPT, typename K>
 static bool tree_big_lds(K kernel, size_t lds) {
-    if (lds <= 64 * 1024) return true;
-    static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-        revs::set_error("tree form: %zu bytes of LDS refused: %s", lds, hipGetErrorString(e));
-        return false;
-    }
-    return true;
+    return grant_lds(reinterpret_cast<const void *>(kernel), lds, "tree form");
 }
 
 struct BlockVerdict {

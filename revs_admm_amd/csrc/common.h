@@ -312,6 +312,12 @@ __device__ __forceinline__ float clip3(float v, float lo, float hi) {
 
 }  // namespace revs
 
+// More than 64 KB of dynamic LDS has to be granted per kernel -- and per device: one grant per (kernel, current device)
+// and size (a `static const` result was per process).  false + revs_last_error when the runtime refuses.
+namespace revs {
+bool grant_lds(const void *kernel, size_t bytes, const char *who);
+}
+
 // Stage stamps of the latency-bound operator launches exist in tuning builds only (csrc/tuning.h, never included by
 // the product build: python -m revs_admm_amd.build --out tune/lib.so -DREVS_TUNING -DREVS_KV_STAMPS | -DREVS_BPP_STAMPS | -DREVS_VD_STAMPS)
 #ifdef REVS_TUNING

@@ -1863,14 +1863,8 @@ int chain_kv_launch(const ChainKv &c, void *stream) {
     // (a slot's rows are staged in LDS: 4 m doubles beside the tree's scan buffer and ~30 KB of static LDS)
     REVS_REQUIRE(c.m <= REVS_CHAIN_FOLD_MAX_M && lds <= 128 * 1024,
                  "chain_kv_launch: m = %d rows do not fit the operator launch's LDS (at most %d)", c.m, REVS_CHAIN_FOLD_MAX_M);
-    if (lds > 64 * 1024) {       // (more than 64 KB of dynamic LDS has to be granted, once)
-        static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&op_chain_kv_kernel),
-                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-        if (e != hipSuccess) {
-            revs::set_error("chain_kv_launch: %zu bytes of LDS refused: %s", lds, hipGetErrorString(e));
-            return REVS_ELAUNCH;
-        }
-    }
+    if (!grant_lds(reinterpret_cast<const void *>(&op_chain_kv_kernel), lds > 64 * 1024 ? 128 * 1024 : lds, "chain_kv_launch"))
+        return REVS_ELAUNCH;
     k.stamps = c.sh_b + mt;
     hipLaunchKernelGGL(op_chain_kv_kernel, dim3((c.has_e2 ? 2 : 1) * c.T), dim3(256), lds, (hipStream_t)stream, k);
     REVS_CHECK_LAUNCH("chain_kv_launch");
@@ -1977,14 +1971,7 @@ extern "C" int revs_op_dual_model(int32_t m, int32_t T, const double *R, const d
                  k_full && yhat && info && kappa > 0 && delta >= 0 && max_pivots > 0 &&
                  nks >= 1 && nks <= 64, "revs_op_dual_model: bad argument");
     static const size_t lds = sizeof(double) * kAmax * (kAmax + 1);
-    static const hipError_t attr = hipFuncSetAttribute(
-        reinterpret_cast<const void *>(&op_dual_bpp_kernel),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (attr != hipSuccess) {
-        revs::set_error("revs_op_dual_model: %zu bytes of LDS refused: %s", lds,
-                        hipGetErrorString(attr));
-        return REVS_ELAUNCH;
-    }
+    if (!grant_lds(reinterpret_cast<const void *>(&op_dual_bpp_kernel), lds, "revs_op_dual_model")) return REVS_ELAUNCH;
     hipLaunchKernelGGL(op_dual_gram_kernel, dim3(T, nks, kWords * kWords), dim3(256), 0, S_(stream),
                        m, T, R, n_free, cand_idx, cand_cnt, nks, k_slabs);
     hipLaunchKernelGGL(op_dual_bpp_kernel, dim3(T), dim3(256), lds, S_(stream), k_slabs, nks,
@@ -2061,15 +2048,8 @@ static bool tree_ok_big(const revs_tree_t *tree) {   // the evaluations' row lau
     return tree && tree->n > 0 && tree->n <= REVS_TREE_MAX && tree->n % tree_shape(tree->n).ipt == 0 && tree->pack && tree->w;
 }
 template <int NT, int IPT, typename K>
-static bool rows_big_lds(K kernel, size_t lds) {     // more than 64 KB of dynamic LDS is granted per kernel, once
-    if (lds <= 64 * 1024) return true;
-    static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) {
-        revs::set_error("revs_op_dual_rows_tree: %zu bytes of LDS refused: %s", lds, hipGetErrorString(e));
-        return false;
-    }
-    return true;
+static bool rows_big_lds(K kernel, size_t lds) {     // more than 64 KB of dynamic LDS is granted per kernel and device
+    return grant_lds(reinterpret_cast<const void *>(kernel), lds, "revs_op_dual_rows_tree");
 }
 
 extern "C" int revs_op_dual_rows_tree(int32_t m, int32_t T, const revs_tree_t *tree, const double *pnq,
@@ -2108,14 +2088,9 @@ extern "C" int revs_op_dual_rows_tree(int32_t m, int32_t T, const revs_tree_t *t
         // (the rows go to the selection through LDS where they fit: vfull / viol are scratch of this call then)
         const size_t staged_lds = ((tree_lds_bytes(tree->n) / sizeof(double) + 1) / 2 * 2 + 3 * (size_t)m + 4) * sizeof(double);
         const bool staged = staged_lds <= 120 * 1024;
-        if (staged && staged_lds > 64 * 1024) {
-            static const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&op_tree_rows_kernel<true>),
-                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024);
-            if (e != hipSuccess) {
-                revs::set_error("revs_op_dual_rows_tree: %zu bytes of LDS refused: %s", staged_lds, hipGetErrorString(e));
-                return REVS_ELAUNCH;
-            }
-        }
+        if (staged && !grant_lds(reinterpret_cast<const void *>(&op_tree_rows_kernel<true>), staged_lds > 64 * 1024 ? 120 * 1024 : staged_lds,
+                                 "revs_op_dual_rows_tree"))
+            return REVS_ELAUNCH;
         hipLaunchKernelGGL((op_tree_rows_kernel<true>), dim3(T), dim3(256), staged ? staged_lds : tree_lds_bytes(tree->n), S_(stream),
                            ta, sa, staged ? 1 : 0);
     } else {

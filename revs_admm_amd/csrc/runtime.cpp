@@ -10,6 +10,28 @@
 #include <vector>
 #include <cstring>
 
+#include <map>
+#include <mutex>
+namespace revs {
+bool grant_lds(const void *kernel, size_t bytes, const char *who) {
+    if (bytes <= 64 * 1024) return true;
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, size_t> granted;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    size_t &g = granted[{kernel, dev}];
+    if (g >= bytes) return true;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        set_error("%s: %zu bytes of LDS refused: %s", who, bytes, hipGetErrorString(e));
+        return false;
+    }
+    g = bytes;
+    return true;
+}
+}  // namespace revs
+
 namespace revs {
 static thread_local char g_err[512] = "";
 void set_error(const char *fmt, ...) {
