@@ -618,6 +618,18 @@ def main():
         # the reference's own feeder and iteration count
         extras["value_feeder_121144"] = feeder_121144(torch, not args.no_cpu_baseline)
 
+    # The same first iterations as ONE call (what a run does: AdmmEngine.run / run_steps -- the iterations behind the
+    # transient stream, 32 to a launch, instead of being issued and waited for one by one as the spin-up above does to
+    # time each): the engine is set back to iteration 0 and walks them again.
+    one_call_ms = None
+    if world == 1 and args.spinup > 0:
+        eng.reset()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        eng.run_steps(args.spinup)
+        torch.cuda.synchronize()
+        one_call_ms = (time.perf_counter() - t1) * 1e3
+
     if rank == 0:
         warm = (None if eng.pdhg_dual is None else
                 ("full" if eng.pdhg_dual.dim() == 2 else "scalar"))
@@ -759,6 +771,11 @@ def main():
                     "ms_per_step_mean": float(np.mean(spin_ms)) if spin_ms else None,
                     "ms_per_step_max": float(np.max(spin_ms)) if spin_ms else None,
                     "ms_total": float(np.sum(spin_ms)) if spin_ms else None,
+                    "timed": "every iteration issued and waited for on its own (step + synchronize)",
+                    "one_call_ms_total": one_call_ms,
+                    "one_call_ms_per_step_mean": (one_call_ms / args.spinup) if one_call_ms is not None else None,
+                    "one_call": "the same iterations from iteration 0 again as ONE run_steps call (the iterations behind "
+                                "the transient stream)",
                     "operator_inner_iters": spin_inner,
                     "operator_paths": spin_paths,
                 },

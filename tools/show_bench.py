@@ -16,4 +16,4 @@ if j.get("roofline_valu"):
 if j.get("cpu_baseline"):
     print("cpu", round(j["cpu_baseline"]["value"]), j["cpu_baseline"]["cores"])
 t = j["breakdown"]["transient"]
-print("transient", round(t["ms_total"], 2), round(t["ms_per_step_mean"], 3), round(t["ms_per_step_max"], 2), "iters_to_eps", j["breakdown"]["admm_iters_to_eps"])
+print("transient", round(t["ms_total"], 2), round(t["ms_per_step_mean"], 3), round(t["ms_per_step_max"], 2), "one call", t.get("one_call_ms_total") and round(t["one_call_ms_total"], 2), "iters_to_eps", j["breakdown"]["admm_iters_to_eps"])
