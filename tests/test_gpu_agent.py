@@ -249,7 +249,7 @@ def test_pdhg_warm_start(gpu_lib):
     assert ((first3["status"] >> 8)[oh.ev] == 0).mean() > 0.5
 
 
-@pytest.mark.parametrize("mode", ["binary", "relaxed_exact", "pdhg"])
+@pytest.mark.parametrize("mode", ["binary", "relaxed_exact", "pdhg", "pdhg_presolve"])
 def test_edge_parameters(gpu_lib, mode):
     """Residences the reference would accept but rarely sees: already charged past 90 %
     (no slot needed), windows reaching outside the horizon, one-slot windows, T = 1, 2, 3."""
@@ -274,7 +274,10 @@ def test_edge_parameters(gpu_lib, mode):
                      1.05, 5.0)
         oh = oracle_homes(w)
         pe_old, pe_new, ps, gm = _state(w, T)
-        r = _run_agent(gpu_lib, w, pe_old, pe_new, ps, gm, mode)
+        if mode == "pdhg_presolve":        # (the KKT steps first, from a zero multiplier: revs_pdhg_t::polish = 3)
+            r = _run_agent(gpu_lib, w, pe_old, pe_new, ps, gm, "pdhg", dict(polish=3))
+        else:
+            r = _run_agent(gpu_lib, w, pe_old, pe_new, ps, gm, mode)
         solve = ro.home_solve_binary if mode == "binary" else ro.home_solve_relaxed
         p, s, g, st = solve(w.cost, oh, pe_old, ps, gm, w.kappa)
         assert ((r["status"] & 0xFF) == st).all()
@@ -292,7 +295,7 @@ def test_edge_parameters(gpu_lib, mode):
 
 
 @pytest.mark.parametrize("lanes,T", [(16, 24), (32, 24), (16, 32), (32, 17)])
-@pytest.mark.parametrize("mode", ["pdhg", "relaxed_exact", "binary"])
+@pytest.mark.parametrize("mode", ["pdhg", "relaxed_exact", "binary", "pdhg_presolve"])
 def test_wide_lane_shapes_match_oracle(gpu_lib, lanes, T, mode):
     """revs_pdhg_t::lanes -- 16 lanes x 2 slots / 32 lanes x 1 slot per residence at T <= 32 (the shapes for a GPU
     that holds few residences: BASELINE config 2's 12 500 per GPU) -- against the oracle at the default shape's
@@ -302,7 +305,10 @@ def test_wide_lane_shapes_match_oracle(gpu_lib, lanes, T, mode):
     n = 1501
     w, oh = _prep(n, T, seed=300 + T + lanes, binary_feasible=(mode == "binary"))
     pe_old, pe_new, ps, gm = _state(w, T + lanes)
-    r = _run_agent(gpu_lib, w, pe_old, pe_new, ps, gm, mode, dict(lanes=lanes))
+    extra = {}
+    if mode == "pdhg_presolve":            # (the KKT steps in front of PDHG on the wide shapes: their sums cross 16 / 32 lanes)
+        mode, extra = "pdhg", dict(polish=3)
+    r = _run_agent(gpu_lib, w, pe_old, pe_new, ps, gm, mode, dict(lanes=lanes, **extra))
     r0 = _run_agent(gpu_lib, w, pe_old, pe_new, ps, gm, mode)
     if mode == "binary":
         p, s, g, st = ro.home_solve_binary(w.cost, oh, pe_old, ps, gm, w.kappa)
