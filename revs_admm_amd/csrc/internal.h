@@ -96,6 +96,9 @@ struct ChainKv {
     double *fwd_dst = nullptr;
 };
 int chain_kv_launch(const ChainKv &c, void *stream);
+// revs_op_dual_step with y_trial = y (all rows of every slot) copied in front, one launch (newton_kernels.hip)
+int dual_step_copy(int32_t T, const int64_t *cand_idx, const int32_t *cand_cnt, const double *cand_val, const double *yhat,
+                   const double *alpha, const double *y, int32_t m, double *y_trial, double *lin_out, void *stream);
 
 // Verdicts by blocks (agent_kernels.hip).  A no-op when a launch numbered base_seq..gate_seq has
 // failed its verdict.  Judges `nb` slices of node sums -- `pre` (the caller's array: the sums of

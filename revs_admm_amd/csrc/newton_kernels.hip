@@ -1075,6 +1075,27 @@ __global__ __launch_bounds__(64) void op_dual_step_kernel(
     dual_step_body<64>(t, T, cidx, ccnt, cval, yhat, al, ytrial, lin_out, ycopy, m);
 }
 
+// The step with the copy of the slot's column of multipliers in front (y_trial[., t] = y[., t], eight loads in flight per
+// thread), one launch: the native Newton loop made a device-to-device copy of all of y and then the step -- a dispatch
+// and a kernel boundary per Newton iteration.
+__global__ __launch_bounds__(256) void op_dual_step_copy_kernel(
+        int T, const int64_t *__restrict__ cidx, const int32_t *__restrict__ ccnt,
+        const double *__restrict__ cval, const double *__restrict__ yhat,
+        const double *__restrict__ alpha, double *__restrict__ ytrial,
+        double *__restrict__ lin_out, const double *__restrict__ ycopy, int m) {
+    const int t = blockIdx.x;
+    for (int r0 = threadIdx.x; r0 < m; r0 += 8 * 256) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = r0 + 256 * q < m ? ycopy[(int64_t)(r0 + 256 * q) * T + t] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (r0 + 256 * q < m) ytrial[(int64_t)(r0 + 256 * q) * T + t] = v[q];
+    }
+    __syncthreads();
+    dual_step_body<256>(t, T, cidx, ccnt, cval, yhat, alpha[t], ytrial, lin_out, nullptr, m);
+}
+
 // Selection, small model and full/zero step of one slot in ONE workgroup (the chained Newton
 // iteration of the binding steady state: three launches and two reloads of the candidate
 // lists less).  A slot with more than 8 candidates gets info = -999 from the model part, as
@@ -2025,6 +2046,18 @@ extern "C" int revs_op_dual_step(int32_t T, const int64_t *cand_idx, const int32
     REVS_CHECK_LAUNCH("revs_op_dual_step");
     return REVS_OK;
 }
+
+namespace revs {
+int dual_step_copy(int32_t T, const int64_t *cand_idx, const int32_t *cand_cnt, const double *cand_val, const double *yhat,
+                   const double *alpha, const double *y, int32_t m, double *y_trial, double *lin_out, void *stream) {
+    REVS_REQUIRE(T > 0 && cand_idx && cand_cnt && cand_val && yhat && alpha && y && m > 0 && y_trial && y_trial != y && lin_out,
+                 "dual_step_copy: bad argument");
+    hipLaunchKernelGGL(op_dual_step_copy_kernel, dim3(T), dim3(256), 0, S_(stream), T, cand_idx, cand_cnt, cand_val, yhat,
+                       alpha, y_trial, lin_out, y, m);
+    REVS_CHECK_LAUNCH("dual_step_copy");
+    return REVS_OK;
+}
+}  // namespace revs
 
 extern "C" int revs_op_dual_step_pending(int32_t T, const int64_t *cand_idx, const int32_t *cand_cnt,
                                          const double *cand_val, const double *yhat,

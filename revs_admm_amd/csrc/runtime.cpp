@@ -643,11 +643,8 @@ extern "C" int revs_plan_newton_solve(revs_plan_t *plan, revs_newton_state_t *st
             } else {
                 from_pre = false;
                 for (int t = 0; t < T; ++t) o.alpha_host[t] = alpha[t];        // read by the step kernel through its mapping
-                if (hipMemcpyAsync(ytrial, ycur, sizeof(double) * mt, hipMemcpyDeviceToDevice, s) != hipSuccess) {
-                    revs::set_error("revs_plan_newton_solve: copying the multipliers failed");
-                    return REVS_ELAUNCH;
-                }
-                rc = revs_op_dual_step(T, ci[cur], cc[cur], cv[cur], d.yhat, o.alpha_dev, ytrial, sd[nxt] + 4, stream);
+                // (the trial starts from the current multipliers: copied by the step's own launch)
+                rc = revs::dual_step_copy(T, ci[cur], cc[cur], cv[cur], d.yhat, o.alpha_dev, ycur, d.m, ytrial, sd[nxt] + 4, stream);
                 if (rc == REVS_OK) rc = evaluate(ytrial, 1, nxt, few ? cur : -1, stn.data());
                 if (rc != REVS_OK) return rc;
             }
