@@ -1359,8 +1359,9 @@ __global__ __launch_bounds__(NT) void stream_block_verdict_kernel(const BlockVer
     double rmax = 0.0;
     if (!extra) {
         if constexpr (PAIR)
-            rmax = ring_slice ? tree_rmax_pair<NT, IPT>(b.tree, slice, b.T, 2 * t, b.vlo, b.vhi, tree_lds, slice, pk0, wgt0)
-                              : tree_rmax_pair<NT, IPT>(b.tree, b.pre, b.T, 2 * t, b.vlo, b.vhi, tree_lds, nullptr, pk0, wgt0);
+            // (the slice is cleared whole, with coalesced stores, by the last of its workgroups to arrive: 2048 scattered
+            // 16-byte stores per workgroup and the wait for them were ~5.7 us of every workgroup's chain)
+            rmax = tree_rmax_pair<NT, IPT>(b.tree, ring_slice ? slice : b.pre, b.T, 2 * t, b.vlo, b.vhi, tree_lds, nullptr, pk0, wgt0);
         else
             rmax = ring_slice ? tree_rmax<NT, IPT, true>(b.tree, slice, b.T, t, b.vlo, b.vhi, tree_lds, nullptr, slice, pk0, wgt0)
                               : tree_rmax<NT, IPT, true>(b.tree, b.pre, b.T, t, b.vlo, b.vhi, tree_lds, nullptr, nullptr, pk0, wgt0);
@@ -1378,7 +1379,7 @@ __global__ __launch_bounds__(NT) void stream_block_verdict_kernel(const BlockVer
                 if (ib + q * NT < i1) { b.hand_over[ib + q * NT] = v[q]; slice[ib + q * NT] = 0.0; }
         }
     }
-    __shared__ int last_s;
+    __shared__ int last_s, slice_last_s;
     __shared__ unsigned int bad_s;
     VD_STAMP(2);
     if (tid == 0) {
@@ -1393,14 +1394,24 @@ __global__ __launch_bounds__(NT) void stream_block_verdict_kernel(const BlockVer
         unsigned int *const mine = reinterpret_cast<unsigned int *>(b.grp_arrive + g);
         const unsigned int members = extra ? (unsigned int)kHandOverGroups : (unsigned int)per_slice;
         const unsigned int old1 = __hip_atomic_fetch_add(mine, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        slice_last_s = old1 == members - 1u;
+        if (slice_last_s) __hip_atomic_store(mine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last_s = 0;
-        if (old1 == members - 1u) {
-            __hip_atomic_store(mine, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned int old = __hip_atomic_fetch_add(&b.ctl->arrive, 1u, __ATOMIC_RELAXED,
-                                                            __HIP_MEMORY_SCOPE_AGENT);
-            last_s = old == (unsigned int)(b.nb + (b.hand_over ? 1 : 0)) - 1u;
-        }
         bad_s = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    if (!slice_last_s) return;              // (uniform)
+    if constexpr (PAIR) {
+        if (!extra && ring_slice) {         // every workgroup of the slice has read it: clear it whole (mt is even here)
+            TreeD2 *const z = reinterpret_cast<TreeD2 *>(slice);
+            for (int i = tid; i < b.mt / 2; i += NT) z[i] = TreeD2{{0.0, 0.0}};
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {
+        const unsigned int old = __hip_atomic_fetch_add(&b.ctl->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = old == (unsigned int)(b.nb + (b.hand_over ? 1 : 0)) - 1u;
     }
     VD_STAMP(3);
     __syncthreads();

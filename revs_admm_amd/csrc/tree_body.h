@@ -289,6 +289,7 @@ __device__ __forceinline__ double tree_rmax_pair(const TreeArgs &tr, const doubl
 #pragma unroll
     for (int i = 0; i < IPT; ++i) b[i] = wgt_pre[i];
     tree_scan<NT, IPT, true>(tr, t, lds, a0, b, pk);
+    VD_STAMP(6);
 #pragma unroll
     for (int i = 0; i < IPT; ++i)
         if ((pk[i] & 0xFFFFu) != 0ull) rmax = fmax(rmax, fmax(fmax(a0[i] - vhi, vlo - a0[i]), 0.0));
@@ -296,6 +297,7 @@ __device__ __forceinline__ double tree_rmax_pair(const TreeArgs &tr, const doubl
 #pragma unroll
     for (int i = 0; i < IPT; ++i) b[i] = wgt_pre[i];
     tree_scan<NT, IPT, true>(tr, t + 1, lds, a1, b, pk);
+    VD_STAMP(7);
 #pragma unroll
     for (int i = 0; i < IPT; ++i)
         if ((pk[i] & 0xFFFFu) != 0ull) rmax = fmax(rmax, fmax(fmax(a1[i] - vhi, vlo - a1[i]), 0.0));

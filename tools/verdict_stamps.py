@@ -27,12 +27,15 @@ h = np.frombuffer(buf, dtype=np.float64).reshape(1024, 8)
 live = h[:, 0] > h[:, 0].max() - 500.0
 n = int(live.sum())
 t0 = h[live, 0].min()
-rel = (h[live, :6] - t0) * 0.01
+rel = (h[live, :8] - t0) * 0.01
 print("workgroups stamped", n)
 print("start: min %.1f median %.1f max %.1f us" % (rel[:, 0].min(), np.median(rel[:, 0]), rel[:, 0].max()))
 for i, name in ((1, "control word read"), (2, "rows judged / slice copied"), (3, "counted")):
     d = rel[:, i] - rel[:, 0]
     print("%-28s since the workgroup's start: median %.1f max %.1f us; since the launch's first start: max %.1f" % (name, np.median(d), d.max(), rel[:, i].max()))
+jd = rel[:n - 32]
+print("two-slot workgroups: first scan done median %.1f, second scan done median %.1f us since the workgroup's start" % (
+    np.median(jd[:, 6] - jd[:, 0]), np.median(jd[:, 7] - jd[:, 0])))
 last = int(np.argmax(np.where(h[live, 5] > h[live, 0], h[live, 5], 0.0)))
 print("last arriver: records from %.1f to %.1f us" % (rel[last, 4], rel[last, 5]))
 ex = rel[n - 32:n]                     # (kHandOverGroups workgroups at the end of the grid)
