@@ -72,6 +72,14 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
 F64_MFMA_PEAK_TFLOPS = 78.6    # MI355X datasheet, dense f64 matrix
+# VALU issue: shader cycles one SIMD needs per wave64 VALU instruction, sustained with several wavefronts per SIMD and
+# independent dependency chains -- measured on this part by tools/probes/valu_rate.hip (s_memtime around the loop, the
+# wavefronts' SIMDs read from HW_ID), raw output committed as profiles/r05_probe_valu_rate.txt
+VALU_CYCLES = 4
+SQ_QUAD = 4     # SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / SQ_WAIT_* count quad-cycles (MI355X_MICROARCH.md, constants table)
+VALU_PEAK = 1024 * 2.4e9 / VALU_CYCLES           # wave64 VALU instructions per second, 1024 SIMDs at 2.4 GHz
+VALU_PEAK_SOURCE = ("profiles/r05_probe_valu_rate.txt (tools/probes/valu_rate.hip: cycles per v_fma_f32 / v_add_f32 per SIMD by "
+                    "s_memtime at 1 / 2 / 4 / 8 wavefronts per SIMD, 8 and 16 independent chains per wavefront)")
 
 
 def multi_bytes_per_home(T, pdhg_dual, hist=False, inner=1):
@@ -219,8 +227,32 @@ def feeder_121144(torch, with_cpu):
         row_out = {"ms_15_iterations": dt * 1e3, "home_solves_per_sec": len(res) * 15 / dt, "residences": len(res),
                    "ev_residences": int(ev.sum()), "T": T, "operator_evaluations": int(sum(e.op_iters_hist)),
                    "newton_iterations": [int(h[0]) for h in e.newton_hist],
-                   "rows_judged_by": "tree form" if e._tree_newton else "dense f64 product",
+                   "rows_judged_by": "tree form" if e._tree_eval else "dense f64 product",
+                   "fused_launches": bool(e._tree_newton), "tree_recovered_from_matrix": bool(getattr(e, "tree_recovered", False)),
                    "chained_iterations": int(e.chain_hist[0])}
+        if T == 96:
+            # BASELINE config 3 is named "operator R.p voltage matvec on MFMA": the f64 matrix-core product at THIS shape
+            # (M = 1 126 residence rows, T = 96 columns).  The product's own launch, 200 times, by HIP events -- the run
+            # above judges its rows by the tree form (rows_judged_by), OperatorOptions(voltage="dense") puts this kernel
+            # on the path instead; its MFMA counters: profiles/r05_pmc_mfma.csv (tools/matvec_run.py --config3).
+            reps = 200
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e.pnq.uniform_(0.0, 3.0)
+            for _ in range(20):
+                e._gemm1(e.R64T, e.pnq[2], e.v_sl)
+            e0.record()
+            for _ in range(reps):
+                e._gemm1(e.R64T, e.pnq[2], e.v_sl)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            fl = 2.0 * e.M * e.M * T
+            row_out["matvec"] = {"kernel": "gemm_tn_kernel<double> (R p, M x M x T)", "M": int(e.M), "T": T, "bound": "mfma",
+                                 "achieved": fl / (ms * 1e-3) / 1e12, "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": fl / (ms * 1e-3) / 1e12 / F64_MFMA_PEAK_TFLOPS, "avg_launch_ms": ms,
+                                 "matrix_stream_GBs": 8.0 * e.M * e.M / (ms * 1e-3) / 1e9,
+                                 "mfma_counters": "profiles/r05_pmc_mfma.csv (rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES ... "
+                                                  "of tools/matvec_run.py --config3)"}
         if with_cpu:
             from oracle import revs_oracle as ro
             oh = ro.homes_from_records(load, homes)
@@ -609,6 +641,8 @@ def main():
         # BASELINE config 4's per-GPU shape
         if (args.homes, args.T) == (100_000, 24):
             extras["value_125k_T96"] = regime(125_000, 96, "pdhg", args.stress, 40, 100)
+            # ... and BASELINE config 4 at its stated size, all of it on this one GPU (~6.5 GB of state)
+            extras["value_1M_T96"] = regime(1_000_000, 96, "pdhg", args.stress, 40, 100)
         # the headline regime with revs_pdhg_t::polish = 3: the KKT steps run from the carried multiplier BEFORE
         # PDHG too, and in this regime they settle every residence -- PDHG is the fallback that is not entered
         # (pdhg_passes_mean 0).  Reported beside the headline, which keeps PDHG in every solve (polish = 1).
@@ -617,6 +651,36 @@ def main():
                                                   args.steps, nblocks=len(burst_rows), polish=3)
         # the reference's own feeder and iteration count
         extras["value_feeder_121144"] = feeder_121144(torch, not args.no_cpu_baseline)
+        extras["roofline_matvec_config3"] = extras["value_feeder_121144"]["all_communities_90pct_T96"].pop("matvec", None)
+
+    # Time to the eps-residual, measured: ONE AdmmEngine.run(iter_max = 1000, eps) from the zero state of
+    # lpsolver.py:244-246 on a fresh engine -- transient, streaming steady state, the stopping test (max_h diff <= eps
+    # for 8 iterations in a row, on the records the launches fold on the device) and the last iteration that writes the
+    # schedules -- wall clock between two synchronises, median of 5 fresh engines; and the reference's own stopping
+    # rule (iter_max = 15, on/off chargers: lpsolver.py:243, 254) the same way.  history=False: the per-residence diff of
+    # every iteration (lpsolver.solve_ADMM's return value: 200 MB at 500 iterations) is not carried to the host; the
+    # run WITH it is timed beside.
+    tte = None
+    if world == 1 and not args.no_extras and not args.no_converge:
+        def fresh_runs(mode, iter_max, eps, reps, history=False):
+            ms, its, conv = [], [], []
+            for _ in range(reps):
+                w3, e3, _ = build(args.homes, args.T, mode, args.stress, args.voltage)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                r = e3.run(iter_max, eps=eps, history=history)
+                torch.cuda.synchronize()
+                ms.append((time.perf_counter() - t1) * 1e3)
+                its.append(int(r if not history else len(r)))
+                conv.append(e3.converged_at)
+                del e3, w3, r
+                torch.cuda.empty_cache()
+            i = int(np.argsort(ms)[len(ms) // 2])
+            return {"ms": ms[i], "iterations": its[i], "converged_at": conv[i], "all_ms": ms, "home_solver": mode}
+        tte = {"pdhg_eps": fresh_runs("pdhg", 1000, args.eps, 5) if args.mode == "pdhg" else None,
+               "pdhg_eps_with_diff_history": fresh_runs("pdhg", 1000, args.eps, 3, history=True) if args.mode == "pdhg" else None,
+               "reference_rule_binary_15_iterations": fresh_runs("binary", 15, None, 5),
+               "reference_rule_binary_15_iterations_with_diff_history": fresh_runs("binary", 15, None, 3, history=True)}
 
     # The same first iterations as ONE call (what a run does: AdmmEngine.run / run_steps -- the iterations behind the
     # transient stream, 32 to a launch, instead of being issued and waited for one by one as the spin-up above does to
@@ -793,18 +857,19 @@ def main():
             c = tj.get("sq_counters_per_launch", {})
             if (tj.get("homes") == n_local and tj.get("T") == args.T and tj.get("mode") == args.mode
                     and tj.get("iterations_per_launch") == inner and c.get("SQ_INSTS_VALU") and launch_ms):
-                peak = 1024 * 2.4e9 / 4
+                peak = VALU_PEAK
                 # (the counters are per launch of `inner` iterations; the timed launches carry
                 # steps / n_launch of them each -- 20 in the driver's run)
                 it_launch = args.steps / n_launch
                 ach_v = c["SQ_INSTS_VALU"] * (it_launch / inner) / (launch_ms * 1e-3)
                 valu = {"kernel": "agent_step_kernel<MULTI>", "bound": "valu-issue", "achieved": ach_v / 1e9,
-                        "peak": peak / 1e9, "unit": "G wave64 VALU instructions/s", "frac": ach_v / peak,
+                        "peak": peak / 1e9, "peak_source": VALU_PEAK_SOURCE,
+                        "unit": "G wave64 VALU instructions/s", "frac": ach_v / peak,
                         "valu_instructions_per_launch": c["SQ_INSTS_VALU"] * (it_launch / inner),
                         "iterations_per_timed_launch": it_launch,
                         "valu_instructions_per_wavefront_and_iteration": c["SQ_INSTS_VALU"] / max(c.get("SQ_WAVES", 1), 1) / inner,
                         "salu_instructions_per_launch": (c["SQ_INSTS_SALU"] * (it_launch / inner) if c.get("SQ_INSTS_SALU") else None),
-                        "valu_busy_share_of_launch": (c["SQ_ACTIVE_INST_VALU"] * (it_launch / inner) * 4 / 1024 / (launch_ms * 1e-3 * 2.4e9)
+                        "valu_busy_share_of_launch": (c["SQ_ACTIVE_INST_VALU"] * (it_launch / inner) * SQ_QUAD / 1024 / (launch_ms * 1e-3 * 2.4e9)
                                                       if c.get("SQ_ACTIVE_INST_VALU") else None),
                         "source": tj.get("source")}
         except Exception:
@@ -838,32 +903,56 @@ def main():
         except Exception:
             rb = None
         out["roofline_binding"] = rb
-        # BASELINE config 4's per-GPU shape: what bounds the T = 96 sweep (counters from the committed --pmc passes of
-        # tools/regime_run.py at 125 000 x 96, duration live from this run's value_125k_T96)
-        r96 = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "t96_traffic.json")))
-            c = tj["sq_counters_per_launch"]
-            if "value_125k_T96" in extras and tj["homes"] == 125_000 and tj["T"] == 96:
+        # BASELINE config 4: what bounds the T = 96 sweep at its per-GPU shape (125 000 x 96) and at the config's whole size
+        # on ONE GPU (1 000 000 x 96: the residences' state no longer fits the Infinity Cache) -- counters from the
+        # committed --pmc passes of tools/regime_run.py, duration live from this run's value_125k_T96 / value_1M_T96
+        def t96_roofline(tfile, key, homes):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", tfile)))
+                c = tj["sq_counters_per_launch"]
+                if not (key in extras and tj["homes"] == homes and tj["T"] == 96):
+                    return None
                 it, us = tj["iterations_per_launch"], tj["avg_launch_us_profiled"]
-                peak = 1024 * 2.4e9 / 4
-                r96 = {"kernel": tj["kernel"] + f" ({it} ADMM iterations of 125 000 residences x 96 slots per launch)",
-                       "bound": "valu-issue", "achieved": c["SQ_INSTS_VALU"] / (us * 1e-6) / 1e9, "peak": peak / 1e9,
-                       "unit": "G wave64 VALU instructions/s", "frac": c["SQ_INSTS_VALU"] / (us * 1e-6) / peak,
-                       "valu_busy_share_of_launch": c["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (us * 1e-6 * 2.4e9),
-                       "valu_instructions_per_wavefront_and_iteration": c["SQ_INSTS_VALU"] / c["SQ_WAVES"] / it,
-                       "salu_instructions_per_wavefront_and_iteration": c["SQ_INSTS_SALU"] / c["SQ_WAVES"] / it,
-                       "hbm": {"bound": "hbm", "achieved": tj["algorithmic_bytes_per_launch"] / (us * 1e-6) / 1e9,
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": tj["algorithmic_bytes_per_launch"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                               "traffic": tj["hbm_bytes_per_launch"], "bytes_per_launch": tj["algorithmic_bytes_per_launch"]},
-                       "avg_launch_ms_profiled": us * 1e-3, "ms_per_step_live": extras["value_125k_T96"]["ms_per_step"],
-                       "source": tj["source"]}
-        except Exception:
-            r96 = None
-        out["roofline_125k_T96"] = r96
+                peak = VALU_PEAK
+                return {"kernel": tj["kernel"] + f" ({it} ADMM iterations of {homes} residences x 96 slots per launch)",
+                        "bound": "valu-issue", "achieved": c["SQ_INSTS_VALU"] / (us * 1e-6) / 1e9, "peak": peak / 1e9,
+                        "peak_source": VALU_PEAK_SOURCE,
+                        "unit": "G wave64 VALU instructions/s", "frac": c["SQ_INSTS_VALU"] / (us * 1e-6) / peak,
+                        "valu_busy_share_of_launch": c["SQ_ACTIVE_INST_VALU"] * SQ_QUAD / 1024 / (us * 1e-6 * 2.4e9),
+                        "valu_instructions_per_wavefront_and_iteration": c["SQ_INSTS_VALU"] / c["SQ_WAVES"] / it,
+                        "salu_instructions_per_wavefront_and_iteration": c["SQ_INSTS_SALU"] / c["SQ_WAVES"] / it,
+                        "hbm": {"bound": "hbm", "achieved": tj["algorithmic_bytes_per_launch"] / (us * 1e-6) / 1e9,
+                                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": tj["algorithmic_bytes_per_launch"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                "traffic": tj["hbm_bytes_per_launch"], "bytes_per_launch": tj["algorithmic_bytes_per_launch"]},
+                        "avg_launch_ms_profiled": us * 1e-3, "ms_per_step_live": extras[key]["ms_per_step"],
+                        "source": tj["source"]}
+            except Exception:
+                return None
+        out["roofline_125k_T96"] = t96_roofline("t96_traffic.json", "value_125k_T96", 125_000)
+        out["roofline_1M_T96"] = t96_roofline("t96_1m_traffic.json", "value_1M_T96", 1_000_000)
         out.update(extras)
         out["cpu_baseline"] = cpu_baseline(w, state) if state is not None else None
+        if tte is not None:
+            cpu_it_s = (n_total / out["cpu_baseline"]["value"]) if out.get("cpu_baseline") else None
+            a, b = tte["pdhg_eps"], tte["reference_rule_binary_15_iterations"]
+            out["time_to_eps"] = {
+                "time_to_eps_ms": a["ms"] if a else None, "iterations": a["iterations"] if a else None,
+                "converged_at": a["converged_at"] if a else None, "eps": args.eps, "runs_ms": a["all_ms"] if a else None,
+                "rule": "ONE AdmmEngine.run(iter_max=1000, eps, history=False) from the zero state on a fresh engine, wall clock "
+                        "between two synchronises, median of 5 engines; stops after max_h diff <= eps has held for 8 iterations "
+                        "(+ at most the rest of a 64-iteration burst) and one more iteration that writes the schedules",
+                "with_per_residence_diff_history_ms": (tte["pdhg_eps_with_diff_history"] or {}).get("ms"),
+                "cpu_time_to_eps_s_projected": (a["iterations"] * cpu_it_s) if (a and cpu_it_s) else None,
+                "cpu_projection": "iterations x the cpu_baseline's time for one iteration's work (steady-state work; the "
+                                  "transient's operator QPs would come on top)",
+                "reference_rule": {"ms": b["ms"], "iterations": b["iterations"], "home_solver": "binary", "runs_ms": b["all_ms"],
+                                   "with_per_residence_diff_history_ms":
+                                       tte["reference_rule_binary_15_iterations_with_diff_history"]["ms"],
+                                   "rule": "the reference's own stopping rule: iter_max = 15 iterations, on/off chargers "
+                                           "(lpsolver.py:243, 254), AdmmEngine.run(15) from the zero state",
+                                   "cpu_s_projected": (15 * cpu_it_s) if cpu_it_s else None},
+            }
         print(json.dumps(out), flush=True)
     if group is not None:
         dist.barrier()

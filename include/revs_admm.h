@@ -461,7 +461,7 @@ int revs_plan_set_fold_redo(revs_plan_t *plan, int32_t steps);
  *        desc.info (pinned int32[T]: the models' pivot counts) -- and the loop's limits.
  *   st   in: y = the current multipliers, y_trial = scratch (double[m][T] each); use_y: y is not all zero;
  *        sup: candidate set (0 / 1) that lists every row with y != 0 (few of them: row-wise shifts), or
- *        -1; the state; have_first: stats block 0 already holds the evaluation of y on this state;
+ *        -1; the state; have_first: stats block 0 already holds the evaluation of y on this state (first_tag);
  *        have_pre: ... and block 1 the evaluation of the chain's trial (small model on set 0, full step
  *        for the slots not within tolerance), made with the row-wise shifts iff chain_few_in;
  *        out: ok (P_est_new holds the answer to tolerance; else y has been cleared and the caller's ADMM
@@ -485,6 +485,10 @@ typedef struct {
     float *p_est_new;
     int32_t have_first, have_pre, chain_few_in;
     int32_t ok, newton, evals, pivots, models_small, models_general, last_small, few, pre_kept, cur, nsup_sum, nsup_max;
+    /* in: the sequence tags ([8 t + 5] of every slot's record) of the evaluations have_first / have_pre refer to, as the
+     * caller saw them (0: not checked).  A block that no longer carries its tag -- a launch wrote it since -- is
+     * REVS_EINVAL, not a solve from other numbers. */
+    double first_tag, pre_tag;
 } revs_newton_state_t;
 int revs_plan_newton_solve(revs_plan_t *plan, revs_newton_state_t *st, void *stream);
 

@@ -18,7 +18,7 @@ problems* and solves them exactly:
   ADMM loop         lpsolver.py:242-290  -> solve_ADMM
   individual mode   lpsolver.py:407-460  -> solve_residence
 
-Parity pin (tests/test_oracle_golden.py): the reference's own stored results
+Parity pin (tests/test_oracle.py): the reference's own stored results
 under out/121144-com2/ (tests/golden/revs_121144.npz).  `diff[1]` of all 267 EV
 homes of the stored distributed run is reproduced to 1e-12, the stored
 individual-mode schedules are optimal for the restated model with identical

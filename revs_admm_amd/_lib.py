@@ -91,7 +91,7 @@ class NewtonState(C.Structure):
                 ("ok", C.c_int32), ("newton", C.c_int32), ("evals", C.c_int32), ("pivots", C.c_int32),
                 ("models_small", C.c_int32), ("models_general", C.c_int32), ("last_small", C.c_int32),
                 ("few", C.c_int32), ("pre_kept", C.c_int32), ("cur", C.c_int32), ("nsup_sum", C.c_int32),
-                ("nsup_max", C.c_int32)]
+                ("nsup_max", C.c_int32), ("first_tag", C.c_double), ("pre_tag", C.c_double)]
 
 
 class Tree(C.Structure):

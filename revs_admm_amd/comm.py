@@ -35,3 +35,50 @@ def host_hook(fn):
             traceback.print_exc()
             return 1
     return HOST_ALLREDUCE_FN(cb)
+
+
+class LocalRanks:
+    """N logical ranks inside ONE process (one thread each), for rehearsing the sharded native loops on a single
+    device beyond the two processes RCCL-less boxes allow: `LocalRanks(8).rank(r)` is handed to `AdmmEngine(group=...)`
+    by thread r, and every all-reduce of that engine -- the library's hook communicator (revs_comm_create_hook) inside
+    the native loops included -- becomes a barrier-synchronised in-memory reduction: every rank deposits its buffer,
+    all wait, every rank reduces the N buffers in rank order (the same order on every rank: identical bits), all wait
+    again before the buffers are reused.  A rank that issues another collective than its peers (other size, or none)
+    breaks the barrier after `timeout` seconds instead of hanging.  Used by tests/test_gpu_sharded.py (world size 8)."""
+
+    def __init__(self, size, timeout=120.0):
+        import threading
+        self.size = int(size)
+        self._bar = threading.Barrier(self.size, timeout=timeout)
+        self._slots = [None] * self.size
+        self.calls = [[] for _ in range(self.size)]      # element counts of every collective, per rank
+
+    def rank(self, r):
+        return _LocalRank(self, int(r))
+
+    def abort(self):
+        self._bar.abort()
+
+
+class _LocalRank:
+    def __init__(self, world, r):
+        self.world, self.rank_id, self.size = world, r, world.size
+
+    def allreduce_host(self, a, op=0):
+        """In place on a contiguous float64 numpy array; op 0 sum, 2 max, 3 min (revs_comm_allreduce_f64's codes)."""
+        w = self.world
+        w.calls[self.rank_id].append(int(a.size))
+        w._slots[self.rank_id] = a
+        w._bar.wait()
+        if any(s.size != a.size for s in w._slots):
+            w._bar.abort()
+            raise RuntimeError(f"LocalRanks: rank {self.rank_id} reduces {a.size} elements, its peers "
+                               f"{[s.size for s in w._slots]}")
+        fn = {0: np.add, 2: np.maximum, 3: np.minimum}[int(op)]
+        out = w._slots[0].copy()
+        for s in w._slots[1:]:
+            fn(out, s, out=out)
+        w._bar.wait()                    # every rank has read every buffer
+        a[...] = out
+        w._bar.wait()                    # ... and written its own: the slots may be reused
+        return a

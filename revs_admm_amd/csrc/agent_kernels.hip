@@ -145,32 +145,41 @@ constexpr int kBlock = 256;
 constexpr float kSocTarget = 0.9f;   // lpsolver.py:109
 constexpr float kSocMax = 1.0f;      // lpsolver.py:102-103
 
-// rank of each of this lane's SPL keys among the group's LPA*SPL keys, ties to
-// the earlier slot: rank_j = #{tau : key_tau < key_j or (key_tau == key_j and tau < t_j)}
-// = #{tau : (key_tau, tau) < (key_j, t_j)} lexicographically: the key mapped to an integer of the same order in the
-// high word, the slot in the low word, ONE 64-bit compare and an add-with-carry per pair (the two float compares,
-// the slot compare and the mask logic were five vector and two scalar instructions per pair: 360 + 144 per
-// wavefront, most of the on/off charger's solve).
+// rank of each of this lane's SPL keys among the group's LPA*SPL keys, ties to the earlier slot:
+// rank_j = #{tau : key_tau < key_j or (key_tau == key_j and tau < t_j)} -- numpy's stable argsort, which is what the
+// oracle ranks with (oracle/revs_oracle.py home_solve_binary; the reference's Gurobi picks among exactly tied slots
+// by an order of its own).  The keys are DOUBLES formed from the float inputs in the oracle's
+// own order of operations (round 5; they were floats, and near-ties inside float rounding went to another slot of
+// equal cost for ~0.3 % of the residences): mapped to integers of the same order, (key, slot) pairs compare
+// lexicographically as ord_tau < ord_j + [tau < t_j] -- every slot of an earlier lane precedes every slot of this
+// one, none of a later lane does, and the lane's own slots are settled behind the loop.
 template <int LPA, int SPL>
-__device__ __forceinline__ void group_rank(const float (&key)[SPL], int t0, int (&rank)[SPL]) {
-    int ord[SPL];
-    long long mine[SPL];
+__device__ __forceinline__ void group_rank(const double (&key)[SPL], int lig, int (&rank)[SPL]) {
+    long long ord[SPL];
 #pragma unroll
     for (int j = 0; j < SPL; ++j) {
-        const int b = __float_as_int(key[j]);
-        ord[j] = b ^ ((b >> 31) & 0x7fffffff);           // floats -> integers of the same order (-0 < +0: keys are sums, never -0)
-        mine[j] = ((long long)ord[j] << 32) | (unsigned int)(t0 + j);
+        const long long b = __double_as_longlong(key[j]);
+        ord[j] = b ^ ((b >> 63) & 0x7fffffffffffffffLL);  // doubles -> integers of the same order (keys are sums and products of a positive rating: never -0)
         rank[j] = 0;
     }
 #pragma unroll 1
     for (int sl = 0; sl < LPA; ++sl) {
+        const long long c = sl < lig ? 1 : 0;
+        long long thr[SPL];
+#pragma unroll
+        for (int j = 0; j < SPL; ++j) thr[j] = ord[j] + c;          // (+inf + 1 does not overflow)
 #pragma unroll
         for (int sj = 0; sj < SPL; ++sj) {
-            const long long other = ((long long)__shfl(ord[sj], sl, LPA) << 32) | (unsigned int)(sl * SPL + sj);
+            const long long other = __shfl(ord[sj], sl, LPA);
 #pragma unroll
-            for (int j = 0; j < SPL; ++j) rank[j] += other < mine[j] ? 1 : 0;
+            for (int j = 0; j < SPL; ++j) rank[j] += other < thr[j] ? 1 : 0;
         }
     }
+    // (sl == lig compared strictly: an equal key at an EARLIER slot of this lane precedes as well)
+#pragma unroll
+    for (int j = 1; j < SPL; ++j)
+#pragma unroll
+        for (int sj = 0; sj < j; ++sj) rank[j] += ord[sj] == ord[j] ? 1 : 0;
 }
 
 // One slot's verdict inside the streaming sweep's launch (workgroup t < T).
@@ -226,11 +235,12 @@ __device__ __forceinline__ void stream_verdict_body(const AgentArgs &a, const in
 #ifndef REVS_AGENT_CHAIN_WAVES
 #define REVS_AGENT_CHAIN_WAVES 6     // ... of the folded chain's sweep (tuning: build with -D; 5 / 6 / 7 / 8: 0.0469 / 0.0462 / 0.0466 / 0.0497 ms per binding iteration)
 #endif
-constexpr int agent_waves(int spl, bool full_rows, bool multi, bool chain) {
-    return (spl <= 4 && !full_rows) ? (multi ? REVS_AGENT_MULTI_WAVES : (chain ? REVS_AGENT_CHAIN_WAVES : 8)) : 4;
+// (on/off chargers, one iteration per launch: 7 -- the double ranking keys of round 5 do not fit 64 registers without scratch)
+constexpr int agent_waves(int spl, bool full_rows, bool multi, bool chain, int mode) {
+    return (spl <= 4 && !full_rows) ? (multi ? REVS_AGENT_MULTI_WAVES : (chain ? REVS_AGENT_CHAIN_WAVES : (mode == REVS_MODE_BINARY ? 7 : 8))) : 4;
 }
 template <int LPA, int SPL, int MODE, bool FULL_ROWS = false, bool MULTI = false, bool CHAIN = false>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(agent_waves(SPL, FULL_ROWS, MULTI, CHAIN))))
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(agent_waves(SPL, FULL_ROWS, MULTI, CHAIN, MODE))))
 void agent_step_kernel(const AgentArgs a) {
     constexpr int kHomesPerBlock = kBlock / LPA;
     // An earlier launch of this call failed its verdict: this launch must write nothing.  The
@@ -495,23 +505,28 @@ void agent_step_kernel(const AgentArgs a) {
         // p_t = e_t * rating, e_t binary (lpsolver.py:92-98).  Switching slot t on
         // costs delta_t = rating ((kappa/2) rating + q_t); take the nmin cheapest,
         // then more while delta < 0, up to nmax.
-        float key[SPL];
+        double key[SPL];
         int rank[SPL];
         int nwin = 0;
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
 #pragma clang fp contract(off)
-            key[j] = win[j] ? h.rating * (0.5f * kappa * h.rating + q[j]) : INFINITY;
+            // delta_t in double, from the float inputs, in the oracle's order of operations (home_linear_term,
+            // home_solve_binary): the on/off decision is then the float64 restatement's, bit for bit
+            const double kd = (double)kappa, rt = (double)h.rating;
+            const double at = (double)gm[j] + 0.5 * kd * ((double)pe[j] + (double)pso[j]);
+            const double qd = kd * (double)L[j] + (double)cst[j] - at;
+            key[j] = win[j] ? rt * (0.5 * kd * rt + qd) : (double)INFINITY;
             nwin += win[j] ? 1 : 0;
         }
         nwin = (int)group_sum<LPA>((float)nwin);
-        group_rank<LPA, SPL>(key, t0, rank);
+        group_rank<LPA, SPL>(key, lig, rank);
         const bool infeasible = ev && (h.nmin > h.nmax || h.nmin > nwin);
         status = infeasible ? 1 : 0;
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
             const bool take = win[j] && !infeasible &&
-                              (rank[j] < h.nmin || (rank[j] < h.nmax && key[j] < 0.f));
+                              (rank[j] < h.nmin || (rank[j] < h.nmax && key[j] < 0.0));
             p[j] = take ? h.rating : 0.f;
         }
     } else if constexpr (MODE == REVS_MODE_RELAXED_PDHG) {
@@ -998,7 +1013,8 @@ __global__ __launch_bounds__(kBlock) void residence_kernel(
     if (live) h = homes[agent];
     else { h.ev = 0; h.start = 0; h.end = 0; h.nmin = 0; h.nmax = 0; h.rating = 0.f; h.capacity = 1.f; h.initial = 0.f; }
     const bool ev = h.ev != 0;
-    float key[SPL], p[SPL], pfx[SPL];
+    double key[SPL];
+    float p[SPL], pfx[SPL];
     int rank[SPL];
     bool win[SPL];
 #pragma unroll
@@ -1006,14 +1022,15 @@ __global__ __launch_bounds__(kBlock) void residence_kernel(
 #pragma clang fp contract(off)
         const int t = t0 + j;
         win[j] = ev && live && t < T && t >= h.start && t < h.end;
-        const float c = (t < T) ? tariff[t] : 0.f;
-        key[j] = win[j] ? 0.01f * c * h.rating - 0.99f * (h.rating / h.capacity) : INFINITY;
+        const double c = (t < T) ? (double)tariff[t] : 0.0;
+        // (double, the oracle's order of operations: solve_residence)
+        key[j] = win[j] ? 0.01 * c * (double)h.rating - 0.99 * ((double)h.rating / (double)h.capacity) : (double)INFINITY;
     }
-    group_rank<LPA, SPL>(key, t0, rank);
+    group_rank<LPA, SPL>(key, lig, rank);
     float acc = 0.f;
 #pragma unroll
     for (int j = 0; j < SPL; ++j) {
-        p[j] = (win[j] && rank[j] < h.nmax && key[j] < 0.f) ? h.rating : 0.f;
+        p[j] = (win[j] && rank[j] < h.nmax && key[j] < 0.0) ? h.rating : 0.f;
         acc += p[j];
         pfx[j] = acc;
     }

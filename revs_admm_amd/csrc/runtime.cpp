@@ -519,10 +519,19 @@ extern "C" int revs_plan_newton_solve(revs_plan_t *plan, revs_newton_state_t *st
                  st->p_est_new && st->sup >= -1 && st->sup <= 1, "revs_plan_newton_solve: bad argument");
     const revs_plan_desc_t &d = plan->d;
     const revs_newton_opts_t &o = plan->newton;
-    REVS_REQUIRE(o.k_slabs && d.cand_idx1 && d.cand_cnt1 && d.cand_val1 && d.stats1 && d.stats1_host && d.yhat && d.k_full &&
+    REVS_REQUIRE(o.k_slabs && d.cand_idx1 && d.cand_cnt1 && d.cand_val1 && d.stats && d.stats_host && d.stats1 && d.stats1_host && d.yhat && d.k_full &&
                  d.info && d.max_pivots > 0 && d.eps > 0, "revs_plan_newton_solve: revs_plan_set_newton / the chain's buffers are missing");
     const int T = d.T, A = REVS_DUAL_AMAX;
     REVS_REQUIRE(T <= 256, "revs_plan_newton_solve: T = %d", T);
+    // the blocks the caller refers to still hold the evaluations it saw (every slot's record carries the evaluation's tag)
+    for (int blk = 0; blk < 2; ++blk) {
+        const double want = blk ? st->pre_tag : st->first_tag;
+        if (!(blk ? st->have_pre : st->have_first) || want == 0.0) continue;
+        const volatile double *b = blk ? d.stats1_host : d.stats_host;
+        for (int t = 0; t < T; ++t)
+            REVS_REQUIRE(b[8 * t + 5] == want, "revs_plan_newton_solve: stats block %d no longer holds evaluation %g (slot %d carries %g)",
+                         blk, want, t, (double)b[8 * t + 5]);
+    }
     hipStream_t s = (hipStream_t)stream;
     int64_t *const ci[2] = {d.cand_idx, d.cand_idx1};
     int32_t *const cc[2] = {d.cand_cnt, d.cand_cnt1};
@@ -819,7 +828,11 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
     // most two sweeps are unjudged at any time); a word joins the sticky one when its iteration is kept.
     REVS_REQUIRE((st->p_est_3 != nullptr) == (st->p_sch_3 != nullptr) && (st->p_est_3 != nullptr) == (st->gamma_3 != nullptr),
                  "revs_plan_chain_fold_run: the third set of state buffers is all three or none");
-    static const bool no_spec = getenv("REVS_FOLD_NO_SPEC") != nullptr;     // (debugging aid)
+#ifdef REVS_TUNING        // (debugging aids of tuning builds; the product build has no process-wide toggles in this loop)
+    static const bool no_spec = getenv("REVS_FOLD_NO_SPEC") != nullptr;
+#else
+    constexpr bool no_spec = false;
+#endif
     const bool can_spec = st->p_est_3 != nullptr && !no_spec;
     bool swept = false;
     unsigned int sweep_no = 0;
@@ -974,7 +987,11 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
         int why = 0;
         const int acc = chain_accept_impl(d.T, S0.st_host, S1.st_host, scale, d.eps, REVS_DUAL_AMAX, d.kadd, 1,
                                           &nsum, &nmax, &why);
+#ifdef REVS_TUNING
         static const bool ftrace = getenv("REVS_FOLD_TRACE") != nullptr;
+#else
+        constexpr bool ftrace = false;
+#endif
         if (ftrace && !acc) {
             double r0 = 0, r1 = 0, ncm = 0;
             int arm = 0;
@@ -1069,7 +1086,11 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
         st->c_out = nullptr;
         ++*kept_steps;
         par ^= 1;
-        static const bool no_pipe = getenv("REVS_FOLD_NO_PIPE") != nullptr;     // (debugging aid)
+#ifdef REVS_TUNING
+        static const bool no_pipe = getenv("REVS_FOLD_NO_PIPE") != nullptr;
+#else
+        constexpr bool no_pipe = false;
+#endif
         have_k1 = !no_pipe;
         if (redo > 0) {                       // (the caller books this iteration's extra Newton steps: it is the call's last)
             st->redone = redo;

@@ -230,9 +230,13 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
         local_counts = np.bincount(node_of, minlength=M).astype(np.int64)
         node_ptr = np.concatenate([[0], np.cumsum(local_counts)]).astype(np.int64)
         counts = local_counts.copy()
+        # (a comm.LocalRanks rank: logical ranks inside one process -- a host-side transport like a gloo group)
+        self._local_group = group is not None and hasattr(group, "allreduce_host")
         self._host_group = (group is not None and _kernels is None
-                            and torch.distributed.get_backend(group) != "nccl")
-        if group is not None:
+                            and (self._local_group or torch.distributed.get_backend(group) != "nccl"))
+        if self._local_group:
+            counts = group.allreduce_host(counts.astype(np.float64), 0).astype(np.int64)
+        elif group is not None:
             ct = torch.from_numpy(counts) if self._host_group else torch.from_numpy(counts).to(self.dev)
             torch.distributed.all_reduce(ct, group=group)
             counts = ct.cpu().numpy()
@@ -434,15 +438,21 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
                 except ValueError:                 # (row indices beyond the packed fields)
                     if self.op.voltage == "tree":
                         raise
+            rejected = False
             if tr is not None:
+                # verified row by row: every constrained row's voltage for two random injection profiles, relative to
+                # THAT row's own magnitude (a row whose entries are small against the feeder's largest is checked as
+                # tightly as the largest)
                 probe = np.random.default_rng(0).uniform(0.5, 1.5, (M, 2)) * (counts > 0)[:, None]
                 ref = (Rn @ probe) * (counts > 0)[:, None]
                 got = tree_voltage_host(tr, probe)
-                if np.abs(got - ref).max() > 1e-9 * max(np.abs(ref).max(), 1e-300):
+                row_scale = np.maximum(np.abs(ref).max(axis=1, keepdims=True), 1e-300)
+                # (1e-13 of the largest voltage: the prefix sums' own rounding, which a small row cannot be held to)
+                if (np.abs(got - ref) > np.maximum(1e-9 * row_scale, 1e-13 * np.abs(ref).max())).any():
                     if not recovered:
                         raise ValueError("feeder: the tree does not reproduce Rn (R[i][j] = 2 x the "
                                          "resistance shared by the substation->i and ->j paths)")
-                    tr = None                              # (Rn is not a radial feeder's matrix: dense product)
+                    tr, rejected = None, True              # (Rn is not a radial feeder's matrix: dense product)
             if tr is not None:
                 self._tree_host = tr
                 self._tree_dev = {k: up(tr[k].view(np.int64) if k == "pack" else tr[k]) for k in ("pack", "w")}
@@ -452,16 +462,24 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
                           "revs_plan_set_tree")
                     self._tree_newton = tr["n"] <= _lib.TREE_SWEEP_MAX
                     self._tree_eval = True
+            elif self.op.voltage == "tree" and rejected:
+                raise ValueError('OperatorOptions(voltage="tree"): Rn is not the matrix of a radial feeder (the tree recovered '
+                                 "from it does not reproduce its rows); pass feeder= or use the dense product")
             elif self.op.voltage == "tree":
                 raise ValueError(f"feeder has {len(par)} nodes; the tree form holds {_lib.TREE_MAX}")
         elif self.op.voltage == "tree":
             raise ValueError('OperatorOptions(voltage="tree") needs feeder=')
+        self.tree_recovered = bool(recovered and self._tree is not None)   # the tree form runs on a tree recovered from Rn
         self._hook_ref = None
         if group is not None and cuda and _kernels is None and (comm_hook is not None or self._host_group):
             # the caller's transport behind the library's communicator (revs_comm_create_hook)
-            ws, rk = torch.distributed.get_world_size(group), torch.distributed.get_rank(group)
+            if self._local_group:
+                ws, rk = group.size, group.rank_id
+            else:
+                ws, rk = torch.distributed.get_world_size(group), torch.distributed.get_rank(group)
             from .comm import group_allreduce_hook, host_hook
-            self._hook_ref = host_hook(comm_hook if comm_hook is not None else group_allreduce_hook(group))
+            self._hook_ref = host_hook(comm_hook if comm_hook is not None else
+                                       (group.allreduce_host if self._local_group else group_allreduce_hook(group)))
             self._comm = self.lib.revs_comm_create_hook(self._hook_ref, None, rk, ws)
             if not self._comm:
                 raise _lib.RevsError("revs_comm_create_hook failed: " + self.lib.revs_last_error().decode())
@@ -529,6 +547,12 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
             code = 0 if op in (None, RO.SUM) else (2 if op == RO.MAX else 3)
             check(self.lib.revs_comm_allreduce_f64(self._comm, ptr(t), t.numel(), code, self.stream),
                   "revs_comm_allreduce_f64")
+            return
+        if getattr(self, "_local_group", False):                  # logical ranks in this process: through the host, as doubles
+            code = 0 if op in (None, RO.SUM) else (2 if op == RO.MAX else 3)
+            h = t.detach().cpu().to(torch.float64).contiguous()
+            self.group.allreduce_host(h.numpy().reshape(-1), code)
+            t.copy_(h.to(t.dtype))
             return
         if getattr(self, "_host_group", False) and t.is_cuda:     # a CPU-side group: through the host
             h = t.cpu()
@@ -892,12 +916,22 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
             f = int(self.lib.revs_plan_status_flags(self._plan, 1))
         else:
             f = 0
-        f |= int((self.status & 3).max().item()) if self.n else 0
+        if self.n:      # bits 0-2 of the last sweep's per-residence status words, OR-ed (one read-back)
+            st = self.status
+            f |= sum(int(v) for v in torch.stack([(st & b).max() for b in (1, 2, 4)]).cpu().tolist())
         if self.group is not None:
-            t = torch.tensor([float(f & 1), float((f >> 1) & 1)], dtype=torch.float64, device=self.dev)
+            t = torch.tensor([float(f & 1), float((f >> 1) & 1), float((f >> 2) & 1)], dtype=torch.float64, device=self.dev)
             self._allreduce(t, torch.distributed.ReduceOp.MAX)
-            a, b = t.cpu().tolist()
-            f = int(a) | (int(b) << 1)
+            a, b, c = t.cpu().tolist()
+            f = int(a) | (int(b) << 1) | (int(c) << 2)
+        if f & 4:
+            # bit 2: a PDHG residence's KKT polish did not settle within its six steps -- its schedule is PDHG's
+            # iterate at the loosened 1e-4 step tolerance (feasible, a little off the optimum): counted, warned once
+            self.polish_unsettled = getattr(self, "polish_unsettled", 0) + 1
+            if self.polish_unsettled == 1:
+                import warnings
+                warnings.warn("revs_admm_amd: a residence's KKT polish did not settle (status bit 2); its schedule is "
+                              "PDHG's iterate at the 1e-4 step tolerance", RuntimeWarning, stacklevel=2)
         if f & 1:
             raise _lib.RevsError("No solution found (lpsolver.py:153-155): a residence's "
                                  "charging window cannot reach 90% state of charge")
@@ -928,7 +962,7 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
         except Exception:
             pass
 
-    def run(self, iter_max=15, eps=None, patience=8):
+    def run(self, iter_max=15, eps=None, patience=8, history=True):
         """Full solve_ADMM loop; returns diff (iterations, n) in the caller's home order.
         The per-iteration diff of every residence (lpsolver.py:284) is collected on the device --
         the steady-state launches write their row themselves -- and fetched in pieces of at most
@@ -939,11 +973,16 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
         ~0 in every run and rows that start to bind make it jump: one iteration proves nothing) --
         judged on the records the streaming launches leave (`max_diff`: folded on the device, no
         read-back of diff), at the end of the burst in which it happened; one more iteration then
-        writes the schedules.  `converged_at`: the first iteration of that stretch, or None."""
-        diffs = torch.empty((iter_max, self.n), dtype=torch.float32)
-        rows = max(1, min(iter_max, int(2e9) // (4 * max(self.n, 1))))
-        hist = torch.empty((rows, self.n), dtype=torch.float32, device=self.dev)
-        inv = torch.from_numpy(np.ascontiguousarray(self.inv_perm, dtype=np.int64)).to(self.dev)
+        writes the schedules.  `converged_at`: the first iteration of that stretch, or None.
+        `history=False`: the per-residence diff of every iteration is neither kept nor fetched (at
+        100 000 residences x 500 iterations it is 200 MB to carry to the host, more time than the
+        iterations themselves take); returns the number of iterations run, `max_diff` holds max_h diff[h]
+        of the streamed ones."""
+        rows = max(1, min(iter_max, int(2e9) // (4 * max(self.n, 1)))) if history else iter_max
+        if history:
+            diffs = torch.empty((iter_max, self.n), dtype=torch.float32)
+            hist = torch.empty((rows, self.n), dtype=torch.float32, device=self.dev)
+            inv = torch.from_numpy(np.ascontiguousarray(self.inv_perm, dtype=np.int64)).to(self.dev)
         self.converged_at = None
         k, it0, good, seen, stop = 0, self.iteration, 0, self.iteration, False
         while k < iter_max:
@@ -953,10 +992,11 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
                 if (not last and self._stream_ok() and self._fused_ready):
                     # (with eps: bursts of at most 64, so that the run ends soon after the stretch)
                     done = self._stream_run(min(rows - r, iter_max - 1 - k, 64 if eps is not None else rows),
-                                            hist[r:])
+                                            hist[r:] if history else None)
                 else:
                     self.step(write_sc=last)
-                    hist[r].copy_(self.diff)
+                    if history:
+                        hist[r].copy_(self.diff)
                     done = 1
                     if k == 0:
                         self.check_status()          # (synchronises once)
@@ -974,11 +1014,12 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
                             self.converged_at = seen - patience + 1
                             stop = True
             # (back to the caller's home order on the device: one gather, one copy)
-            diffs[base:k].copy_(hist[:r].index_select(1, inv))
+            if history:
+                diffs[base:k].copy_(hist[:r].index_select(1, inv))
             if stop and last:
                 break
         self.check_status()
-        return diffs[:k].numpy()
+        return diffs[:k].numpy() if history else k
 
     # ------------------------------------------------------- state in / out
     def set_state(self, P_est, P_sch, G, iteration=None):

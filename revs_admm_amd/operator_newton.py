@@ -113,7 +113,7 @@ class DualNewtonMixin:
         `_pre_kept`: the accepted state is exactly the one `pre` (or `first`) left behind."""
         o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
         if o.native_newton and self._plan is not None and (self.group is None or self._comm is not None):
-            return self._operator_solve_newton_native(first is not None, pre is not None)
+            return self._operator_solve_newton_native(first, pre)
         A = _lib.DUAL_AMAX
         scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
         self._fold_resume = False
@@ -231,15 +231,21 @@ class DualNewtonMixin:
         self.op_converged = True
         return True
 
-    def _operator_solve_newton_native(self, have_first, have_pre):
+    def _operator_solve_newton_native(self, first, pre):
         """_operator_solve_newton's loop inside the library (revs_plan_newton_solve): same iterates and the
-        same bookkeeping, one native call per operator solve."""
+        same bookkeeping, one native call per operator solve.  `first` / `pre`: the caller's copies of stats blocks
+        0 / 1; the library works from the pinned blocks themselves and is told the tags the caller saw, so that a
+        launch that touched a block in between is an error, not a silently different solve."""
+        have_first, have_pre = first is not None, pre is not None
         o = self.op
         self._fold_resume = False
         ys = (self.yd[0], self.yd[1])
         sup = self._sup if (self._y_support and self._sup is not None) else -1
         st = _lib.NewtonState(ptr(ys[0]), ptr(ys[1]), int(self._y_support), sup, ptr(self.P_est), ptr(self.P_sch),
                               ptr(self.G), ptr(self.P_est_new), int(have_first), int(have_pre), int(self._chain_few))
+        # (one tag per evaluation, the same in every slot's record; a block whose slots carry different tags is not checked)
+        st.first_tag = float(first[0, 5]) if have_first and (first[:, 5] == first[0, 5]).all() else 0.0
+        st.pre_tag = float(pre[0, 5]) if have_pre and (pre[:, 5] == pre[0, 5]).all() else 0.0
         check(self.lib.revs_plan_newton_solve(self._plan, C.byref(st), self.stream), "revs_plan_newton_solve")
         self._pending_tag = [None, None]         # (the stats blocks were written by the native loop, which waited itself)
         self.yd = [ys[0], ys[1]] if st.y == ys[0].data_ptr() else [ys[1], ys[0]]

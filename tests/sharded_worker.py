@@ -20,7 +20,7 @@ sys.path.insert(0, HERE)
 sys.path.insert(0, os.path.dirname(HERE))
 
 
-def node_aligned_split(node_of, world):
+def node_aligned_split(node_of, world, align=32):
     """Shard boundaries at node boundaries (every node's residences then sit on ONE rank: its sums
     are formed in the one-process order and the all-reduce adds exact zeros) that are also a
     multiple of 32 residences (a PDHG residence iterates until the slowest of the residences sharing
@@ -31,7 +31,7 @@ def node_aligned_split(node_of, world):
     node_of = np.asarray(node_of)
     n = len(node_of)
     ok = np.flatnonzero((node_of[1:] != node_of[:-1])) + 1
-    ok = ok[ok % 32 == 0]
+    ok = ok[ok % align == 0]          # (align: 32 = a workgroup at T = 24; 8 = a wavefront there, which is what the grouping needs)
     cuts = [0]
     for r in range(1, world):
         cuts.append(int(ok[np.argmin(np.abs(ok - (n * r) // world))]))
@@ -66,8 +66,65 @@ def run_chunks(e, chunks, mode):
     return out
 
 
+def main_local(spec):
+    """`world` LOGICAL ranks in this one process, a thread each (revs_admm_amd.comm.LocalRanks): the library's hook
+    communicator with nranks = world -- the 64 x ranks partial-maximum slots of a ring slice, the block collectives, the
+    3 : 1 split of a burst's tail -- beyond the two processes the other cases use (a GPU box admits few processes on
+    its card; eight ranks of the real thing are the driver's 8-GPU run)."""
+    import threading
+    import traceback
+    import numpy as np
+    import torch
+    from revs_admm_amd.comm import LocalRanks
+    from revs_admm_amd.engine import AdmmEngine, OperatorOptions
+    world = spec["world"]
+    torch.cuda.set_device(0)
+    for case in spec["cases"]:
+        w = make_case(case)
+        cuts = node_aligned_split(w.node_of, world, align=case.get("align", 32))
+        counts = np.bincount(w.node_of, minlength=w.M)
+        for cfg in case["configs"]:
+            ranks = LocalRanks(world, timeout=180.0)
+            outs, errs = [None] * world, [None] * world
+
+            def work(r, _ranks=ranks, _outs=outs, _errs=errs, _cfg=cfg):
+                try:
+                    torch.cuda.set_device(0)
+                    lo, hi = int(cuts[r]), int(cuts[r + 1])
+                    kw = dict(case.get("burst") or {})
+                    e = AdmmEngine(w.cost, w.homes[lo:hi], w.load[lo:hi], w.node_of[lo:hi], w.Rn, kappa=w.kappa,
+                                   vset=w.vset, vlow=w.vlow, vhigh=w.vhigh, mode=case["mode"], device="cuda:0",
+                                   group=_ranks.rank(r), node_counts=counts, feeder=w.feeder,
+                                   op=OperatorOptions(stream_block=_cfg["block"], stream_overlap=_cfg["overlap"], **kw))
+                    assert e._comm is not None and e._plan is not None and e._tree is not None
+                    assert e._block == (_cfg["block"] if _cfg["block"] > 1 else 0)
+                    out = run_chunks(e, case["chunks"], case["mode"])
+                    out["lo"], out["hi"] = np.asarray(lo), np.asarray(hi)
+                    _outs[r] = out
+                    del e
+                except Exception:
+                    _errs[r] = traceback.format_exc()
+                    _ranks.abort()
+
+            threads = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+            bad = [f"rank {r}:\n{x}" for r, x in enumerate(errs) if x]
+            if bad:
+                print("\n".join(bad), flush=True)
+                raise SystemExit(1)
+            for r in range(world):
+                outs[r]["hook_calls"] = np.asarray(ranks.calls[r], np.int64)
+                np.savez(os.path.join(spec["outdir"], f"{case['name']}_{cfg['tag']}_r{r}.npz"), **outs[r])
+            torch.cuda.empty_cache()
+
+
 def main():
     spec = json.load(open(sys.argv[1]))
+    if spec.get("local"):
+        return main_local(spec)
     rank, world = spec["rank"], spec["world"]
     import numpy as np
     import torch

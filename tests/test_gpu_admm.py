@@ -20,7 +20,8 @@ def _engine(w, mode, **kw):
 @pytest.mark.parametrize("mode,omode", [("relaxed_exact", "relaxed"), ("pdhg", "relaxed"), ("pdhg_presolve", "relaxed")])
 def test_relaxed_trajectory(gpu_lib, mode, omode, stress, solver):
     """Continuous homes: the iteration map is Lipschitz, so the whole trajectory must
-    follow the oracle.  Tolerance: 2e-3 kW on schedules, 1e-3 relative on diff.
+    follow the oracle.  Tolerance: 5e-4 kW on schedules with the default operator solver (3 x the measured error;
+    2e-3 with the ADMM fallback forms, whose operator answers carry 2e-5 relative), 1e-3 relative on diff.
     (pdhg_presolve: revs_pdhg_t::polish = 3, the KKT steps from the carried multiplier before PDHG.)"""
     from helpers import f32, oracle_homes
     from oracle import revs_oracle as ro
@@ -38,9 +39,12 @@ def test_relaxed_trajectory(gpu_lib, mode, omode, stress, solver):
     d_ref, P_ref, S_ref, C_ref = ro.solve_ADMM(oracle_homes(w), w.Rn, w.node_of, w.cost, w.kappa,
                                                iters, w.vset, w.vlow, w.vhigh, mode=omode,
                                                util_eps=1e-10)
+    print(f"trajectory {mode}/{solver}: max |diff - oracle| {np.abs(diffs - d_ref).max():.2e}, |S - oracle| "
+          f"{np.abs(S - S_ref).max():.2e} kW, |C - oracle| {np.abs(C - C_ref).max():.2e}")
     assert np.abs(diffs - d_ref).max() < 1e-3 * max(1.0, d_ref.max())
-    assert np.abs(S - S_ref).max() < 2e-3
-    assert np.abs(P_sch - P_ref).max() < 2e-3
+    tol = 5e-4 if solver == "newton" else 2e-3     # (3 x the measured error; was 2e-3 for both)
+    assert np.abs(S - S_ref).max() < tol
+    assert np.abs(P_sch - P_ref).max() < tol
     assert np.abs(C - C_ref).max() < 2e-4
     # the run is doing real work: operator rows bind, and the first iterations (where some
     # g0 go negative) pass through the general home-space path before the fast path resumes
@@ -413,8 +417,9 @@ def test_relaxed_trajectory_T96(gpu_lib, solver):
     d_ref, P_ref, S_ref, C_ref = ro.solve_ADMM(oracle_homes(w), w.Rn, w.node_of, w.cost, w.kappa, 5,
                                                w.vset, w.vlow, w.vhigh, mode="relaxed",
                                                util_eps=1e-10)
+    print(f"T = 96 trajectory, {solver}: |S - oracle| {np.abs(S - S_ref).max():.2e} kW")
     assert np.abs(diffs - d_ref).max() < 1e-3 * max(1.0, d_ref.max())
-    assert np.abs(S - S_ref).max() < 2e-3 and np.abs(C - C_ref).max() < 2e-4
+    assert np.abs(S - S_ref).max() < (5e-4 if solver == "newton" else 2e-3) and np.abs(C - C_ref).max() < 2e-4
 
 
 def test_config3_all_communities_90pct_T96(gpu_lib, golden, feeder_R):
@@ -451,8 +456,82 @@ def test_config3_all_communities_90pct_T96(gpu_lib, golden, feeder_R):
     P_sch, S, C = e.result()
     d_ref, P_ref, S_ref, C_ref = ro.solve_ADMM(oh, feeder_R, np.arange(n), cost, 5.0, 3, 1.03,
                                                0.95, 1.05, mode="relaxed", util_eps=1e-10)
+    print(f"config 3, closed form, 3 iterations: |S - oracle| {np.abs(S - S_ref).max():.2e} kW")
     assert np.abs(diffs - d_ref).max() < 1e-3 * max(1.0, d_ref.max())
-    assert np.abs(S - S_ref).max() < 2e-3 and np.abs(C - C_ref).max() < 2e-4
+    assert np.abs(S - S_ref).max() < 5e-4 and np.abs(C - C_ref).max() < 2e-4
+
+
+def _config3(golden):
+    """BASELINE config 3's inputs (all communities, 90 % adoption drawn as revs_fixture.py:174-177 does, T = 96)."""
+    from helpers import f32
+    from oracle import revs_oracle as ro
+    from revs_admm_amd.engine import pack_homes
+    z, fd = golden
+    res_ids = z["res_id"]
+    n = len(res_ids)
+    np.random.seed(1234)
+    ev_homes = np.random.choice(res_ids, int(90 * 1e-2 * n), replace=False)
+    idx = {h: i for i, h in enumerate(res_ids)}
+    ev = np.zeros(n, bool)
+    ev[[idx[h] for h in ev_homes]] = True
+    LOAD = f32(np.repeat(z["LOAD"], 4, axis=1))
+    cost = f32(np.repeat(z["tariff_shift6"], 4))
+    return n, cost, LOAD, ro.Homes.uniform(LOAD, ev, 4.8, 20.0, 0.2, 44, 92), pack_homes(ev, 4.8, 20.0, 0.2, 44, 92)
+
+
+def test_config3_pdhg_15_iterations(gpu_lib, golden, feeder_R):
+    """Config 3 as bench.py's value_feeder_121144 runs it -- AdmmEngine.run(15), the reference's iter_max -- with PDHG
+    residences (the relaxed QP has unique optima: the whole trajectory is comparable): every residence's diff at all
+    15 iterations, the final schedules and SOC against the oracle's run."""
+    from oracle import revs_oracle as ro
+    from revs_admm_amd.engine import AdmmEngine
+    n, cost, LOAD, oh, rec = _config3(golden)
+    e = AdmmEngine(cost, rec, LOAD, np.arange(n), feeder_R, kappa=5.0, vset=1.03, vlow=0.95, vhigh=1.05, mode="pdhg")
+    diffs = e.run(15)
+    assert set(e.op_path_hist) == {"dual"} and e._tree_eval
+    P_sch, S, C = e.result()
+    d_ref, P_ref, S_ref, C_ref = ro.solve_ADMM(oh, feeder_R, np.arange(n), cost, 5.0, 15, 1.03, 0.95, 1.05,
+                                               mode="relaxed", util_method="dual")
+    print(f"config 3, PDHG, 15 iterations: max |diff - oracle| {np.abs(diffs - d_ref).max():.2e} (diff max {d_ref.max():.2e}, "
+          f"last {d_ref[-1].max():.2e}), |S - oracle| {np.abs(S - S_ref).max():.2e} kW, operator evaluations {sum(e.op_iters_hist)}")
+    assert np.abs(diffs - d_ref).max() < 1e-3 * max(1.0, d_ref.max())
+    assert np.abs(diffs[-1] - d_ref[-1]).max() < 0.02 * d_ref[-1].max() + 2e-6
+    assert np.abs(S - S_ref).max() < 5e-4 and np.abs(P_sch - P_ref).max() < 5e-4 and np.abs(C - C_ref).max() < 2e-4
+
+
+def test_config3_binary_teacher_forced_15_iterations(gpu_lib, golden, feeder_R):
+    """Config 3 with the reference's on/off chargers, 15 iterations, teacher-forced (every iteration starts from the
+    ORACLE's state rounded to float: one flipped exact tie would otherwise change every later iterate; the engine keeps
+    its own multipliers and fast-path flags).  Per iteration: the operator's answer against the oracle's, the
+    schedules against the oracle's home solve of the SAME float state -- identical for every residence (double keys)
+    -- and the dual update."""
+    from helpers import f32
+    from oracle import revs_oracle as ro
+    from revs_admm_amd.engine import AdmmEngine
+    n, cost, LOAD, oh, rec = _config3(golden)
+    iters = 15
+    *_, tr = ro.solve_ADMM(oh, feeder_R, np.arange(n), cost, 5.0, iters, 1.03, 0.95, 1.05, mode="binary", keep=True,
+                           util_method="dual")
+    e = AdmmEngine(cost, rec, LOAD, np.arange(n), feeder_R, kappa=5.0, vset=1.03, vlow=0.95, vhigh=1.05, mode="binary")
+    z0 = np.zeros_like(LOAD)
+    states = [(z0, z0, z0)] + [(tr.P_est[k], tr.P_sch[k], tr.G[k]) for k in range(iters)]
+    worst_pe = 0.0
+    for k in range(iters):
+        pe, ps, gm = (f32(a) for a in states[k])
+        chain_ok = e._chain_ok
+        e.set_state(pe, ps, gm)
+        e._chain_ok = chain_ok
+        e.step()
+        pe_new = e.P_est.cpu().numpy()[e.inv_perm]
+        worst_pe = max(worst_pe, float(np.abs(pe_new - tr.P_est[k]).max()))
+        P_sch, S, C = e.result()
+        p_chk = ro.home_solve_binary(cost, oh, pe, ps, gm, 5.0)[0]
+        assert (np.abs(S - p_chk).max(axis=1) == 0).all(), k
+        G = e.G.cpu().numpy()[e.inv_perm]
+        np.testing.assert_allclose(G, gm + 2.5 * (pe_new.astype(np.float64) - (p_chk + LOAD)), rtol=1e-5, atol=1e-5)
+    print(f"config 3, on/off chargers, teacher-forced x{iters}: worst |P_est - oracle| {worst_pe:.2e} kW, Newton iterations "
+          f"{[h[0] for h in e.newton_hist]}")
+    assert worst_pe < 1e-4
 
 
 def test_config0_com2_30pct_adoption(gpu_lib, golden, feeder_R):
@@ -492,6 +571,45 @@ def test_config0_com2_30pct_adoption(gpu_lib, golden, feeder_R):
     assert (np.abs(S - p1) < 1e-6).all()             # same home problem as iteration 1
     np.testing.assert_allclose(d[1], np.linalg.norm(ref - g1, axis=1) / T, atol=2e-5)
     assert e.op_path_hist[-1] == "dual" and pe2.min() == 0.0   # residences clamped at zero
+
+
+def test_config0_15_iterations(gpu_lib, golden, feeder_R):
+    """BASELINE config 0 for the reference's 15 iterations (lpsolver.py:243, on/off chargers) against the oracle's own
+    run of it.  Per residence the runs part ways at the first exactly tied MIQP optimum that float state and double
+    state resolve differently, so beyond iteration 1 they are compared on the tie-robust
+    statistics the stored 90 % run is pinned with: mean diff[k] of the EV residences per iteration, the sorted-diff
+    distance, EV slots per tariff block of the final schedules and the total EV energy cost."""
+    from helpers import f32
+    from oracle import revs_oracle as ro
+    from revs_admm_amd.engine import AdmmEngine, pack_homes
+    z, fd = golden
+    res_ids = z["res_id"]
+    com2 = z["com_flat"][z["com_offsets"][1]:z["com_offsets"][2]]
+    np.random.seed(1234)
+    ev_homes = np.random.choice(com2, int(30 * 1e-2 * len(com2)), replace=False)
+    idx = {h: i for i, h in enumerate(res_ids)}
+    evi = np.array([idx[h] for h in ev_homes])
+    ev = np.zeros(len(res_ids), bool)
+    ev[evi] = True
+    oh = ro.Homes.uniform(f32(z["LOAD"]), ev, 4.8, 20.0, 0.2, 11, 23)
+    cost = f32(z["tariff_shift6"])
+    n, T = oh.LOAD.shape
+    e = AdmmEngine(cost, pack_homes(ev, 4.8, 20.0, 0.2, 11, 23), oh.LOAD, np.arange(n), feeder_R,
+                   kappa=5.0, vset=1.03, vlow=0.95, vhigh=1.05, mode="binary")
+    d = e.run(15)
+    P_sch, S, C = e.result()
+    d_or, P_or, S_or, C_or = ro.solve_ADMM(oh, feeder_R, np.arange(n), cost, 5.0, 15, 1.03, 0.95, 1.05, mode="binary",
+                                           util_method="dual")
+    rel = np.abs(d[:, evi].mean(1) / d_or[:, evi].mean(1) - 1)
+    w1 = max(np.abs(np.sort(d[k, evi]) - np.sort(d_or[k, evi])).mean() / d_or[k, evi].mean() for k in range(1, 15))
+    on, on_or = S[evi] > 1e-6, S_or[evi] > 1e-6
+    blocks = max(abs(int(on[:, cost == b].sum()) - int(on_or[:, cost == b].sum())) for b in np.unique(cost))
+    ev_cost = abs((S[evi] * cost).sum() / (S_or[evi] * cost).sum() - 1)
+    same = float((np.abs(S - S_or).max(1) == 0).mean())
+    print(f"config 0, 15 iterations: mean diff[k] GPU/oracle - 1 {np.round(rel, 5).tolist()}, sorted-diff distance {w1:.4f}, "
+          f"EV slots per tariff block off by {blocks}, EV cost off by {ev_cost:.2e}, identical final schedules {same:.3f}")
+    # (bounds: those of the stored run's pin, helpers.GOLDEN_BOUNDS -- the spread between two consistent tie rules)
+    assert rel[0] < 1e-5 and rel.max() < 0.13 and w1 < 0.145 and blocks <= 6 and ev_cost < 3.2e-3
 
 
 def test_revs_fixture_end_to_end(gpu_lib, golden, tmp_path):

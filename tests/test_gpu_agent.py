@@ -85,8 +85,10 @@ def test_binary_matches_oracle(gpu_lib, T, n, zero_state):
     obj_ref = ro.home_objective(w.cost, oh, p, pe_old, ps, gm, w.kappa)
     scale = np.maximum(1.0, np.abs(obj_ref))
     assert np.max(np.abs(obj_gpu - obj_ref) / scale) < 2e-5
+    # round 5: the ranking keys are doubles formed from the float inputs in the oracle's order of operations, so the
+    # on/off decision IS the float64 restatement's -- every residence, exact ties included (both sides: earlier slot)
     same = (np.abs(r["S"] - p).max(axis=1) == 0)
-    assert same.mean() > 0.995
+    assert same.all(), (int((~same).sum()), n)
     # slot counts and window are exact
     assert ((r["S"] > 0).sum(1) == (p > 0).sum(1)).all()
     assert (r["S"][~oh.window()] == 0).all()
@@ -287,8 +289,11 @@ def test_edge_parameters(gpu_lib, mode):
             obj_r = ro.home_objective(w.cost, oh, p, pe_old, ps, gm, w.kappa)
             assert np.max(np.abs(obj_g - obj_r)[ok] / np.maximum(1, np.abs(obj_r[ok]))) < 2e-5
             assert ((r["S"] > 0).sum(1) == (p > 0).sum(1))[ok].all()
+            assert (np.abs(r["S"] - p)[ok].max(axis=1) == 0).all()      # (double keys: the oracle's decision, every residence)
         else:
-            assert np.abs(r["S"] - p)[ok].max() < 2e-3
+            err = np.abs(r["S"] - p)[ok].max()
+            print(f"edge residences, {mode}: max |S - oracle| = {err:.2e} kW")
+            assert err < 1e-4
         assert (r["S"][~oh.window()] == 0).all()
         assert (r["S"][~ok] == 0).all()                      # flagged homes get no schedule
         np.testing.assert_allclose(r["C"][ok][:, 0], np.where(oh.ev, oh.initial, 0)[ok], atol=1e-6)

@@ -1,10 +1,14 @@
 """BASELINE config 4 (1M homes x T = 96 over 8 GPUs: 125 000 x 96 per GPU; convergence against
 the centralized LP), the golden feeder's k >= 2 pin on the GPU, and long-horizon parity with the
 oracle in the regime bench.py times."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def _engine(w, mode, **kw):
@@ -102,6 +106,124 @@ def test_config4_per_gpu_shape_invariants(gpu_lib):
     torch.cuda.synchronize()
     assert torch.equal(outs[0], full[0][sl]) and torch.equal(outs[1], full[1][sl])
     assert torch.equal(dd[0], fd[0][sl])
+
+
+def _dual_kkt_f64_chunked(e, w, pe0, ps0, gm0, chunk=125_000):
+    """test_gpu_admm._dual_kkt_f64 for a million residences: the float64 KKT certificate of the dual Newton path's
+    last answer (stationarity g = max(g0 - (R^T y / kappa)[node], 0) is the estimate handed on; the rows of R (A g)
+    respect their bounds; y is non-zero only on rows at a bound, with the right sign), with the residences walked in
+    blocks (they are sorted by node: a block's node sums are one reduceat).  Returns the rows at the upper bound."""
+    y = e.yd[0].cpu().numpy()
+    node = w.node_of[e.perm]
+    d = w.Rn.T @ y / e.kappa
+    got = e.P_est.cpu().numpy()                           # after the swap: the operator's answer
+    p = np.zeros((e.M, e.T))
+    worst, gmax = 0.0, 0.0
+    for lo in range(0, e.n, chunk):
+        sl = slice(lo, min(lo + chunk, e.n))
+        g0 = 0.5 * (pe0[sl].astype(np.float64) + ps0[sl]) - gm0[sl].astype(np.float64) / e.kappa
+        g = np.maximum(g0 - d[node[sl]], 0.0)
+        worst = max(worst, float(np.abs(got[sl] - g).max()))
+        gmax = max(gmax, float(g.max()))
+        starts = np.flatnonzero(np.diff(node[sl], prepend=-1))
+        p[node[sl][starts]] += np.add.reduceat(g, starts, axis=0)
+    assert worst < 1e-6 * max(1.0, gmax), worst
+    v = w.Rn @ p
+    scale = max(abs(e.vlo), abs(e.vhi))
+    assert v.max() <= e.vhi + 1e-7 * scale and v.min() >= e.vlo - 1e-7 * scale
+    act_hi, act_lo = v >= e.vhi - 1e-6 * scale, v <= e.vlo + 1e-6 * scale
+    assert (y[~(act_hi | act_lo)] == 0).all() and (y[act_hi] >= 0).all() and (y[act_lo] <= 0).all()
+    return int(act_hi.sum())
+
+
+@pytest.mark.parametrize("n,T", [(64_000, 96), (1_000_000, 96), (1_000_000, 24)])
+def test_config4_full_size(gpu_lib, n, T):
+    """BASELINE config 4 AT ITS STATED SIZE on one MI355X: 1 000 000 residences x T = 96 on the 2048-node feeder (and
+    1M x 24 beside it) -- ~6.5 GB of state, the first size at which the residences' profiles leave the Infinity Cache.
+      * the transient: three iterations with voltage rows binding, every operator answer certified in float64 on the
+        host (KKT of lpsolver.py:163-238's QP);
+      * on into the streaming steady state (sweeps of 16 / 32 ADMM iterations per launch, verdicts by blocks), 40
+        iterations of it, status clean; SOC rows, windows, energy bounds and the epilogue identities of
+        lpsolver.py:275-284 for EVERY residence; voltage feasibility of the operator's estimate;
+      * shard invariance -- what the 8-GPU layout of config 4 rests on: the residences rank 3 of 8 would own (a
+        node-aligned ~125 000), taken out at the start of those 40 iterations and run ALONE in an engine of their own
+        (same feeder, the other ranks' sums absent), end in the same P_est / P_sch / G / carried multipliers / diff,
+        bit for bit.
+    (64 000 x 96: the same walk at a size that takes seconds.)"""
+    import torch
+    sys.path.insert(0, HERE)
+    from sharded_worker import node_aligned_split
+    from revs_admm_amd.synthetic import make_workload
+    w = make_workload(n, T, n_nodes=2048, seed=0, binary_feasible=False, stress=1.0)
+    e = _engine(w, "pdhg")
+    n_active = []
+    for _ in range(3):
+        pe0, ps0, gm0 = e.P_est.cpu().numpy(), e.P_sch.cpu().numpy(), e.G.cpu().numpy()
+        e.step(write_sc=False)
+        assert e.op_path_hist[-1] == "dual"
+        n_active.append(_dual_kkt_f64_chunked(e, w, pe0, ps0, gm0))
+    del pe0, ps0, gm0
+    assert max(n_active) > 0                              # the voltage rows do bind on the way
+    while not (e._stream_ok() and e._fused_ready) and e.iteration < 120:
+        e.run_steps(1)
+    assert e._stream_ok() and e._fused_ready, (e.iteration, e.op_iters_hist[-10:])
+    k_stream = e.iteration
+    # the residences rank 3 of 8 would own, as they are now
+    cuts = node_aligned_split(w.node_of, 8)
+    lo, hi = int(cuts[3]), int(cuts[4])
+    assert 0.8 * n / 8 < hi - lo < 1.2 * n / 8 and lo % 32 == 0 and hi % 32 == 0
+    assert np.array_equal(w.node_of[e.perm[lo:hi]], w.node_of[lo:hi])        # (sorted by node: the shard is a block of e's order too)
+    shard_state = [t[lo:hi].clone() for t in (e.P_est, e.P_sch, e.G, e.pdhg_dual)]
+    s0 = list(e.spec_hist)
+    e.run_steps(40)
+    torch.cuda.synchronize()
+    assert [e.spec_hist[0] - s0[0], e.spec_hist[1] - s0[1]] == [40, 0], (s0, e.spec_hist)
+    assert e._inner == (16 if T == 96 else 32) and e._block == 32
+    e.check_status()
+    full_after = [t[lo:hi].clone() for t in (e.P_est, e.P_sch, e.G, e.pdhg_dual, e.diff)]
+    # ---- the shard alone ----
+    e2 = _engine(type(w)(w.cost, w.load[lo:hi], w.homes[lo:hi], w.node_of[lo:hi], w.Rn, w.parent, w.edge_r, w.vset,
+                         w.vlow, w.vhigh, w.kappa), "pdhg", node_counts=np.bincount(w.node_of, minlength=w.M))
+    assert np.array_equal(e2.perm + lo, e.perm[lo:hi])
+    inv2 = torch.from_numpy(e2.inv_perm).to(e2.dev)
+    e2.set_state(*(t.index_select(0, inv2).cpu().numpy() for t in shard_state[:3]))
+    e2.pdhg_dual.copy_(shard_state[3])
+    e2.run_steps(40)
+    torch.cuda.synchronize()
+    assert e2.spec_hist[1] == 0 and e2.iteration == 40
+    for name, a, b in zip(("P_est", "P_sch", "G", "pdhg_dual", "diff"), full_after,
+                          (e2.P_est, e2.P_sch, e2.G, e2.pdhg_dual, e2.diff)):
+        assert torch.equal(a, b), (name, float((a - b).abs().max()))
+    del e2, shard_state, full_after
+    torch.cuda.empty_cache()
+    # ---- every residence's rows and the epilogue identities, on the schedules one more iteration writes ----
+    G_before = e.G.clone()
+    e.step(write_sc=True)
+    st = e.status.cpu().numpy()
+    assert ((st & 0xFF) == 0).all()
+    P_sch, S, C = e.result()
+    h = w.homes
+    ev = h["ev"] == 1
+    t = np.arange(T)[None, :]
+    win = ev[:, None] & (t >= h["start"][:, None]) & (t < h["end"][:, None])
+    assert (S[~win] == 0).all() and (S >= 0).all() and (S <= h["rating"][:, None] * (1 + 1e-6)).all()
+    del win
+    np.testing.assert_allclose(P_sch, w.load.astype(np.float32) + S, rtol=1e-6, atol=1e-6)
+    soc = np.where(ev[:, None], h["initial"][:, None] + np.cumsum(S, 1, dtype=np.float64) / h["capacity"][:, None], 0)
+    np.testing.assert_allclose(C[:, 1:], soc, atol=5e-5)
+    del soc
+    assert (C[ev, -1] >= 0.9 - 3e-4).all() and (C <= 1 + 3e-4).all() and (np.diff(C, axis=1) >= -1e-6).all()
+    pe = e.P_est.cpu().numpy()[e.inv_perm]
+    chk = pe - P_sch
+    nrm = np.linalg.norm(chk, axis=1) / T
+    np.testing.assert_allclose(e.diff.cpu().numpy()[e.inv_perm], nrm, rtol=1e-4, atol=1e-7)
+    np.testing.assert_allclose(e.G.cpu().numpy()[e.inv_perm], G_before.cpu().numpy()[e.inv_perm] + 2.5 * chk,
+                               rtol=1e-4, atol=1e-4)
+    v = e.voltage(e.P_est).cpu().numpy()
+    assert pe.min() >= 0 and v.max() <= e.vhi * (1 + 1e-4)
+    assert e.residuals(1e-4)[2] == pytest.approx(nrm.max(), rel=1e-4)
+    print(f"config 4 at full size, {n} x {T}: rows at the upper bound in the first three iterations {n_active}, streaming from "
+          f"iteration {k_stream}, shard [{lo}, {hi}) alone == inside the million, max diff {nrm.max():.3e}")
 
 
 @pytest.mark.parametrize("T,iters,bound", [(96, 200, 0.025), (24, 400, 0.016)])
@@ -285,6 +407,9 @@ def test_binary_teacher_forced_long(gpu_lib):
         P_sch, S, C = e.result()
         same = np.abs(S - tr.S[k]).max(axis=1) == 0
         worst_same = min(worst_same, same.mean())
+        # (tr.S[k] is the oracle's answer to its float64 state; to the float state the engine was handed, the oracle's
+        # answer is the engine's for EVERY residence: the ranking keys are doubles in the oracle's order of operations)
+        assert (np.abs(S - ro.home_solve_binary(w.cost, oh, pe, ps, gm, w.kappa)[0]).max(axis=1) == 0).all(), k
         obj_g = ro.home_objective(w.cost, oh, S.astype(float), pe, ps, gm, w.kappa)
         obj_r = ro.home_objective(w.cost, oh, tr.S[k], pe, ps, gm, w.kappa)
         assert np.max(np.abs(obj_g - obj_r) / np.maximum(1, np.abs(obj_r))) < 1e-4, k

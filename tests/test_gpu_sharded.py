@@ -154,6 +154,67 @@ def test_two_ranks_with_real_partial_sums_equal_one_rank(two_rank_runs, case):
             assert any(b.startswith(("P_sch", "G_", "stream_calls", "spec_hist", "chain_hist", "op_iters")) for b in bad), bad[:8]
 
 
+# ---- world size 8: eight logical ranks (threads) in one process on the one GPU, the library's hook communicator with
+# nranks = 8 (revs_admm_amd.comm.LocalRanks) ----
+CASES8 = [
+    dict(name="deep8", mode="pdhg", n=40000, nodes=512, seed=0, stress=1.0, T=24, chunks=(40, 400, 400), align=8,
+         configs=[dict(tag="b32ov", block=32, overlap=True, hook="local"),
+                  dict(tag="b4", block=4, overlap=False, hook="local")]),
+    dict(name="head8", mode="pdhg", n=16000, nodes=400, seed=3, stress=1.02, T=24, chunks=_RAGGED, f32=True, align=8,
+         burst=_SMALL_BURST,
+         configs=[dict(tag="b32ov", block=32, overlap=True, hook="local"),
+                  dict(tag="b1", block=1, overlap=False, hook="local")]),
+    dict(name="t96x8", mode="pdhg", n=8000, nodes=400, seed=3, stress=1.02, T=96, chunks=_RAGGED, f32=True, align=4,
+         burst=_SMALL_BURST,
+         configs=[dict(tag="b32ov", block=32, overlap=True, hook="local")]),
+]
+
+
+@pytest.fixture(scope="module")
+def eight_rank_runs(gpu_lib, tmp_path_factory):
+    out = tmp_path_factory.mktemp("sharded8")
+    spec = dict(local=True, world=8, outdir=str(out), cases=CASES8)
+    path = out / "spec.json"
+    path.write_text(json.dumps(spec))
+    env = dict(os.environ, OMP_NUM_THREADS="2", OPENBLAS_NUM_THREADS="2", MKL_NUM_THREADS="2")
+    with open(out / "worker.log", "w") as log:
+        p = subprocess.Popen([sys.executable, os.path.join(HERE, "sharded_worker.py"), str(path)], stdout=log,
+                             stderr=subprocess.STDOUT, env=env)
+        try:
+            rc = p.wait(timeout=1200)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            rc = -9
+    assert rc == 0, (out / "worker.log").read_text()[-4000:]
+    return out
+
+
+@pytest.mark.parametrize("case", CASES8, ids=[c["name"] for c in CASES8])
+def test_eight_logical_ranks_equal_one_rank(eight_rank_runs, case):
+    """World size 8 on one GPU: every rank's residences after every chunk equal the one-process run bit for bit, all
+    ranks issued the same collectives, and a block collective carries 64 x 8 partial maxima of diff per ring slice."""
+    w, ref = _reference(case)
+    mt = w.M * w.T
+    failed = [(int(c), int(k)) for c, k in ref["stream_calls"] if k < c]
+    assert failed, ref["stream_calls"]                     # failed verdicts were crossed
+    for cfg in case["configs"]:
+        shards = [np.load(eight_rank_runs / f"{case['name']}_{cfg['tag']}_r{r}.npz") for r in range(8)]
+        edges = [int(s["lo"]) for s in shards] + [int(shards[-1]["hi"])]
+        assert edges[0] == 0 and edges[-1] == case["n"] and all(a < b for a, b in zip(edges[:-1], edges[1:]))
+        assert [int(s["hi"]) for s in shards[:-1]] == edges[1:-1]
+        bad = _mismatch(case, ref, shards)
+        assert not bad, (cfg, bad[:8])
+        for s in shards[1:]:
+            assert np.array_equal(s["hook_calls"], shards[0]["hook_calls"])
+        sizes = shards[0]["hook_calls"]
+        slice_ = mt + 8 * 64              # a ring slice: the node sums, then REVS_DMAX_SLOTS partial maxima of diff per rank
+        if cfg["block"] > 1:
+            blocks = sizes[(sizes >= slice_) & (sizes % slice_ == 0)]
+            assert len(blocks) > 3 and blocks.max() <= cfg["block"] * slice_
+        else:
+            assert (sizes[sizes >= mt] == mt).sum() > 60
+
+
 @pytest.mark.parametrize("transport", ["rccl", "share-gpu"])
 def test_bench_two_ranks_through_its_own_launcher(gpu_lib, transport):
     """`python bench.py --gpus 2` end to end: the self-launcher (Popen children, never exec), sharding, the native

@@ -1,68 +1,129 @@
-// VALU issue rate on gfx950, measured: how many wave64 instructions per SIMD-cycle for v_fma_f32,
-// v_pk_fma_f32, a DPP add and v_med3_f32, at 1..8 wavefronts per SIMD.
-//   hipcc -O3 --offload-arch=gfx950 tools/probes/valu_rate.hip -o /tmp/valu_rate && /tmp/valu_rate
+// VALU issue rate on gfx950, measured in SHADER CYCLES: how many cycles one SIMD needs per wave64 VALU
+// instruction -- v_fma_f32, v_pk_fma_f32, v_add_f32, a DPP add, v_med3_f32, v_fma_f64 -- with 1, 2, 4 and 8
+// wavefronts resident per SIMD, every wavefront running 8 or 16 INDEPENDENT dependency chains (so that a
+// chain's latency never gates issue), on the whole chip at once (as the sweep runs) and on one CU alone.
+//
+// Why cycles: the wall-clock rate (ns per instruction) folds the clock the chip sustains under the load
+// into the figure.  Every wavefront brackets its loop with s_memtime (the shader-clock counter) and
+// s_memrealtime (the constant 100 MHz counter): cycles per instruction per SIMD = the wavefront's cycles x
+// (wavefronts sharing its SIMD) / instructions issued on that SIMD, and the ratio of the two counters is the
+// clock the loop ran at.  Where each wavefront sat (XCC, SE, CU, SIMD: HW_REG_HW_ID / HW_REG_XCC_ID) is
+// recorded, and the host prints how many wavefronts really shared a SIMD -- the "waves per SIMD" column is
+// measured, not assumed from the grid.
+//   hipcc -O3 --offload-arch=gfx950 tools/probes/valu_rate.hip -o tools/probes/valu_rate.bin && tools/probes/valu_rate.bin
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdio>
+#include <map>
 #include <vector>
 
 typedef float float2v __attribute__((ext_vector_type(2)));
 
-template <int KIND>
-__global__ __launch_bounds__(256) void rate_kernel(float *out, int iters, float a, float b) {
-    float x[8];
-    float2v y[8];
+struct WaveRec { unsigned long long c0, c1, r0, r1; unsigned hw, xcc; };
+
+template <int KIND, int CH>
+__global__ __launch_bounds__(1024) void rate_kernel(float *out, WaveRec *rec, int iters, float a, float b) {
+    float x[CH];
+    float2v y[CH];
+    double z[CH];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { x[i] = threadIdx.x * 0.001f + i; y[i] = float2v{x[i], x[i] + 1.f}; }
+    for (int i = 0; i < CH; ++i) { x[i] = threadIdx.x * 0.001f + i; y[i] = float2v{x[i], x[i] + 1.f}; z[i] = x[i]; }
     const float2v a2{a, a}, b2{b, b};
-    long long t0 = clock64();
+    const double ad = a, bd = b;
+    __syncthreads();
+    unsigned long long c0, c1, r0, r1;
+    asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(c0), "=s"(r0)::"memory");
     for (int k = 0; k < iters; ++k) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < CH; ++i) {
             if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(a), "v"(b));
             if (KIND == 1) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(y[i]) : "v"(a2), "v"(b2));
             if (KIND == 2) asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(x[i]));
             if (KIND == 3) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(x[i]) : "v"(a), "v"(b));
             if (KIND == 4) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[i]) : "v"(a));
+            if (KIND == 5) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(z[i]) : "v"(ad), "v"(bd));
         }
     }
-    long long t1 = clock64();
+    asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) s += x[i] + y[i].x + y[i].y;
+    for (int i = 0; i < CH; ++i) s += x[i] + y[i].x + y[i].y + (float)z[i];
     if (s == 123.456f) out[0] = s;
-    if (threadIdx.x == 0 && blockIdx.x == 0) out[1] = (float)(t1 - t0);
+    if ((threadIdx.x & 63) == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n s_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
+        rec[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = WaveRec{c0, c1, r0, r1, hw, xcc};
+    }
+}
+
+template <int KIND, int CH>
+static void run(const char *name, int blocks, const char *scope, float *d, WaveRec *drec, int iters, int threads = 256) {
+    std::vector<WaveRec> h(blocks * (threads / 64));
+    hipLaunchKernelGGL((rate_kernel<KIND, CH>), dim3(blocks), dim3(threads), 0, 0, d, drec, iters, 1.0001f, 0.5f);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((rate_kernel<KIND, CH>), dim3(blocks), dim3(threads), 0, 0, d, drec, iters, 1.0001f, 0.5f);
+    hipEventRecord(e1);
+    hipDeviceSynchronize();
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipMemcpy(h.data(), drec, sizeof(WaveRec) * h.size(), hipMemcpyDeviceToHost);
+    // wavefronts per SIMD as placed: key = (xcc, se, sh, cu, simd) from HW_ID [simd 5:4, cu 11:8, sh 12, se 15:13]
+    std::map<unsigned, int> per;
+    for (auto &w : h) per[((w.xcc & 0xf) << 16) | (w.hw & 0xfff0) >> 4 << 0] += 1;
+    std::vector<int> occ;
+    for (auto &p : per) occ.push_back(p.second);
+    std::sort(occ.begin(), occ.end());
+    // overlap-aware: a wavefront's loop shares its SIMD with occ-1 others for (nearly) its whole length when the
+    // grid is one resident round; cycles per instruction per SIMD = median over wavefronts of cycles x ... / (occ x n)
+    std::vector<double> cpi, mhz;
+    const double n = (double)iters * CH;
+    for (auto &w : h) {
+        const int o = per[((w.xcc & 0xf) << 16) | (w.hw & 0xfff0) >> 4];
+        cpi.push_back((double)(w.c1 - w.c0) / (n * o));
+        mhz.push_back((double)(w.c1 - w.c0) / (double)(w.r1 - w.r0) * 100.0);
+    }
+    std::sort(cpi.begin(), cpi.end());
+    std::sort(mhz.begin(), mhz.end());
+    const double instr_per_simd = n * occ[occ.size() / 2];
+    printf("%-14s %-9s chains %2d  SIMDs used %4zu  waves/SIMD min %d med %d max %d | cycles per instr per SIMD: med %.2f (p10 %.2f p90 %.2f) "
+           "| shader clock %.0f MHz | launch %.1f us = %.2f ns per instr per SIMD\n",
+           name, scope, CH, occ.size(), occ.front(), occ[occ.size() / 2], occ.back(), cpi[cpi.size() / 2], cpi[cpi.size() / 10],
+           cpi[cpi.size() * 9 / 10], mhz[mhz.size() / 2], ms * 1e3, ms * 1e6 / instr_per_simd);
 }
 
 int main() {
     float *d;
+    WaveRec *drec;
     hipMalloc(&d, 64);
-    const char *names[] = {"v_fma_f32", "v_pk_fma_f32", "v_add_f32_dpp", "v_med3_f32", "v_add_f32"};
+    hipMalloc(&drec, sizeof(WaveRec) * 4 * 256 * 8);
+    hipDeviceProp_t pr;
+    hipGetDeviceProperties(&pr, 0);
+    printf("device %s, %d CUs, clockRate %d kHz\n", pr.gcnArchName, pr.multiProcessorCount, pr.clockRate);
     const int iters = 4000;
-    for (int kind = 0; kind < 5; ++kind) {
-        for (int wps : {1, 2, 4, 8}) {
-            const int blocks = 256 * wps;      // 256 CUs x wps workgroups of 4 wavefronts = wps wavefronts per SIMD
-            hipEvent_t e0, e1;
-            hipEventCreate(&e0); hipEventCreate(&e1);
-            auto launch = [&] {
-                if (kind == 0) hipLaunchKernelGGL(rate_kernel<0>, dim3(blocks), dim3(256), 0, 0, d, iters, 1.0001f, 0.5f);
-                if (kind == 1) hipLaunchKernelGGL(rate_kernel<1>, dim3(blocks), dim3(256), 0, 0, d, iters, 1.0001f, 0.5f);
-                if (kind == 2) hipLaunchKernelGGL(rate_kernel<2>, dim3(blocks), dim3(256), 0, 0, d, iters, 1.0001f, 0.5f);
-                if (kind == 3) hipLaunchKernelGGL(rate_kernel<3>, dim3(blocks), dim3(256), 0, 0, d, iters, 1.0001f, 0.5f);
-                if (kind == 4) hipLaunchKernelGGL(rate_kernel<4>, dim3(blocks), dim3(256), 0, 0, d, iters, 1.0001f, 0.5f);
-            };
-            launch();
-            hipDeviceSynchronize();
-            hipEventRecord(e0);
-            launch();
-            hipEventRecord(e1);
-            hipDeviceSynchronize();
-            float ms = 0.f, h[2];
-            hipEventElapsedTime(&ms, e0, e1);
-            hipMemcpy(h, d, 8, hipMemcpyDeviceToHost);
-            const double instr_per_simd = (double)wps * iters * 8;
-            printf("%-14s %d waves/SIMD: %8.1f us, %.2f ns per instruction per SIMD, %.2f clock64 ticks per instr of one wave\n",
-                   names[kind], wps, ms * 1e3, ms * 1e6 / instr_per_simd, h[1] / (iters * 8.0));
-        }
+    const char *names[] = {"v_fma_f32", "v_pk_fma_f32", "v_add_f32_dpp", "v_med3_f32", "v_add_f32", "v_fma_f64"};
+    for (int wps : {1, 2, 4, 8}) {
+        const int blocks = pr.multiProcessorCount * wps;   // workgroups of 4 wavefronts: wps wavefronts per SIMD when spread evenly
+        char scope[32];
+        snprintf(scope, sizeof scope, "chip x%d", wps);
+        run<0, 8>(names[0], blocks, scope, d, drec, iters);
+        run<0, 16>(names[0], blocks, scope, d, drec, iters);
+        run<1, 8>(names[1], blocks, scope, d, drec, iters);
+        run<2, 8>(names[2], blocks, scope, d, drec, iters);
+        run<3, 8>(names[3], blocks, scope, d, drec, iters);
+        run<4, 8>(names[4], blocks, scope, d, drec, iters);
+        run<5, 8>(names[5], blocks, scope, d, drec, iters);
+    }
+    // ONE workgroup alone on the chip (no power / clock effect of 1024 busy SIMDs): 256 x wps threads = wps wavefronts
+    // on each SIMD of one CU
+    for (int wps : {1, 2, 4}) {
+        char scope[32];
+        snprintf(scope, sizeof scope, "one CU x%d", wps);
+        run<0, 8>(names[0], 1, scope, d, drec, iters, 256 * wps);
+        run<1, 8>(names[1], 1, scope, d, drec, iters, 256 * wps);
+        run<4, 8>(names[4], 1, scope, d, drec, iters, 256 * wps);
     }
     return 0;
 }
