@@ -567,8 +567,17 @@ void agent_step_kernel(const AgentArgs a) {
                     const bool up = mu > 0.f || (mu == 0.f && S > hi);
                     const bool dn = mu < 0.f || (mu == 0.f && S < lo_last);
                     const float tgt = up ? hi : (dn ? lo_last : S);
-                    fine = fine || fabsf(S - tgt) <= 5e-7f * fmaxf(1.f, fabsf(tgt));
-                    if (r == 6 || __all(fine)) break;
+                    const float resid = fabsf(S - tgt), tscale = fmaxf(1.f, fabsf(tgt));
+                    fine = fine || resid <= 5e-7f * tscale;
+                    if (r == 6) {
+                        // (round 5) S is a float sum over the window: at 48 free slots its own rounding reaches ~1e-6, and a
+                        // residence whose row sits 10 ulps off its bound can neither pass the test above nor move (the
+                        // step is below mu's resolution).  Its iterate here is Newton's, two orders closer than the
+                        // PDHG iterate it would otherwise fall back to: accepted.
+                        fine = fine || resid <= 4e-6f * tscale;
+                        break;
+                    }
+                    if (__all(fine)) break;
                     // The step: S is piecewise linear in mu with slope -delta^2 x (slots strictly inside their box),
                     // counted in the direction the step has to go (a slot sitting exactly on a bound moves one way only).
                     const bool rise = S > tgt;               // mu has to rise (S falls with mu)

@@ -79,6 +79,7 @@ struct revs_plan {
     int32_t overlap = 0;                   // all-reduce + verdicts of a block on `side`, beside the next block's sweeps
     int32_t inner = 1;                     // ADMM iterations per sweep launch (revs_plan_set_stream_inner)
     int32_t fold_redo = 2;                 // Newton steps beyond the first inside the folded chain (revs_plan_set_fold_redo)
+    int32_t kadd_cold = 0, kadd_cold_at = 0;   // revs_plan_set_kadd_cold: rows admitted per Newton iteration while many are violated
     double *ring = nullptr;                // device: node sums (+ diff tails) of two blocks, double[2][block][stride]
     size_t ring_cap = 0;                   // ... doubles allocated
     bool ring_dirty = true;                // the ring is not known to be all zero (fresh, or a call failed)
@@ -545,15 +546,15 @@ extern "C" int revs_plan_newton_solve(revs_plan_t *plan, revs_newton_state_t *st
     double *ycur = st->y, *ytrial = st->y_trial;
     // One evaluation of multipliers yy (p, N, D, the voltage rows, candidate lists and stats into set k; P_est_new =
     // the answer for yy), waited for: the selection tags the pinned stats block behind a system-scope fence.
-    auto evaluate = [&](const double *yy, int uy, int k, int sup, double *out /* [T][8] */) -> int {
+    auto evaluate = [&](const double *yy, int uy, int k, int sup, double *out /* [T][8] */, int kadd) -> int {
         const double tag = (plan->seq += 1.0) + 0.25;      // (Python's evaluations: n + 0.5; the other native loops: whole numbers)
         auto phase = [&](int ph) -> int {
             if (tf)
                 return revs_op_dual_evaluate_tree(ph, d.m, T, d.node_ptr, st->p_est, st->p_sch, st->gamma, d.R, &trh, yy, uy,
-                                                  d.kappa, d.vlo, d.vhi, d.kadd, d.ksplit, d.d_slabs, d.pnq, st->p_est_new, d.vfull,
+                                                  d.kappa, d.vlo, d.vhi, kadd, d.ksplit, d.d_slabs, d.pnq, st->p_est_new, d.vfull,
                                                   d.viol, d.partial, ci[k], cc[k], cv[k], sd[k], tag, stream);
             return revs_op_dual_evaluate(ph, d.m, T, d.node_ptr, st->p_est, st->p_sch, st->gamma, d.R, d.Rt, yy, uy, d.kappa,
-                                         d.vlo, d.vhi, d.kadd, d.ksplit, d.d_slabs, d.v_slabs, d.pnq, st->p_est_new, d.vfull, d.viol,
+                                         d.vlo, d.vhi, kadd, d.ksplit, d.d_slabs, d.v_slabs, d.pnq, st->p_est_new, d.vfull, d.viol,
                                          d.partial, ci[k], cc[k], cv[k], sd[k], tag, plan->counters, stream);
         };
         int rc;
@@ -596,12 +597,17 @@ extern "C" int revs_plan_newton_solve(revs_plan_t *plan, revs_newton_state_t *st
     std::vector<char> pending((size_t)T);
     int cur = 0, rc = REVS_OK;
     if (st->have_first) for (int i = 0; i < 8 * T; ++i) stt[i] = d.stats_host[i];
-    else if ((rc = evaluate(ycur, st->use_y, 0, st->use_y ? st->sup : -1, stt.data())) != REVS_OK) return rc;
+    else if ((rc = evaluate(ycur, st->use_y, 0, st->use_y ? st->sup : -1, stt.data(), d.kadd)) != REVS_OK) return rc;
+    // Rows admitted to a slot's model per Newton iteration: d.kadd (2: the warm solves' models stay small) -- but
+    // plan->kadd_cold while some slot still shows more than plan->kadd_cold_at violated rows without a multiplier (a cold
+    // solve: admitting two at a time makes it as many Newton iterations as half the rows that end up binding).
+    // kadd_stt: what the evaluation behind `stt` admitted with (its candidate lists are that long).
+    int kadd_stt = d.kadd;
     int evals = 1, newton = 0, pivots = 0, stall = 0, n_small = 0, n_general = 0;
     bool ok_all = false, last_small = false, few = false, from_pre = st->have_pre != 0;
     double best = INFINITY;
     for (;;) {
-        double rmax = 0.0, ns_max = 0.0, nc_max = 0.0;
+        double rmax = 0.0, ns_max = 0.0, nc_max = 0.0, nv_max = 0.0;
         bool over = false, full = false;
         for (int t = 0; t < T; ++t) {
             const double *a = &stt[8 * t];
@@ -611,8 +617,10 @@ extern "C" int revs_plan_newton_solve(revs_plan_t *plan, revs_newton_state_t *st
             // a slot whose model is full of multipliers while rows are still violated cannot take them in
             if (a[2] >= A && a[3] > 0 && r > d.eps) full = true;
             ns_max = std::max(ns_max, a[2]);
-            nc_max = std::max(nc_max, a[2] + std::min(a[3], std::min((double)d.kadd, A - a[2])));
+            nc_max = std::max(nc_max, a[2] + std::min(a[3], std::min((double)kadd_stt, A - a[2])));
+            nv_max = std::max(nv_max, a[3]);
         }
+        const int kadd_next = (plan->kadd_cold > d.kadd && nv_max > plan->kadd_cold_at) ? plan->kadd_cold : d.kadd;
         if (over) break;
         if (rmax <= d.eps) { ok_all = true; break; }
         if (newton >= o.newton_max || full) break;
@@ -621,7 +629,7 @@ extern "C" int revs_plan_newton_solve(revs_plan_t *plan, revs_newton_state_t *st
         else if (++stall >= 10) break;
         ++newton;
         last_small = nc_max <= 8;
-        few = ns_max + d.kadd <= 48;
+        few = ns_max + kadd_stt <= 48;
         // (the chain guessed how its trial's home pass gets d = R^T y / kappa -- row-wise or dense; another choice here
         // would differ in the last bits: then the trial is made again)
         const bool use_pre = st->have_pre && newton == 1 && last_small && few == (st->chain_few_in != 0);
@@ -646,7 +654,9 @@ extern "C" int revs_plan_newton_solve(revs_plan_t *plan, revs_newton_state_t *st
             alpha[t] = pending[t] ? 1.0 : 0.0;
         }
         const int nxt = 1 - cur;
+        int kadd_stn = kadd_next;
         for (int ls = 0; ls < o.ls_max; ++ls) {
+            kadd_stn = (use_pre && ls == 0) ? d.kadd : kadd_next;      // (the chain's trial admitted with the plan's own)
             if (use_pre && ls == 0) {
                 for (int i = 0; i < 8 * T; ++i) stn[i] = d.stats1_host[i];      // that trial and its evaluation: already there
             } else {
@@ -654,7 +664,7 @@ extern "C" int revs_plan_newton_solve(revs_plan_t *plan, revs_newton_state_t *st
                 for (int t = 0; t < T; ++t) o.alpha_host[t] = alpha[t];        // read by the step kernel through its mapping
                 // (the trial starts from the current multipliers: copied by the step's own launch)
                 rc = revs::dual_step_copy(T, ci[cur], cc[cur], cv[cur], d.yhat, o.alpha_dev, ycur, d.m, ytrial, sd[nxt] + 4, stream);
-                if (rc == REVS_OK) rc = evaluate(ytrial, 1, nxt, few ? cur : -1, stn.data());
+                if (rc == REVS_OK) rc = evaluate(ytrial, 1, nxt, few ? cur : -1, stn.data(), kadd_next);
                 if (rc != REVS_OK) return rc;
             }
             ++evals;
@@ -673,6 +683,7 @@ extern "C" int revs_plan_newton_solve(revs_plan_t *plan, revs_newton_state_t *st
         std::swap(ycur, ytrial);
         cur = nxt;
         stt.swap(stn);
+        kadd_stt = kadd_stn;
     }
     st->y = ycur;
     st->y_trial = ytrial;
@@ -1312,6 +1323,13 @@ extern "C" int revs_plan_set_stream_block(revs_plan_t *plan, int32_t block, int3
     }
     plan->block = block;
     plan->overlap = overlap != 0;
+    return REVS_OK;
+}
+
+extern "C" int revs_plan_set_kadd_cold(revs_plan_t *plan, int32_t kadd_cold, int32_t cold_at) {
+    REVS_REQUIRE(plan && kadd_cold >= 0 && kadd_cold <= 64 && cold_at >= 0, "revs_plan_set_kadd_cold: kadd_cold=%d (0..64), cold_at=%d", kadd_cold, cold_at);
+    plan->kadd_cold = kadd_cold;
+    plan->kadd_cold_at = cold_at;
     return REVS_OK;
 }
 

@@ -100,6 +100,12 @@ class OperatorOptions:
     # iterations 11.4 -> 10.9 ms, the transient 3.5 -> 3.3 ms.  (1 starves the cold solves: the 121144 feeder's hand
     # themselves to the ADMM forms, 300 ms; 4 and more lengthen the chained iteration's slowest slot.)
     newton_kadd: int = 2
+    # ... but newton_kadd_cold of them in an evaluation that follows one in which some slot showed more than
+    # newton_kadd_cold_at violated rows without a multiplier (round 5): a cold solve -- the first ADMM iterations of the
+    # 121144 feeder end with 50-69 binding rows in a slot -- took as many Newton iterations as half of those rows
+    # (19 and 14 in iterations 2 and 3, of 79 in all 15); the warm solves keep their small models.  0: off.
+    newton_kadd_cold: int = 0
+    newton_kadd_cold_at: int = 6
     chain: bool = True           # binding steady state: one Newton iteration enqueued unread
     # ... and folded (one GPU, feeder as a tree): the sweep forms the operator's answer for the trial
     # itself and folds both evaluations' node sums into its own pass -- one pass over the residences
@@ -410,6 +416,8 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
                 raise _lib.RevsError("revs_plan_create failed: "
                                      + self.lib.revs_last_error().decode())
             check(self.lib.revs_plan_set_fold_redo(self._plan, int(self.op.fold_redo)), "revs_plan_set_fold_redo")
+            check(self.lib.revs_plan_set_kadd_cold(self._plan, int(self.op.newton_kadd_cold), int(self.op.newton_kadd_cold_at)),
+                  "revs_plan_set_kadd_cold")
             no = _lib.NewtonOpts(ptr(self.k_slabs), self.nks, self.alpha_h.data_ptr(), self.alpha_dev,
                                  self.info_h.data_ptr(), int(self.op.newton_max), int(self.op.newton_ls))
             check(self.lib.revs_plan_set_newton(self._plan, C.byref(no)), "revs_plan_set_newton")

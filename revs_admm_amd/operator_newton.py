@@ -14,8 +14,9 @@ from ._lib import check, ptr
 
 
 class DualNewtonMixin:
-    def _dual_phase(self, phase: int, y, use_y: bool, k: int):
+    def _dual_phase(self, phase: int, y, use_y: bool, k: int, kadd=None):
         lib, M, T = self.lib, self.M, self.T
+        kadd = self.op.newton_kadd if kadd is None else int(kadd)
         # an evaluation that ends with its own selection tags the stats block (pinned host
         # memory, written by the selection's workgroups behind a system-scope fence) with a
         # fresh number: _dual_wait polls for it -- no event record on the stream, no
@@ -30,7 +31,7 @@ class DualNewtonMixin:
             check(lib.revs_op_dual_evaluate_tree(
                 phase, M, T, ptr(self.node_ptr), ptr(self.P_est), ptr(self.P_sch), ptr(self.G),
                 ptr(self.R64), C.byref(self._tree), ptr(y), int(use_y), self.kappa, self.vlo, self.vhi,
-                self.op.newton_kadd, self.ksplit1, ptr(self.d_sl), ptr(self.pnq), ptr(self.P_est_new),
+                kadd, self.ksplit1, ptr(self.d_sl), ptr(self.pnq), ptr(self.P_est_new),
                 ptr(self.vfull), ptr(self.violw), ptr(self.d_part), ptr(self.c_idx[k]),
                 ptr(self.c_cnt[k]), ptr(self.c_val[k]), self.stats_dev[k], tag, self.stream),
                 "revs_op_dual_evaluate_tree")
@@ -38,7 +39,7 @@ class DualNewtonMixin:
         check(lib.revs_op_dual_evaluate(
             phase, M, T, ptr(self.node_ptr), ptr(self.P_est), ptr(self.P_sch), ptr(self.G),
             ptr(self.R64), ptr(self.R64T), ptr(y), int(use_y), self.kappa, self.vlo, self.vhi,
-            self.op.newton_kadd, self.ksplit1, ptr(self.d_sl), ptr(self.v_sl), ptr(self.pnq),
+            kadd, self.ksplit1, ptr(self.d_sl), ptr(self.v_sl), ptr(self.pnq),
             ptr(self.P_est_new), ptr(self.vfull), ptr(self.violw), ptr(self.d_part),
             ptr(self.c_idx[k]), ptr(self.c_cnt[k]), ptr(self.c_val[k]), self.stats_dev[k],
             tag, ptr(self.tile_cnt), self.stream), "revs_op_dual_evaluate")
@@ -51,7 +52,7 @@ class DualNewtonMixin:
             ptr(self.R64), ptr(self.c_idx[sup]), ptr(self.c_cnt[sup]), ptr(y), self.kappa,
             ptr(self.pnq), ptr(self.P_est_new), self.stream), "revs_op_dual_eval_rows")
 
-    def _dual_launch(self, y, use_y: bool, k: int, full: bool = True, sup=None, record=True):
+    def _dual_launch(self, y, use_y: bool, k: int, full: bool = True, sup=None, record=True, kadd=None):
         """Enqueue one evaluation: p, N, D and the voltage rows for the multipliers y;
         candidate lists and stats into buffer set k, stats on their way to pinned host
         memory.  Also writes P_est_new = max(g0 - R^T y / kappa, 0).  Does not wait.
@@ -64,13 +65,13 @@ class DualNewtonMixin:
             self._dual_home_pass_rows(y, sup)
             if self.group is not None:
                 self._allreduce(self.pnq if full else self.pnq[0])
-            self._dual_phase(2, y, use_y, k)
+            self._dual_phase(2, y, use_y, k, kadd)
         elif self.group is None:
-            self._dual_phase(3, y, use_y, k)
+            self._dual_phase(3, y, use_y, k, kadd)
         else:
-            self._dual_phase(1, y, use_y, k)
+            self._dual_phase(1, y, use_y, k, kadd)
             self._allreduce(self.pnq if full else self.pnq[0])   # the only exchange
-            self._dual_phase(2, y, use_y, k)
+            self._dual_phase(2, y, use_y, k, kadd)
 
     def _dual_complete(self, y, use_y: bool, k: int):
         """After a full=False evaluation that did not settle the solve: exchange N and the
@@ -98,8 +99,8 @@ class DualNewtonMixin:
             self._pending_tag[k] = None
         return self.stats_host[k].numpy().copy()
 
-    def _dual_evaluate(self, y, use_y: bool, k: int, sup=None):
-        self._dual_launch(y, use_y, k, sup=sup)
+    def _dual_evaluate(self, y, use_y: bool, k: int, sup=None, kadd=None):
+        self._dual_launch(y, use_y, k, sup=sup, kadd=kadd)
         return self._dual_wait(k)
 
     def _operator_solve_newton(self, first=None, pre=None):
@@ -124,6 +125,7 @@ class DualNewtonMixin:
         stt = (self._dual_evaluate(ycur, self._y_support, cur, sup=self._sup)
                if first is None else first)
         evals, newton, pivots, ok_all = 1, 0, 0, False
+        kadd_stt = o.newton_kadd         # what the evaluation behind `stt` admitted with (revs_plan_set_kadd_cold's rule)
         best, stall = np.inf, 0
         last_small = False
         from_pre = pre is not None       # P_est_new is what `pre` (== `first` if nothing moved) wrote
@@ -150,10 +152,12 @@ class DualNewtonMixin:
             # model of every slot: K_t = R_F N_t R_F^T / kappa over its candidates, maximised
             # over the sign constraints (block principal pivoting, one workgroup per slot)
             # (candidates of a slot = its rows with a multiplier + the violated rows admitted)
-            ncand = stt[:, 2] + np.minimum(stt[:, 3], np.minimum(o.newton_kadd, A - stt[:, 2]))
+            ncand = stt[:, 2] + np.minimum(stt[:, 3], np.minimum(kadd_stt, A - stt[:, 2]))
             self.model_calls[0 if ncand.max() <= 8 else 1] += 1
             last_small = bool(ncand.max() <= 8)
-            few = stt[:, 2].max() + o.newton_kadd <= 48
+            few = stt[:, 2].max() + kadd_stt <= 48
+            kadd_next = (o.newton_kadd_cold if (o.newton_kadd_cold > o.newton_kadd and stt[:, 3].max() > o.newton_kadd_cold_at)
+                         else o.newton_kadd)
             # (the chain guessed how its trial's home pass gets d = R^T y / kappa -- row-wise or
             # dense; another choice here would differ in the last bits: then redo the trial)
             use_pre = (pre is not None and newton == 1 and last_small
@@ -178,6 +182,7 @@ class DualNewtonMixin:
             alpha = pending.astype(np.float64)
             nxt = 1 - cur
             for ls in range(o.newton_ls):
+                kadd_stn = o.newton_kadd if (use_pre and ls == 0) else kadd_next
                 if use_pre and ls == 0:
                     stn = pre                    # that trial and its evaluation: already there
                 else:
@@ -189,7 +194,7 @@ class DualNewtonMixin:
                                                 self.alpha_dev, ptr(ytrial),
                                                 self.stats_dev[nxt] + 32, st),
                           "revs_op_dual_step")
-                    stn = self._dual_evaluate(ytrial, True, nxt, sup=cur if few else None)
+                    stn = self._dual_evaluate(ytrial, True, nxt, sup=cur if few else None, kadd=kadd_next)
                 evals += 1
                 # (slack 1e-11 |D|: the evaluations sum the squares rounded to 2^-32 so that the sums do
                 # not depend on their order -- a rounding of ~1e-13 |D| per evaluation)
@@ -202,7 +207,7 @@ class DualNewtonMixin:
             if pending.any():
                 break                                    # no ascent found: leave it to ADMM
             ycur, ytrial = ytrial, ycur
-            cur, stt = nxt, stn
+            cur, stt, kadd_stt = nxt, stn, kadd_stn
         self.yd = [ycur, ytrial]
         self.newton_hist.append((newton, evals, pivots))
         self._pre_kept = bool(ok_all and from_pre and newton <= 1)

@@ -50,6 +50,9 @@ run("dual Newton (default)", OperatorOptions())
 if "--kadd" in sys.argv:
     for _k in (1, 2, 4, 8):
         run(f"dual Newton, kadd {_k}", OperatorOptions(newton_kadd=_k))
+if "--kadd-cold" in sys.argv:      # rows admitted per Newton iteration while a slot shows many violated rows (round 5)
+    for _c, _at in ((4, 2), (6, 3), (8, 4), (8, 8), (12, 6), (16, 6), (16, 12), (32, 8)):
+        run(f"dual Newton, kadd 2, cold {_c} above {_at} violated", OperatorOptions(newton_kadd_cold=_c, newton_kadd_cold_at=_at))
 if "--admm" in sys.argv:
     for rv in (1.0, 25.0):
         run(f"ADMM forms, rho_v {rv}", OperatorOptions(solver="admm", rho_v_scale=rv))

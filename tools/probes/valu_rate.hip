@@ -47,7 +47,11 @@ __global__ __launch_bounds__(1024) void rate_kernel(float *out, WaveRec *rec, in
     asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < CH; ++i) s += x[i] + y[i].x + y[i].y + (float)z[i];
+    for (int i = 0; i < CH; ++i) {      // (only the kind's own registers live across the loop)
+        if (KIND == 1) s += y[i].x + y[i].y;
+        else if (KIND == 5) s += (float)z[i];
+        else s += x[i];
+    }
     if (s == 123.456f) out[0] = s;
     if ((threadIdx.x & 63) == 0) {
         unsigned hw, xcc;
@@ -76,22 +80,35 @@ static void run(const char *name, int blocks, const char *scope, float *d, WaveR
     std::vector<int> occ;
     for (auto &p : per) occ.push_back(p.second);
     std::sort(occ.begin(), occ.end());
-    // overlap-aware: a wavefront's loop shares its SIMD with occ-1 others for (nearly) its whole length when the
-    // grid is one resident round; cycles per instruction per SIMD = median over wavefronts of cycles x ... / (occ x n)
-    std::vector<double> cpi, mhz;
+    // cycles per instruction per SIMD, rigorously: on every SIMD, (last wavefront's end - first wavefront's start) by the
+    // shader clock, over the instructions its wavefronts issued there (s_memtime is one counter per XCC: the wavefronts
+    // of a SIMD share it).  "steady": the same over the window in which ALL of the SIMD's wavefronts were inside their
+    // loops (latest start .. earliest end), with the instructions pro-rated -- what the SIMD sustains with `occ`
+    // wavefronts resident, free of the ramp at either end.
+    std::vector<double> cpi, cpi_steady, mhz;
     const double n = (double)iters * CH;
-    for (auto &w : h) {
-        const int o = per[((w.xcc & 0xf) << 16) | (w.hw & 0xfff0) >> 4];
-        cpi.push_back((double)(w.c1 - w.c0) / (n * o));
-        mhz.push_back((double)(w.c1 - w.c0) / (double)(w.r1 - w.r0) * 100.0);
+    std::map<unsigned, std::vector<const WaveRec *>> by;
+    for (auto &w : h) by[((w.xcc & 0xf) << 16) | (w.hw & 0xfff0) >> 4].push_back(&w);
+    for (auto &kv : by) {
+        unsigned long long a0 = ~0ull, a1 = 0, b0 = 0, b1 = ~0ull;
+        for (auto *w : kv.second) { a0 = std::min(a0, w->c0); a1 = std::max(a1, w->c1); b0 = std::max(b0, w->c0); b1 = std::min(b1, w->c1); }
+        cpi.push_back((double)(a1 - a0) / (n * kv.second.size()));
+        if (b1 > b0) {
+            double issued = 0.0;
+            for (auto *w : kv.second) issued += n * (double)(b1 - b0) / (double)(w->c1 - w->c0);
+            cpi_steady.push_back((double)(b1 - b0) / issued);
+        }
     }
+    for (auto &w : h) mhz.push_back((double)(w.c1 - w.c0) / (double)(w.r1 - w.r0) * 100.0);
     std::sort(cpi.begin(), cpi.end());
+    std::sort(cpi_steady.begin(), cpi_steady.end());
     std::sort(mhz.begin(), mhz.end());
+    const double steady = cpi_steady.empty() ? 0.0 : cpi_steady[cpi_steady.size() / 2];
     const double instr_per_simd = n * occ[occ.size() / 2];
-    printf("%-14s %-9s chains %2d  SIMDs used %4zu  waves/SIMD min %d med %d max %d | cycles per instr per SIMD: med %.2f (p10 %.2f p90 %.2f) "
-           "| shader clock %.0f MHz | launch %.1f us = %.2f ns per instr per SIMD\n",
+    printf("%-14s %-9s chains %2d  SIMDs used %4zu  waves/SIMD min %d med %d max %d | cycles per instr per SIMD: span med %.2f (p10 %.2f p90 %.2f), "
+           "all-resident window med %.2f | shader clock %.0f MHz | launch %.1f us = %.2f ns per instr per SIMD\n",
            name, scope, CH, occ.size(), occ.front(), occ[occ.size() / 2], occ.back(), cpi[cpi.size() / 2], cpi[cpi.size() / 10],
-           cpi[cpi.size() * 9 / 10], mhz[mhz.size() / 2], ms * 1e3, ms * 1e6 / instr_per_simd);
+           cpi[cpi.size() * 9 / 10], steady, mhz[mhz.size() / 2], ms * 1e3, ms * 1e6 / instr_per_simd);
 }
 
 int main() {
@@ -110,6 +127,8 @@ int main() {
         snprintf(scope, sizeof scope, "chip x%d", wps);
         run<0, 8>(names[0], blocks, scope, d, drec, iters);
         run<0, 16>(names[0], blocks, scope, d, drec, iters);
+        run<0, 32>(names[0], blocks, scope, d, drec, iters);
+        run<4, 32>(names[4], blocks, scope, d, drec, iters);
         run<1, 8>(names[1], blocks, scope, d, drec, iters);
         run<2, 8>(names[2], blocks, scope, d, drec, iters);
         run<3, 8>(names[3], blocks, scope, d, drec, iters);
@@ -122,6 +141,7 @@ int main() {
         char scope[32];
         snprintf(scope, sizeof scope, "one CU x%d", wps);
         run<0, 8>(names[0], 1, scope, d, drec, iters, 256 * wps);
+        run<0, 32>(names[0], 1, scope, d, drec, iters, 256 * wps);
         run<1, 8>(names[1], 1, scope, d, drec, iters, 256 * wps);
         run<4, 8>(names[4], 1, scope, d, drec, iters, 256 * wps);
     }
