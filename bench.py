@@ -72,10 +72,19 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (6.3 TB/s achievable)
 F64_MFMA_PEAK_TFLOPS = 78.6    # MI355X datasheet, dense f64 matrix
-# VALU issue: shader cycles one SIMD needs per wave64 VALU instruction, sustained with several wavefronts per SIMD and
-# independent dependency chains -- measured on this part by tools/probes/valu_rate.hip (s_memtime around the loop, the
-# wavefronts' SIMDs read from HW_ID), raw output committed as profiles/r05_probe_valu_rate.txt
-VALU_CYCLES = 4
+# VALU issue: shader cycles one SIMD needs per wave64 VALU instruction.  2 = the SIMD-32 rate behind the 157.3 TFLOP/s fp32
+# vector peak (MI355X_MICROARCH.md: `v_fma_f32` (wave64) 2 cyc; one wave alone: 4).  Measured on this part by
+# tools/probes/valu_rate.hip (s_memtime around every wavefront's loop, first start to last end per SIMD, the wavefronts'
+# SIMDs read from HW_ID; raw output: profiles/r05_probe_valu_rate.txt): v_fma_f32 / v_add_f32 with 32 independent chains
+# per wavefront sustain 5.0 cycles per instruction with one wavefront per SIMD, 2.5 with two, 2.31-2.48 with four or eight
+# (the loop's own branch included) -- NOT 4, which rounds 3-4 priced this kernel against (0.79 then; 0.40 by this);
+# v_add_f32_dpp, v_med3_f32, v_pk_fma_f32 and v_fma_f64 run at half that rate (4.4 cycles).
+VALU_CYCLES = 2
+VALU_CYCLES_SUSTAINED = 2.31                     # best measured: v_fma_f32, 8 wavefronts per SIMD, 16 chains
+VALU_PEAK = 1024 * 2.4e9 / VALU_CYCLES           # wave64 VALU instructions per second, 1024 SIMDs at 2.4 GHz
+VALU_PEAK_SOURCE = ("2 shader cycles per wave64 VALU instruction per SIMD (SIMD-32; MI355X_MICROARCH.md constants table) x 1024 SIMDs x "
+                    "2.4 GHz; profiles/r05_probe_valu_rate.txt (tools/probes/valu_rate.hip) measures 2.31-2.48 cycles sustained "
+                    "for v_fma_f32 / v_add_f32 at 4-8 wavefronts per SIMD, 4.4 for DPP adds, v_med3_f32, v_pk_fma_f32, v_fma_f64")
 SQ_QUAD = 4     # SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / SQ_WAIT_* count quad-cycles (MI355X_MICROARCH.md, constants table)
 VALU_PEAK = 1024 * 2.4e9 / VALU_CYCLES           # wave64 VALU instructions per second, 1024 SIMDs at 2.4 GHz
 VALU_PEAK_SOURCE = ("profiles/r05_probe_valu_rate.txt (tools/probes/valu_rate.hip: cycles per v_fma_f32 / v_add_f32 per SIMD by "
@@ -666,6 +675,7 @@ def main():
             ms, its, conv = [], [], []
             for _ in range(reps):
                 w3, e3, _ = build(args.homes, args.T, mode, args.stress, args.voltage)
+                clock_warm(e3)               # (building the workload left the GPU idle for ~0.5 s: the run is timed at steady clocks, like the steps)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 r = e3.run(iter_max, eps=eps, history=history)
@@ -848,9 +858,7 @@ def main():
         # VALU issue: the multi-iteration sweep is bound by instruction issue, not by HBM (its bytes per
         # ADMM iteration are 1/8 of the one-iteration sweep's).  Instructions per launch from the committed
         # SQ counter pass (profiles/agent_traffic.json, same workload), duration live (avg_launch_ms).
-        # Peak: one wave64 VALU instruction per 4 cycles per SIMD (16 lanes per SIMD and cycle: the
-        # 157.3 TFLOP/s fp32 vector peak counts packed FMAs) x 1024 SIMDs x 2.4 GHz; measured on this
-        # chip with tools/probes/valu_rate.hip: 1.56-1.76 ns per v_fma_f32 per SIMD at 4-8 wavefronts.
+        # Peak: VALU_PEAK above (one wave64 VALU instruction per 2 cycles per SIMD; profiles/r05_probe_valu_rate.txt).
         valu = None
         try:
             tj = json.load(open(tpath))
@@ -865,6 +873,7 @@ def main():
                 valu = {"kernel": "agent_step_kernel<MULTI>", "bound": "valu-issue", "achieved": ach_v / 1e9,
                         "peak": peak / 1e9, "peak_source": VALU_PEAK_SOURCE,
                         "unit": "G wave64 VALU instructions/s", "frac": ach_v / peak,
+                        "frac_of_measured_sustained_rate": ach_v / (1024 * 2.4e9 / VALU_CYCLES_SUSTAINED),
                         "valu_instructions_per_launch": c["SQ_INSTS_VALU"] * (it_launch / inner),
                         "iterations_per_timed_launch": it_launch,
                         "valu_instructions_per_wavefront_and_iteration": c["SQ_INSTS_VALU"] / max(c.get("SQ_WAVES", 1), 1) / inner,
@@ -939,8 +948,9 @@ def main():
             out["time_to_eps"] = {
                 "time_to_eps_ms": a["ms"] if a else None, "iterations": a["iterations"] if a else None,
                 "converged_at": a["converged_at"] if a else None, "eps": args.eps, "runs_ms": a["all_ms"] if a else None,
-                "rule": "ONE AdmmEngine.run(iter_max=1000, eps, history=False) from the zero state on a fresh engine, wall clock "
-                        "between two synchronises, median of 5 engines; stops after max_h diff <= eps has held for 8 iterations "
+                "rule": "ONE AdmmEngine.run(iter_max=1000, eps, history=False) from the zero state on a fresh engine (GPU clocks "
+                        "warmed by throw-away products first, as before the timed steps), wall clock between two synchronises, "
+                        "median of 5 engines; stops after max_h diff <= eps has held for 8 iterations "
                         "(+ at most the rest of a 64-iteration burst) and one more iteration that writes the schedules",
                 "with_per_residence_diff_history_ms": (tte["pdhg_eps_with_diff_history"] or {}).get("ms"),
                 "cpu_time_to_eps_s_projected": (a["iterations"] * cpu_it_s) if (a and cpu_it_s) else None,

@@ -109,6 +109,12 @@ typedef struct {
                              in every wavefront's instruction chain and 2 - 4 x the wavefronts: the shape for a GPU
                              that holds few residences (BASELINE config 2 over eight GPUs: 12 500 each, 391 workgroups
                              of the default shape on 256 compute units).  Other values, or T > 32: as 0. */
+    int32_t keys64;       /* on/off chargers (REVS_MODE_BINARY): 1 = the slots' switching costs delta_t are formed and
+                             ranked in double, in the float64 restatement's order of operations -- the decision is then
+                             the oracle's for every residence on identical inputs.  0 (default): in float, by the same
+                             operations that update the state, so that the closed loop's exactly tied optima
+                             (lpsolver.py:92-110 on flat tariff blocks x repeated loads) stay tied from one ADMM
+                             iteration to the next, as they do in the reference's double arithmetic. */
 } revs_pdhg_t;
 
 const char *revs_version(void);

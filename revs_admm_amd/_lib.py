@@ -29,7 +29,7 @@ MODES = {"binary": MODE_BINARY, "relaxed": MODE_RELAXED_PDHG, "pdhg": MODE_RELAX
 class PDHG(C.Structure):
     _fields_ = [("max_iter", C.c_int32), ("check", C.c_int32), ("tol", C.c_float),
                 ("tau_scale", C.c_float), ("sigma_scale", C.c_float), ("full_rows", C.c_int32),
-                ("polish", C.c_int32), ("lanes", C.c_int32)]
+                ("polish", C.c_int32), ("lanes", C.c_int32), ("keys64", C.c_int32)]
 
 
 class PlanDesc(C.Structure):

@@ -145,12 +145,39 @@ constexpr int kBlock = 256;
 constexpr float kSocTarget = 0.9f;   // lpsolver.py:109
 constexpr float kSocMax = 1.0f;      // lpsolver.py:102-103
 
-// rank of each of this lane's SPL keys among the group's LPA*SPL keys, ties to the earlier slot:
+// rank of each of this lane's SPL keys among the group's LPA*SPL keys, ties to
+// the earlier slot: rank_j = #{tau : key_tau < key_j or (key_tau == key_j and tau < t_j)}
+// = #{tau : (key_tau, tau) < (key_j, t_j)} lexicographically: the key mapped to an integer of the same order in the
+// high word, the slot in the low word, ONE 64-bit compare and an add-with-carry per pair (the two float compares,
+// the slot compare and the mask logic were five vector and two scalar instructions per pair: 360 + 144 per
+// wavefront, most of the on/off charger's solve).
+template <int LPA, int SPL>
+__device__ __forceinline__ void group_rank(const float (&key)[SPL], int t0, int (&rank)[SPL]) {
+    int ord[SPL];
+    long long mine[SPL];
+#pragma unroll
+    for (int j = 0; j < SPL; ++j) {
+        const int b = __float_as_int(key[j]);
+        ord[j] = b ^ ((b >> 31) & 0x7fffffff);           // floats -> integers of the same order (-0 < +0: keys are sums, never -0)
+        mine[j] = ((long long)ord[j] << 32) | (unsigned int)(t0 + j);
+        rank[j] = 0;
+    }
+#pragma unroll 1
+    for (int sl = 0; sl < LPA; ++sl) {
+#pragma unroll
+        for (int sj = 0; sj < SPL; ++sj) {
+            const long long other = ((long long)__shfl(ord[sj], sl, LPA) << 32) | (unsigned int)(sl * SPL + sj);
+#pragma unroll
+            for (int j = 0; j < SPL; ++j) rank[j] += other < mine[j] ? 1 : 0;
+        }
+    }
+}
+
+// The same ranks from DOUBLE keys (revs_pdhg_t::keys64, and the individual mode):
 // rank_j = #{tau : key_tau < key_j or (key_tau == key_j and tau < t_j)} -- numpy's stable argsort, which is what the
 // oracle ranks with (oracle/revs_oracle.py home_solve_binary; the reference's Gurobi picks among exactly tied slots
-// by an order of its own).  The keys are DOUBLES formed from the float inputs in the oracle's
-// own order of operations (round 5; they were floats, and near-ties inside float rounding went to another slot of
-// equal cost for ~0.3 % of the residences): mapped to integers of the same order, (key, slot) pairs compare
+// by an order of its own).  The keys are doubles formed from the float inputs in the oracle's
+// own order of operations (round 5): mapped to integers of the same order, (key, slot) pairs compare
 // lexicographically as ord_tau < ord_j + [tau < t_j] -- every slot of an earlier lane precedes every slot of this
 // one, none of a later lane does, and the lane's own slots are settled behind the loop.
 template <int LPA, int SPL>
@@ -286,6 +313,7 @@ void agent_step_kernel(const AgentArgs a) {
     constexpr int kAcc = MULTI ? shape_max_inner(kSlots) : 1;
     __shared__ double nacc[kAcc][kNodeLoc][kSlots];
     __shared__ unsigned int dmx[kAcc];
+    __shared__ unsigned int arrived;      // wavefronts of this workgroup that have finished their residences (the last one flushes)
     const int64_t first = (int64_t)bid * kHomesPerBlock;
     // Every global load of the kernel is issued before the first use of any of them (one exposed
     // memory latency per wavefront, not three): profiles, then the home record and the carried
@@ -337,6 +365,7 @@ void agent_step_kernel(const AgentArgs a) {
         if (a.p_next) {
             for (int i = tid; i < kin * kNodeLoc * kSlots; i += kBlock) (&nacc[0][0][0])[i] = 0.0;
             if (tid < kAcc) dmx[tid] = 0u;
+            if (tid == 0) arrived = 0u;
         }
         base = a.node_of[first < a.n ? first : a.n - 1];
         if constexpr (CHAIN) {
@@ -505,28 +534,47 @@ void agent_step_kernel(const AgentArgs a) {
         // p_t = e_t * rating, e_t binary (lpsolver.py:92-98).  Switching slot t on
         // costs delta_t = rating ((kappa/2) rating + q_t); take the nmin cheapest,
         // then more while delta < 0, up to nmax.
-        double key[SPL];
         int rank[SPL];
         int nwin = 0;
+        bool neg[SPL];               // delta_t < 0: worth taking beyond the nmin slots the SOC rows demand
 #pragma unroll
-        for (int j = 0; j < SPL; ++j) {
-#pragma clang fp contract(off)
-            // delta_t in double, from the float inputs, in the oracle's order of operations (home_linear_term,
-            // home_solve_binary): the on/off decision is then the float64 restatement's, bit for bit
-            const double kd = (double)kappa, rt = (double)h.rating;
-            const double at = (double)gm[j] + 0.5 * kd * ((double)pe[j] + (double)pso[j]);
-            const double qd = kd * (double)L[j] + (double)cst[j] - at;
-            key[j] = win[j] ? rt * (0.5 * kd * rt + qd) : (double)INFINITY;
-            nwin += win[j] ? 1 : 0;
-        }
+        for (int j = 0; j < SPL; ++j) nwin += win[j] ? 1 : 0;
         nwin = (int)group_sum<LPA>((float)nwin);
-        group_rank<LPA, SPL>(key, lig, rank);
+        if (a.pd.keys64) {
+            // delta_t in DOUBLE, from the float inputs, in the oracle's order of operations (home_linear_term,
+            // home_solve_binary): on identical inputs the on/off decision is the float64 restatement's for every
+            // residence (tests/test_gpu_agent.py).  NOT the closed loop's default: there the exactly tied optima of the
+            // reference's data (flat tariff blocks x repeated loads) stay tied only while a_t is formed by the very
+            // float operations that formed the state -- G = -(kappa/2) g and (kappa/2)(P_est + P_sch) cancel EXACTLY in
+            // float, and differ by G's own rounding in double: ties are then redrawn by that noise every iteration
+            // and the 121144 feeder's run leaves the reference's band (mean diff[k] off by 4 x, measured in round 5).
+            double key[SPL];
+#pragma unroll
+            for (int j = 0; j < SPL; ++j) {
+#pragma clang fp contract(off)
+                const double kd = (double)kappa, rt = (double)h.rating;
+                const double at = (double)gm[j] + 0.5 * kd * ((double)pe[j] + (double)pso[j]);
+                const double qd = kd * (double)L[j] + (double)cst[j] - at;
+                key[j] = win[j] ? rt * (0.5 * kd * rt + qd) : (double)INFINITY;
+                neg[j] = key[j] < 0.0;
+            }
+            group_rank<LPA, SPL>(key, lig, rank);
+        } else {
+            float key[SPL];
+#pragma unroll
+            for (int j = 0; j < SPL; ++j) {
+#pragma clang fp contract(off)
+                key[j] = win[j] ? h.rating * (0.5f * kappa * h.rating + q[j]) : INFINITY;
+                neg[j] = key[j] < 0.f;
+            }
+            group_rank<LPA, SPL>(key, t0, rank);
+        }
         const bool infeasible = ev && (h.nmin > h.nmax || h.nmin > nwin);
         status = infeasible ? 1 : 0;
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
             const bool take = win[j] && !infeasible &&
-                              (rank[j] < h.nmin || (rank[j] < h.nmax && key[j] < 0.0));
+                              (rank[j] < h.nmin || (rank[j] < h.nmax && neg[j]));
             p[j] = take ? h.rating : 0.f;
         }
     } else if constexpr (MODE == REVS_MODE_RELAXED_PDHG) {
@@ -926,20 +974,32 @@ void agent_step_kernel(const AgentArgs a) {
     }
     if (a.p_next) {
         if (a.dmax_out && (tid & 63) < kin && dmx_mine != 0u) atomicMax(&dmx[tid & 63], dmx_mine);
-        __syncthreads();
-        for (int i = tid; i < kin * kNodeLoc * T; i += kBlock) {
-            const int itq = i / (kNodeLoc * T), r = i - itq * (kNodeLoc * T);
+        // No workgroup barrier in front of the flush (round 5): a wavefront that is done counts itself and leaves; the LAST
+        // of the workgroup's wavefronts to arrive flushes the accumulators for all.  (A wavefront of residences without an
+        // EV runs a third of the instructions of one that solves QPs -- the engine's order puts like with like, so most
+        // workgroups hold both kinds; at a barrier the quick ones sat on their registers until the slow ones came, and
+        // nearly half of all wave-cycles were spent parked: SQ_WAIT_ANY 187 M of SQ_WAVE_CYCLES 415 M, r04.)  Ordering:
+        // a wavefront's LDS operations execute in issue order, so its adds into nacc / dmx are performed before its
+        // increment of `arrived` is; the last arriver's reads are issued after its own increment has returned.
+        unsigned int before = 0u;
+        if ((tid & 63) == 0) before = atomicAdd(&arrived, 1u);
+        before = (unsigned int)__builtin_amdgcn_readfirstlane((int)before);
+        if (before != kBlock / 64 - 1) return;
+        const int ln = tid & 63;
+        for (int r = ln; r < kNodeLoc * T; r += 64) {
             const int l = r / T, t = r - l * T;
-            const double v = nacc[itq][l][t];
-            if (v != 0.0)
-                unsafeAtomicAdd(&a.p_next[(long long)itq * a.slice_stride + (int64_t)(base + l) * T + t], v);
+            double *dst = a.p_next + (int64_t)(base + l) * T + t;
+            for (int itq = 0; itq < kin; ++itq, dst += a.slice_stride) {
+                const double v = nacc[itq][l][t];
+                if (v != 0.0) unsafeAtomicAdd(dst, v);
+            }
         }
-        if (a.dmax_out && tid < kin && dmx[tid] != 0u)
+        if (a.dmax_out && ln < kin && dmx[ln] != 0u)
             // (REVS_DMAX_SLOTS addresses per iteration: thousands of workgroups on ONE address serialise
             // in the L2 -- measured 27 us per launch at 3 125 workgroups)
-            __hip_atomic_fetch_max((unsigned long long *)(a.dmax_out + (long long)tid * a.slice_stride +
+            __hip_atomic_fetch_max((unsigned long long *)(a.dmax_out + (long long)ln * a.slice_stride +
                                                           (bid & (REVS_DMAX_SLOTS - 1))),
-                                   (unsigned long long)__double_as_longlong((double)__uint_as_float(dmx[tid])),
+                                   (unsigned long long)__double_as_longlong((double)__uint_as_float(dmx[ln])),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if constexpr (CHAIN) {
@@ -1175,6 +1235,7 @@ extern "C" void revs_pdhg_defaults(revs_pdhg_t *o) {
     o->full_rows = 0;
     o->polish = 1;
     o->lanes = 0;
+    o->keys64 = 0;
 }
 
 static int64_t agent_num_blocks(int64_t n_homes, int32_t T, int lanes) {

@@ -103,8 +103,10 @@ class OperatorOptions:
     # ... but newton_kadd_cold of them in an evaluation that follows one in which some slot showed more than
     # newton_kadd_cold_at violated rows without a multiplier (round 5): a cold solve -- the first ADMM iterations of the
     # 121144 feeder end with 50-69 binding rows in a slot -- took as many Newton iterations as half of those rows
-    # (19 and 14 in iterations 2 and 3, of 79 in all 15); the warm solves keep their small models.  0: off.
-    newton_kadd_cold: int = 0
+    # (19 and 17 in iterations 2 and 3, of 78 in all 15); the warm solves keep their small models.  0: off.
+    # Measured on that feeder (tests/tools/feeder_iters.py --kadd-cold, 15 iterations): off 11.1 ms / 98 evaluations;
+    # 4 above 2: 10.0; 8 above 4: 10.1; 12 above 6: 9.9; 16 above 6: 9.7 / 78 evaluations; 32 above 8: 10.5.
+    newton_kadd_cold: int = 16
     newton_kadd_cold_at: int = 6
     chain: bool = True           # binding steady state: one Newton iteration enqueued unread
     # ... and folded (one GPU, feeder as a tree): the sweep forms the operator's answer for the trial
@@ -993,14 +995,24 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
             inv = torch.from_numpy(np.ascontiguousarray(self.inv_perm, dtype=np.int64)).to(self.dev)
         self.converged_at = None
         k, it0, good, seen, stop = 0, self.iteration, 0, self.iteration, False
+        cap = 64
         while k < iter_max:
             base, r = k, 0
             while r < rows and k < iter_max:
                 last = k == iter_max - 1 or stop
                 if (not last and self._stream_ok() and self._fused_ready):
-                    # (with eps: bursts of at most 64, so that the run ends soon after the stretch)
-                    done = self._stream_run(min(rows - r, iter_max - 1 - k, 64 if eps is not None else rows),
+                    # (with eps: bursts sized by where the records say max diff will cross eps -- its decay is close to
+                    # geometric -- so that the run ends soon after the stretch without paying a burst's fixed cost, the
+                    # exposed last verdict launch and the host's turn, every 64 iterations)
+                    done = self._stream_run(min(rows - r, iter_max - 1 - k, cap if eps is not None else rows),
                                             hist[r:] if history else None)
+                    if eps is not None and done >= 8:
+                        d0, d1 = self.max_diff.get(self.iteration - done + 1), self.max_diff.get(self.iteration)
+                        if d0 and d1 and eps < d1 < d0:
+                            left = math.log(d1 / eps) * (done - 1) / math.log(d0 / d1)
+                            cap = int(min(512, max(32, 0.85 * left)))
+                        else:
+                            cap = 32
                 else:
                     self.step(write_sc=last)
                     if history:

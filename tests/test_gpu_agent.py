@@ -65,17 +65,20 @@ def _prep(n, T, seed, **kw):
 @pytest.mark.parametrize("T,n", [(24, 3001), (96, 3001), (7, 3001), (33, 3001), (130, 3001), (192, 3001), (2, 3001),
                                  (24, 100_000)])
 @pytest.mark.parametrize("zero_state", [True, False])
-def test_binary_matches_oracle(gpu_lib, T, n, zero_state):
-    """Binary charger = the reference MIQP.  Bit-exact schedule wherever the oracle's
-    decision margin exceeds float rounding; objective equal everywhere.  (100 000 x 24: BASELINE's
-    headline size, every residence against the oracle.)"""
+@pytest.mark.parametrize("keys64", [1, 0])
+def test_binary_matches_oracle(gpu_lib, T, n, zero_state, keys64):
+    """Binary charger = the reference MIQP.  keys64 = 1 (revs_pdhg_t::keys64): the slots' switching costs formed and
+    ranked in double in the oracle's order of operations -- the SAME schedule for EVERY residence, exact ties included
+    (both sides: earlier slot).  keys64 = 0, the closed loop's default (float keys, formed by the operations that update
+    the state: include/revs_admm.h says why): bit-exact wherever the oracle's decision margin exceeds float rounding,
+    objective equal everywhere.  (100 000 x 24: BASELINE's headline size, every residence against the oracle.)"""
     from oracle import revs_oracle as ro
     w, oh = _prep(n, T, seed=T)
     if zero_state:
         pe_old = pe_new = ps = gm = np.zeros((n, T))          # lpsolver.py:244-246
     else:
         pe_old, pe_new, ps, gm = _state(w, T)
-    r = _run_agent(gpu_lib, w, pe_old, pe_new, ps, gm, "binary")
+    r = _run_agent(gpu_lib, w, pe_old, pe_new, ps, gm, "binary", dict(keys64=keys64))
     p, s, g, st = ro.home_solve_binary(w.cost, oh, pe_old, ps, gm, w.kappa)
     assert ((r["status"] & 0xFF) == st).all()          # same homes flagged infeasible
     assert (st == 0).mean() > (0.9 if T > 4 else 0.3)     # (T = 2: few windows can reach 90 %)
@@ -85,10 +88,11 @@ def test_binary_matches_oracle(gpu_lib, T, n, zero_state):
     obj_ref = ro.home_objective(w.cost, oh, p, pe_old, ps, gm, w.kappa)
     scale = np.maximum(1.0, np.abs(obj_ref))
     assert np.max(np.abs(obj_gpu - obj_ref) / scale) < 2e-5
-    # round 5: the ranking keys are doubles formed from the float inputs in the oracle's order of operations, so the
-    # on/off decision IS the float64 restatement's -- every residence, exact ties included (both sides: earlier slot)
     same = (np.abs(r["S"] - p).max(axis=1) == 0)
-    assert same.all(), (int((~same).sum()), n)
+    if keys64:
+        assert same.all(), (int((~same).sum()), n)
+    else:
+        assert same.mean() > 0.995
     # slot counts and window are exact
     assert ((r["S"] > 0).sum(1) == (p > 0).sum(1)).all()
     assert (r["S"][~oh.window()] == 0).all()
@@ -279,7 +283,7 @@ def test_edge_parameters(gpu_lib, mode):
         if mode == "pdhg_presolve":        # (the KKT steps first, from a zero multiplier: revs_pdhg_t::polish = 3)
             r = _run_agent(gpu_lib, w, pe_old, pe_new, ps, gm, "pdhg", dict(polish=3))
         else:
-            r = _run_agent(gpu_lib, w, pe_old, pe_new, ps, gm, mode)
+            r = _run_agent(gpu_lib, w, pe_old, pe_new, ps, gm, mode, dict(keys64=1) if mode == "binary" else None)
         solve = ro.home_solve_binary if mode == "binary" else ro.home_solve_relaxed
         p, s, g, st = solve(w.cost, oh, pe_old, ps, gm, w.kappa)
         assert ((r["status"] & 0xFF) == st).all()

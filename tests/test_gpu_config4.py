@@ -312,7 +312,7 @@ def test_iterations_to_the_eps_residual_match_the_oracle(gpu_lib):
     mx = d.max(axis=1)
     first = next(k for k in range(8, iters) if (mx[k - 7:k + 1] <= 3e-4).all()) - 7 + 1     # (1-based)
     print(f"run(eps=3e-4) stopped after {len(d2)} iterations, converged_at {e2.converged_at} (first stretch of 8: {first})")
-    assert e2.converged_at == first and first + 7 <= len(d2) <= first + 7 + 64 + 1
+    assert e2.converged_at == first and first + 7 <= len(d2) <= first + 7 + 96 + 1      # (the burst in which it happened ends the run; bursts are sized by the decay of max diff)
     np.testing.assert_array_equal(d2, d[:len(d2)])
     P2, S2, C2 = e2.result()
     assert np.abs(S2.sum(1) - (C2[:, -1] - C2[:, 0]) * np.where(w.homes["ev"] == 1, w.homes["capacity"], 0)).max() < 1e-3
@@ -392,7 +392,7 @@ def test_binary_teacher_forced_long(gpu_lib):
     iters = 100
     *_, tr = ro.solve_ADMM(oh, w.Rn, w.node_of, w.cost, w.kappa, iters, w.vset, w.vlow, w.vhigh,
                            mode="binary", keep=True, util_method="dual")
-    e = _engine(w, "binary")
+    e = _engine(w, "binary", pdhg=dict(keys64=1))
     z = np.zeros_like(w.load)
     states = [(z, z, z)] + [(tr.P_est[k], tr.P_sch[k], tr.G[k]) for k in range(iters)]
     worst_pe, worst_same = 0.0, 1.0
