@@ -107,6 +107,10 @@ struct AgentArgs {
     int32_t sh_m;
     double sh_kappa;
     double *fold_a, *fold_b;
+    // wg_order != NULL (nsel == 0): workgroup b of the launch takes the residences of workgroup wg_order[b] -- the
+    // workgroups that hold the most residences with an EV first, so that the launch's last round, which cannot fill
+    // the chip, is made of the quick ones (runtime.cpp: plan_wg_order)
+    const int32_t *wg_order;
 };
 constexpr int kMaxInner = REVS_AGENT_MAX_INNER;
 // nodes whose sums a workgroup accumulates in LDS (residences are sorted by node; the others' go straight to
@@ -282,7 +286,7 @@ void agent_step_kernel(const AgentArgs a) {
         else dual_select_body(a.sel, (int)blockIdx.x);
         return;
     }
-    const int bid = (int)blockIdx.x - a.nsel;
+    const int bid = a.wg_order ? a.wg_order[blockIdx.x] : (int)blockIdx.x - a.nsel;
     const int tid = threadIdx.x;
     const int lig = tid & (LPA - 1);
     const int T = a.T;
@@ -1284,6 +1288,7 @@ static int agent_step_impl(int64_t n_homes, int32_t T, const float *cost,
     a.kin = 1; a.pe_out = nullptr; a.y_out = pdhg_dual; a.slice_stride = 0; a.diff_stride = 0; a.dmax_out = nullptr;
     a.sh_a = nullptr; a.sh_b = nullptr; a.sh_m = 0; a.sh_kappa = 0.0;
     a.fold_a = nullptr; a.fold_b = nullptr;
+    a.wg_order = nullptr;
     if (cf) {
         REVS_REQUIRE(cf->sh_a && cf->sh_b && cf->m > 0 && cf->kappa > 0 && cf->fold_a && cf->fold_b &&
                      cf->fold_a != cf->fold_b && cf->pe_out && node_of && !p_est_new && !p_next && !sel && !sx &&
@@ -1306,6 +1311,7 @@ static int agent_step_impl(int64_t n_homes, int32_t T, const float *cost,
         a.kin = sx->kin; a.pe_out = sx->pe_out; a.slice_stride = sx->slice_stride; a.diff_stride = sx->diff_stride;
         a.dmax_out = sx->dmax_out;
         if (sx->y_out) a.y_out = sx->y_out;
+        a.wg_order = sx->wg_order;          // (as many entries as this launch has workgroups: plan_wg_order)
     } else if (sx) {
         REVS_REQUIRE(sx->ctl && sx->rec && sx->p_in && sx->tree.n > 0 && sx->tree.n <= REVS_TREE_SWEEP_MAX && sx->tree.n % 8 == 0 &&
                      sx->tree.pack && sx->tree.w &&
@@ -1332,6 +1338,11 @@ static int agent_step_impl(int64_t n_homes, int32_t T, const float *cost,
 }
 
 namespace revs {
+int64_t agent_homes_per_block(int32_t T, int32_t lanes) {
+    if (T <= 0 || T > REVS_MAX_T) return 0;
+    return kBlock / pick_shape(T, lanes).lpa;
+}
+
 int agent_step_stream(int64_t n_homes, int32_t T, const float *cost, const revs_home_t *homes,
                       const float *load, const float *p_est_old, const float *p_est_new,
                       const float *p_sch, const float *gamma, float *p_sch_out, float *gamma_out,

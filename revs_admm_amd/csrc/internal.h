@@ -24,7 +24,9 @@ struct StreamExtra {
     int64_t slice_stride = 0;   // doubles between the node-sum slices of consecutive inner iterations
     int64_t diff_stride = 0;    // floats between their diff rows (0: one row, the last iteration's)
     double *dmax_out = nullptr; // per inner iteration (stride slice_stride): max diff, bits of a double
+    const int32_t *wg_order = nullptr;   // NULL, or the residence workgroup each workgroup of the launch takes (verdict == false)
 };
+int64_t agent_homes_per_block(int32_t T, int32_t lanes);     // residences per workgroup of the sweep's launch
 
 // revs_agent_step_select's sweep with the next home pass folded in, plus `sx` (see above).
 int agent_step_stream(int64_t n_homes, int32_t T, const float *cost, const revs_home_t *homes,

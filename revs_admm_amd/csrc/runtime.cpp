@@ -79,7 +79,9 @@ struct revs_plan {
     int32_t overlap = 0;                   // all-reduce + verdicts of a block on `side`, beside the next block's sweeps
     int32_t inner = 1;                     // ADMM iterations per sweep launch (revs_plan_set_stream_inner)
     int32_t fold_redo = 2;                 // Newton steps beyond the first inside the folded chain (revs_plan_set_fold_redo)
-    int32_t kadd_cold = 0, kadd_cold_at = 0;   // revs_plan_set_kadd_cold: rows admitted per Newton iteration while many are violated
+    int32_t kadd_cold = 0, kadd_cold_at = 0;
+    int32_t *wg_order = nullptr;           // the sweep's workgroups, heaviest first (plan_wg_order), device; built on first use
+    bool wg_order_tried = false;   // revs_plan_set_kadd_cold: rows admitted per Newton iteration while many are violated
     double *ring = nullptr;                // device: node sums (+ diff tails) of two blocks, double[2][block][stride]
     size_t ring_cap = 0;                   // ... doubles allocated
     bool ring_dirty = true;                // the ring is not known to be all zero (fresh, or a call failed)
@@ -164,6 +166,7 @@ extern "C" int revs_newton_chain_accept(int32_t T, const double *s0, const doubl
     return chain_accept_impl(T, s0, s1, scale, eps, amax, kadd, chain_few, nsup_sum, nsup_max, &why);
 }
 
+static const int32_t *plan_wg_order(revs_plan_t *plan);
 extern "C" revs_plan_t *revs_plan_create(const revs_plan_desc_t *desc) {
     if (!desc || !desc->stats || !desc->stats_host || !desc->pnq || desc->T <= 0 || desc->m <= 0) {
         revs::set_error("revs_plan_create: bad descriptor");
@@ -208,11 +211,44 @@ extern "C" revs_plan_t *revs_plan_create(const revs_plan_desc_t *desc) {
         revs_plan_destroy(p);
         return nullptr;
     }
+    (void)plan_wg_order(p);       // (here, not inside the first burst: a copy of the residence records to the host and a sort)
     return p;
+}
+
+// The order in which a multi-iteration sweep's launch takes its workgroups of residences: those that hold the most
+// residences with an EV first (a residence without one has no QP to solve: its wavefront runs a third of the
+// instructions).  A launch of 100 000 residences is 3 125 workgroups on a chip that holds 1 280 at a time: its last round
+// cannot fill the chip, and with the heavy workgroups in front that round is made of the quick ones.  Nothing else
+// changes: the same workgroups do the same work (node sums are exact: order-independent).  NULL when the descriptor
+// carries no residence records (then: launch order = residence order).
+static const int32_t *plan_wg_order(revs_plan_t *plan) {
+    if (plan->wg_order_tried) return plan->wg_order;
+    plan->wg_order_tried = true;
+#ifdef REVS_TUNING        // (tuning builds: A/B of the order inside one job)
+    if (getenv("REVS_NO_WG_ORDER")) return nullptr;
+#endif
+    const revs_plan_desc_t &d = plan->d;
+    const int64_t per = revs::agent_homes_per_block(d.T, d.pdhg.lanes);
+    if (!d.homes || d.n_homes <= 0 || per <= 0) return nullptr;
+    const int64_t nb = (d.n_homes + per - 1) / per;
+    if (nb < 2 || nb >= (1ll << 31)) return nullptr;
+    std::vector<revs_home_t> h((size_t)d.n_homes);
+    if (hipMemcpy(h.data(), d.homes, sizeof(revs_home_t) * (size_t)d.n_homes, hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+    std::vector<int32_t> w((size_t)nb, 0), order((size_t)nb);
+    for (int64_t i = 0; i < d.n_homes; ++i) w[(size_t)(i / per)] += h[(size_t)i].ev != 0;
+    for (int64_t b = 0; b < nb; ++b) order[(size_t)b] = (int32_t)b;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return w[(size_t)x] > w[(size_t)y]; });
+    if (hipMalloc((void **)&plan->wg_order, sizeof(int32_t) * (size_t)nb) != hipSuccess) { plan->wg_order = nullptr; return nullptr; }
+    if (hipMemcpy(plan->wg_order, order.data(), sizeof(int32_t) * (size_t)nb, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(plan->wg_order);
+        plan->wg_order = nullptr;
+    }
+    return plan->wg_order;
 }
 
 extern "C" void revs_plan_destroy(revs_plan_t *plan) {
     if (!plan) return;
+    if (plan->wg_order) (void)hipFree(plan->wg_order);
     if (plan->ev) (void)hipEventDestroy(plan->ev);
     if (plan->counters) (void)hipFree(plan->counters);
     if (plan->ctl) (void)hipFree(plan->ctl);
@@ -1566,6 +1602,7 @@ extern "C" int revs_plan_stream_run_blocks(revs_plan_t *plan, int32_t max_steps,
     auto ring_of = [&](int b) { return plan->ring + (ov ? (int64_t)(b & 1) * B * stride : 0); };
     // One launch: iterations k .. k + kin - 1 from set `in` to set `out`; their node sums and diff
     // tails to slices (k - k0) .. of `ring` (replay: one scratch region, no tails).
+    const int32_t *const wg_order = plan_wg_order(plan);
     auto sweep = [&](int k, int kin, int in, int out, double *slice0, bool replay, float *pe_next,
                      bool y_in_place) -> int {
         revs::StreamExtra sx{};
@@ -1580,6 +1617,7 @@ extern "C" int revs_plan_stream_run_blocks(revs_plan_t *plan, int32_t max_steps,
         sx.slice_stride = stride;
         sx.diff_stride = st->diff_hist ? d.n_homes : 0;
         sx.dmax_out = replay ? nullptr : slice0 + mt + (int64_t)rank * REVS_DMAX_SLOTS;
+        sx.wg_order = wg_order;
         return revs::agent_step_stream(
             d.n_homes, d.T, d.cost, d.homes, d.load, st->p_est[in], nullptr, st->p_sch[in], st->gamma[in],
             st->p_sch[out], st->gamma[out],

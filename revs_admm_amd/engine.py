@@ -950,6 +950,16 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
                                  f"({self.pdhg.max_iter}) before its tolerance "
                                  f"({self.pdhg.tol:g}{' = automatic' if self.pdhg.tol == 0 else ''})")
 
+    def _resolve_max_diff(self, pending):
+        """Fetch the device-side maxima collected for iterations outside the streaming loop (one transfer), over every
+        rank's residences when they are sharded (see _max_diff_all_ranks), into self.max_diff; empties `pending`."""
+        mx = torch.stack([v for _, v in pending]).to(torch.float64)
+        if self.group is not None:
+            self._allreduce(mx, torch.distributed.ReduceOp.MAX)
+        for (it, _), v in zip(pending, mx.cpu().tolist()):
+            self.max_diff[it] = float(v)
+        pending.clear()
+
     def _max_diff_all_ranks(self):
         """max_h diff[h] of the iteration just finished over EVERY rank's residences (the streaming
         loop's records are global already: each rank's partial maxima travel with the all-reduce).
@@ -995,7 +1005,7 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
             inv = torch.from_numpy(np.ascontiguousarray(self.inv_perm, dtype=np.int64)).to(self.dev)
         self.converged_at = None
         k, it0, good, seen, stop = 0, self.iteration, 0, self.iteration, False
-        cap = 64
+        cap, pending = 64, []
         while k < iter_max:
             base, r = k, 0
             while r < rows and k < iter_max:
@@ -1021,13 +1031,17 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
                     if k == 0:
                         self.check_status()          # (synchronises once)
                     if eps is not None and self.iteration not in self.max_diff:
-                        self.max_diff[self.iteration] = self._max_diff_all_ranks()
+                        # (max_h diff of an iteration outside the streaming loop: reduced on the device now, fetched with
+                        # the others' when the stopping rule is next evaluated -- no host wait per iteration)
+                        pending.append((self.iteration, self.diff.max() if self.n else torch.zeros((), dtype=torch.float32, device=self.dev)))
                 k += done
                 r += done
                 if stop:
                     break
+                if eps is not None and pending and (done > 1 or len(pending) >= patience or k >= iter_max - 1):
+                    self._resolve_max_diff(pending)
                 if eps is not None:                  # the stretch of iterations at or below eps so far
-                    while seen < it0 + k and not stop:
+                    while seen < it0 + k - len(pending) and not stop:
                         seen += 1
                         good = good + 1 if self.max_diff.get(seen, np.inf) <= eps else 0
                         if good >= patience:
