@@ -450,9 +450,10 @@ int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, revs_chain_fo
  * (default 2; 0: every such iteration is handed back at its step, resume = 2). */
 int revs_plan_set_fold_redo(revs_plan_t *plan, int32_t steps);
 /* revs_plan_newton_solve admits desc.kadd violated rows per slot and Newton iteration -- and kadd_cold of them (0: off)
- * in an evaluation that follows one in which some slot showed more than cold_at violated rows without a multiplier (a
- * cold solve: lpsolver.py:183-194 hands Gurobi every row at once; here two at a time would be as many Newton iterations
- * as half the rows that end up binding). */
+ * in an evaluation that follows one in which some slot showed more than cold_at violated rows without a multiplier AND
+ * at least half of the rows admitted the time before kept a multiplier (a cold solve on a feeder whose rows bind one by
+ * one: lpsolver.py:183-194 hands Gurobi every row at once; here two at a time would be as many Newton iterations as half
+ * the rows that end up binding). */
 int revs_plan_set_kadd_cold(revs_plan_t *plan, int32_t kadd_cold, int32_t cold_at);
 
 /* ---- the operator's Newton solve as ONE native call -----------------------------------------

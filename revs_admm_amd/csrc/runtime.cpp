@@ -638,12 +638,17 @@ extern "C" int revs_plan_newton_solve(revs_plan_t *plan, revs_newton_state_t *st
     // plan->kadd_cold while some slot still shows more than plan->kadd_cold_at violated rows without a multiplier (a cold
     // solve: admitting two at a time makes it as many Newton iterations as half the rows that end up binding).
     // kadd_stt: what the evaluation behind `stt` admitted with (its candidate lists are that long).
+    // ... and only while the rows admitted last time nearly all kept a multiplier (kept >= 0.5: each binds on its own, the
+    // 121144 feeder; on long laterals a handful of multipliers clears hundreds of violated rows and most admitted rows
+    // end without one: there the small lists stay).
     int kadd_stt = d.kadd;
+    double ns_prev = 0.0, adm_prev = 0.0;
+    bool have_prev = false;
     int evals = 1, newton = 0, pivots = 0, stall = 0, n_small = 0, n_general = 0;
     bool ok_all = false, last_small = false, few = false, from_pre = st->have_pre != 0;
     double best = INFINITY;
     for (;;) {
-        double rmax = 0.0, ns_max = 0.0, nc_max = 0.0, nv_max = 0.0;
+        double rmax = 0.0, ns_max = 0.0, nc_max = 0.0, nv_max = 0.0, ns_sum = 0.0, adm_now = 0.0;
         bool over = false, full = false;
         for (int t = 0; t < T; ++t) {
             const double *a = &stt[8 * t];
@@ -655,8 +660,12 @@ extern "C" int revs_plan_newton_solve(revs_plan_t *plan, revs_newton_state_t *st
             ns_max = std::max(ns_max, a[2]);
             nc_max = std::max(nc_max, a[2] + std::min(a[3], std::min((double)kadd_stt, A - a[2])));
             nv_max = std::max(nv_max, a[3]);
+            ns_sum += a[2];
+            adm_now += std::min(a[3], std::min((double)kadd_stt, A - a[2]));
         }
-        const int kadd_next = (plan->kadd_cold > d.kadd && nv_max > plan->kadd_cold_at) ? plan->kadd_cold : d.kadd;
+        const double kept = have_prev ? (ns_sum - ns_prev) / std::max(adm_prev, 1.0) : 0.0;
+        const int kadd_next = (plan->kadd_cold > d.kadd && nv_max > plan->kadd_cold_at && kept >= 0.5) ? plan->kadd_cold : d.kadd;
+        ns_prev = ns_sum; adm_prev = adm_now; have_prev = true;
         if (over) break;
         if (rmax <= d.eps) { ok_all = true; break; }
         if (newton >= o.newton_max || full) break;

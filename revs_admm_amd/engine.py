@@ -101,13 +101,17 @@ class OperatorOptions:
     # themselves to the ADMM forms, 300 ms; 4 and more lengthen the chained iteration's slowest slot.)
     newton_kadd: int = 2
     # ... but newton_kadd_cold of them in an evaluation that follows one in which some slot showed more than
-    # newton_kadd_cold_at violated rows without a multiplier (round 5): a cold solve -- the first ADMM iterations of the
+    # newton_kadd_cold_at violated rows without a multiplier and at least half of the rows admitted the time before kept
+    # one (round 5; on the synthetic feeders' long laterals three multipliers clear a thousand violated rows and the
+    # small lists stay -- tools/newton_trace.py): a cold solve -- the first ADMM iterations of the
     # 121144 feeder end with 50-69 binding rows in a slot -- took as many Newton iterations as half of those rows
     # (19 and 17 in iterations 2 and 3, of 78 in all 15); the warm solves keep their small models.  0: off.
     # Measured on that feeder (tests/tools/feeder_iters.py --kadd-cold, 15 iterations): off 11.1 ms / 98 evaluations;
     # 4 above 2: 10.0; 8 above 4: 10.1; 12 above 6: 9.9; 16 above 6: 9.7 / 78 evaluations; 32 above 8: 10.5.
     newton_kadd_cold: int = 16
     newton_kadd_cold_at: int = 6
+    newton_trace: bool = False   # Python Newton loop only (native_newton=False): per evaluation (ADMM iteration, Newton iteration,
+                                 # violated rows without a multiplier: sum / max over slots, rows with one: sum / max, kadd) in .newton_trace
     chain: bool = True           # binding steady state: one Newton iteration enqueued unread
     # ... and folded (one GPU, feeder as a tree): the sweep forms the operator's answer for the trial
     # itself and folds both evaluations' node sums into its own pass -- one pass over the residences
@@ -1011,18 +1015,11 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
             while r < rows and k < iter_max:
                 last = k == iter_max - 1 or stop
                 if (not last and self._stream_ok() and self._fused_ready):
-                    # (with eps: bursts sized by where the records say max diff will cross eps -- its decay is close to
-                    # geometric -- so that the run ends soon after the stretch without paying a burst's fixed cost, the
-                    # exposed last verdict launch and the host's turn, every 64 iterations)
+                    # (with eps: bursts of at most 64, so that the run ends soon after the stretch.  max_h diff is no
+                    # geometric decay one could size the bursts by: on the bench workload it sits on a plateau of ~6e-4 from
+                    # iteration 100 to 480 and falls to 7e-5 within ten iterations -- tools/newton_trace.py)
                     done = self._stream_run(min(rows - r, iter_max - 1 - k, cap if eps is not None else rows),
                                             hist[r:] if history else None)
-                    if eps is not None and done >= 8:
-                        d0, d1 = self.max_diff.get(self.iteration - done + 1), self.max_diff.get(self.iteration)
-                        if d0 and d1 and eps < d1 < d0:
-                            left = math.log(d1 / eps) * (done - 1) / math.log(d0 / d1)
-                            cap = int(min(512, max(32, 0.85 * left)))
-                        else:
-                            cap = 32
                 else:
                     self.step(write_sc=last)
                     if history:

@@ -126,10 +126,16 @@ class DualNewtonMixin:
                if first is None else first)
         evals, newton, pivots, ok_all = 1, 0, 0, False
         kadd_stt = o.newton_kadd         # what the evaluation behind `stt` admitted with (revs_plan_set_kadd_cold's rule)
+        ns_prev, adm_prev = None, 0.0
         best, stall = np.inf, 0
         last_small = False
         from_pre = pre is not None       # P_est_new is what `pre` (== `first` if nothing moved) wrote
         while True:
+            if o.newton_trace:
+                if not hasattr(self, "newton_trace"):
+                    self.newton_trace = []
+                self.newton_trace.append((self.iteration, newton, int(stt[:, 3].sum()), int(stt[:, 3].max()), int(stt[:, 2].sum()),
+                                          int(stt[:, 2].max()), int(kadd_stt), float((stt[:, 0] / scale).max())))
             if (stt[:, 2] > A).any():
                 break                                    # more multipliers than a model holds
             rmax = stt[:, 0] / scale
@@ -156,8 +162,15 @@ class DualNewtonMixin:
             self.model_calls[0 if ncand.max() <= 8 else 1] += 1
             last_small = bool(ncand.max() <= 8)
             few = stt[:, 2].max() + kadd_stt <= 48
-            kadd_next = (o.newton_kadd_cold if (o.newton_kadd_cold > o.newton_kadd and stt[:, 3].max() > o.newton_kadd_cold_at)
-                         else o.newton_kadd)
+            # rows to admit next (revs_plan_set_kadd_cold's rule): many, while the rows admitted last time nearly all kept a
+            # multiplier (each binds on its own: the 121144 feeder) and a slot still shows many violated ones; few, while a
+            # handful of multipliers clears hundreds of violated rows at once (long laterals: the synthetic feeders)
+            ns_sum = float(stt[:, 2].sum())
+            adm_now = float(np.minimum(stt[:, 3], np.minimum(kadd_stt, A - stt[:, 2])).sum())
+            kept = (ns_sum - ns_prev) / max(adm_prev, 1.0) if ns_prev is not None else 0.0
+            kadd_next = (o.newton_kadd_cold if (o.newton_kadd_cold > o.newton_kadd and stt[:, 3].max() > o.newton_kadd_cold_at
+                                                and kept >= 0.5) else o.newton_kadd)
+            ns_prev, adm_prev = ns_sum, adm_now
             # (the chain guessed how its trial's home pass gets d = R^T y / kappa -- row-wise or
             # dense; another choice here would differ in the last bits: then redo the trial)
             use_pre = (pre is not None and newton == 1 and last_small
