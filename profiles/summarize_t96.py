@@ -36,6 +36,6 @@ out = {"homes": homes, "T": T, "mode": "pdhg", "iterations_per_launch": inner, "
        "sq_counters_per_launch": {c: get("sq", c) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVES", "SQ_ACTIVE_INST_VALU",
                                                             "SQ_WAVE_CYCLES", "SQ_WAIT_ANY")},
        "source": f"profiles/{tag}_t96{sfx}_pmc_summary.csv (rocprofv3 --pmc, separate passes of `tools/regime_run.py --regime steady "
-                 f"--homes {homes} --T 96 --steps 128 --spin 48`; FETCH_SIZE x2 and KiB per MI355X_MICROARCH.md)"}
+                 f"--homes {homes} --T 96 --steps {128 if homes == 125_000 else 64} --spin 48`; FETCH_SIZE x2 and KiB per MI355X_MICROARCH.md)"}
 json.dump(out, open(os.path.join(ROOT, "profiles", f"t96{sfx}_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -369,8 +369,8 @@ void agent_step_kernel(const AgentArgs a) {
         if (a.p_next) {
             for (int i = tid; i < kin * kNodeLoc * kSlots; i += kBlock) (&nacc[0][0][0])[i] = 0.0;
             if (tid < kAcc) dmx[tid] = 0u;
-            if (tid == 0) arrived = 0u;
         }
+        if (tid == 0) arrived = 0u;
         base = a.node_of[first < a.n ? first : a.n - 1];
         if constexpr (CHAIN) {
             for (int i = tid; i < 2 * 3 * kNodeLoc * kSlots; i += kBlock) (&facc[0][0][0][0])[i] = 0.0;
@@ -1007,10 +1007,8 @@ void agent_step_kernel(const AgentArgs a) {
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if constexpr (CHAIN) {
+#ifdef REVS_CHAIN_BARRIER_FLUSH       // (tuning builds: the form of rounds 3-4, every thread flushes behind a workgroup barrier)
         __syncthreads();
-        // (fold_a / fold_b are slot-major, [T][m][4] = {p, N, q, 0}: a slot's block is contiguous for the operator launch's
-        // coalesced read, and this workgroup's kNodeLoc nodes x 3 quantities of a slot are 12 consecutive threads on one
-        // or two cache lines)
         for (int i = tid; i < 2 * T * kNodeLoc * 3; i += kBlock) {
             const int f = i / (T * kNodeLoc * 3), r0 = i - f * (T * kNodeLoc * 3);
             const int tl = r0 / 3, q = r0 - tl * 3;
@@ -1020,6 +1018,30 @@ void agent_step_kernel(const AgentArgs a) {
                 unsafeAtomicAdd((f ? a.fold_b : a.fold_a) + 4 * ((int64_t)t * a.sh_m + base + l) + q,
                                 q == 2 ? -0.5 * a.sh_kappa * v : v);
         }
+#else
+        // as the multi-iteration sweep above: no barrier, the last wavefront of the workgroup to arrive flushes for all
+        // (fold_a / fold_b are slot-major, [T][m][4] = {p, N, q, 0}: a slot's block is contiguous for the operator launch's
+        // coalesced read; this workgroup's kNodeLoc nodes x 3 quantities of a slot sit on one or two cache lines)
+        unsigned int before = 0u;
+        if ((tid & 63) == 0) before = atomicAdd(&arrived, 1u);
+        before = (unsigned int)__builtin_amdgcn_readfirstlane((int)before);
+        if (before != kBlock / 64 - 1) return;
+        const int ln = tid & 63;
+        // lane -> (node l, quantity q) of a slot: kNodeLoc * 3 <= 12 lanes per slot, 64 / 12 = 5 slots per trip
+        constexpr int kPerSlot = kNodeLoc * 3, kSlotsPerTrip = 64 / kPerSlot;
+        const int sl = ln / kPerSlot, lq = ln - sl * kPerSlot, l = lq / 3, q = lq - 3 * l;
+        if (sl < kSlotsPerTrip && base + l < a.sh_m) {
+            for (int t = sl; t < T; t += kSlotsPerTrip) {
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    const double v = facc[f][q][l][t];
+                    if (v != 0.0)
+                        unsafeAtomicAdd((f ? a.fold_b : a.fold_a) + 4 * ((int64_t)t * a.sh_m + base + l) + q,
+                                        q == 2 ? -0.5 * a.sh_kappa * v : v);
+                }
+            }
+        }
+#endif
     }
 }
 
@@ -1297,6 +1319,7 @@ static int agent_step_impl(int64_t n_homes, int32_t T, const float *cost,
         a.sh_a = cf->sh_a; a.sh_b = cf->sh_b; a.sh_m = cf->m; a.sh_kappa = cf->kappa;
         a.fold_a = cf->fold_a; a.fold_b = cf->fold_b; a.pe_out = cf->pe_out;
         if (cf->y_out) a.y_out = cf->y_out;
+        a.wg_order = cf->wg_order;
     }
     if (sx && !sx->verdict) {         // judged by blocks (stream_block_verdict): silencing only
         REVS_REQUIRE(!sel, "revs_agent_step: bad streaming argument");      // (ctl == NULL: never silenced)

@@ -49,6 +49,7 @@ struct ChainFold {
     double *fold_a, *fold_b;
     float *pe_out;
     float *y_out = nullptr;     // the carried PDHG multipliers after this sweep (NULL: in place)
+    const int32_t *wg_order = nullptr;   // as StreamExtra::wg_order
 };
 int agent_step_chain(int64_t n_homes, int32_t T, const float *cost, const revs_home_t *homes,
                      const float *load, const float *p_est, const float *p_sch, const float *gamma,

@@ -905,6 +905,7 @@ extern "C" int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, re
         revs::ChainFold cf{plan->fold_sh[0], plan->fold_sh[1], d.m, d.kappa, plan->fold_e2[parity],
                            plan->fold_e1[parity ^ 1], pe_out};
         cf.y_out = ybuf ? y_out : nullptr;
+        cf.wg_order = plan_wg_order(plan);
         int r = revs::agent_step_chain(d.n_homes, d.T, d.cost, d.homes, d.load, pe, ps, gm, ps_out, gm_out, s_out, c_out, d.diff,
                                        d.dsq, d.status, ybuf ? y_in : d.pdhg_dual, (float)d.kappa, d.mode, &d.pdhg, d.node_of, cf,
                                        plan->flags_dev ? plan->flags_dev + 1 + sweep_no % 3u : nullptr, stream);
