@@ -451,7 +451,8 @@ int revs_plan_chain_fold_run(revs_plan_t *plan, int32_t max_steps, revs_chain_fo
 int revs_plan_set_fold_redo(revs_plan_t *plan, int32_t steps);
 /* revs_plan_newton_solve admits desc.kadd violated rows per slot and Newton iteration -- and kadd_cold of them (0: off)
  * in an evaluation that follows one in which some slot showed more than cold_at violated rows without a multiplier AND
- * at least half of the rows admitted the time before kept a multiplier (a cold solve on a feeder whose rows bind one by
+ * either at least half of the rows admitted the time before kept a multiplier or some slot carries 16 multipliers already
+ * (a cold solve on a feeder whose rows bind one by
  * one: lpsolver.py:183-194 hands Gurobi every row at once; here two at a time would be as many Newton iterations as half
  * the rows that end up binding). */
 int revs_plan_set_kadd_cold(revs_plan_t *plan, int32_t kadd_cold, int32_t cold_at);
@@ -501,6 +502,10 @@ typedef struct {
      * caller saw them (0: not checked).  A block that no longer carries its tag -- a launch wrote it since -- is
      * REVS_EINVAL, not a solve from other numbers. */
     double first_tag, pre_tag;
+    /* out: the solve stopped because a slot holds more rows than a model of REVS_DUAL_AMAX (128) takes -- more multipliers
+     * than that, or a full model with rows still violated.  y is NOT cleared then (ok = 0): the caller goes on from it on
+     * lists of up to REVS_DUAL_AMAX_BIG rows (include/revs_admm_ops.h: revs_op_dual_*_big). */
+    int32_t big_needed, reserved_;
 } revs_newton_state_t;
 int revs_plan_newton_solve(revs_plan_t *plan, revs_newton_state_t *st, void *stream);
 

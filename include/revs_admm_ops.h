@@ -377,6 +377,30 @@ int revs_newton_chain_accept(int32_t T, const double *s0, const double *s1, doub
                              int32_t amax, int32_t kadd, int32_t chain_few, int32_t *nsup_sum,
                              int32_t *nsup_max);
 
+/* ---- the model problem beyond REVS_DUAL_AMAX rows per slot (csrc/newton_big.hip) ------------------------------
+ * The dual Newton path above holds REVS_DUAL_AMAX = 128 candidate rows per slot (its factor lives in LDS).  The reference
+ * hands Gurobi every row (lpsolver.py:183-194); a slot with 129 ... REVS_DUAL_AMAX_BIG binding rows stays on the Newton
+ * path through these three launches -- lists, Gram slabs, Hessian and factor in global memory (cand_idx
+ * int64[T][BIG], cand_cnt int32[T] (-1: more rows with a multiplier than BIG), cand_val double[T][3][BIG] = sign |
+ * gradient | current multiplier, k_slabs double[T][nks][BIG][BIG], k_full / l_factor double[T][BIG][BIG] each,
+ * yhat double[T][BIG], info int32[T]: pivoting rounds, negative when the limit was hit, -998 for a slot flagged -1):
+ *   revs_op_dual_select_big  the rows with y != 0 in row order + the `kadd` most violated rows without one (ties to the
+ *                            lower row), from the multipliers and the row arrays vfull / viol ([m][T]) an evaluation by
+ *                            the dense path (revs_op_dual_evaluate) left
+ *   revs_op_dual_model_big   K_t = R_F N_t R_F^T / kappa and the LCP u >= 0, K'u - c >= 0, u.(K'u - c) = 0 by block
+ *                            principal pivoting (same regularisation, tolerances and rule as revs_op_dual_model)
+ *   revs_op_dual_step_big    y_trial = y, then y + alpha[t] (yhat - y) on slot t's listed rows; lin_out[8 t] = gradient . step */
+#define REVS_DUAL_AMAX_BIG 512
+int revs_op_dual_select_big(int32_t m, int32_t T, const double *y, const double *vfull, const double *viol, double vlo,
+                            double vhi, int32_t kadd, int64_t *cand_idx, int32_t *cand_cnt, double *cand_val, void *stream);
+int revs_op_dual_model_big(int32_t m, int32_t T, const double *R, const double *n_free, const int64_t *cand_idx,
+                           const int32_t *cand_cnt, const double *cand_val, double kappa, double delta, int32_t max_pivots,
+                           int32_t nks, double *k_slabs, double *k_full, double *l_factor, double *yhat, int32_t *info,
+                           void *stream);
+int revs_op_dual_step_big(int32_t T, const int64_t *cand_idx, const int32_t *cand_cnt, const double *cand_val,
+                          const double *yhat, const double *alpha, const double *y, int32_t m, double *y_trial,
+                          double *lin_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

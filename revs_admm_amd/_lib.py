@@ -91,7 +91,8 @@ class NewtonState(C.Structure):
                 ("ok", C.c_int32), ("newton", C.c_int32), ("evals", C.c_int32), ("pivots", C.c_int32),
                 ("models_small", C.c_int32), ("models_general", C.c_int32), ("last_small", C.c_int32),
                 ("few", C.c_int32), ("pre_kept", C.c_int32), ("cur", C.c_int32), ("nsup_sum", C.c_int32),
-                ("nsup_max", C.c_int32), ("first_tag", C.c_double), ("pre_tag", C.c_double)]
+                ("nsup_max", C.c_int32), ("first_tag", C.c_double), ("pre_tag", C.c_double),
+                ("big_needed", C.c_int32), ("_pad", C.c_int32)]
 
 
 class Tree(C.Structure):
@@ -204,6 +205,9 @@ SIGNATURES = {
     "revs_op_dual_model_small": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p, _f64, _f64, _i32, _p, _p,
                                            _p, _p]),
     "revs_op_dual_step": (C.c_int, [_i32, _p, _p, _p, _p, _p, _p, _p, _p]),
+    "revs_op_dual_select_big": (C.c_int, [_i32, _i32, _p, _p, _p, _f64, _f64, _i32, _p, _p, _p, _p]),
+    "revs_op_dual_model_big": (C.c_int, [_i32, _i32, _p, _p, _p, _p, _p, _f64, _f64, _i32, _i32, _p, _p, _p, _p, _p, _p]),
+    "revs_op_dual_step_big": (C.c_int, [_i32, _p, _p, _p, _p, _p, _p, _i32, _p, _p, _p]),
     "revs_op_dual_select_model_step": (C.c_int, [_i32, _i32, _p, _i32, _p, _f64, _f64, _i32, _p, _p, _p,
                                                 _p, _p, _p, _f64, _p, _p, _f64, _f64, _i32, _p, _p, _p,
                                                 _f64, _f64, _p, _p, _p]),
@@ -241,6 +245,7 @@ SIGNATURES = {
     "revs_op_dual_step_pending": (C.c_int, [_i32, _p, _p, _p, _p, _p, _f64, _f64, _p, _i32, _p, _p, _p]),
 }
 DUAL_AMAX = 128          # REVS_DUAL_AMAX
+DUAL_AMAX_BIG = 512      # REVS_DUAL_AMAX_BIG
 
 _lib = None
 

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librevs_admm.so")
-SOURCES = ["runtime.cpp", "agent_kernels.hip", "operator_kernels.hip", "newton_kernels.hip",
+SOURCES = ["runtime.cpp", "agent_kernels.hip", "operator_kernels.hip", "newton_kernels.hip", "newton_big.hip",
            "gemm_kernels.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "tuning.h"), os.path.join(CSRC, "select_body.h"),
            os.path.join(CSRC, "tree_body.h"), os.path.join(CSRC, "internal.h"),

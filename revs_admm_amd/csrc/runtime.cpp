@@ -638,14 +638,14 @@ extern "C" int revs_plan_newton_solve(revs_plan_t *plan, revs_newton_state_t *st
     // plan->kadd_cold while some slot still shows more than plan->kadd_cold_at violated rows without a multiplier (a cold
     // solve: admitting two at a time makes it as many Newton iterations as half the rows that end up binding).
     // kadd_stt: what the evaluation behind `stt` admitted with (its candidate lists are that long).
-    // ... and only while the rows admitted last time nearly all kept a multiplier (kept >= 0.5: each binds on its own, the
-    // 121144 feeder; on long laterals a handful of multipliers clears hundreds of violated rows and most admitted rows
-    // end without one: there the small lists stay).
+    // ... and only while the rows admitted last time nearly all kept a multiplier (kept >= 0.5) or some slot already carries
+    // 16 of them: rows that bind one by one, the 121144 feeder; on long laterals a handful of multipliers clears hundreds of
+    // violated rows, most admitted rows end without one and a slot ends with 3-4 multipliers: there the small lists stay.
     int kadd_stt = d.kadd;
     double ns_prev = 0.0, adm_prev = 0.0;
     bool have_prev = false;
     int evals = 1, newton = 0, pivots = 0, stall = 0, n_small = 0, n_general = 0;
-    bool ok_all = false, last_small = false, few = false, from_pre = st->have_pre != 0;
+    bool ok_all = false, last_small = false, few = false, from_pre = st->have_pre != 0, big_needed = false;
     double best = INFINITY;
     for (;;) {
         double rmax = 0.0, ns_max = 0.0, nc_max = 0.0, nv_max = 0.0, ns_sum = 0.0, adm_now = 0.0;
@@ -664,7 +664,8 @@ extern "C" int revs_plan_newton_solve(revs_plan_t *plan, revs_newton_state_t *st
             adm_now += std::min(a[3], std::min((double)kadd_stt, A - a[2]));
         }
         const double kept = have_prev ? (ns_sum - ns_prev) / std::max(adm_prev, 1.0) : 0.0;
-        const int kadd_next = (plan->kadd_cold > d.kadd && nv_max > plan->kadd_cold_at && kept >= 0.5) ? plan->kadd_cold : d.kadd;
+        if (over || full) big_needed = true;
+        const int kadd_next = (plan->kadd_cold > d.kadd && nv_max > plan->kadd_cold_at && (kept >= 0.5 || ns_max >= 16.0)) ? plan->kadd_cold : d.kadd;
         ns_prev = ns_sum; adm_prev = adm_now; have_prev = true;
         if (over) break;
         if (rmax <= d.eps) { ok_all = true; break; }
@@ -746,7 +747,9 @@ extern "C" int revs_plan_newton_solve(revs_plan_t *plan, revs_newton_state_t *st
     for (int t = 0; t < T; ++t) { sum += stt[8 * t + 2]; mx = std::max(mx, stt[8 * t + 2]); }
     st->nsup_sum = (int32_t)sum;
     st->nsup_max = (int32_t)mx;
-    if (!ok_all && hipMemsetAsync(ycur, 0, sizeof(double) * mt, s) != hipSuccess) {
+    st->big_needed = big_needed ? 1 : 0;
+    st->reserved_ = 0;
+    if (!ok_all && !big_needed && hipMemsetAsync(ycur, 0, sizeof(double) * mt, s) != hipSuccess) {
         revs::set_error("revs_plan_newton_solve: clearing the multipliers failed");
         return REVS_ELAUNCH;
     }

@@ -14,7 +14,7 @@ from ._lib import check, ptr
 
 
 class DualNewtonMixin:
-    def _dual_phase(self, phase: int, y, use_y: bool, k: int, kadd=None):
+    def _dual_phase(self, phase: int, y, use_y: bool, k: int, kadd=None, dense=False):
         lib, M, T = self.lib, self.M, self.T
         kadd = self.op.newton_kadd if kadd is None else int(kadd)
         # an evaluation that ends with its own selection tags the stats block (pinned host
@@ -26,7 +26,7 @@ class DualNewtonMixin:
         if (phase & 2) and not (phase & 4):
             self._eval_seq += 1.0
             tag = self._pending_tag[k] = self._eval_seq + 0.5
-        if self._tree_eval and self._tree is not None:
+        if self._tree_eval and self._tree is not None and not dense:
             # the feeder as a tree: R p and the rows of every slot in O(nodes), one workgroup per slot
             check(lib.revs_op_dual_evaluate_tree(
                 phase, M, T, ptr(self.node_ptr), ptr(self.P_est), ptr(self.P_sch), ptr(self.G),
@@ -52,7 +52,7 @@ class DualNewtonMixin:
             ptr(self.R64), ptr(self.c_idx[sup]), ptr(self.c_cnt[sup]), ptr(y), self.kappa,
             ptr(self.pnq), ptr(self.P_est_new), self.stream), "revs_op_dual_eval_rows")
 
-    def _dual_launch(self, y, use_y: bool, k: int, full: bool = True, sup=None, record=True, kadd=None):
+    def _dual_launch(self, y, use_y: bool, k: int, full: bool = True, sup=None, record=True, kadd=None, dense=False):
         """Enqueue one evaluation: p, N, D and the voltage rows for the multipliers y;
         candidate lists and stats into buffer set k, stats on their way to pinned host
         memory.  Also writes P_est_new = max(g0 - R^T y / kappa, 0).  Does not wait.
@@ -65,13 +65,13 @@ class DualNewtonMixin:
             self._dual_home_pass_rows(y, sup)
             if self.group is not None:
                 self._allreduce(self.pnq if full else self.pnq[0])
-            self._dual_phase(2, y, use_y, k, kadd)
+            self._dual_phase(2, y, use_y, k, kadd, dense)
         elif self.group is None:
-            self._dual_phase(3, y, use_y, k, kadd)
+            self._dual_phase(3, y, use_y, k, kadd, dense)
         else:
-            self._dual_phase(1, y, use_y, k, kadd)
+            self._dual_phase(1, y, use_y, k, kadd, dense)
             self._allreduce(self.pnq if full else self.pnq[0])   # the only exchange
-            self._dual_phase(2, y, use_y, k, kadd)
+            self._dual_phase(2, y, use_y, k, kadd, dense)
 
     def _dual_complete(self, y, use_y: bool, k: int):
         """After a full=False evaluation that did not settle the solve: exchange N and the
@@ -99,8 +99,8 @@ class DualNewtonMixin:
             self._pending_tag[k] = None
         return self.stats_host[k].numpy().copy()
 
-    def _dual_evaluate(self, y, use_y: bool, k: int, sup=None, kadd=None):
-        self._dual_launch(y, use_y, k, sup=sup, kadd=kadd)
+    def _dual_evaluate(self, y, use_y: bool, k: int, sup=None, kadd=None, dense=False):
+        self._dual_launch(y, use_y, k, sup=sup, kadd=kadd, dense=dense)
         return self._dual_wait(k)
 
     def _operator_solve_newton(self, first=None, pre=None):
@@ -127,6 +127,7 @@ class DualNewtonMixin:
         evals, newton, pivots, ok_all = 1, 0, 0, False
         kadd_stt = o.newton_kadd         # what the evaluation behind `stt` admitted with (revs_plan_set_kadd_cold's rule)
         ns_prev, adm_prev = None, 0.0
+        big = False                      # a slot needs more rows than a model of 128 takes: the lists of up to 512 go on
         best, stall = np.inf, 0
         last_small = False
         from_pre = pre is not None       # P_est_new is what `pre` (== `first` if nothing moved) wrote
@@ -137,7 +138,8 @@ class DualNewtonMixin:
                 self.newton_trace.append((self.iteration, newton, int(stt[:, 3].sum()), int(stt[:, 3].max()), int(stt[:, 2].sum()),
                                           int(stt[:, 2].max()), int(kadd_stt), float((stt[:, 0] / scale).max())))
             if (stt[:, 2] > A).any():
-                break                                    # more multipliers than a model holds
+                big = True                               # more multipliers than a model of 128 rows holds
+                break
             rmax = stt[:, 0] / scale
             if rmax.max() <= o.eps:
                 ok_all = True
@@ -147,6 +149,7 @@ class DualNewtonMixin:
             # a slot whose model is full of multipliers while rows are still violated cannot
             # take them in; and a solve that stopped improving is not worth more iterations
             if ((stt[:, 2] >= A) & (stt[:, 3] > 0) & (rmax > o.eps)).any():
+                big = True
                 break
             if rmax.max() < 0.5 * best:
                 best, stall = rmax.max(), 0
@@ -162,14 +165,15 @@ class DualNewtonMixin:
             self.model_calls[0 if ncand.max() <= 8 else 1] += 1
             last_small = bool(ncand.max() <= 8)
             few = stt[:, 2].max() + kadd_stt <= 48
-            # rows to admit next (revs_plan_set_kadd_cold's rule): many, while the rows admitted last time nearly all kept a
-            # multiplier (each binds on its own: the 121144 feeder) and a slot still shows many violated ones; few, while a
-            # handful of multipliers clears hundreds of violated rows at once (long laterals: the synthetic feeders)
+            # rows to admit next (revs_plan_set_kadd_cold's rule): many, while a slot still shows many violated ones and either
+            # the rows admitted last time nearly all kept a multiplier or some slot already carries 16 of them (rows that bind
+            # one by one: the 121144 feeder); few, while a handful of multipliers clears hundreds of violated rows at once
+            # (long laterals: the synthetic feeders, whose slots end with 3-4 multipliers)
             ns_sum = float(stt[:, 2].sum())
             adm_now = float(np.minimum(stt[:, 3], np.minimum(kadd_stt, A - stt[:, 2])).sum())
             kept = (ns_sum - ns_prev) / max(adm_prev, 1.0) if ns_prev is not None else 0.0
             kadd_next = (o.newton_kadd_cold if (o.newton_kadd_cold > o.newton_kadd and stt[:, 3].max() > o.newton_kadd_cold_at
-                                                and kept >= 0.5) else o.newton_kadd)
+                                                and (kept >= 0.5 or stt[:, 2].max() >= 16)) else o.newton_kadd)
             ns_prev, adm_prev = ns_sum, adm_now
             # (the chain guessed how its trial's home pass gets d = R^T y / kappa -- row-wise or
             # dense; another choice here would differ in the last bits: then redo the trial)
@@ -222,6 +226,8 @@ class DualNewtonMixin:
             ycur, ytrial = ytrial, ycur
             cur, stt, kadd_stt = nxt, stn, kadd_stn
         self.yd = [ycur, ytrial]
+        if big:
+            return self._operator_solve_newton_big(newton, evals, pivots)
         self.newton_hist.append((newton, evals, pivots))
         self._pre_kept = bool(ok_all and from_pre and newton <= 1)
         # a solve of exactly one Newton iteration on the small model tends to repeat: the next
@@ -249,6 +255,96 @@ class DualNewtonMixin:
         self.op_converged = True
         return True
 
+    def _ensure_big(self):
+        """Buffers of the model problem beyond 128 rows per slot (csrc/newton_big.hip), on first use: lists, Gram slabs,
+        Hessian and factor of up to REVS_DUAL_AMAX_BIG = 512 rows per slot in global memory (T = 24: ~300 MB)."""
+        if getattr(self, "_big", None) is None:
+            A2, T, dev = _lib.DUAL_AMAX_BIG, self.T, self.dev
+            f64 = dict(dtype=torch.float64, device=dev)
+            nks = int(min(4, max(1, self.M // 256)))
+            self._big = dict(ci=torch.zeros(T, A2, dtype=torch.int64, device=dev), cc=torch.zeros(T, dtype=torch.int32, device=dev),
+                             cv=torch.zeros(T, 3, A2, **f64), nks=nks, ks=torch.zeros(T, nks, A2, A2, **f64),
+                             kf=torch.zeros(T, A2, A2, **f64), lf=torch.zeros(T, A2, A2, **f64), yh=torch.zeros(T, A2, **f64))
+        return self._big
+
+    def _operator_solve_newton_big(self, newton0=0, evals0=0, pivots0=0):
+        """The Newton loop above on candidate lists of up to REVS_DUAL_AMAX_BIG = 512 rows per slot: where it goes on when a
+        slot carries more multipliers than a model of 128 rows holds, or fills one with rows still violated (the
+        reference hands Gurobi every row, lpsolver.py:183-194; the 121144 feeder needs 50-69, a feeder run closer to its
+        limit more).  Same iteration -- lists, model maximised over the sign constraints by block principal pivoting,
+        Armijo per slot, the same stopping test -- on kernels whose lists, Hessian and factor live in global memory
+        (slow by construction: one workgroup per slot).  Evaluations go through the dense path (R p on the matrix cores:
+        the row arrays the selection reads are then in memory).  False: more than 512 rows, no ascent, or no progress --
+        the ADMM forms take the iteration, as before."""
+        o, lib, M, T, st = self.op, self.lib, self.M, self.T, self.stream
+        A2 = _lib.DUAL_AMAX_BIG
+        scale = max(abs(self.vlo), abs(self.vhi), 1e-300)
+        b = self._ensure_big()
+        self._fold_resume = False
+        self.big_solves = getattr(self, "big_solves", 0) + 1
+        ycur, ytrial = self.yd
+        stt = self._dual_evaluate(ycur, True, 0, dense=True)
+        evals, newton, pivots, ok_all = evals0 + 1, newton0, pivots0, False
+        best, stall, steps = np.inf, 0, 0
+        while True:
+            if (stt[:, 2] > A2).any():
+                break
+            rmax = stt[:, 0] / scale
+            if rmax.max() <= o.eps:
+                ok_all = True
+                break
+            if steps >= 4 * o.newton_max or ((stt[:, 2] >= A2) & (stt[:, 3] > 0) & (rmax > o.eps)).any():
+                break
+            if rmax.max() < 0.5 * best:
+                best, stall = rmax.max(), 0
+            else:
+                stall += 1
+                if stall >= 10:
+                    break
+            newton += 1
+            steps += 1
+            kadd = max(o.newton_kadd, o.newton_kadd_cold) if stt[:, 3].max() > o.newton_kadd_cold_at else o.newton_kadd
+            check(lib.revs_op_dual_select_big(M, T, ptr(ycur), ptr(self.vfull), ptr(self.violw), self.vlo, self.vhi, int(kadd),
+                                              ptr(b["ci"]), ptr(b["cc"]), ptr(b["cv"]), st), "revs_op_dual_select_big")
+            check(lib.revs_op_dual_model_big(M, T, ptr(self.R64), ptr(self.pnq[1]), ptr(b["ci"]), ptr(b["cc"]), ptr(b["cv"]),
+                                             self.kappa, o.newton_delta, o.newton_pivots, b["nks"], ptr(b["ks"]), ptr(b["kf"]),
+                                             ptr(b["lf"]), ptr(b["yh"]), self.info_dev, st), "revs_op_dual_model_big")
+            D = stt[:, 1]
+            pending = rmax > o.eps
+            alpha = pending.astype(np.float64)
+            for ls in range(o.newton_ls):
+                self.alpha_h.numpy()[:] = alpha
+                check(lib.revs_op_dual_step_big(T, ptr(b["ci"]), ptr(b["cc"]), ptr(b["cv"]), ptr(b["yh"]), self.alpha_dev,
+                                                ptr(ycur), M, ptr(ytrial), self.stats_dev[1] + 32, st), "revs_op_dual_step_big")
+                stn = self._dual_evaluate(ytrial, True, 1, dense=True)
+                evals += 1
+                okk = stn[:, 1] >= D + 1e-4 * stn[:, 4] - 1e-11 * np.abs(D)
+                pending &= ~okk
+                if not pending.any():
+                    break
+                alpha[pending] *= 0.5
+            pivots += int(np.abs(self.info_h.numpy()).sum())
+            if pending.any():
+                break
+            # (the accepted trial's evaluation sits in stats block 1 and its row arrays in vfull / viol: the next lists are
+            # built from them; the multipliers swap roles)
+            ycur, ytrial = ytrial, ycur
+            stt = stn
+        self.yd = [ycur, ytrial]
+        self.newton_hist.append((newton, evals, pivots))
+        self._pre_kept = self._chain_ok = self._chain_few = self._spec_ok = False
+        if not ok_all:
+            ycur.zero_()
+            self._y_support = False
+            self._sup = None
+            return False
+        self._y_support = bool(stt[:, 2].sum() > 0)
+        self._sup = None
+        self.op_iters_hist.append(evals)
+        self.op_path_hist.append("dual")
+        self.op_converged = True
+        return True
+
     def _operator_solve_newton_native(self, first, pre):
         """_operator_solve_newton's loop inside the library (revs_plan_newton_solve): same iterates and the
         same bookkeeping, one native call per operator solve.  `first` / `pre`: the caller's copies of stats blocks
@@ -269,6 +365,8 @@ class DualNewtonMixin:
         self.yd = [ys[0], ys[1]] if st.y == ys[0].data_ptr() else [ys[1], ys[0]]
         self.model_calls[0] += st.models_small
         self.model_calls[1] += st.models_general
+        if st.big_needed:                        # (y is where the loop stopped, not cleared)
+            return self._operator_solve_newton_big(st.newton, st.evals, st.pivots)
         ok_all, newton = bool(st.ok), st.newton
         self.newton_hist.append((newton, st.evals, st.pivots))
         self._pre_kept = bool(st.pre_kept)

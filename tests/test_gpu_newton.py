@@ -647,3 +647,166 @@ def test_wavefront_reductions_keep_the_butterfly_bits(gpu_lib, tmp_path):
                     "-I", os.path.join(root, "revs_admm_amd", "csrc"), src, "-o", exe], check=True, capture_output=True)
     out = subprocess.run([exe], capture_output=True, text=True).stdout
     assert "mismatches 0 of 65536; max / min / scan disagreements 0;" in out, out
+
+
+# ---- the model problem beyond REVS_DUAL_AMAX rows per slot (csrc/newton_big.hip) -----------------------------------------
+A2 = 512         # REVS_DUAL_AMAX_BIG
+
+
+@pytest.mark.parametrize("a", [5, 129, 200, 400, 512])
+def test_model_problem_sizes_big(gpu_lib, a):
+    """revs_op_dual_model_big at 129 / 200 / 400 / 512 candidate rows (and at 5: the path must not need many): the Gram matrix
+    equals numpy's, the returned point satisfies the LCP of the model (u >= 0, K'u - c >= 0, complementary) and reaches the
+    optimal value of the sign-constrained quadratic, which a non-negative least-squares solve on the Cholesky factor gives
+    independently.  K = R N R^T / kappa with R a x a; an exactly repeated row makes K singular; slot 1 has clamped nodes,
+    slot 2 mirrored signs."""
+    import torch
+    from scipy.optimize import nnls
+    from revs_admm_amd._lib import check, ptr
+    rng = np.random.default_rng(a)
+    M, T, kappa, delta, nks = a, 3, 5.0, 1e-10, 3
+    R = rng.normal(size=(M, M)) * (rng.uniform(size=(M, M)) < 0.5) + np.eye(M) * 0.1
+    if a > 4:
+        R[3] = R[1]
+    nfree = np.ones((M, T))
+    nfree[rng.integers(0, M, M // 5), 1] = 0.0
+    cidx = np.tile(np.arange(A2, dtype=np.int64), (T, 1)); cidx[:, a:] = 0
+    ccnt = np.full(T, a, np.int32)
+    cval = np.zeros((T, 3, A2))
+    sgn = np.where(rng.uniform(size=a) < 0.7, 1.0, -1.0)
+    for t in range(T):
+        s = sgn if t != 2 else -sgn
+        cval[t, 0, :a] = s
+        cval[t, 1, :a] = rng.normal(size=a)
+        cval[t, 2, :a] = s * np.maximum(rng.normal(size=a), 0.0)
+    cval[:, 0, a:] = 1.0
+    up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to("cuda:0")
+    dR, dN, dci, dcc, dcv = up(R), up(nfree), up(cidx), up(ccnt), up(cval)
+    f64 = dict(dtype=torch.float64, device="cuda:0")
+    ksl, kf, lf = torch.zeros(T, nks, A2, A2, **f64), torch.zeros(T, A2, A2, **f64), torch.zeros(T, A2, A2, **f64)
+    yh, info = torch.zeros(T, A2, **f64), torch.zeros(T, dtype=torch.int32, device="cuda:0")
+    check(gpu_lib.revs_op_dual_model_big(M, T, ptr(dR), ptr(dN), ptr(dci), ptr(dcc), ptr(dcv), kappa, delta, 400, nks,
+                                         ptr(ksl), ptr(kf), ptr(lf), ptr(yh), ptr(info), None), "model_big")
+    torch.cuda.synchronize()
+    yh, inf, Kg = yh.cpu().numpy(), info.cpu().numpy(), kf.cpu().numpy()
+    assert (inf > 0).all(), inf
+    for t in range(T):
+        s, grad, ycur = cval[t, 0, :a], cval[t, 1, :a], cval[t, 2, :a]
+        K0 = (R * nfree[:, t][None, :]) @ R.T / kappa
+        np.testing.assert_allclose(Kg[t, :a, :a], K0, rtol=1e-11, atol=1e-13 * np.abs(K0).max())
+        Kp = K0 * s[:, None] * s[None, :] + (delta * np.trace(K0) / a) * np.eye(a)
+        c = s * grad + Kp @ np.maximum(s * ycur, 0.0)
+        u = s * yh[t, :a]
+        w = Kp @ u - c
+        tol = 1e-8 * (np.abs(Kp).sum(axis=1).max() * max(u.max(), 1e-300) + np.abs(c).max())
+        assert u.min() >= 0.0 and w.min() >= -tol and np.abs(w[u > 0]).max(initial=0.0) <= tol, (t, u.min(), w.min(), tol)
+        assert (yh[t, a:] == 0).all()
+        # an independent solve of min 1/2 u'K'u - c'u, u >= 0: with K' = L L^T it is the NNLS problem |L^T u - L^-1 c|
+        Lc = np.linalg.cholesky(Kp + 1e-13 * np.trace(Kp) / a * np.eye(a))
+        u_ref, _ = nnls(Lc.T, np.linalg.solve(Lc, c), maxiter=50 * a)
+        obj = lambda z: 0.5 * z @ Kp @ z - c @ z
+        assert obj(u) <= obj(u_ref) + 1e-6 * (abs(obj(u_ref)) + 1e-300), (t, obj(u), obj(u_ref))
+    # a model without curvature moves nothing; a slot flagged -1 (more multipliers than 512) moves nothing and says so
+    dcc2 = up(np.array([a, -1, a], np.int32))
+    y0 = torch.zeros(T, A2, **f64)
+    check(gpu_lib.revs_op_dual_model_big(M, T, ptr(dR), ptr(torch.zeros_like(dN)), ptr(dci), ptr(dcc2), ptr(dcv), kappa, delta,
+                                         400, nks, ptr(ksl), ptr(kf), ptr(lf), ptr(y0), ptr(info), None), "model_big")
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(y0.cpu().numpy()[[0, 2], :a], cval[[0, 2], 2, :a])
+    assert info.cpu().numpy().tolist() == [0, -998, 0]
+
+
+def test_select_and_step_big(gpu_lib):
+    """revs_op_dual_select_big: the rows with a multiplier in row order, then the kadd most violated rows without one
+    (larger violation first, ties to the lower row), signs and gradients from the row arrays -- 300 multipliers in one slot,
+    more than 512 in another (flagged -1), none in a third; revs_op_dual_step_big: y_trial = y + alpha (yhat - y) on the
+    listed rows only, gradient . step in lin_out."""
+    import torch
+    from revs_admm_amd._lib import check, ptr
+    rng = np.random.default_rng(5)
+    M, T, kadd, vlo, vhi = 2000, 4, 9, -0.05, 0.06
+    y = np.zeros((M, T))
+    y[rng.choice(M, 300, replace=False), 0] = rng.normal(0, 50, 300)
+    y[rng.choice(M, 600, replace=False), 1] = 1.0
+    y[rng.choice(M, 40, replace=False), 3] = -2.0
+    v = rng.uniform(vlo, vhi, (M, T))
+    viol = np.zeros((M, T))
+    for t in (0, 2, 3):
+        rows = rng.choice(np.flatnonzero(y[:, t] == 0), 25, replace=False)
+        hi = rng.uniform(size=25) < 0.6
+        amt = np.round(rng.uniform(1e-4, 1e-2, 25), 4)               # (repeated values: ties)
+        v[rows, t] = np.where(hi, vhi + amt, vlo - amt)
+        viol[rows, t] = amt
+    up = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to("cuda:0")
+    f64 = dict(dtype=torch.float64, device="cuda:0")
+    dy, dv, dvi = up(y), up(v), up(viol)
+    ci, cc, cv = torch.zeros(T, A2, dtype=torch.int64, device="cuda:0"), torch.zeros(T, dtype=torch.int32, device="cuda:0"), torch.zeros(T, 3, A2, **f64)
+    check(gpu_lib.revs_op_dual_select_big(M, T, ptr(dy), ptr(dv), ptr(dvi), vlo, vhi, kadd, ptr(ci), ptr(cc), ptr(cv), None), "select_big")
+    torch.cuda.synchronize()
+    ci_h, cc_h, cv_h = ci.cpu().numpy(), cc.cpu().numpy(), cv.cpu().numpy()
+    assert cc_h[1] == -1
+    for t in (0, 2, 3):
+        sup = np.flatnonzero(y[:, t] != 0)
+        cand = np.flatnonzero((y[:, t] == 0) & (viol[:, t] > 0))
+        order = cand[np.lexsort((cand, -viol[cand, t]))][:kadd]
+        want = np.concatenate([sup, order])
+        assert cc_h[t] == len(want) and (ci_h[t, :len(want)] == want).all(), t
+        yv, vv = y[want, t], v[want, t]
+        sg = np.where(yv != 0, np.sign(yv), np.where(vv > vhi, 1.0, -1.0))
+        np.testing.assert_array_equal(cv_h[t, 0, :len(want)], sg)
+        np.testing.assert_array_equal(cv_h[t, 1, :len(want)], vv - np.where(sg > 0, vhi, vlo))
+        np.testing.assert_array_equal(cv_h[t, 2, :len(want)], yv)
+        assert (cv_h[t, 0, len(want):] == 1).all() and (cv_h[t, 1:, len(want):] == 0).all()
+    # the step
+    yhat = up(rng.normal(0, 30, (T, A2)))
+    alpha = up(np.array([1.0, 0.0, 0.5, 0.0]))
+    ytr, lin = torch.full((M, T), 7.0, **f64), torch.zeros(T, 8, **f64)
+    cc_fix = cc.clone(); cc_fix[1] = 0
+    check(gpu_lib.revs_op_dual_step_big(T, ptr(ci), ptr(cc_fix), ptr(cv), ptr(yhat), ptr(alpha), ptr(dy), M, ptr(ytr), ptr(lin), None), "step_big")
+    torch.cuda.synchronize()
+    yt, yh_h, lin_h = ytr.cpu().numpy(), yhat.cpu().numpy(), lin.cpu().numpy()
+    for t, al in ((0, 1.0), (2, 0.5), (3, 0.0)):
+        n_ = cc_h[t]
+        want = y[:, t].copy()
+        rows = ci_h[t, :n_]
+        want[rows] = yh_h[t, :n_] if al == 1.0 else (y[rows, t] if al == 0.0 else y[rows, t] + al * (yh_h[t, :n_] - y[rows, t]))
+        np.testing.assert_array_equal(yt[:, t], want)
+        np.testing.assert_allclose(lin_h[t, 0], (cv_h[t, 1, :n_] * (want[rows] - y[rows, t])).sum(), rtol=1e-12, atol=1e-300)
+    np.testing.assert_array_equal(yt[:, 1], y[:, 1])
+
+
+@pytest.mark.parametrize("vset,mode", [(1.043, "relaxed_exact"), (1.046, "binary")])
+def test_more_than_128_binding_rows_stay_on_the_newton_path(gpu_lib, golden, feeder_R, vset, mode):
+    """The reference's feeder run closer to its upper voltage limit (vset 1.043 / 1.046 instead of 1.03: 150 - 300 rows
+    bind in a slot where 1.03 binds 50 - 69): lpsolver.py:183-194 hands Gurobi every row and gets an answer; here the
+    operator's solves go on from the 128-row models to lists of up to 512 rows (csrc/newton_big.hip) instead of
+    handing the iteration to the ADMM forms.  Three iterations against the oracle (its working-set dual solver, KKT-
+    certified): diff, schedules, and the operator's last answer; the big path ran and the ADMM forms did not."""
+    from conftest import golden_homes
+    from helpers import f32
+    from oracle import revs_oracle as ro
+    from revs_admm_amd.engine import AdmmEngine, pack_homes
+    z, fd = golden
+    oh, evi = golden_homes(z, "dis_a90_r4800", 4.8)
+    n, T = oh.LOAD.shape
+    cost = f32(z["tariff_shift6"])
+    oh = ro.Homes.uniform(f32(oh.LOAD), oh.ev, 4.8, 20.0, 0.2, 11, 23)
+    e = AdmmEngine(cost, pack_homes(oh.ev, 4.8, 20.0, 0.2, 11, 23), oh.LOAD, np.arange(n), feeder_R, kappa=5.0, vset=vset,
+                   vlow=0.95, vhigh=1.05, mode=mode)
+    iters = 3
+    d = e.run(iters)
+    P, S, Cs = e.result()
+    assert set(e.op_path_hist) == {"dual"} and getattr(e, "big_solves", 0) >= 1
+    nsup = int((e.yd[0].cpu().numpy() != 0).sum(0).max())
+    omode = "relaxed" if mode == "relaxed_exact" else "binary"
+    d_ref, P_ref, S_ref, C_ref, tr = ro.solve_ADMM(oh, feeder_R, np.arange(n), cost, 5.0, iters, vset, 0.95, 1.05, mode=omode,
+                                                   util_method="dual", keep=True)
+    pe = e.P_est.cpu().numpy()[e.inv_perm]
+    print(f"vset {vset}, {mode}: rows with a multiplier in the fullest slot {nsup}, big solves {e.big_solves}, newton "
+          f"{[h[0] for h in e.newton_hist]}, evaluations {e.op_iters_hist}; |P_est - oracle| {np.abs(pe - tr.P_est[-1]).max():.2e} kW, "
+          f"|diff - oracle| {np.abs(d - d_ref).max():.2e}")
+    assert nsup > 128
+    assert np.abs(d[:2] - d_ref[:2]).max() < 1e-3 * max(1.0, d_ref.max())
+    if mode == "relaxed_exact":
+        assert np.abs(d - d_ref).max() < 1e-3 * max(1.0, d_ref.max())
+        assert np.abs(pe - tr.P_est[-1]).max() < 1e-4 and np.abs(S - S_ref).max() < 1e-4
