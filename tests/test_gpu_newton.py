@@ -172,8 +172,9 @@ def test_dual_evaluate_and_model_match_numpy(gpu_lib, n, M, T, n_mult):
 
 
 def test_more_multipliers_than_the_model_holds(gpu_lib):
-    """A slot with more than REVS_DUAL_AMAX multipliers is flagged (cand_cnt = -1), the others
-    are served; the engine then hands the iteration to the ADMM forms."""
+    """A slot with more than REVS_DUAL_AMAX multipliers is flagged (cand_cnt = -1) by the 128-row selection, the others
+    are served; the engine's Newton loops then go on with lists of up to 512 rows (revs_op_dual_*_big:
+    test_more_than_128_binding_rows_stay_on_the_newton_path)."""
     import torch
     from fake_kernels import FakeKernels
     from revs_admm_amd._lib import ptr
