@@ -821,8 +821,8 @@ def main():
                 "on_path": "since round 3 only for feeders given as a matrix, and in the Newton evaluations of "
                            "feeders beyond the tree form's 2048 nodes: the steady state, the Newton evaluations and "
                            "the binding chain judge their rows by the tree form of R p",
-                "mfma_counters": "profiles/r03_pmc_mfma.csv (unchanged kernel; 131 072 v_mfma_f64_16x16x4 per launch, matrix pipes "
-                                 "busy 8 192 of ~32 000 cycles per SIMD: 25 %; x 24/32 useful tile columns)",
+                "mfma_counters": "profiles/r05_pmc_mfma.csv (rocprofv3 --pmc of tools/matvec_run.py: 131 072 v_mfma_f64_16x16x4 per launch, "
+                                 "SQ_VALU_MFMA_BUSY_CYCLES 8 388 608 = 8 192 per SIMD of the launch's ~32 000 cycles: 25 %; x 24/32 useful tile columns)",
             },
             # the same timed region counted on the residences that have a QP to solve
             "value_ev_only": float((w.homes["ev"] != 0).sum()) * args.steps / dt,
