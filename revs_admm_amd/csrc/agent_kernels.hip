@@ -577,8 +577,8 @@ void agent_step_kernel(const AgentArgs a) {
         status = infeasible ? 1 : 0;
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
-            const bool take = win[j] && !infeasible &&
-                              (rank[j] < h.nmin || (rank[j] < h.nmax && neg[j]));
+            const bool take = win[j] & !infeasible &
+                              ((rank[j] < h.nmin) | ((rank[j] < h.nmax) & neg[j]));
             p[j] = take ? h.rating : 0.f;
         }
     } else if constexpr (MODE == REVS_MODE_RELAXED_PDHG) {
@@ -594,7 +594,7 @@ void agent_step_kernel(const AgentArgs a) {
             x[j] = a.y_state ? clip3((pso[j] - L[j]) * inv_rate, 0.f, w[j]) : 0.f;
         }
         const bool infeasible = pd_infeasible;
-        bool done = !ev || infeasible;
+        bool done = !ev | infeasible;
         bool unpolished = false;
         int iters = 0;
         const int check = max(a.pd.check, 1);
@@ -616,17 +616,20 @@ void agent_step_kernel(const AgentArgs a) {
                     }
                     sxm = group_sum<LPA>(sxm);
                     const float S = delta * sxm;
-                    const bool up = mu > 0.f || (mu == 0.f && S > hi);
-                    const bool dn = mu < 0.f || (mu == 0.f && S < lo_last);
+                    // (bitwise, not short-circuit: `a || (b && c)` on per-lane values compiles to nested exec-mask branches --
+                    // four of them per round here, ~25 scalar instructions; as mask arithmetic it is three compares and two ops)
+                    const bool mz = mu == 0.f;
+                    const bool up = (mu > 0.f) | (mz & (S > hi));
+                    const bool dn = (mu < 0.f) | (mz & (S < lo_last));
                     const float tgt = up ? hi : (dn ? lo_last : S);
                     const float resid = fabsf(S - tgt), tscale = fmaxf(1.f, fabsf(tgt));
-                    fine = fine || resid <= 5e-7f * tscale;
+                    fine = fine | (resid <= 5e-7f * tscale);
                     if (r == 6) {
                         // (round 5) S is a float sum over the window: at 48 free slots its own rounding reaches ~1e-6, and a
                         // residence whose row sits 10 ulps off its bound can neither pass the test above nor move (the
                         // step is below mu's resolution).  Its iterate here is Newton's, two orders closer than the
                         // PDHG iterate it would otherwise fall back to: accepted.
-                        fine = fine || resid <= 4e-6f * tscale;
+                        fine = fine | (resid <= 4e-6f * tscale);
                         break;
                     }
                     if (__all(fine)) break;
@@ -671,10 +674,10 @@ void agent_step_kernel(const AgentArgs a) {
             float mu_pre = sig1 * yy;
             bool pre = false;
             if (a.pd.polish & 2) {
-                pre = !ev || infeasible;
+                pre = !ev | infeasible;
                 kkt_newton(mu_pre, pre);
                 kkt_take(mu_pre, pre);
-                done = done || pre;
+                done = done | pre;
             }
             // The sweep is VALU-issue bound and half of its instructions are this loop, so the
             // iteration is arranged for the fewest operations:
@@ -709,7 +712,7 @@ void agent_step_kernel(const AgentArgs a) {
                 float res = iterate1(std::true_type{});
                 iters += done ? 0 : check;
                 res = group_max_nonneg<LPA>(res);
-                done = done || (res <= pd_tol);
+                done = done | (res <= pd_tol);
             }
             // KKT polish on the piece PDHG has identified.  For the terminal row's multiplier mu
             // (= sigma yy) the minimiser is x(mu) = clip(-b - delta mu, 0, w) and delta sum x(mu) is
@@ -720,7 +723,7 @@ void agent_step_kernel(const AgentArgs a) {
             // gone for the price of ~2 passes, and PDHG itself may stop much earlier (pd.tol).
             if ((a.pd.polish & 1) && !__all(pre)) {
                 float mu = pre ? mu_pre : sig1 * yy;
-                bool fine = pre || !ev || infeasible;       // the row's KKT conditions hold at x(mu) to float rounding
+                bool fine = pre | !ev | infeasible;       // the row's KKT conditions hold at x(mu) to float rounding
                 // (a Newton step is exact while the free slots stay free: one or two steps from where
                 // PDHG stopped; the loop ends as soon as every residence of the wavefront is there)
                 kkt_newton(mu, fine);
@@ -780,17 +783,17 @@ void agent_step_kernel(const AgentArgs a) {
             float res = iterate(std::true_type{});
             iters += done ? 0 : check;
             res = group_max<LPA>(res);
-            done = done || (res <= pd_tol);
+            done = done | (res <= pd_tol);
         }
 #pragma unroll
         for (int j = 0; j < SPL; ++j) yrow[j] = ev ? yrow[j] : 0.f;
         }
 #pragma unroll
-        for (int j = 0; j < SPL; ++j) p[j] = (ev && !infeasible) ? x[j] * h.rating : 0.f;
+        for (int j = 0; j < SPL; ++j) p[j] = (ev & !infeasible) ? x[j] * h.rating : 0.f;
         // bit 1: the iteration cap was reached before the tolerance (the schedule is then only
         // as good as max_iter passes make it: surfaced, not silently accepted)
         // bit 2: the KKT polish did not settle (the schedule is PDHG's iterate at its step tolerance)
-        status = (iters << 8) | (unpolished ? 4 : 0) | ((ev && !infeasible && !done) ? 2 : 0) | (infeasible ? 1 : 0);
+        status = (iters << 8) | (unpolished ? 4 : 0) | ((ev & !infeasible & !done) ? 2 : 0) | (infeasible ? 1 : 0);
     } else {
         // closed form: p_t = clip(u_t + nu, 0, ub_t), u = -q/kappa; nu is the
         // multiplier of the terminal SOC rows (the only ones that can bind when
@@ -861,7 +864,7 @@ void agent_step_kernel(const AgentArgs a) {
 #pragma unroll
         for (int j = 0; j < SPL; ++j) {
             const float g0 = revs_g0f(pen[j], gn[j], gmn[j], inv_kf);
-            pe2[j] = (valid[j] && g0 > 0.f) ? g0 : 0.f;
+            pe2[j] = (valid[j] & (g0 > 0.f)) ? g0 : 0.f;
         }
     }
     if constexpr (CHAIN) {      // the evaluation of the same multipliers on the state just produced
@@ -901,6 +904,8 @@ void agent_step_kernel(const AgentArgs a) {
         // answer of zero adds +0.0 to an accumulator nobody reads / exactly nothing: straight-line LDS adds)
         const int loc = node - base;
         if (loc < kNodeLoc) {
+            // (round 5, tuning builds: without these adds the launch is 4-5 % shorter -- they are not what bounds it; summing
+            // the wavefront's residences across its lane groups first, one add per slot from 8 lanes instead of 64: +14 %)
 #pragma unroll
             for (int j = 0; j < SPL; ++j) unsafeAtomicAdd(&nacc[it][loc][t0 + j], (double)pe2[j]);
         } else {
