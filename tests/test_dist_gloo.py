@@ -144,3 +144,86 @@ def test_run_eps_stops_every_rank_at_the_same_iteration(tmp_path):
                     vhigh=w.vhigh, mode="relaxed_exact", device="cpu", _kernels=FakeKernels())
     d1 = e1.run(80, eps=eps, patience=3)
     assert e1.converged_at == int(r[0]["at"]) and d1.shape[0] == r[0]["d"].shape[0]
+
+
+def test_local_ranks_allreduce_and_mismatch():
+    """revs_admm_amd.comm.LocalRanks (logical ranks as threads of one process: the transport of the eight-rank GPU test):
+    sum / max / min over 8 ranks, the same bits on every rank; a rank that reduces another size than its peers ends in an
+    error on every rank, not in a hang."""
+    import threading
+    from revs_admm_amd.comm import LocalRanks
+    W = LocalRanks(8, timeout=20.0)
+    res, errs = [None] * 8, [None] * 8
+
+    def work(r):
+        g = W.rank(r)
+        a = np.arange(5, dtype=np.float64) * (r + 1) + 0.1 * r
+        b, c = a.copy(), a.copy()
+        g.allreduce_host(a, 0); g.allreduce_host(b, 2); g.allreduce_host(c, 3)
+        res[r] = (a, b, c)
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(8)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    base = [np.arange(5, dtype=np.float64) * (r + 1) + 0.1 * r for r in range(8)]
+    want = base[0].copy()
+    for x in base[1:]:
+        want = want + x
+    for r in range(8):
+        np.testing.assert_array_equal(res[r][0], want)
+        np.testing.assert_array_equal(res[r][1], np.max(base, axis=0))
+        np.testing.assert_array_equal(res[r][2], np.min(base, axis=0))
+    assert W.calls[0] == [5, 5, 5] and all(c == W.calls[0] for c in W.calls)
+    W2 = LocalRanks(3, timeout=5.0)
+
+    def bad(r):
+        try:
+            W2.rank(r).allreduce_host(np.zeros(4 if r else 7), 0)
+        except Exception as ex:              # RuntimeError on the ranks that compared sizes, BrokenBarrierError on the others
+            errs[r] = ex
+    ts = [threading.Thread(target=bad, args=(r,)) for r in range(3)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert all(errs[r] is not None for r in range(3))
+
+
+@pytest.mark.parametrize("mode,stress,iters", [("relaxed_exact", 1.02, 12), ("binary", 1.3, 4)])
+def test_four_local_ranks_equal_one_rank(mode, stress, iters):
+    """The engine over comm.LocalRanks (four logical ranks, a thread each, the numpy test double of the C ABI): same
+    trajectory as one rank, every rank takes the same decisions (the sharded driver logic without gloo or processes --
+    what tests/test_gpu_sharded.py::test_eight_logical_ranks_equal_one_rank runs on the GPU with the real kernels)."""
+    import threading
+    sys.path.insert(0, HERE)
+    from fake_kernels import FakeKernels
+    from helpers import f32
+    from revs_admm_amd.comm import LocalRanks
+    from revs_admm_amd.engine import AdmmEngine
+    from revs_admm_amd.synthetic import make_workload
+    w = make_workload(240, 12, n_nodes=24, seed=6, stress=stress, binary_feasible=(mode == "binary"))
+    w.load, w.cost = f32(w.load), f32(w.cost)
+    world = 4
+    W = LocalRanks(world, timeout=60.0)
+    out, errs = [None] * world, [None] * world
+
+    def work(r):
+        try:
+            lo, hi = w.shard(r, world)
+            e = AdmmEngine(w.cost, w.homes[lo:hi], w.load[lo:hi], w.node_of[lo:hi], w.Rn, kappa=w.kappa, vset=w.vset,
+                           vlow=w.vlow, vhigh=w.vhigh, mode=mode, device="cpu", group=W.rank(r), _kernels=FakeKernels())
+            assert (e.node_counts == np.bincount(w.node_of, minlength=w.M)).all()
+            d = e.run(iters)
+            out[r] = (d, e.result()[1], list(e.op_iters_hist), list(e.spec_hist), list(e.chain_hist))
+        except Exception:
+            import traceback
+            errs[r] = traceback.format_exc()
+            W.abort()
+    ts = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in ts]; [t.join() for t in ts]
+    assert not any(errs), [x for x in errs if x]
+    e1 = AdmmEngine(w.cost, w.homes, w.load, w.node_of, w.Rn, kappa=w.kappa, vset=w.vset, vlow=w.vlow, vhigh=w.vhigh,
+                    mode=mode, device="cpu", _kernels=FakeKernels())
+    d1 = e1.run(iters)
+    S1 = e1.result()[1]
+    d4 = np.concatenate([o[0] for o in out], axis=1)
+    S4 = np.concatenate([o[1] for o in out], axis=0)
+    assert np.abs(d4 - d1).max() < 1e-5 and np.abs(S4 - S1).max() < 1e-4
+    for o in out[1:]:
+        assert o[2:] == out[0][2:]
+    assert out[0][2] == list(e1.op_iters_hist) and out[0][3] == list(e1.spec_hist)
