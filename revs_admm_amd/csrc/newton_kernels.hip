@@ -468,6 +468,13 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
     auto Ls = [&](int i, int j) -> double & { return Ls_dyn[i * (kAmax + 1) + j]; };
     const double *const Kp = a <= 64 ? (const double *)(Ls_dyn + 64 * (kAmax + 1)) : (const double *)Kt;
     const int ks = a <= 64 ? kKl : kAmax;
+    // (the factorisations read K through two pointers in their own address spaces, on two code paths: through the one
+    // above -- LDS or global by `a`, a generic pointer -- every entry was a flat load the compiler waited for on its own)
+    const bool klds = a <= 64;
+    typedef const __attribute__((address_space(3))) double *lds_cdp;
+    typedef const __attribute__((address_space(1))) double *glb_cdp;
+    const lds_cdp Kl = (lds_cdp)(Ls_dyn + 64 * (kAmax + 1));
+    const glb_cdp Kg = (glb_cdp)Kt;
     __shared__ double s_s[kAmax], c_s[kAmax], u_s[kAmax], w_s[kAmax], wred[4], idk_s[kAmax], col_s[2][4][kAmax];
     __shared__ int bl[kAmax];
     __shared__ unsigned long long Bsh[kWords], Vsh[kWords];
@@ -527,6 +534,8 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
         if (mp == 0) c_s[mi] = mi < a ? s_s[mi] * cg[mi] + ku : 0.0;
     }
     if (tid < kAmax) {
+        // (started from every candidate basic instead -- the newly admitted rows are all violated at u_cur -- the
+        // feeder's 15 iterations took 12.6 ms instead of 10.1: more rounds, not fewer; r05)
         const unsigned long long B0 = __ballot(tid < a && u_s[tid] > 0.0);
         if (lane == 0) Bsh[wave] = B0;
     }
@@ -569,14 +578,41 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
         auto factor = [&](auto nt_tag) {
             constexpr int NT = decltype(nt_tag)::value;
             const int ti = tid >> 4, tj = tid & 15;
+            // This thread's block of K'_BB: the candidates' numbers and signs of its rows and columns, then EVERY entry
+            // requested (clamped addresses, no condition around a load) before the first is used, masked afterwards.
+            // (As `cond ? kp(bl[i], bl[j]) : 0` each entry was a branch around two dependent LDS reads and a flat load
+            // with its own s_waitcnt: 16 or 64 memory round trips one after the other at the top of every factorisation.)
             double am[NT][NT];
+            {
+                int bi[NT], bj[NT];
 #pragma unroll
-            for (int x = 0; x < NT; ++x)
-#pragma unroll
-                for (int y = 0; y < NT; ++y) {
-                    const int i = ti + 16 * x, j = tj + 16 * y;
-                    am[x][y] = (i < nb && j <= i) ? kp(bl[i], bl[j]) : 0.0;
+                for (int x = 0; x < NT; ++x) {
+                    const int i = ti + 16 * x, j = tj + 16 * x;
+                    bi[x] = bl[i < nb ? i : 0];
+                    bj[x] = bl[j < nb ? j : 0];
                 }
+                if (klds) {
+#pragma unroll
+                    for (int x = 0; x < NT; ++x)
+#pragma unroll
+                        for (int y = 0; y < NT; ++y) am[x][y] = y <= x ? Kl[bi[x] * kKl + bj[y]] : 0.0;
+                } else {
+#pragma unroll
+                    for (int x = 0; x < NT; ++x)
+#pragma unroll
+                        for (int y = 0; y < NT; ++y) am[x][y] = y <= x ? Kg[bi[x] * kAmax + bj[y]] : 0.0;
+                }
+                double si[NT], sj[NT];
+#pragma unroll
+                for (int x = 0; x < NT; ++x) { si[x] = s_s[bi[x]]; sj[x] = s_s[bj[x]]; }
+#pragma unroll
+                for (int x = 0; x < NT; ++x)
+#pragma unroll
+                    for (int y = 0; y < NT; ++y) {
+                        const int i = ti + 16 * x, j = tj + 16 * y;
+                        am[x][y] = (i < nb && j <= i) ? si[x] * sj[y] * am[x][y] + (bi[x] == bj[y] ? dl : 0.0) : 0.0;
+                    }
+            }
             const double floor_ = dl * 1e-6;
 #pragma unroll
             for (int yb = 0; yb < NT; ++yb) {
@@ -694,6 +730,9 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
                 const int hi = __builtin_amdgcn_readlane((int)(bb >> 32), k);
                 return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
             };
+            // (Four pivots per step -- their components and the block's six entries of L read across with twenty
+            // independent readlanes, the 4 x 4 triangle solved by every lane for itself -- measured slower: 8.4 us
+            // against 6.5 for both solves at 59 rows; r05.)
             // L y = c_B (unit diagonal): column k of L, rows lane and lane + 64
             auto colf = [&](int k, double (&a0)[4], double (&a1)[4]) {
 #pragma unroll

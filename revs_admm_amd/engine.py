@@ -312,7 +312,7 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
         self.vfull = nz()
         self.violw = nz()
         self.d_part = torch.zeros(int(self.lib.revs_op_dual_blocks(M)), T, 4, **f64)
-        self.nks = int(min(16, max(1, M // 128)))       # column slabs of the model Hessian
+        self.nks = int(min(16, max(1, M // 128)))       # column slabs of the model Hessian (121144, M = 1126: 8; 4 / 16 / 32 measured slower, r05)
         self.k_slabs = torch.zeros(T, self.nks, A, A, **f64)
         self.k_full = torch.zeros(T, A, A, **f64)
         self.tile_cnt = torch.zeros((M + 31) // 32, dtype=torch.int32, device=self.dev)

@@ -1,0 +1,8 @@
+#!/bin/bash
+# triangular solves of the pivoting kernel four pivots at a time: stamps, the Newton tests, the feeder
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05o; mkdir -p $O; cd $R
+step() { "$@"; rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "timed out: $*"; exit $rc; fi; return $rc; }
+REVS_LIB=$R/revs_admm_amd/tune_bpp.so step timeout -k 10 300 python tools/bpp_stamps.py > $O/stamps.txt 2>&1; tail -4 $O/stamps.txt | cut -c1-300
+step timeout -k 10 900 python -m pytest tests/test_gpu_newton.py tests/test_gpu_operator.py -m gpu -q -x > $O/tests.log 2>&1; echo "tests rc $?"; tail -3 $O/tests.log
+step timeout -k 10 300 python tests/tools/feeder_iters.py > $O/feeder.txt 2>&1; tail -1 $O/feeder.txt | cut -c1-400
+step timeout -k 10 300 python tests/tools/feeder_config3.py > $O/feeder3.txt 2>&1; tail -2 $O/feeder3.txt | cut -c1-300
