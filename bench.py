@@ -671,10 +671,10 @@ def main():
     # run WITH it is timed beside.
     tte = None
     if world == 1 and not args.no_extras and not args.no_converge:
-        def fresh_runs(mode, iter_max, eps, reps, history=False):
+        def fresh_runs(mode, iter_max, eps, reps, history=False, polish=None):
             ms, its, conv = [], [], []
             for _ in range(reps):
-                w3, e3, _ = build(args.homes, args.T, mode, args.stress, args.voltage)
+                w3, e3, _ = build(args.homes, args.T, mode, args.stress, args.voltage, polish=polish)
                 clock_warm(e3)               # (building the workload left the GPU idle for ~0.5 s: the run is timed at steady clocks, like the steps)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
@@ -689,6 +689,9 @@ def main():
             return {"ms": ms[i], "iterations": its[i], "converged_at": conv[i], "all_ms": ms, "home_solver": mode}
         tte = {"pdhg_eps": fresh_runs("pdhg", 1000, args.eps, 5) if args.mode == "pdhg" else None,
                "pdhg_eps_with_diff_history": fresh_runs("pdhg", 1000, args.eps, 3, history=True) if args.mode == "pdhg" else None,
+               # (revs_pdhg_t::polish = 3, as value_kkt_presolve: the KKT steps settle a residence before PDHG is entered)
+               "pdhg_eps_kkt_presolve": (fresh_runs("pdhg", 1000, args.eps, 3, polish=3)
+                                         if args.mode == "pdhg" and args.pdhg_polish is None else None),
                "reference_rule_binary_15_iterations": fresh_runs("binary", 15, None, 5),
                "reference_rule_binary_15_iterations_with_diff_history": fresh_runs("binary", 15, None, 3, history=True)}
 
@@ -953,6 +956,10 @@ def main():
                         "median of 5 engines; stops after max_h diff <= eps has held for 8 iterations "
                         "(+ at most the rest of a 64-iteration burst) and one more iteration that writes the schedules",
                 "with_per_residence_diff_history_ms": (tte["pdhg_eps_with_diff_history"] or {}).get("ms"),
+                "kkt_presolve": ({"ms": tte["pdhg_eps_kkt_presolve"]["ms"], "iterations": tte["pdhg_eps_kkt_presolve"]["iterations"],
+                                  "runs_ms": tte["pdhg_eps_kkt_presolve"]["all_ms"],
+                                  "note": "the same run with revs_pdhg_t::polish = 3 (value_kkt_presolve's option; not the default)"}
+                                 if tte.get("pdhg_eps_kkt_presolve") else None),
                 "cpu_time_to_eps_s_projected": (a["iterations"] * cpu_it_s) if (a and cpu_it_s) else None,
                 "cpu_projection": "iterations x the cpu_baseline's time for one iteration's work (steady-state work; the "
                                   "transient's operator QPs would come on top)",

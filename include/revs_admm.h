@@ -222,6 +222,12 @@ int revs_agent_step_select(int64_t n_homes, int32_t T,
 int revs_residual_finalize(const float *diff, const float *dsq, int64_t n_homes, int32_t T,
                            float kappa, float eps, double *scratch, float *out, void *stream);
 
+/* OR of bits 0-2 of every residence's status word (1: no solution -- lpsolver.py:153-155's message --, 2: PDHG stopped at its
+ * cap, 4: the KKT polish did not settle) into *out, a word of PINNED host memory by its device-side address
+ * (revs_host_device_ptr) that the caller has cleared: one small launch and a stream synchronise instead of a read-back of
+ * the status array.  *out is complete when the stream has passed the launch. */
+int revs_status_or(int64_t n_homes, const int32_t *status, uint32_t *out, void *stream);
+
 /* Individual mode, lpsolver.py:430-460 (solve_residence): min 0.01 tariff.g +
  * 0.99 (1 - s_T), binary charger, SOC box, no s_T >= 0.9 row.
  *   p_out float[n][T], soc_out float[n][T+1], g_out float[n][T]                 */
@@ -456,6 +462,11 @@ int revs_plan_set_fold_redo(revs_plan_t *plan, int32_t steps);
  * one: lpsolver.py:183-194 hands Gurobi every row at once; here two at a time would be as many Newton iterations as half
  * the rows that end up binding). */
 int revs_plan_set_kadd_cold(revs_plan_t *plan, int32_t kadd_cold, int32_t cold_at);
+/* Allocates now what the run loops (revs_plan_stream_run_blocks, revs_plan_chain_fold_run) otherwise allocate the first
+ * time they are entered -- the ring of node-sum slices and the event pool for the block size, overlap and communicator
+ * set so far, the folded chain's buffers -- so that a fresh plan's first run makes no allocation between its launches.
+ * Optional; call after revs_plan_set_tree / set_comm / set_stream_block. */
+int revs_plan_prepare(revs_plan_t *plan);
 
 /* ---- the operator's Newton solve as ONE native call -----------------------------------------
  * Utility(...).solve() (reference lpsolver.py:163-238, called at lpsolver.py:256-259) through its dual:

@@ -232,6 +232,8 @@ SIGNATURES = {
     "revs_plan_set_stream_inner": (C.c_int, [_p, C.c_int32]),
     "revs_plan_set_fold_redo": (C.c_int, [_p, C.c_int32]),
     "revs_plan_set_kadd_cold": (C.c_int, [_p, C.c_int32, C.c_int32]),
+    "revs_plan_prepare": (C.c_int, [_p]),
+    "revs_status_or": (C.c_int, [C.c_int64, _p, _p, _p]),
     "revs_plan_set_newton": (C.c_int, [_p, C.POINTER(NewtonOpts)]),
     "revs_plan_newton_solve": (C.c_int, [_p, C.POINTER(NewtonState), _p]),
     "revs_plan_set_pdhg_dual": (C.c_int, [_p, _p]),

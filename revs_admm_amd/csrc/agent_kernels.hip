@@ -1743,6 +1743,25 @@ extern "C" int revs_residual_finalize(const float *diff, const float *dsq, int64
     return REVS_OK;
 }
 
+// OR of the low three bits of every residence's status word into *out (a word the host can read: pinned memory).
+__global__ __launch_bounds__(256) void status_or_kernel(int64_t n, const int32_t *__restrict__ status,
+                                                        unsigned int *__restrict__ out) {
+    unsigned int v = 0u;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) v |= (unsigned int)status[i] & 7u;
+    const unsigned long long any = __ballot(v != 0u);
+    if (any == 0ull) return;                                   // (the usual case: nothing to report)
+    if (v) __hip_atomic_fetch_or(out, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+extern "C" int revs_status_or(int64_t n_homes, const int32_t *status, uint32_t *out, void *stream) {
+    REVS_REQUIRE(n_homes > 0 && status && out, "revs_status_or: bad argument");
+    const int64_t nb = (n_homes + 255) / 256;
+    hipLaunchKernelGGL(status_or_kernel, dim3((unsigned)(nb < 1024 ? nb : 1024)), dim3(256), 0, (hipStream_t)stream, n_homes,
+                       status, out);
+    REVS_CHECK_LAUNCH("revs_status_or");
+    return REVS_OK;
+}
+
 extern "C" int revs_residence_solve(int64_t n_homes, int32_t T, const float *tariff,
                                     const revs_home_t *homes, const float *load, float *p_out,
                                     float *soc_out, float *g_out, void *stream) {

@@ -1375,6 +1375,46 @@ extern "C" int revs_plan_set_stream_block(revs_plan_t *plan, int32_t block, int3
     return REVS_OK;
 }
 
+// Everything the run loops would otherwise allocate the first time they need it: the ring of node-sum slices and the
+// event pool of the block form (for the block size, stream count and communicator the plan has NOW -- a later
+// change is picked up by the loops as before), the folded chain's buffers.  A fresh engine's first run then makes no
+// allocation, no synchronising memset and no event between its launches (round 5: ~0.5 ms of a 2.2 ms transient).
+extern "C" int revs_plan_prepare(revs_plan_t *plan) {
+    REVS_REQUIRE(plan, "revs_plan_prepare: null plan");
+    const revs_plan_desc_t &d = plan->d;
+    if (d.cand_idx1 && d.stats1_host && plan->tree.n > 0) {
+        const int rc = fold_alloc(plan);
+        if (rc != REVS_OK) return rc;
+    }
+    if (plan->block > 1 && d.n_homes > 0) {
+        const int nranks = plan->comm ? plan->comm->nranks : 1;
+        const size_t stride = (size_t)d.m * d.T + (size_t)REVS_DMAX_SLOTS * nranks;
+        const size_t need = (size_t)2 * plan->block * stride;
+        hipError_t e = hipSuccess;
+        if (plan->ring_cap < need) {
+            if (plan->ring) { (void)hipDeviceSynchronize(); (void)hipFree(plan->ring); }
+            plan->ring = nullptr;
+            plan->ring_cap = 0;
+            e = hipMalloc((void **)&plan->ring, sizeof(double) * need);
+            if (e == hipSuccess) plan->ring_cap = need;
+        }
+        if (e == hipSuccess && plan->ring_dirty) {
+            e = hipMemset(plan->ring, 0, sizeof(double) * plan->ring_cap);
+            if (e == hipSuccess) plan->ring_dirty = false;
+        }
+        while (e == hipSuccess && plan->events.size() < 2 * 8 + 1) {      // (a burst of eight blocks: 256 iterations)
+            hipEvent_t ev;
+            e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+            if (e == hipSuccess) plan->events.push_back(ev);
+        }
+        if (e != hipSuccess) {
+            revs::set_error("revs_plan_prepare: %s", hipGetErrorString(e));
+            return REVS_ELAUNCH;
+        }
+    }
+    return REVS_OK;
+}
+
 extern "C" int revs_plan_set_kadd_cold(revs_plan_t *plan, int32_t kadd_cold, int32_t cold_at) {
     REVS_REQUIRE(plan && kadd_cold >= 0 && kadd_cold <= 64 && cold_at >= 0, "revs_plan_set_kadd_cold: kadd_cold=%d (0..64), cold_at=%d", kadd_cold, cold_at);
     plan->kadd_cold = kadd_cold;

@@ -152,6 +152,9 @@ class OperatorOptions:
     # ~3 us each, so a regime that fails often keeps its bursts short
     stream_burst: int = 8
     stream_burst_max: int = 512
+    # The buffers the run loops need beyond the constructor's (state pools of the streaming steady state, the folded
+    # chain's arrays, ring and events: revs_plan_prepare) are allocated at construction; False: on first use.
+    preallocate: bool = True
     # Residences sharded: the verdicts of this many consecutive iterations are taken together,
     # after ONE all-reduce of their node sums (revs_plan_set_stream_block) -- a collective per
     # sweep would make the collective's latency the step.  1: every iteration, as on one GPU.
@@ -354,8 +357,18 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
         self.alpha_h = torch.zeros(T, dtype=torch.float64, pin_memory=cuda)
         self.info_h = torch.zeros(T, dtype=torch.int32, pin_memory=cuda)
         self.alpha_dev, self.info_dev = self.alpha_h.data_ptr(), self.info_h.data_ptr()
+        # ... and the word check_status() has the residences' status bits OR-ed into (revs_status_or)
+        self._flag_h = torch.zeros(2, dtype=torch.int32, pin_memory=cuda)
+        self._flag_np = self._flag_h.numpy()
+        self._flag_dev = None
+        # ... and the residual records (revs_residual_finalize's float[4]) of iterations outside the streaming loop,
+        # which run(eps=) collects until its stopping rule is next evaluated
+        self._dmx_h = torch.zeros(64, 4, dtype=torch.float32, pin_memory=cuda)
+        self._dmx_np = self._dmx_h.numpy()
+        self._dmx_dev = None
         if cuda:
-            for name, t in (("alpha_dev", self.alpha_h), ("info_dev", self.info_h)):
+            for name, t in (("alpha_dev", self.alpha_h), ("info_dev", self.info_h), ("_flag_dev", self._flag_h),
+                            ("_dmx_dev", self._dmx_h)):
                 dp = C.c_void_p()
                 check(self.lib.revs_host_device_ptr(t.data_ptr(), C.byref(dp)),
                       "revs_host_device_ptr")
@@ -542,6 +555,16 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
         self.R32 = up(Rn.astype(np.float32))
         self.node_load = torch.zeros(M, T, **f32)
         self.volt = torch.zeros(M, T, **f32)
+        # What the run loops would allocate on first use, now (OperatorOptions.preallocate): the pools the state
+        # rotates through, the folded chain's third multiplier array, the plan's ring / events / chain buffers
+        # (revs_plan_prepare) -- a fresh engine's first run then makes no allocation between its launches
+        # (~0.5 ms of the 2.2 ms transient at 100 000 x 24, tools/transient_hostgaps.py).
+        if self._plan is not None and self._tree is not None and self.op.preallocate:
+            self._state_pools()
+            self._y_spare = torch.zeros_like(self.yd[0])
+            check(self.lib.revs_plan_prepare(self._plan), "revs_plan_prepare")
+            if cuda:
+                torch.cuda.synchronize(self.dev)
 
     # ------------------------------------------------------------------ util
     @property
@@ -921,16 +944,37 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
                 self.iteration += 1
                 done += 1
 
-    def check_status(self):
+    def check_status(self, launch_only=False, deferred=False):
         """Raise if a residence reported 'no solution' (lpsolver.py:153-155) or a PDHG residence
         stopped at its iteration cap, in any sweep since the last check -- a collective decision
         when residences are sharded (every rank raises, or none).  Call at a point where the
-        stream has been synchronised (run(), result() and residuals() do)."""
-        if self._plan is not None:
+        stream has been synchronised (run(), result() and residuals() do).
+        launch_only / deferred (one GPU, no group): the reduction of the status words is enqueued now and read by a
+        second call with deferred=True -- run() puts the next iteration between the two, so that the report that
+        follows the first iteration (as the reference's does) costs the host no wait for that iteration's sweep."""
+        if deferred and not (self.n and self._flag_dev is not None and self.group is None):
+            return
+        if launch_only and not (self.n and self._flag_dev is not None and self.group is None):
+            launch_only = False
+        if self._plan is not None and not deferred:
             f = int(self.lib.revs_plan_status_flags(self._plan, 1))
         else:
             f = 0
-        if self.n:      # bits 0-2 of the last sweep's per-residence status words, OR-ed (one read-back)
+        if self.n and self._flag_dev is not None:
+            # bits 0-2 of the last sweep's per-residence status words, OR-ed on the device into a pinned word: one
+            # small launch and a stream synchronise (as six torch reductions and a read-back this check was 0.3 ms
+            # of host time in front of the second iteration of every run -- tools/transient_hostgaps.py, r05)
+            if not deferred:
+                self._flag_np[0] = 0
+                check(self.lib.revs_status_or(self.n, ptr(self.status), self._flag_dev, self.stream), "revs_status_or")
+                if launch_only:          # (read by check_status(deferred=True) behind the next iteration's own wait)
+                    self._flag_np[1] = f
+                    return
+            else:
+                f |= int(self._flag_np[1])
+            torch.cuda.current_stream(self.dev).synchronize()
+            f |= int(self._flag_np[0]) & 7
+        elif self.n:    # (host stand-in of the kernels: one read-back)
             st = self.status
             f |= sum(int(v) for v in torch.stack([(st & b).max() for b in (1, 2, 4)]).cpu().tolist())
         if self.group is not None:
@@ -957,6 +1001,12 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
     def _resolve_max_diff(self, pending):
         """Fetch the device-side maxima collected for iterations outside the streaming loop (one transfer), over every
         rank's residences when they are sharded (see _max_diff_all_ranks), into self.max_diff; empties `pending`."""
+        if pending and isinstance(pending[0][1], int):        # records in pinned memory (one GPU): wait, read
+            torch.cuda.current_stream(self.dev).synchronize()
+            for it, slot in pending:
+                self.max_diff[it] = float(self._dmx_np[slot, 2])
+            pending.clear()
+            return
         mx = torch.stack([v for _, v in pending]).to(torch.float64)
         if self.group is not None:
             self._allreduce(mx, torch.distributed.ReduceOp.MAX)
@@ -1009,7 +1059,7 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
             inv = torch.from_numpy(np.ascontiguousarray(self.inv_perm, dtype=np.int64)).to(self.dev)
         self.converged_at = None
         k, it0, good, seen, stop = 0, self.iteration, 0, self.iteration, False
-        cap, pending = 64, []
+        cap, pending, status_pending = 64, [], False
         while k < iter_max:
             base, r = k, 0
             while r < rows and k < iter_max:
@@ -1026,16 +1076,32 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
                         hist[r].copy_(self.diff)
                     done = 1
                     if k == 0:
-                        self.check_status()          # (synchronises once)
+                        # the reference reports a residence without a solution right after the first iteration
+                        # (lpsolver.py:153-155): the reduction is enqueued here and read behind the next iteration
+                        # (sharded: the whole check now, which synchronises once)
+                        self.check_status(launch_only=True)
+                        status_pending = True
                     if eps is not None and self.iteration not in self.max_diff:
                         # (max_h diff of an iteration outside the streaming loop: reduced on the device now, fetched with
                         # the others' when the stopping rule is next evaluated -- no host wait per iteration)
-                        pending.append((self.iteration, self.diff.max() if self.n else torch.zeros((), dtype=torch.float32, device=self.dev)))
+                        if self._dmx_dev is not None and self.group is None and self.n:
+                            # (one GPU: the residual kernels write their record into a slot of pinned memory -- no
+                            # torch reduction per iteration, no stack-and-copy when the records are wanted)
+                            slot = len(pending)
+                            check(self.lib.revs_residual_finalize(ptr(self.diff), ptr(self.dsq), self.n, self.T, self.kappa,
+                                                                  eps, ptr(self.res_scratch), self._dmx_dev + 16 * slot,
+                                                                  self.stream), "revs_residual_finalize")
+                            pending.append((self.iteration, slot))
+                        else:
+                            pending.append((self.iteration, self.diff.max() if self.n else torch.zeros((), dtype=torch.float32, device=self.dev)))
                 k += done
                 r += done
+                if status_pending and k >= 2:
+                    status_pending = False
+                    self.check_status(deferred=True)
                 if stop:
                     break
-                if eps is not None and pending and (done > 1 or len(pending) >= patience or k >= iter_max - 1):
+                if eps is not None and pending and (done > 1 or len(pending) >= min(patience, 64) or k >= iter_max - 1):
                     self._resolve_max_diff(pending)
                 if eps is not None:                  # the stretch of iterations at or below eps so far
                     while seen < it0 + k - len(pending) and not stop:
@@ -1049,6 +1115,8 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
                 diffs[base:k].copy_(hist[:r].index_select(1, inv))
             if stop and last:
                 break
+        if status_pending:
+            self.check_status(deferred=True)
         self.check_status()
         return diffs[:k].numpy() if history else k
 

@@ -21,6 +21,8 @@ if j.get("time_to_eps"):
     te = j["time_to_eps"]
     print("time_to_eps_ms", te["time_to_eps_ms"] and round(te["time_to_eps_ms"], 3), "iterations", te["iterations"], "runs", [round(x, 2) for x in te["runs_ms"] or []],
           "with history", te["with_per_residence_diff_history_ms"] and round(te["with_per_residence_diff_history_ms"], 2), "cpu projected s", te["cpu_time_to_eps_s_projected"])
+    if te.get("kkt_presolve"):
+        print("time_to_eps with the KKT steps before PDHG ms", round(te["kkt_presolve"]["ms"], 3), "iterations", te["kkt_presolve"]["iterations"], [round(x, 2) for x in te["kkt_presolve"]["runs_ms"]])
     rr = te["reference_rule"]
     print("reference rule (15 iterations, binary) ms", round(rr["ms"], 3), [round(x, 2) for x in rr["runs_ms"]], "with history", round(rr["with_per_residence_diff_history_ms"], 2))
 for k in ("roofline_matvec", "roofline_matvec_config3", "roofline_1M_T96"):
