@@ -997,3 +997,57 @@ def test_native_newton_solve_equals_python_loop(gpu_lib, golden, feeder_R, case)
     for x, y in zip(a[1], b[1]):
         np.testing.assert_array_equal(x, y)
     np.testing.assert_array_equal(a[2], b[2])
+
+
+@pytest.mark.gpu
+def test_status_or_and_the_report_after_the_first_iteration(gpu_lib):
+    """revs_status_or: the OR of bits 0-2 of the status words in a word of pinned memory (what check_status reads
+    instead of fetching the array).  AdmmEngine.run reports a residence without a solution after the first iteration
+    as the reference does (lpsolver.py:153-155) -- the reduction is enqueued behind that iteration's sweep and read
+    behind the next one, whichever path that one takes."""
+    import ctypes as C
+    import torch
+    from revs_admm_amd import _lib
+    from revs_admm_amd._lib import check, ptr
+    from revs_admm_amd.synthetic import make_workload
+    dev = torch.device("cuda:0")
+    flag = torch.zeros(2, dtype=torch.int32, pin_memory=True)
+    dp = C.c_void_p()
+    check(gpu_lib.revs_host_device_ptr(flag.data_ptr(), C.byref(dp)), "revs_host_device_ptr")
+    for n, bits in ((1, 0), (1000, 0), (100_001, 4), (100_001, 1 | 2), (5, 2), (300_000, (3 << 8) | 4)):
+        st = torch.full((n,), 7 << 8, dtype=torch.int32, device=dev)       # (PDHG pass counts in the high bits: ignored)
+        if bits:
+            st[n // 2] |= bits & 7
+            st[n - 1] |= bits
+        flag.zero_()
+        check(gpu_lib.revs_status_or(n, ptr(st), dp.value, torch.cuda.current_stream(dev).cuda_stream), "revs_status_or")
+        torch.cuda.synchronize()
+        assert int(flag[0]) == (bits & 7) and int(flag[1]) == 0
+    w = make_workload(3000, 24, n_nodes=100, seed=5, binary_feasible=False, stress=0.9)
+    e = _engine(w, "pdhg")
+    assert e.run(6, history=False) == 6                                 # (a feasible run: nothing raised)
+    w.homes["end"][7:9] = w.homes["start"][7:9] + 1                     # one slot cannot deliver the energy
+    w.homes["ev"][7:9] = 1
+    for it in (1, 2, 12):
+        e = _engine(w, "pdhg")
+        with pytest.raises(_lib.RevsError, match="No solution found"):
+            e.run(it, history=False)
+        # ... after the second iteration at the latest (iter_max = 1: at the end of the run)
+        assert e.iteration <= 2
+
+
+@pytest.mark.gpu
+def test_preallocation_changes_nothing(gpu_lib):
+    """OperatorOptions(preallocate=False) -- pools, ring, events and the chained iteration's buffers on first use, as
+    before round 5 -- walks the same trajectory bit for bit, through transient, chained iterations and streaming."""
+    from revs_admm_amd.engine import OperatorOptions
+    from revs_admm_amd.synthetic import make_workload
+    w = make_workload(6000, 24, n_nodes=256, seed=2, binary_feasible=False, stress=1.2)
+    runs = []
+    for pre in (True, False):
+        e = _engine(w, "pdhg", op=OperatorOptions(preallocate=pre))
+        e.run_steps(45)
+        runs.append((e.get_state(), list(e.op_iters_hist), e.spec_hist[0] + e.chain_hist[0]))
+    for a, b in zip(runs[0][0], runs[1][0]):
+        assert np.array_equal(a, b)
+    assert runs[0][1] == runs[1][1] and runs[0][2] == runs[1][2] and runs[0][2] > 0
