@@ -788,6 +788,10 @@ def main():
                             "block_sweeps_ms": timed_steps.collective[1],
                             "iterations_in_that_block": timed_steps.collective[2],
                             "bytes": int(timed_steps.collective[2]) * (eng.M * args.T + 64 * world) * 8,
+                            "bytes_per_iteration": (eng.M * args.T + 64 * world) * 8,
+                            # (a T-double screen of the ranks' row maxima in front of it was evaluated on 8 logical shards
+                            # of this workload and dropped: profiles/r05_screen_bound.txt)
+                            "screened": False,
                             "hidden": bool(eng.op.stream_overlap and timed_steps.collective[0] < timed_steps.collective[1])}),
             "roofline": {
                 "kernel": ("agent_step_kernel<MULTI> (%d ADMM iterations of every residence per launch: home QP "
