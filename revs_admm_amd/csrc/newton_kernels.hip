@@ -326,27 +326,37 @@ __global__ __launch_bounds__(256) void op_dual_gram_kernel(
     const int a = ccnt[t];
     if (a <= 0 || bi * 64 >= a || bj * 64 >= a) return;
     constexpr int KC = 32;
-    __shared__ double Ws[64][KC + 1], Rs_[64][KC + 1];
-    __shared__ int64_t rows_i[64], rows_j[64];
-    if (tid < 64) {
-        rows_i[tid] = bi * 64 + tid < a ? cidx[(int64_t)t * kAmax + bi * 64 + tid] : -1;
-        rows_j[tid] = bj * 64 + tid < a ? cidx[(int64_t)t * kAmax + bj * 64 + tid] : -1;
-    }
-    __syncthreads();
+    // (row stride 36 doubles: the matrix cores' operand reads below -- lane = row % 16 + 16 (column % 4) -- then fall on
+    // 4 row + column, every bank pair once per half wavefront)
+    constexpr int KS = KC + 4;
+    __shared__ double Ws[64][KS], Rs_[64][KS];
     const int ai = min(64, (a - bi * 64 + 3) & ~3), aj = min(64, (a - bj * 64 + 3) & ~3);
-    const int ti = tid >> 4, tj = tid & 15;
-    const bool mine = ti * 4 < ai && tj * 4 < aj;
-    double acc[4][4] = {};
+    // The products on the matrix cores (round 5): wavefront w forms rows 16 w .. 16 w + 15 of the tile against its 64
+    // columns, four v_mfma_f64_16x16x4 per four columns of the chunk -- five LDS reads per lane for 4096 multiply-adds.
+    // (As 4 x 4 register blocks on the vector pipe every multiply-add pair took an LDS read: the launch was bound by
+    // LDS bandwidth, ~24 us on the 121144 feeder whatever the loads did.)
+    typedef double d4 __attribute__((ext_vector_type(4)));
+    const int lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fk = lane >> 4;              // operand row (A) / column (B) inside a 16-tile, k inside a step
+    const bool mine = wave * 16 < ai;
+    d4 acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = d4{0.0, 0.0, 0.0, 0.0};
     const int chunk = (m + nks - 1) / nks;
     const int k0 = ks * chunk, k1 = min(m, k0 + chunk);
     // stage: 256 threads = 8 rows x 32 columns per pass.  All sixteen entries of a chunk are requested before the first is
     // used (clamped addresses, masked afterwards: with the loads inside the tests the loop was sixteen dependent round trips
     // per chunk -- 29 us per launch on the 121144 feeder), and the next chunk's before this chunk's products are formed.
+    // (the rows' numbers straight from the lists into the registers of the threads that fetch them -- they went through LDS
+    // and a barrier before the first fetch could be issued; the diagonal tile, the only one up to 64 candidates, fetches
+    // its rows once, not once for either side of the product: r05)
+    const bool diag = bi == bj;
     int64_t rwi[8], rwj[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        rwi[q] = rows_i[(tid >> 5) + 8 * q];
-        rwj[q] = rows_j[(tid >> 5) + 8 * q];
+        const int li = bi * 64 + (tid >> 5) + 8 * q, lj = bj * 64 + (tid >> 5) + 8 * q;
+        rwi[q] = li < a ? cidx[(int64_t)t * kAmax + li] : -1;
+        rwj[q] = diag ? rwi[q] : (lj < a ? cidx[(int64_t)t * kAmax + lj] : -1);
     }
     double rvi[8], rvj[8], nv = 0.0;
     auto fetch = [&](int kk) {
@@ -354,9 +364,13 @@ __global__ __launch_bounds__(256) void op_dual_gram_kernel(
         const int cc = c < k1 ? c : k1 - 1;
         nv = Nn[(int64_t)cc * T + t];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            rvi[q] = R[(rwi[q] >= 0 ? rwi[q] : 0) * m + cc];
-            rvj[q] = R[(rwj[q] >= 0 ? rwj[q] : 0) * m + cc];
+        for (int q = 0; q < 8; ++q) rvi[q] = R[(rwi[q] >= 0 ? rwi[q] : 0) * m + cc];
+        if (diag) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rvj[q] = rvi[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rvj[q] = R[(rwj[q] >= 0 ? rwj[q] : 0) * m + cc];
         }
     };
     if (k0 < k1) fetch(k0);
@@ -371,27 +385,29 @@ __global__ __launch_bounds__(256) void op_dual_gram_kernel(
         }
         __syncthreads();
         if (kk + KC < k1) fetch(kk + KC);                   // (uniform; in flight behind the products below)
-        if (mine) {
-#pragma unroll 8
-            for (int cc = 0; cc < KC; ++cc) {
-                double wv[4], rv[4];
+        if (mine) {                                         // (uniform per wavefront)
 #pragma unroll
-                for (int x = 0; x < 4; ++x) { wv[x] = Ws[ti * 4 + x][cc]; rv[x] = Rs_[tj * 4 + x][cc]; }
+            for (int st = 0; st < KC / 4; ++st) {
+                const double av = Ws[wave * 16 + fr][4 * st + fk];
+                double bv[4];
 #pragma unroll
-                for (int x = 0; x < 4; ++x)
+                for (int n = 0; n < 4; ++n) bv[n] = Rs_[16 * n + fr][4 * st + fk];
 #pragma unroll
-                    for (int z = 0; z < 4; ++z) acc[x][z] += wv[x] * rv[z];
+                for (int n = 0; n < 4; ++n) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[n], acc[n], 0, 0, 0);
             }
         }
         __syncthreads();
     }
     if (mine) {
+        // C / D map of v_mfma_f64_16x16x4_f64 (gemm_kernels.hip): column = lane & 15, row = (lane >> 4) + 4 reg
         double *o = Kslab + ((int64_t)t * nks + ks) * kAmax * kAmax;
 #pragma unroll
-        for (int x = 0; x < 4; ++x)
+        for (int n = 0; n < 4; ++n)
 #pragma unroll
-            for (int z = 0; z < 4; ++z)
-                o[(bi * 64 + ti * 4 + x) * kAmax + bj * 64 + tj * 4 + z] = acc[x][z];
+            for (int reg = 0; reg < 4; ++reg) {
+                const int li = wave * 16 + fk + 4 * reg, lj = 16 * n + fr;
+                if (li < ai && lj < aj) o[(bi * 64 + li) * kAmax + bj * 64 + lj] = acc[n][reg];
+            }
     }
 }
 
