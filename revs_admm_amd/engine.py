@@ -155,6 +155,8 @@ class OperatorOptions:
     # The buffers the run loops need beyond the constructor's (state pools of the streaming steady state, the folded
     # chain's arrays, ring and events: revs_plan_prepare) are allocated at construction; False: on first use.
     preallocate: bool = True
+    # column slabs the model Hessian's Gram launch splits the nodes into (0: M // 128, at most 16)
+    newton_nks: int = 0
     # Residences sharded: the verdicts of this many consecutive iterations are taken together,
     # after ONE all-reduce of their node sums (revs_plan_set_stream_block) -- a collective per
     # sweep would make the collective's latency the step.  1: every iteration, as on one GPU.
@@ -315,7 +317,7 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
         self.vfull = nz()
         self.violw = nz()
         self.d_part = torch.zeros(int(self.lib.revs_op_dual_blocks(M)), T, 4, **f64)
-        self.nks = int(min(16, max(1, M // 128)))       # column slabs of the model Hessian (121144, M = 1126: 8; 4 / 16 / 32 measured slower, r05)
+        self.nks = int(self.op.newton_nks) if self.op.newton_nks else int(min(16, max(1, M // 128)))       # column slabs of the model Hessian (121144, M = 1126: 8; 4 / 16 / 32 measured slower, r05)
         self.k_slabs = torch.zeros(T, self.nks, A, A, **f64)
         self.k_full = torch.zeros(T, A, A, **f64)
         self.tile_cnt = torch.zeros((M + 31) // 32, dtype=torch.int32, device=self.dev)

@@ -53,6 +53,10 @@ if "--kadd" in sys.argv:
 if "--kadd-cold" in sys.argv:      # rows admitted per Newton iteration while a slot shows many violated rows (round 5)
     for _c, _at in ((4, 2), (6, 3), (8, 4), (8, 8), (12, 6), (16, 6), (16, 12), (32, 8)):
         run(f"dual Newton, kadd 2, cold {_c} above {_at} violated", OperatorOptions(newton_kadd_cold=_c, newton_kadd_cold_at=_at))
+if "--nks" in sys.argv:            # column slabs of the Gram launch (round 5, after the products moved to the matrix cores)
+    for _n in (4, 6, 8, 12, 16, 24):
+        run(f"dual Newton, {_n} column slabs", OperatorOptions(newton_nks=_n))
+        run(f"dual Newton, {_n} column slabs", OperatorOptions(newton_nks=_n))
 if "--admm" in sys.argv:
     for rv in (1.0, 25.0):
         run(f"ADMM forms, rho_v {rv}", OperatorOptions(solver="admm", rho_v_scale=rv))
