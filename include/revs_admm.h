@@ -52,6 +52,11 @@ extern "C" {
 #define REVS_CHAIN_FOLD_MAX_M 2048
 /* candidate rows per slot in the dual Newton model of the operator QP (the plan's candidate buffers: T x this) */
 #define REVS_DUAL_AMAX 128
+/* While no slot's list (multipliers + the rows an evaluation may admit) is longer than this, an evaluation forms the
+ * shifts R^T y / kappa straight from the listed rows of R; beyond it by the dense f64 product. */
+#ifndef REVS_DUAL_FEW
+#define REVS_DUAL_FEW 48
+#endif
 typedef struct {
     int32_t n;
     const uint64_t *pack;

@@ -138,7 +138,7 @@ static int chain_accept_impl(int32_t T, const double *s0, const double *s1, doub
     }
     if (!(rmax0 > eps)) return 0;                        // already converged: the general path
     if (ncand_max > 8) return 0;                         // not the small model
-    if ((ns_max + kadd <= 48) != (chain_few != 0)) return 0;
+    if ((ns_max + kadd <= REVS_DUAL_FEW) != (chain_few != 0)) return 0;
     double rmax1 = 0.0, sum = 0.0, mx = 0.0;
     for (int t = 0; t < T; ++t) {
         const double *a = s0 + 8 * t, *b = s1 + 8 * t;
@@ -675,7 +675,7 @@ extern "C" int revs_plan_newton_solve(revs_plan_t *plan, revs_newton_state_t *st
         else if (++stall >= 10) break;
         ++newton;
         last_small = nc_max <= 8;
-        few = ns_max + kadd_stt <= 48;
+        few = ns_max + kadd_stt <= REVS_DUAL_FEW;
         // (the chain guessed how its trial's home pass gets d = R^T y / kappa -- row-wise or dense; another choice here
         // would differ in the last bits: then the trial is made again)
         const bool use_pre = st->have_pre && newton == 1 && last_small && few == (st->chain_few_in != 0);
@@ -772,7 +772,7 @@ extern "C" int revs_plan_chain_run(revs_plan_t *plan, int32_t max_steps, revs_ch
         if (!acc) return REVS_OK;              // the caller's general loop takes this iteration
         std::swap(st->y, st->y_trial);
         st->use_y = nsum > 0;
-        st->sup0 = (nsum > 0 && nmax + plan->d.kadd <= 48) ? 1 : -1;
+        st->sup0 = (nsum > 0 && nmax + plan->d.kadd <= REVS_DUAL_FEW) ? 1 : -1;
         std::swap(st->p_sch, st->p_sch_alt);
         std::swap(st->gamma, st->gamma_alt);
         std::swap(st->p_est, st->p_est_new);

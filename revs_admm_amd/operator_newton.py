@@ -164,7 +164,7 @@ class DualNewtonMixin:
             ncand = stt[:, 2] + np.minimum(stt[:, 3], np.minimum(kadd_stt, A - stt[:, 2]))
             self.model_calls[0 if ncand.max() <= 8 else 1] += 1
             last_small = bool(ncand.max() <= 8)
-            few = stt[:, 2].max() + kadd_stt <= 48
+            few = stt[:, 2].max() + kadd_stt <= _lib.DUAL_FEW
             # rows to admit next (revs_plan_set_kadd_cold's rule): many, while a slot still shows many violated ones and either
             # the rows admitted last time nearly all kept a multiplier or some slot already carries 16 of them (rows that bind
             # one by one: the 121144 feeder); few, while a handful of multipliers clears hundreds of violated rows at once
@@ -249,7 +249,7 @@ class DualNewtonMixin:
             return False
         self._y_support = bool(stt[:, 2].sum() > 0)
         # the accepted evaluation's candidate set `cur` lists the rows with y != 0 first
-        self._sup = cur if (self._y_support and stt[:, 2].max() + o.newton_kadd <= 48) else None
+        self._sup = cur if (self._y_support and stt[:, 2].max() + o.newton_kadd <= _lib.DUAL_FEW) else None
         self.op_iters_hist.append(evals)
         self.op_path_hist.append("dual")
         self.op_converged = True
@@ -382,7 +382,7 @@ class DualNewtonMixin:
             self._sup = None
             return False
         self._y_support = st.nsup_sum > 0
-        self._sup = st.cur if (self._y_support and st.nsup_max + o.newton_kadd <= 48) else None
+        self._sup = st.cur if (self._y_support and st.nsup_max + o.newton_kadd <= _lib.DUAL_FEW) else None
         self.op_iters_hist.append(st.evals)
         self.op_path_hist.append("dual")
         self.op_converged = True
@@ -485,7 +485,7 @@ class DualNewtonMixin:
         self.newton_hist.append((1, 2, int(np.abs(self.info_h.numpy()).sum())))
         self._pre_kept, self._chain_ok, self._spec_ok = True, True, False
         self._y_support = nsum > 0
-        self._sup = 1 if (self._y_support and nmax + o.newton_kadd <= 48) else None
+        self._sup = 1 if (self._y_support and nmax + o.newton_kadd <= _lib.DUAL_FEW) else None
         self.op_iters_hist.append(2)
         self.op_path_hist.append("dual")
         self.op_converged = True
