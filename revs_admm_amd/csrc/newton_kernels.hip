@@ -285,7 +285,13 @@ __global__ __launch_bounds__(NT) void op_tree_rows_big_kernel(const TreeRowsArgs
 // stores and three column loads of m cache lines each off a latency-bound workgroup)
 template <bool SELECT>
 __global__ __launch_bounds__(256) void op_tree_rows_kernel(const TreeRowsArgs ta, const SelectArgs sa, const int staged) {
+#ifdef REVS_TUNING
+    REVS_KVS_BEGIN(SELECT ? REVS_ROWS_STAMP_PTR : nullptr);
+    __syncthreads();
+    REVS_KVS(blockIdx.x, 0);
+#else
     REVS_KVS_BEGIN(nullptr);
+#endif
     extern __shared__ double tree_lds[];
     if constexpr (SELECT) {
         if (staged) {
@@ -295,6 +301,7 @@ __global__ __launch_bounds__(256) void op_tree_rows_kernel(const TreeRowsArgs ta
             SelectArgs s2 = sa;
             s2.rows_lds = rows_lds;
             dual_select_body<true>(s2, blockIdx.x);
+            REVS_KVS(blockIdx.x, 11);
             return;
         }
     }
@@ -883,6 +890,11 @@ __global__ __launch_bounds__(256) void op_dual_bpp_kernel(
                     g_bpp_stamps[blockIdx.x][27] = (double)clock64(); }     // (shader clock ticks: [28] at the start)
 #endif
 }
+#if defined(REVS_KV_STAMPS) && defined(REVS_ROWS_STAMPS)
+extern "C" int revs_tuning_rows_stamps(double *out_host) {
+    return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_rows_stamps), sizeof(double) * 256 * 32) == hipSuccess ? 0 : -1;
+}
+#endif
 #ifdef REVS_BPP_STAMPS
 extern "C" int revs_tuning_bpp_stamps(double *out_host) {
     return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_bpp_stamps), sizeof(double) * 256 * 32) == hipSuccess ? 0 : -1;

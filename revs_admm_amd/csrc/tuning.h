@@ -21,6 +21,14 @@ static __shared__ double *kvs_lds;
 #define REVS_KVS(t, i) do { } while (0)
 #define REVS_KVV(t, i, val) do { } while (0)
 #endif
+//   -DREVS_KV_STAMPS -DREVS_ROWS_STAMPS   the evaluations' rows + selection launch (op_tree_rows_kernel<true>) writes the
+//                      same stamps into g_rows_stamps (tools/rows_stamps.py)
+#if defined(REVS_KV_STAMPS) && defined(REVS_ROWS_STAMPS) && defined(REVS_KVS_TU)
+namespace revs { __device__ double g_rows_stamps[256 * 32]; }
+#define REVS_ROWS_STAMP_PTR revs::g_rows_stamps
+#else
+#define REVS_ROWS_STAMP_PTR nullptr
+#endif
 #if defined(REVS_BPP_STAMPS) && defined(REVS_KVS_TU)
 namespace revs { __device__ double g_bpp_stamps[256][32]; }
 #define BPP_STAMP(i) do { if (threadIdx.x == 0 && (i) < 32) revs::g_bpp_stamps[blockIdx.x][i] = (double)wall_clock64(); } while (0)
