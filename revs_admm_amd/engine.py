@@ -12,6 +12,7 @@ built library raises.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 import dataclasses
 import math
@@ -180,6 +181,22 @@ def _dev_check(device):
     return torch.device(device)
 
 
+def _on_current_stream(fn):
+    """step / run_steps / run: torch's current stream, looked up once at the outermost entry."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(self, *a, **k):
+        if self._stream_pin is not None or self.dev.type != "cuda":
+            return fn(self, *a, **k)
+        self._stream_pin = torch.cuda.current_stream(self.dev).cuda_stream
+        try:
+            return fn(self, *a, **k)
+        finally:
+            self._stream_pin = None
+    return wrapped
+
+
 class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
     """State of one ADMM run on one GPU.
 
@@ -202,6 +219,11 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
                      evaluates R p in O(nodes) (OperatorOptions.voltage); the constructor checks
                      that the tree reproduces Rn.
     """
+
+    # the HIP stream of a run in progress: step / run_steps / run look torch's current stream up once at their entry
+    # (2.5 us a look-up, ~3 per iteration otherwise) and every launch inside goes there
+    _stream_pin = None
+
 
     def __init__(self, cost, homes, load, node_of, Rn, kappa=5.0, vset=1.0, vlow=0.95,
                  vhigh=1.05, mode="binary", device="cuda:0", pdhg=None,
@@ -569,8 +591,21 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
                 torch.cuda.synchronize(self.dev)
 
     # ------------------------------------------------------------------ util
+    @contextlib.contextmanager
+    def _capture(self, g):
+        """torch.cuda.graph(g) for the engine's own launches: inside it `stream` is torch's capture stream, not the
+        one a run in progress has pinned."""
+        pin, self._stream_pin = self._stream_pin, None
+        try:
+            with torch.cuda.graph(g):
+                yield
+        finally:
+            self._stream_pin = pin
+
     @property
     def stream(self):
+        if self._stream_pin is not None:
+            return self._stream_pin
         if self.dev.type != "cuda":
             return None
         return torch.cuda.current_stream(self.dev).cuda_stream
@@ -737,6 +772,7 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
                     bool(mx.item() <= eps))
         return r[0], r[1], r[2], bool(r[3] > 0.5)
 
+    @_on_current_stream
     def step(self, write_sc=True, events=None):
         """One iteration of the while-loop of lpsolver.py:254-287.  `events`: HIP events
         [1], [2] recorded between the operator part and the home sweep, and after the sweep
@@ -878,6 +914,7 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
             self.P_est_new, self.P_est_alt = self.P_est_alt, self.P_est_new
         self.iteration += 1
 
+    @_on_current_stream
     def run_steps(self, count):
         """`count` iterations of step(write_sc=False).  Consecutive steady-state iterations
         (one GPU, no multipliers, speculation on) run inside ONE native call,
@@ -1038,6 +1075,7 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
         except Exception:
             pass
 
+    @_on_current_stream
     def run(self, iter_max=15, eps=None, patience=8, history=True):
         """Full solve_ADMM loop; returns diff (iterations, n) in the caller's home order.
         The per-iteration diff of every residence (lpsolver.py:284) is collected on the device --

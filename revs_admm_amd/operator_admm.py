@@ -165,7 +165,7 @@ class AdmmFormsMixin:
         if self.group is None:
             if self._graph is None:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with self._capture(g):
                     body()
                 self._graph = g
             return self._graph.replay()
@@ -173,7 +173,7 @@ class AdmmFormsMixin:
             gs = []
             for chk in (False, True):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with self._capture(g):
                     self._node_half(check=chk, fuse=not chk)
                     if chk:
                         self._home_pass(with_update=True, check=True, reduce=False)
@@ -265,7 +265,7 @@ class AdmmFormsMixin:
             return body()
         if self._fgraph is None:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with self._capture(g):
                 body()
             self._fgraph = g
         self._fgraph.replay()
