@@ -1,6 +1,6 @@
 #!/bin/bash
 # status bits by one launch (revs_status_or): host gaps of the run to eps, status tests, the bench's time_to_eps
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05ai; mkdir -p $O; cd $R
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/hostgaps; mkdir -p $O; cd $R
 step() { "$@"; rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "timed out: $*"; exit $rc; fi; return $rc; }
 step timeout -k 10 300 python tools/transient_hostgaps.py 0 > $O/hostgaps_eps.txt 2>&1; head -4 $O/hostgaps_eps.txt; tail -1 $O/hostgaps_eps.txt
 step timeout -k 10 900 python -m pytest tests/test_gpu_admm.py tests/test_gpu_config4.py tests/test_abi.py -m gpu -q -x -k "not full_size" > $O/tests.log 2>&1; echo "tests rc $?"; tail -3 $O/tests.log
