@@ -554,8 +554,9 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
         self._sets = None               # buffer pools of the block form (allocated on first use)
         # max_h diff[h] (lpsolver.py:284) of the iterations whose sweeps folded it on the device:
         # {iteration number (1-based, as the reference's diff[k]): value}
-        self.max_diff = {}
+        self.max_diff = {}               # (property: also clears the bursts' records not yet folded in)
         self._dmax_buf = (C.c_double * 1024)()
+        self._dmax_addr = C.addressof(self._dmax_buf)
         self.stream_calls = []          # (launches enqueued, iterations kept) of every native burst
         # arguments of revs_plan_stream_run, built once (a burst of 20 sweeps is 0.4 ms: every
         # microsecond of Python around it is a microsecond of idle GPU)
@@ -591,6 +592,26 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
                 torch.cuda.synchronize(self.dev)
 
     # ------------------------------------------------------------------ util
+    # max_h diff[h] per iteration (1-based) -- a dict; the streaming bursts leave their records as (first iteration, values)
+    # and the dict is brought up to date when somebody looks (a burst of 20 iterations is 150 us: the 3 us of twenty dict
+    # entries per burst belong to whoever reads them)
+    _max_diff = None
+    _max_diff_bursts = ()
+
+    @property
+    def max_diff(self):
+        if self._max_diff_bursts:
+            md = self._max_diff
+            for it, vals in self._max_diff_bursts:
+                md.update(zip(range(it + 1, it + 1 + len(vals)), vals))
+            self._max_diff_bursts = []
+        return self._max_diff
+
+    @max_diff.setter
+    def max_diff(self, value):
+        self._max_diff = value
+        self._max_diff_bursts = []
+
     @contextlib.contextmanager
     def _capture(self, g):
         """torch.cuda.graph(g) for the engine's own launches: inside it `stream` is torch's capture stream, not the
@@ -1193,7 +1214,7 @@ class AdmmEngine(DualNewtonMixin, AdmmFormsMixin, SteadyStateMixin):
         self._spec_wait, self._spec_back = 0, 1
         self.op_cold = self._fast_cold = True
         self._burst = max(1, int(self.op.stream_burst))
-        self.max_diff = {}
+        self.max_diff = {}               # (property: also clears the bursts' records not yet folded in)
         for h in (self.op_iters_hist, self.op_path_hist, self.newton_hist, self.stream_calls):
             h.clear()
         self.spec_hist, self.chain_hist, self.model_calls, self.fold_steps = [0, 0], [0, 0], [0, 0], 0

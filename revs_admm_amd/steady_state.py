@@ -186,7 +186,7 @@ class SteadyStateMixin:
         kept, rm = self._stream_out
         check(self.lib.revs_plan_stream_run_blocks(self._plan, count, self._sets_ref, self._scale, o.eps,
                                                    self._stream_out_ref[0], self._stream_out_ref[1],
-                                                   C.addressof(self._dmax_buf), self.stream),
+                                                   self._dmax_addr, self.stream),
               "revs_plan_stream_run_blocks")
         n = kept.value
         self.stream_calls.append((count, n))
@@ -204,7 +204,8 @@ class SteadyStateMixin:
         if n == count:
             self._fused_p = p0_out
         it = self.iteration
-        self.max_diff.update(zip(range(it + 1, it + n + 1), self._dmax_buf[:n]))
+        if n:
+            self._max_diff_bursts.append((it, self._dmax_buf[:n]))      # (folded into max_diff when it is next read)
         if n:
             self.op_iters_hist.extend([1] * n)
             self.op_path_hist.extend(["dual"] * n)
