@@ -25,6 +25,7 @@ ap.add_argument("--oracle", action="store_true")
 ap.add_argument("--adopt", type=int, default=90)
 ap.add_argument("--T", type=int, default=96)
 ap.add_argument("--iters", type=int, default=15)
+ap.add_argument("--nks", type=int, default=0, help="column slabs of the Gram launch (0: the engine's choice)")
 args = ap.parse_args()
 
 z, fd = ro.load_golden(os.path.join(ROOT, "tests", "golden", "revs_121144.npz"))
@@ -50,7 +51,7 @@ print(f"{n} residences, {ev.sum()} EVs, T = {args.T}, window [{start}, {end})", 
 
 def run(mode):
     e = AdmmEngine(cost, pack_homes(ev, 4.8, 20.0, 0.2, start, end), LOAD, np.arange(n), Rr,
-                   kappa=5.0, vset=1.03, vlow=0.95, vhigh=1.05, mode=mode, op=OperatorOptions())
+                   kappa=5.0, vset=1.03, vlow=0.95, vhigh=1.05, mode=mode, op=OperatorOptions(newton_nks=args.nks))
     for r in range(2):
         for t in (e.P_est, e.P_sch, e.G):
             t.zero_()
