@@ -629,6 +629,68 @@ def test_rows_by_the_tree_form_equal_the_dense_rows(gpu_lib, M, T):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,T", [(300, 24), (1126, 96), (2048, 24), (4096, 24), (8192, 6), (12001, 5)])
+def test_shifts_by_the_tree_form_equal_the_dense_product(gpu_lib, M, T):
+    """The first half of a Newton evaluation with multipliers: d = R^T y by the tree form of a radial feeder's R
+    (revs_op_dual_evaluate_tree, phase 1: op_tree_shift_kernel in every shape of tree_body.h, round 5) against the dense
+    f64 product on the matrix cores (revs_op_dual_evaluate): the same node sums p | N | q and the same answer P_est_new
+    -- the shifts agree to 1e-12 of the largest; a residence whose g0 sits within that of its shift may land on the other
+    side of the kink (none does on these inputs)."""
+    import ctypes as C
+    import torch
+    from revs_admm_amd import _lib
+    from revs_admm_amd.engine import feeder_tree
+    from revs_admm_amd.synthetic import make_workload
+    rng = np.random.default_rng(M + T)
+    n = max(M * 3, 10)
+    w = make_workload(n, 24, n_nodes=M, seed=4)
+    par, er, cons = w.feeder
+    Rn = w.Rn
+    counts = np.bincount(w.node_of, minlength=M)
+    tr = feeder_tree(par, er, cons, counts > 0)
+    order = np.argsort(w.node_of, kind="stable")
+    node_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    pe, ps, gm = (rng.uniform(0.0, 3.0, (n, T)).astype(np.float32)[order] for _ in range(3))
+    y = np.zeros((M, T))
+    have = np.flatnonzero(counts > 0)
+    for t in range(T):
+        rows = rng.choice(have, min(60, len(have)), replace=False)        # (more than REVS_DUAL_FEW rows: the product's case)
+        y[rows, t] = rng.normal(0, 40.0, len(rows))
+    kappa, ks = 5.0, 4
+    dev = "cuda:0"
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d = {"pack": up(tr["pack"].view(np.int64)), "w": up(tr["w"])}
+    tree = _lib.Tree(tr["n"], d["pack"].data_ptr(), d["w"].data_ptr())
+    dR, dy, dptr = up(Rn), up(y), up(node_ptr)
+    dpe, dps, dgm = up(pe), up(ps), up(gm)
+    out = {}
+    for which in ("dense", "tree"):
+        z = lambda shape, dt=torch.float64: torch.zeros(shape, dtype=dt, device=dev)
+        b = dict(d_sl=z((ks, M, T)), pnq=z((3, M, T)), pen=z((n, T), torch.float32))
+        q = lambda t: t.data_ptr()
+        if which == "dense":
+            _lib.check(gpu_lib.revs_op_dual_evaluate(
+                1, M, T, q(dptr), q(dpe), q(dps), q(dgm), q(dR), None, q(dy), 1, kappa, -1.0, 1.0, 2, ks, q(b["d_sl"]),
+                None, q(b["pnq"]), q(b["pen"]), None, None, None, None, None, None, None, 0.0, None, None), "revs_op_dual_evaluate")
+        else:
+            _lib.check(gpu_lib.revs_op_dual_evaluate_tree(
+                1, M, T, q(dptr), q(dpe), q(dps), q(dgm), q(dR), C.byref(tree), q(dy), 1, kappa, -1.0, 1.0, 2, ks, q(b["d_sl"]),
+                q(b["pnq"]), q(b["pen"]), None, None, None, None, None, None, None, 0.0, None), "revs_op_dual_evaluate_tree")
+        torch.cuda.synchronize()
+        out[which] = {k: v.cpu().numpy() for k, v in b.items()}
+    ref = Rn.T @ y
+    dd, dt = out["dense"]["d_sl"].sum(0), out["tree"]["d_sl"][0]
+    occupied = counts > 0
+    np.testing.assert_allclose(dd[occupied], ref[occupied], rtol=0, atol=1e-12 * np.abs(ref).max())
+    np.testing.assert_allclose(dt[occupied], ref[occupied], rtol=0, atol=1e-12 * np.abs(ref).max())
+    assert np.abs(ref[occupied]).max() > 0
+    np.testing.assert_allclose(out["tree"]["pen"], out["dense"]["pen"], rtol=0, atol=5e-7)      # (float32 answers: one ulp)
+    np.testing.assert_allclose(out["tree"]["pnq"][0], out["dense"]["pnq"][0], rtol=0, atol=1e-8)
+    np.testing.assert_array_equal(out["tree"]["pnq"][1], out["dense"]["pnq"][1])
+    assert (out["dense"]["pen"] > 0).any() and (out["dense"]["pen"] == 0).any()
+
+
+@pytest.mark.gpu
 def test_wavefront_reductions_keep_the_butterfly_bits(gpu_lib, tmp_path):
     """wave_sum_d (common.h: v_permlane32_swap / v_permlane16_swap + DPP row rotations) must give the xor
     butterfly's sums bit for bit -- the general loop's stand-alone kernels and the folded chain share it, and
