@@ -283,7 +283,9 @@ __global__ __launch_bounds__(NT) void op_tree_rows_big_kernel(const TreeRowsArgs
 // three prefix sums with the multipliers in the place of the node sums), one workgroup per slot, into slab 0 of the
 // dense product's output (rows that carry no checked position -- nodes without a residence -- are not written: the
 // home pass reads d only where residences are).  Replaces the f64 matrix-core product of the evaluations on radial
-// feeders: 22.8 us per evaluation at M = 1 126, T = 96 (0.14 of the MFMA peak: launch- and latency-bound), 11.8 at T = 24.
+// feeders: 22.8 us per evaluation at M = 1 126, T = 96 (0.14 of the MFMA peak: launch- and latency-bound), 11.8 at T = 24;
+// this launch: 6.4 us.  (Folded into the step's launch in front of it -- the same T workgroups -- the feeder's 15 iterations
+// took 8.7-8.9 ms against 8.6: measured and dropped, r05.)
 template <int NT, int IPT>
 __global__ __launch_bounds__(NT) void op_tree_shift_kernel(const TreeArgs tr, const int T, const double *__restrict__ y,
                                                            double *__restrict__ d_out) {
